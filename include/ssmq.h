@@ -1,0 +1,220 @@
+/*
+ * ssmq.h - C ABI of the MI355X-native sigma-point / Bayesian-quadrature moment-transform library (libssmq.so).
+ *
+ * This is the drop-in boundary for ONE path of jacobnzw/SSMToybox: the moment transform that the filters in
+ * ssmtoybox/ssinf.py call twice per time step, plus the quadrature-weight construction that feeds it.  The reference
+ * is pure Python and has no FFI; the entry points below are what a ctypes binding for that path would bind, and each
+ * cites the reference interface (file:line under the reference tree) it replaces.  INTEGRATION.md shows the
+ * reference-side stub.
+ *
+ * Conventions
+ *   - plain C types only; all floating point is IEEE fp64 (`double`); integers are int32 unless stated.
+ *   - host arrays are C-contiguous in the reference's NumPy layout ("AoS": trajectory-major, e.g. cov[b][i][j]).
+ *   - device arrays handed to the *_dev entry points are in the library's HBM layout ("SoA planes"): element e of
+ *     trajectory b lives at ptr[e * ld + b]; ld >= B is the plane pitch in doubles.  Matrices are row-major in e
+ *     (e = i * ncol + j).  ssmq_aos_to_soa / ssmq_soa_to_aos convert on the device.
+ *   - return value: 0 ok; > 0 = 1 + index of the first batch item whose input covariance is not positive definite
+ *     (the reference raises numpy.linalg.LinAlgError there: bq/bqmtran.py:98, mtran.py:139); < 0 error
+ *     (SSMQ_E_*); ssmq_last_error() gives the text.  No exception crosses the ABI.
+ *   - a transform handle is bound to the device that was current when it was created; one HIP stream per process
+ *     (ssmq calls are not thread-safe on one handle; different handles are independent).
+ *   - there is NO CPU fallback anywhere behind this ABI: without a usable gfx950 device every compute entry point
+ *     returns SSMQ_E_HIP.
+ */
+#ifndef SSMQ_H
+#define SSMQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSMQ_VERSION 100
+
+#define SSMQ_OK 0
+#define SSMQ_E_ARG (-1)          /* bad argument (null pointer, size out of range, unknown id) */
+#define SSMQ_E_HIP (-2)          /* HIP runtime error / no device */
+#define SSMQ_E_UNSUPPORTED (-3)  /* combination not implemented */
+#define SSMQ_E_NOMEM (-4)
+
+#define SSMQ_MAX_FPAR 16 /* doubles of integrand constants */
+#define SSMQ_MAX_FIDX 8  /* state-index entries */
+#define SSMQ_MAX_DIM 16  /* D, E (input / output dimension of a transform) */
+#define SSMQ_MAX_PTS 1024 /* N (sigma points) */
+
+/* Integrands: closed-form dynamics / measurement functions of ssmtoybox/ssmod.py evaluated on the device so sigma
+ * points never leave the GPU (bq/bqmtran.py:132-156 evaluates a Python callable column by column). */
+enum ssmq_integrand_id {
+    SSMQ_F_UNGM_DYN = 1,          /* ssmod.py:268-269   par: -            in 1 out 1, uses time          */
+    SSMQ_F_UNGM_MEAS = 2,         /* ssmod.py:1060-1061 par: -            in 1 out 1                     */
+    SSMQ_F_UNGMNA_DYN = 3,        /* ssmod.py:299-300   input [x, q]      in 2 out 1, uses time          */
+    SSMQ_F_UNGMNA_MEAS = 4,       /* ssmod.py:1085-1086 input [x, r]      in 2 out 1                     */
+    SSMQ_F_PENDULUM_DYN = 5,      /* ssmod.py:357-358   par: dt           in 2 out 2                     */
+    SSMQ_F_PENDULUM_MEAS = 6,     /* ssmod.py:1114-1115                   in 1 out 1                     */
+    SSMQ_F_REENTRY1D_DYN = 7,     /* ssmod.py:424-427   par: dt           in 3 out 3                     */
+    SSMQ_F_RANGE_MEAS = 8,        /* ssmod.py:1147-1149                   in 1 out 1                     */
+    SSMQ_F_REENTRY2D_DYN = 9,     /* ssmod.py:530-564   par: dt           in 5 out 5                     */
+    SSMQ_F_RADAR2D_MEAS = 10,     /* ssmod.py:1227-1252 par: loc_x loc_y  in 2 out 2                     */
+    SSMQ_F_CT_DYN = 11,           /* ssmod.py:675-690   par: dt           in 5 out 5                     */
+    SSMQ_F_BEARING_MEAS = 12,     /* ssmod.py:1189-1195 par: S x (sx, sy) in 2 out S (S = n_par / 2 <= 8) */
+    SSMQ_F_CTRS_DYN = 13,         /* ssmod.py:755-774   par: dt, input [x(5), q(2)]  in 7 out 5          */
+    SSMQ_F_CV_DYN = 14,           /* ssmod.py:839-846   par: dt           in 4 out 4                     */
+    SSMQ_F_REENTRY2D_BIAS_DYN = 15 /* this build's synthetic 6-D case: reentry-2D + pass-through state, in 6 out 6 */
+};
+
+/* One integrand = id + constants + optional sub-state selection (MeasurementModel.state_index, ssmod.py:990-991):
+ * if n_idx > 0 the integrand sees x[idx[0]], x[idx[1]], ... of the D-dimensional sigma point. */
+typedef struct ssmq_integrand {
+    int32_t id;
+    int32_t n_par;
+    int32_t n_idx;
+    int32_t reserved;
+    double par[SSMQ_MAX_FPAR];
+    int32_t idx[SSMQ_MAX_FIDX];
+} ssmq_integrand;
+
+/* Form of the moment equations. */
+enum ssmq_form {
+    SSMQ_FORM_BQ = 0,    /* bq/bqmtran.py:158-223: mean = fx wm; cov = fx Wc fx' - mean mean' + emv; ccov = fx Wcc' L' */
+    SSMQ_FORM_SIGMA = 1  /* mtran.py:141-149: centred, diagonal Wc: cov = dfx diag(wc) dfx'; ccov = dfx diag(wc) (x-m)' */
+};
+
+/* How the expected model variance enters the covariance (bq/bqmtran.py:198 `model_var * I_out`). */
+enum ssmq_emv_mode {
+    SSMQ_EMV_DIAG = 0,      /* I_out = eye(E): only the diagonal of the (E, E) emv matrix is added            */
+    SSMQ_EMV_BROADCAST = 1  /* I_out = eye(1) with E > 1 (ssinf.py StudentProcessKalman builds its transforms so):
+                               the whole (E, E) matrix is added                                                 */
+};
+
+typedef struct ssmq_transform ssmq_transform; /* opaque; replaces the attribute carriers BQTransform / Model
+                                                 (bq/bqmtran.py:11-58, bq/bqmod.py:15-106) on the device side */
+
+/* ---- library / device ------------------------------------------------------------------------------------- */
+int ssmq_version(void);
+const char *ssmq_last_error(void);
+int ssmq_device_count(int *n);
+int ssmq_set_device(int device);
+int ssmq_device_name(char *buf, int len);
+
+/* ---- device memory, layout conversion, timing (plumbing) ---------------------------------------------------- */
+int ssmq_malloc(void **dptr, size_t bytes);
+int ssmq_free(void *dptr);
+int ssmq_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int ssmq_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int ssmq_memcpy_d2d(void *dst, const void *src, size_t bytes);
+int ssmq_memset(void *dptr, int value, size_t bytes);
+int ssmq_sync(void);
+/* AoS [B][n] (reference layout) <-> SoA planes [n][ld] (HBM layout), both on the device. */
+int ssmq_aos_to_soa(const double *d_aos, double *d_soa, int n, int64_t B, int64_t ld);
+int ssmq_soa_to_aos(const double *d_soa, double *d_aos, int n, int64_t B, int64_t ld);
+/* HIP events on the library's stream (bench.py times kernels with these). */
+int ssmq_event_create(void **ev);
+int ssmq_event_destroy(void *ev);
+int ssmq_event_record(void *ev);
+int ssmq_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+/* index of the first non-zero entry of a device status vector, or -1 */
+int ssmq_status_first(const int32_t *d_status, int64_t B, int64_t *first);
+
+/* ---- quadrature weights (theta-batched, computed on the device) --------------------------------------------- */
+/*
+ * GP quadrature weights for P kernel-parameter rows at once.
+ * Replaces GaussianProcessModel.bq_weights (bq/bqmod.py:495-523) together with RBFGauss.eval / exp_x_kx / exp_x_xkx /
+ * exp_x_kxkx / exp_x_kxx / exp_xy_kxy (bq/bqkern.py:329-424), utils.maha (utils.py:385-409) and
+ * Kernel.eval_inv_dot / _cho_inv (bq/bqkern.py:38-64, 96-120).
+ *   xi  [D*N]      unit sigma points, row-major (D, N)            (host)
+ *   par [P*(1+D)]  rows [alpha, ell_1..ell_D]                     (host)
+ * outputs (host; any may be NULL): wm [P*N], Wc [P*N*N], Wcc [P*D*N], iK [P*N*N] (scaling=False inverse),
+ *   q [P*N], Q [P*N*N], R [P*D*N], model_var [P], integral_var [P], status [P] (1 = K + jitter I not PD).
+ */
+int ssmq_weights_gp(int D, int N, const double *xi, const double *par, int P, double jitter,
+                    double *wm, double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R,
+                    double *model_var, double *integral_var, int32_t *status);
+/*
+ * Bayes-Sard quadrature weights.  Replaces BayesSardModel.bq_weights (bq/bqmod.py:893-992) with _exp_x_px / _exp_x_xpx
+ * / _exp_x_pxpx / _exp_x_kxpx (bq/bqmod.py:635-797) and utils.vandermonde (utils.py:478-502).
+ *   mulind [D*NB]  multi-indices, row-major (D, NB), NB <= N; NB == N selects the unisolvent branch (:952-961).
+ * outputs as ssmq_weights_gp (iK, q, Q, R as there; Q / R are only produced in the NB < N branch).
+ */
+int ssmq_weights_bs(int D, int N, const double *xi, const double *par, int P, double jitter,
+                    const int32_t *mulind, int NB,
+                    double *wm, double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R,
+                    double *model_var, double *integral_var, int32_t *status);
+
+/* ---- transform handle --------------------------------------------------------------------------------------- */
+/*
+ * Upload the constants of one moment transform (what BQTransform.__init__ / SigmaPointTransform.__init__ keep as
+ * tf.wm / tf.Wc / tf.Wcc / tf.model.points / tf.model.model_var / tf.model.iK / tf.model.nu: bq/bqmtran.py:55-58,
+ * 306-310, 387-392; mtran.py:165-168, 226-232).
+ *   xi [D*N]; wm [N]; Wc: [N*N] (BQ form) or the diagonal [N] (SIGMA form); Wcc [D*N] (BQ form; NULL for SIGMA);
+ *   emv [E*E] expected model variance as an (E, E) matrix (scalar model_var -> model_var * ones; NULL = 0);
+ *   tp_nu > 0 selects the Student-t process covariance (bq/bqmtran.py:394-415, bq/bqmod.py:1132-1160) and needs
+ *   tp_iK [N*N].
+ * Returns NULL on error.
+ */
+ssmq_transform *ssmq_transform_create(int D, int E, int N, int form, const double *xi, const double *wm,
+                                      const double *Wc, const double *Wcc, const double *emv, int emv_mode,
+                                      double tp_nu, const double *tp_iK);
+/* Replace the constants in place (research code overwrites tf.wm / tf.Wc / tf.Wcc / model_var:
+ * research/tpq/tpq_ungm.py:114-124, research/bsq/bsq_tracking.py:276-281).  Any pointer may be NULL = keep. */
+int ssmq_transform_update(ssmq_transform *h, const double *xi, const double *wm, const double *Wc, const double *Wcc,
+                          const double *emv, int emv_mode, double tp_nu, const double *tp_iK);
+void ssmq_transform_destroy(ssmq_transform *h);
+int ssmq_transform_dims(const ssmq_transform *h, int *D, int *E, int *N);
+
+/* ---- the moment transform, batched over independent trajectories --------------------------------------------- */
+/*
+ * B moment transforms in one launch.  Replaces BQTransform.apply (bq/bqmtran.py:60-109) / SigmaPointTransform.apply
+ * (mtran.py:105-149) for the built-in integrands: Cholesky of each cov, sigma points x = mean + L xi, integrand,
+ * weighted mean / covariance / cross-covariance.
+ * Host version, reference layout: mean [B*D], cov [B*D*D], time [B] or [1] (time_stride 1 or 0; the reference passes
+ * np.atleast_1d(k - 1): ssinf.py:276-277), outputs mean_f [B*E], cov_f [B*E*E], cov_fx [B*E*D], status [B] (may be NULL).
+ * B == 1 serves the drop-in apply().
+ */
+int ssmq_apply_batch(ssmq_transform *h, const ssmq_integrand *f, int64_t B, const double *mean, const double *cov,
+                     const double *time, int time_stride, double *mean_f, double *cov_f, double *cov_fx,
+                     int32_t *status);
+/* Device version, SoA planes with pitch ld; d_time [B] or [1]; d_status [B] int32 (required).  Asynchronous on the
+ * library stream.  Only the lower triangle of each input covariance is read (as LAPACK dpotrf 'L' does). */
+int ssmq_apply_batch_dev(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
+                         const double *d_cov, const double *d_time, int time_stride, double *d_mean_f,
+                         double *d_cov_f, double *d_cov_fx, int32_t *d_status);
+/* Which kernel ssmq_apply_batch_dev would run for this (transform, integrand): writes its name (for profiles). */
+int ssmq_apply_kernel_name(const ssmq_transform *h, const ssmq_integrand *f, char *buf, int len);
+
+/*
+ * Arbitrary Python integrand f: the sigma points are formed on the device, f is evaluated by the caller, and the
+ * weighted reductions run on the device (bq/bqmtran.py:97-101 and :104-107 around the `_fcn_eval` call at :102).
+ *   ssmq_sigma_points_batch: x [B*D*N] (each (D, N) row-major), chol [B*D*D] lower factors.
+ *   ssmq_apply_fx_batch:     fx [B*E*N]; `mean` / `x` are only read for the SIGMA form (centred cross-covariance).
+ */
+int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, const double *cov, double *x,
+                            double *chol, int32_t *status);
+int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const double *mean, const double *x,
+                        const double *fx, double *mean_f, double *cov_f, double *cov_fx);
+
+/* ---- callers of the path kept on the device (filter recursion) ------------------------------- */
+/*
+ * Gaussian measurement update for B trajectories (ssinf.py:297-323): gain = (P_y^-1 P_yx)' by Cholesky,
+ * m = m_pr + gain (y - y_mean), P = P_pr - gain P_y gain' (left unsymmetrised as the reference does, :323).
+ * SoA planes, pitch ld.  P_yx is (Y, D) as returned by the obs transform.  In-place (m_fi == m_pr etc.) is allowed.
+ */
+int ssmq_kalman_update_dev(int D, int Y, int64_t B, int64_t ld, const double *d_m_pr, const double *d_P_pr,
+                           const double *d_y_mean, const double *d_P_y, const double *d_P_yx, const double *d_y,
+                           double *d_m_fi, double *d_P_fi, int32_t *d_status);
+/*
+ * Forward pass of an additive-noise Gaussian filter for B trajectories and T steps (ssinf.py:66-118, 254-323):
+ * per step k = 1..T: dyn transform at time k-1, += GQG', obs transform at time k-1, += R, measurement update.
+ *   d_y [T][Y][ld]; d_m0 [D][ld], d_P0 [D*D][ld] (read only); GQG [D*D], R [Y*Y] host;
+ *   outputs d_fm [T][D][ld], d_fP [T][D*D][ld]; d_status [ld] (0 ok, else 1 + first failing step).
+ */
+int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                            const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
+                            const double *d_m0, const double *d_P0, const double *GQG, const double *R,
+                            double *d_fm, double *d_fP, int32_t *d_status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSMQ_H */

@@ -1,0 +1,103 @@
+"""
+Kernels of the integrand model: attribute carrier + device-computed expectations (reference: ssmtoybox/bq/bqkern.py).
+
+Only the RBF kernel with Gaussian expectations is on the accelerated path (`RBFGauss`, bq/bqkern.py:295-454).  The
+Monte-Carlo `RBFStudent` and the approximate `RQ` kernels of the reference are out of scope (SURVEY.md section 2, row
+3b): their weights are RNG-dependent and enter this build as injected data (assign tf.wm / tf.Wc / tf.Wcc).
+
+All numbers come from one device kernel (`ssmq_weights_gp`, ssmtoybox_amd/csrc/ssmq_weights.hip), which evaluates the
+kernel matrix, its Cholesky-based inverse and the expectations q, R, Q together; the methods below select from it.
+"""
+import numpy as np
+
+from .. import _lib
+
+
+def device_gp_weights(points, par, jitter=1e-8):
+    """All GP-quadrature quantities for P parameter rows.  points (D, N); par (P, 1 + D).
+    Returns dict of arrays with a leading P axis: wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var, status."""
+    lib = _lib.load()
+    x, px = _lib.as_c(points)
+    par = np.atleast_2d(np.asarray(par, dtype=np.float64))
+    par, pp = _lib.as_c(par)
+    D, N = x.shape
+    P = par.shape[0]
+    if par.shape[1] != D + 1:
+        raise ValueError('kernel parameters must have 1 + dim entries per row')
+    out = {k: _lib.out_c(s) for k, s in (('wm', (P, N)), ('Wc', (P, N, N)), ('Wcc', (P, D, N)), ('iK', (P, N, N)),
+                                         ('q', (P, N)), ('Q', (P, N, N)), ('R', (P, D, N)), ('model_var', (P,)),
+                                         ('integral_var', (P,)))}
+    st = np.zeros(P, dtype=np.int32)
+    rc = _lib.check(lib.ssmq_weights_gp(D, N, px, pp, P, float(jitter), out['wm'][1], out['Wc'][1], out['Wcc'][1],
+                                        out['iK'][1], out['q'][1], out['Q'][1], out['R'][1], out['model_var'][1],
+                                        out['integral_var'][1], st.ctypes.data_as(_lib.c_int32_p)), 'ssmq_weights_gp')
+    res = {k: v[0] for k, v in out.items()}
+    res['status'] = st
+    if rc > 0:
+        raise np.linalg.LinAlgError('kernel matrix not positive definite for parameter row {}'.format(rc - 1))
+    return res
+
+
+class Kernel:
+    """Base class (bq/bqkern.py:11-36): `par` is forced to a 2-D float array (dim_out, 1 + dim)."""
+
+    def __init__(self, dim, par, jitter):
+        self.par = np.atleast_2d(par).astype(float)
+        assert self.par.ndim == 2
+        self.scale = self.par[:, 0]
+        self.dim = dim
+        self.jitter = jitter
+        self.eye_d = np.eye(dim)
+
+    def get_parameters(self, par=None):
+        if par is None:
+            return self.par
+        par = np.atleast_2d(par).astype(float)
+        assert par.ndim == 2
+        return par
+
+
+class RBFGauss(Kernel):
+    """k(x, x') = s^2 exp(-(x - x')' Lam^-1 (x - x') / 2), parameters [s, ell_1, ..., ell_D] (bq/bqkern.py:295-454)."""
+
+    def __init__(self, dim, par, jitter=1e-8):
+        par = np.atleast_2d(par)
+        assert par.shape[1] == dim + 1
+        super().__init__(dim, par, jitter)
+
+    def _all(self, par, x):
+        return device_gp_weights(x, np.atleast_2d(par)[:1], self.jitter)
+
+    def eval_inv_dot(self, par, x, b=None, scaling=True):
+        """(K + jitter I)^-1 [b]  (bq/bqkern.py:96-120).  The device kernel forms the scaling=False inverse; with
+        scaling the inverse is divided by alpha^2 only approximately (jitter is not rescaled), so scaling=True is refused
+        rather than approximated."""
+        if scaling and float(np.atleast_2d(par)[0, 0]) != 1.0:
+            raise NotImplementedError('eval_inv_dot(scaling=True) with alpha != 1 is not on the device path')
+        iK = self._all(par, x)['iK'][0]
+        return iK if b is None else iK.dot(b)
+
+    def exp_x_kx(self, par, x, scaling=False):
+        """Kernel mean (bq/bqkern.py:345-356)."""
+        q = self._all(par, x)['q'][0]
+        return q * float(np.atleast_2d(par)[0, 0]) ** 2 if scaling else q
+
+    def exp_x_xkx(self, par, x):
+        """bq/bqkern.py:358-364."""
+        return self._all(par, x)['R'][0]
+
+    def exp_x_kxkx(self, par_0, par_1, x, scaling=False):
+        """bq/bqkern.py:366-415 for equal parameter rows (the only case on the filter path)."""
+        if not np.array_equal(np.atleast_2d(par_0), np.atleast_2d(par_1)):
+            raise NotImplementedError('exp_x_kxkx with two different parameter rows is not on the device path')
+        Q = self._all(par_0, x)['Q'][0]
+        return Q * float(np.atleast_2d(par_0)[0, 0]) ** 4 if scaling else Q
+
+    def exp_x_kxx(self, par):
+        """bq/bqkern.py:417-419."""
+        return float(np.atleast_2d(par)[0, 0]) ** 2
+
+    def exp_xy_kxy(self, par):
+        """bq/bqkern.py:421-424."""
+        p = np.atleast_2d(par).astype(float)[0]
+        return p[0] ** 2 * np.prod(2 * p[1:] ** -2 + 1.0) ** -0.5

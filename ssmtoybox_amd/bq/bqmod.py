@@ -1,0 +1,182 @@
+"""
+Integrand models of Bayesian quadrature: kernel + point set -> quadrature weights (reference: ssmtoybox/bq/bqmod.py).
+
+The weights are computed on the device (`ssmq_weights_gp` / `ssmq_weights_bs`, ssmtoybox_amd/csrc/ssmq_weights.hip);
+this module keeps the reference's attribute surface: `points`, `kernel`, `dim_in`, `num_pts`, `q`, `Q`, `R`, `iK`,
+`model_var`, `integral_var`, `nu`, `mulind` (bq/bqmod.py:85-106) and the `bq_weights(par, *args)` /
+`exp_model_variance` / `integral_variance` methods the reference's tests and research scripts call.
+Hyper-parameter optimisation, prediction, plotting and the multi-output models are out of scope.
+"""
+import numpy as np
+
+from .. import _lib
+from ..mtran import (SphericalRadialTransform, UnscentedTransform, GaussHermiteTransform,
+                     FullySymmetricStudentTransform)
+from .bqkern import RBFGauss, device_gp_weights
+
+
+def n_sum_k(n, k):
+    """All n-tuples of non-negative integers summing to k, in the reference's column order (utils.py:459-475)."""
+    if k == 0:
+        return np.zeros((n, 1), dtype=int)
+    if k == 1:
+        return np.eye(n, dtype=int)
+    a = n_sum_k(n, k - 1)
+    eye = np.eye(n, dtype=int)
+    temp = np.zeros((n, (n * (1 + n) // 2) - 1), dtype=int)
+    t = 0
+    for i in range(n - 1):
+        for j in range(i, n):
+            temp[:, t] = a[:, i] + eye[:, j]
+            t += 1
+    return np.hstack((temp, a[:, n - 1:] + eye[:, -1, None]))
+
+
+class Model:
+    """Kernel + point set (bq/bqmod.py:15-106)."""
+
+    _supported_points_ = ['sr', 'ut', 'gh', 'fs']
+    _supported_kernels_ = ['rbf']
+
+    def __init__(self, dim, kern_par, kern_str, point_str, point_par, estimate_par):
+        self.kernel = Model.get_kernel(dim, kern_str, kern_par)
+        self.points = Model.get_points(dim, point_str, point_par)
+        self.estimate_par = estimate_par
+        self.str_pts = point_str
+        self.str_pts_par = str(point_par)
+        self.dim_in, self.num_pts = self.points.shape
+        self.eye_d, self.eye_n = np.eye(self.dim_in), np.eye(self.num_pts)
+        self.q, self.Q, self.R, self.iK = None, None, None, None
+        self.model_var = None
+        self.integral_var = None
+
+    def __str__(self):
+        return '{} {}\n{} {}'.format(type(self.kernel).__name__, self.kernel.par, self.str_pts, self.str_pts_par)
+
+    @staticmethod
+    def get_points(dim, points, point_par):
+        """bq/bqmod.py:340-382; unknown strings print a message and return None, as the reference does."""
+        points = points.lower()
+        if points not in Model._supported_points_:
+            print('Points {} not supported. Supported points are {}.'.format(points, Model._supported_points_))
+            return None
+        point_par = {} if point_par is None else point_par
+        if points == 'sr':
+            return SphericalRadialTransform.unit_sigma_points(dim)
+        if points == 'ut':
+            return UnscentedTransform.unit_sigma_points(dim, **point_par)
+        if points == 'gh':
+            return GaussHermiteTransform.unit_sigma_points(dim, **point_par)
+        return FullySymmetricStudentTransform.unit_sigma_points(dim, **point_par)
+
+    @staticmethod
+    def get_kernel(dim, kernel, par):
+        """bq/bqmod.py:384-423 ('rq' and 'rbf-student' are not on this path)."""
+        kernel = kernel.lower()
+        if kernel not in Model._supported_kernels_:
+            print('Kernel {} not supported. Supported kernels are {}.'.format(kernel, Model._supported_kernels_))
+            return None
+        return RBFGauss(dim, par)
+
+
+class GaussianProcessModel(Model):
+    """GP quadrature weights (bq/bqmod.py:426-535)."""
+
+    def __init__(self, dim, kern_par, kern_str, point_str, point_par=None, estimate_par=False):
+        super().__init__(dim, kern_par, kern_str, point_str, point_par, estimate_par)
+
+    def bq_weights(self, par, *args):
+        """wm = q iK, Wc = iK Q iK (symmetrised), Wcc = R iK and the model / integral variances (bq/bqmod.py:495-523)."""
+        par = self.kernel.get_parameters(par)
+        w = device_gp_weights(self.points, par[:1], self.kernel.jitter)
+        self.q, self.Q, self.R, self.iK = w['q'][0], w['Q'][0], w['R'][0], w['iK'][0]
+        self.model_var = float(w['model_var'][0])
+        self.integral_var = float(w['integral_var'][0])
+        return w['wm'][0], w['Wc'][0], w['Wcc'][0], self.model_var, self.integral_var
+
+    def bq_weights_batch(self, pars):
+        """theta-batched weights: pars (P, 1 + D) -> dict with a leading P axis (one workgroup per row)."""
+        return device_gp_weights(self.points, np.atleast_2d(pars), self.kernel.jitter)
+
+    def exp_model_variance(self, par, *args):
+        """bq/bqmod.py:525-528.  The reference evaluates K with scaling here; alpha = 1 is the common case and the only
+        one on the device path."""
+        par = self.kernel.get_parameters(par)
+        if float(par[0, 0]) != 1.0:
+            raise NotImplementedError('exp_model_variance with alpha != 1 is not on the device path')
+        return float(device_gp_weights(self.points, par[:1], self.kernel.jitter)['model_var'][0])
+
+    def integral_variance(self, par, *args):
+        """bq/bqmod.py:530-535."""
+        par = self.kernel.get_parameters(par)
+        return float(device_gp_weights(self.points, par[:1], self.kernel.jitter)['integral_var'][0])
+
+
+class StudentTProcessModel(GaussianProcessModel):
+    """Student-t process: GP weights, data-dependent model variance (bq/bqmod.py:1060-1190)."""
+
+    def __init__(self, dim, kern_par, kern_str, point_str, point_par=None, estimate_par=False, nu=4.0):
+        super().__init__(dim, kern_par, kern_str, point_str, point_par, estimate_par)
+        self.nu = 3.0 if nu < 2 else nu
+
+    def exp_model_variance(self, par, *args):
+        """(nu - 2 + fx iK fx') / (nu - 2 + N) * model_var with the cached scaling=False inverse
+        (bq/bqmod.py:1132-1160, estimate_par=False branch).  Host arithmetic on (E, N) data for callers that ask for the
+        number; `apply()` computes the same quantity inside the device kernel."""
+        fcn_obs = np.squeeze(args[0])
+        scale = (self.nu - 2 + fcn_obs.dot(self.iK).dot(fcn_obs.T)) / (self.nu - 2 + self.num_pts)
+        return scale * self.model_var
+
+    def integral_variance(self, par, *args):
+        fcn_obs = np.squeeze(args[0])
+        scale = (self.nu - 2 + fcn_obs.dot(self.iK).dot(fcn_obs.T)) / (self.nu - 2 + self.num_pts)
+        return scale * self.integral_var
+
+
+class BayesSardModel(Model):
+    """GP with a multivariate polynomial prior mean (bq/bqmod.py:599-1057)."""
+
+    def __init__(self, dim, kern_par, multi_ind=2, point_str='ut', point_par=None, estimate_par=False):
+        super().__init__(dim, kern_par, 'rbf', point_str, point_par, estimate_par)
+        if type(multi_ind) is int:
+            self.mulind = np.hstack([n_sum_k(dim, td) for td in range(multi_ind + 1)])
+        elif type(multi_ind) is np.ndarray:
+            self.mulind = multi_ind
+        else:
+            raise ValueError('Multi-index error: multi-index has to be either int or ndarray')
+
+    def bq_weights(self, par, multi_ind=None):
+        """bq/bqmod.py:893-992.  NOTE the reference crashes when handed an int multi-index here (SURVEY.md appendix
+        B-2); this build falls back to the expanded `self.mulind` for anything that is not an ndarray."""
+        if not isinstance(multi_ind, np.ndarray):
+            multi_ind = self.mulind
+        par = self.kernel.get_parameters(par)
+        if multi_ind.shape[0] != self.dim_in:
+            raise ValueError('Dimension mismatch {:d} != {:d}. Dimension of monomials must be equal to the dimension'
+                             ' of the sigma-points.'.format(multi_ind.shape[0], self.dim_in))
+        nb = multi_ind.shape[1]
+        if nb > self.num_pts:
+            raise ValueError('Number of basis functions needs to be lower than or equal to the number of points.'
+                             'You supplied {:d} basis functions and {:d} points.'.format(nb, self.num_pts))
+        lib = _lib.load()
+        x, px = _lib.as_c(self.points)
+        p, pp = _lib.as_c(par[:1])
+        mi = np.ascontiguousarray(multi_ind, dtype=np.int32)
+        D, N = x.shape
+        out = {k: _lib.out_c(s) for k, s in (('wm', (N,)), ('Wc', (N, N)), ('Wcc', (D, N)), ('iK', (N, N)),
+                                             ('q', (N,)), ('Q', (N, N)), ('R', (D, N)), ('mv', (1,)), ('iv', (1,)))}
+        st = np.zeros(1, dtype=np.int32)
+        rc = _lib.check(lib.ssmq_weights_bs(D, N, px, pp, 1, float(self.kernel.jitter),
+                                            mi.ctypes.data_as(_lib.c_int32_p), nb, out['wm'][1], out['Wc'][1],
+                                            out['Wcc'][1], out['iK'][1], out['q'][1], out['Q'][1], out['R'][1],
+                                            out['mv'][1], out['iv'][1], st.ctypes.data_as(_lib.c_int32_p)),
+                        'ssmq_weights_bs')
+        if rc > 0:
+            raise np.linalg.LinAlgError('Bayes-Sard weights: matrix not positive definite / singular (code {})'.format(
+                int(st[0])))
+        self.q, self.iK = out['q'][0], out['iK'][0]
+        if nb < N:
+            self.Q, self.R = out['Q'][0], out['R'][0]
+        self.model_var = float(out['mv'][0][0])
+        self.integral_var = float(out['iv'][0][0])
+        return out['wm'][0], out['Wc'][0], out['Wcc'][0], self.model_var, self.integral_var

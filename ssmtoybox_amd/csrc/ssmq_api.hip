@@ -1,0 +1,685 @@
+// C ABI of libssmq (include/ssmq.h): device plumbing, transform handles, kernel dispatch.  No CPU fallback exists
+// behind these entry points: every compute call ends in a HIP kernel launch or returns an error.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "ssmq_host.h"
+
+namespace ssmq {
+
+static thread_local std::string g_err;
+static hipStream_t g_stream = nullptr;
+static int g_stream_dev = -1;
+
+void set_error(const std::string &msg) { g_err = msg; }
+
+int hip_fail(hipError_t e, const char *what) {
+    if (e == hipSuccess) return SSMQ_OK;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return SSMQ_E_HIP;
+}
+
+int ensure_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (libssmq has no CPU fallback)");
+        return SSMQ_E_HIP;
+    }
+    int dev = 0;
+    SSMQ_HIP(hipGetDevice(&dev));
+    if (g_stream == nullptr || g_stream_dev != dev) {
+        SSMQ_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        g_stream_dev = dev;
+    }
+    return SSMQ_OK;
+}
+
+hipStream_t stream() { return g_stream; }
+
+void fill_fpar(const ssmq_integrand *f, FPar *fp) {
+    memset(fp, 0, sizeof(*fp));
+    fp->n_par = std::max(0, std::min<int>(f->n_par, SSMQ_MAX_FPAR));
+    fp->n_idx = std::max(0, std::min<int>(f->n_idx, SSMQ_MAX_FIDX));
+    for (int i = 0; i < fp->n_par; ++i) fp->p[i] = f->par[i];
+    for (int i = 0; i < fp->n_idx; ++i) fp->idx[i] = f->idx[i];
+}
+
+const SmallEntry *small_table_a(int *n);
+const SmallEntry *small_table_b(int *n);
+const SmallEntry *small_table_c(int *n);
+const SmallEntry *small_table_d(int *n);
+
+const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int sel) {
+    typedef const SmallEntry *(*tab_fn)(int *);
+    static const tab_fn tabs[] = {small_table_a, small_table_b, small_table_c, small_table_d};
+    for (tab_fn t : tabs) {
+        int n = 0;
+        const SmallEntry *e = t(&n);
+        for (int i = 0; i < n; ++i)
+            if (e[i].fid == fid && e[i].D == D && e[i].E == E && e[i].N == N && e[i].form == form && e[i].tp == tp &&
+                e[i].sel == sel)
+                return &e[i];
+    }
+    return nullptr;
+}
+
+// ---- layout conversion ---------------------------------------------------------------------------------------------
+// AoS [B][n] <-> SoA [n][ld] through a padded LDS tile: both the global read and the global write are coalesced.
+constexpr int kTile = 64;
+__global__ __launch_bounds__(256) void k_aos_to_soa(const double *__restrict__ aos, double *__restrict__ soa, int n,
+                                                     int64_t B, int64_t ld) {
+    __shared__ double tile[kTile][kTile + 1];
+    const int64_t b0 = (int64_t)blockIdx.x * kTile;
+    const int e0 = blockIdx.y * kTile;
+    const int tx = threadIdx.x % kTile, ty = threadIdx.x / kTile;  // 64 x 4
+    for (int r = ty; r < kTile; r += 4) {  // r: trajectory within tile, tx: element within tile
+        const int64_t b = b0 + r;
+        const int e = e0 + tx;
+        if (b < B && e < n) tile[r][tx] = aos[b * n + e];
+    }
+    __syncthreads();
+    for (int r = ty; r < kTile; r += 4) {  // r: element within tile, tx: trajectory
+        const int64_t b = b0 + tx;
+        const int e = e0 + r;
+        if (b < B && e < n) soa[(int64_t)e * ld + b] = tile[tx][r];
+    }
+}
+__global__ __launch_bounds__(256) void k_soa_to_aos(const double *__restrict__ soa, double *__restrict__ aos, int n,
+                                                     int64_t B, int64_t ld) {
+    __shared__ double tile[kTile][kTile + 1];
+    const int64_t b0 = (int64_t)blockIdx.x * kTile;
+    const int e0 = blockIdx.y * kTile;
+    const int tx = threadIdx.x % kTile, ty = threadIdx.x / kTile;
+    for (int r = ty; r < kTile; r += 4) {  // r: element, tx: trajectory
+        const int64_t b = b0 + tx;
+        const int e = e0 + r;
+        if (b < B && e < n) tile[r][tx] = soa[(int64_t)e * ld + b];
+    }
+    __syncthreads();
+    for (int r = ty; r < kTile; r += 4) {  // r: trajectory, tx: element
+        const int64_t b = b0 + r;
+        const int e = e0 + tx;
+        if (b < B && e < n) aos[b * n + e] = tile[tx][r];
+    }
+}
+
+__global__ void k_status_first(const int32_t *st, int64_t B, unsigned long long *first) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B && st[i] != 0) atomicMin(first, (unsigned long long)i);
+}
+
+static int upload_consts(ssmq_transform *h) {
+    const int D = h->D, E = h->E, N = h->N;
+    const bool sigma = h->form == SSMQ_FORM_SIGMA;
+    const ConstLayout cs = const_layout(D, E, N, h->form);
+    const WideLayout cw = wide_layout(D, E, N, h->form);
+    std::vector<double> s(cs.total, 0.0), w(cw.total, 0.0);
+    for (int d = 0; d < D; ++d)
+        for (int n = 0; n < N; ++n) {
+            s[cs.xi + n * D + d] = h->xi[d * N + n];
+            w[cw.xiT + n * D + d] = h->xi[d * N + n];
+        }
+    for (int n = 0; n < N; ++n) s[cs.wm + n] = w[cw.wm + n] = h->wm[n];
+    if (sigma) {
+        for (int n = 0; n < N; ++n) s[cs.Wc + n] = w[cw.Wc + n] = h->Wc[n];
+    } else {
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                s[cs.Wc + j * N + i] = h->Wc[i * N + j];  // transposed: column j contiguous
+                w[cw.Wc + i * N + j] = h->Wc[i * N + j];
+            }
+        for (int d = 0; d < D; ++d)
+            for (int n = 0; n < N; ++n) {
+                s[cs.Wcc + n * D + d] = h->Wcc[d * N + n];
+                w[cw.Wcc + d * N + n] = h->Wcc[d * N + n];
+            }
+    }
+    for (int i = 0; i < E * E; ++i) s[cs.emv + i] = w[cw.emv + i] = h->emv[i];
+    if (h->tp_nu > 0.0) {
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                s[cs.iK + j * N + i] = h->iK[i * N + j];
+                w[cw.iK + i * N + j] = h->iK[i * N + j];
+            }
+    }
+    SSMQ_HIP(hipMemcpyAsync(h->d_small, s.data(), sizeof(double) * cs.total, hipMemcpyHostToDevice, stream()));
+    SSMQ_HIP(hipMemcpyAsync(h->d_wide, w.data(), sizeof(double) * cw.total, hipMemcpyHostToDevice, stream()));
+    SSMQ_HIP(hipStreamSynchronize(stream()));
+    return SSMQ_OK;
+}
+
+static int sel_pattern(const ssmq_integrand *f, int din) {
+    // 0: leading entries, 1: (0, 2, 4, ...), -1: anything else
+    if (f->n_idx <= 0) return 0;
+    bool lead = true, even = true;
+    for (int k = 0; k < din && k < f->n_idx; ++k) {
+        lead = lead && f->idx[k] == k;
+        even = even && f->idx[k] == 2 * k;
+    }
+    if (f->n_idx < din) return -1;
+    return lead ? 0 : (even ? 1 : -1);
+}
+
+static int check_integrand(const ssmq_transform *h, const ssmq_integrand *f, FInfo *fi) {
+    if (!f || !integrand_info(f->id, fi)) {
+        set_error("unknown integrand id");
+        return SSMQ_E_ARG;
+    }
+    if (f->id == SSMQ_F_BEARING_MEAS) {
+        fi->dout = f->n_par / 2;
+        if (fi->dout < 1 || fi->dout > SSMQ_MAX_FPAR / 2) {
+            set_error("bearing measurement: n_par must be 2 * sensors, 1..8 sensors");
+            return SSMQ_E_ARG;
+        }
+    }
+    if (fi->dout != h->E) {
+        set_error("integrand output dimension does not match the transform's E");
+        return SSMQ_E_ARG;
+    }
+    if (f->n_idx > SSMQ_MAX_FIDX || f->n_par > SSMQ_MAX_FPAR || f->n_idx < 0 || f->n_par < 0) {
+        set_error("integrand: n_idx / n_par out of range");
+        return SSMQ_E_ARG;
+    }
+    if (f->n_idx > 0) {
+        if (f->n_idx < fi->din) {
+            set_error("integrand: state index shorter than the integrand's input");
+            return SSMQ_E_ARG;
+        }
+        for (int k = 0; k < f->n_idx; ++k)
+            if (f->idx[k] < 0 || f->idx[k] >= h->D) {
+                set_error("integrand: state index out of range");
+                return SSMQ_E_ARG;
+            }
+    } else if (fi->din > h->D) {
+        set_error("integrand reads more inputs than the transform's D");
+        return SSMQ_E_ARG;
+    }
+    return SSMQ_OK;
+}
+
+int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
+                   const double *d_cov, const double *d_time, int time_stride, double *d_mean_f, double *d_cov_f,
+                   double *d_cov_fx, int32_t *d_status, const double *d_cov_add, const char **kernel_name,
+                   bool dry_run) {
+    FInfo fi;
+    int rc = check_integrand(h, f, &fi);
+    if (rc) return rc;
+    const int tp = h->tp_nu > 0.0 ? 1 : 0;
+    const int sel = sel_pattern(f, fi.din);
+    const SmallEntry *se = sel >= 0 ? find_small(f->id, h->D, h->E, h->N, h->form, tp, sel) : nullptr;
+    if (kernel_name) *kernel_name = se ? se->name : "k_apply_wide";
+    if (dry_run) return SSMQ_OK;
+    if (B <= 0) return SSMQ_OK;
+    if (!d_mean || !d_cov || !d_mean_f || !d_cov_f || !d_cov_fx || !d_status || (fi.uses_time && !d_time) ||
+        ld < B) {
+        set_error("apply: null pointer or ld < B");
+        return SSMQ_E_ARG;
+    }
+    if (se) {
+        ApplyArgs a;
+        a.mean = d_mean; a.cov = d_cov; a.time = d_time ? d_time : d_mean; a.mean_f = d_mean_f; a.cov_f = d_cov_f;
+        a.cov_fx = d_cov_fx; a.status = d_status; a.consts = h->d_small; a.cov_add = d_cov_add; a.B = B; a.ld = ld;
+        a.time_stride = d_time ? time_stride : 0; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
+        fill_fpar(f, &a.fp);
+        return hip_fail(se->fn(a, stream()), se->name);
+    }
+    if (wide_lds_bytes(h->D, h->E, h->N) > 160 * 1024 - 64) {
+        set_error("apply: shape too large for the LDS-resident generic kernel");
+        return SSMQ_E_UNSUPPORTED;
+    }
+    WideArgs a;
+    memset(&a, 0, sizeof(a));
+    a.D = h->D; a.E = h->E; a.N = h->N; a.form = h->form; a.mode = SSMQ_WIDE_FULL; a.fid = f->id;
+    a.time_stride = d_time ? time_stride : 0; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu; a.consts = h->d_wide;
+    a.cov_add = d_cov_add; a.mean = d_mean; a.cov = d_cov; a.time = d_time; a.es_in = ld; a.bs_mean = 1; a.bs_cov = 1;
+    a.mean_f = d_mean_f; a.cov_f = d_cov_f; a.cov_fx = d_cov_fx; a.es_out = ld; a.bs_mf = a.bs_cf = a.bs_cfx = 1;
+    a.status = d_status;
+    fill_fpar(f, &a.fp);
+    return hip_fail(launch_apply_wide(a, B, stream()), "k_apply_wide");
+}
+
+}  // namespace ssmq
+
+using namespace ssmq;
+
+extern "C" {
+
+int ssmq_version(void) { return SSMQ_VERSION; }
+const char *ssmq_last_error(void) { return g_err.c_str(); }
+
+int ssmq_device_count(int *n) {
+    if (!n) return SSMQ_E_ARG;
+    *n = 0;
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) {
+        *n = 0;
+        return hip_fail(e, "hipGetDeviceCount");
+    }
+    return SSMQ_OK;
+}
+int ssmq_set_device(int device) {
+    SSMQ_HIP(hipSetDevice(device));
+    return ensure_device();
+}
+int ssmq_device_name(char *buf, int len) {
+    if (!buf || len <= 0) return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0;
+    SSMQ_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    SSMQ_HIP(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return SSMQ_OK;
+}
+
+int ssmq_malloc(void **dptr, size_t bytes) {
+    if (!dptr) return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    SSMQ_HIP(hipMalloc(dptr, bytes ? bytes : 8));
+    return SSMQ_OK;
+}
+int ssmq_free(void *dptr) {
+    if (!dptr) return SSMQ_OK;
+    SSMQ_HIP(hipFree(dptr));
+    return SSMQ_OK;
+}
+int ssmq_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    SSMQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream()));
+    SSMQ_HIP(hipStreamSynchronize(stream()));
+    return SSMQ_OK;
+}
+int ssmq_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    SSMQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream()));
+    SSMQ_HIP(hipStreamSynchronize(stream()));
+    return SSMQ_OK;
+}
+int ssmq_memcpy_d2d(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    SSMQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream()));
+    return SSMQ_OK;
+}
+int ssmq_memset(void *dptr, int value, size_t bytes) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    SSMQ_HIP(hipMemsetAsync(dptr, value, bytes, stream()));
+    return SSMQ_OK;
+}
+int ssmq_sync(void) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    SSMQ_HIP(hipStreamSynchronize(stream()));
+    return SSMQ_OK;
+}
+
+int ssmq_aos_to_soa(const double *d_aos, double *d_soa, int n, int64_t B, int64_t ld) {
+    if (!d_aos || !d_soa || n <= 0 || B < 0 || ld < B) return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return SSMQ_OK;
+    dim3 grid((unsigned)((B + kTile - 1) / kTile), (unsigned)((n + kTile - 1) / kTile));
+    hipLaunchKernelGGL(k_aos_to_soa, grid, dim3(256), 0, stream(), d_aos, d_soa, n, B, ld);
+    return hip_fail(hipGetLastError(), "k_aos_to_soa");
+}
+int ssmq_soa_to_aos(const double *d_soa, double *d_aos, int n, int64_t B, int64_t ld) {
+    if (!d_aos || !d_soa || n <= 0 || B < 0 || ld < B) return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return SSMQ_OK;
+    dim3 grid((unsigned)((B + kTile - 1) / kTile), (unsigned)((n + kTile - 1) / kTile));
+    hipLaunchKernelGGL(k_soa_to_aos, grid, dim3(256), 0, stream(), d_soa, d_aos, n, B, ld);
+    return hip_fail(hipGetLastError(), "k_soa_to_aos");
+}
+
+int ssmq_event_create(void **ev) {
+    if (!ev) return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipEvent_t e;
+    SSMQ_HIP(hipEventCreate(&e));
+    *ev = (void *)e;
+    return SSMQ_OK;
+}
+int ssmq_event_destroy(void *ev) {
+    if (!ev) return SSMQ_OK;
+    SSMQ_HIP(hipEventDestroy((hipEvent_t)ev));
+    return SSMQ_OK;
+}
+int ssmq_event_record(void *ev) {
+    if (!ev) return SSMQ_E_ARG;
+    SSMQ_HIP(hipEventRecord((hipEvent_t)ev, stream()));
+    return SSMQ_OK;
+}
+int ssmq_event_elapsed_ms(void *start, void *stop, float *ms) {
+    if (!start || !stop || !ms) return SSMQ_E_ARG;
+    SSMQ_HIP(hipEventSynchronize((hipEvent_t)stop));
+    SSMQ_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SSMQ_OK;
+}
+
+int ssmq_status_first(const int32_t *d_status, int64_t B, int64_t *first) {
+    if (!d_status || !first || B < 0) return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    *first = -1;
+    if (B == 0) return SSMQ_OK;
+    unsigned long long *d_first = nullptr;
+    SSMQ_HIP(hipMalloc((void **)&d_first, sizeof(unsigned long long)));
+    unsigned long long init = ~0ull;
+    SSMQ_HIP(hipMemcpyAsync(d_first, &init, sizeof(init), hipMemcpyHostToDevice, stream()));
+    hipLaunchKernelGGL(k_status_first, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream(), d_status, B, d_first);
+    unsigned long long res = ~0ull;
+    hipError_t e = hipMemcpyAsync(&res, d_first, sizeof(res), hipMemcpyDeviceToHost, stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(stream());
+    hipFree(d_first);
+    if (e != hipSuccess) return hip_fail(e, "ssmq_status_first");
+    *first = (res == ~0ull) ? -1 : (int64_t)res;
+    return SSMQ_OK;
+}
+
+// ---- transform handle ----------------------------------------------------------------------------------------------
+ssmq_transform *ssmq_transform_create(int D, int E, int N, int form, const double *xi, const double *wm,
+                                      const double *Wc, const double *Wcc, const double *emv, int emv_mode,
+                                      double tp_nu, const double *tp_iK) {
+    if (D < 1 || D > SSMQ_MAX_DIM || E < 1 || E > SSMQ_MAX_DIM || N < 1 || N > SSMQ_MAX_PTS ||
+        (form != SSMQ_FORM_BQ && form != SSMQ_FORM_SIGMA) || !xi || !wm || !Wc || (form == SSMQ_FORM_BQ && !Wcc) ||
+        (tp_nu > 0.0 && !tp_iK) || (emv_mode != SSMQ_EMV_DIAG && emv_mode != SSMQ_EMV_BROADCAST)) {
+        set_error("transform_create: bad argument");
+        return nullptr;
+    }
+    if (ensure_device()) return nullptr;
+    ssmq_transform *h = new ssmq_transform();
+    h->D = D; h->E = E; h->N = N; h->form = form; h->emv_mode = emv_mode; h->tp_nu = tp_nu;
+    hipGetDevice(&h->device);
+    h->xi.assign(xi, xi + D * N);
+    h->wm.assign(wm, wm + N);
+    h->Wc.assign(Wc, Wc + (form == SSMQ_FORM_SIGMA ? N : N * N));
+    if (form == SSMQ_FORM_BQ) h->Wcc.assign(Wcc, Wcc + D * N);
+    h->emv.assign(E * E, 0.0);
+    if (emv) h->emv.assign(emv, emv + E * E);
+    if (tp_nu > 0.0) h->iK.assign(tp_iK, tp_iK + N * N);
+    h->d_small = h->d_wide = nullptr;
+    const ConstLayout cs = const_layout(D, E, N, form);
+    const WideLayout cw = wide_layout(D, E, N, form);
+    if (hipMalloc((void **)&h->d_small, sizeof(double) * cs.total) != hipSuccess ||
+        hipMalloc((void **)&h->d_wide, sizeof(double) * cw.total) != hipSuccess || upload_consts(h) != SSMQ_OK) {
+        if (g_err.empty()) set_error("transform_create: device allocation failed");
+        ssmq_transform_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+int ssmq_transform_update(ssmq_transform *h, const double *xi, const double *wm, const double *Wc, const double *Wcc,
+                          const double *emv, int emv_mode, double tp_nu, const double *tp_iK) {
+    if (!h) return SSMQ_E_ARG;
+    const int D = h->D, E = h->E, N = h->N;
+    if (xi) h->xi.assign(xi, xi + D * N);
+    if (wm) h->wm.assign(wm, wm + N);
+    if (Wc) h->Wc.assign(Wc, Wc + (h->form == SSMQ_FORM_SIGMA ? N : N * N));
+    if (Wcc && h->form == SSMQ_FORM_BQ) h->Wcc.assign(Wcc, Wcc + D * N);
+    if (emv) h->emv.assign(emv, emv + E * E);
+    if (emv_mode == SSMQ_EMV_DIAG || emv_mode == SSMQ_EMV_BROADCAST) h->emv_mode = emv_mode;
+    if (tp_iK) h->iK.assign(tp_iK, tp_iK + N * N);
+    if (tp_nu > 0.0) {
+        if (h->iK.empty()) {
+            set_error("transform_update: tp_nu > 0 needs tp_iK");
+            return SSMQ_E_ARG;
+        }
+        h->tp_nu = tp_nu;
+    }
+    return upload_consts(h);
+}
+
+void ssmq_transform_destroy(ssmq_transform *h) {
+    if (!h) return;
+    if (h->d_small) hipFree(h->d_small);
+    if (h->d_wide) hipFree(h->d_wide);
+    delete h;
+}
+
+int ssmq_transform_dims(const ssmq_transform *h, int *D, int *E, int *N) {
+    if (!h) return SSMQ_E_ARG;
+    if (D) *D = h->D;
+    if (E) *E = h->E;
+    if (N) *N = h->N;
+    return SSMQ_OK;
+}
+
+// ---- apply -----------------------------------------------------------------------------------------------------------
+int ssmq_apply_batch_dev(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
+                         const double *d_cov, const double *d_time, int time_stride, double *d_mean_f,
+                         double *d_cov_f, double *d_cov_fx, int32_t *d_status) {
+    if (!h || !f) return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    return apply_dev_impl(h, f, B, ld, d_mean, d_cov, d_time, time_stride, d_mean_f, d_cov_f, d_cov_fx, d_status,
+                          nullptr, nullptr, false);
+}
+
+int ssmq_apply_kernel_name(const ssmq_transform *h, const ssmq_integrand *f, char *buf, int len) {
+    if (!h || !f || !buf || len <= 0) return SSMQ_E_ARG;
+    const char *name = nullptr;
+    int rc = apply_dev_impl(const_cast<ssmq_transform *>(h), f, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, &name, true);
+    if (rc) return rc;
+    snprintf(buf, len, "%s", name ? name : "");
+    return SSMQ_OK;
+}
+
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hip_fail(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc"); }
+    double *d() { return (double *)p; }
+};
+}  // namespace
+
+int ssmq_apply_batch(ssmq_transform *h, const ssmq_integrand *f, int64_t B, const double *mean, const double *cov,
+                     const double *time, int time_stride, double *mean_f, double *cov_f, double *cov_fx,
+                     int32_t *status) {
+    if (!h || !f || B < 0 || !mean || !cov || !mean_f || !cov_f || !cov_fx) {
+        set_error("apply_batch: null argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return SSMQ_OK;
+    const int D = h->D, E = h->E;
+    const int64_t ld = (B + 63) / 64 * 64;
+    const int n_in = D + D * D, n_out = E + E * E + E * D;
+    DevBuf aos_in, soa_in, aos_out, soa_out, d_time, d_st;
+    if ((rc = aos_in.alloc(sizeof(double) * B * n_in)) || (rc = soa_in.alloc(sizeof(double) * ld * n_in)) ||
+        (rc = aos_out.alloc(sizeof(double) * B * n_out)) || (rc = soa_out.alloc(sizeof(double) * ld * n_out)) ||
+        (rc = d_time.alloc(sizeof(double) * (time_stride ? B : 1))) || (rc = d_st.alloc(sizeof(int32_t) * ld)))
+        return rc;
+    hipStream_t s = stream();
+    // host AoS -> device AoS (mean block, then cov block) -> SoA planes
+    SSMQ_HIP(hipMemcpyAsync(aos_in.d(), mean, sizeof(double) * B * D, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(aos_in.d() + B * D, cov, sizeof(double) * B * D * D, hipMemcpyHostToDevice, s));
+    double tzero = 0.0;
+    SSMQ_HIP(hipMemcpyAsync(d_time.d(), time ? time : &tzero, sizeof(double) * (time && time_stride ? B : 1),
+                            hipMemcpyHostToDevice, s));
+    if ((rc = ssmq_aos_to_soa(aos_in.d(), soa_in.d(), D, B, ld))) return rc;
+    if ((rc = ssmq_aos_to_soa(aos_in.d() + B * D, soa_in.d() + ld * D, D * D, B, ld))) return rc;
+    double *o_mf = soa_out.d(), *o_cf = o_mf + ld * E, *o_cfx = o_cf + ld * E * E;
+    rc = apply_dev_impl(h, f, B, ld, soa_in.d(), soa_in.d() + ld * D, d_time.d(), time && time_stride ? 1 : 0, o_mf, o_cf,
+                        o_cfx, (int32_t *)d_st.p, nullptr, nullptr, false);
+    if (rc) return rc;
+    double *a_mf = aos_out.d(), *a_cf = a_mf + B * E, *a_cfx = a_cf + B * E * E;
+    if ((rc = ssmq_soa_to_aos(o_mf, a_mf, E, B, ld))) return rc;
+    if ((rc = ssmq_soa_to_aos(o_cf, a_cf, E * E, B, ld))) return rc;
+    if ((rc = ssmq_soa_to_aos(o_cfx, a_cfx, E * D, B, ld))) return rc;
+    SSMQ_HIP(hipMemcpyAsync(mean_f, a_mf, sizeof(double) * B * E, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(cov_f, a_cf, sizeof(double) * B * E * E, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(cov_fx, a_cfx, sizeof(double) * B * E * D, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> st(B);
+    SSMQ_HIP(hipMemcpyAsync(st.data(), d_st.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    int first = 0;
+    for (int64_t i = 0; i < B; ++i) {
+        if (status) status[i] = st[i];
+        if (st[i] && !first) first = (int)std::min<int64_t>(i + 1, 0x7fffffff);
+    }
+    return first;
+}
+
+int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, const double *cov, double *x,
+                            double *chol, int32_t *status) {
+    if (!h || B < 0 || !mean || !cov || !x || !chol) return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return SSMQ_OK;
+    const int D = h->D, N = h->N;
+    if (wide_lds_bytes(D, h->E, N) > 160 * 1024 - 64) return SSMQ_E_UNSUPPORTED;
+    DevBuf dm, dc, dx, dl, ds;
+    if ((rc = dm.alloc(sizeof(double) * B * D)) || (rc = dc.alloc(sizeof(double) * B * D * D)) ||
+        (rc = dx.alloc(sizeof(double) * B * D * N)) || (rc = dl.alloc(sizeof(double) * B * D * D)) ||
+        (rc = ds.alloc(sizeof(int32_t) * B)))
+        return rc;
+    hipStream_t s = stream();
+    SSMQ_HIP(hipMemcpyAsync(dm.p, mean, sizeof(double) * B * D, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dc.p, cov, sizeof(double) * B * D * D, hipMemcpyHostToDevice, s));
+    WideArgs a;
+    memset(&a, 0, sizeof(a));
+    a.D = D; a.E = h->E; a.N = N; a.form = h->form; a.mode = SSMQ_WIDE_POINTS; a.consts = h->d_wide;
+    a.mean = dm.d(); a.cov = dc.d(); a.es_in = 1; a.bs_mean = D; a.bs_cov = D * D; a.status = (int32_t *)ds.p;
+    a.x_out = dx.d(); a.chol_out = dl.d();
+    if ((rc = hip_fail(launch_apply_wide(a, B, s), "k_apply_wide(points)"))) return rc;
+    SSMQ_HIP(hipMemcpyAsync(x, dx.p, sizeof(double) * B * D * N, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(chol, dl.p, sizeof(double) * B * D * D, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> st(B);
+    SSMQ_HIP(hipMemcpyAsync(st.data(), ds.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    int first = 0;
+    for (int64_t i = 0; i < B; ++i) {
+        if (status) status[i] = st[i];
+        if (st[i] && !first) first = (int)std::min<int64_t>(i + 1, 0x7fffffff);
+    }
+    return first;
+}
+
+int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const double *mean, const double *x,
+                        const double *fx, double *mean_f, double *cov_f, double *cov_fx) {
+    if (!h || B < 0 || !chol || !fx || !mean_f || !cov_f || !cov_fx) return SSMQ_E_ARG;
+    if (h->form == SSMQ_FORM_SIGMA && (!mean || !x)) {
+        set_error("apply_fx_batch: the centred form needs mean and x");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return SSMQ_OK;
+    const int D = h->D, E = h->E, N = h->N;
+    if (wide_lds_bytes(D, E, N) > 160 * 1024 - 64) return SSMQ_E_UNSUPPORTED;
+    DevBuf dl, dfx, dm, dx, omf, ocf, ocfx;
+    if ((rc = dl.alloc(sizeof(double) * B * D * D)) || (rc = dfx.alloc(sizeof(double) * B * E * N)) ||
+        (rc = dm.alloc(sizeof(double) * B * D)) || (rc = dx.alloc(sizeof(double) * B * D * N)) ||
+        (rc = omf.alloc(sizeof(double) * B * E)) || (rc = ocf.alloc(sizeof(double) * B * E * E)) ||
+        (rc = ocfx.alloc(sizeof(double) * B * E * D)))
+        return rc;
+    hipStream_t s = stream();
+    SSMQ_HIP(hipMemcpyAsync(dl.p, chol, sizeof(double) * B * D * D, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dfx.p, fx, sizeof(double) * B * E * N, hipMemcpyHostToDevice, s));
+    if (h->form == SSMQ_FORM_SIGMA) {
+        SSMQ_HIP(hipMemcpyAsync(dm.p, mean, sizeof(double) * B * D, hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * B * D * N, hipMemcpyHostToDevice, s));
+    }
+    WideArgs a;
+    memset(&a, 0, sizeof(a));
+    a.D = D; a.E = E; a.N = N; a.form = h->form; a.mode = SSMQ_WIDE_FX; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
+    a.consts = h->d_wide; a.mean = dm.d(); a.chol_in = dl.d(); a.fx_in = dfx.d(); a.x_in = dx.d();
+    a.mean_f = omf.d(); a.cov_f = ocf.d(); a.cov_fx = ocfx.d(); a.es_out = 1; a.bs_mf = E; a.bs_cf = E * E;
+    a.bs_cfx = E * D;
+    if ((rc = hip_fail(launch_apply_wide(a, B, s), "k_apply_wide(fx)"))) return rc;
+    SSMQ_HIP(hipMemcpyAsync(mean_f, omf.p, sizeof(double) * B * E, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(cov_f, ocf.p, sizeof(double) * B * E * E, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(cov_fx, ocfx.p, sizeof(double) * B * E * D, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    return SSMQ_OK;
+}
+
+// ---- filter recursion around the path ---------------------------------------------------------------------------------
+int ssmq_kalman_update_dev(int D, int Y, int64_t B, int64_t ld, const double *d_m_pr, const double *d_P_pr,
+                           const double *d_y_mean, const double *d_P_y, const double *d_P_yx, const double *d_y,
+                           double *d_m_fi, double *d_P_fi, int32_t *d_status) {
+    if (D < 1 || Y < 1 || B < 0 || ld < B || !d_m_pr || !d_P_pr || !d_y_mean || !d_P_y || !d_P_yx || !d_y || !d_m_fi ||
+        !d_P_fi || !d_status)
+        return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return SSMQ_OK;
+    SSMQ_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * B, stream()));
+    return launch_kalman_update(D, Y, B, ld, d_m_pr, d_P_pr, d_y_mean, d_P_y, d_P_yx, d_y, d_m_fi, d_P_fi, d_status,
+                                stream());
+}
+
+}  // extern "C"
+
+namespace ssmq {
+int launch_kalman_update_ex(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
+                            const double *y_mean, const double *P_y, const double *P_yx, const double *y,
+                            double *m_fi, double *P_fi, int32_t *status, const int32_t *st_a, const int32_t *st_b,
+                            int step, hipStream_t s);
+}
+
+extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                       const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
+                                       const double *d_m0, const double *d_P0, const double *GQG, const double *R,
+                                       double *d_fm, double *d_fP, int32_t *d_status) {
+    if (!h_dyn || !h_obs || !f_dyn || !f_obs || B < 0 || ld < B || T < 0 || !d_y || !d_m0 || !d_P0 || !d_fm || !d_fP ||
+        !d_status) {
+        set_error("filter_forward: bad argument");
+        return SSMQ_E_ARG;
+    }
+    const int D = h_dyn->D, Y = h_obs->E;
+    if (h_dyn->E != D || h_obs->D != D) {
+        set_error("filter_forward: additive-noise filter needs dyn (D -> D) and obs (D -> Y) transforms");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0 || T == 0) return SSMQ_OK;
+    hipStream_t s = stream();
+    DevBuf m_pr, P_pr, C_xx, y_mean, P_y, P_yx, tvec, gqg, rr, st_a, st_b;
+    if ((rc = m_pr.alloc(sizeof(double) * ld * D)) || (rc = P_pr.alloc(sizeof(double) * ld * D * D)) ||
+        (rc = C_xx.alloc(sizeof(double) * ld * D * D)) || (rc = y_mean.alloc(sizeof(double) * ld * Y)) ||
+        (rc = P_y.alloc(sizeof(double) * ld * Y * Y)) || (rc = P_yx.alloc(sizeof(double) * ld * Y * D)) ||
+        (rc = tvec.alloc(sizeof(double) * T)) || (rc = gqg.alloc(sizeof(double) * D * D)) ||
+        (rc = rr.alloc(sizeof(double) * Y * Y)) || (rc = st_a.alloc(sizeof(int32_t) * ld)) ||
+        (rc = st_b.alloc(sizeof(int32_t) * ld)))
+        return rc;
+    std::vector<double> tv(T), zg(D * D, 0.0), zr(Y * Y, 0.0);
+    for (int k = 0; k < T; ++k) tv[k] = (double)k;  // both transforms of step k use time index k - 1 (ssinf.py:104)
+    SSMQ_HIP(hipMemcpyAsync(tvec.p, tv.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(gqg.p, GQG ? GQG : zg.data(), sizeof(double) * D * D, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(rr.p, R ? R : zr.data(), sizeof(double) * Y * Y, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, s));
+    SSMQ_HIP(hipStreamSynchronize(s));  // host staging vectors go out of scope only after this call returns anyway
+    for (int k = 0; k < T; ++k) {
+        const double *m_in = k == 0 ? d_m0 : d_fm + (int64_t)(k - 1) * D * ld;
+        const double *P_in = k == 0 ? d_P0 : d_fP + (int64_t)(k - 1) * D * D * ld;
+        rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec.d() + k, 0, m_pr.d(), P_pr.d(), C_xx.d(),
+                            (int32_t *)st_a.p, gqg.d(), nullptr, false);
+        if (rc) return rc;
+        rc = apply_dev_impl(h_obs, f_obs, B, ld, m_pr.d(), P_pr.d(), tvec.d() + k, 0, y_mean.d(), P_y.d(), P_yx.d(),
+                            (int32_t *)st_b.p, rr.d(), nullptr, false);
+        if (rc) return rc;
+        rc = launch_kalman_update_ex(D, Y, B, ld, m_pr.d(), P_pr.d(), y_mean.d(), P_y.d(), P_yx.d(),
+                                     d_y + (int64_t)k * Y * ld, d_fm + (int64_t)k * D * ld,
+                                     d_fP + (int64_t)k * D * D * ld, d_status, (const int32_t *)st_a.p,
+                                     (const int32_t *)st_b.p, k, s);
+        if (rc) return rc;
+    }
+    SSMQ_HIP(hipStreamSynchronize(s));
+    return SSMQ_OK;
+}

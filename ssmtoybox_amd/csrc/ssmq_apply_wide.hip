@@ -1,0 +1,240 @@
+// Generic batched moment transform: run-time D, E, N and integrand id, one 64-lane workgroup per trajectory, the
+// sigma points / integrand values / intermediate products resident in LDS.  This is the path for shapes that have no
+// register-resident specialisation (ssmq_apply_small.h) - e.g. Bayes-Sard quadrature at D = 10 with N = 21 or 201 -
+// and for the split entry points that serve an arbitrary Python integrand (sigma points out, reductions in).
+//
+// Work split inside a workgroup: lanes over sigma points n for x_n = mean + L xi_n and f(x_n); lanes over output
+// entries (e, j) for T = fx Wc (Wc rows streamed from L2, coalesced over j) and for every (E x E) / (E x D) result.
+#include "ssmq_device.h"
+#include "ssmq_wide.h"
+
+namespace ssmq {
+
+__device__ __forceinline__ void eval_integrand(int id, const double *xs, double t, const FPar &fp, double *o) {
+#define SSMQ_CASE(F)                      \
+    case F: {                             \
+        Fn<F> fn;                         \
+        fn.init(t, fp);                   \
+        fn.template eval<SSMQ_MAX_FIDX>(xs, o); \
+    } break;
+    switch (id) {
+        SSMQ_CASE(SSMQ_F_UNGM_DYN)
+        SSMQ_CASE(SSMQ_F_UNGM_MEAS)
+        SSMQ_CASE(SSMQ_F_UNGMNA_DYN)
+        SSMQ_CASE(SSMQ_F_UNGMNA_MEAS)
+        SSMQ_CASE(SSMQ_F_PENDULUM_DYN)
+        SSMQ_CASE(SSMQ_F_PENDULUM_MEAS)
+        SSMQ_CASE(SSMQ_F_REENTRY1D_DYN)
+        SSMQ_CASE(SSMQ_F_RANGE_MEAS)
+        SSMQ_CASE(SSMQ_F_REENTRY2D_DYN)
+        SSMQ_CASE(SSMQ_F_RADAR2D_MEAS)
+        SSMQ_CASE(SSMQ_F_CT_DYN)
+        SSMQ_CASE(SSMQ_F_BEARING_MEAS)
+        SSMQ_CASE(SSMQ_F_CTRS_DYN)
+        SSMQ_CASE(SSMQ_F_CV_DYN)
+        SSMQ_CASE(SSMQ_F_REENTRY2D_BIAS_DYN)
+        default: break;
+    }
+#undef SSMQ_CASE
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
+    extern __shared__ __align__(16) double lds[];
+    const int D = a.D, E = a.E, N = a.N;
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    double *sL = lds;               // D*D   lower factor, row-major, zeros above the diagonal
+    double *sm = sL + D * D;        // D
+    double *sx = sm + D;            // D*N   sigma points
+    double *sfx = sx + D * N;       // E*N   integrand values (centred in place for the SIGMA form)
+    double *sT = sfx + E * N;       // E*N   fx Wc  (then fx iK for the TP model variance)
+    double *smf = sT + E * N;       // E
+    double *sS = smf + E;           // E*E   TP quadratic form
+    double *sC = sS + E * E;        // E*E   fx Wc fx'
+    double *sg = sC + E * E;        // E*D
+    __shared__ int s_ok;
+    const double *c = a.consts;
+    const WideLayout cl = wide_layout(D, E, N, a.form);
+    const double nan = __builtin_nan("");
+
+    // ---- 1. inputs -> LDS, Cholesky --------------------------------------------------------------------------
+    if (a.mode != SSMQ_WIDE_FX) {
+        for (int d = lane; d < D; d += kWideBlock) sm[d] = a.mean[d * a.es_in + b * a.bs_mean];
+        for (int i = lane; i < D * D; i += kWideBlock) {
+            const int r = i / D, cc = i % D;
+            sL[i] = (cc <= r) ? a.cov[(int64_t)i * a.es_in + b * a.bs_cov] : 0.0;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            bool ok = true;
+            for (int j = 0; j < D; ++j) {
+                double ajj = sL[j * D + j];
+                for (int k = 0; k < j; ++k) ajj -= sL[j * D + k] * sL[j * D + k];
+                ok = ok && (ajj > 0.0);
+                ajj = sqrt(ajj);
+                sL[j * D + j] = ajj;
+                const double r = 1.0 / ajj;
+                for (int i = j + 1; i < D; ++i) {
+                    double s = sL[i * D + j];
+                    for (int k = 0; k < j; ++k) s -= sL[i * D + k] * sL[j * D + k];
+                    sL[i * D + j] = s * r;
+                }
+            }
+            s_ok = ok ? 1 : 0;
+            if (a.status) a.status[b] = ok ? 0 : 1;
+        }
+        __syncthreads();
+        // ---- 2. sigma points and integrand -----------------------------------------------------------------------
+        const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
+        for (int n = lane; n < N; n += kWideBlock) {
+            for (int d = 0; d < D; ++d) {
+                double s = sm[d];
+                for (int k = 0; k <= d; ++k) s += sL[d * D + k] * c[cl.xiT + n * D + k];
+                sx[d * N + n] = s;
+            }
+            if (a.mode == SSMQ_WIDE_FULL) {
+                double xs[SSMQ_MAX_FIDX], o[SSMQ_MAX_DIM];
+#pragma unroll
+                for (int k = 0; k < SSMQ_MAX_FIDX; ++k) {
+                    const int src = a.fp.n_idx > 0 ? (k < a.fp.n_idx ? a.fp.idx[k] : 0) : (k < D ? k : 0);
+                    xs[k] = sx[src * N + n];
+                }
+#pragma unroll
+                for (int e = 0; e < SSMQ_MAX_DIM; ++e) o[e] = 0.0;
+                eval_integrand(a.fid, xs, t, a.fp, o);
+#pragma unroll
+                for (int e = 0; e < SSMQ_MAX_DIM; ++e)
+                    if (e < E) sfx[e * N + n] = o[e];
+            }
+        }
+        __syncthreads();
+        if (a.mode == SSMQ_WIDE_POINTS) {
+            // outputs in the reference layout: x [b][D][N], chol [b][D][D]
+            for (int i = lane; i < D * N; i += kWideBlock) a.x_out[b * D * N + i] = s_ok ? sx[i] : nan;
+            for (int i = lane; i < D * D; i += kWideBlock) a.chol_out[b * D * D + i] = s_ok ? sL[i] : nan;
+            return;
+        }
+    } else {
+        // reductions only: L, fx (and x, mean for the centred form) come from the caller, reference layout
+        for (int i = lane; i < D * D; i += kWideBlock) sL[i] = a.chol_in[b * D * D + i];
+        for (int i = lane; i < E * N; i += kWideBlock) sfx[i] = a.fx_in[b * E * N + i];
+        if (a.form == SSMQ_FORM_SIGMA) {
+            for (int i = lane; i < D * N; i += kWideBlock) sx[i] = a.x_in[b * D * N + i];
+            for (int d = lane; d < D; d += kWideBlock) sm[d] = a.mean[b * D + d];
+        }
+        if (lane == 0) s_ok = 1;
+        __syncthreads();
+    }
+    const bool ok = s_ok != 0;
+#define OUT_ADDR(ptr, e, bs) ptr[(int64_t)(e) * a.es_out + b * (bs)]
+
+    // ---- 3. mean ---------------------------------------------------------------------------------------------
+    for (int e = 0; e < E; ++e) {
+        double s = 0.0;
+        for (int n = lane; n < N; n += kWideBlock) s += sfx[e * N + n] * c[cl.wm + n];
+        s = wave_sum(s);
+        if (lane == 0) smf[e] = s;
+    }
+    __syncthreads();
+    for (int e = lane; e < E; e += kWideBlock) OUT_ADDR(a.mean_f, e, a.bs_mf) = ok ? smf[e] : nan;
+
+    if (a.form == SSMQ_FORM_BQ) {
+        // ---- 4. T = fx Wc; cov = T fx' - mean mean' + emv -------------------------------------------------------
+        for (int idx = lane; idx < E * N; idx += kWideBlock) {
+            const int e = idx / N, j = idx % N;
+            double s = 0.0;
+            for (int i = 0; i < N; ++i) s += sfx[e * N + i] * c[cl.Wc + (int64_t)i * N + j];
+            sT[idx] = s;
+        }
+        __syncthreads();
+        for (int idx = lane; idx < E * E; idx += kWideBlock) {
+            const int e = idx / E, e2 = idx % E;
+            double s = 0.0;
+            for (int j = 0; j < N; ++j) s += sT[e * N + j] * sfx[e2 * N + j];
+            sC[idx] = s;
+        }
+        __syncthreads();
+        if (a.tp_nu > 0.0) {
+            for (int idx = lane; idx < E * N; idx += kWideBlock) {
+                const int e = idx / N, j = idx % N;
+                double s = 0.0;
+                for (int i = 0; i < N; ++i) s += sfx[e * N + i] * c[cl.iK + (int64_t)i * N + j];
+                sT[idx] = s;
+            }
+            __syncthreads();
+            for (int idx = lane; idx < E * E; idx += kWideBlock) {
+                const int e = idx / E, e2 = idx % E;
+                double s = 0.0;
+                for (int j = 0; j < N; ++j) s += sT[e * N + j] * sfx[e2 * N + j];
+                sS[idx] = s;
+            }
+            __syncthreads();
+        }
+        for (int idx = lane; idx < E * E; idx += kWideBlock) {
+            const int e = idx / E, e2 = idx % E;
+            const bool use = (e == e2) || (a.emv_mode == SSMQ_EMV_BROADCAST);
+            double em = use ? c[cl.emv + idx] : 0.0;
+            if (a.tp_nu > 0.0) em = (a.tp_nu - 2.0 + sS[idx]) * (1.0 / (a.tp_nu - 2.0 + (double)N)) * em;
+            double v = sC[idx] - smf[e] * smf[e2] + em;
+            if (a.cov_add) v += a.cov_add[idx];
+            OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? v : nan;
+        }
+        // ---- 5. cross-covariance (fx Wcc') L' ------------------------------------------------------------------
+        for (int idx = lane; idx < E * D; idx += kWideBlock) {
+            const int e = idx / D, d = idx % D;
+            double s = 0.0;
+            for (int n = 0; n < N; ++n) s += sfx[e * N + n] * c[cl.Wcc + d * N + n];
+            sg[idx] = s;
+        }
+        __syncthreads();
+        for (int idx = lane; idx < E * D; idx += kWideBlock) {
+            const int e = idx / D, j = idx % D;
+            double s = 0.0;
+            for (int d = 0; d <= j; ++d) s += sg[e * D + d] * sL[j * D + d];
+            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? s : nan;
+        }
+    } else {
+        // ---- classical centred form (mtran.py:141-149), Wc = diag(wc) -------------------------------------------
+        for (int idx = lane; idx < E * N; idx += kWideBlock) sfx[idx] -= smf[idx / N];
+        __syncthreads();
+        for (int idx = lane; idx < E * E; idx += kWideBlock) {
+            const int e = idx / E, e2 = idx % E;
+            double s = 0.0;
+            for (int n = 0; n < N; ++n) s += (sfx[e * N + n] * c[cl.Wc + n]) * sfx[e2 * N + n];
+            if (a.cov_add) s += a.cov_add[idx];
+            OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? s : nan;
+        }
+        for (int idx = lane; idx < E * D; idx += kWideBlock) {
+            const int e = idx / D, d = idx % D;
+            double s = 0.0;
+            for (int n = 0; n < N; ++n) s += (sfx[e * N + n] * c[cl.Wc + n]) * (sx[d * N + n] - sm[d]);
+            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? s : nan;
+        }
+    }
+#undef OUT_ADDR
+}
+
+size_t wide_lds_bytes(int D, int E, int N) {
+    return sizeof(double) * (size_t)(D * D + D + D * N + 2 * E * N + E + 2 * E * E + E * D);
+}
+
+hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s) {
+    const size_t lds = wide_lds_bytes(a.D, a.E, a.N);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_apply_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_apply_wide, dim3((unsigned)B), dim3(kWideBlock), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ssmq

@@ -1,0 +1,322 @@
+// Device-side building blocks shared by every kernel of libssmq: argument blocks, the in-register Cholesky, and the
+// closed-form integrands of the reference's ssmod.py as __device__ functors.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/ssmq.h"
+
+namespace ssmq {
+
+// Integrand constants as they travel in the kernel-argument segment (wave-uniform -> SGPRs).
+struct FPar {
+    double p[SSMQ_MAX_FPAR];
+    int32_t idx[SSMQ_MAX_FIDX];
+    int32_t n_idx;
+    int32_t n_par;
+};
+
+// Offsets (in doubles) into a transform's constant block in HBM; every thread reads it with wave-uniform addresses,
+// so the loads are scalar (s_load) and the block stays in the scalar cache / L2.
+struct ConstLayout {
+    int32_t xi, wm, Wc, Wcc, emv, iK, total;
+};
+__host__ __device__ constexpr inline ConstLayout const_layout(int D, int E, int N, int form) {
+    ConstLayout c{};
+    c.xi = 0;
+    c.wm = c.xi + D * N;
+    c.Wc = c.wm + N;
+    c.Wcc = c.Wc + (form == SSMQ_FORM_SIGMA ? N : N * N);
+    c.emv = c.Wcc + D * N;
+    c.iK = c.emv + E * E;
+    c.total = c.iK + N * N;
+    return c;
+}
+
+struct ApplyArgs {
+    const double *mean;     // [D][ld]
+    const double *cov;      // [D*D][ld], lower triangle read
+    const double *time;     // [B] or [1]
+    double *mean_f;         // [E][ld]
+    double *cov_f;          // [E*E][ld]
+    double *cov_fx;         // [E*D][ld]
+    int32_t *status;        // [B]
+    const double *consts;   // transform constant block
+    const double *cov_add;  // [E*E] added to cov_f after the model variance (G Q G' / R of the filters), or null
+    int64_t B, ld;
+    int32_t time_stride;
+    int32_t emv_mode;
+    double tp_nu;
+    FPar fp;
+};
+
+// Transform constants are read through the constant address space: wave-uniform constant-space loads are always
+// selected as scalar loads (s_load), even after the kernel has started storing its outputs.
+typedef const __attribute__((address_space(4))) double *cdouble_p;
+
+#define SSMQ_PK(i, j) ((i) * ((i) + 1) / 2 + (j))  // packed lower-triangular index, j <= i
+
+// In-register lower Cholesky of a packed symmetric matrix, column by column with reciprocal scaling, the operation
+// order of LAPACK dpotf2 'L' that numpy.linalg.cholesky ends in (bq/bqmtran.py:98).  Returns false at the first
+// non-positive (or NaN) pivot - where the reference raises LinAlgError.
+template <int D>
+__device__ __forceinline__ bool chol_packed(double (&L)[D * (D + 1) / 2]) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double ajj = L[SSMQ_PK(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) ajj -= L[SSMQ_PK(j, k)] * L[SSMQ_PK(j, k)];
+        ok = ok && (ajj > 0.0);
+        ajj = sqrt(ajj);
+        L[SSMQ_PK(j, j)] = ajj;
+        const double r = 1.0 / ajj;
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            double s = L[SSMQ_PK(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[SSMQ_PK(i, k)] * L[SSMQ_PK(j, k)];
+            L[SSMQ_PK(i, j)] = s * r;
+        }
+    }
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Integrands.  Each functor: DIN = leading inputs it reads, init(t, par) once per trajectory, eval<E>(x, out).
+// Formulas: ssmod.py lines cited in include/ssmq.h.  Additive-noise models are evaluated with zero noise
+// (ssmod.py:153-158, 993-998).
+// ---------------------------------------------------------------------------------------------------------------
+template <int F>
+struct Fn;
+
+template <>
+struct Fn<SSMQ_F_UNGM_DYN> {
+    static constexpr int DIN = 1;
+    double c;
+    __device__ __forceinline__ void init(double t, const FPar &) { c = 8.0 * cos(1.2 * t); }
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        o[0] = 0.5 * x[0] + 25.0 * (x[0] / (1.0 + x[0] * x[0])) + c;
+    }
+};
+template <>
+struct Fn<SSMQ_F_UNGM_MEAS> {
+    static constexpr int DIN = 1;
+    __device__ __forceinline__ void init(double, const FPar &) {}
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        o[0] = 0.05 * (x[0] * x[0]);
+    }
+};
+template <>
+struct Fn<SSMQ_F_UNGMNA_DYN> {
+    static constexpr int DIN = 2;
+    double c;
+    __device__ __forceinline__ void init(double t, const FPar &) { c = cos(1.2 * t); }
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        o[0] = 0.5 * x[0] + 25.0 * (x[0] / (1.0 + x[0] * x[0])) + 8.0 * x[1] * c;
+    }
+};
+template <>
+struct Fn<SSMQ_F_UNGMNA_MEAS> {
+    static constexpr int DIN = 2;
+    __device__ __forceinline__ void init(double, const FPar &) {}
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        o[0] = 0.05 * x[1] * (x[0] * x[0]);
+    }
+};
+template <>
+struct Fn<SSMQ_F_PENDULUM_DYN> {
+    static constexpr int DIN = 2;
+    double dt;
+    __device__ __forceinline__ void init(double, const FPar &p) { dt = p.p[0]; }
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        o[0] = x[0] + x[1] * dt;
+        o[1] = x[1] - 9.81 * dt * sin(x[0]);
+    }
+};
+template <>
+struct Fn<SSMQ_F_PENDULUM_MEAS> {
+    static constexpr int DIN = 1;
+    __device__ __forceinline__ void init(double, const FPar &) {}
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        o[0] = sin(x[0]);
+    }
+};
+template <>
+struct Fn<SSMQ_F_REENTRY1D_DYN> {
+    static constexpr int DIN = 3;
+    double dt;
+    __device__ __forceinline__ void init(double, const FPar &p) { dt = p.p[0]; }
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        const double gam = 1.0 / 6.096;
+        o[0] = x[0] - dt * x[1];
+        o[1] = x[1] - dt * exp(-gam * x[0]) * (x[1] * x[1]) * x[2];
+        o[2] = x[2];
+    }
+};
+template <>
+struct Fn<SSMQ_F_RANGE_MEAS> {
+    static constexpr int DIN = 1;
+    __device__ __forceinline__ void init(double, const FPar &) {}
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        const double sx = 30.0, sy = 30.0;
+        o[0] = sqrt(sx * sx + (x[0] - sy) * (x[0] - sy));
+    }
+};
+struct ReentryCore {
+    double dt;
+    __device__ __forceinline__ void init(double, const FPar &p) { dt = p.p[0]; }
+    __device__ __forceinline__ void core(const double *x, double *o) const {
+        const double r0 = 6374.0, h0 = 13.406, gm0 = 3.9860e5, b0 = -0.59783;
+        const double b = b0 * exp(x[4]);
+        const double rr = sqrt(x[0] * x[0] + x[1] * x[1]);
+        const double vv = sqrt(x[2] * x[2] + x[3] * x[3]);
+        const double dr = b * exp((r0 - rr) / h0) * vv;
+        const double gr = -gm0 / (rr * rr * rr);
+        o[0] = x[0] + dt * x[2];
+        o[1] = x[1] + dt * x[3];
+        o[2] = x[2] + dt * (dr * x[2] + gr * x[0]);
+        o[3] = x[3] + dt * (dr * x[3] + gr * x[1]);
+        o[4] = x[4];
+    }
+};
+template <>
+struct Fn<SSMQ_F_REENTRY2D_DYN> : ReentryCore {
+    static constexpr int DIN = 5;
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        core(x, o);
+    }
+};
+template <>
+struct Fn<SSMQ_F_REENTRY2D_BIAS_DYN> : ReentryCore {
+    static constexpr int DIN = 6;
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        core(x, o);
+        o[5] = x[5];
+    }
+};
+template <>
+struct Fn<SSMQ_F_RADAR2D_MEAS> {
+    static constexpr int DIN = 2;
+    double lx, ly;
+    __device__ __forceinline__ void init(double, const FPar &p) {
+        lx = p.n_par >= 2 ? p.p[0] : 0.0;
+        ly = p.n_par >= 2 ? p.p[1] : 0.0;
+    }
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        const double dx = x[0] - lx, dy = x[1] - ly;
+        o[0] = sqrt(dx * dx + dy * dy);
+        o[1] = atan2(dy, dx);
+    }
+};
+template <>
+struct Fn<SSMQ_F_CT_DYN> {
+    static constexpr int DIN = 5;
+    double dt;
+    __device__ __forceinline__ void init(double, const FPar &p) { dt = p.p[0]; }
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        const double om = x[4];
+        double a, b;
+        sincos(om * dt, &a, &b);
+        const double c = a / om, d = (1.0 - b) / om;
+        o[0] = x[0] + c * x[1] - d * x[3];
+        o[1] = b * x[1] - a * x[3];
+        o[2] = d * x[1] + x[2] + c * x[3];
+        o[3] = a * x[1] + b * x[3];
+        o[4] = x[4];
+    }
+};
+template <>
+struct Fn<SSMQ_F_BEARING_MEAS> {
+    static constexpr int DIN = 2;
+    const FPar *fp;
+    __device__ __forceinline__ void init(double, const FPar &p) { fp = &p; }
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            if (s < SSMQ_MAX_FPAR / 2) o[s] = atan2(x[1] - fp->p[2 * s + 1], x[0] - fp->p[2 * s]);
+        }
+    }
+};
+template <>
+struct Fn<SSMQ_F_CTRS_DYN> {
+    static constexpr int DIN = 7;
+    double dt;
+    __device__ __forceinline__ void init(double, const FPar &p) { dt = p.p[0]; }
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        const double q0 = x[5], q1 = x[6];
+        double s3, c3;
+        sincos(x[3], &s3, &c3);
+        double f0, f1;
+        if (x[4] == 0.0) {
+            f0 = dt * x[2] * c3;
+            f1 = dt * x[2] * s3;
+        } else {
+            const double c = x[2] / x[4];
+            double s34, c34;
+            sincos(x[3] + x[4] * dt, &s34, &c34);
+            f0 = c * (s34 - s3) + 0.5 * dt * dt * c3 * q0;
+            f1 = c * (-c34 + c3) + 0.5 * dt * dt * s3 * q0;
+        }
+        o[0] = x[0] + f0;
+        o[1] = x[1] + f1;
+        o[2] = x[2] + dt * q0;
+        o[3] = x[3] + (dt * x[3] + 0.5 * dt * dt * q1);
+        o[4] = x[4] + dt * q1;
+    }
+};
+template <>
+struct Fn<SSMQ_F_CV_DYN> {
+    static constexpr int DIN = 4;
+    double dt;
+    __device__ __forceinline__ void init(double, const FPar &p) { dt = p.p[0]; }
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+        o[0] = x[0] + dt * x[1];
+        o[1] = x[1];
+        o[2] = x[2] + dt * x[3];
+        o[3] = x[3];
+    }
+};
+
+// Host-visible table: inputs read / outputs produced by each integrand (0 = "set by the transform's E").
+struct FInfo {
+    int din, dout;
+    bool uses_time;
+};
+__host__ inline bool integrand_info(int id, FInfo *o) {
+    switch (id) {
+        case SSMQ_F_UNGM_DYN: *o = {1, 1, true}; return true;
+        case SSMQ_F_UNGM_MEAS: *o = {1, 1, false}; return true;
+        case SSMQ_F_UNGMNA_DYN: *o = {2, 1, true}; return true;
+        case SSMQ_F_UNGMNA_MEAS: *o = {2, 1, false}; return true;
+        case SSMQ_F_PENDULUM_DYN: *o = {2, 2, false}; return true;
+        case SSMQ_F_PENDULUM_MEAS: *o = {1, 1, false}; return true;
+        case SSMQ_F_REENTRY1D_DYN: *o = {3, 3, false}; return true;
+        case SSMQ_F_RANGE_MEAS: *o = {1, 1, false}; return true;
+        case SSMQ_F_REENTRY2D_DYN: *o = {5, 5, false}; return true;
+        case SSMQ_F_RADAR2D_MEAS: *o = {2, 2, false}; return true;
+        case SSMQ_F_CT_DYN: *o = {5, 5, false}; return true;
+        case SSMQ_F_BEARING_MEAS: *o = {2, 0, false}; return true;
+        case SSMQ_F_CTRS_DYN: *o = {7, 5, false}; return true;
+        case SSMQ_F_CV_DYN: *o = {4, 4, false}; return true;
+        case SSMQ_F_REENTRY2D_BIAS_DYN: *o = {6, 6, false}; return true;
+        default: return false;
+    }
+}
+
+}  // namespace ssmq

@@ -1,0 +1,203 @@
+// Gaussian measurement update, batched, one trajectory per lane (ssinf.py:297-323):
+//   gain = (P_y^-1 P_yx)'  via Cholesky of P_y;  m = m_pr + gain (y - y_mean);  P = P_pr - (gain P_y) gain'
+// The covariance is left unsymmetrised exactly as the reference leaves it (ssinf.py:323); the next time update reads
+// only its lower triangle (LAPACK 'L').  SoA planes, pitch ld.
+#include "ssmq_host.h"
+
+namespace ssmq {
+
+constexpr int kUpdBlock = 64;
+
+struct UpdArgs {
+    const double *m_pr, *P_pr, *y_mean, *P_y, *P_yx, *y;
+    double *m_fi, *P_fi;
+    int32_t *status;            // aggregated: 0 ok, else 1 + first failing step
+    const int32_t *st_a, *st_b; // per-step status of the two transforms (may be null)
+    int64_t B, ld;
+    int32_t step, D, Y;
+};
+
+template <int D, int Y>
+__global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
+    const uint32_t b = blockIdx.x * kUpdBlock + threadIdx.x;
+    if ((int64_t)b >= a.B) return;
+    const int64_t ld = a.ld;
+    double S[Y * (Y + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < Y; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) S[SSMQ_PK(i, j)] = a.P_y[(i * Y + j) * ld + b];
+    double Py[Y][Y];
+#pragma unroll
+    for (int i = 0; i < Y; ++i)
+#pragma unroll
+        for (int j = 0; j < Y; ++j) Py[i][j] = a.P_y[(i * Y + j) * ld + b];
+    bool ok = chol_packed<Y>(S);
+    // X = P_y^-1 P_yx, column by column (forward then backward substitution); gain[d][i] = X[i][d]
+    double G[D][Y];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        double v[Y];
+#pragma unroll
+        for (int i = 0; i < Y; ++i) {
+            double s = a.P_yx[(i * D + d) * ld + b];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= S[SSMQ_PK(i, k)] * v[k];
+            v[i] = s / S[SSMQ_PK(i, i)];
+        }
+#pragma unroll
+        for (int i = Y - 1; i >= 0; --i) {
+            double s = v[i];
+#pragma unroll
+            for (int k = i + 1; k < Y; ++k) s -= S[SSMQ_PK(k, i)] * v[k];
+            v[i] = s / S[SSMQ_PK(i, i)];
+        }
+#pragma unroll
+        for (int i = 0; i < Y; ++i) G[d][i] = v[i];
+    }
+    double dy[Y];
+#pragma unroll
+    for (int i = 0; i < Y; ++i) dy[i] = a.y[i * ld + b] - a.y_mean[i * ld + b];
+    int32_t agg = a.status[b];
+    int32_t bad = ok ? 0 : 1;
+    if (a.st_a) bad |= a.st_a[b];
+    if (a.st_b) bad |= a.st_b[b];
+    if (agg == 0 && bad) agg = a.step + 1;
+    a.status[b] = agg;
+    const double nan = __builtin_nan("");
+    const bool good = (agg == 0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < Y; ++i) s += G[d][i] * dy[i];
+        const double mp = a.m_pr[d * ld + b];
+        a.m_fi[d * ld + b] = good ? mp + s : nan;
+    }
+    // W = gain P_y (D x Y);  P = P_pr - W gain'
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        double w[Y];
+#pragma unroll
+        for (int j = 0; j < Y; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < Y; ++i) s += G[d][i] * Py[i][j];
+            w[j] = s;
+        }
+#pragma unroll
+        for (int d2 = 0; d2 < D; ++d2) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < Y; ++j) s += w[j] * G[d2][j];
+            const double pp = a.P_pr[(d * D + d2) * ld + b];
+            a.P_fi[(d * D + d2) * ld + b] = good ? pp - s : nan;
+        }
+    }
+}
+
+// Run-time-shape fallback (D, Y <= SSMQ_MAX_DIM); private arrays live in scratch.
+__global__ __launch_bounds__(kUpdBlock) void k_kalman_update_generic(const UpdArgs a) {
+    const uint32_t b = blockIdx.x * kUpdBlock + threadIdx.x;
+    if ((int64_t)b >= a.B) return;
+    const int64_t ld = a.ld;
+    const int D = a.D, Y = a.Y;
+    double S[SSMQ_MAX_DIM * SSMQ_MAX_DIM], G[SSMQ_MAX_DIM * SSMQ_MAX_DIM], v[SSMQ_MAX_DIM], w[SSMQ_MAX_DIM];
+    for (int i = 0; i < Y; ++i)
+        for (int j = 0; j < Y; ++j) S[i * Y + j] = a.P_y[(i * Y + j) * ld + b];
+    bool ok = true;
+    for (int j = 0; j < Y; ++j) {
+        double ajj = S[j * Y + j];
+        for (int k = 0; k < j; ++k) ajj -= S[j * Y + k] * S[j * Y + k];
+        ok = ok && (ajj > 0.0);
+        ajj = sqrt(ajj);
+        S[j * Y + j] = ajj;
+        const double r = 1.0 / ajj;
+        for (int i = j + 1; i < Y; ++i) {
+            double s = S[i * Y + j];
+            for (int k = 0; k < j; ++k) s -= S[i * Y + k] * S[j * Y + k];
+            S[i * Y + j] = s * r;
+        }
+    }
+    for (int d = 0; d < D; ++d) {
+        for (int i = 0; i < Y; ++i) {
+            double s = a.P_yx[(i * D + d) * ld + b];
+            for (int k = 0; k < i; ++k) s -= S[i * Y + k] * v[k];
+            v[i] = s / S[i * Y + i];
+        }
+        for (int i = Y - 1; i >= 0; --i) {
+            double s = v[i];
+            for (int k = i + 1; k < Y; ++k) s -= S[k * Y + i] * v[k];
+            v[i] = s / S[i * Y + i];
+        }
+        for (int i = 0; i < Y; ++i) G[d * Y + i] = v[i];
+    }
+    int32_t agg = a.status[b];
+    int32_t bad = ok ? 0 : 1;
+    if (a.st_a) bad |= a.st_a[b];
+    if (a.st_b) bad |= a.st_b[b];
+    if (agg == 0 && bad) agg = a.step + 1;
+    a.status[b] = agg;
+    const double nan = __builtin_nan("");
+    const bool good = (agg == 0);
+    for (int d = 0; d < D; ++d) {
+        double s = 0.0;
+        for (int i = 0; i < Y; ++i) s += G[d * Y + i] * (a.y[i * ld + b] - a.y_mean[i * ld + b]);
+        a.m_fi[d * ld + b] = good ? a.m_pr[d * ld + b] + s : nan;
+    }
+    for (int d = 0; d < D; ++d) {
+        for (int j = 0; j < Y; ++j) {
+            double s = 0.0;
+            for (int i = 0; i < Y; ++i) s += G[d * Y + i] * a.P_y[(i * Y + j) * ld + b];
+            w[j] = s;
+        }
+        for (int d2 = 0; d2 < D; ++d2) {
+            double s = 0.0;
+            for (int j = 0; j < Y; ++j) s += w[j] * G[d2 * Y + j];
+            a.P_fi[(d * D + d2) * ld + b] = good ? a.P_pr[(d * D + d2) * ld + b] - s : nan;
+        }
+    }
+}
+
+template <int D, int Y>
+static void launch_upd(const UpdArgs &a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.B + kUpdBlock - 1) / kUpdBlock);
+    hipLaunchKernelGGL((k_kalman_update<D, Y>), dim3(grid), dim3(kUpdBlock), 0, s, a);
+}
+
+int launch_kalman_update_ex(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
+                            const double *y_mean, const double *P_y, const double *P_yx, const double *y,
+                            double *m_fi, double *P_fi, int32_t *status, const int32_t *st_a, const int32_t *st_b,
+                            int step, hipStream_t s) {
+    UpdArgs a{m_pr, P_pr, y_mean, P_y, P_yx, y, m_fi, P_fi, status, st_a, st_b, B, ld, step, D, Y};
+#define SSMQ_UPD(d, y_)                  \
+    if (D == d && Y == y_) {             \
+        launch_upd<d, y_>(a, s);         \
+        return hip_fail(hipGetLastError(), "k_kalman_update"); \
+    }
+    SSMQ_UPD(1, 1)
+    SSMQ_UPD(2, 1)
+    SSMQ_UPD(2, 2)
+    SSMQ_UPD(3, 1)
+    SSMQ_UPD(4, 2)
+    SSMQ_UPD(5, 2)
+    SSMQ_UPD(5, 4)
+    SSMQ_UPD(6, 2)
+#undef SSMQ_UPD
+    if (D > SSMQ_MAX_DIM || Y > SSMQ_MAX_DIM) {
+        set_error("kalman update: D or Y above SSMQ_MAX_DIM");
+        return SSMQ_E_UNSUPPORTED;
+    }
+    const unsigned grid = (unsigned)((B + kUpdBlock - 1) / kUpdBlock);
+    hipLaunchKernelGGL(k_kalman_update_generic, dim3(grid), dim3(kUpdBlock), 0, s, a);
+    return hip_fail(hipGetLastError(), "k_kalman_update_generic");
+}
+
+int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
+                         const double *y_mean, const double *P_y, const double *P_yx, const double *y, double *m_fi,
+                         double *P_fi, int32_t *status, hipStream_t s) {
+    return launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, y, m_fi, P_fi, status, nullptr, nullptr,
+                                   0, s);
+}
+
+}  // namespace ssmq

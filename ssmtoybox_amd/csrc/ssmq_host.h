@@ -1,0 +1,48 @@
+// Host-side internals of libssmq shared between translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "ssmq_device.h"
+#include "ssmq_wide.h"
+
+struct ssmq_transform {
+    int D, E, N, form, emv_mode, device;
+    double tp_nu;
+    // host copies in the reference's natural layout
+    std::vector<double> xi, wm, Wc, Wcc, emv, iK;
+    // device constant blocks: `small` = transposed layout of ssmq_apply_small.h, `wide` = natural layout
+    double *d_small, *d_wide;
+};
+
+namespace ssmq {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+hipStream_t stream();
+int ensure_device();
+
+#define SSMQ_HIP(call)                                        \
+    do {                                                      \
+        hipError_t e__ = (call);                              \
+        if (e__ != hipSuccess) return ssmq::hip_fail(e__, #call); \
+    } while (0)
+
+void fill_fpar(const ssmq_integrand *f, FPar *fp);
+
+// dispatch table of the register-resident kernels (ssmq_apply_small_*.hip)
+typedef hipError_t (*small_launch_fn)(const ApplyArgs &, hipStream_t);
+struct SmallEntry {
+    int fid, D, E, N, form, tp, sel;
+    small_launch_fn fn;
+    const char *name;
+};
+const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int sel);
+void register_small(const SmallEntry *entries, int n);
+
+// fused filter kernels (ssmq_filter.hip)
+int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
+                         const double *y_mean, const double *P_y, const double *P_yx, const double *y, double *m_fi,
+                         double *P_fi, int32_t *status, hipStream_t s);
+
+}  // namespace ssmq

@@ -1,0 +1,13 @@
+// Instantiation helper for the register-resident moment-transform kernels: each (integrand, D, E, N, SEL) shape gets
+// the BQ form, the BQ form with the Student-t process model variance, and the classical centred form.
+#pragma once
+#include "ssmq_apply_small.h"
+#include "ssmq_host.h"
+
+#define SSMQ_SMALL_ONE(F, D, E, N, FORM, TP, SEL)                                                    \
+    {F, D, E, N, FORM, TP, SEL, &ssmq::launch_apply_small<D, E, N, F, FORM, TP, SEL>,                 \
+     "k_apply_small<D=" #D ",E=" #E ",N=" #N "," #F "," #FORM ",TP=" #TP ",SEL=" #SEL ">"}
+#define SSMQ_SMALL(F, D, E, N, SEL)                       \
+    SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_BQ, 0, SEL),     \
+    SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_BQ, 1, SEL),     \
+    SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_SIGMA, 0, SEL)

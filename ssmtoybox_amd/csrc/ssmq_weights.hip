@@ -1,0 +1,603 @@
+// Quadrature weights on the device, batched over kernel-parameter rows (theta): one 256-thread workgroup per theta.
+//
+//   RBF kernel matrix over the unit sigma points        bq/bqkern.py:329-343 + utils.maha utils.py:385-409
+//   (K + jitter I)^-1 by a right-looking Cholesky and two triangular solves against I, then symmetrised
+//                                                        bq/bqkern.py:38-64, 96-120
+//   Gaussian expectations q, R, Q, kbar                  bq/bqkern.py:345-424
+//   GP weights  wm = q iK, Wc = iK Q iK, Wcc = R iK      bq/bqmod.py:495-523
+//   Bayes-Sard weights (unisolvent + general branch)     bq/bqmod.py:893-992, polynomial moments :635-797
+//
+// For N <= 64 the kernel matrix, its factor and the inverse are LDS-resident (2 N^2 doubles <= 64 KiB); larger point
+// sets (fully-symmetric degree 5 at D = 10: N = 201) factor in an L2-resident workspace with the same code.
+// The algebra follows the reference step by step (explicit inverse, symmetrisation, jitter placement) because the
+// results are only reproducible to cond(K) eps, not because it is the best-conditioned route.
+#include <cstring>
+#include <vector>
+#include "ssmq_host.h"
+
+namespace ssmq {
+
+constexpr int kWgtBlock = 256;
+
+struct WgtArgs {
+    int32_t D, N, P, NB, bs, use_lds;
+    double jitter;
+    const double *xi;       // [D][N]
+    const double *par;      // [P][1+D]
+    const int32_t *mulind;  // [D][NB]
+    const double *px, *xpx, *pxpx;  // [NB], [D][NB], [NB][NB]
+    double *wm, *Wc, *Wcc, *iK, *q, *Q, *R, *mv, *iv;
+    int32_t *status;
+    double *work;           // per-theta workspace
+    int64_t work_stride;    // doubles
+};
+
+__device__ __forceinline__ void bsync() { __syncthreads(); }
+
+// C (M x N, ldc) = op(A) op(B); op(A) is M x K, op(B) is K x N.  Block-cooperative; ends with a barrier.
+__device__ void gemm(double *C, int ldc, const double *A, int lda, bool ta, const double *B, int ldb, bool tb, int M,
+                     int N, int K) {
+    for (int idx = threadIdx.x; idx < M * N; idx += kWgtBlock) {
+        const int i = idx / N, j = idx % N;
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double a = ta ? A[k * lda + i] : A[i * lda + k];
+            const double b = tb ? B[j * ldb + k] : B[k * ldb + j];
+            s += a * b;
+        }
+        C[i * ldc + j] = s;
+    }
+    bsync();
+}
+
+// In-place right-looking Cholesky (lower) of the n x n matrix A; the strict upper triangle is left untouched.
+// Returns false (to every thread) at the first non-positive pivot.
+__device__ bool chol_block(double *A, int n, int *flag) {
+    if (threadIdx.x == 0) *flag = 1;
+    bsync();
+    for (int k = 0; k < n; ++k) {
+        if (threadIdx.x == 0) {
+            const double p = A[k * n + k];
+            if (!(p > 0.0)) *flag = 0;
+            A[k * n + k] = sqrt(p);
+        }
+        bsync();
+        if (*flag == 0) return false;
+        const double r = 1.0 / A[k * n + k];
+        for (int i = k + 1 + threadIdx.x; i < n; i += kWgtBlock) A[i * n + k] *= r;
+        bsync();
+        const int m = n - k - 1;
+        for (int idx = threadIdx.x; idx < m * m; idx += kWgtBlock) {
+            const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+            if (j <= i) A[i * n + j] -= A[i * n + k] * A[j * n + k];
+        }
+        bsync();
+    }
+    return true;
+}
+
+// X = (L L')^-1 for the lower factor L (n x n): each thread owns columns of X; forward then backward substitution.
+__device__ void chol_inverse(const double *L, double *X, int n) {
+    for (int c = threadIdx.x; c < n; c += kWgtBlock) {
+        for (int i = 0; i < n; ++i) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) s -= L[i * n + k] * X[k * n + c];   // X[k][c] = 0 for k < c
+            X[i * n + c] = (i < c) ? 0.0 : s / L[i * n + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = X[i * n + c];
+            for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * X[k * n + c];
+            X[i * n + c] = s / L[i * n + i];
+        }
+    }
+    bsync();
+}
+
+// X = A^-1 for a general n x n matrix by LU with partial pivoting (numpy.linalg.solve(V, I), bq/bqmod.py:954).
+// A is destroyed.  Single-thread pivot search, block-parallel elimination; n is small (<= N).
+__device__ bool lu_inverse(double *A, double *X, int n, int *piv, int *flag) {
+    for (int idx = threadIdx.x; idx < n * n; idx += kWgtBlock) X[idx] = (idx / n == idx % n) ? 1.0 : 0.0;
+    if (threadIdx.x == 0) *flag = 1;
+    bsync();
+    for (int k = 0; k < n; ++k) {
+        if (threadIdx.x == 0) {
+            int p = k;
+            double best = fabs(A[k * n + k]);
+            for (int i = k + 1; i < n; ++i)
+                if (fabs(A[i * n + k]) > best) { best = fabs(A[i * n + k]); p = i; }
+            *piv = p;
+            if (best == 0.0) *flag = 0;
+        }
+        bsync();
+        if (*flag == 0) return false;
+        const int p = *piv;
+        if (p != k) {
+            for (int j = threadIdx.x; j < n; j += kWgtBlock) {
+                double t = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = t;
+                t = X[k * n + j]; X[k * n + j] = X[p * n + j]; X[p * n + j] = t;
+            }
+        }
+        bsync();
+        const double r = 1.0 / A[k * n + k];
+        for (int i = k + 1 + threadIdx.x; i < n; i += kWgtBlock) A[i * n + k] *= r;
+        bsync();
+        const int m = n - k - 1;
+        for (int idx = threadIdx.x; idx < m * n; idx += kWgtBlock) {
+            const int i = k + 1 + idx / n, j = idx % n;
+            const double l = A[i * n + k];
+            if (j > k) A[i * n + j] -= l * A[k * n + j];
+            X[i * n + j] -= l * X[k * n + j];
+        }
+        bsync();
+    }
+    // back substitution U X = Y, thread per column
+    for (int c = threadIdx.x; c < n; c += kWgtBlock) {
+        for (int i = n - 1; i >= 0; --i) {
+            double s = X[i * n + c];
+            for (int k = i + 1; k < n; ++k) s -= A[i * n + k] * X[k * n + c];
+            X[i * n + c] = s / A[i * n + i];
+        }
+    }
+    bsync();
+    return true;
+}
+
+__device__ double block_sum(double v, double *red) {
+    // 256 threads -> one value (to every thread)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    bsync();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    bsync();
+    const double s = red[0] + red[1] + red[2] + red[3];
+    bsync();
+    return s;
+}
+
+__device__ double ipow(double x, int k) {
+    double r = 1.0;
+    for (int i = 0; i < k; ++i) r *= x;
+    return r;
+}
+
+__global__ __launch_bounds__(kWgtBlock) void k_weights(const WgtArgs a) {
+    extern __shared__ __align__(16) double lds[];
+    __shared__ double s_sil[SSMQ_MAX_DIM], s_red[4];
+    __shared__ int s_flag, s_piv;
+    const int D = a.D, N = a.N, NB = a.NB, p = blockIdx.x, tid = threadIdx.x;
+    const double *par = a.par + (int64_t)p * (1 + D);
+    const double alpha = par[0];
+    double *w = a.work + (int64_t)p * a.work_stride;
+    // workspace carve-up (global); A and X move to LDS when they fit
+    double *gA = w; w += N * N;
+    double *gX = w; w += N * N;
+    double *M1 = w; w += N * N;
+    double *M2 = w; w += N * N;
+    double *zs = w; w += D * N;       // length-scale-normalised points
+    double *nrm = w; w += N;
+    double *A = a.use_lds ? lds : gA;
+    double *X = a.use_lds ? lds + N * N : gX;
+    double *oq = a.q + (int64_t)p * N, *oQ = a.Q + (int64_t)p * N * N, *oR = a.R + (int64_t)p * D * N;
+    double *oiK = a.iK + (int64_t)p * N * N, *owm = a.wm + (int64_t)p * N, *oWc = a.Wc + (int64_t)p * N * N;
+    double *oWcc = a.Wcc + (int64_t)p * D * N;
+
+    if (tid < D) s_sil[tid] = 1.0 / par[1 + tid];   // par[1:] ** -1   (bq/bqkern.py:454)
+    bsync();
+    // ---- kernel matrix, scaling=False (alpha = 1): exp(2 log(1) - maha / 2) ------------------------------------
+    for (int idx = tid; idx < D * N; idx += kWgtBlock) zs[idx] = s_sil[idx / N] * a.xi[idx];
+    bsync();
+    for (int n = tid; n < N; n += kWgtBlock) {
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) s += zs[d * N + n] * zs[d * N + n];
+        nrm[n] = s;
+    }
+    bsync();
+    for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+        const int i = idx / N, j = idx % N;
+        double dot = 0.0;
+        for (int d = 0; d < D; ++d) dot += zs[d * N + i] * zs[d * N + j];
+        const double mh = (nrm[i] + nrm[j]) - 2.0 * dot;
+        A[idx] = exp(0.0 - 0.5 * mh) + (i == j ? a.jitter : 0.0);
+    }
+    bsync();
+    // ---- (K + jitter I)^-1 ----------------------------------------------------------------------------------------
+    const bool pd = chol_block(A, N, &s_flag);
+    if (tid == 0) a.status[p] = pd ? 0 : 1;
+    if (!pd) {
+        const double nan = __builtin_nan("");
+        for (int idx = tid; idx < N * N; idx += kWgtBlock) { oiK[idx] = nan; oWc[idx] = nan; oQ[idx] = nan; }
+        for (int idx = tid; idx < D * N; idx += kWgtBlock) { oWcc[idx] = nan; oR[idx] = nan; }
+        for (int n = tid; n < N; n += kWgtBlock) { owm[n] = nan; oq[n] = nan; }
+        if (tid == 0) { a.mv[p] = nan; a.iv[p] = nan; }
+        return;
+    }
+    chol_inverse(A, X, N);
+    for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+        const int i = idx / N, j = idx % N;
+        oiK[idx] = 0.5 * (X[i * N + j] + X[j * N + i]);
+    }
+    bsync();
+    const double *iK = oiK;
+    // ---- Gaussian expectations of the kernel ------------------------------------------------------------------------
+    double cq = 1.0, cQ = 1.0, ck = 1.0;
+    for (int d = 0; d < D; ++d) {
+        const double il = s_sil[d] * s_sil[d];
+        cq *= il + 1.0;
+        cQ *= il + il + 1.0;
+        ck *= 2.0 * il + 1.0;
+    }
+    cq = 1.0 / sqrt(cq);   // det(Lam^-1 + I) ** -0.5
+    cQ = 1.0 / sqrt(cQ);   // det(2 Lam^-1 + I) ** -0.5
+    const double kbar = alpha * alpha * (1.0 / sqrt(ck));
+    for (int n = tid; n < N; n += kWgtBlock) {
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double il = s_sil[d] * s_sil[d];
+            const double lam = 1.0 / il;
+            const double x = a.xi[d * N + n];
+            s += x * ((1.0 / (lam + 1.0)) * x);
+        }
+        oq[n] = cq * exp(-0.5 * s);
+    }
+    bsync();
+    for (int idx = tid; idx < D * N; idx += kWgtBlock) {
+        const int d = idx / N, n = idx % N;
+        const double sl = s_sil[d];
+        const double lam = 1.0 / (sl * sl);
+        oR[idx] = oq[n] * ((1.0 / (lam + 1.0)) * a.xi[idx]);
+    }
+    const bool general = (NB == 0) || (NB < N);
+    if (general) {
+        for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+            const int i = idx / N, j = idx % N;
+            // xi_i + xi_j + maha(Lam^-1 x_i, -Lam^-1 x_j; (2 Lam^-1 + I)^-1) / 2
+            double m2i = 0.0, m2j = 0.0, mij = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double il = s_sil[d] * s_sil[d];
+                const double v = 1.0 / (il + il + 1.0);
+                const double yi = il * a.xi[d * N + i], yj = -(il * a.xi[d * N + j]);
+                m2i += (yi * v) * yi;
+                m2j += (yj * v) * yj;
+                mij += (yi * v) * yj;
+            }
+            const double mh = (m2i + m2j) - 2.0 * mij;
+            const double e = ((0.0 - 0.5 * nrm[i]) + (0.0 - 0.5 * nrm[j])) + 0.5 * mh;
+            oQ[idx] = cQ * exp(e);
+        }
+    }
+    bsync();
+
+    if (NB == 0) {
+        // ---- GP weights (bq/bqmod.py:495-523) -------------------------------------------------------------------------
+        gemm(owm, N, oq, N, false, iK, N, false, 1, N, N);          // wm = q iK
+        gemm(M1, N, oQ, N, false, iK, N, false, N, N, N);           // M1 = Q iK
+        gemm(M2, N, iK, N, false, M1, N, false, N, N, N);           // M2 = iK Q iK
+        gemm(oWcc, N, oR, N, false, iK, N, false, D, N, N);         // Wcc = R iK
+        for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+            const int i = idx / N, j = idx % N;
+            oWc[idx] = 0.5 * (M2[i * N + j] + M2[j * N + i]);
+        }
+        double tr = 0.0, qq = 0.0;
+        for (int n = tid; n < N; n += kWgtBlock) { tr += M1[n * N + n]; qq += owm[n] * oq[n]; }
+        tr = block_sum(tr, s_red);
+        qq = block_sum(qq, s_red);
+        if (tid == 0) {
+            a.mv[p] = (alpha * alpha) * (1.0 - tr);
+            a.iv[p] = kbar - qq;
+        }
+        return;
+    }
+
+    // ---- Bayes-Sard weights (bq/bqmod.py:893-992) -----------------------------------------------------------------------
+    double *V = w; w += N * NB;       // Vandermonde (N x NB)
+    double *Z = w; w += NB * N;       // V' iK
+    double *G = w; w += NB * NB;      // V' iK V + 1e-8 I  -> Cholesky factor
+    double *iG = w; w += NB * NB;     // its inverse ("iViKV")
+    double *kx = w; w += N * NB;      // E[k(x, x_n) p_q(x)]
+    double *T1 = w; w += N * N;
+    double *T2 = w; w += N * N;
+    double *bv = w; w += NB;
+    for (int idx = tid; idx < N * NB; idx += kWgtBlock) {
+        const int n = idx / NB, qb = idx % NB;
+        double v = 1.0, kprod = 1.0;
+        for (int d = 0; d < D; ++d) {
+            const int al = a.mulind[d * NB + qb];
+            const double x = a.xi[d * N + n];
+            v *= ipow(x, al);
+            // closed form of bq/bqmod.py:733-797; its `ell` is sqrt_inv_lam ** -2 = ell^2, reproduced as written there
+            const double sl = s_sil[d];
+            const double el = 1.0 / (sl * sl);
+            const double e1 = 1.0 + el * el;
+            const double ea = el * pow(e1, -(1.0 + al) / 2.0) * exp(-(x * x) / (2.0 * e1));
+            double eb = 0.0;
+            const double xs = x / sqrt(e1);
+            for (int m = 0; m <= al / 2; ++m) {
+                // al! / (2^m m! (al - 2m)!)
+                double num = 1.0, den = 1.0;
+                for (int t = 2; t <= al; ++t) num *= t;
+                for (int t = 0; t < m; ++t) den *= 2.0;
+                for (int t = 2; t <= m; ++t) den *= t;
+                for (int t = 2; t <= al - 2 * m; ++t) den *= t;
+                eb += (num / den) * (ipow(el, 2 * m) * ipow(xs, al - 2 * m));
+            }
+            kprod *= ea * eb;
+        }
+        V[idx] = v;
+        kx[idx] = kprod;
+    }
+    bsync();
+    gemm(Z, N, V, NB, true, iK, N, false, NB, N, N);        // Z = V' iK
+    gemm(G, NB, Z, N, false, V, NB, false, NB, NB, N);      // G = Z V
+    for (int i = tid; i < NB; i += kWgtBlock) G[i * NB + i] += 1e-8;
+    bsync();
+    const bool pd2 = chol_block(G, NB, &s_flag);
+    if (!pd2) {
+        if (tid == 0) a.status[p] = 2;
+        return;
+    }
+    chol_inverse(G, iG, NB);                                 // cho_solve(cho_factor(.), I): not symmetrised
+    const double ks2 = alpha * alpha;
+    if (NB == N) {
+        // pi-unisolvent points: weights from the inverse Vandermonde matrix only (:952-961)
+        double *Vc = T1, *iV = T2;
+        for (int idx = tid; idx < N * N; idx += kWgtBlock) Vc[idx] = V[idx];
+        bsync();
+        if (!lu_inverse(Vc, iV, N, &s_piv, &s_flag)) {
+            if (tid == 0) a.status[p] = 3;
+            return;
+        }
+        gemm(owm, N, a.px, NB, false, iV, N, false, 1, N, NB);              // wm = iV' px  == px' iV
+        gemm(M1, N, a.pxpx, NB, false, iV, N, false, NB, N, NB);            // pxpx iV
+        gemm(M2, N, iV, N, true, M1, N, false, N, N, NB);                   // iV' pxpx iV
+        gemm(oWcc, N, a.xpx, NB, false, iV, N, false, D, N, NB);            // xpx iV
+        for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+            const int i = idx / N, j = idx % N;
+            oWc[idx] = 0.5 * (M2[i * N + j] + M2[j * N + i]);
+        }
+        // model_var = ks2 (1 - tr(kxpx' iV' + kxpx iV - pxpx iViKV));  tr(kxpx' iV') = tr(iV kxpx) = tr(kxpx iV)
+        gemm(M1, N, kx, NB, false, iV, N, false, N, N, NB);                 // kxpx iV   (N x N)
+        gemm(M2, NB, a.pxpx, NB, false, iG, NB, false, NB, NB, NB);         // pxpx iViKV
+        double tr = 0.0;
+        for (int n = tid; n < N; n += kWgtBlock) tr += 2.0 * M1[n * N + n] - M2[n * NB + n];
+        tr = block_sum(tr, s_red);
+        // integral_var = kbar - q' iV' px - px' iV q + px' iViKV px
+        double t1 = 0.0, t3 = 0.0;
+        for (int n = tid; n < N; n += kWgtBlock) {
+            t1 += owm[n] * oq[n];                                           // (px' iV) q
+            double s = 0.0;
+            for (int k = 0; k < NB; ++k) s += iG[n * NB + k] * a.px[k];
+            t3 += a.px[n] * s;
+        }
+        t1 = block_sum(t1, s_red);
+        t3 = block_sum(t3, s_red);
+        if (tid == 0) {
+            a.mv[p] = ks2 * (1.0 - tr);
+            a.iv[p] = kbar - t1 - t1 + t3;
+        }
+        return;
+    }
+    // general case NB < N (:963-982)
+    double *Am = T1;                     // A = V iViKV          (N x NB)
+    double *Bm = T2;                     // B                    (NB x NB)
+    double *Dm = w; w += D * NB;         // D = R Z' - xpx       (D x NB)
+    double *T3 = w; w += N * N;
+    double *T4 = w; w += N * N;
+    gemm(Am, NB, V, NB, false, iG, NB, false, N, NB, NB);
+    // b = Z q - px
+    for (int i = tid; i < NB; i += kWgtBlock) {
+        double s = 0.0;
+        for (int n = 0; n < N; ++n) s += Z[i * N + n] * oq[n];
+        bv[i] = s - a.px[i];
+    }
+    bsync();
+    // B = Z Q Z' + pxpx - Z kxpx - kxpx' Z'
+    gemm(T3, N, Z, N, false, oQ, N, false, NB, N, N);                       // Z Q         (NB x N)
+    gemm(T4, NB, T3, N, false, Z, N, true, NB, NB, N);                      // Z Q Z'      (NB x NB)
+    gemm(T3, NB, Z, N, false, kx, NB, false, NB, NB, N);                    // Z kxpx      (NB x NB)
+    for (int idx = tid; idx < NB * NB; idx += kWgtBlock) {
+        const int i = idx / NB, j = idx % NB;
+        Bm[idx] = ((T4[idx] + a.pxpx[idx]) - T3[i * NB + j]) - T3[j * NB + i];
+    }
+    bsync();
+    // D = R Z' - xpx
+    gemm(Dm, NB, oR, N, false, Z, N, true, D, NB, N);
+    for (int idx = tid; idx < D * NB; idx += kWgtBlock) Dm[idx] -= a.xpx[idx];
+    bsync();
+    // wm = iK (q - A b)
+    for (int n = tid; n < N; n += kWgtBlock) {
+        double s = 0.0;
+        for (int k = 0; k < NB; ++k) s += Am[n * NB + k] * bv[k];
+        nrm[n] = oq[n] - s;
+    }
+    bsync();
+    gemm(owm, 1, iK, N, false, nrm, 1, false, N, 1, N);
+    // Wc = iK (Q - A B A') iK
+    gemm(T3, NB, Am, NB, false, Bm, NB, false, N, NB, NB);                  // A B         (N x NB)
+    gemm(T4, N, T3, NB, false, Am, NB, true, N, N, NB);                     // A B A'      (N x N)
+    for (int idx = tid; idx < N * N; idx += kWgtBlock) T4[idx] = oQ[idx] - T4[idx];
+    bsync();
+    gemm(M1, N, T4, N, false, iK, N, false, N, N, N);
+    gemm(M2, N, iK, N, false, M1, N, false, N, N, N);
+    for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+        const int i = idx / N, j = idx % N;
+        oWc[idx] = 0.5 * (M2[i * N + j] + M2[j * N + i]);
+    }
+    // Wcc = (R - D A') iK
+    gemm(T3, N, Dm, NB, false, Am, NB, true, D, N, NB);                     // D A'        (D x N)
+    for (int idx = tid; idx < D * N; idx += kWgtBlock) T3[idx] = oR[idx] - T3[idx];
+    bsync();
+    gemm(oWcc, N, T3, N, false, iK, N, false, D, N, N);
+    // model_var = ks2 (1 - tr(Q iK) + tr(B iViKV)); integral_var = kbar - q' iK q + b' iViKV b
+    gemm(M1, N, oQ, N, false, iK, N, false, N, N, N);
+    gemm(T3, NB, Bm, NB, false, iG, NB, false, NB, NB, NB);
+    double tr1 = 0.0, tr2 = 0.0, qq = 0.0, bb = 0.0;
+    for (int n = tid; n < N; n += kWgtBlock) {
+        tr1 += M1[n * N + n];
+        double s = 0.0;
+        for (int k = 0; k < N; ++k) s += iK[n * N + k] * oq[k];
+        qq += oq[n] * s;
+    }
+    for (int i = tid; i < NB; i += kWgtBlock) {
+        tr2 += T3[i * NB + i];
+        double s = 0.0;
+        for (int k = 0; k < NB; ++k) s += iG[i * NB + k] * bv[k];
+        bb += bv[i] * s;
+    }
+    tr1 = block_sum(tr1, s_red);
+    tr2 = block_sum(tr2, s_red);
+    qq = block_sum(qq, s_red);
+    bb = block_sum(bb, s_red);
+    if (tid == 0) {
+        a.mv[p] = ks2 * (1.0 - tr1 + tr2);
+        a.iv[p] = kbar - qq + bb;
+    }
+}
+
+// ---- host side: polynomial moments under N(0, I) (integer tables; bq/bqmod.py:635-731) -----------------------------
+static double dfact(int n) {  // (-1)!! = 0!! = 1  
+    double r = 1.0;
+    for (; n > 1; n -= 2) r *= n;
+    return r;
+}
+
+static void poly_moments(int D, int NB, const int32_t *mi, std::vector<double> &px, std::vector<double> &xpx,
+                         std::vector<double> &pxpx) {
+    px.assign(NB, 0.0);
+    xpx.assign((size_t)D * NB, 0.0);
+    pxpx.assign((size_t)NB * NB, 0.0);
+    for (int q = 0; q < NB; ++q) {
+        bool even = true;
+        for (int d = 0; d < D; ++d) even = even && (mi[d * NB + q] % 2 == 0);
+        if (even) {
+            double v = 1.0;
+            for (int d = 0; d < D; ++d) v *= dfact(mi[d * NB + q] - 1);
+            px[q] = v;
+        }
+        for (int e = 0; e < D; ++e) {
+            bool rest_even = true;
+            for (int d = 0; d < D; ++d)
+                if (d != e) rest_even = rest_even && (mi[d * NB + q] % 2 == 0);
+            if ((mi[e * NB + q] + 1) % 2 == 0 && rest_even) {
+                double v = mi[e * NB + q];
+                for (int d = 0; d < D; ++d)
+                    if (d != e) v *= dfact(mi[d * NB + q] - 1);
+                xpx[(size_t)e * NB + q] = v;
+            }
+        }
+        for (int r = 0; r < NB; ++r) {
+            bool ev = true;
+            for (int d = 0; d < D; ++d) ev = ev && ((mi[d * NB + r] + mi[d * NB + q]) % 2 == 0);
+            if (ev) {
+                double v = 1.0;
+                for (int d = 0; d < D; ++d) v *= dfact(mi[d * NB + r] + mi[d * NB + q] - 1);
+                pxpx[(size_t)r * NB + q] = v;
+            }
+        }
+    }
+}
+
+namespace {
+struct DBuf {
+    void *p = nullptr;
+    ~DBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hip_fail(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc"); }
+    double *d() { return (double *)p; }
+};
+}  // namespace
+
+static int weights_impl(int D, int N, const double *xi, const double *par, int P, double jitter, const int32_t *mulind,
+                        int NB, double *wm, double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R,
+                        double *model_var, double *integral_var, int32_t *status) {
+    if (D < 1 || D > SSMQ_MAX_DIM || N < 1 || N > SSMQ_MAX_PTS || P < 1 || !xi || !par || NB < 0 || NB > N ||
+        (NB > 0 && !mulind)) {
+        set_error("weights: bad argument");
+        return SSMQ_E_ARG;
+    }
+    if (NB > 0)
+        for (int i = 0; i < D * NB; ++i)
+            if (mulind[i] < 0 || mulind[i] > 20) {
+                set_error("weights: multi-index entries must be in 0..20");
+                return SSMQ_E_ARG;
+            }
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = stream();
+    const size_t nn = (size_t)N * N;
+    const int64_t work_stride = (int64_t)(10 * nn + 4 * (size_t)N * std::max(NB, 1) + 2 * (size_t)std::max(NB, 1) * NB +
+                                          (size_t)D * (N + NB) + 2 * N + NB + 64);
+    DBuf dxi, dpar, dmi, dpx, dxpx, dpxpx, dwm, dWc, dWcc, diK, dq, dQ, dR, dmv, div, dst, dwork;
+    if ((rc = dxi.alloc(sizeof(double) * D * N)) || (rc = dpar.alloc(sizeof(double) * P * (1 + D))) ||
+        (rc = dmi.alloc(sizeof(int32_t) * D * std::max(NB, 1))) || (rc = dpx.alloc(sizeof(double) * std::max(NB, 1))) ||
+        (rc = dxpx.alloc(sizeof(double) * D * std::max(NB, 1))) ||
+        (rc = dpxpx.alloc(sizeof(double) * std::max(NB, 1) * std::max(NB, 1))) ||
+        (rc = dwm.alloc(sizeof(double) * P * N)) || (rc = dWc.alloc(sizeof(double) * P * nn)) ||
+        (rc = dWcc.alloc(sizeof(double) * P * D * N)) || (rc = diK.alloc(sizeof(double) * P * nn)) ||
+        (rc = dq.alloc(sizeof(double) * P * N)) || (rc = dQ.alloc(sizeof(double) * P * nn)) ||
+        (rc = dR.alloc(sizeof(double) * P * D * N)) || (rc = dmv.alloc(sizeof(double) * P)) ||
+        (rc = div.alloc(sizeof(double) * P)) || (rc = dst.alloc(sizeof(int32_t) * P)) ||
+        (rc = dwork.alloc(sizeof(double) * (size_t)P * work_stride)))
+        return rc;
+    SSMQ_HIP(hipMemcpyAsync(dxi.p, xi, sizeof(double) * D * N, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dpar.p, par, sizeof(double) * P * (1 + D), hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemsetAsync(dQ.p, 0, sizeof(double) * P * nn, s));
+    std::vector<double> px, xpx, pxpx;
+    if (NB > 0) {
+        poly_moments(D, NB, mulind, px, xpx, pxpx);
+        SSMQ_HIP(hipMemcpyAsync(dmi.p, mulind, sizeof(int32_t) * D * NB, hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(dpx.p, px.data(), sizeof(double) * NB, hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(dxpx.p, xpx.data(), sizeof(double) * D * NB, hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(dpxpx.p, pxpx.data(), sizeof(double) * NB * NB, hipMemcpyHostToDevice, s));
+    }
+    WgtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.D = D; a.N = N; a.P = P; a.NB = NB; a.jitter = jitter; a.use_lds = (N <= 64) ? 1 : 0;
+    a.xi = dxi.d(); a.par = dpar.d(); a.mulind = (const int32_t *)dmi.p; a.px = dpx.d(); a.xpx = dxpx.d();
+    a.pxpx = dpxpx.d(); a.wm = dwm.d(); a.Wc = dWc.d(); a.Wcc = dWcc.d(); a.iK = diK.d(); a.q = dq.d(); a.Q = dQ.d();
+    a.R = dR.d(); a.mv = dmv.d(); a.iv = div.d(); a.status = (int32_t *)dst.p; a.work = dwork.d();
+    a.work_stride = work_stride;
+    const size_t lds = a.use_lds ? sizeof(double) * 2 * nn : 0;
+    hipLaunchKernelGGL(k_weights, dim3(P), dim3(kWgtBlock), lds, s, a);
+    if ((rc = hip_fail(hipGetLastError(), "k_weights"))) return rc;
+#define SSMQ_D2H(host, dev, count) \
+    if (host) SSMQ_HIP(hipMemcpyAsync(host, dev.p, sizeof(*host) * (count), hipMemcpyDeviceToHost, s));
+    SSMQ_D2H(wm, dwm, (size_t)P * N)
+    SSMQ_D2H(Wc, dWc, (size_t)P * nn)
+    SSMQ_D2H(Wcc, dWcc, (size_t)P * D * N)
+    SSMQ_D2H(iK, diK, (size_t)P * nn)
+    SSMQ_D2H(q, dq, (size_t)P * N)
+    SSMQ_D2H(Q, dQ, (size_t)P * nn)
+    SSMQ_D2H(R, dR, (size_t)P * D * N)
+    SSMQ_D2H(model_var, dmv, (size_t)P)
+    SSMQ_D2H(integral_var, div, (size_t)P)
+#undef SSMQ_D2H
+    std::vector<int32_t> st(P);
+    SSMQ_HIP(hipMemcpyAsync(st.data(), dst.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    int first = 0;
+    for (int i = 0; i < P; ++i) {
+        if (status) status[i] = st[i];
+        if (st[i] && !first) first = i + 1;
+    }
+    return first;
+}
+
+}  // namespace ssmq
+
+extern "C" int ssmq_weights_gp(int D, int N, const double *xi, const double *par, int P, double jitter, double *wm,
+                               double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R, double *model_var,
+                               double *integral_var, int32_t *status) {
+    return ssmq::weights_impl(D, N, xi, par, P, jitter, nullptr, 0, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var,
+                              status);
+}
+
+extern "C" int ssmq_weights_bs(int D, int N, const double *xi, const double *par, int P, double jitter,
+                               const int32_t *mulind, int NB, double *wm, double *Wc, double *Wcc, double *iK,
+                               double *q, double *Q, double *R, double *model_var, double *integral_var,
+                               int32_t *status) {
+    if (NB < 1) {
+        ssmq::set_error("weights_bs: NB must be >= 1");
+        return SSMQ_E_ARG;
+    }
+    return ssmq::weights_impl(D, N, xi, par, P, jitter, mulind, NB, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var,
+                              status);
+}

@@ -1,0 +1,52 @@
+// Argument block and constant layout of the generic (run-time shape) moment-transform kernel.
+#pragma once
+#include "ssmq_device.h"
+
+namespace ssmq {
+
+constexpr int kWideBlock = 64;
+
+enum WideMode {
+    SSMQ_WIDE_FULL = 0,    // chol + sigma points + built-in integrand + moments
+    SSMQ_WIDE_POINTS = 1,  // chol + sigma points, written out for a host-evaluated integrand
+    SSMQ_WIDE_FX = 2       // moments from caller-supplied integrand values
+};
+
+// Second constant block of a transform, natural (row-major, untransposed) layout.
+struct WideLayout {
+    int32_t xiT, wm, Wc, Wcc, emv, iK, total;
+};
+__host__ __device__ constexpr inline WideLayout wide_layout(int D, int E, int N, int form) {
+    WideLayout c{};
+    c.xiT = 0;                                              // [N][D]
+    c.wm = c.xiT + D * N;                                   // [N]
+    c.Wc = c.wm + N;                                        // [N][N] row-major, or [N] diagonal (SIGMA)
+    c.Wcc = c.Wc + (form == SSMQ_FORM_SIGMA ? N : N * N);   // [D][N]
+    c.emv = c.Wcc + D * N;                                  // [E][E]
+    c.iK = c.emv + E * E;                                   // [N][N] row-major
+    c.total = c.iK + N * N;
+    return c;
+}
+
+struct WideArgs {
+    int32_t D, E, N, form, mode, fid, time_stride, emv_mode;
+    double tp_nu;
+    const double *consts;   // WideLayout block
+    const double *cov_add;  // [E*E] or null
+    // inputs: element e of trajectory b at ptr[e * es_in + b * bs_*]
+    const double *mean, *cov, *time;
+    int64_t es_in, bs_mean, bs_cov;
+    // outputs
+    double *mean_f, *cov_f, *cov_fx;
+    int64_t es_out, bs_mf, bs_cf, bs_cfx;
+    int32_t *status;
+    // split entry points (reference layout, trajectory-major)
+    double *x_out, *chol_out;
+    const double *chol_in, *fx_in, *x_in;
+    FPar fp;
+};
+
+size_t wide_lds_bytes(int D, int E, int N);
+hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s);
+
+}  // namespace ssmq

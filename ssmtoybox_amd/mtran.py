@@ -1,0 +1,347 @@
+"""
+Moment transforms: the API surface of the reference's `ssmtoybox/mtran.py`, computed on an MI355X.
+
+`MomentTransform.apply(f, mean, cov, fcn_pars, tf_pars=None) -> (mean_f, cov_f, cov_fx)` is kept exactly
+(mtran.py:11-46) so filters written against the reference drop in; `apply_batch` is what this build adds: many
+independent trajectories per kernel launch.
+
+Point-set generators and classical weights are tiny init-time host computations (mtran.py:171-204, 234-293, 315-360,
+405-578); everything per-trajectory - Cholesky factor, sigma points, integrand, weighted reductions - runs in HIP
+kernels behind the C ABI (include/ssmq.h).  There is no NumPy fallback for that part.
+"""
+import ctypes
+import math
+from abc import ABCMeta, abstractmethod
+
+import numpy as np
+from numpy.polynomial.hermite_e import hermegauss, hermeval
+
+from . import _lib
+from ._lib import Integrand, FORM_BQ, FORM_SIGMA, EMV_DIAG, EMV_BROADCAST
+
+
+class MomentTransform(metaclass=ABCMeta):
+    """Base class of all moment transforms (mtran.py:11-46)."""
+
+    @abstractmethod
+    def apply(self, f, mean, cov, fcn_pars, tf_pars=None):
+        """Transform a random variable with given mean and covariance through `f`.
+
+        Returns (mean_f, cov_f, cov_fx): fresh, writable, unaliased ndarrays of shapes (E,), (E, E), (E, D)."""
+
+
+def resolve_integrand(f):
+    """If `f` is the bound `dyn_eval` / `meas_eval` of one of this package's models, return (Integrand, dim_out); the
+    integrand then runs on the device.  Otherwise None: `f` is evaluated by the caller on device-made sigma points."""
+    owner = getattr(f, '__self__', None)
+    name = getattr(f, '__name__', '')
+    if owner is not None and name in ('dyn_eval', 'meas_eval') and hasattr(owner, 'device_integrand'):
+        return owner.device_integrand()
+    return None
+
+
+class DeviceTransform:
+    """Owner of one `ssmq_transform` handle; re-uploads the constants when the Python-side attributes were replaced
+    (the reference's research code assigns tf.wm / tf.Wc / tf.Wcc / model.model_var after construction)."""
+
+    def __init__(self):
+        self._handle = None
+        self._key = None
+        self._snap = None
+
+    def get(self, D, E, N, form, xi, wm, Wc, Wcc, emv, emv_mode, tp_nu, iK):
+        lib = _lib.load()
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (xi, wm, Wc, Wcc, emv, iK)]
+        key = (D, E, N, form)
+        snap = (emv_mode, float(tp_nu)) + tuple(None if a is None else a.tobytes() for a in arrs)
+        if self._handle is not None and key == self._key and snap == self._snap:
+            return self._handle
+        ptr = [None if a is None else a.ctypes.data_as(_lib.c_double_p) for a in arrs]
+        if self._handle is not None and key == self._key:
+            _lib.check(lib.ssmq_transform_update(ctypes.c_void_p(self._handle), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
+                                                 emv_mode, tp_nu, ptr[5]), 'ssmq_transform_update')
+        else:
+            self.close()
+            h = lib.ssmq_transform_create(D, E, N, form, ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], emv_mode, tp_nu, ptr[5])
+            if not h:
+                raise _lib.SsmqError('ssmq_transform_create failed: ' + _lib.last_error())
+            self._handle = h
+        self._key, self._snap = key, snap
+        return self._handle
+
+    def close(self):
+        if self._handle is not None:
+            _lib.load().ssmq_transform_destroy(ctypes.c_void_p(self._handle))
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _raise_not_pd(rc):
+    if rc > 0:
+        # the reference's error convention: numpy.linalg.cholesky raises inside apply() (mtran.py:139, bq/bqmtran.py:98)
+        raise np.linalg.LinAlgError('Matrix is not positive definite (batch item {})'.format(rc - 1))
+
+
+class _DeviceApply:
+    """apply() / apply_batch() on top of a transform handle; subclasses provide `_handle_for(E)`."""
+
+    def apply(self, f, mean, cov, fcn_pars, tf_pars=None):
+        mean = np.asarray(mean, dtype=np.float64)
+        cov = np.asarray(cov, dtype=np.float64)
+        t = np.atleast_1d(np.asarray(fcn_pars, dtype=np.float64)) if fcn_pars is not None else np.zeros(1)
+        mf, cf, cfx = self.apply_batch(f, mean[None, :], cov[None, :, :], t[:1], fcn_pars=fcn_pars)
+        return mf[0], cf[0], cfx[0]
+
+    def apply_batch(self, f, mean, cov, time=0.0, fcn_pars=None, return_status=False):
+        """B transforms in one launch.  mean (B, D), cov (B, D, D), time scalar or (B,).
+        `f`: bound dyn_eval / meas_eval of a model from `ssmtoybox_amd.ssmod` (evaluated on the device), or any
+        callable f(x_column, fcn_pars) (evaluated here on device-made sigma points; reductions on the device)."""
+        lib = _lib.load()
+        mean, pm = _lib.as_c(mean)
+        cov, pc = _lib.as_c(cov)
+        B, D = mean.shape
+        if cov.shape != (B, D, D):
+            raise ValueError('cov must have shape (B, D, D)')
+        dev = resolve_integrand(f)
+        if dev is not None:
+            integ, E = dev
+            h = self._handle_for(E)
+            time = np.ascontiguousarray(np.asarray(time, dtype=np.float64).reshape(-1))
+            if time.size == B and B > 1:
+                stride = 1
+            elif time.size >= 1:
+                time, stride = time[:1].copy(), 0
+            else:
+                time, stride = np.zeros(1), 0
+            mf, pmf = _lib.out_c((B, E))
+            cf, pcf = _lib.out_c((B, E, E))
+            cfx, pcfx = _lib.out_c((B, E, D))
+            st = np.zeros(B, dtype=np.int32)
+            rc = _lib.check(lib.ssmq_apply_batch(ctypes.c_void_p(h), ctypes.byref(integ), B, pm, pc,
+                                                 time.ctypes.data_as(_lib.c_double_p), stride, pmf, pcf, pcfx,
+                                                 st.ctypes.data_as(_lib.c_int32_p)), 'ssmq_apply_batch')
+        else:
+            # arbitrary Python integrand: sigma points from the device, f on the host, reductions on the device
+            h0 = self._handle_for(1)
+            N = self._num_points()
+            x, px = _lib.out_c((B, D, N))
+            chol, pl = _lib.out_c((B, D, D))
+            st = np.zeros(B, dtype=np.int32)
+            rc = _lib.check(lib.ssmq_sigma_points_batch(ctypes.c_void_p(h0), B, pm, pc, px, pl,
+                                                        st.ctypes.data_as(_lib.c_int32_p)), 'ssmq_sigma_points_batch')
+            if rc > 0 and not return_status:
+                _raise_not_pd(rc)
+            times = np.broadcast_to(np.asarray(time, dtype=np.float64).reshape(-1), (B,)) if np.size(time) in (1, B) \
+                else np.zeros(B)
+            fx0 = None
+            for b in range(B):
+                if st[b]:
+                    continue
+                par = fcn_pars if (fcn_pars is not None and B == 1) else np.atleast_1d(times[b])
+                fxb = np.apply_along_axis(f, 0, x[b], par)
+                if fx0 is None:
+                    fx0 = np.full((B,) + fxb.shape, np.nan)
+                fx0[b] = fxb
+            if fx0 is None:
+                fx0 = np.full((B, 1, N), np.nan)
+            E = fx0.shape[1]
+            h = self._handle_for(E)
+            fx0, pfx = _lib.as_c(fx0)
+            mf, pmf = _lib.out_c((B, E))
+            cf, pcf = _lib.out_c((B, E, E))
+            cfx, pcfx = _lib.out_c((B, E, D))
+            _lib.check(lib.ssmq_apply_fx_batch(ctypes.c_void_p(h), B, pl, pm, px, pfx, pmf, pcf, pcfx),
+                       'ssmq_apply_fx_batch')
+        if return_status:
+            return mf, cf, cfx, st
+        _raise_not_pd(rc)
+        return mf, cf, cfx
+
+    def apply_batch_dev(self, f, mean, cov, time, mean_f, cov_f, cov_fx, status, time_stride=0):
+        """Device-resident variant: all arguments are `_lib.SoA` planes (time: DeviceBuffer); asynchronous."""
+        dev = resolve_integrand(f)
+        if dev is None:
+            raise ValueError('apply_batch_dev needs a built-in (device) integrand')
+        integ, E = dev
+        h = self._handle_for(E)
+        _lib.check(_lib.load().ssmq_apply_batch_dev(ctypes.c_void_p(h), ctypes.byref(integ), mean.B, mean.ld, mean.ptr,
+                                                    cov.ptr, ctypes.c_void_p(time.ptr), time_stride, mean_f.ptr,
+                                                    cov_f.ptr, cov_fx.ptr, ctypes.c_void_p(status.ptr)),
+                   'ssmq_apply_batch_dev')
+
+    def kernel_name(self, f):
+        integ, E = resolve_integrand(f)
+        buf = ctypes.create_string_buffer(256)
+        _lib.check(_lib.load().ssmq_apply_kernel_name(ctypes.c_void_p(self._handle_for(E)), ctypes.byref(integ), buf,
+                                                      256), 'ssmq_apply_kernel_name')
+        return buf.value.decode()
+
+
+"""
+Sigma-point transforms.
+"""
+
+
+class SigmaPointTransform(_DeviceApply, MomentTransform):
+    """Classical sigma-point rules: centred moments with diagonal covariance weights (mtran.py:102-149).
+    Subclasses set `wm`, `Wc` (diagonal matrix, as in the reference) and `unit_sp`."""
+
+    def _num_points(self):
+        return self.unit_sp.shape[1]
+
+    def _handle_for(self, E):
+        if not hasattr(self, '_dev'):
+            self._dev = {}
+        D, N = self.unit_sp.shape
+        dt = self._dev.setdefault(E, DeviceTransform())
+        wc = np.diag(self.Wc) if np.ndim(self.Wc) == 2 else np.asarray(self.Wc)
+        return dt.get(D, E, N, FORM_SIGMA, self.unit_sp, self.wm, wc, None, None, EMV_DIAG, 0.0, None)
+
+
+class SphericalRadialTransform(SigmaPointTransform):
+    """Spherical-radial rule, 2*dim points (mtran.py:152-204)."""
+
+    def __init__(self, dim):
+        self.wm = self.weights(dim)
+        self.Wc = np.diag(self.wm)
+        self.unit_sp = self.unit_sigma_points(dim)
+
+    @staticmethod
+    def weights(dim):
+        return np.full(2 * dim, 1 / (2.0 * dim))
+
+    @staticmethod
+    def unit_sigma_points(dim):
+        c = np.sqrt(dim)
+        return np.hstack((c * np.eye(dim), -c * np.eye(dim)))
+
+
+class UnscentedTransform(SigmaPointTransform):
+    """Unscented rule, 2*dim + 1 points (mtran.py:207-293)."""
+
+    def __init__(self, dim, kappa=None, alpha=1.0, beta=2.0):
+        self.wm, self.wc = self.weights(dim, kappa=kappa, alpha=alpha, beta=beta)
+        self.Wm = np.diag(self.wm)
+        self.Wc = np.diag(self.wc)
+        self.unit_sp = self.unit_sigma_points(dim, kappa=kappa, alpha=alpha)
+
+    @staticmethod
+    def _lambda(dim, kappa, alpha):
+        kappa = max(3.0 - dim, 0.0) if kappa is None else kappa
+        return alpha ** 2 * (dim + kappa) - dim
+
+    @staticmethod
+    def unit_sigma_points(dim, kappa=None, alpha=1.0):
+        c = np.sqrt(dim + UnscentedTransform._lambda(dim, kappa, alpha))
+        return np.hstack((np.zeros((dim, 1)), c * np.eye(dim), -c * np.eye(dim)))
+
+    @staticmethod
+    def weights(dim, kappa=None, alpha=1.0, beta=2.0):
+        lam = UnscentedTransform._lambda(dim, kappa, alpha)
+        wm = np.full(2 * dim + 1, 1.0 / (2.0 * (dim + lam)))
+        wc = wm.copy()
+        wm[0] = lam / (dim + lam)
+        wc[0] = wm[0] + (1 - alpha ** 2 + beta)
+        return wm, wc
+
+
+def _product_grid(v, dim):
+    # all dim-tuples from v, last coordinate fastest (the ordering the reference gets from sklearn's `cartesian`)
+    return np.stack([g.reshape(-1) for g in np.meshgrid(*([v] * dim), indexing='ij')], axis=1)
+
+
+class GaussHermiteTransform(SigmaPointTransform):
+    """Gauss-Hermite product rule, degree**dim points (mtran.py:296-360)."""
+
+    def __init__(self, dim, degree=3):
+        self.degree = degree
+        self.wm = self.weights(dim, degree)
+        self.Wc = np.diag(self.wm)
+        self.unit_sp = self.unit_sigma_points(dim, degree)
+
+    @staticmethod
+    def weights(dim, degree=3):
+        x, _ = hermegauss(degree)
+        # not hermegauss's weights: deg! / (deg^2 He_{deg-1}(x)^2)   (mtran.py:334-336)
+        w = math.factorial(degree) / (degree ** 2 * hermeval(x, [0] * (degree - 1) + [1]) ** 2)
+        return np.prod(_product_grid(w, dim), axis=1)
+
+    @staticmethod
+    def unit_sigma_points(dim, degree=3):
+        x, _ = hermegauss(degree)
+        return _product_grid(x, dim).T
+
+
+class FullySymmetricStudentTransform(SigmaPointTransform):
+    """Fully symmetric rule for Student-t densities, degree 3 or 5 (mtran.py:363-578)."""
+
+    _supported_degrees_ = [3, 5]
+
+    def __init__(self, dim, degree=3, kappa=None, dof=4):
+        self.degree, self.kappa, self.dof = degree, kappa, dof
+        self.wm = self.weights(dim, degree, kappa, dof)
+        self.Wc = np.diag(self.wm)
+        self.unit_sp = self.unit_sigma_points(dim, degree, kappa, dof)
+
+    @staticmethod
+    def _normalise(dim, degree, kappa, dof):
+        if degree not in FullySymmetricStudentTransform._supported_degrees_:
+            print('Defaulting to degree 3. Supplied degree {} not supported. Supported degrees: {}'.format(
+                degree, FullySymmetricStudentTransform._supported_degrees_))
+            degree = 3
+        kappa = max(3.0 - dim, 0.0) if kappa is None else kappa
+        return degree, kappa, max(dof, degree)
+
+    @staticmethod
+    def weights(dim, degree=3, kappa=None, dof=4.0):
+        degree, kappa, dof = FullySymmetricStudentTransform._normalise(dim, degree, kappa, dof)
+        if degree == 3:
+            w = np.full(2 * dim + 1, 1 / (2 * (dim + kappa)))
+            w[0] = kappa / (dim + kappa)
+            return w
+        i2 = dof / (dof - 2)
+        i22 = dof ** 2 / ((dof - 2) * (dof - 4))
+        i4 = 3 * i22
+        a0 = 1 - dim * (i2 / i4) ** 2 * (i4 - 0.5 * (dim - 1) * i22)
+        a1 = 0.5 * (i2 / i4) ** 2 * (i4 - (dim - 1) * i22)
+        a11 = 0.25 * (i2 / i4) ** 2 * i22
+        return np.hstack((a0, a1 * np.ones(2 * dim), a11 * np.ones(2 * dim * (dim - 1))))
+
+    @staticmethod
+    def unit_sigma_points(dim, degree=3, kappa=None, dof=4.0):
+        degree, kappa, dof = FullySymmetricStudentTransform._normalise(dim, degree, kappa, dof)
+        i2 = dof / (dof - 2)
+        if degree == 3:
+            u = np.sqrt(i2 * (dim + kappa))
+            return u * np.hstack((np.zeros((dim, 1)), np.eye(dim), -np.eye(dim)))
+        i4 = 3 * dof ** 2 / ((dof - 2) * (dof - 4))
+        u = np.sqrt(i4 / i2)
+        sym = FullySymmetricStudentTransform.symmetric_set
+        return np.hstack((sym(dim, []), sym(dim, [u]), sym(dim, [u, u])))
+
+    @staticmethod
+    def symmetric_set(dim, gen):
+        """Fully symmetric point set of a generator with equal entries; column order as the reference's recursion
+        produces it (mtran.py:522-578): leading index ascending, then each sub-point as +u, -u."""
+        gen = list(gen)
+        if not gen:
+            return np.zeros((dim, 1))
+        cols = []
+        for i in range(dim):
+            if len(gen) == 1:
+                tails = [np.zeros(dim - i - 1)]
+            else:
+                sub = FullySymmetricStudentTransform.symmetric_set(dim - i - 1, gen[1:]) if dim - i - 1 > 0 \
+                    else np.zeros((0, 0))
+                tails = [sub[:, j] for j in range(sub.shape[1])]
+            for tail in tails:
+                u = np.zeros(dim)
+                u[i] = gen[0]
+                u[i + 1:] = tail
+                cols += [u, -u]
+        return np.stack(cols, axis=1) if cols else np.zeros((dim, 0))

@@ -1,0 +1,146 @@
+"""
+Callers of the moment-transform path kept on the device: additive-noise Gaussian filters (reference:
+ssmtoybox/ssinf.py:215-323, 347-552) running B independent trajectories per kernel launch.
+
+`forward_pass(data)` keeps the reference's one-trajectory signature; `forward_pass_batch(data)` takes
+data of shape (dim_y, T, B) - the reference's Monte-Carlo axis (`for imc in range(mc)` in its research scripts,
+e.g. research/tpq/tpq_base.py:175-192) - and returns (D, T, B) / (D, D, T, B).
+
+Per time step k = 1..T (both transforms use time index k - 1: ssinf.py:104, 276-288):
+    dyn transform, + G Q G'   ->   obs transform, + R   ->   Kalman update (ssinf.py:297-323)
+all inside `ssmq_filter_forward_dev` (ssmtoybox_amd/csrc); nothing is computed in NumPy.
+Smoothing, the Studentian filters, marginalised inference and non-additive noise are outside this round's scope.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .mtran import (MomentTransform, UnscentedTransform, SphericalRadialTransform, GaussHermiteTransform,
+                    resolve_integrand)
+from .bq.bqmtran import GaussianProcessTransform, BayesSardTransform, StudentTProcessTransform
+from .ssmod import TransitionModel, MeasurementModel
+
+
+class GaussianInference:
+    """Additive-noise Gaussian filter (ssinf.py:215-323)."""
+
+    def __init__(self, mod_dyn, mod_obs, tf_dyn, tf_obs):
+        assert isinstance(mod_dyn, TransitionModel) and isinstance(mod_obs, MeasurementModel)
+        assert isinstance(tf_dyn, MomentTransform) and isinstance(tf_obs, MomentTransform)
+        if not (mod_dyn.noise_additive and mod_obs.noise_additive):
+            raise NotImplementedError('the device filter loop covers additive-noise models')
+        self.mod_dyn, self.mod_obs, self.tf_dyn, self.tf_obs = mod_dyn, mod_obs, tf_dyn, tf_obs
+        self.x0_mean, self.x0_cov = mod_dyn.init_rv.get_stats()
+        self.q_mean, self.q_cov = mod_dyn.noise_rv.get_stats()
+        self.r_mean, self.r_cov = mod_obs.noise_rv.get_stats()
+        self.G = mod_dyn.noise_gain
+        self.fi_mean = self.fi_cov = None
+        self.status = None
+
+    def reset(self):
+        self.fi_mean = self.fi_cov = None
+        self.status = None
+
+    def forward_pass(self, data):
+        """data (dim_y, T) -> filtered means (D, T), covariances (D, D, T)  (ssinf.py:66-118)."""
+        fm, fP = self.forward_pass_batch(np.asarray(data)[..., None])
+        return fm[..., 0], fP[..., 0]
+
+    def forward_pass_batch(self, data, x0_mean=None, x0_cov=None, raise_on_failure=True):
+        """data (dim_y, T, B).  Optional per-trajectory initial moments x0_mean (B, D), x0_cov (B, D, D)."""
+        lib = _lib.load()
+        data = np.asarray(data, dtype=np.float64)
+        Y, T, B = data.shape
+        D = self.mod_dyn.dim_state
+        ld = (B + 63) // 64 * 64
+        # measurements are already plane-shaped: [T][Y][ld]
+        ybuf = np.zeros((T, Y, ld))
+        ybuf[:, :, :B] = data.transpose(1, 0, 2)
+        d_y = _lib.DeviceBuffer(ybuf.nbytes)
+        d_y.upload(ybuf)
+        m0 = np.broadcast_to(self.x0_mean, (B, D)) if x0_mean is None else np.asarray(x0_mean, dtype=np.float64)
+        P0 = np.broadcast_to(self.x0_cov, (B, D, D)) if x0_cov is None else np.asarray(x0_cov, dtype=np.float64)
+        mbuf = np.zeros((D, ld))
+        mbuf[:, :B] = m0.T
+        Pbuf = np.zeros((D * D, ld))
+        Pbuf[:, :B] = P0.reshape(B, D * D).T
+        if ld > B:       # padding lanes are never read (b >= B), keep them PD anyway
+            Pbuf[:, B:] = np.eye(D).reshape(-1, 1)
+        d_m0, d_P0 = _lib.DeviceBuffer(mbuf.nbytes), _lib.DeviceBuffer(Pbuf.nbytes)
+        d_m0.upload(mbuf)
+        d_P0.upload(Pbuf)
+        d_fm, d_fP = _lib.DeviceBuffer(8 * T * D * ld), _lib.DeviceBuffer(8 * T * D * D * ld)
+        d_st = _lib.DeviceBuffer(4 * ld)
+        f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
+        f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
+        h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
+        gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
+        rr, pr = _lib.as_c(self.r_cov)
+        _lib.check(lib.ssmq_filter_forward_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
+                                               ctypes.byref(f_obs), B, ld, T, ctypes.c_void_p(d_y.ptr),
+                                               ctypes.c_void_p(d_m0.ptr), ctypes.c_void_p(d_P0.ptr), pg, pr,
+                                               ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
+                                               ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_forward_dev')
+        fm = d_fm.download((T, D, ld))[:, :, :B].transpose(1, 0, 2)
+        fP = d_fP.download((T, D, D, ld))[:, :, :, :B].transpose(1, 2, 0, 3)
+        self.status = d_st.download((ld,), dtype=np.int32)[:B]
+        for buf in (d_y, d_m0, d_P0, d_fm, d_fP, d_st):
+            buf.free()
+        if raise_on_failure and self.status.any():
+            b = int(np.flatnonzero(self.status)[0])
+            raise np.linalg.LinAlgError('Matrix is not positive definite (trajectory {}, step {})'.format(
+                b, int(self.status[b]) - 1))
+        self.fi_mean, self.fi_cov = np.ascontiguousarray(fm), np.ascontiguousarray(fP)
+        return self.fi_mean, self.fi_cov
+
+
+class CubatureKalman(GaussianInference):
+    """ssinf.py:360-371."""
+
+    def __init__(self, dyn, obs):
+        super().__init__(dyn, obs, SphericalRadialTransform(dyn.dim_in), SphericalRadialTransform(obs.dim_in))
+
+
+class UnscentedKalman(GaussianInference):
+    """ssinf.py:374-402."""
+
+    def __init__(self, dyn, obs, kappa=None, alpha=1.0, beta=2.0):
+        super().__init__(dyn, obs, UnscentedTransform(dyn.dim_in, kappa=kappa, alpha=alpha, beta=beta),
+                         UnscentedTransform(obs.dim_in, kappa=kappa, alpha=alpha, beta=beta))
+
+
+class GaussHermiteKalman(GaussianInference):
+    """ssinf.py:405-420."""
+
+    def __init__(self, dyn, obs, deg=3):
+        super().__init__(dyn, obs, GaussHermiteTransform(dyn.dim_in, degree=deg),
+                         GaussHermiteTransform(obs.dim_in, degree=deg))
+
+
+class GaussianProcessKalman(GaussianInference):
+    """ssinf.py:423-463."""
+
+    def __init__(self, dyn, obs, kern_par_dyn, kern_par_obs, kernel='rbf', points='ut', point_hyp=None):
+        t_dyn = GaussianProcessTransform(dyn.dim_in, dyn.dim_state, kern_par_dyn, kernel, points, point_hyp)
+        t_obs = GaussianProcessTransform(obs.dim_in, obs.dim_out, kern_par_obs, kernel, points, point_hyp)
+        super().__init__(dyn, obs, t_dyn, t_obs)
+
+
+class BayesSardKalman(GaussianInference):
+    """ssinf.py:466-502."""
+
+    def __init__(self, dyn, obs, kern_par_dyn, kern_par_obs, mulind_dyn=2, mulind_obs=2, points='ut', point_hyp=None):
+        t_dyn = BayesSardTransform(dyn.dim_in, dyn.dim_state, kern_par_dyn, mulind_dyn, points, point_hyp)
+        t_obs = BayesSardTransform(obs.dim_in, obs.dim_out, kern_par_obs, mulind_obs, points, point_hyp)
+        super().__init__(dyn, obs, t_dyn, t_obs)
+
+
+class StudentProcessKalman(GaussianInference):
+    """ssinf.py:505-552.  As in the reference the transforms are built with dim_out = 1 (I_out = eye(1)), so the whole
+    scaled (E, E) model-variance matrix is added for E > 1."""
+
+    def __init__(self, dyn, obs, kern_par_dyn, kern_par_obs, kernel='rbf', points='ut', point_hyp=None, nu=3.0):
+        t_dyn = StudentTProcessTransform(dyn.dim_in, 1, kern_par_dyn, kernel, points, point_hyp, nu=nu)
+        t_obs = StudentTProcessTransform(obs.dim_in, 1, kern_par_obs, kernel, points, point_hyp, nu=nu)
+        super().__init__(dyn, obs, t_dyn, t_obs)

@@ -1,0 +1,313 @@
+"""
+State-space models: the closed-form dynamics / measurement functions of the reference's `ssmtoybox/ssmod.py`, each tied
+to its device integrand (include/ssmq.h `enum ssmq_integrand_id`) so that a moment transform given `model.dyn_eval` /
+`model.meas_eval` evaluates it on the GPU and sigma points never leave HBM.
+
+Only what the moment-transform path needs is here: dimensions, noise additivity, noise gain, the integrand descriptor and
+a NumPy evaluation of the same formula for callers that want function values on the host (it is never used by
+`apply()`).  Simulators, Jacobians and random variables of the reference are out of scope.
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import Integrand
+
+
+class GaussRV:
+    """Mean / covariance carrier with the reference's `get_stats()` protocol (utils.py:580-625); no sampling."""
+
+    def __init__(self, dim, mean=None, cov=None):
+        self.dim = dim
+        self.mean = np.zeros(dim) if mean is None else np.atleast_1d(np.asarray(mean, dtype=float))
+        self.cov = np.eye(dim) if cov is None else np.atleast_2d(np.asarray(cov, dtype=float))
+
+    def get_stats(self):
+        return self.mean, self.cov
+
+
+class TransitionModel:
+    """x_{k+1} = f(x_k, q_k, k)   (ssmod.py:10-244)."""
+    dim_state = None
+    dim_noise = None
+    noise_additive = True
+    _fid = None
+
+    def __init__(self, init_rv=None, noise_rv=None, noise_gain=None):
+        self.dim_in = self.dim_state if self.noise_additive else self.dim_state + self.dim_noise
+        self.init_rv, self.noise_rv = init_rv, noise_rv
+        self.zero_q = np.zeros(self.dim_noise)
+        self.noise_gain = np.eye(self.dim_state, self.dim_noise) if noise_gain is None else noise_gain
+
+    def _par(self):
+        return ()
+
+    def device_integrand(self):
+        """(ssmq_integrand, dim_out) for the C ABI."""
+        return Integrand.make(self._fid, self._par()), self.dim_state
+
+    def dyn_fcn(self, x, q, time):
+        raise NotImplementedError
+
+    def dyn_eval(self, xq, time, dx=False):
+        """Noise-additivity-aware evaluation (ssmod.py:129-166): additive models are evaluated at zero noise."""
+        if dx:
+            raise NotImplementedError('Jacobians are outside the moment-transform path')
+        if self.noise_additive:
+            return self.dyn_fcn(xq, self.zero_q, time)
+        return self.dyn_fcn(xq[:self.dim_state], xq[-self.dim_noise:], time)
+
+
+class UNGMTransition(TransitionModel):
+    """ssmod.py:247-275."""
+    dim_state, dim_noise, noise_additive, _fid = 1, 1, True, _lib.F_UNGM_DYN
+
+    def dyn_fcn(self, x, q, time):
+        return np.asarray(0.5 * x[0] + 25 * (x[0] / (1 + x[0] ** 2)) + 8 * np.cos(1.2 * time)) + q
+
+
+class UNGMNATransition(TransitionModel):
+    """ssmod.py:278-306 (non-additive noise: input [x, q])."""
+    dim_state, dim_noise, noise_additive, _fid = 1, 1, False, _lib.F_UNGMNA_DYN
+
+    def dyn_fcn(self, x, q, time):
+        return np.asarray(0.5 * x[0] + 25 * (x[0] / (1 + x[0] ** 2)) + 8 * q[0] * np.cos(1.2 * time))
+
+
+class Pendulum2DTransition(TransitionModel):
+    """ssmod.py:309-365."""
+    dim_state, dim_noise, noise_additive, _fid = 2, 2, True, _lib.F_PENDULUM_DYN
+    g = 9.81
+
+    def __init__(self, init_rv=None, noise_rv=None, dt=0.01):
+        super().__init__(init_rv, noise_rv)
+        self.dt = dt
+
+    def _par(self):
+        return (self.dt,)
+
+    def dyn_fcn(self, x, q, time):
+        return np.array([x[0] + x[1] * self.dt, x[1] - self.g * self.dt * np.sin(x[0])]) + q
+
+
+class ReentryVehicle1DTransition(TransitionModel):
+    """ssmod.py:368-435."""
+    dim_state, dim_noise, noise_additive, _fid = 3, 3, True, _lib.F_REENTRY1D_DYN
+
+    def __init__(self, init_rv=None, noise_rv=None, dt=0.1):
+        super().__init__(init_rv, noise_rv)
+        self.dt = dt
+        self.Gamma = 1 / 6.096
+
+    def _par(self):
+        return (self.dt,)
+
+    def dyn_fcn(self, x, q, time):
+        return np.array([x[0] - self.dt * x[1] + q[0],
+                         x[1] - self.dt * np.exp(-self.Gamma * x[0]) * x[1] ** 2 * x[2] + q[1], x[2] + q[2]])
+
+
+class ReentryVehicle2DTransition(TransitionModel):
+    """ssmod.py:438-584 (5-D state [x, y, vx, vy, omega]; noise enters the last three states)."""
+    dim_state, dim_noise, noise_additive, _fid = 5, 3, True, _lib.F_REENTRY2D_DYN
+
+    def __init__(self, init_rv=None, noise_rv=None, dt=0.1):
+        self.dt = dt
+        self.R0, self.H0, self.Gm0, self.b0 = 6374, 13.406, 3.9860e5, -0.59783
+        super().__init__(init_rv, noise_rv, np.vstack((np.zeros((2, 3)), np.eye(3))))
+
+    def _par(self):
+        return (self.dt,)
+
+    def _core(self, x):
+        b = self.b0 * np.exp(x[4])
+        R = np.sqrt(x[0] ** 2 + x[1] ** 2)
+        V = np.sqrt(x[2] ** 2 + x[3] ** 2)
+        D = b * np.exp((self.R0 - R) / self.H0) * V
+        G = -self.Gm0 / R ** 3
+        return [x[0] + self.dt * x[2], x[1] + self.dt * x[3], x[2] + self.dt * (D * x[2] + G * x[0]),
+                x[3] + self.dt * (D * x[3] + G * x[1]), x[4]]
+
+    def dyn_fcn(self, x, q, time):
+        return np.array(self._core(x)) + self.noise_gain.dot(q)
+
+
+class ReentryVehicle2DBiasTransition(ReentryVehicle2DTransition):
+    """This build's synthetic 6-D benchmark model: reentry-2D on states 0..4 plus a
+    pass-through sixth state.  Not part of the reference."""
+    dim_state, dim_noise, noise_additive, _fid = 6, 4, True, _lib.F_REENTRY2D_BIAS_DYN
+
+    def __init__(self, init_rv=None, noise_rv=None, dt=0.1):
+        self.dt = dt
+        self.R0, self.H0, self.Gm0, self.b0 = 6374, 13.406, 3.9860e5, -0.59783
+        TransitionModel.__init__(self, init_rv, noise_rv, np.vstack((np.zeros((2, 4)), np.eye(4))))
+
+    def dyn_fcn(self, x, q, time):
+        return np.array(self._core(x) + [x[5]]) + self.noise_gain.dot(q)
+
+
+class CoordinatedTurnTransition(TransitionModel):
+    """ssmod.py:587-696."""
+    dim_state, dim_noise, noise_additive, _fid = 5, 5, True, _lib.F_CT_DYN
+
+    def __init__(self, init_rv=None, noise_rv=None, dt=0.1):
+        super().__init__(init_rv, noise_rv)
+        self.dt = dt
+
+    def _par(self):
+        return (self.dt,)
+
+    def dyn_fcn(self, x, q, *args):
+        om = x[4]
+        a, b = np.sin(om * self.dt), np.cos(om * self.dt)
+        c, d = np.sin(om * self.dt) / om, (1 - np.cos(om * self.dt)) / om
+        return np.array([x[0] + c * x[1] - d * x[3], b * x[1] - a * x[3], d * x[1] + x[2] + c * x[3],
+                         a * x[1] + b * x[3], x[4]]) + q
+
+
+class ConstantTurnRateSpeed(TransitionModel):
+    """ssmod.py:699-780 (non-additive noise: input [x(5), q(2)])."""
+    dim_state, dim_noise, noise_additive, _fid = 5, 2, False, _lib.F_CTRS_DYN
+
+    def __init__(self, init_rv=None, noise_rv=None, dt=0.05):
+        super().__init__(init_rv, noise_rv)
+        self.dt = dt
+
+    def _par(self):
+        return (self.dt,)
+
+    def dyn_fcn(self, x, q, time):
+        dt = self.dt
+        if x[4] == 0:
+            f = np.array([dt * x[2] * np.cos(x[3]), dt * x[2] * np.sin(x[3]), dt * q[0],
+                          dt * x[3] + 0.5 * dt ** 2 * q[1], dt * q[1]])
+        else:
+            c = x[2] / x[4]
+            f = np.array([c * (np.sin(x[3] + x[4] * dt) - np.sin(x[3])) + 0.5 * dt ** 2 * np.cos(x[3]) * q[0],
+                          c * (-np.cos(x[3] + x[4] * dt) + np.cos(x[3])) + 0.5 * dt ** 2 * np.sin(x[3]) * q[0],
+                          dt * q[0], dt * x[3] + 0.5 * dt ** 2 * q[1], dt * q[1]])
+        return x + f
+
+
+class ConstantVelocity(TransitionModel):
+    """ssmod.py:783-855."""
+    dim_state, dim_noise, noise_additive, _fid = 4, 2, True, _lib.F_CV_DYN
+
+    def __init__(self, init_rv=None, noise_rv=None, dt=0.1):
+        self.dt = dt
+        gain = np.array([[dt ** 2 / 2, 0], [dt, 0], [0, dt ** 2 / 2], [0, dt]])
+        super().__init__(init_rv, noise_rv, gain)
+
+    def _par(self):
+        return (self.dt,)
+
+    def dyn_fcn(self, x, q, time):
+        return np.array([x[0] + self.dt * x[1], x[1], x[2] + self.dt * x[3], x[3]]) + self.noise_gain.dot(q)
+
+
+class MeasurementModel:
+    """y_k = h(x_k, r_k, k)   (ssmod.py:863-1039)."""
+    dim_in = None
+    dim_out = None
+    dim_noise = None
+    dim_substate = None
+    noise_additive = True
+    _fid = None
+
+    def __init__(self, noise_rv, dim_state, state_index=None):
+        self.noise_rv = noise_rv
+        self.zero_r = np.zeros(self.dim_noise)
+        self.state_index = state_index
+        self.dim_in = dim_state if self.noise_additive else dim_state + self.dim_noise
+        self.dim_state = dim_state
+
+    def _par(self):
+        return ()
+
+    def device_integrand(self):
+        idx = None
+        if self.state_index is not None:
+            idx = list(self.state_index)
+            if not self.noise_additive:   # the noise components follow the selected sub-state
+                idx += list(range(self.dim_state, self.dim_state + self.dim_noise))
+        return Integrand.make(self._fid, self._par(), idx), self.dim_out
+
+    def meas_fcn(self, x, r, time):
+        raise NotImplementedError
+
+    def meas_eval(self, xr, time, dx=False):
+        """ssmod.py:960-1009."""
+        if dx:
+            raise NotImplementedError('Jacobians are outside the moment-transform path')
+        if self.noise_additive:
+            if self.state_index is not None:
+                xr = xr[self.state_index]
+            return self.meas_fcn(xr, self.zero_r, time)
+        x, r = xr[:self.dim_state], xr[-self.dim_noise:]
+        if self.state_index is not None:
+            x = x[self.state_index]
+        return self.meas_fcn(x, r, time)
+
+
+class UNGMMeasurement(MeasurementModel):
+    """ssmod.py:1042-1064."""
+    dim_out, dim_substate, dim_noise, noise_additive, _fid = 1, 1, 1, True, _lib.F_UNGM_MEAS
+
+    def meas_fcn(self, x, r, time):
+        return np.asarray([0.05 * x[0] ** 2]) + r
+
+
+class UNGMNAMeasurement(MeasurementModel):
+    """ssmod.py:1067-1089 (non-additive noise: input [x, r])."""
+    dim_out, dim_substate, dim_noise, noise_additive, _fid = 1, 1, 1, False, _lib.F_UNGMNA_MEAS
+
+    def meas_fcn(self, x, r, time):
+        return np.asarray([0.05 * r[0] * x[0] ** 2])
+
+
+class Pendulum2DMeasurement(MeasurementModel):
+    """ssmod.py:1092-1118."""
+    dim_out, dim_substate, dim_noise, noise_additive, _fid = 1, 1, 1, True, _lib.F_PENDULUM_MEAS
+
+    def meas_fcn(self, x, r, time):
+        return np.array([np.sin(x[0])]) + r
+
+
+class RangeMeasurement(MeasurementModel):
+    """ssmod.py:1121-1152."""
+    dim_out, dim_substate, dim_noise, noise_additive, _fid = 1, 1, 1, True, _lib.F_RANGE_MEAS
+
+    def meas_fcn(self, x, r, time):
+        return np.array([np.sqrt(30.0 ** 2 + (x[0] - 30.0) ** 2)]) + r
+
+
+class BearingMeasurement(MeasurementModel):
+    """ssmod.py:1155-1198 (one bearing per sensor; default 4 sensors)."""
+    dim_substate, noise_additive, _fid = 2, True, _lib.F_BEARING_MEAS
+
+    def __init__(self, noise_rv, dim_state, state_index=None, sensor_pos=None):
+        self.sensor_pos = np.vstack((np.eye(2), -np.eye(2))) if sensor_pos is None else np.asarray(sensor_pos, float)
+        self.dim_out = len(self.sensor_pos)
+        self.dim_noise = self.dim_out
+        super().__init__(noise_rv, dim_state, state_index)
+
+    def _par(self):
+        return tuple(self.sensor_pos.reshape(-1))
+
+    def meas_fcn(self, x, r, time):
+        return np.arctan2(x[1] - self.sensor_pos[:, 1], x[0] - self.sensor_pos[:, 0]) + r
+
+
+class Radar2DMeasurement(MeasurementModel):
+    """ssmod.py:1201-1255 (range and bearing from the radar location)."""
+    dim_out, dim_substate, dim_noise, noise_additive, _fid = 2, 2, 2, True, _lib.F_RADAR2D_MEAS
+
+    def __init__(self, noise_rv, dim_state, state_index=None, radar_loc=None):
+        super().__init__(noise_rv, dim_state, state_index)
+        self.radar_loc = np.array([0.0, 0.0]) if radar_loc is None else np.asarray(radar_loc, dtype=float)
+
+    def _par(self):
+        return (self.radar_loc[0], self.radar_loc[1])
+
+    def meas_fcn(self, x, r, time):
+        dx, dy = x[0] - self.radar_loc[0], x[1] - self.radar_loc[1]
+        return np.array([np.sqrt(dx ** 2 + dy ** 2), np.arctan2(dy, dx)]) + r

@@ -34,3 +34,32 @@ def rel_err(a, b):
     den = np.max(np.abs(b)) if b.size else 0.0
     num = np.max(np.abs(a - b)) if b.size else 0.0
     return num / den if den > 0 else num
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tolerance of one moment transform against the NumPy reference (north star: 1e-10 relative, fp64)
+# ---------------------------------------------------------------------------------------------------------------
+RTOL = 1e-10
+
+
+def moment_scales(mf_ref, cf_ref, cfx_ref, cov_in):
+    """Scales the 1e-10 relative bar is taken against.  mean: max |mean_f|.  cov_f: the uncentred BQ covariance
+    subtracts mean mean' from fx Wc fx' (bq/bqmtran.py:199), so its rounding error is relative to max|mean_f|^2, not to
+    the (possibly much smaller) result - the reference's own result carries that noise.
+    cov_fx: max |mean_f| * sqrt(max |cov|)."""
+    ms = max(float(np.max(np.abs(mf_ref))), 1e-300)
+    cs = max(float(np.max(np.abs(cf_ref))), ms ** 2)
+    xs = max(float(np.max(np.abs(cfx_ref))), ms * float(np.sqrt(np.max(np.abs(cov_in)))))
+    return ms, cs, xs
+
+
+def assert_moments_close(got, ref, cov_in, rtol=RTOL, what=''):
+    mf, cf, cfx = got
+    mf_r, cf_r, cfx_r = ref
+    ms, cs, xs = moment_scales(mf_r, cf_r, cfx_r, cov_in)
+    e1 = float(np.max(np.abs(mf - mf_r))) / ms
+    e2 = float(np.max(np.abs(cf - cf_r))) / cs
+    e3 = float(np.max(np.abs(cfx - cfx_r))) / xs
+    assert np.all(np.isfinite(mf)) and np.all(np.isfinite(cf)) and np.all(np.isfinite(cfx)), what
+    assert e1 <= rtol and e2 <= rtol and e3 <= rtol, (what, e1, e2, e3)
+    return max(e1, e2, e3)

@@ -1,0 +1,376 @@
+"""
+Parity of the HIP path (through the C ABI / ctypes, never through the oracle) with the reference:
+  - golden vectors produced by the reference itself (tests/golden/*.npz),
+  - the CPU oracle on seeded random batches,
+  - size-independent properties at BASELINE.json's full batch sizes.
+Bar: 1e-10 relative in fp64 (scales defined in tests/_cases.py: moment_scales); weights that go through K^-1 are
+reproducible only to cond(K) eps / cond(K)^2 eps and are checked against that.
+All tests need a real MI355X.
+"""
+import numpy as np
+import pytest
+
+from oracle import ssmq_oracle as orc
+from tests._cases import MODELS, SIGMA_TF, BQ_TF, SENSORS, assert_moments_close, rel_err, RTOL
+from tests.golden.make_golden_cases import GP_CASES, BS_CASES, gp_par
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import ssmtoybox_amd
+    assert ssmtoybox_amd.device_count() >= 1, 'no GPU visible - the HIP path cannot run (there is no CPU fallback)'
+    return ssmtoybox_amd
+
+
+def make_model(name):
+    from ssmtoybox_amd import ssmod as sm
+    r = sm.GaussRV
+    table = {
+        'ungm_dyn': lambda: (sm.UNGMTransition(), 'dyn'),
+        'ungm_meas': lambda: (sm.UNGMMeasurement(r(1), 1), 'meas'),
+        'ungmna_dyn': lambda: (sm.UNGMNATransition(), 'dyn'),
+        'ungmna_meas': lambda: (sm.UNGMNAMeasurement(r(1), 1), 'meas'),
+        'pend_dyn': lambda: (sm.Pendulum2DTransition(dt=0.01), 'dyn'),
+        'pend_meas': lambda: (sm.Pendulum2DMeasurement(r(1), 2), 'meas'),
+        'reentry_dyn': lambda: (sm.ReentryVehicle2DTransition(), 'dyn'),
+        'radar_meas': lambda: (sm.Radar2DMeasurement(r(2), 5), 'meas'),
+        'ct_dyn': lambda: (sm.CoordinatedTurnTransition(), 'dyn'),
+        'bearing_meas': lambda: (sm.BearingMeasurement(r(4), 5, state_index=[0, 2], sensor_pos=SENSORS), 'meas'),
+        'cv_dyn': lambda: (sm.ConstantVelocity(), 'dyn'),
+        'reentry1d_dyn': lambda: (sm.ReentryVehicle1DTransition(), 'dyn'),
+        'range_meas': lambda: (sm.RangeMeasurement(r(1), 3), 'meas'),
+        'ctrs_dyn': lambda: (sm.ConstantTurnRateSpeed(), 'dyn'),
+    }
+    mod, kind = table[name]()
+    return mod, (mod.dyn_eval if kind == 'dyn' else mod.meas_eval)
+
+
+def make_transform(amd, tname, din, dout, g=None, key=None):
+    """Transform object of this build; BQ weights are then overwritten with the reference's own (golden) weights, as
+    the reference's research code does (research/tpq/tpq_ungm.py:114-124), so that apply() is compared in isolation."""
+    if tname == 'ut':
+        return amd.UnscentedTransform(din)
+    if tname == 'sr':
+        return amd.SphericalRadialTransform(din)
+    if tname == 'gh':
+        return amd.GaussHermiteTransform(din, 3)
+    if tname == 'fs':
+        return amd.FullySymmetricStudentTransform(din, 3)
+    ell = 3.0
+    par = gp_par(din, ell)
+    if tname == 'gpq':
+        tf = amd.GaussianProcessTransform(din, dout, par, 'rbf', 'ut')
+    elif tname == 'gpqsr':
+        tf = amd.GaussianProcessTransform(din, dout, gp_par(din, 3.0, 1.3, True), 'rbf', 'sr')
+    elif tname == 'tpq':
+        tf = amd.StudentTProcessTransform(din, dout, par, 'rbf', 'ut')
+    elif tname == 'tpq1':
+        tf = amd.StudentTProcessTransform(din, 1, par, 'rbf', 'ut')
+    else:
+        mi = np.hstack((np.zeros((din, 1)), np.eye(din), 2 * np.eye(din))).astype(int)
+        tf = amd.BayesSardTransform(din, dout, par, mi, 'ut')
+    if g is not None:
+        assert np.array_equal(tf.model.points, g[key + '_pts'])
+        tf.wm, tf.Wc, tf.Wcc = g[key + '_wm'], g[key + '_Wc'], g[key + '_Wcc']
+        tf.model.model_var = float(g[key + '_mv'])
+        if tname.startswith('tpq'):
+            tf.model.iK = g[key + '_iK']
+            assert tf.model.nu == float(g[key + '_nu']) == 4.0
+    return tf
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_layout_roundtrip(amd):
+    from ssmtoybox_amd import _lib
+    rng = np.random.default_rng(0)
+    for B, n in ((1, 1), (7, 3), (64, 36), (1000, 42), (4097, 78)):
+        a = rng.standard_normal((B, n))
+        s = _lib.SoA.from_host(a)
+        assert np.array_equal(s.to_host(), a)
+        planes = s.buf.download((n, s.ld))
+        assert np.array_equal(planes[:, :B], a.T)
+
+
+@pytest.mark.parametrize('name', sorted(MODELS))
+def test_apply_golden(amd, golden, name):
+    """apply() and apply_batch() against outputs of the reference's apply() on the same inputs and weights."""
+    g = golden('g3_apply')
+    fid, p, sidx, din, dout = MODELS[name]
+    mod, f = make_model(name)
+    means, covs, times = g[name + '_mean'], g[name + '_cov'], g[name + '_time']
+    worst = 0.0
+    for tname in SIGMA_TF + BQ_TF:
+        key = '{}_{}'.format(name, tname)
+        if key + '_mf' not in g:
+            continue
+        tf = make_transform(amd, tname, din, dout, g if tname in BQ_TF else None, key)
+        ref = (g[key + '_mf'], g[key + '_cf'], g[key + '_cfx'])
+        got = tf.apply_batch(f, means, covs, times.astype(float))
+        for i in range(means.shape[0]):
+            worst = max(worst, assert_moments_close([a[i] for a in got], [a[i] for a in ref], covs[i],
+                                                    what=(key, i, tf.kernel_name(f))))
+        # the drop-in single call (B = 1) returns fresh, writable arrays of the reference's shapes
+        mf, cf, cfx = tf.apply(f, means[3], covs[3], np.atleast_1d(times[3]))
+        assert mf.shape == (dout,) and cf.shape == (dout, dout) and cfx.shape == (dout, din)
+        cf += 1.0
+        assert_moments_close((mf, cf - 1.0, cfx), [a[3] for a in ref], covs[3], what=key)
+    print('{}: worst scaled error {:.2e}'.format(name, worst))
+
+
+@pytest.mark.parametrize('name', sorted(MODELS))
+def test_apply_generic_kernel_matches(amd, golden, name):
+    """The run-time-shape kernel (forced through an unusual state index / odd N) agrees with the oracle."""
+    g = golden('g3_apply')
+    fid, p, sidx, din, dout = MODELS[name]
+    mod, f = make_model(name)
+    means, covs, times = g[name + '_mean'], g[name + '_cov'], g[name + '_time']
+    if din > 3:
+        pytest.skip('GH-5 grid too large')
+    tf = amd.GaussHermiteTransform(din, 5)       # N = 5^D: no register-resident specialisation for D >= 2
+    pts, wm = orc.points_gh(din, 5), orc.weights_gh(din, 5)
+    got = tf.apply_batch(f, means, covs, times.astype(float))
+    for i in range(means.shape[0]):
+        ref = orc.apply_sigma(fid, means[i], covs[i], times[i], pts, wm, wm, p, sidx)
+        assert_moments_close([a[i] for a in got], ref, covs[i], what=(name, i, tf.kernel_name(f)))
+
+
+def test_apply_python_callable(amd, golden):
+    """Arbitrary Python integrand: device sigma points, host f, device reductions (bq/bqmtran.py:97-107 split)."""
+    g = golden('g3_apply')
+    name = 'reentry_dyn'
+    fid, p, sidx, din, dout = MODELS[name]
+    means, covs, times = g[name + '_mean'], g[name + '_cov'], g[name + '_time']
+
+    def f(x, par):
+        return orc.integrand(fid, x, par[0], p)      # a host callable the library knows nothing about
+    for tname in ('ut', 'gpq', 'tpq'):
+        key = '{}_{}'.format(name, tname)
+        tf = make_transform(amd, tname, din, dout, g if tname in BQ_TF else None, key)
+        for i in (0, 5):
+            got = tf.apply(f, means[i], covs[i], np.atleast_1d(times[i]))
+            ref = (g[key + '_mf'][i], g[key + '_cf'][i], g[key + '_cfx'][i])
+            assert_moments_close(got, ref, covs[i], what=(key, i))
+
+
+def test_not_positive_definite(amd):
+    from ssmtoybox_amd import ssmod as sm
+    tf = amd.UnscentedTransform(2)
+    f = sm.Pendulum2DTransition().dyn_eval
+    bad = np.array([[1.0, 2.0], [2.0, 1.0]])
+    with pytest.raises(np.linalg.LinAlgError):
+        tf.apply(f, np.zeros(2), bad, np.atleast_1d(0))
+    covs = np.stack([np.eye(2), bad, np.eye(2), -np.eye(2)])
+    mf, cf, cfx, st = tf.apply_batch(f, np.zeros((4, 2)), covs, 0.0, return_status=True)
+    assert list(st) == [0, 1, 0, 1]
+    assert np.all(np.isfinite(mf[[0, 2]])) and np.all(np.isnan(mf[[1, 3]])) and np.all(np.isnan(cf[1]))
+    with pytest.raises(np.linalg.LinAlgError):
+        tf.apply_batch(f, np.zeros((4, 2)), covs, 0.0)
+    # empty batch
+    mf, cf, cfx = tf.apply_batch(f, np.zeros((0, 2)), np.zeros((0, 2, 2)), 0.0)
+    assert mf.shape == (0, 2) and cf.shape == (0, 2, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', GP_CASES, ids=[c[0] for c in GP_CASES])
+def test_gp_weights_golden(amd, golden, case):
+    from ssmtoybox_amd.bq.bqkern import device_gp_weights
+    g = golden('g2_gp_weights')
+    tag, dim, ell, pstr, ppar = case
+    for aniso, alpha in ((False, 1.0), (True, 1.7)):
+        t = 'gp_' + tag + ('_aniso' if aniso else '')
+        if t + '_par' not in g:
+            continue
+        par = gp_par(dim, ell, alpha, aniso)
+        tf = amd.GaussianProcessTransform(dim, dim, par, 'rbf', pstr, ppar)
+        assert np.array_equal(tf.model.points, g[t + '_pts'])
+        cond = float(g[t + '_cond'])
+        tol1 = max(RTOL, 64 * cond * 2.2e-16)          # one application of K^-1
+        tol2 = max(RTOL, 8 * cond ** 2 * 2.2e-16)      # two (Wc = iK Q iK, variances)
+        assert rel_err(tf.model.q, g[t + '_q']) < 1e-13
+        assert rel_err(tf.model.Q, g[t + '_Q']) < 1e-13
+        assert rel_err(tf.model.R, g[t + '_R']) < 1e-13
+        assert rel_err(tf.model.iK, g[t + '_iK']) < tol1
+        assert rel_err(tf.wm, g[t + '_wm']) < tol1
+        assert rel_err(tf.Wcc, g[t + '_Wcc']) < tol1
+        assert rel_err(tf.Wc, g[t + '_Wc']) < tol2
+        assert np.array_equal(tf.Wc, tf.Wc.T)
+        assert abs(tf.model.model_var - g[t + '_mv']) < tol2 * max(1.0, abs(float(g[t + '_mv'])))
+        assert abs(tf.model.integral_var - g[t + '_iv']) < tol2
+        # theta-batched: every row of a (P, 1 + D) parameter matrix gets its own workgroup
+        pars = np.vstack([par, gp_par(dim, ell * 1.5, 1.0, aniso), par])
+        w = device_gp_weights(tf.model.points, pars)
+        assert np.array_equal(w['wm'][0], tf.wm) and np.array_equal(w['wm'][2], tf.wm)
+        assert np.array_equal(w['Wc'][0], tf.Wc) and not np.array_equal(w['wm'][1], tf.wm)
+
+
+def test_gp_weights_scaling_invariance(amd):
+    # tests/test_bqmtran.py:40-46 of the reference: exact equality
+    tf = amd.GaussianProcessTransform(3, 3, np.array([[1.0, 3.0, 3.0, 3.0]]))
+    wm, wc, wcc = tf.weights(np.array([[50.0, 3.0, 3.0, 3.0]]))
+    assert np.array_equal(wm, tf.wm) and np.array_equal(wc, tf.Wc) and np.array_equal(wcc, tf.Wcc)
+
+
+@pytest.mark.parametrize('case', BS_CASES, ids=[c[0] for c in BS_CASES])
+def test_bs_weights_golden(amd, golden, case):
+    g = golden('g2_bs_weights')
+    tag, dim, pstr, ppar, mi, ell = case
+    t = 'bs_' + tag
+    par = gp_par(dim, ell)
+    mi = g[t + '_mi']
+    tf = amd.BayesSardTransform(dim, dim, par, mi, pstr, ppar)
+    assert np.array_equal(tf.model.points, g[t + '_pts'])
+    tol = 1e-8
+    assert rel_err(tf.wm, g[t + '_wm']) < tol
+    assert rel_err(tf.Wc, g[t + '_Wc']) < tol
+    assert rel_err(tf.Wcc, g[t + '_Wcc']) < tol
+    assert abs(tf.model.model_var - g[t + '_mv']) < 1e-6 * max(1.0, abs(float(g[t + '_mv'])))
+    assert abs(tf.model.integral_var - g[t + '_iv']) < 1e-6
+
+
+def test_bs_reproduces_classical_rules(amd):
+    # the reference's known-answer tests (tests/test_bqmod.py:368-459) on the device path
+    one = np.array([[1.0, 1.0]])
+    tf = amd.BayesSardTransform(1, 1, one, np.array([[0, 1, 2]]), 'ut')
+    assert np.allclose(tf.wm, amd.UnscentedTransform.weights(1)[0])
+    tf = amd.BayesSardTransform(1, 1, one, np.array([[0, 1, 2, 3, 4]]), 'gh', {'degree': 5})
+    assert np.allclose(tf.wm, amd.GaussHermiteTransform.weights(1, 5))
+    two = np.array([[1.0, 1.0, 1.0]])
+    tf = amd.BayesSardTransform(2, 2, two, np.array([[0, 1, 0, 2, 0], [0, 0, 1, 0, 2]]), 'ut')
+    assert np.allclose(tf.wm, amd.UnscentedTransform.weights(2)[0])
+    mi = np.array([[0, 1, 0, 1, 2, 0, 1, 2, 2], [0, 0, 1, 1, 0, 2, 2, 1, 2]])
+    tf = amd.BayesSardTransform(2, 2, two, mi, 'gh', {'degree': 3})
+    assert np.allclose(tf.wm, amd.GaussHermiteTransform.weights(2, 3))
+    assert tf.model.model_var >= 0 and tf.model.integral_var >= 0
+    np.linalg.cholesky(tf.Wc)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the filter recursion around the path
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['ukf', 'ckf', 'ghkf', 'gpqkf', 'tpqkf', 'bsqkf'])
+def test_ungm_filter_golden(amd, golden, name):
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g4_filters')
+    y = g['ungm_y']                                    # (1, T, seeds)
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    par = np.array([[1.0, 3.0]])
+    mi = np.array([[0, 1, 2]])
+    alg = {'ukf': lambda: ssinf.UnscentedKalman(dyn, obs), 'ckf': lambda: ssinf.CubatureKalman(dyn, obs),
+           'ghkf': lambda: ssinf.GaussHermiteKalman(dyn, obs, deg=5),
+           'gpqkf': lambda: ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut'),
+           'tpqkf': lambda: ssinf.StudentProcessKalman(dyn, obs, par, par, 'rbf', 'ut'),
+           'bsqkf': lambda: ssinf.BayesSardKalman(dyn, obs, par, par, mi, mi, 'ut')}[name]()
+    fm, fP = alg.forward_pass_batch(y)                 # all seeds in one batch
+    k = 'ungm_' + name
+    assert rel_err(fm, g[k + '_fm']) < 1e-8, name      # 100 steps amplify weight round-off ~900x
+    assert rel_err(fP, g[k + '_fc']) < 1e-8, name
+    # the reference's one-trajectory interface
+    fm1, fP1 = alg.forward_pass(y[..., 0])
+    assert np.array_equal(fm1, fm[..., 0]) and np.array_equal(fP1, fP[..., 0])
+
+
+def test_reentry_ukf_golden(amd, golden):
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g4_filters')
+    y = g['rer_y']
+    dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, g['rer_m0'], g['rer_P0']), sm.GaussRV(3, cov=g['rer_Q']))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=g['rer_R']), 5)
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    fm, fP = alg.forward_pass_batch(y)
+    assert rel_err(fm, g['rer_ukf_fm']) < 1e-9
+    assert rel_err(fP, g['rer_ukf_fc']) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full-size batches (BASELINE.json configs): oracle on a sample + size-independent properties
+# ---------------------------------------------------------------------------------------------------------------
+def synthetic_reentry6(B, seed=2):
+    """reentry-shaped 6-D batch."""
+    rng = np.random.default_rng(seed)
+    m0 = np.array([6500.4, 349.14, -1.8093, -6.7967, 0.6932, 0.0])
+    p0 = np.array([1e-6, 1e-6, 1e-6, 1e-6, 1.0, 1e-2])
+    means = m0 + rng.standard_normal((B, 6)) * np.sqrt(p0)
+    a = rng.standard_normal((B, 6, 6)) / np.sqrt(6)
+    s = np.sqrt(p0)
+    covs = np.einsum('i,bij,bkj,k->bik', s, a, a, s) + 1e-6 * np.diag(p0)
+    return means, 0.5 * (covs + covs.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize('ell', [3.0, 25.0])
+def test_gpq_d6_full_batch(amd, ell):
+    from ssmtoybox_amd import ssmod as sm
+    B = 100000
+    means, covs = synthetic_reentry6(B)
+    par = gp_par(6, ell)
+    tf = amd.GaussianProcessTransform(6, 6, par, 'rbf', 'ut')
+    w = orc.gp_weights(par, orc.points_ut(6))
+    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']   # identical weights
+    f = sm.ReentryVehicle2DBiasTransition(dt=0.1).dyn_eval
+    assert 'k_apply_small<D=6,E=6,N=13' in tf.kernel_name(f)
+    mf, cf, cfx, st = tf.apply_batch(f, means, covs, 0.0, return_status=True)
+    assert not st.any() and np.all(np.isfinite(cf))
+    assert np.array_equal(cf, cf.transpose(0, 2, 1))
+    # oracle on a sample of the batch
+    idx = np.random.default_rng(5).choice(B, 200, replace=False)
+    for i in idx:
+        ref = orc.apply_bq(orc.F_REENTRY2D_BIAS_DYN, means[i], covs[i], 0, orc.points_ut(6), w, (0.1,))
+        assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=('d6', ell, i))
+    # properties: trajectories are independent (a permuted batch gives the permuted result, bit for bit) ...
+    perm = np.random.default_rng(6).permutation(B)[:4096]
+    mf2, cf2, cfx2 = tf.apply_batch(f, means[perm], covs[perm], 0.0)
+    assert np.array_equal(mf2, mf[perm]) and np.array_equal(cf2, cf[perm]) and np.array_equal(cfx2, cfx[perm])
+    # ... and the pass-through sixth state is integrated exactly when sum(wm) = 1:  E[x6] = m6 sum(wm) + L6. xi wm
+    pts = orc.points_ut(6)
+    chol = np.linalg.cholesky(covs[:1000])
+    x6 = means[:1000, 5, None] + np.einsum('bk,kn->bn', chol[:, 5, :], pts)
+    assert np.allclose(mf[:1000, 5], x6.dot(w['wm']), rtol=1e-12, atol=1e-14)
+
+
+def test_ungm_gpq_full_batch(amd):
+    """Config C2 shape: D = 1, N = 3, B = 1e4, per-trajectory time index."""
+    from ssmtoybox_amd import ssmod as sm
+    B = 10000
+    rng = np.random.default_rng(1)
+    means = rng.standard_normal((B, 1)) * 3
+    covs = (0.1 + rng.random((B, 1, 1)) * 5)
+    times = rng.integers(0, 100, B).astype(float)
+    par = np.array([[1.0, 3.0]])
+    tf = amd.GaussianProcessTransform(1, 1, par)
+    w = orc.gp_weights(par, orc.points_ut(1))
+    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
+    for mod, fid in ((sm.UNGMTransition(), orc.F_UNGM_DYN), (sm.UNGMMeasurement(sm.GaussRV(1), 1), orc.F_UNGM_MEAS)):
+        f = mod.dyn_eval if fid == orc.F_UNGM_DYN else mod.meas_eval
+        mf, cf, cfx = tf.apply_batch(f, means, covs, times)
+        for i in range(0, B, 37):
+            ref = orc.apply_bq(fid, means[i], covs[i], times[i], orc.points_ut(1), w)
+            assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=('ungm', fid, i))
+
+
+def test_bsq_d10(amd, golden):
+    """Config C5 shapes: D = E = 10 with N = 21 (unisolvent UT) and N = 201 (fully-symmetric degree 5)."""
+    g = golden('g2_bs_weights')
+    rng = np.random.default_rng(9)
+    B = 64
+    means = rng.standard_normal((B, 10))
+    a = rng.standard_normal((B, 10, 10)) / np.sqrt(10)
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(10)
+
+    def f(x, par):                                        # smooth 10-D test integrand, evaluated on the host
+        return np.concatenate((np.sin(x[:5]) + x[5:] ** 2, x[5:] * np.cos(x[:5])))
+    for tag, pstr, ppar in (('d10_ut', 'ut', None), ('d10_fs5_td2', 'fs', {'degree': 5})):
+        t = 'bs_' + tag
+        tf = amd.BayesSardTransform(10, 10, gp_par(10, 3.0), g[t + '_mi'], pstr, ppar)
+        w = dict(wm=g[t + '_wm'], Wc=g[t + '_Wc'], Wcc=g[t + '_Wcc'], model_var=float(g[t + '_mv']))
+        tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
+        mf, cf, cfx = tf.apply_batch(f, means, covs, 0.0)
+        pts = g[t + '_pts']
+        for i in range(0, B, 7):
+            chol = np.linalg.cholesky(covs[i])
+            fx = np.apply_along_axis(f, 0, means[i][:, None] + chol.dot(pts), None)
+            ref = orc.moments_bq(fx, chol, w['wm'], w['Wc'], w['Wcc'], w['model_var'])
+            assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=(tag, i))
