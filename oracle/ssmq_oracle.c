@@ -12,7 +12,7 @@
  *   SigmaPointTransform.apply                                 mtran.py:105-149
  *   integrands                                                ssmod.py (lines cited at each case)
  *   GaussianInference._time_update / _measurement_update      ssinf.py:254-323, forward_pass ssinf.py:66-118
- * Pinned in tests/test_oracle_c.py against the golden vectors generated from the reference (tests/golden/*.npz) and
+ * Pinned in tests/test_oracle_c.py against the golden vectors generated from the reference (the .npz fixtures under tests/golden) and
  * against the NumPy oracle.  All arithmetic is IEEE fp64; compile WITHOUT -ffast-math.
  */
 #include <math.h>

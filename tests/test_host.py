@@ -1,0 +1,126 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports every symbol include/ssmq.h declares, the
+host logic (point sets, multi-indices, integrand descriptors, model formulas) matches the reference's golden vectors,
+and every compute entry point fails loudly without a GPU (no CPU fallback).  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import ssmq_oracle as orc
+from tests._cases import MODELS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    from ssmtoybox_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'ssmq.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(ssmq_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 30
+    lib = _lib.load()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.ssmq_version() == 100
+
+
+def test_integrand_struct_layout():
+    from ssmtoybox_amd import _lib
+    # struct ssmq_integrand: 4 int32 + 16 doubles + 8 int32 = 176 bytes
+    assert ctypes.sizeof(_lib.Integrand) == 16 + 8 * 16 + 4 * 8
+    s = _lib.Integrand.make(12, (1.0, 2.0, 3.0, 4.0), (0, 2))
+    assert (s.id, s.n_par, s.n_idx, s.par[3], s.idx[1]) == (12, 4, 2, 4.0, 2)
+    with pytest.raises(ValueError):
+        _lib.Integrand.make(1, range(17))
+
+
+def test_integrand_ids_match_oracle_numbering():
+    from ssmtoybox_amd import _lib
+    for name in dir(orc):
+        if name.startswith('F_'):
+            assert getattr(_lib, name) == getattr(orc, name), name
+
+
+def test_point_sets_golden(golden):
+    import ssmtoybox_amd as amd
+    g = golden('g1_points')
+    for d in (1, 2, 3, 5, 6, 10):
+        for kappa in (None, 0.0, 2.0):
+            tag = 'ut_d{}_k{}'.format(d, 'none' if kappa is None else int(kappa))
+            assert np.array_equal(amd.UnscentedTransform.unit_sigma_points(d, kappa=kappa), g[tag + '_pts'])
+            wm, wc = amd.UnscentedTransform.weights(d, kappa=kappa)
+            assert np.array_equal(wm, g[tag + '_wm']) and np.array_equal(wc, g[tag + '_wc'])
+        assert np.array_equal(amd.SphericalRadialTransform.unit_sigma_points(d), g['sr_d{}_pts'.format(d)])
+        assert np.array_equal(amd.SphericalRadialTransform.weights(d), g['sr_d{}_w'.format(d)])
+        for deg in (3, 5):
+            fs = amd.FullySymmetricStudentTransform
+            assert np.array_equal(fs.unit_sigma_points(d, degree=deg), g['fs_d{}_deg{}_pts'.format(d, deg)])
+            assert np.allclose(fs.weights(d, degree=deg), g['fs_d{}_deg{}_w'.format(d, deg)], rtol=1e-13, atol=0)
+        assert np.array_equal(fs.unit_sigma_points(d, 5, None, 7.0), g['fs_d{}_deg5_dof7_pts'.format(d)])
+        assert np.array_equal(fs.unit_sigma_points(d, 3, 1.0, 6.0), g['fs_d{}_deg3_k1_pts'.format(d)])
+    for d, degs in ((1, (3, 5, 7)), (2, (3, 5, 7)), (3, (3, 5)), (5, (3,))):
+        for deg in degs:
+            gh = amd.GaussHermiteTransform
+            assert np.array_equal(gh.unit_sigma_points(d, deg), g['gh_d{}_deg{}_pts'.format(d, deg)])
+            assert np.allclose(gh.weights(d, deg), g['gh_d{}_deg{}_w'.format(d, deg)], rtol=1e-13, atol=0)
+    from ssmtoybox_amd.bq.bqmod import n_sum_k
+    for n, k in ((1, 0), (1, 2), (2, 2), (3, 2), (3, 3), (5, 2), (10, 2)):
+        assert np.array_equal(n_sum_k(n, k), g['nsumk_{}_{}'.format(n, k)])
+
+
+def test_transform_objects_have_reference_attributes():
+    import ssmtoybox_amd as amd
+    ut = amd.UnscentedTransform(3, kappa=1.0)
+    assert isinstance(ut, amd.MomentTransform) and ut.unit_sp.shape == (3, 7) and ut.Wc.shape == (7, 7)
+    assert np.array_equal(np.diag(ut.Wc), ut.wc) and np.isclose(ut.wm.sum(), 1.0)
+    for cls, n in ((amd.SphericalRadialTransform, 6), (amd.FullySymmetricStudentTransform, 7)):
+        t = cls(3)
+        assert t.unit_sp.shape == (3, n) and t.Wc.shape == (n, n) and np.isclose(t.wm.sum(), 1.0)
+    gh = amd.GaussHermiteTransform(2, degree=5)
+    assert gh.unit_sp.shape == (2, 25) and np.isclose(gh.wm.sum(), 1.0)
+
+
+def test_model_host_formulas_match_oracle():
+    """The NumPy evaluation the model classes offer to callers is the same formula as the oracle's integrand table."""
+    from tests.test_gpu_parity import make_model
+    rng = np.random.default_rng(4)
+    for name, (fid, p, sidx, din, dout) in MODELS.items():
+        mod, f = make_model(name)
+        integ, e = mod.device_integrand()
+        assert integ.id == fid and e == dout
+        assert [integ.par[i] for i in range(integ.n_par)] == [float(v) for v in p]
+        x = rng.standard_normal(din) + (np.array([6500.0, 350.0, -1.8, -6.8, 0.7]) if 'reentry_' in name and din == 5
+                                        else 0.0)
+        ref = orc.integrand(fid, x if sidx is None else x[list(sidx)], 3, p)
+        assert np.allclose(np.atleast_1d(f(x, 3)), ref, rtol=1e-14, atol=0), name
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every compute entry point raises; nothing silently computes on the host."""
+    import ssmtoybox_amd as amd
+    from ssmtoybox_amd import ssmod, _lib
+    if amd.device_count() > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(amd.SsmqError):
+        amd.GaussianProcessTransform(1, 1, np.array([[1.0, 3.0]]))
+    with pytest.raises(amd.SsmqError):
+        amd.BayesSardTransform(1, 1, np.array([[1.0, 3.0]]), np.array([[0, 1, 2]]))
+    ut = amd.UnscentedTransform(1)
+    with pytest.raises(amd.SsmqError):
+        ut.apply(ssmod.UNGMTransition().dyn_eval, np.zeros(1), np.eye(1), np.atleast_1d(0))
+    with pytest.raises(amd.SsmqError):
+        ut.apply(lambda x, t: x, np.zeros(1), np.eye(1), np.atleast_1d(0))
+    with pytest.raises(amd.SsmqError):
+        _lib.SoA.from_host(np.zeros((4, 2)))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under ssmtoybox_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'ssmtoybox_amd')):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert 'ssmq_oracle' not in src and 'from oracle' not in src and 'import oracle' not in src, fn
