@@ -632,6 +632,28 @@ int launch_kalman_update_ex(int D, int Y, int64_t B, int64_t ld, const double *m
                             int step, hipStream_t s);
 }
 
+namespace {
+// Grow-only device workspace + captured launch sequence of the filter loop, kept between calls so that a repeated
+// forward pass (Monte-Carlo studies, bench.py) neither allocates nor pays 3 T kernel-launch latencies: the whole time
+// loop is replayed as one hipGraph while the argument set is unchanged.
+struct FilterCache {
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<uint64_t> key;
+    std::vector<double> gqg, rr;
+    void drop_graph() {
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph) hipGraphDestroy(graph);
+        exec = nullptr;
+        graph = nullptr;
+        key.clear();
+    }
+};
+FilterCache g_fc;
+}  // namespace
+
 extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
                                        const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                                        const double *d_m0, const double *d_P0, const double *GQG, const double *R,
@@ -650,36 +672,82 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
     if (rc) return rc;
     if (B == 0 || T == 0) return SSMQ_OK;
     hipStream_t s = stream();
-    DevBuf m_pr, P_pr, C_xx, y_mean, P_y, P_yx, tvec, gqg, rr, st_a, st_b;
-    if ((rc = m_pr.alloc(sizeof(double) * ld * D)) || (rc = P_pr.alloc(sizeof(double) * ld * D * D)) ||
-        (rc = C_xx.alloc(sizeof(double) * ld * D * D)) || (rc = y_mean.alloc(sizeof(double) * ld * Y)) ||
-        (rc = P_y.alloc(sizeof(double) * ld * Y * Y)) || (rc = P_yx.alloc(sizeof(double) * ld * Y * D)) ||
-        (rc = tvec.alloc(sizeof(double) * T)) || (rc = gqg.alloc(sizeof(double) * D * D)) ||
-        (rc = rr.alloc(sizeof(double) * Y * Y)) || (rc = st_a.alloc(sizeof(int32_t) * ld)) ||
-        (rc = st_b.alloc(sizeof(int32_t) * ld)))
-        return rc;
-    std::vector<double> tv(T), zg(D * D, 0.0), zr(Y * Y, 0.0);
-    for (int k = 0; k < T; ++k) tv[k] = (double)k;  // both transforms of step k use time index k - 1 (ssinf.py:104)
-    SSMQ_HIP(hipMemcpyAsync(tvec.p, tv.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(gqg.p, GQG ? GQG : zg.data(), sizeof(double) * D * D, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(rr.p, R ? R : zr.data(), sizeof(double) * Y * Y, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, s));
-    SSMQ_HIP(hipStreamSynchronize(s));  // host staging vectors go out of scope only after this call returns anyway
-    for (int k = 0; k < T; ++k) {
-        const double *m_in = k == 0 ? d_m0 : d_fm + (int64_t)(k - 1) * D * ld;
-        const double *P_in = k == 0 ? d_P0 : d_fP + (int64_t)(k - 1) * D * D * ld;
-        rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec.d() + k, 0, m_pr.d(), P_pr.d(), C_xx.d(),
-                            (int32_t *)st_a.p, gqg.d(), nullptr, false);
-        if (rc) return rc;
-        rc = apply_dev_impl(h_obs, f_obs, B, ld, m_pr.d(), P_pr.d(), tvec.d() + k, 0, y_mean.d(), P_y.d(), P_yx.d(),
-                            (int32_t *)st_b.p, rr.d(), nullptr, false);
-        if (rc) return rc;
-        rc = launch_kalman_update_ex(D, Y, B, ld, m_pr.d(), P_pr.d(), y_mean.d(), P_y.d(), P_yx.d(),
-                                     d_y + (int64_t)k * Y * ld, d_fm + (int64_t)k * D * ld,
-                                     d_fP + (int64_t)k * D * D * ld, d_status, (const int32_t *)st_a.p,
-                                     (const int32_t *)st_b.p, k, s);
-        if (rc) return rc;
+    // workspace carve-up (doubles first, then the two int32 status planes)
+    const size_t n_dbl = (size_t)ld * (D + 2 * D * D + Y + Y * Y + Y * D) + (size_t)T + D * D + Y * Y;
+    const size_t need = sizeof(double) * n_dbl + 2 * sizeof(int32_t) * (size_t)ld;
+    if (g_fc.ws_bytes < need) {
+        g_fc.drop_graph();
+        if (g_fc.ws) hipFree(g_fc.ws);
+        g_fc.ws = nullptr;
+        g_fc.ws_bytes = 0;
+        SSMQ_HIP(hipMalloc(&g_fc.ws, need));
+        g_fc.ws_bytes = need;
     }
-    SSMQ_HIP(hipStreamSynchronize(s));
+    double *w = (double *)g_fc.ws;
+    double *m_pr = w; w += (size_t)ld * D;
+    double *P_pr = w; w += (size_t)ld * D * D;
+    double *C_xx = w; w += (size_t)ld * D * D;
+    double *y_mean = w; w += (size_t)ld * Y;
+    double *P_y = w; w += (size_t)ld * Y * Y;
+    double *P_yx = w; w += (size_t)ld * Y * D;
+    double *tvec = w; w += T;
+    double *gqg = w; w += D * D;
+    double *rr = w; w += Y * Y;
+    int32_t *st_a = (int32_t *)w, *st_b = st_a + ld;
+
+    std::vector<double> hg(D * D, 0.0), hr(Y * Y, 0.0);
+    if (GQG) hg.assign(GQG, GQG + D * D);
+    if (R) hr.assign(R, R + Y * Y);
+    std::vector<uint64_t> key = {(uint64_t)(uintptr_t)h_dyn, (uint64_t)(uintptr_t)h_obs, (uint64_t)B, (uint64_t)ld,
+                                 (uint64_t)T, (uint64_t)(uintptr_t)d_y, (uint64_t)(uintptr_t)d_m0,
+                                 (uint64_t)(uintptr_t)d_P0, (uint64_t)(uintptr_t)d_fm, (uint64_t)(uintptr_t)d_fP,
+                                 (uint64_t)(uintptr_t)d_status, (uint64_t)(uintptr_t)h_dyn->d_small,
+                                 (uint64_t)(uintptr_t)g_fc.ws};
+    const unsigned char *fb = (const unsigned char *)f_dyn;
+    for (size_t i = 0; i + 8 <= sizeof(ssmq_integrand); i += 8) { uint64_t v; memcpy(&v, fb + i, 8); key.push_back(v); }
+    fb = (const unsigned char *)f_obs;
+    for (size_t i = 0; i + 8 <= sizeof(ssmq_integrand); i += 8) { uint64_t v; memcpy(&v, fb + i, 8); key.push_back(v); }
+    key.push_back((uint64_t)h_dyn->emv_mode * 2 + (uint64_t)h_obs->emv_mode);
+    key.push_back(((uint64_t)D << 48) | ((uint64_t)Y << 32) | ((uint64_t)h_dyn->N << 16) | (uint64_t)h_obs->N);
+    key.push_back(((uint64_t)h_dyn->form << 1) | (uint64_t)h_obs->form);
+    key.push_back((uint64_t)(uintptr_t)h_obs->d_small);
+    { uint64_t v; memcpy(&v, &h_dyn->tp_nu, 8); key.push_back(v); memcpy(&v, &h_obs->tp_nu, 8); key.push_back(v); }
+
+    if (!(g_fc.exec && g_fc.key == key && g_fc.gqg == hg && g_fc.rr == hr)) {
+        g_fc.drop_graph();
+        std::vector<double> tv(T);
+        for (int k = 0; k < T; ++k) tv[k] = (double)k;  // both transforms of step k + 1 use time index k (ssinf.py:104)
+        SSMQ_HIP(hipMemcpyAsync(tvec, tv.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(gqg, hg.data(), sizeof(double) * D * D, hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(rr, hr.data(), sizeof(double) * Y * Y, hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipStreamSynchronize(s));
+        SSMQ_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        rc = hip_fail(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, s), "hipMemsetAsync");
+        for (int k = 0; k < T && !rc; ++k) {
+            const double *m_in = k == 0 ? d_m0 : d_fm + (int64_t)(k - 1) * D * ld;
+            const double *P_in = k == 0 ? d_P0 : d_fP + (int64_t)(k - 1) * D * D * ld;
+            rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec + k, 0, m_pr, P_pr, C_xx, st_a, gqg, nullptr, false);
+            if (!rc)
+                rc = apply_dev_impl(h_obs, f_obs, B, ld, m_pr, P_pr, tvec + k, 0, y_mean, P_y, P_yx, st_b, rr, nullptr,
+                                    false);
+            if (!rc)
+                rc = launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, d_y + (int64_t)k * Y * ld,
+                                             d_fm + (int64_t)k * D * ld, d_fP + (int64_t)k * D * D * ld, d_status,
+                                             st_a, st_b, k, s);
+        }
+        hipGraph_t g = nullptr;
+        hipError_t ce = hipStreamEndCapture(s, &g);
+        if (rc) {
+            if (g) hipGraphDestroy(g);
+            return rc;
+        }
+        SSMQ_HIP(ce);
+        g_fc.graph = g;
+        SSMQ_HIP(hipGraphInstantiate(&g_fc.exec, g_fc.graph, nullptr, nullptr, 0));
+        g_fc.key = key;
+        g_fc.gqg = hg;
+        g_fc.rr = hr;
+    }
+    SSMQ_HIP(hipGraphLaunch(g_fc.exec, s));
     return SSMQ_OK;
 }
