@@ -90,8 +90,11 @@ class UngmFilterBench:
         self.h_obs = self.alg.tf_obs._handle_for(1)
         self.gqg, self.pg = _lib.as_c(np.array([[10.0]]))
         self.rr, self.pr = _lib.as_c(np.array([[1.0]]))
-        self.kernels = [self.alg.tf_dyn.kernel_name(dyn.dyn_eval), self.alg.tf_obs.kernel_name(obs.meas_eval),
-                        'k_kalman_update<1,1>']
+        buf = ctypes.create_string_buffer(512)
+        _lib.check(_lib.load().ssmq_filter_kernel_name(ctypes.c_void_p(self.h_dyn), ctypes.byref(self.f_dyn),
+                                                       ctypes.c_void_p(self.h_obs), ctypes.byref(self.f_obs), buf, 512),
+                   'ssmq_filter_kernel_name')
+        self.kernel = buf.value.decode()
 
     def step(self):
         lib = self._lib.load()
@@ -178,13 +181,14 @@ class Mt6Bench:
         return float(worst)
 
 
-def cpu_baseline_ungm(B, T, seed, budget_s=12.0):
-    """The oracle's C restatement of the same filter pass on the host cores (kind "port"), bounded to ~budget_s."""
+def cpu_baseline_ungm(B, T, seed, tf, budget_s=12.0, max_threads=16):
+    """The oracle's C restatement of the same filter pass on the host cores (kind "port"), bounded to ~budget_s.
+    It is handed the very weights the GPU run used (tf.wm / Wc / Wcc / model_var as produced by the HIP weights kernel),
+    so the cross-check below compares the filter arithmetic, not two evaluations of an ill-conditioned inverse."""
     from oracle import ssmq_oracle as orc
     from oracle import c_oracle as co
-    par = np.array([1.0, 3.0])
     pts = orc.points_ut(1)
-    w = orc.gp_weights(par, pts)
+    w = dict(wm=tf.wm, Wc=tf.Wc, Wcc=tf.Wcc, model_var=tf.model.model_var)
     one = np.ones((1, 1))
     td, k1 = co.make_transform(0, 1, 1, pts, w['wm'], w['Wc'], w['Wcc'], w['model_var'] * one,
                                integrand=co.Integrand.make(orc.F_UNGM_DYN))
@@ -194,7 +198,7 @@ def cpu_baseline_ungm(B, T, seed, budget_s=12.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = min(cores, co.max_threads())
+    cores = min(cores, co.max_threads(), max_threads)   # a 1-GPU box's CPU share is 16 cores
     _, y = simulate_ungm(B, T, seed)
     yb = np.ascontiguousarray(y.T[:, :, None])
     t0 = time.perf_counter()
@@ -292,7 +296,7 @@ def main():
                        'mc_per_gpu': B, 'time_steps': T, 'parallelism': 'mc-shard x{}'.format(world)},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'filter pass = hipGraph of {} launches: {}'.format(3 * T, ' | '.join(wl.kernels)),
+                         'kernel': wl.kernel,
                          'bytes_per_launch': bytes_pass, 'ms_per_launch': pass_ms_dev,
                          'note': 'fp64-ALU / latency bound at B=1e4 (157 waves on 1024 SIMDs), not HBM bound: '
                                  'SURVEY.md 7-4'},
@@ -309,7 +313,7 @@ def main():
                                'transforms_per_s': mt.B / (ms * 1e-3), 'max_scaled_err_vs_oracle': err,
                                'workload': 'batched GPQ moment transform, D=E=6, N=13, B=1e5, 4 rotating buffer sets'}
     if rank == 0 and not args.no_cpu_baseline:
-        cb, (cpu_fm, cpu_st) = cpu_baseline_ungm(B, T, seed=1 + rank)
+        cb, (cpu_fm, cpu_st) = cpu_baseline_ungm(B, T, seed=1 + rank, tf=wl.alg.tf_dyn)
         out['cpu_baseline'] = cb
         # the GPU pass and the CPU port ran the same trajectories: cross-check them
         good = (st == 0) & (cpu_st == 0)

@@ -208,11 +208,17 @@ int ssmq_kalman_update_dev(int D, int Y, int64_t B, int64_t ld, const double *d_
  * per step k = 1..T: dyn transform at time k-1, += GQG', obs transform at time k-1, += R, measurement update.
  *   d_y [T][Y][ld]; d_m0 [D][ld], d_P0 [D*D][ld] (read only); GQG [D*D], R [Y*Y] host;
  *   outputs d_fm [T][D][ld], d_fP [T][D*D][ld]; d_status [ld] (0 ok, else 1 + first failing step).
+ * Asynchronous on the library stream.  Common (models, shape, form) combinations run as ONE fused kernel with the
+ * filter state in registers; every other combination replays the 3 T launches of the loop as a hipGraph.
  */
 int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
                             const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                             const double *d_m0, const double *d_P0, const double *GQG, const double *R,
                             double *d_fm, double *d_fP, int32_t *d_status);
+
+/* Name of the kernel(s) ssmq_filter_forward_dev would run for this pair of transforms (for profiles). */
+int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
+                            const ssmq_integrand *f_obs, char *buf, int len);
 
 #ifdef __cplusplus
 }

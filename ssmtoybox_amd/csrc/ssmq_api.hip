@@ -1,6 +1,7 @@
 // C ABI of libssmq (include/ssmq.h): device plumbing, transform handles, kernel dispatch.  No CPU fallback exists
 // behind these entry points: every compute call ends in a HIP kernel launch or returns an error.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -632,6 +633,13 @@ int launch_kalman_update_ex(int D, int Y, int64_t B, int64_t ld, const double *m
                             int step, hipStream_t s);
 }
 
+namespace ssmq {
+int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho,
+                     const ssmq_integrand *fo, int sel_obs, int64_t B, int64_t ld, int T, const double *d_y,
+                     const double *d_m0, const double *d_P0, const double *d_gqg, const double *d_rr, double *d_fm,
+                     double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run);
+}
+
 namespace {
 // Grow-only device workspace + captured launch sequence of the filter loop, kept between calls so that a repeated
 // forward pass (Monte-Carlo studies, bench.py) neither allocates nor pays 3 T kernel-launch latencies: the whole time
@@ -643,6 +651,8 @@ struct FilterCache {
     hipGraphExec_t exec = nullptr;
     std::vector<uint64_t> key;
     std::vector<double> gqg, rr;
+    int T = -1;
+    bool consts_ok = false;
     void drop_graph() {
         if (exec) hipGraphExecDestroy(exec);
         if (graph) hipGraphDestroy(graph);
@@ -677,6 +687,7 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
     const size_t need = sizeof(double) * n_dbl + 2 * sizeof(int32_t) * (size_t)ld;
     if (g_fc.ws_bytes < need) {
         g_fc.drop_graph();
+        g_fc.consts_ok = false;
         if (g_fc.ws) hipFree(g_fc.ws);
         g_fc.ws = nullptr;
         g_fc.ws_bytes = 0;
@@ -713,7 +724,7 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
     key.push_back((uint64_t)(uintptr_t)h_obs->d_small);
     { uint64_t v; memcpy(&v, &h_dyn->tp_nu, 8); key.push_back(v); memcpy(&v, &h_obs->tp_nu, 8); key.push_back(v); }
 
-    if (!(g_fc.exec && g_fc.key == key && g_fc.gqg == hg && g_fc.rr == hr)) {
+    if (!(g_fc.consts_ok && g_fc.gqg == hg && g_fc.rr == hr && g_fc.T == T)) {
         g_fc.drop_graph();
         std::vector<double> tv(T);
         for (int k = 0; k < T; ++k) tv[k] = (double)k;  // both transforms of step k + 1 use time index k (ssinf.py:104)
@@ -721,6 +732,25 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
         SSMQ_HIP(hipMemcpyAsync(gqg, hg.data(), sizeof(double) * D * D, hipMemcpyHostToDevice, s));
         SSMQ_HIP(hipMemcpyAsync(rr, hr.data(), sizeof(double) * Y * Y, hipMemcpyHostToDevice, s));
         SSMQ_HIP(hipStreamSynchronize(s));
+        g_fc.gqg = hg;
+        g_fc.rr = hr;
+        g_fc.T = T;
+        g_fc.consts_ok = true;
+    }
+    // one fused kernel for the whole time loop when this (models, shapes, form) combination has one
+    if (!getenv("SSMQ_NO_FUSED")) {
+        FInfo fio;
+        if (!integrand_info(f_obs->id, &fio)) {
+            set_error("unknown integrand id");
+            return SSMQ_E_ARG;
+        }
+        rc = try_launch_fused(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), B, ld, T, d_y, d_m0, d_P0, gqg,
+                              rr, d_fm, d_fP, d_status, s, nullptr, false);
+        if (rc < 0) return rc;
+        if (rc == 1) return SSMQ_OK;
+    }
+    if (!(g_fc.exec && g_fc.key == key)) {
+        g_fc.drop_graph();
         SSMQ_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         rc = hip_fail(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, s), "hipMemsetAsync");
         for (int k = 0; k < T && !rc; ++k) {
@@ -745,9 +775,22 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
         g_fc.graph = g;
         SSMQ_HIP(hipGraphInstantiate(&g_fc.exec, g_fc.graph, nullptr, nullptr, 0));
         g_fc.key = key;
-        g_fc.gqg = hg;
-        g_fc.rr = hr;
     }
     SSMQ_HIP(hipGraphLaunch(g_fc.exec, s));
+    return SSMQ_OK;
+}
+
+extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,
+                                       const ssmq_transform *h_obs, const ssmq_integrand *f_obs, char *buf, int len) {
+    if (!h_dyn || !h_obs || !f_dyn || !f_obs || !buf || len <= 0) return SSMQ_E_ARG;
+    FInfo fio;
+    if (!integrand_info(f_obs->id, &fio)) return SSMQ_E_ARG;
+    const char *name = nullptr;
+    int rc = getenv("SSMQ_NO_FUSED") ? 0
+                                     : try_launch_fused(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), 0, 0, 0,
+                                                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                        nullptr, nullptr, &name, true);
+    if (rc < 0) return rc;
+    snprintf(buf, len, "%s", rc == 1 ? name : "hipGraph of 3 T launches (apply dyn | apply obs | k_kalman_update)");
     return SSMQ_OK;
 }

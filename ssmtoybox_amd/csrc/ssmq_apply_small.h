@@ -2,7 +2,8 @@
 //
 // HBM layout: SoA planes [element][ld]; lane b of a wave reads element e at ptr[e*ld + b], so every global access of a
 // wave is one contiguous 512-byte segment.  Per trajectory the kernel reads D + D(D+1)/2 doubles and writes
-// E + E*E + E*D doubles; the transform constants (xi, wm, Wc, Wcc, emv, iK) are read with wave-uniform addresses
+// E + E*E + E*D doubles; the transform constants (xi', wm, Wc', Wcc', emv, iK' - stored TRANSPOSED so that what one
+// unrolled body consumes is contiguous: point n's D coordinates, column j of Wc) are read with wave-uniform addresses
 // (scalar loads, scalar cache / L2 resident) and never count towards per-trajectory traffic.
 //
 // Algorithm per trajectory (bq/bqmtran.py:60-109, 158-223; mtran.py:105-149):
@@ -10,6 +11,10 @@
 //   BQ form:    mean_f = fx wm; cov_f = (fx Wc) fx' - mean_f mean_f' + emv (+ cov_add); cov_fx = (fx Wcc') L'
 //   SIGMA form: mean_f = fx wm; dfx = fx - mean_f; cov_f = dfx diag(wc) dfx'; cov_fx = dfx diag(wc) (x - mean)'
 //   TP:         emv_e = (nu - 2 + fx_e iK fx_e') / (nu - 2 + N) * emv_e   (bq/bqmod.py:1132-1160)
+//
+// The arithmetic lives in moment_transform_core<>, parameterised by a "sink" that receives every result element in
+// registers: the stand-alone kernel's sink stores straight to the SoA planes, the fused filter loop
+// (ssmq_filter_fused.h) keeps the results in registers for the next stage.
 #pragma once
 #include "ssmq_device.h"
 
@@ -21,10 +26,17 @@ constexpr int kSmallBlock = 64;
 // live ranges of all N bodies overlap and the D = 6 kernel needs > 512 registers (170 spills).
 #define SSMQ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// Hides the constant-block base pointer from value numbering so that loads repeated in successive unrolled bodies are
+// re-issued (cheap scalar-cache hits) instead of being merged into one long-lived SGPR set that has to be spilled.
+__device__ __forceinline__ cdouble_p launder(cdouble_p p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // Sub-state selection (MeasurementModel.state_index, ssmod.py:990-991) is a compile-time pattern here: a run-time
 // index would need 2*D*DIN scalar condition masks live across the whole kernel.  SEL 0: the leading entries (the
-// default, state_index=None); SEL 1: entries (0, 2) (position components of [x, vx, y, vy, ...] states, the only other
-// pattern the reference's tests and research scripts use).  Anything else runs on the generic kernel.
+// default, state_index=None); SEL 1: entries (0, 2, ...) (position components of [x, vx, y, vy, ...] states, the only
+// other pattern the reference's tests and research scripts use).  Anything else runs on the generic kernel.
 template <int D, int DIN, int SEL>
 __device__ __forceinline__ void select_inputs(const double (&x)[D], double (&xs)[DIN]) {
 #pragma unroll
@@ -34,40 +46,65 @@ __device__ __forceinline__ void select_inputs(const double (&x)[D], double (&xs)
     }
 }
 
-template <int D, int E, int N, int F, int FORM, int TP, int SEL>
-__global__ __launch_bounds__(kSmallBlock) void k_apply_small(const ApplyArgs a) {
-    const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;  // 32-bit lane offset: plane base stays scalar
-    if ((int64_t)b >= a.B) return;
-    const int64_t ld = a.ld;
-    const cdouble_p c = (cdouble_p)a.consts;
-    const cdouble_p cadd = (cdouble_p)a.cov_add;
+// Software prefetch of wave-uniform constants.  The unrolled bodies are fenced from each other (SSMQ_SCHED_FENCE), so
+// without help every body would start by waiting for its own scalar loads.  Instead body r issues the loads of body
+// r + 1 at its top and pins them at its bottom (an empty asm that needs the values in SGPRs forces the s_waitcnt there,
+// after the arithmetic of body r has covered the scalar-cache latency).
+template <int CNT>
+struct SBuf {
+    double v[CNT];
+};
+template <int CNT>
+__device__ __forceinline__ void sload(SBuf<CNT> &b, cdouble_p p) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) b.v[i] = p[i];
+}
+template <int CNT>
+__device__ __forceinline__ void spin(const SBuf<CNT> &b) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) asm volatile("" ::"s"(b.v[i]));
+}
+
+// Pins a value in a VGPR at this point of the program: IR-level sinking otherwise moves whole dot products (e.g. the
+// mean) down to their last use and re-creates the constant loads they need there.
+__device__ __forceinline__ void pin_v(double &x) { asm volatile("" : "+v"(x)); }
+
+struct CoreParams {
+    cdouble_p c;      // transform constant block (const_layout)
+    cdouble_p cadd;   // [E*E] added to the covariance, or null
+    int32_t emv_mode;
+    double tp_nu;
+};
+
+// m: mean; L: in = packed lower triangle of cov, out = its Cholesky factor.  Returns false if cov is not PD (results
+// are then garbage; the caller writes NaN).  Sink interface: mean(e, v), cov(e, e2, v) for e2 <= e, ccov(e, d, v).
+template <int D, int E, int N, int F, int FORM, int TP, int SEL, bool NEED_CCOV, class Sink>
+__device__ __forceinline__ bool moment_transform_core(const double (&m)[D], double (&L)[D * (D + 1) / 2], double t,
+                                                      const FPar &fp, const CoreParams &cp, Sink &out) {
     constexpr ConstLayout cl = const_layout(D, E, N, FORM);
     using Fun = Fn<F>;
     constexpr int DIN = Fun::DIN;
-
-    double m[D], L[D * (D + 1) / 2];
-#pragma unroll
-    for (int d = 0; d < D; ++d) m[d] = a.mean[d * ld + b];
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) L[SSMQ_PK(i, j)] = a.cov[(i * D + j) * ld + b];
-    const double t = a.time[a.time_stride ? b : 0];
+    const cdouble_p c = cp.c;
 
     const bool ok = chol_packed<D>(L);
 
     Fun fn;
-    fn.init(t, a.fp);
+    fn.init(t, fp);
 
     double fx[E][N];
+    SBuf<D> xic;
+    sload(xic, c + cl.xi);
+    spin(xic);
 #pragma unroll
     for (int n = 0; n < N; ++n) {
+        SBuf<D> xin;
+        if (n + 1 < N) sload(xin, c + cl.xi + (n + 1) * D);
         double x[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             double s = m[d];
 #pragma unroll
-            for (int k = 0; k <= d; ++k) s += L[SSMQ_PK(d, k)] * c[cl.xi + n * D + k];
+            for (int k = 0; k <= d; ++k) s += L[SSMQ_PK(d, k)] * xic.v[k];
             x[d] = s;
         }
         double xs[DIN], o[E];
@@ -75,6 +112,10 @@ __global__ __launch_bounds__(kSmallBlock) void k_apply_small(const ApplyArgs a) 
         fn.template eval<E>(xs, o);
 #pragma unroll
         for (int e = 0; e < E; ++e) fx[e][n] = o[e];
+        if (n + 1 < N) {
+            spin(xin);
+            xic = xin;
+        }
         SSMQ_SCHED_FENCE();
     }
 
@@ -84,47 +125,91 @@ __global__ __launch_bounds__(kSmallBlock) void k_apply_small(const ApplyArgs a) 
         double s = 0.0;
 #pragma unroll
         for (int n = 0; n < N; ++n) s += fx[e][n] * c[cl.wm + n];
+        pin_v(s);
         mf[e] = s;
+        out.mean(e, s);
     }
-
-    const double nan = __builtin_nan("");
-    if (!ok) a.status[b] = 1;
-    else a.status[b] = 0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) a.mean_f[e * ld + b] = ok ? mf[e] : nan;
+    SSMQ_SCHED_FENCE();
 
     if (FORM == SSMQ_FORM_BQ) {
+        // ---- cross-covariance first, one output row at a time: (fx_e Wcc') L'.  After it L is dead, which keeps the
+        //      covariance stage (fx + accumulators) inside 256 registers ---------------------------------------------
+        if (NEED_CCOV) {
+            constexpr int CH = 2;                       // sigma points per constant chunk (CH * D doubles in SGPRs)
+            constexpr int NCH = (N + CH - 1) / CH;
+            SBuf<CH * D> wcur;
+            sload(wcur, launder(c) + cl.Wcc);           // Wcc' is [N][D]: chunk ch = rows ch*CH .. ch*CH+CH-1 (padded
+            spin(wcur);                                 // reads past row N-1 fall into the emv block: harmless)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                double g[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) g[d] = 0.0;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    constexpr int kLast = 0;
+                    (void)kLast;
+                    const bool more = !(e == E - 1 && ch == NCH - 1);
+                    SBuf<CH * D> wnext;
+                    if (more) sload(wnext, launder(c) + cl.Wcc + ((ch + 1) % NCH) * CH * D);
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int n = ch * CH + q;
+                        if (n < N) {
+#pragma unroll
+                            for (int d = 0; d < D; ++d) g[d] += fx[e][n] * wcur.v[q * D + d];
+                        }
+                    }
+                    if (more) {
+                        spin(wnext);
+                        wcur = wnext;
+                    }
+                    SSMQ_SCHED_FENCE();
+                }
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int d = 0; d <= j; ++d) s += g[d] * L[SSMQ_PK(j, d)];
+                    out.ccov(e, j, s);
+                }
+                SSMQ_SCHED_FENCE();
+            }
+        }
         // ---- covariance: (fx Wc) fx' - mean mean' + emv --------------------------------------------------------
         double cv[E * (E + 1) / 2];
 #pragma unroll
         for (int i = 0; i < E * (E + 1) / 2; ++i) cv[i] = 0.0;
+        SBuf<N> colc;
+        sload(colc, launder(c) + cl.Wc);
+        spin(colc);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
+            SBuf<N> coln;
+            if (j + 1 < N) sload(coln, launder(c) + cl.Wc + (j + 1) * N);
             double tj[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 double s = 0.0;
 #pragma unroll
-                for (int i = 0; i < N; ++i) s += fx[e][i] * c[cl.Wc + j * N + i];
+                for (int i = 0; i < N; ++i) s += fx[e][i] * colc.v[i];
                 tj[e] = s;
             }
 #pragma unroll
             for (int e = 0; e < E; ++e)
 #pragma unroll
                 for (int e2 = 0; e2 <= e; ++e2) cv[SSMQ_PK(e, e2)] += tj[e] * fx[e2][j];
+#pragma unroll
+            for (int i = 0; i < E * (E + 1) / 2; ++i) pin_v(cv[i]);   // keeps column j's work in body j (see pin_v)
+            if (j + 1 < N) {
+                spin(coln);
+                colc = coln;
+            }
             SSMQ_SCHED_FENCE();
         }
         // expected model variance: constant, or scaled by the data for a Student-t process model
-        double em[E * (E + 1) / 2];
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-#pragma unroll
-            for (int e2 = 0; e2 <= e; ++e2) {
-                const bool use = (e == e2) || (a.emv_mode == SSMQ_EMV_BROADCAST);
-                em[SSMQ_PK(e, e2)] = use ? c[cl.emv + e * E + e2] : 0.0;
-            }
+        double sv[TP ? E * (E + 1) / 2 : 1];
         if (TP) {
-            double sv[E * (E + 1) / 2];
 #pragma unroll
             for (int i = 0; i < E * (E + 1) / 2; ++i) sv[i] = 0.0;
 #pragma unroll
@@ -141,48 +226,24 @@ __global__ __launch_bounds__(kSmallBlock) void k_apply_small(const ApplyArgs a) 
                 for (int e = 0; e < E; ++e)
 #pragma unroll
                     for (int e2 = 0; e2 <= e; ++e2) sv[SSMQ_PK(e, e2)] += tj[e] * fx[e2][j];
+#pragma unroll
+                for (int i = 0; i < E * (E + 1) / 2; ++i) pin_v(sv[i]);
                 SSMQ_SCHED_FENCE();
             }
-            const double den = 1.0 / (a.tp_nu - 2.0 + (double)N);
-#pragma unroll
-            for (int i = 0; i < E * (E + 1) / 2; ++i) em[i] = (a.tp_nu - 2.0 + sv[i]) * den * em[i];
         }
+        const double den = TP ? 1.0 / (cp.tp_nu - 2.0 + (double)N) : 0.0;
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
             for (int e2 = 0; e2 <= e; ++e2) {
-                double v = cv[SSMQ_PK(e, e2)] - mf[e] * mf[e2] + em[SSMQ_PK(e, e2)];
-                if (a.cov_add) v += cadd[e * E + e2];
-                v = ok ? v : nan;
-                a.cov_f[(e * E + e2) * ld + b] = v;
-                if (e2 != e) a.cov_f[(e2 * E + e) * ld + b] = v;
+                const bool use = (e == e2) || (cp.emv_mode == SSMQ_EMV_BROADCAST);
+                double em = use ? c[cl.emv + e * E + e2] : 0.0;
+                if (TP) em = (cp.tp_nu - 2.0 + sv[TP ? SSMQ_PK(e, e2) : 0]) * den * em;
+                double v = cv[SSMQ_PK(e, e2)] - mf[e] * mf[e2] + em;
+                if (cp.cadd) v += cp.cadd[e * E + e2];
+                out.cov(e, e2, v);
+                if (e2 == e) SSMQ_SCHED_FENCE();   // one output row per scheduling region (bounds live SGPRs)
             }
-        // ---- cross-covariance: (fx Wcc') L' -------------------------------------------------------------------
-        double g[E][D];
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-#pragma unroll
-            for (int d = 0; d < D; ++d) g[e][d] = 0.0;
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const double w = c[cl.Wcc + n * D + d];
-#pragma unroll
-                for (int e = 0; e < E; ++e) g[e][d] += fx[e][n] * w;
-            }
-            SSMQ_SCHED_FENCE();
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                double s = 0.0;
-#pragma unroll
-                for (int d = 0; d <= j; ++d) s += g[e][d] * L[SSMQ_PK(j, d)];
-                a.cov_fx[(e * D + j) * ld + b] = ok ? s : nan;
-            }
-        }
     } else {
         // ---- classical centred form, diagonal covariance weights -----------------------------------------------
 #pragma unroll
@@ -196,33 +257,84 @@ __global__ __launch_bounds__(kSmallBlock) void k_apply_small(const ApplyArgs a) 
                 double s = 0.0;
 #pragma unroll
                 for (int n = 0; n < N; ++n) s += (fx[e][n] * c[cl.Wc + n]) * fx[e2][n];
-                if (a.cov_add) s += cadd[e * E + e2];
-                s = ok ? s : nan;
-                a.cov_f[(e * E + e2) * ld + b] = s;
-                if (e2 != e) a.cov_f[(e2 * E + e) * ld + b] = s;
+                if (cp.cadd) s += cp.cadd[e * E + e2];
+                out.cov(e, e2, s);
             }
-        double cx[E][D];
+        if (NEED_CCOV) {
+            double cx[E][D];
 #pragma unroll
-        for (int e = 0; e < E; ++e)
+            for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int d = 0; d < D; ++d) cx[e][d] = 0.0;
+                for (int d = 0; d < D; ++d) cx[e][d] = 0.0;
 #pragma unroll
-        for (int n = 0; n < N; ++n) {
+            for (int n = 0; n < N; ++n) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                // x_n - mean exactly as the reference forms it: (mean + L xi_n) - mean   (mtran.py:139,148)
-                double s = m[d];
+                for (int d = 0; d < D; ++d) {
+                    // x_n - mean exactly as the reference forms it: (mean + L xi_n) - mean   (mtran.py:139,148)
+                    double s = m[d];
 #pragma unroll
-                for (int k = 0; k <= d; ++k) s += L[SSMQ_PK(d, k)] * c[cl.xi + n * D + k];
-                const double dx = s - m[d];
+                    for (int k = 0; k <= d; ++k) s += L[SSMQ_PK(d, k)] * c[cl.xi + n * D + k];
+                    const double dx = s - m[d];
 #pragma unroll
-                for (int e = 0; e < E; ++e) cx[e][d] += (fx[e][n] * c[cl.Wc + n]) * dx;
+                    for (int e = 0; e < E; ++e) cx[e][d] += (fx[e][n] * c[cl.Wc + n]) * dx;
+                }
+                SSMQ_SCHED_FENCE();
             }
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int d = 0; d < D; ++d) out.ccov(e, d, cx[e][d]);
         }
+    }
+    return ok;
+}
+
+// Sink of the stand-alone kernel: every element goes straight to its SoA plane.
+template <int D, int E>
+struct GlobalSink {
+    double *mean_f, *cov_f, *cov_fx;
+    int64_t ld;
+    uint32_t b;
+    __device__ __forceinline__ void mean(int e, double v) { mean_f[e * ld + b] = v; }
+    __device__ __forceinline__ void cov(int e, int e2, double v) {
+        cov_f[(e * E + e2) * ld + b] = v;
+        if (e2 != e) cov_f[(e2 * E + e) * ld + b] = v;
+    }
+    __device__ __forceinline__ void ccov(int e, int d, double v) { cov_fx[(e * D + d) * ld + b] = v; }
+};
+
+// __launch_bounds__(64, 2): at least two waves per SIMD, i.e. at most 256 registers per lane.  The D = E = 6, N = 13
+// kernel needs ~270 without the bound (one wave per SIMD, no latency hiding at all); with it hipcc spills 8 registers
+// and B = 1e5 trajectories (1563 waves) are all resident at once.
+template <int D, int E, int N, int F, int FORM, int TP, int SEL>
+__global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs a) {
+    const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;  // 32-bit lane offset: plane base stays scalar
+    if ((int64_t)b >= a.B) return;
+    const int64_t ld = a.ld;
+    double m[D], L[D * (D + 1) / 2];
 #pragma unroll
-        for (int e = 0; e < E; ++e)
+    for (int d = 0; d < D; ++d) m[d] = a.mean[d * ld + b];
 #pragma unroll
-            for (int d = 0; d < D; ++d) a.cov_fx[(e * D + d) * ld + b] = ok ? cx[e][d] : nan;
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[SSMQ_PK(i, j)] = a.cov[(i * D + j) * ld + b];
+    const double t = a.time[a.time_stride ? b : 0];
+
+    CoreParams cp{(cdouble_p)a.consts, (cdouble_p)a.cov_add, a.emv_mode, a.tp_nu};
+    GlobalSink<D, E> sink{a.mean_f, a.cov_f, a.cov_fx, ld, b};
+    const bool ok = moment_transform_core<D, E, N, F, FORM, TP, SEL, true>(m, L, t, a.fp, cp, sink);
+    a.status[b] = ok ? 0 : 1;
+    if (!ok) {
+        // the reference raises LinAlgError here (bq/bqmtran.py:98); a batch marks the item and poisons its outputs
+        const double nan = __builtin_nan("");
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            sink.mean(e, nan);
+#pragma unroll
+            for (int e2 = 0; e2 <= e; ++e2) sink.cov(e, e2, nan);
+#pragma unroll
+            for (int d = 0; d < D; ++d) sink.ccov(e, d, nan);
+        }
     }
 }
 

@@ -176,11 +176,15 @@ struct ReentryCore {
     __device__ __forceinline__ void init(double, const FPar &p) { dt = p.p[0]; }
     __device__ __forceinline__ void core(const double *x, double *o) const {
         const double r0 = 6374.0, h0 = 13.406, gm0 = 3.9860e5, b0 = -0.59783;
-        const double b = b0 * exp(x[4]);
-        const double rr = sqrt(x[0] * x[0] + x[1] * x[1]);
+        // Same formula as ssmod.py:547-557, arranged for the fp64 vector ALU: the two exponentials b0 exp(x4) and
+        // exp((R0 - R) / H0) are one exp of the summed argument, and R, 1 / R^3 come from one reciprocal square root
+        // (differences from the reference's evaluation order are a few ulp, far inside the 1e-10 parity bar).
+        const double r2 = x[0] * x[0] + x[1] * x[1];
+        const double ir = rsqrt(r2);
+        const double rr = r2 * ir;
         const double vv = sqrt(x[2] * x[2] + x[3] * x[3]);
-        const double dr = b * exp((r0 - rr) / h0) * vv;
-        const double gr = -gm0 / (rr * rr * rr);
+        const double dr = b0 * exp(x[4] + (r0 - rr) * (1.0 / h0)) * vv;
+        const double gr = -gm0 * (ir * ir * ir);
         o[0] = x[0] + dt * x[2];
         o[1] = x[1] + dt * x[3];
         o[2] = x[2] + dt * (dr * x[2] + gr * x[0]);

@@ -1,0 +1,190 @@
+// Fused filter time loop: ONE kernel runs all T steps of an additive-noise Gaussian sigma-point / BQ filter for a batch of
+// independent trajectories, one trajectory per lane, the filter state (mean, covariance) held in registers from step to
+// step (reference recursion: ssinf.py:66-118, 254-323).  Per step and trajectory it reads the measurement (Y doubles)
+// and writes the filtered mean and the full, unsymmetrised covariance (D + D*D doubles) - the per-step HBM traffic the
+// reference's forward_pass implies (bytes_step = 8 (dim_y + D + D^2)); the predictive moments never
+// leave the register file and the 3 T kernel launches of the unfused loop collapse into one.
+//
+// The input-state cross-covariance of the dynamics transform is only consumed by the smoother (ssinf.py:105-107,
+// 325-344) and is not formed in the forward pass.
+#include "ssmq_apply_small.h"
+#include "ssmq_host.h"
+
+namespace ssmq {
+
+struct FusedArgs {
+    const double *y;        // [T][Y][ld]
+    const double *m0, *P0;  // [D][ld], [D*D][ld]
+    double *fm, *fP;        // [T][D][ld], [T][D*D][ld]
+    int32_t *status;        // [B]: 0 or 1 + first failing step
+    const double *c_dyn, *c_obs, *gqg, *rr;
+    int64_t B, ld;
+    int32_t T, emv_dyn, emv_obs;
+    double nu_dyn, nu_obs;
+    FPar fd, fo;
+};
+
+template <int D, int E>
+struct RegSink {
+    double mf[E];
+    double cv[E * (E + 1) / 2];
+    double cx[E][D];
+    __device__ __forceinline__ void mean(int e, double v) { mf[e] = v; }
+    __device__ __forceinline__ void cov(int e, int e2, double v) { cv[SSMQ_PK(e, e2)] = v; }
+    __device__ __forceinline__ void ccov(int e, int d, double v) { cx[e][d] = v; }
+};
+template <int D, int E>
+struct RegSinkNoCross {
+    double mf[E];
+    double cv[E * (E + 1) / 2];
+    __device__ __forceinline__ void mean(int e, double v) { mf[e] = v; }
+    __device__ __forceinline__ void cov(int e, int e2, double v) { cv[SSMQ_PK(e, e2)] = v; }
+    __device__ __forceinline__ void ccov(int, int, double) {}
+};
+
+template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
+__global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(const FusedArgs a) {
+    const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;
+    if ((int64_t)b >= a.B) return;
+    const int64_t ld = a.ld;
+    double m[D], Pl[D * (D + 1) / 2];
+#pragma unroll
+    for (int d = 0; d < D; ++d) m[d] = a.m0[d * ld + b];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Pl[SSMQ_PK(i, j)] = a.P0[(i * D + j) * ld + b];
+    const CoreParams cpd{(cdouble_p)a.c_dyn, (cdouble_p)a.gqg, a.emv_dyn, a.nu_dyn};
+    const CoreParams cpo{(cdouble_p)a.c_obs, (cdouble_p)a.rr, a.emv_obs, a.nu_obs};
+    const double nan = __builtin_nan("");
+    int32_t agg = 0;
+#pragma unroll 1
+    for (int k = 0; k < a.T; ++k) {
+        const double t = (double)k;  // both transforms of step k + 1 use time index k (ssinf.py:104, 276-288)
+        // ---- time update: predictive state moments, + G Q G' (ssinf.py:276-279) ----------------------------------
+        RegSinkNoCross<D, D> pr;
+        bool ok = moment_transform_core<D, D, ND, FD, FORM, TP, 0, false>(m, Pl, t, a.fd, cpd, pr);
+        // ---- predictive measurement moments, + R (ssinf.py:287-291) ------------------------------------------------
+        double L2[D * (D + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < D * (D + 1) / 2; ++i) L2[i] = pr.cv[i];
+        RegSink<D, Y> ob;
+        ok = moment_transform_core<D, Y, NO, FO, FORM, TP, SELO, true>(pr.mf, L2, t, a.fo, cpo, ob) && ok;
+        // ---- measurement update (ssinf.py:321-323) ---------------------------------------------------------------------
+        double S[Y * (Y + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < Y * (Y + 1) / 2; ++i) S[i] = ob.cv[i];
+        ok = chol_packed<Y>(S) && ok;
+        double G[D][Y];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double v[Y];
+#pragma unroll
+            for (int i = 0; i < Y; ++i) {
+                double s = ob.cx[i][d];
+#pragma unroll
+                for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * v[q];
+                v[i] = s / S[SSMQ_PK(i, i)];
+            }
+#pragma unroll
+            for (int i = Y - 1; i >= 0; --i) {
+                double s = v[i];
+#pragma unroll
+                for (int q = i + 1; q < Y; ++q) s -= S[SSMQ_PK(q, i)] * v[q];
+                v[i] = s / S[SSMQ_PK(i, i)];
+            }
+#pragma unroll
+            for (int i = 0; i < Y; ++i) G[d][i] = v[i];
+        }
+        if (agg == 0 && !ok) agg = k + 1;
+        const bool good = (agg == 0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < Y; ++i) s += G[d][i] * (a.y[((int64_t)k * Y + i) * ld + b] - ob.mf[i]);
+            m[d] = good ? pr.mf[d] + s : nan;
+            a.fm[((int64_t)k * D + d) * ld + b] = m[d];
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double w[Y];
+#pragma unroll
+            for (int j = 0; j < Y; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < Y; ++i) s += G[d][i] * ob.cv[i >= j ? SSMQ_PK(i, j) : SSMQ_PK(j, i)];
+                w[j] = s;
+            }
+#pragma unroll
+            for (int d2 = 0; d2 < D; ++d2) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < Y; ++j) s += w[j] * G[d2][j];
+                double p = pr.cv[d >= d2 ? SSMQ_PK(d, d2) : SSMQ_PK(d2, d)] - s;
+                p = good ? p : nan;
+                a.fP[((int64_t)k * D * D + d * D + d2) * ld + b] = p;
+                if (d2 <= d) Pl[SSMQ_PK(d, d2)] = p;   // the next Cholesky reads the lower triangle only (LAPACK 'L')
+            }
+        }
+    }
+    a.status[b] = agg;
+}
+
+template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
+static hipError_t launch_fused(const FusedArgs &a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.B + kSmallBlock - 1) / kSmallBlock);
+    hipLaunchKernelGGL((k_filter_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO>), dim3(grid), dim3(kSmallBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+typedef hipError_t (*fused_fn)(const FusedArgs &, hipStream_t);
+struct FusedEntry {
+    int fd, fo, D, Y, ND, NO, form, tp, selo;
+    fused_fn fn;
+    const char *name;
+};
+
+#define SSMQ_FUSED_ONE(FD, FO, D, Y, ND, NO, FORM, TP, SELO)                                   \
+    {FD, FO, D, Y, ND, NO, FORM, TP, SELO, &launch_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO>, \
+     "k_filter_fused<D=" #D ",Y=" #Y ",ND=" #ND ",NO=" #NO "," #FD "," #FO "," #FORM ",TP=" #TP ",SELO=" #SELO ">"}
+#define SSMQ_FUSED(FD, FO, D, Y, N, SELO)                                   \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 0, SELO),              \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 1, SELO),              \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_SIGMA, 0, SELO)
+
+static const FusedEntry kFused[] = {
+    SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 2, 0),
+    SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 0),
+    SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 5, 0),
+    SSMQ_FUSED(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 5, 0),
+    SSMQ_FUSED(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
+    SSMQ_FUSED(SSMQ_F_REENTRY2D_BIAS_DYN, SSMQ_F_RADAR2D_MEAS, 6, 2, 13, 0),
+};
+
+// Returns 1 if a fused kernel was launched, 0 if none exists for this combination, < 0 on error.
+int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho,
+                     const ssmq_integrand *fo, int sel_obs, int64_t B, int64_t ld, int T, const double *d_y,
+                     const double *d_m0, const double *d_P0, const double *d_gqg, const double *d_rr, double *d_fm,
+                     double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run) {
+    if (hd->form != ho->form || (hd->tp_nu > 0.0) != (ho->tp_nu > 0.0) || sel_obs < 0 || fd->n_idx > 0) return 0;
+    const int tp = hd->tp_nu > 0.0 ? 1 : 0;
+    for (const FusedEntry &e : kFused) {
+        if (e.fd == fd->id && e.fo == fo->id && e.D == hd->D && e.Y == ho->E && e.ND == hd->N && e.NO == ho->N &&
+            e.form == hd->form && e.tp == tp && e.selo == sel_obs) {
+            if (name) *name = e.name;
+            if (dry_run) return 1;
+            FusedArgs a;
+            a.y = d_y; a.m0 = d_m0; a.P0 = d_P0; a.fm = d_fm; a.fP = d_fP; a.status = d_status;
+            a.c_dyn = hd->d_small; a.c_obs = ho->d_small; a.gqg = d_gqg; a.rr = d_rr; a.B = B; a.ld = ld; a.T = T;
+            a.emv_dyn = hd->emv_mode; a.emv_obs = ho->emv_mode; a.nu_dyn = hd->tp_nu; a.nu_obs = ho->tp_nu;
+            fill_fpar(fd, &a.fd);
+            fill_fpar(fo, &a.fo);
+            int rc = hip_fail(e.fn(a, s), e.name);
+            return rc ? rc : 1;
+        }
+    }
+    return 0;
+}
+
+}  // namespace ssmq

@@ -42,6 +42,17 @@ class GaussianInference:
         self.fi_mean = self.fi_cov = None
         self.status = None
 
+    def kernel_name(self):
+        """Which kernel(s) the device filter loop runs for this filter (one fused kernel, or a replayed hipGraph)."""
+        f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
+        f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
+        buf = ctypes.create_string_buffer(512)
+        _lib.check(_lib.load().ssmq_filter_kernel_name(ctypes.c_void_p(self.tf_dyn._handle_for(e_dyn)),
+                                                       ctypes.byref(f_dyn),
+                                                       ctypes.c_void_p(self.tf_obs._handle_for(e_obs)),
+                                                       ctypes.byref(f_obs), buf, 512), 'ssmq_filter_kernel_name')
+        return buf.value.decode()
+
     def forward_pass(self, data):
         """data (dim_y, T) -> filtered means (D, T), covariances (D, D, T)  (ssinf.py:66-118)."""
         fm, fP = self.forward_pass_batch(np.asarray(data)[..., None])

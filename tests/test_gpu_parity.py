@@ -274,6 +274,39 @@ def test_ungm_filter_golden(amd, golden, name):
     assert np.array_equal(fm1, fm[..., 0]) and np.array_equal(fP1, fP[..., 0])
 
 
+def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
+    """The one-kernel time loop and the 3 T-launch loop (hipGraph replay) are the same arithmetic."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g4_filters')
+    y = np.repeat(g['ungm_y'], 40, axis=2)[..., :300]
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    par = np.array([[1.0, 3.0]])
+    for alg in (ssinf.GaussianProcessKalman(dyn, obs, par, par), ssinf.UnscentedKalman(dyn, obs),
+                ssinf.StudentProcessKalman(dyn, obs, par, par)):
+        monkeypatch.delenv('SSMQ_NO_FUSED', raising=False)
+        assert 'k_filter_fused' in alg.kernel_name()
+        fm, fP = alg.forward_pass_batch(y)
+        monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+        assert 'hipGraph' in alg.kernel_name()
+        fm2, fP2 = alg.forward_pass_batch(y)
+        fm3, fP3 = alg.forward_pass_batch(y)          # second call replays the captured graph
+        monkeypatch.delenv('SSMQ_NO_FUSED')
+        assert np.array_equal(fm2, fm3) and np.array_equal(fP2, fP3)
+        assert rel_err(fm, fm2) < 1e-12 and rel_err(fP, fP2) < 1e-12
+    # reentry: fused (5, 2, 11) kernel against the loop of stand-alone kernels
+    y = g['rer_y']
+    dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, g['rer_m0'], g['rer_P0']), sm.GaussRV(3, cov=g['rer_Q']))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=g['rer_R']), 5)
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    assert 'k_filter_fused<D=5,Y=2' in alg.kernel_name()
+    fm, fP = alg.forward_pass_batch(y)
+    monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+    fm2, fP2 = alg.forward_pass_batch(y)
+    monkeypatch.delenv('SSMQ_NO_FUSED')
+    assert rel_err(fm, fm2) < 1e-11 and rel_err(fP, fP2) < 1e-7
+
+
 def test_reentry_ukf_golden(amd, golden):
     from ssmtoybox_amd import ssinf, ssmod as sm
     g = golden('g4_filters')
