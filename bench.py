@@ -30,6 +30,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed PMC summary (profiles/pmc_traffic.json, produced by
+    profiles/collect_pmc.sh + profiles/pmc_summary.py from separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the
+    gfx950 note in MI355X_MICROARCH.md prescribes).  None if the kernel is not in the summary."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    import re
+    base = kernel_name.split('<')[0]
+    want = [int(v) for v in re.findall(r'=(\d+)', kernel_name)]
+    nshape = 4 if 'fused' in base else 3           # (D, Y, ND, NO) or (D, E, N) identify the shape
+    for key, rec in table.items():
+        if key.startswith('_') or key.split('<')[0] != base:
+            continue
+        have = [int(v) for v in re.findall(r'(\d+)', key.split('<', 1)[1])]
+        if have[:nshape] == want[:nshape]:
+            return rec.get('hbm_bytes_per_launch')
+    return None
+
+
 def simulate_ungm(B, T, seed):
     """Synthetic UNGM trajectories + measurements (x0 ~ N(0,1), q ~ N(0,10), r ~ N(0,1): tests/test_ssinf.py:23-30 of the
     reference), vectorised over the batch.  Returns x (T, B), y (T, B)."""
@@ -205,7 +227,7 @@ def cpu_baseline_ungm(B, T, seed, tf, budget_s=12.0, max_threads=16):
     fm, fP, st = co.filter_forward(td, to, yb, np.zeros(1), one, 10.0 * one, one, threads=cores)
     dt = time.perf_counter() - t0
     passes, total = 1, dt
-    while total + dt < budget_s and passes < 200:
+    while total + dt < budget_s and passes < 2000:
         t0 = time.perf_counter()
         co.filter_forward(td, to, yb, np.zeros(1), one, 10.0 * one, one, threads=cores)
         total += time.perf_counter() - t0
@@ -270,16 +292,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # final aggregation: per-time-step squared-error sums -> RMSE (the path's only collective)
+    # final aggregation: per-time-step error sums -> RMSE / NLL (the path's only collective)
+    from ssmtoybox_amd import mcshard
     fm, fP, st = wl.results()
     ok = st == 0
-    se = np.concatenate((((fm - wl.x_true) ** 2)[:, ok].sum(axis=1), [ok.sum()]))
-    if dist is not None:
-        import torch
-        tse = torch.tensor(se, dtype=torch.float64, device='cuda')
-        dist.all_reduce(tse, op=dist.ReduceOp.SUM)
-        se = tse.cpu().numpy()
-    rmse = float(np.sqrt(se[:-1].sum() / max(se[-1] * T, 1)))
+    loc = mcshard.local_error_sums(wl.x_true[None], fm[None], fP[None, None], ok)
+    agg = mcshard.finalize(mcshard.allreduce_sums(loc, dist))
+    rmse, nll = agg['rmse_total'], float(agg['nll_avg'].mean())
 
     out = None
     if rank == 0:
@@ -295,12 +314,13 @@ def main():
                                    '{} MC trajectories per GPU x T={} time steps per pass (BASELINE configs[1])'.format(B, T),
                        'mc_per_gpu': B, 'time_steps': T, 'parallelism': 'mc-shard x{}'.format(world)},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(wl.kernel),
                          'kernel': wl.kernel,
                          'bytes_per_launch': bytes_pass, 'ms_per_launch': pass_ms_dev,
                          'note': 'fp64-ALU / latency bound at B=1e4 (157 waves on 1024 SIMDs), not HBM bound: '
                                  'SURVEY.md 7-4'},
-            'rmse': rmse, 'failed_trajectories': int((~ok).sum()),
+            'rmse': rmse, 'nll': nll, 'trajectories_aggregated': int(agg['count']),
+            'failed_trajectories_rank0': int((~ok).sum()),
         }
     if rank == 0 and not args.no_mt6:
         mt = Mt6Bench(amd, 100000, seed=2)
@@ -308,7 +328,7 @@ def main():
         ms, b_alg, b_mov = mt.measure()
         ach = b_alg / (ms * 1e-3) / 1e9
         out['roofline_mt6'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': ach / HBM_PEAK_GBS, 'traffic': None, 'kernel': mt.kernel,
+                               'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(mt.kernel), 'kernel': mt.kernel,
                                'bytes_per_launch': b_alg, 'bytes_moved_per_launch': b_mov, 'ms_per_launch': ms,
                                'transforms_per_s': mt.B / (ms * 1e-3), 'max_scaled_err_vs_oracle': err,
                                'workload': 'batched GPQ moment transform, D=E=6, N=13, B=1e5, 4 rotating buffer sets'}
@@ -317,8 +337,11 @@ def main():
         out['cpu_baseline'] = cb
         # the GPU pass and the CPU port ran the same trajectories: cross-check them
         good = (st == 0) & (cpu_st == 0)
-        out['max_rel_diff_vs_cpu_port'] = float(np.max(np.abs(fm[:, good] - cpu_fm[:, good])) /
-                                                np.max(np.abs(cpu_fm[:, good])))
+        rel = np.abs(fm[:, good] - cpu_fm[:, good]) / np.max(np.abs(cpu_fm[:, good]))
+        # identical weights and measurements; the UNGM recursion amplifies rounding differences along a trajectory
+        # (uncentred covariance, bq/bqmtran.py:199), hence median and max over the 1e6 filtered means
+        out['rel_diff_vs_cpu_port'] = {'median': float(np.median(rel)), 'p99': float(np.quantile(rel, 0.99)),
+                                       'max': float(rel.max())}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: MC trajectories sharded over 2 ranks (gloo), error sums all-reduced, against the single-process
+result.  The per-rank filter here is the C oracle (no GPU in this test); what is under test is the sharding and the
+two-phase aggregation that bench.py uses unchanged with backend nccl (RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from ssmtoybox_amd import mcshard
+
+
+def test_shard_bounds_cover_everything():
+    for total in (0, 1, 7, 10000, 100001):
+        for world in (1, 2, 3, 8):
+            spans = [mcshard.shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _study(B=48, T=30, seed=3):
+    from bench import simulate_ungm
+    from oracle import ssmq_oracle as orc, c_oracle as co
+    x, y = simulate_ungm(B, T, seed)
+    par = np.array([1.0, 3.0])
+    pts = orc.points_ut(1)
+    w = orc.gp_weights(par, pts)
+    one = np.ones((1, 1))
+    td, k1 = co.make_transform(0, 1, 1, pts, w['wm'], w['Wc'], w['Wcc'], w['model_var'] * one,
+                               integrand=co.Integrand.make(orc.F_UNGM_DYN))
+    to, k2 = co.make_transform(0, 1, 1, pts, w['wm'], w['Wc'], w['Wcc'], w['model_var'] * one,
+                               integrand=co.Integrand.make(orc.F_UNGM_MEAS))
+    fm, fP, st = co.filter_forward(td, to, np.ascontiguousarray(y.T[:, :, None]), np.zeros(1), one, 10.0 * one, one)
+    return x[None], fm.transpose(2, 1, 0), fP.transpose(2, 3, 1, 0), st == 0     # (D,T,B), (D,T,B), (D,D,T,B)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    x, fm, fP, ok = _study()
+    lo, hi = mcshard.shard_bounds(fm.shape[2], rank, world)
+    loc = mcshard.local_error_sums(x[..., lo:hi], fm[..., lo:hi], fP[..., lo:hi], ok[lo:hi])
+    tot = mcshard.finalize(mcshard.allreduce_sums(loc, dist))
+    lcr = mcshard.allreduce_sums(mcshard.local_lcr_sums(x[..., lo:hi], fm[..., lo:hi], fP[..., lo:hi], tot['mse'],
+                                                        ok[lo:hi]), dist)
+    if rank == 0:
+        q.put((tot, lcr))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_aggregation_matches_single_process():
+    import torch.multiprocessing as mp
+    x, fm, fP, ok = _study()
+    ref = mcshard.finalize(mcshard.local_error_sums(x, fm, fP, ok))
+    ref_lcr = mcshard.local_lcr_sums(x, fm, fP, ref['mse'], ok)
+    # direct formulas of the reference's metrics on the same data (utils.py:18-148)
+    assert np.isclose(ref['rmse_avg'][5], np.mean(np.sqrt(((x - fm) ** 2).sum(axis=0))[5]))
+    d = (x - fm)[0, 7, 0]
+    p = fP[0, 0, 7, 0]
+    assert np.isclose(mcshard.local_error_sums(x[..., :1], fm[..., :1], fP[..., :1])['nll'][7],
+                      0.5 * (np.log(p) + d * d / p + np.log(2 * np.pi)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    tot, lcr = q.get(timeout=120)
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    for k in ('rmse_avg', 'nll_avg', 'mse'):
+        assert np.allclose(tot[k], ref[k], rtol=1e-12, atol=1e-12), k
+    assert np.isclose(tot['rmse_total'], ref['rmse_total'], rtol=1e-12) and tot['count'] == ref['count']
+    assert np.allclose(lcr['lcr'], ref_lcr['lcr'], rtol=1e-10, atol=1e-10)
