@@ -253,11 +253,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
+        # launched by torch.distributed.run: one rank per GPU; RCCL ("nccl" on ROCm) only for barriers + the final reduce
         import torch
         import torch.distributed as dist
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl')      # RCCL on ROCm
+        dist.init_process_group('nccl')
 
     import ssmtoybox_amd as amd
     if amd.device_count() < 1:

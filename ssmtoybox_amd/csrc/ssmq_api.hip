@@ -222,7 +222,8 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     if (se) {
         ApplyArgs a;
         a.mean = d_mean; a.cov = d_cov; a.time = d_time ? d_time : d_mean; a.mean_f = d_mean_f; a.cov_f = d_cov_f;
-        a.cov_fx = d_cov_fx; a.status = d_status; a.consts = h->d_small; a.cov_add = d_cov_add; a.B = B; a.ld = ld;
+        a.cov_fx = d_cov_fx; a.status = d_status; a.consts = h->d_small;
+        a.cov_add = d_cov_add ? d_cov_add : h->d_small + const_layout(h->D, h->E, h->N, h->form).zero; a.B = B; a.ld = ld;
         a.time_stride = d_time ? time_stride : 0; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
         fill_fpar(f, &a.fp);
         return hip_fail(se->fn(a, stream()), se->name);

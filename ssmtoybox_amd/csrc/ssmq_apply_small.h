@@ -71,7 +71,7 @@ __device__ __forceinline__ void pin_v(double &x) { asm volatile("" : "+v"(x)); }
 
 struct CoreParams {
     cdouble_p c;      // transform constant block (const_layout)
-    cdouble_p cadd;   // [E*E] added to the covariance, or null
+    cdouble_p cadd;   // [E*E] added to the covariance (a block of zeros when the caller has nothing to add)
     int32_t emv_mode;
     double tp_nu;
 };
@@ -85,6 +85,13 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
     using Fun = Fn<F>;
     constexpr int DIN = Fun::DIN;
     const cdouble_p c = cp.c;
+    // Tiny shapes (UNGM: D = E = 1, N = 3) need none of the register-pressure / prefetch machinery below, and inside the
+    // fused time loop it would only stop the compiler from hoisting the ~40 constant loads out of the loop.
+    constexpr bool kTiny = (N * N + 2 * D * N + E * E) <= 48;
+#define SSMQ_FENCE_T() do { if (!kTiny) SSMQ_SCHED_FENCE(); } while (0)
+#define SSMQ_LAUNDER_T(p) (kTiny ? (p) : launder(p))
+#define SSMQ_SPIN_T(b) do { if (!kTiny) spin(b); } while (0)
+#define SSMQ_PIN_T(x) do { if (!kTiny) pin_v(x); } while (0)
 
     const bool ok = chol_packed<D>(L);
 
@@ -94,7 +101,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
     double fx[E][N];
     SBuf<D> xic;
     sload(xic, c + cl.xi);
-    spin(xic);
+    SSMQ_SPIN_T(xic);
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         SBuf<D> xin;
@@ -113,10 +120,10 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 #pragma unroll
         for (int e = 0; e < E; ++e) fx[e][n] = o[e];
         if (n + 1 < N) {
-            spin(xin);
+            SSMQ_SPIN_T(xin);
             xic = xin;
         }
-        SSMQ_SCHED_FENCE();
+        SSMQ_FENCE_T();
     }
 
     double mf[E];
@@ -125,11 +132,11 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
         double s = 0.0;
 #pragma unroll
         for (int n = 0; n < N; ++n) s += fx[e][n] * c[cl.wm + n];
-        pin_v(s);
+        SSMQ_PIN_T(s);
         mf[e] = s;
         out.mean(e, s);
     }
-    SSMQ_SCHED_FENCE();
+    SSMQ_FENCE_T();
 
     if (FORM == SSMQ_FORM_BQ) {
         // ---- cross-covariance first, one output row at a time: (fx_e Wcc') L'.  After it L is dead, which keeps the
@@ -138,8 +145,8 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
             constexpr int CH = 2;                       // sigma points per constant chunk (CH * D doubles in SGPRs)
             constexpr int NCH = (N + CH - 1) / CH;
             SBuf<CH * D> wcur;
-            sload(wcur, launder(c) + cl.Wcc);           // Wcc' is [N][D]: chunk ch = rows ch*CH .. ch*CH+CH-1 (padded
-            spin(wcur);                                 // reads past row N-1 fall into the emv block: harmless)
+            sload(wcur, SSMQ_LAUNDER_T(c) + cl.Wcc);           // Wcc' is [N][D]: chunk ch = rows ch*CH .. ch*CH+CH-1 (padded
+            SSMQ_SPIN_T(wcur);                                 // reads past row N-1 fall into the emv block: harmless)
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 double g[D];
@@ -151,7 +158,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                     (void)kLast;
                     const bool more = !(e == E - 1 && ch == NCH - 1);
                     SBuf<CH * D> wnext;
-                    if (more) sload(wnext, launder(c) + cl.Wcc + ((ch + 1) % NCH) * CH * D);
+                    if (more) sload(wnext, SSMQ_LAUNDER_T(c) + cl.Wcc + ((ch + 1) % NCH) * CH * D);
 #pragma unroll
                     for (int q = 0; q < CH; ++q) {
                         const int n = ch * CH + q;
@@ -161,10 +168,10 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                         }
                     }
                     if (more) {
-                        spin(wnext);
+                        SSMQ_SPIN_T(wnext);
                         wcur = wnext;
                     }
-                    SSMQ_SCHED_FENCE();
+                    SSMQ_FENCE_T();
                 }
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
@@ -173,7 +180,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                     for (int d = 0; d <= j; ++d) s += g[d] * L[SSMQ_PK(j, d)];
                     out.ccov(e, j, s);
                 }
-                SSMQ_SCHED_FENCE();
+                SSMQ_FENCE_T();
             }
         }
         // ---- covariance: (fx Wc) fx' - mean mean' + emv --------------------------------------------------------
@@ -181,12 +188,12 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 #pragma unroll
         for (int i = 0; i < E * (E + 1) / 2; ++i) cv[i] = 0.0;
         SBuf<N> colc;
-        sload(colc, launder(c) + cl.Wc);
-        spin(colc);
+        sload(colc, SSMQ_LAUNDER_T(c) + cl.Wc);
+        SSMQ_SPIN_T(colc);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             SBuf<N> coln;
-            if (j + 1 < N) sload(coln, launder(c) + cl.Wc + (j + 1) * N);
+            if (j + 1 < N) sload(coln, SSMQ_LAUNDER_T(c) + cl.Wc + (j + 1) * N);
             double tj[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -200,12 +207,12 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 #pragma unroll
                 for (int e2 = 0; e2 <= e; ++e2) cv[SSMQ_PK(e, e2)] += tj[e] * fx[e2][j];
 #pragma unroll
-            for (int i = 0; i < E * (E + 1) / 2; ++i) pin_v(cv[i]);   // keeps column j's work in body j (see pin_v)
+            for (int i = 0; i < E * (E + 1) / 2; ++i) SSMQ_PIN_T(cv[i]);   // keeps column j's work in body j (see pin_v)
             if (j + 1 < N) {
-                spin(coln);
+                SSMQ_SPIN_T(coln);
                 colc = coln;
             }
-            SSMQ_SCHED_FENCE();
+            SSMQ_FENCE_T();
         }
         // expected model variance: constant, or scaled by the data for a Student-t process model
         double sv[TP ? E * (E + 1) / 2 : 1];
@@ -227,8 +234,8 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 #pragma unroll
                     for (int e2 = 0; e2 <= e; ++e2) sv[SSMQ_PK(e, e2)] += tj[e] * fx[e2][j];
 #pragma unroll
-                for (int i = 0; i < E * (E + 1) / 2; ++i) pin_v(sv[i]);
-                SSMQ_SCHED_FENCE();
+                for (int i = 0; i < E * (E + 1) / 2; ++i) SSMQ_PIN_T(sv[i]);
+                SSMQ_FENCE_T();
             }
         }
         const double den = TP ? 1.0 / (cp.tp_nu - 2.0 + (double)N) : 0.0;
@@ -240,9 +247,9 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                 double em = use ? c[cl.emv + e * E + e2] : 0.0;
                 if (TP) em = (cp.tp_nu - 2.0 + sv[TP ? SSMQ_PK(e, e2) : 0]) * den * em;
                 double v = cv[SSMQ_PK(e, e2)] - mf[e] * mf[e2] + em;
-                if (cp.cadd) v += cp.cadd[e * E + e2];
+                v += cp.cadd[e * E + e2];
                 out.cov(e, e2, v);
-                if (e2 == e) SSMQ_SCHED_FENCE();   // one output row per scheduling region (bounds live SGPRs)
+                if (e2 == e) SSMQ_FENCE_T();   // one output row per scheduling region (bounds live SGPRs)
             }
     } else {
         // ---- classical centred form, diagonal covariance weights -----------------------------------------------
@@ -257,7 +264,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                 double s = 0.0;
 #pragma unroll
                 for (int n = 0; n < N; ++n) s += (fx[e][n] * c[cl.Wc + n]) * fx[e2][n];
-                if (cp.cadd) s += cp.cadd[e * E + e2];
+                s += cp.cadd[e * E + e2];
                 out.cov(e, e2, s);
             }
         if (NEED_CCOV) {
@@ -278,7 +285,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 #pragma unroll
                     for (int e = 0; e < E; ++e) cx[e][d] += (fx[e][n] * c[cl.Wc + n]) * dx;
                 }
-                SSMQ_SCHED_FENCE();
+                SSMQ_FENCE_T();
             }
 #pragma unroll
             for (int e = 0; e < E; ++e)
@@ -287,6 +294,10 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
         }
     }
     return ok;
+#undef SSMQ_FENCE_T
+#undef SSMQ_LAUNDER_T
+#undef SSMQ_SPIN_T
+#undef SSMQ_PIN_T
 }
 
 // Sink of the stand-alone kernel: every element goes straight to its SoA plane.

@@ -19,7 +19,7 @@ struct FPar {
 // Offsets (in doubles) into a transform's constant block in HBM; every thread reads it with wave-uniform addresses,
 // so the loads are scalar (s_load) and the block stays in the scalar cache / L2.
 struct ConstLayout {
-    int32_t xi, wm, Wc, Wcc, emv, iK, total;
+    int32_t xi, wm, Wc, Wcc, emv, iK, zero, total;
 };
 __host__ __device__ constexpr inline ConstLayout const_layout(int D, int E, int N, int form) {
     ConstLayout c{};
@@ -29,7 +29,8 @@ __host__ __device__ constexpr inline ConstLayout const_layout(int D, int E, int 
     c.Wcc = c.Wc + (form == SSMQ_FORM_SIGMA ? N : N * N);
     c.emv = c.Wcc + D * N;
     c.iK = c.emv + E * E;
-    c.total = c.iK + N * N;
+    c.zero = c.iK + N * N;   // E*E zeros: the default `cov_add`, so that the kernels add it unconditionally
+    c.total = c.zero + E * E;
     return c;
 }
 
@@ -42,7 +43,7 @@ struct ApplyArgs {
     double *cov_fx;         // [E*D][ld]
     int32_t *status;        // [B]
     const double *consts;   // transform constant block
-    const double *cov_add;  // [E*E] added to cov_f after the model variance (G Q G' / R of the filters), or null
+    const double *cov_add;  // [E*E] added to cov_f after the model variance (G Q G' / R of the filters); never null
     int64_t B, ld;
     int32_t time_stride;
     int32_t emv_mode;

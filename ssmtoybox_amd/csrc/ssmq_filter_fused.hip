@@ -7,6 +7,7 @@
 //
 // The input-state cross-covariance of the dynamics transform is only consumed by the smoother (ssinf.py:105-107,
 // 325-344) and is not formed in the forward pass.
+#include <cstdlib>
 #include "ssmq_apply_small.h"
 #include "ssmq_host.h"
 
@@ -19,7 +20,7 @@ struct FusedArgs {
     int32_t *status;        // [B]: 0 or 1 + first failing step
     const double *c_dyn, *c_obs, *gqg, *rr;
     int64_t B, ld;
-    int32_t T, emv_dyn, emv_obs;
+    int32_t T, emv_dyn, emv_obs, lpw;   // lpw: active lanes (trajectories) per wave
     double nu_dyn, nu_obs;
     FPar fd, fo;
 };
@@ -44,7 +45,8 @@ struct RegSinkNoCross {
 
 template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
 __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(const FusedArgs a) {
-    const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;
+    if ((int)threadIdx.x >= a.lpw) return;
+    const uint32_t b = blockIdx.x * a.lpw + threadIdx.x;
     if ((int64_t)b >= a.B) return;
     const int64_t ld = a.ld;
     double m[D], Pl[D * (D + 1) / 2];
@@ -58,9 +60,19 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
     const CoreParams cpo{(cdouble_p)a.c_obs, (cdouble_p)a.rr, a.emv_obs, a.nu_obs};
     const double nan = __builtin_nan("");
     int32_t agg = 0;
+    double ynext[Y];   // the measurement of step k + 1 is requested one step ahead: its HBM latency hides behind step k
+#pragma unroll
+    for (int i = 0; i < Y; ++i) ynext[i] = a.y[(int64_t)i * ld + b];
 #pragma unroll 1
     for (int k = 0; k < a.T; ++k) {
         const double t = (double)k;  // both transforms of step k + 1 use time index k (ssinf.py:104, 276-288)
+        double ycur[Y];
+#pragma unroll
+        for (int i = 0; i < Y; ++i) ycur[i] = ynext[i];
+        if (k + 1 < a.T) {
+#pragma unroll
+            for (int i = 0; i < Y; ++i) ynext[i] = a.y[((int64_t)(k + 1) * Y + i) * ld + b];
+        }
         // ---- time update: predictive state moments, + G Q G' (ssinf.py:276-279) ----------------------------------
         RegSinkNoCross<D, D> pr;
         bool ok = moment_transform_core<D, D, ND, FD, FORM, TP, 0, false>(m, Pl, t, a.fd, cpd, pr);
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
         for (int d = 0; d < D; ++d) {
             double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < Y; ++i) s += G[d][i] * (a.y[((int64_t)k * Y + i) * ld + b] - ob.mf[i]);
+            for (int i = 0; i < Y; ++i) s += G[d][i] * (ycur[i] - ob.mf[i]);
             m[d] = good ? pr.mf[d] + s : nan;
             a.fm[((int64_t)k * D + d) * ld + b] = m[d];
         }
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
 
 template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
 static hipError_t launch_fused(const FusedArgs &a, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.B + kSmallBlock - 1) / kSmallBlock);
+    const unsigned grid = (unsigned)((a.B + a.lpw - 1) / a.lpw);
     hipLaunchKernelGGL((k_filter_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO>), dim3(grid), dim3(kSmallBlock), 0, s, a);
     return hipGetLastError();
 }
@@ -178,6 +190,11 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
             a.y = d_y; a.m0 = d_m0; a.P0 = d_P0; a.fm = d_fm; a.fP = d_fP; a.status = d_status;
             a.c_dyn = hd->d_small; a.c_obs = ho->d_small; a.gqg = d_gqg; a.rr = d_rr; a.B = B; a.ld = ld; a.T = T;
             a.emv_dyn = hd->emv_mode; a.emv_obs = ho->emv_mode; a.nu_dyn = hd->tp_nu; a.nu_obs = ho->tp_nu;
+            a.lpw = 64;
+            if (const char *ev = getenv("SSMQ_FUSED_LPW")) {
+                const int v = atoi(ev);
+                if (v == 16 || v == 32 || v == 64) a.lpw = v;
+            }
             fill_fpar(fd, &a.fd);
             fill_fpar(fo, &a.fo);
             int rc = hip_fail(e.fn(a, s), e.name);
