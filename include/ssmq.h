@@ -216,6 +216,21 @@ int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, 
                             const double *d_m0, const double *d_P0, const double *GQG, const double *R,
                             double *d_fm, double *d_fP, int32_t *d_status);
 
+/*
+ * Forward pass of a Studentian filter (ssinf.py:555-736: StudentianInference._time_update / _measurement_update) for B
+ * trajectories.  Same loop as ssmq_filter_forward_dev with the reference's scale-matrix bookkeeping:
+ *   transforms are fed the SCALE matrix; scale[k] * cov_f (+ G q_smat G') and scale[k] * (cov_f, cov_fx) (+ r_smat)
+ *   replace the Gaussian predictive covariances; after the Kalman-form update P = S_pr - K S_y K' the next step's scale
+ *   matrix is (dof + delta'delta) / (dof + Y) * P with delta = chol(S_y)^-1 (y - y_mean).
+ *   d_S0 [D*D][ld] initial scale matrix ((dof - 2) / dof * x0_cov); GqG [D*D], r_smat [Y*Y], scale [T] host arrays
+ *   (scale[k] = (dof_pr - 2) / dof_pr of step k - it depends on the degrees of freedom only, not on the data);
+ *   outputs as above: d_fm filtered means, d_fP the reference's `x_cov_fi` (ssinf.py:726).
+ */
+int ssmq_student_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                    const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
+                                    const double *d_m0, const double *d_S0, const double *GqG, const double *r_smat,
+                                    const double *scale, double dof, double *d_fm, double *d_fP, int32_t *d_status);
+
 /* Name of the kernel(s) ssmq_filter_forward_dev would run for this pair of transforms (for profiles). */
 int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
                             const ssmq_integrand *f_obs, char *buf, int len);

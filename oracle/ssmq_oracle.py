@@ -595,3 +595,46 @@ def gaussian_filter(y, m0, P0, Qn, Rn, G, tf_dyn, tf_obs):
         fm[:, k - 1], fP[..., k - 1] = m, P
         pm[:, k - 1], pP[..., k - 1], pC[..., k - 1] = m_pr, P_pr, C_xx
     return fm, fP, pm, pP, pC
+
+
+def student_scale_sequence(steps, dim_y, x0_dof, q_dof, r_dof, dof=4.0, fixed_dof=True):
+    """(dof_pr - 2) / dof_pr used by each time update of a Studentian filter; the filtered dof grows by dim_y per
+    measurement update (ssinf.py:652-660, 735-736), so the sequence depends on the degrees of freedom only."""
+    out = np.zeros(steps)
+    dof_fi = x0_dof
+    for k in range(steps):
+        if fixed_dof:
+            dof_pr = min(dof_fi, q_dof, r_dof)
+            out[k] = (dof_pr - 2) / dof_pr
+        else:
+            out[k] = (dof - 2) / dof
+        dof_fi += dim_y
+    return out
+
+
+def student_filter(y, m0, S0_scale, q_scale, r_scale, G, tf_dyn, tf_obs, scale_seq, dof=4.0):
+    """Forward pass of an additive-noise Studentian filter.  ssinf.py:634-736.
+    S0_scale / q_scale / r_scale are the SCALE matrices the reference's StudentRV.get_stats() returns (it stores them in
+    variables called *_cov); the filter multiplies them by (dof - 2) / dof (ssinf.py:617-621).
+    Returns the filtered means (D, T) and the reference's x_cov_fi (D, D, T)."""
+    dim, steps = m0.shape[0], y.shape[1]
+    c = (dof - 2) / dof
+    smat, q_smat, r_smat = c * S0_scale, c * q_scale, c * r_scale
+    GqG = G.dot(q_smat).dot(G.T)
+    m = m0.copy()
+    fm, fP = np.zeros((dim, steps)), np.zeros((dim, dim, steps))
+    for k in range(steps):
+        sc = scale_seq[k]
+        m_pr, P_pr, _ = tf_dyn(m, smat, k)
+        S_pr = sc * P_pr + GqG
+        y_mean, P_y, P_yx = tf_obs(m_pr, S_pr, k)
+        S_y = sc * P_y + r_smat
+        S_yx = sc * P_yx
+        gain = cho_solve(cho_factor(S_y), S_yx).T
+        dy = y[:, k] - y_mean
+        m = m_pr + gain.dot(dy)
+        P = S_pr - gain.dot(S_y).dot(gain.T)
+        delta = np.linalg.solve(np.linalg.cholesky(S_y), dy)
+        smat = (dof + delta.dot(delta)) / (dof + y.shape[0]) * P
+        fm[:, k], fP[..., k] = m, P
+    return fm, fP

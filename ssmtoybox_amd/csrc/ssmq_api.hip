@@ -204,7 +204,7 @@ static int check_integrand(const ssmq_transform *h, const ssmq_integrand *f, FIn
 int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
                    const double *d_cov, const double *d_time, int time_stride, double *d_mean_f, double *d_cov_f,
                    double *d_cov_fx, int32_t *d_status, const double *d_cov_add, const char **kernel_name,
-                   bool dry_run) {
+                   bool dry_run, double cov_scale = 1.0, double ccov_scale = 1.0) {
     FInfo fi;
     int rc = check_integrand(h, f, &fi);
     if (rc) return rc;
@@ -225,6 +225,7 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         a.cov_fx = d_cov_fx; a.status = d_status; a.consts = h->d_small;
         a.cov_add = d_cov_add ? d_cov_add : h->d_small + const_layout(h->D, h->E, h->N, h->form).zero; a.B = B; a.ld = ld;
         a.time_stride = d_time ? time_stride : 0; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
+        a.cov_scale = cov_scale; a.ccov_scale = ccov_scale;
         fill_fpar(f, &a.fp);
         return hip_fail(se->fn(a, stream()), se->name);
     }
@@ -236,6 +237,7 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     memset(&a, 0, sizeof(a));
     a.D = h->D; a.E = h->E; a.N = h->N; a.form = h->form; a.mode = SSMQ_WIDE_FULL; a.fid = f->id;
     a.time_stride = d_time ? time_stride : 0; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu; a.consts = h->d_wide;
+    a.cov_scale = cov_scale; a.ccov_scale = ccov_scale;
     a.cov_add = d_cov_add; a.mean = d_mean; a.cov = d_cov; a.time = d_time; a.es_in = ld; a.bs_mean = 1; a.bs_cov = 1;
     a.mean_f = d_mean_f; a.cov_f = d_cov_f; a.cov_fx = d_cov_fx; a.es_out = ld; a.bs_mf = a.bs_cf = a.bs_cfx = 1;
     a.status = d_status;
@@ -555,6 +557,7 @@ int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, co
     WideArgs a;
     memset(&a, 0, sizeof(a));
     a.D = D; a.E = h->E; a.N = N; a.form = h->form; a.mode = SSMQ_WIDE_POINTS; a.consts = h->d_wide;
+    a.cov_scale = a.ccov_scale = 1.0;
     a.mean = dm.d(); a.cov = dc.d(); a.es_in = 1; a.bs_mean = D; a.bs_cov = D * D; a.status = (int32_t *)ds.p;
     a.x_out = dx.d(); a.chol_out = dl.d();
     if ((rc = hip_fail(launch_apply_wide(a, B, s), "k_apply_wide(points)"))) return rc;
@@ -599,6 +602,7 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
     WideArgs a;
     memset(&a, 0, sizeof(a));
     a.D = D; a.E = E; a.N = N; a.form = h->form; a.mode = SSMQ_WIDE_FX; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
+    a.cov_scale = a.ccov_scale = 1.0;
     a.consts = h->d_wide; a.mean = dm.d(); a.chol_in = dl.d(); a.fx_in = dfx.d(); a.x_in = dx.d();
     a.mean_f = omf.d(); a.cov_f = ocf.d(); a.cov_fx = ocfx.d(); a.es_out = 1; a.bs_mf = E; a.bs_cf = E * E;
     a.bs_cfx = E * D;
@@ -631,14 +635,15 @@ namespace ssmq {
 int launch_kalman_update_ex(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
                             const double *y_mean, const double *P_y, const double *P_yx, const double *y,
                             double *m_fi, double *P_fi, int32_t *status, const int32_t *st_a, const int32_t *st_b,
-                            int step, hipStream_t s);
+                            int step, hipStream_t s, double student_dof, double *smat_out);
 }
 
 namespace ssmq {
 int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho,
                      const ssmq_integrand *fo, int sel_obs, int64_t B, int64_t ld, int T, const double *d_y,
                      const double *d_m0, const double *d_P0, const double *d_gqg, const double *d_rr, double *d_fm,
-                     double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run);
+                     double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run,
+                     const double *d_sscale, double student_dof);
 }
 
 namespace {
@@ -651,7 +656,7 @@ struct FilterCache {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     std::vector<uint64_t> key;
-    std::vector<double> gqg, rr;
+    std::vector<double> gqg, rr, ss;
     int T = -1;
     bool consts_ok = false;
     void drop_graph() {
@@ -665,10 +670,12 @@ struct FilterCache {
 FilterCache g_fc;
 }  // namespace
 
-extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
-                                       const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
-                                       const double *d_m0, const double *d_P0, const double *GQG, const double *R,
-                                       double *d_fm, double *d_fP, int32_t *d_status) {
+// sscale (host, [T]) / student_dof: Studentian recursion (ssinf.py:634-736); null / 0 for the Gaussian filters.
+static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                               const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
+                               const double *d_m0, const double *d_P0, const double *GQG, const double *R,
+                               double *d_fm, double *d_fP, int32_t *d_status, const double *sscale,
+                               double student_dof) {
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || B < 0 || ld < B || T < 0 || !d_y || !d_m0 || !d_P0 || !d_fm || !d_fP ||
         !d_status) {
         set_error("filter_forward: bad argument");
@@ -684,7 +691,7 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
     if (B == 0 || T == 0) return SSMQ_OK;
     hipStream_t s = stream();
     // workspace carve-up (doubles first, then the two int32 status planes)
-    const size_t n_dbl = (size_t)ld * (D + 2 * D * D + Y + Y * Y + Y * D) + (size_t)T + D * D + Y * Y;
+    const size_t n_dbl = (size_t)ld * (D + 3 * D * D + Y + Y * Y + Y * D) + 2 * (size_t)T + D * D + Y * Y;
     const size_t need = sizeof(double) * n_dbl + 2 * sizeof(int32_t) * (size_t)ld;
     if (g_fc.ws_bytes < need) {
         g_fc.drop_graph();
@@ -702,7 +709,9 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
     double *y_mean = w; w += (size_t)ld * Y;
     double *P_y = w; w += (size_t)ld * Y * Y;
     double *P_yx = w; w += (size_t)ld * Y * D;
+    double *smat = w; w += (size_t)ld * D * D;   // Studentian: rescaled scale matrix fed to the next time update
     double *tvec = w; w += T;
+    double *svec = w; w += T;
     double *gqg = w; w += D * D;
     double *rr = w; w += Y * Y;
     int32_t *st_a = (int32_t *)w, *st_b = st_a + ld;
@@ -710,6 +719,8 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
     std::vector<double> hg(D * D, 0.0), hr(Y * Y, 0.0);
     if (GQG) hg.assign(GQG, GQG + D * D);
     if (R) hr.assign(R, R + Y * Y);
+    std::vector<double> hs(T, 1.0);
+    if (sscale) hs.assign(sscale, sscale + T);
     std::vector<uint64_t> key = {(uint64_t)(uintptr_t)h_dyn, (uint64_t)(uintptr_t)h_obs, (uint64_t)B, (uint64_t)ld,
                                  (uint64_t)T, (uint64_t)(uintptr_t)d_y, (uint64_t)(uintptr_t)d_m0,
                                  (uint64_t)(uintptr_t)d_P0, (uint64_t)(uintptr_t)d_fm, (uint64_t)(uintptr_t)d_fP,
@@ -723,16 +734,19 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
     key.push_back(((uint64_t)D << 48) | ((uint64_t)Y << 32) | ((uint64_t)h_dyn->N << 16) | (uint64_t)h_obs->N);
     key.push_back(((uint64_t)h_dyn->form << 1) | (uint64_t)h_obs->form);
     key.push_back((uint64_t)(uintptr_t)h_obs->d_small);
-    { uint64_t v; memcpy(&v, &h_dyn->tp_nu, 8); key.push_back(v); memcpy(&v, &h_obs->tp_nu, 8); key.push_back(v); }
+    { uint64_t v; memcpy(&v, &h_dyn->tp_nu, 8); key.push_back(v); memcpy(&v, &h_obs->tp_nu, 8); key.push_back(v);
+      memcpy(&v, &student_dof, 8); key.push_back(v); key.push_back(sscale ? 1 : 0); }
 
-    if (!(g_fc.consts_ok && g_fc.gqg == hg && g_fc.rr == hr && g_fc.T == T)) {
+    if (!(g_fc.consts_ok && g_fc.gqg == hg && g_fc.rr == hr && g_fc.T == T && g_fc.ss == hs)) {
         g_fc.drop_graph();
         std::vector<double> tv(T);
         for (int k = 0; k < T; ++k) tv[k] = (double)k;  // both transforms of step k + 1 use time index k (ssinf.py:104)
         SSMQ_HIP(hipMemcpyAsync(tvec, tv.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
         SSMQ_HIP(hipMemcpyAsync(gqg, hg.data(), sizeof(double) * D * D, hipMemcpyHostToDevice, s));
         SSMQ_HIP(hipMemcpyAsync(rr, hr.data(), sizeof(double) * Y * Y, hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(svec, hs.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
         SSMQ_HIP(hipStreamSynchronize(s));
+        g_fc.ss = hs;
         g_fc.gqg = hg;
         g_fc.rr = hr;
         g_fc.T = T;
@@ -746,7 +760,7 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
             return SSMQ_E_ARG;
         }
         rc = try_launch_fused(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), B, ld, T, d_y, d_m0, d_P0, gqg,
-                              rr, d_fm, d_fP, d_status, s, nullptr, false);
+                              rr, d_fm, d_fP, d_status, s, nullptr, false, sscale ? svec : nullptr, student_dof);
         if (rc < 0) return rc;
         if (rc == 1) return SSMQ_OK;
     }
@@ -756,15 +770,16 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
         rc = hip_fail(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, s), "hipMemsetAsync");
         for (int k = 0; k < T && !rc; ++k) {
             const double *m_in = k == 0 ? d_m0 : d_fm + (int64_t)(k - 1) * D * ld;
-            const double *P_in = k == 0 ? d_P0 : d_fP + (int64_t)(k - 1) * D * D * ld;
-            rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec + k, 0, m_pr, P_pr, C_xx, st_a, gqg, nullptr, false);
+            const double *P_in = k == 0 ? d_P0 : (student_dof > 0.0 ? smat : d_fP + (int64_t)(k - 1) * D * D * ld);
+            rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec + k, 0, m_pr, P_pr, C_xx, st_a, gqg, nullptr, false,
+                                hs[k], 1.0);
             if (!rc)
                 rc = apply_dev_impl(h_obs, f_obs, B, ld, m_pr, P_pr, tvec + k, 0, y_mean, P_y, P_yx, st_b, rr, nullptr,
-                                    false);
+                                    false, hs[k], hs[k]);
             if (!rc)
                 rc = launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, d_y + (int64_t)k * Y * ld,
                                              d_fm + (int64_t)k * D * ld, d_fP + (int64_t)k * D * D * ld, d_status,
-                                             st_a, st_b, k, s);
+                                             st_a, st_b, k, s, student_dof, smat);
         }
         hipGraph_t g = nullptr;
         hipError_t ce = hipStreamEndCapture(s, &g);
@@ -781,6 +796,28 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
     return SSMQ_OK;
 }
 
+extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                       const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
+                                       const double *d_m0, const double *d_P0, const double *GQG, const double *R,
+                                       double *d_fm, double *d_fP, int32_t *d_status) {
+    return filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, GQG, R, d_fm, d_fP, d_status,
+                               nullptr, 0.0);
+}
+
+extern "C" int ssmq_student_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,
+                                               ssmq_transform *h_obs, const ssmq_integrand *f_obs, int64_t B,
+                                               int64_t ld, int T, const double *d_y, const double *d_m0,
+                                               const double *d_S0, const double *GqG, const double *r_smat,
+                                               const double *scale, double dof, double *d_fm, double *d_fP,
+                                               int32_t *d_status) {
+    if (!scale || !(dof > 0.0)) {
+        set_error("student_filter_forward: scale[T] and dof > 0 are required");
+        return SSMQ_E_ARG;
+    }
+    return filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_S0, GqG, r_smat, d_fm, d_fP, d_status,
+                               scale, dof);
+}
+
 extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,
                                        const ssmq_transform *h_obs, const ssmq_integrand *f_obs, char *buf, int len) {
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || !buf || len <= 0) return SSMQ_E_ARG;
@@ -790,7 +827,7 @@ extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_i
     int rc = getenv("SSMQ_NO_FUSED") ? 0
                                      : try_launch_fused(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), 0, 0, 0,
                                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                        nullptr, nullptr, &name, true);
+                                                        nullptr, nullptr, &name, true, nullptr, 0.0);
     if (rc < 0) return rc;
     snprintf(buf, len, "%s", rc == 1 ? name : "hipGraph of 3 T launches (apply dyn | apply obs | k_kalman_update)");
     return SSMQ_OK;

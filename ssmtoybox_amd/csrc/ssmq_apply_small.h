@@ -74,6 +74,9 @@ struct CoreParams {
     cdouble_p cadd;   // [E*E] added to the covariance (a block of zeros when the caller has nothing to add)
     int32_t emv_mode;
     double tp_nu;
+    // Studentian filters turn the transformed covariances into scale matrices before the noise term is added
+    // (ssinf.py:672-693): cov = cov_scale * cov + cadd, ccov = ccov_scale * ccov.  1.0 for everything else.
+    double cov_scale, ccov_scale;
 };
 
 // m: mean; L: in = packed lower triangle of cov, out = its Cholesky factor.  Returns false if cov is not PD (results
@@ -178,7 +181,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                     double s = 0.0;
 #pragma unroll
                     for (int d = 0; d <= j; ++d) s += g[d] * L[SSMQ_PK(j, d)];
-                    out.ccov(e, j, s);
+                    out.ccov(e, j, s * cp.ccov_scale);
                 }
                 SSMQ_FENCE_T();
             }
@@ -247,7 +250,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                 double em = use ? c[cl.emv + e * E + e2] : 0.0;
                 if (TP) em = (cp.tp_nu - 2.0 + sv[TP ? SSMQ_PK(e, e2) : 0]) * den * em;
                 double v = cv[SSMQ_PK(e, e2)] - mf[e] * mf[e2] + em;
-                v += cp.cadd[e * E + e2];
+                v = v * cp.cov_scale + cp.cadd[e * E + e2];
                 out.cov(e, e2, v);
                 if (e2 == e) SSMQ_FENCE_T();   // one output row per scheduling region (bounds live SGPRs)
             }
@@ -264,7 +267,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                 double s = 0.0;
 #pragma unroll
                 for (int n = 0; n < N; ++n) s += (fx[e][n] * c[cl.Wc + n]) * fx[e2][n];
-                s += cp.cadd[e * E + e2];
+                s = s * cp.cov_scale + cp.cadd[e * E + e2];
                 out.cov(e, e2, s);
             }
         if (NEED_CCOV) {
@@ -290,7 +293,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 #pragma unroll
             for (int e = 0; e < E; ++e)
 #pragma unroll
-                for (int d = 0; d < D; ++d) out.ccov(e, d, cx[e][d]);
+                for (int d = 0; d < D; ++d) out.ccov(e, d, cx[e][d] * cp.ccov_scale);
         }
     }
     return ok;
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs 
         for (int j = 0; j <= i; ++j) L[SSMQ_PK(i, j)] = a.cov[(i * D + j) * ld + b];
     const double t = a.time[a.time_stride ? b : 0];
 
-    CoreParams cp{(cdouble_p)a.consts, (cdouble_p)a.cov_add, a.emv_mode, a.tp_nu};
+    CoreParams cp{(cdouble_p)a.consts, (cdouble_p)a.cov_add, a.emv_mode, a.tp_nu, a.cov_scale, a.ccov_scale};
     GlobalSink<D, E> sink{a.mean_f, a.cov_f, a.cov_fx, ld, b};
     const bool ok = moment_transform_core<D, E, N, F, FORM, TP, SEL, true>(m, L, t, a.fp, cp, sink);
     a.status[b] = ok ? 0 : 1;

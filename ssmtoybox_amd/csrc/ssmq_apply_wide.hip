@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             const bool use = (e == e2) || (a.emv_mode == SSMQ_EMV_BROADCAST);
             double em = use ? c[cl.emv + idx] : 0.0;
             if (a.tp_nu > 0.0) em = (a.tp_nu - 2.0 + sS[idx]) * (1.0 / (a.tp_nu - 2.0 + (double)N)) * em;
-            double v = sC[idx] - smf[e] * smf[e2] + em;
+            double v = (sC[idx] - smf[e] * smf[e2] + em) * a.cov_scale;
             if (a.cov_add) v += a.cov_add[idx];
             OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? v : nan;
         }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             const int e = idx / D, j = idx % D;
             double s = 0.0;
             for (int d = 0; d <= j; ++d) s += sg[e * D + d] * sL[j * D + d];
-            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? s : nan;
+            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? s * a.ccov_scale : nan;
         }
     } else {
         // ---- classical centred form (mtran.py:141-149), Wc = diag(wc) -------------------------------------------
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             const int e = idx / E, e2 = idx % E;
             double s = 0.0;
             for (int n = 0; n < N; ++n) s += (sfx[e * N + n] * c[cl.Wc + n]) * sfx[e2 * N + n];
+            s *= a.cov_scale;
             if (a.cov_add) s += a.cov_add[idx];
             OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? s : nan;
         }
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             const int e = idx / D, d = idx % D;
             double s = 0.0;
             for (int n = 0; n < N; ++n) s += (sfx[e * N + n] * c[cl.Wc + n]) * (sx[d * N + n] - sm[d]);
-            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? s : nan;
+            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? s * a.ccov_scale : nan;
         }
     }
 #undef OUT_ADDR

@@ -48,6 +48,7 @@ struct ApplyArgs {
     int32_t time_stride;
     int32_t emv_mode;
     double tp_nu;
+    double cov_scale, ccov_scale;   // 1.0 except inside Studentian filters (ssinf.py:672-693)
     FPar fp;
 };
 

@@ -15,6 +15,10 @@ struct UpdArgs {
     const int32_t *st_a, *st_b; // per-step status of the two transforms (may be null)
     int64_t B, ld;
     int32_t step, D, Y;
+    // Studentian update (ssinf.py:700-736): student_dof > 0 -> the inputs are scale matrices, and besides the filtered
+    // "covariance" P_fi the rescaled scale matrix (dof + delta'delta) / (dof + Y) * P_fi is written to smat_out
+    double student_dof;
+    double *smat_out;
 };
 
 template <int D, int Y>
@@ -66,6 +70,20 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
     a.status[b] = agg;
     const double nan = __builtin_nan("");
     const bool good = (agg == 0);
+    double sc2 = 1.0;
+    if (a.student_dof > 0.0) {
+        // delta = chol(P_y)^-1 (y - y_mean)   (ssinf.py:729-731)
+        double dl[Y], dd = 0.0;
+#pragma unroll
+        for (int i = 0; i < Y; ++i) {
+            double s = dy[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= S[SSMQ_PK(i, k)] * dl[k];
+            dl[i] = s / S[SSMQ_PK(i, i)];
+            dd += dl[i] * dl[i];
+        }
+        sc2 = (a.student_dof + dd) / (a.student_dof + (double)Y);
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         double s = 0.0;
@@ -91,7 +109,9 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
 #pragma unroll
             for (int j = 0; j < Y; ++j) s += w[j] * G[d2][j];
             const double pp = a.P_pr[(d * D + d2) * ld + b];
-            a.P_fi[(d * D + d2) * ld + b] = good ? pp - s : nan;
+            const double pf = good ? pp - s : nan;
+            a.P_fi[(d * D + d2) * ld + b] = pf;
+            if (a.student_dof > 0.0) a.smat_out[(d * D + d2) * ld + b] = sc2 * pf;
         }
     }
 }
@@ -140,6 +160,17 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update_generic(const UpdAr
     a.status[b] = agg;
     const double nan = __builtin_nan("");
     const bool good = (agg == 0);
+    double sc2 = 1.0;
+    if (a.student_dof > 0.0) {
+        double dd = 0.0;
+        for (int i = 0; i < Y; ++i) {
+            double s = a.y[i * ld + b] - a.y_mean[i * ld + b];
+            for (int k = 0; k < i; ++k) s -= S[i * Y + k] * v[k];
+            v[i] = s / S[i * Y + i];
+            dd += v[i] * v[i];
+        }
+        sc2 = (a.student_dof + dd) / (a.student_dof + (double)Y);
+    }
     for (int d = 0; d < D; ++d) {
         double s = 0.0;
         for (int i = 0; i < Y; ++i) s += G[d * Y + i] * (a.y[i * ld + b] - a.y_mean[i * ld + b]);
@@ -154,7 +185,9 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update_generic(const UpdAr
         for (int d2 = 0; d2 < D; ++d2) {
             double s = 0.0;
             for (int j = 0; j < Y; ++j) s += w[j] * G[d2 * Y + j];
-            a.P_fi[(d * D + d2) * ld + b] = good ? a.P_pr[(d * D + d2) * ld + b] - s : nan;
+            const double pf = good ? a.P_pr[(d * D + d2) * ld + b] - s : nan;
+            a.P_fi[(d * D + d2) * ld + b] = pf;
+            if (a.student_dof > 0.0) a.smat_out[(d * D + d2) * ld + b] = sc2 * pf;
         }
     }
 }
@@ -168,8 +201,8 @@ static void launch_upd(const UpdArgs &a, hipStream_t s) {
 int launch_kalman_update_ex(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
                             const double *y_mean, const double *P_y, const double *P_yx, const double *y,
                             double *m_fi, double *P_fi, int32_t *status, const int32_t *st_a, const int32_t *st_b,
-                            int step, hipStream_t s) {
-    UpdArgs a{m_pr, P_pr, y_mean, P_y, P_yx, y, m_fi, P_fi, status, st_a, st_b, B, ld, step, D, Y};
+                            int step, hipStream_t s, double student_dof, double *smat_out) {
+    UpdArgs a{m_pr, P_pr, y_mean, P_y, P_yx, y, m_fi, P_fi, status, st_a, st_b, B, ld, step, D, Y, student_dof, smat_out};
 #define SSMQ_UPD(d, y_)                  \
     if (D == d && Y == y_) {             \
         launch_upd<d, y_>(a, s);         \
@@ -197,7 +230,7 @@ int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr
                          const double *y_mean, const double *P_y, const double *P_yx, const double *y, double *m_fi,
                          double *P_fi, int32_t *status, hipStream_t s) {
     return launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, y, m_fi, P_fi, status, nullptr, nullptr,
-                                   0, s);
+                                   0, s, 0.0, nullptr);
 }
 
 }  // namespace ssmq

@@ -22,6 +22,10 @@ struct FusedArgs {
     int64_t B, ld;
     int32_t T, emv_dyn, emv_obs, lpw;   // lpw: active lanes (trajectories) per wave
     double nu_dyn, nu_obs;
+    // Studentian recursion (ssinf.py:634-736): per-step scale (dof_pr - 2) / dof_pr [T] (null = Gaussian filter), the
+    // filter's dof for the measurement-update rescaling; gqg / rr then hold G q_smat G' and r_smat
+    const double *sscale;
+    double student_dof;
     FPar fd, fo;
 };
 
@@ -56,8 +60,9 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) Pl[SSMQ_PK(i, j)] = a.P0[(i * D + j) * ld + b];
-    const CoreParams cpd{(cdouble_p)a.c_dyn, (cdouble_p)a.gqg, a.emv_dyn, a.nu_dyn};
-    const CoreParams cpo{(cdouble_p)a.c_obs, (cdouble_p)a.rr, a.emv_obs, a.nu_obs};
+    CoreParams cpd{(cdouble_p)a.c_dyn, (cdouble_p)a.gqg, a.emv_dyn, a.nu_dyn, 1.0, 1.0};
+    CoreParams cpo{(cdouble_p)a.c_obs, (cdouble_p)a.rr, a.emv_obs, a.nu_obs, 1.0, 1.0};
+    const cdouble_p ssc = (cdouble_p)a.sscale;
     const double nan = __builtin_nan("");
     int32_t agg = 0;
     double ynext[Y];   // the measurement of step k + 1 is requested one step ahead: its HBM latency hides behind step k
@@ -72,6 +77,12 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
         if (k + 1 < a.T) {
 #pragma unroll
             for (int i = 0; i < Y; ++i) ynext[i] = a.y[((int64_t)(k + 1) * Y + i) * ld + b];
+        }
+        if (ssc) {   // Studentian: transformed covariances become scale matrices before the noise term (ssinf.py:672-693)
+            const double sc = ssc[k];
+            cpd.cov_scale = sc;
+            cpo.cov_scale = sc;
+            cpo.ccov_scale = sc;
         }
         // ---- time update: predictive state moments, + G Q G' (ssinf.py:276-279) ----------------------------------
         RegSinkNoCross<D, D> pr;
@@ -110,6 +121,19 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
         }
         if (agg == 0 && !ok) agg = k + 1;
         const bool good = (agg == 0);
+        double sc2 = 1.0;
+        if (a.student_dof > 0.0) {   // (dof + delta'delta) / (dof + Y), delta = chol(S)^-1 (y - y_mean)  (ssinf.py:729-733)
+            double dl[Y], dd = 0.0;
+#pragma unroll
+            for (int i = 0; i < Y; ++i) {
+                double s = ycur[i] - ob.mf[i];
+#pragma unroll
+                for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * dl[q];
+                dl[i] = s / S[SSMQ_PK(i, i)];
+                dd += dl[i] * dl[i];
+            }
+            sc2 = (a.student_dof + dd) / (a.student_dof + (double)Y);
+        }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             double s = 0.0;
@@ -136,7 +160,7 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
                 double p = pr.cv[d >= d2 ? SSMQ_PK(d, d2) : SSMQ_PK(d2, d)] - s;
                 p = good ? p : nan;
                 a.fP[((int64_t)k * D * D + d * D + d2) * ld + b] = p;
-                if (d2 <= d) Pl[SSMQ_PK(d, d2)] = p;   // the next Cholesky reads the lower triangle only (LAPACK 'L')
+                if (d2 <= d) Pl[SSMQ_PK(d, d2)] = sc2 * p;   // next Cholesky reads the lower triangle only (LAPACK 'L')
             }
         }
     }
@@ -178,7 +202,8 @@ static const FusedEntry kFused[] = {
 int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho,
                      const ssmq_integrand *fo, int sel_obs, int64_t B, int64_t ld, int T, const double *d_y,
                      const double *d_m0, const double *d_P0, const double *d_gqg, const double *d_rr, double *d_fm,
-                     double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run) {
+                     double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run,
+                     const double *d_sscale, double student_dof) {
     if (hd->form != ho->form || (hd->tp_nu > 0.0) != (ho->tp_nu > 0.0) || sel_obs < 0 || fd->n_idx > 0) return 0;
     const int tp = hd->tp_nu > 0.0 ? 1 : 0;
     for (const FusedEntry &e : kFused) {
@@ -190,6 +215,7 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
             a.y = d_y; a.m0 = d_m0; a.P0 = d_P0; a.fm = d_fm; a.fP = d_fP; a.status = d_status;
             a.c_dyn = hd->d_small; a.c_obs = ho->d_small; a.gqg = d_gqg; a.rr = d_rr; a.B = B; a.ld = ld; a.T = T;
             a.emv_dyn = hd->emv_mode; a.emv_obs = ho->emv_mode; a.nu_dyn = hd->tp_nu; a.nu_obs = ho->tp_nu;
+            a.sscale = d_sscale; a.student_dof = student_dof;
             a.lpw = 64;
             if (const char *ev = getenv("SSMQ_FUSED_LPW")) {
                 const int v = atoi(ev);

@@ -30,7 +30,7 @@ __host__ __device__ constexpr inline WideLayout wide_layout(int D, int E, int N,
 
 struct WideArgs {
     int32_t D, E, N, form, mode, fid, time_stride, emv_mode;
-    double tp_nu;
+    double tp_nu, cov_scale, ccov_scale;
     const double *consts;   // WideLayout block
     const double *cov_add;  // [E*E] or null
     // inputs: element e of trajectory b at ptr[e * es_in + b * bs_*]

@@ -9,7 +9,8 @@ e.g. research/tpq/tpq_base.py:175-192) - and returns (D, T, B) / (D, D, T, B).
 Per time step k = 1..T (both transforms use time index k - 1: ssinf.py:104, 276-288):
     dyn transform, + G Q G'   ->   obs transform, + R   ->   Kalman update (ssinf.py:297-323)
 all inside `ssmq_filter_forward_dev` (ssmtoybox_amd/csrc); nothing is computed in NumPy.
-Smoothing, the Studentian filters, marginalised inference and non-additive noise are outside this round's scope.
+`StudentianInference` (ssinf.py:555-736) runs the same loop with the reference's scale-matrix bookkeeping
+(`ssmq_student_filter_forward_dev`).  Smoothing, marginalised inference and non-additive noise are not covered.
 """
 import ctypes
 
@@ -17,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from .mtran import (MomentTransform, UnscentedTransform, SphericalRadialTransform, GaussHermiteTransform,
-                    resolve_integrand)
+                    FullySymmetricStudentTransform, resolve_integrand)
 from .bq.bqmtran import GaussianProcessTransform, BayesSardTransform, StudentTProcessTransform
 from .ssmod import TransitionModel, MeasurementModel
 
@@ -58,6 +59,18 @@ class GaussianInference:
         fm, fP = self.forward_pass_batch(np.asarray(data)[..., None])
         return fm[..., 0], fP[..., 0]
 
+    def _launch(self, lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st):
+        gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
+        rr, pr = _lib.as_c(self.r_cov)
+        _lib.check(lib.ssmq_filter_forward_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
+                                               ctypes.byref(f_obs), B, ld, T, ctypes.c_void_p(d_y.ptr),
+                                               ctypes.c_void_p(d_m0.ptr), ctypes.c_void_p(d_P0.ptr), pg, pr,
+                                               ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
+                                               ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_forward_dev')
+
+    def _initial_cov(self):
+        return self.x0_cov
+
     def forward_pass_batch(self, data, x0_mean=None, x0_cov=None, raise_on_failure=True):
         """data (dim_y, T, B).  Optional per-trajectory initial moments x0_mean (B, D), x0_cov (B, D, D)."""
         lib = _lib.load()
@@ -71,7 +84,7 @@ class GaussianInference:
         d_y = _lib.DeviceBuffer(ybuf.nbytes)
         d_y.upload(ybuf)
         m0 = np.broadcast_to(self.x0_mean, (B, D)) if x0_mean is None else np.asarray(x0_mean, dtype=np.float64)
-        P0 = np.broadcast_to(self.x0_cov, (B, D, D)) if x0_cov is None else np.asarray(x0_cov, dtype=np.float64)
+        P0 = np.broadcast_to(self._initial_cov(), (B, D, D)) if x0_cov is None else np.asarray(x0_cov, dtype=np.float64)
         mbuf = np.zeros((D, ld))
         mbuf[:, :B] = m0.T
         Pbuf = np.zeros((D * D, ld))
@@ -86,13 +99,7 @@ class GaussianInference:
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
         f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
         h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
-        gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
-        rr, pr = _lib.as_c(self.r_cov)
-        _lib.check(lib.ssmq_filter_forward_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
-                                               ctypes.byref(f_obs), B, ld, T, ctypes.c_void_p(d_y.ptr),
-                                               ctypes.c_void_p(d_m0.ptr), ctypes.c_void_p(d_P0.ptr), pg, pr,
-                                               ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
-                                               ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_forward_dev')
+        self._launch(lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st)
         fm = d_fm.download((T, D, ld))[:, :, :B].transpose(1, 0, 2)
         fP = d_fP.download((T, D, D, ld))[:, :, :, :B].transpose(1, 2, 0, 3)
         self.status = d_st.download((ld,), dtype=np.int32)[:B]
@@ -155,3 +162,84 @@ class StudentProcessKalman(GaussianInference):
         t_dyn = StudentTProcessTransform(dyn.dim_in, 1, kern_par_dyn, kernel, points, point_hyp, nu=nu)
         t_obs = StudentTProcessTransform(obs.dim_in, 1, kern_par_obs, kernel, points, point_hyp, nu=nu)
         super().__init__(dyn, obs, t_dyn, t_obs)
+
+
+class StudentianInference(GaussianInference):
+    """Additive-noise Studentian filter (ssinf.py:555-736): the state and measurement are jointly Student-t; the moment
+    transforms are fed scale matrices and the measurement update rescales the filtered scale matrix by
+    (dof + delta'delta) / (dof + dim_y).  `forward_pass*` return the filtered mean and the reference's `x_cov_fi`."""
+
+    def __init__(self, mod_dyn, mod_obs, tf_dyn, tf_obs, dof=4.0, fixed_dof=True):
+        assert isinstance(mod_dyn, TransitionModel) and isinstance(mod_obs, MeasurementModel)
+        assert isinstance(tf_dyn, MomentTransform) and isinstance(tf_obs, MomentTransform)
+        if not (mod_dyn.noise_additive and mod_obs.noise_additive):
+            raise NotImplementedError('the device filter loop covers additive-noise models')
+        if dof <= 2.0:
+            dof = 4.0
+        self.mod_dyn, self.mod_obs, self.tf_dyn, self.tf_obs = mod_dyn, mod_obs, tf_dyn, tf_obs
+        # NB: as in the reference, get_stats() hands back SCALE matrices that are then treated as covariances
+        self.x0_mean, self.x0_cov, self.x0_dof = mod_dyn.init_rv.get_stats()
+        self.q_mean, self.q_cov, self.q_dof = mod_dyn.noise_rv.get_stats()
+        self.r_mean, self.r_cov, self.r_dof = mod_obs.noise_rv.get_stats()
+        self.G = mod_dyn.noise_gain
+        scale = (dof - 2) / dof
+        self.x_smat_0 = scale * self.x0_cov
+        self.q_smat = scale * self.q_cov
+        self.r_smat = scale * self.r_cov
+        self.dof, self.fixed_dof = dof, fixed_dof
+        self.fi_mean = self.fi_cov = None
+        self.status = None
+
+    def _initial_cov(self):
+        return self.x_smat_0
+
+    def scale_sequence(self, steps):
+        """(dof_pr - 2) / dof_pr of every time update (ssinf.py:652-660; dof_fi grows by dim_out per update, :735)."""
+        out = np.zeros(steps)
+        dof_fi = self.x0_dof
+        for k in range(steps):
+            if self.fixed_dof:
+                dof_pr = min(dof_fi, self.q_dof, self.r_dof)
+                out[k] = (dof_pr - 2) / dof_pr
+            else:
+                out[k] = (self.dof - 2) / self.dof
+            dof_fi += self.mod_obs.dim_out
+        return out
+
+    def _launch(self, lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st):
+        gqg, pg = _lib.as_c(self.G.dot(self.q_smat).dot(self.G.T))
+        rr, pr = _lib.as_c(self.r_smat)
+        sc, ps = _lib.as_c(self.scale_sequence(T))
+        _lib.check(lib.ssmq_student_filter_forward_dev(
+            ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs), ctypes.byref(f_obs), B, ld, T,
+            ctypes.c_void_p(d_y.ptr), ctypes.c_void_p(d_m0.ptr), ctypes.c_void_p(d_P0.ptr), pg, pr, ps,
+            ctypes.c_double(self.dof), ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
+            ctypes.c_void_p(d_st.ptr)), 'ssmq_student_filter_forward_dev')
+
+
+class FullySymmetricStudent(StudentianInference):
+    """Student filter with the fully-symmetric rule (ssinf.py:743-790)."""
+
+    def __init__(self, dyn, obs, degree=3, kappa=None, dof=4.0, fixed_dof=True):
+        dyn_dof = min(dyn.init_rv.dof, dyn.noise_rv.dof)
+        obs_dof = min(dyn_dof, obs.noise_rv.dof)
+        t_dyn = FullySymmetricStudentTransform(dyn.dim_in, degree, kappa, dyn_dof)
+        t_obs = FullySymmetricStudentTransform(obs.dim_in, degree, kappa, obs_dof)
+        super().__init__(dyn, obs, t_dyn, t_obs, dof, fixed_dof)
+
+
+class StudentProcessStudent(StudentianInference):
+    """Student-t process quadrature Student filter (ssinf.py:793-857).  The reference builds its weights with the
+    Monte-Carlo 'rbf-student' kernel (RNG-dependent, bq/bqkern.py:457-536), which is out of scope here: construct it with
+    the plain RBF kernel and assign the Monte-Carlo weights (tf.wm / tf.Wc / tf.Wcc / tf.model.model_var / tf.model.iK)
+    as data, exactly as research/tpq/tpq_ungm.py:109-124 does."""
+
+    def __init__(self, dyn, obs, kern_par_dyn, kern_par_obs, point_par=None, dof=4.0, fixed_dof=True, dof_tp=4.0):
+        assert kern_par_dyn.shape[1] == dyn.dim_in + 1 and kern_par_obs.shape[1] == obs.dim_in + 1
+        point_par = {} if point_par is None else point_par
+        pp_dyn, pp_obs = dict(point_par), dict(point_par)
+        pp_dyn.update({'dof': dyn.noise_rv.dof})
+        pp_obs.update({'dof': obs.noise_rv.dof})
+        t_dyn = StudentTProcessTransform(dyn.dim_in, 1, kern_par_dyn, 'rbf', 'fs', pp_dyn, nu=dof_tp)
+        t_obs = StudentTProcessTransform(obs.dim_in, 1, kern_par_obs, 'rbf', 'fs', pp_obs, nu=dof_tp)
+        super().__init__(dyn, obs, t_dyn, t_obs, dof, fixed_dof)

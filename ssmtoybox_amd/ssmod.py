@@ -25,6 +25,19 @@ class GaussRV:
         return self.mean, self.cov
 
 
+class StudentRV:
+    """Mean / scale matrix / degrees of freedom with the reference's `get_stats()` protocol (utils.py:628-674)."""
+
+    def __init__(self, dim, mean=None, scale=None, dof=3.0):
+        self.dim = dim
+        self.mean = np.zeros(dim) if mean is None else np.atleast_1d(np.asarray(mean, dtype=float))
+        self.scale = np.eye(dim) if scale is None else np.atleast_2d(np.asarray(scale, dtype=float))
+        self.dof = 3.0 if dof <= 2.0 else dof
+
+    def get_stats(self):
+        return self.mean, self.scale, self.dof
+
+
 class TransitionModel:
     """x_{k+1} = f(x_k, q_k, k)   (ssmod.py:10-244)."""
     dim_state = None

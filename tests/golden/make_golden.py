@@ -48,7 +48,7 @@ from ssmtoybox.mtran import (UnscentedTransform, SphericalRadialTransform, Gauss
 from ssmtoybox.bq.bqmtran import GaussianProcessTransform, StudentTProcessTransform, BayesSardTransform  # noqa: E402
 from ssmtoybox.bq.bqmod import BayesSardModel  # noqa: E402
 from ssmtoybox.bq.bqkern import RBFGauss  # noqa: E402
-from ssmtoybox.utils import GaussRV, n_sum_k, vandermonde  # noqa: E402
+from ssmtoybox.utils import GaussRV, StudentRV, n_sum_k, vandermonde  # noqa: E402
 from ssmtoybox import ssmod, ssinf  # noqa: E402
 
 
@@ -311,8 +311,66 @@ def g4_filters():
     save('g4_filters', **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G5: Studentian filters (ssinf.py:555-800)
+# ---------------------------------------------------------------------------------------------------------------
+def g5_student():
+    out = {}
+    steps = 100
+    # UNGM with Student RVs (tests/test_ssinf.py:219-227 setup)
+    x0, q, r = StudentRV(1), StudentRV(1, scale=np.array([[10.0]])), StudentRV(1)
+    dyn, obs = ssmod.UNGMTransition(x0, q), ssmod.UNGMMeasurement(r, 1)
+    np.random.seed(77)
+    seeds = 8
+    # (the reference's StudentRV.sample only supports one trajectory per call)
+    x = np.concatenate([dyn.simulate_discrete(steps, 1) for _ in range(seeds)], axis=2)
+    y = np.concatenate([obs.simulate_measurements(x[..., i:i + 1]) for i in range(seeds)], axis=2)
+    out['ungm_x'], out['ungm_y'] = x, y
+    alg = ssinf.FullySymmetricStudent(dyn, obs)
+    fm, fc = np.zeros((1, steps, seeds)), np.zeros((1, 1, steps, seeds))
+    for s in range(seeds):
+        fm[..., s], fc[..., s] = alg.forward_pass(y[..., s])
+        alg.reset()
+    out['ungm_fss_fm'], out['ungm_fss_fc'] = fm.copy(), fc.copy()
+    # t-process quadrature Student filter: its 'rbf-student' weights are Monte-Carlo estimates (bq/bqkern.py:457-536),
+    # i.e. data for this build: dumped here and injected there
+    kerpar = np.atleast_2d(np.ones(2))
+    np.random.seed(1)
+    alg = ssinf.StudentProcessStudent(dyn, obs, kerpar, kerpar)
+    for name, tf in (('dyn', alg.tf_dyn), ('obs', alg.tf_obs)):
+        k = 'ungm_tpqs_' + name
+        out[k + '_wm'], out[k + '_Wc'], out[k + '_Wcc'] = tf.wm, tf.Wc, tf.Wcc
+        out[k + '_pts'], out[k + '_iK'] = tf.model.points, tf.model.iK
+        out[k + '_mv'], out[k + '_nu'] = np.float64(tf.model.model_var), np.float64(tf.model.nu)
+    for s in range(seeds):
+        fm[..., s], fc[..., s] = alg.forward_pass(y[..., s])
+        alg.reset()
+    out['ungm_tpqs_fm'], out['ungm_tpqs_fc'] = fm.copy(), fc.copy()
+
+    # constant velocity + radar with Student RVs (tests/test_ssinf.py:228-243 setup)
+    m_0 = np.array([10175, 295, 980, -35]).astype(float)
+    P_0 = np.diag([10000, 100, 10000, 100]).astype(float)
+    x0 = StudentRV(4, m_0, P_0, 1000.0)
+    q = StudentRV(2, scale=np.diag([50, 5]).astype(float), dof=1000.0)
+    r = StudentRV(2, scale=np.diag([50, 0.4e-6]).astype(float), dof=4.0)
+    dyn = ssmod.ConstantVelocity(x0, q, dt=0.5)
+    obs = ssmod.Radar2DMeasurement(r, 4)
+    np.random.seed(78)
+    seeds = 4
+    x = np.concatenate([dyn.simulate_discrete(steps, 1) for _ in range(seeds)], axis=2)
+    y = np.concatenate([obs.simulate_measurements(x[..., i:i + 1]) for i in range(seeds)], axis=2)
+    out['cv_x'], out['cv_y'], out['cv_m0'], out['cv_P0'] = x, y, m_0, P_0
+    alg = ssinf.FullySymmetricStudent(dyn, obs)
+    fm, fc = np.zeros((4, steps, seeds)), np.zeros((4, 4, steps, seeds))
+    for s in range(seeds):
+        fm[..., s], fc[..., s] = alg.forward_pass(y[..., s])
+        alg.reset()
+    out['cv_fss_fm'], out['cv_fss_fc'] = fm, fc
+    save('g5_student', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5']
     if 'g1' in which:
         g1_points()
     if 'g2' in which:
@@ -321,3 +379,5 @@ if __name__ == '__main__':
         g3_apply()
     if 'g4' in which:
         g4_filters()
+    if 'g5' in which:
+        g5_student()

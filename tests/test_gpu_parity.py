@@ -307,6 +307,45 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
     assert rel_err(fm, fm2) < 1e-11 and rel_err(fP, fP2) < 1e-7
 
 
+def test_student_filters_golden(amd, golden, monkeypatch):
+    """Studentian recursion (ssinf.py:555-857) against the reference's trajectories: fully-symmetric Student filter on
+    UNGM (fused kernel) and on CV + radar (launch loop, generic kernels), and the t-process quadrature Student filter
+    with the reference's Monte-Carlo weights injected."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g5_student')
+    y = g['ungm_y']
+    dyn = sm.UNGMTransition(sm.StudentRV(1), sm.StudentRV(1, scale=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.StudentRV(1), 1)
+    alg = ssinf.FullySymmetricStudent(dyn, obs)
+    assert np.array_equal(alg.tf_dyn.unit_sp, [[0.0, 3.0, -3.0]])
+    for no_fused in (False, True):
+        if no_fused:
+            monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+        else:
+            monkeypatch.delenv('SSMQ_NO_FUSED', raising=False)
+        assert ('hipGraph' if no_fused else 'k_filter_fused') in alg.kernel_name()
+        fm, fP = alg.forward_pass_batch(y)
+        assert rel_err(fm, g['ungm_fss_fm']) < 1e-9 and rel_err(fP, g['ungm_fss_fc']) < 1e-9, no_fused
+    monkeypatch.delenv('SSMQ_NO_FUSED', raising=False)
+    kp = np.atleast_2d(np.ones(2))
+    alg = ssinf.StudentProcessStudent(dyn, obs, kp, kp)
+    for tf, tag in ((alg.tf_dyn, 'dyn'), (alg.tf_obs, 'obs')):
+        k = 'ungm_tpqs_' + tag
+        assert np.array_equal(tf.model.points, g[k + '_pts']) and tf.model.nu == float(g[k + '_nu'])
+        tf.wm, tf.Wc, tf.Wcc = g[k + '_wm'], g[k + '_Wc'], g[k + '_Wcc']
+        tf.model.model_var, tf.model.iK = float(g[k + '_mv']), g[k + '_iK']
+    fm, fP = alg.forward_pass_batch(y)
+    assert rel_err(fm, g['ungm_tpqs_fm']) < 1e-8 and rel_err(fP, g['ungm_tpqs_fc']) < 1e-8
+    # constant velocity + radar
+    y = g['cv_y']
+    dyn = sm.ConstantVelocity(sm.StudentRV(4, g['cv_m0'], g['cv_P0'], 1000.0),
+                              sm.StudentRV(2, scale=np.diag([50.0, 5.0]), dof=1000.0), dt=0.5)
+    obs = sm.Radar2DMeasurement(sm.StudentRV(2, scale=np.diag([50.0, 0.4e-6]), dof=4.0), 4)
+    alg = ssinf.FullySymmetricStudent(dyn, obs)
+    fm, fP = alg.forward_pass_batch(y)
+    assert rel_err(fm, g['cv_fss_fm']) < 1e-9 and rel_err(fP, g['cv_fss_fc']) < 1e-6
+
+
 def test_reentry_ukf_golden(amd, golden):
     from ssmtoybox_amd import ssinf, ssmod as sm
     g = golden('g4_filters')
