@@ -217,6 +217,16 @@ int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, 
                             double *d_fm, double *d_fP, int32_t *d_status);
 
 /*
+ * Forward pass + Rauch-Tung-Striebel backward pass (ssinf.py:120-147, 325-344): as ssmq_filter_forward_dev, and
+ * additionally d_sm [T][D][ld], d_sP [T][D*D][ld] smoothed moments.  The reference's indexing is kept: the recursion
+ * starts at the last filtered estimate and leaves the last two smoothed steps equal to the filtered ones.  Synchronous.
+ */
+int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                           const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
+                           const double *d_m0, const double *d_P0, const double *GQG, const double *R, double *d_fm,
+                           double *d_fP, double *d_sm, double *d_sP, int32_t *d_status);
+
+/*
  * Forward pass of a Studentian filter (ssinf.py:555-736: StudentianInference._time_update / _measurement_update) for B
  * trajectories.  Same loop as ssmq_filter_forward_dev with the reference's scale-matrix bookkeeping:
  *   transforms are fed the SCALE matrix; scale[k] * cov_f (+ G q_smat G') and scale[k] * (cov_f, cov_fx) (+ r_smat)

@@ -638,3 +638,18 @@ def student_filter(y, m0, S0_scale, q_scale, r_scale, G, tf_dyn, tf_obs, scale_s
         smat = (dof + delta.dot(delta)) / (dof + y.shape[0]) * P
         fm[:, k], fP[..., k] = m, P
     return fm, fP
+
+
+def rts_smoother(fm, fP, pm, pP, pC):
+    """Backward pass with the reference's indexing (ssinf.py:120-147, 325-344): arrays hold steps
+    1..T; the loop `for k in range(N - 2, 0, -1)` starts from the last filtered estimate, pairs it with the predictive
+    moments of index k + 1 and leaves the last two smoothed steps equal to the filtered ones."""
+    T = fm.shape[1]
+    sm, sP = fm.copy(), fP.copy()
+    ms, Ps = fm[:, T - 1], fP[..., T - 1]
+    for k in range(T - 2, 0, -1):
+        gain = cho_solve(cho_factor(pP[..., k]), pC[..., k]).T
+        ms = fm[:, k - 1] + gain.dot(ms - pm[:, k])
+        Ps = fP[..., k - 1] + gain.dot(Ps - pP[..., k]).dot(gain.T)
+        sm[:, k - 1], sP[..., k - 1] = ms, Ps
+    return sm, sP

@@ -675,7 +675,8 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
                                const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                                const double *d_m0, const double *d_P0, const double *GQG, const double *R,
                                double *d_fm, double *d_fP, int32_t *d_status, const double *sscale,
-                               double student_dof) {
+                               double student_dof, double *d_pm = nullptr, double *d_pP = nullptr,
+                               double *d_pC = nullptr) {
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || B < 0 || ld < B || T < 0 || !d_y || !d_m0 || !d_P0 || !d_fm || !d_fP ||
         !d_status) {
         set_error("filter_forward: bad argument");
@@ -725,7 +726,8 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
                                  (uint64_t)T, (uint64_t)(uintptr_t)d_y, (uint64_t)(uintptr_t)d_m0,
                                  (uint64_t)(uintptr_t)d_P0, (uint64_t)(uintptr_t)d_fm, (uint64_t)(uintptr_t)d_fP,
                                  (uint64_t)(uintptr_t)d_status, (uint64_t)(uintptr_t)h_dyn->d_small,
-                                 (uint64_t)(uintptr_t)g_fc.ws};
+                                 (uint64_t)(uintptr_t)g_fc.ws, (uint64_t)(uintptr_t)d_pm, (uint64_t)(uintptr_t)d_pP,
+                                 (uint64_t)(uintptr_t)d_pC};
     const unsigned char *fb = (const unsigned char *)f_dyn;
     for (size_t i = 0; i + 8 <= sizeof(ssmq_integrand); i += 8) { uint64_t v; memcpy(&v, fb + i, 8); key.push_back(v); }
     fb = (const unsigned char *)f_obs;
@@ -752,8 +754,10 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
         g_fc.T = T;
         g_fc.consts_ok = true;
     }
-    // one fused kernel for the whole time loop when this (models, shapes, form) combination has one
-    if (!getenv("SSMQ_NO_FUSED")) {
+    // one fused kernel for the whole time loop when this (models, shapes, form) combination has one (it does not keep
+    // the predictive moments, so a pass that has to store them for the smoother takes the launch loop)
+    const bool keep_pred = d_pm && d_pP && d_pC;
+    if (!getenv("SSMQ_NO_FUSED") && !keep_pred) {
         FInfo fio;
         if (!integrand_info(f_obs->id, &fio)) {
             set_error("unknown integrand id");
@@ -771,6 +775,11 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
         for (int k = 0; k < T && !rc; ++k) {
             const double *m_in = k == 0 ? d_m0 : d_fm + (int64_t)(k - 1) * D * ld;
             const double *P_in = k == 0 ? d_P0 : (student_dof > 0.0 ? smat : d_fP + (int64_t)(k - 1) * D * D * ld);
+            if (keep_pred) {   // predictive moments of every step stay in HBM for the backward pass (ssinf.py:105-107)
+                m_pr = d_pm + (int64_t)k * D * ld;
+                P_pr = d_pP + (int64_t)k * D * D * ld;
+                C_xx = d_pC + (int64_t)k * D * D * ld;
+            }
             rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec + k, 0, m_pr, P_pr, C_xx, st_a, gqg, nullptr, false,
                                 hs[k], 1.0);
             if (!rc)
@@ -802,6 +811,37 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
                                        double *d_fm, double *d_fP, int32_t *d_status) {
     return filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, GQG, R, d_fm, d_fP, d_status,
                                nullptr, 0.0);
+}
+
+namespace ssmq {
+int launch_rts_backward(int D, int64_t B, int64_t ld, int T, const double *fm, const double *fP, const double *pm,
+                        const double *pP, const double *pC, double *sm, double *sP, int32_t *status, hipStream_t s);
+}
+
+extern "C" int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                      const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
+                                      const double *d_m0, const double *d_P0, const double *GQG, const double *R,
+                                      double *d_fm, double *d_fP, double *d_sm, double *d_sP, int32_t *d_status) {
+    if (!h_dyn || !d_sm || !d_sP || B < 0 || T < 0 || ld < B) {
+        set_error("filter_smooth: bad argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0 || T == 0) return SSMQ_OK;
+    const int D = h_dyn->D;
+    DevBuf pm, pP, pC;
+    if ((rc = pm.alloc(sizeof(double) * (size_t)T * D * ld)) || (rc = pP.alloc(sizeof(double) * (size_t)T * D * D * ld)) ||
+        (rc = pC.alloc(sizeof(double) * (size_t)T * D * D * ld)))
+        return rc;
+    rc = filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, GQG, R, d_fm, d_fP, d_status,
+                             nullptr, 0.0, pm.d(), pP.d(), pC.d());
+    if (rc) return rc;
+    rc = launch_rts_backward(D, B, ld, T, d_fm, d_fP, pm.d(), pP.d(), pC.d(), d_sm, d_sP, d_status, stream());
+    if (rc) return rc;
+    g_fc.drop_graph();   // the captured loop points into the buffers that are released below
+    SSMQ_HIP(hipStreamSynchronize(stream()));
+    return SSMQ_OK;
 }
 
 extern "C" int ssmq_student_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,

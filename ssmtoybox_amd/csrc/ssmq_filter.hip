@@ -233,4 +233,142 @@ int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr
                                    0, s, 0.0, nullptr);
 }
 
+
+// ---- Rauch-Tung-Striebel backward pass (ssinf.py:120-147, 325-344) ---------------------------------------------------
+// One trajectory per lane, run-time loop over time.  Index convention: arrays hold steps 1..T of the reference's
+// 0..T arrays (element t here = index t + 1 there).  The reference's loop `for k in range(N - 2, 0, -1)` starts from the
+// filtered estimate at index N and pairs it with the predictive moments of index N - 1; the
+// smoothed arrays therefore keep the filtered values at the last two steps.  Reproduced as is.
+struct RtsArgs {
+    const double *fm, *fP;       // filtered   [T][D][ld], [T][D*D][ld]
+    const double *pm, *pP, *pC;  // predictive mean, covariance, cross-covariance of the dynamics transform
+    double *sm, *sP;             // smoothed
+    int32_t *status;             // |= (1 << 30) if a predictive covariance is not PD
+    int64_t B, ld;
+    int32_t T;
+};
+
+template <int D>
+__global__ __launch_bounds__(kUpdBlock) void k_rts_backward(const RtsArgs a) {
+    const uint32_t b = blockIdx.x * kUpdBlock + threadIdx.x;
+    if ((int64_t)b >= a.B) return;
+    const int64_t ld = a.ld;
+    const int T = a.T;
+    double ms[D], Ps[D][D];
+    // smoothed = filtered at the last two steps; the recursion starts from the last filtered estimate
+    for (int t = T - 1; t >= 0 && t >= T - 2; --t) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) a.sm[((int64_t)t * D + d) * ld + b] = a.fm[((int64_t)t * D + d) * ld + b];
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) a.sP[((int64_t)t * D * D + i) * ld + b] = a.fP[((int64_t)t * D * D + i) * ld + b];
+    }
+    if (T < 1) return;
+#pragma unroll
+    for (int d = 0; d < D; ++d) ms[d] = a.fm[((int64_t)(T - 1) * D + d) * ld + b];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Ps[i][j] = a.fP[((int64_t)(T - 1) * D * D + i * D + j) * ld + b];
+    bool allok = true;
+#pragma unroll 1
+    for (int k = T - 2; k >= 1; --k) {
+        // predictive moments of reference index k + 1 = element k here; filtered moments of index k = element k - 1
+        double S[D * (D + 1) / 2], mp[D], Pp[D][D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) mp[d] = a.pm[((int64_t)k * D + d) * ld + b];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                Pp[i][j] = a.pP[((int64_t)k * D * D + i * D + j) * ld + b];
+                if (j <= i) S[SSMQ_PK(i, j)] = Pp[i][j];
+            }
+        allok = chol_packed<D>(S) && allok;
+        // gain = (P_pr^-1 C)'  -> G[d][i] = X[i][d], X = P_pr^-1 C, C = cross-covariance (D_out x D_in)
+        double G[D][D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double v[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double s = a.pC[((int64_t)k * D * D + i * D + d) * ld + b];
+#pragma unroll
+                for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * v[q];
+                v[i] = s / S[SSMQ_PK(i, i)];
+            }
+#pragma unroll
+            for (int i = D - 1; i >= 0; --i) {
+                double s = v[i];
+#pragma unroll
+                for (int q = i + 1; q < D; ++q) s -= S[SSMQ_PK(q, i)] * v[q];
+                v[i] = s / S[SSMQ_PK(i, i)];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) G[d][i] = v[i];
+        }
+        double mn[D], Pn[D][D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) s += G[d][i] * (ms[i] - mp[i]);
+            mn[d] = a.fm[((int64_t)(k - 1) * D + d) * ld + b] + s;
+        }
+        // P_s = P_f + G (P_s_next - P_pr) G'
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double w[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) s += G[d][i] * (Ps[i][j] - Pp[i][j]);
+                w[j] = s;
+            }
+#pragma unroll
+            for (int d2 = 0; d2 < D; ++d2) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) s += w[j] * G[d2][j];
+                Pn[d][d2] = a.fP[((int64_t)(k - 1) * D * D + d * D + d2) * ld + b] + s;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            ms[d] = mn[d];
+            a.sm[((int64_t)(k - 1) * D + d) * ld + b] = mn[d];
+#pragma unroll
+            for (int d2 = 0; d2 < D; ++d2) {
+                Ps[d][d2] = Pn[d][d2];
+                a.sP[((int64_t)(k - 1) * D * D + d * D + d2) * ld + b] = Pn[d][d2];
+            }
+        }
+    }
+    if (!allok) a.status[b] |= (1 << 30);
+}
+
+template <int D>
+static void launch_rts(const RtsArgs &a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.B + kUpdBlock - 1) / kUpdBlock);
+    hipLaunchKernelGGL((k_rts_backward<D>), dim3(grid), dim3(kUpdBlock), 0, s, a);
+}
+
+int launch_rts_backward(int D, int64_t B, int64_t ld, int T, const double *fm, const double *fP, const double *pm,
+                        const double *pP, const double *pC, double *sm, double *sP, int32_t *status, hipStream_t s) {
+    RtsArgs a{fm, fP, pm, pP, pC, sm, sP, status, B, ld, T};
+    switch (D) {
+        case 1: launch_rts<1>(a, s); break;
+        case 2: launch_rts<2>(a, s); break;
+        case 3: launch_rts<3>(a, s); break;
+        case 4: launch_rts<4>(a, s); break;
+        case 5: launch_rts<5>(a, s); break;
+        case 6: launch_rts<6>(a, s); break;
+        case 7: launch_rts<7>(a, s); break;
+        default:
+            set_error("rts_backward: state dimension above 7 is not instantiated");
+            return SSMQ_E_UNSUPPORTED;
+    }
+    return hip_fail(hipGetLastError(), "k_rts_backward");
+}
+
 }  // namespace ssmq

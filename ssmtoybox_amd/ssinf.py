@@ -10,7 +10,8 @@ Per time step k = 1..T (both transforms use time index k - 1: ssinf.py:104, 276-
     dyn transform, + G Q G'   ->   obs transform, + R   ->   Kalman update (ssinf.py:297-323)
 all inside `ssmq_filter_forward_dev` (ssmtoybox_amd/csrc); nothing is computed in NumPy.
 `StudentianInference` (ssinf.py:555-736) runs the same loop with the reference's scale-matrix bookkeeping
-(`ssmq_student_filter_forward_dev`).  Smoothing, marginalised inference and non-additive noise are not covered.
+(`ssmq_student_filter_forward_dev`); `backward_pass*` is the RTS smoother (`ssmq_filter_smooth_dev`).  Marginalised
+inference and non-additive noise are not covered.
 """
 import ctypes
 
@@ -37,11 +38,15 @@ class GaussianInference:
         self.r_mean, self.r_cov = mod_obs.noise_rv.get_stats()
         self.G = mod_dyn.noise_gain
         self.fi_mean = self.fi_cov = None
+        self.sm_mean = self.sm_cov = None
         self.status = None
+        self._data = None
 
     def reset(self):
         self.fi_mean = self.fi_cov = None
+        self.sm_mean = self.sm_cov = None
         self.status = None
+        self._data = None
 
     def kernel_name(self):
         """Which kernel(s) the device filter loop runs for this filter (one fused kernel, or a replayed hipGraph)."""
@@ -71,10 +76,23 @@ class GaussianInference:
     def _initial_cov(self):
         return self.x0_cov
 
-    def forward_pass_batch(self, data, x0_mean=None, x0_cov=None, raise_on_failure=True):
+    def backward_pass(self):
+        """RTS smoothing of the trajectory given to the last forward_pass (ssinf.py:120-147)."""
+        sm, sP = self.backward_pass_batch()
+        return sm[..., 0], sP[..., 0]
+
+    def backward_pass_batch(self):
+        """RTS smoothing of the batch given to the last forward_pass_batch: (D, T, B), (D, D, T, B).  The reference's
+        indexing is kept (the last two smoothed steps equal the filtered ones)."""
+        assert self._data is not None, 'run forward_pass first'     # the reference asserts its 'filtered' flag
+        self.forward_pass_batch(self._data, smooth=True)
+        return self.sm_mean, self.sm_cov
+
+    def forward_pass_batch(self, data, x0_mean=None, x0_cov=None, raise_on_failure=True, smooth=False):
         """data (dim_y, T, B).  Optional per-trajectory initial moments x0_mean (B, D), x0_cov (B, D, D)."""
         lib = _lib.load()
         data = np.asarray(data, dtype=np.float64)
+        self._data = data
         Y, T, B = data.shape
         D = self.mod_dyn.dim_state
         ld = (B + 63) // 64 * 64
@@ -99,7 +117,22 @@ class GaussianInference:
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
         f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
         h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
-        self._launch(lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st)
+        if smooth:
+            d_sm, d_sP = _lib.DeviceBuffer(8 * T * D * ld), _lib.DeviceBuffer(8 * T * D * D * ld)
+            gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
+            rr, pr = _lib.as_c(self.r_cov)
+            _lib.check(lib.ssmq_filter_smooth_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
+                                                  ctypes.byref(f_obs), B, ld, T, ctypes.c_void_p(d_y.ptr),
+                                                  ctypes.c_void_p(d_m0.ptr), ctypes.c_void_p(d_P0.ptr), pg, pr,
+                                                  ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
+                                                  ctypes.c_void_p(d_sm.ptr), ctypes.c_void_p(d_sP.ptr),
+                                                  ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_smooth_dev')
+            self.sm_mean = np.ascontiguousarray(d_sm.download((T, D, ld))[:, :, :B].transpose(1, 0, 2))
+            self.sm_cov = np.ascontiguousarray(d_sP.download((T, D, D, ld))[:, :, :, :B].transpose(1, 2, 0, 3))
+            d_sm.free()
+            d_sP.free()
+        else:
+            self._launch(lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st)
         fm = d_fm.download((T, D, ld))[:, :, :B].transpose(1, 0, 2)
         fP = d_fP.download((T, D, D, ld))[:, :, :, :B].transpose(1, 2, 0, 3)
         self.status = d_st.download((ld,), dtype=np.int32)[:B]
@@ -192,6 +225,9 @@ class StudentianInference(GaussianInference):
 
     def _initial_cov(self):
         return self.x_smat_0
+
+    def backward_pass_batch(self):
+        raise NotImplementedError('the reference has no Student smoother either (ssinf.py:738-740)')
 
     def scale_sequence(self, steps):
         """(dof_pr - 2) / dof_pr of every time update (ssinf.py:652-660; dof_fi grows by dim_out per update, :735)."""

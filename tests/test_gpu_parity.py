@@ -272,6 +272,11 @@ def test_ungm_filter_golden(amd, golden, name):
     # the reference's one-trajectory interface
     fm1, fP1 = alg.forward_pass(y[..., 0])
     assert np.array_equal(fm1, fm[..., 0]) and np.array_equal(fP1, fP[..., 0])
+    # RTS smoother (backward_pass), including the reference's indexing quirk at the last two steps
+    fm, fP = alg.forward_pass_batch(y)
+    sm, sP = alg.backward_pass_batch()
+    assert rel_err(sm, g[k + '_sm']) < 1e-8 and rel_err(sP, g[k + '_sc']) < 1e-8, name
+    assert np.array_equal(sm[:, -2:], fm[:, -2:]) and np.array_equal(alg.fi_mean, fm)
 
 
 def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
