@@ -134,7 +134,7 @@ static int upload_consts(ssmq_transform *h) {
             }
         for (int d = 0; d < D; ++d)
             for (int n = 0; n < N; ++n) {
-                s[cs.Wcc + n * D + d] = h->Wcc[d * N + n];
+                s[cs.Wcc + d * N + n] = h->Wcc[d * N + n];   // row d contiguous (one body of the ccov stage)
                 w[cw.Wcc + d * N + n] = h->Wcc[d * N + n];
             }
     }
@@ -226,6 +226,8 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         a.cov_add = d_cov_add ? d_cov_add : h->d_small + const_layout(h->D, h->E, h->N, h->form).zero; a.B = B; a.ld = ld;
         a.time_stride = d_time ? time_stride : 0; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
         a.cov_scale = cov_scale; a.ccov_scale = ccov_scale;
+        a.stagger_mode = a.stagger_arg = a.stagger_sleeps = 0;
+        if (const char *ev = getenv("SSMQ_STAGGER")) sscanf(ev, "%d,%d,%d", &a.stagger_mode, &a.stagger_arg, &a.stagger_sleeps);
         fill_fpar(f, &a.fp);
         return hip_fail(se->fn(a, stream()), se->name);
     }

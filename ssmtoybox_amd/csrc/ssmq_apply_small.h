@@ -20,7 +20,10 @@
 
 namespace ssmq {
 
-constexpr int kSmallBlock = 64;
+#ifndef SSMQ_SMALL_BLOCK
+#define SSMQ_SMALL_BLOCK 64
+#endif
+constexpr int kSmallBlock = SSMQ_SMALL_BLOCK;
 
 // Keeps hipcc's scheduler from interleaving the fully unrolled per-sigma-point / per-column bodies: without it the
 // live ranges of all N bodies overlap and the D = 6 kernel needs > 512 registers (170 spills).
@@ -145,115 +148,130 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
         // ---- cross-covariance first, one output row at a time: (fx_e Wcc') L'.  After it L is dead, which keeps the
         //      covariance stage (fx + accumulators) inside 256 registers ---------------------------------------------
         if (NEED_CCOV) {
-            constexpr int CH = 2;                       // sigma points per constant chunk (CH * D doubles in SGPRs)
-            constexpr int NCH = (N + CH - 1) / CH;
-            SBuf<CH * D> wcur;
-            sload(wcur, SSMQ_LAUNDER_T(c) + cl.Wcc);           // Wcc' is [N][D]: chunk ch = rows ch*CH .. ch*CH+CH-1 (padded
-            SSMQ_SPIN_T(wcur);                                 // reads past row N-1 fall into the emv block: harmless)
+            // Two passes over halves of the output rows e, each streaming Wcc once, one input dimension d per body:
+            //   g_e = fx_e . Wcc[d, :]  (N FMAs per row), then ccov[e][j] += g_e L[j][d] for j >= d; column d of the
+            // result is complete after body d and leaves at once.  Per body: N scalar constants for ~N EH FMAs, long
+            // enough to cover the scalar-cache latency of the next body's constants; live accumulators EH x D.
+            constexpr int EH = (E + 1) / 2;
+            constexpr int NPASS = (E + EH - 1) / EH;
+            SBuf<N> wcur;
+            sload(wcur, SSMQ_LAUNDER_T(c) + cl.Wcc);   // Wcc block is [D][N] here (row d contiguous)
+            SSMQ_SPIN_T(wcur);
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                double g[D];
+            for (int ps = 0; ps < NPASS; ++ps) {
+                double acc[EH][D];
 #pragma unroll
-                for (int d = 0; d < D; ++d) g[d] = 0.0;
+                for (int q = 0; q < EH; ++q)
 #pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    constexpr int kLast = 0;
-                    (void)kLast;
-                    const bool more = !(e == E - 1 && ch == NCH - 1);
-                    SBuf<CH * D> wnext;
-                    if (more) sload(wnext, SSMQ_LAUNDER_T(c) + cl.Wcc + ((ch + 1) % NCH) * CH * D);
+                    for (int j = 0; j < D; ++j) acc[q][j] = 0.0;
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) {
-                        const int n = ch * CH + q;
-                        if (n < N) {
+                for (int d = 0; d < D; ++d) {
+                    const bool more = !(ps == NPASS - 1 && d == D - 1);
+                    SBuf<N> wnext;
+                    if (more) sload(wnext, SSMQ_LAUNDER_T(c) + cl.Wcc + ((d + 1) % D) * N);
 #pragma unroll
-                            for (int d = 0; d < D; ++d) g[d] += fx[e][n] * wcur.v[q * D + d];
+                    for (int q = 0; q < EH; ++q) {
+                        const int e = ps * EH + q;
+                        if (e < E) {
+                            double g = 0.0;
+#pragma unroll
+                            for (int n = 0; n < N; ++n) g += fx[e][n] * wcur.v[n];
+#pragma unroll
+                            for (int j = d; j < D; ++j) acc[q][j] += g * L[SSMQ_PK(j, d)];
+                            out.ccov(e, d, acc[q][d] * cp.ccov_scale);
                         }
                     }
+#pragma unroll
+                    for (int q = 0; q < EH; ++q)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) SSMQ_PIN_T(acc[q][j]);
                     if (more) {
                         SSMQ_SPIN_T(wnext);
                         wcur = wnext;
                     }
                     SSMQ_FENCE_T();
                 }
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int d = 0; d <= j; ++d) s += g[d] * L[SSMQ_PK(j, d)];
-                    out.ccov(e, j, s * cp.ccov_scale);
-                }
-                SSMQ_FENCE_T();
             }
         }
-        // ---- covariance: (fx Wc) fx' - mean mean' + emv --------------------------------------------------------
-        double cv[E * (E + 1) / 2];
-#pragma unroll
-        for (int i = 0; i < E * (E + 1) / 2; ++i) cv[i] = 0.0;
+        // ---- covariance: (fx Wc) fx' - mean mean' + emv, TWO OUTPUT ROWS AT A TIME -------------------------------
+        // Rows (e0, e0 + 1) are accumulated over all columns j of Wc and stored as soon as they are complete, so the
+        // E*E covariance stores of a wave are spread over the whole stage instead of forming a burst at its end (with
+        // every wave of the launch in the same phase that burst ran at the HBM write limit while the ALUs idled).
+        // Wc is streamed E/2 times from the scalar cache; only 2E - 1 accumulators are live instead of E(E+1)/2.
+        constexpr int RB = 2;
+        const double den = TP ? 1.0 / (cp.tp_nu - 2.0 + (double)N) : 0.0;
         SBuf<N> colc;
         sload(colc, SSMQ_LAUNDER_T(c) + cl.Wc);
         SSMQ_SPIN_T(colc);
+        SBuf<N> kolc;   // same for iK when the model variance is the Student-t process one
+        if (TP) {
+            sload(kolc, SSMQ_LAUNDER_T(c) + cl.iK);
+            SSMQ_SPIN_T(kolc);
+        }
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            SBuf<N> coln;
-            if (j + 1 < N) sload(coln, SSMQ_LAUNDER_T(c) + cl.Wc + (j + 1) * N);
-            double tj[E];
+        for (int e0 = 0; e0 < E; e0 += RB) {
+            double cv[RB][E], sv[RB][E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                double s = 0.0;
+            for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int i = 0; i < N; ++i) s += fx[e][i] * colc.v[i];
-                tj[e] = s;
+                for (int e2 = 0; e2 < E; ++e2) cv[r][e2] = sv[r][e2] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const bool more = !(e0 + RB >= E && j == N - 1);
+                SBuf<N> coln, koln;
+                if (more) sload(coln, SSMQ_LAUNDER_T(c) + cl.Wc + ((j + 1) % N) * N);
+                if (TP && more) sload(koln, SSMQ_LAUNDER_T(c) + cl.iK + ((j + 1) % N) * N);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const int e = e0 + r;
+                    if (e < E) {
+                        double tj = 0.0, uj = 0.0;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) tj += fx[e][i] * colc.v[i];
+#pragma unroll
+                        for (int e2 = 0; e2 <= e; ++e2) cv[r][e2] += tj * fx[e2][j];
+                        if (TP) {
+#pragma unroll
+                            for (int i = 0; i < N; ++i) uj += fx[e][i] * kolc.v[i];
+#pragma unroll
+                            for (int e2 = 0; e2 <= e; ++e2) sv[r][e2] += uj * fx[e2][j];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e2 = 0; e2 < E; ++e2) {
+                        SSMQ_PIN_T(cv[r][e2]);   // keeps column j's work in body j (see pin_v)
+                        if (TP) SSMQ_PIN_T(sv[r][e2]);
+                    }
+                if (more) {
+                    SSMQ_SPIN_T(coln);
+                    colc = coln;
+                    if (TP) {
+                        SSMQ_SPIN_T(koln);
+                        kolc = koln;
+                    }
+                }
+                SSMQ_FENCE_T();
             }
 #pragma unroll
-            for (int e = 0; e < E; ++e)
+            for (int r = 0; r < RB; ++r) {
+                const int e = e0 + r;
+                if (e < E) {
 #pragma unroll
-                for (int e2 = 0; e2 <= e; ++e2) cv[SSMQ_PK(e, e2)] += tj[e] * fx[e2][j];
-#pragma unroll
-            for (int i = 0; i < E * (E + 1) / 2; ++i) SSMQ_PIN_T(cv[i]);   // keeps column j's work in body j (see pin_v)
-            if (j + 1 < N) {
-                SSMQ_SPIN_T(coln);
-                colc = coln;
+                    for (int e2 = 0; e2 <= e; ++e2) {
+                        const bool use = (e == e2) || (cp.emv_mode == SSMQ_EMV_BROADCAST);
+                        double em = use ? c[cl.emv + e * E + e2] : 0.0;
+                        if (TP) em = (cp.tp_nu - 2.0 + sv[r][e2]) * den * em;
+                        double v = cv[r][e2] - mf[e] * mf[e2] + em;
+                        v = v * cp.cov_scale + cp.cadd[e * E + e2];
+                        out.cov(e, e2, v);
+                    }
+                }
             }
             SSMQ_FENCE_T();
         }
-        // expected model variance: constant, or scaled by the data for a Student-t process model
-        double sv[TP ? E * (E + 1) / 2 : 1];
-        if (TP) {
-#pragma unroll
-            for (int i = 0; i < E * (E + 1) / 2; ++i) sv[i] = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                double tj[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) s += fx[e][i] * c[cl.iK + j * N + i];
-                    tj[e] = s;
-                }
-#pragma unroll
-                for (int e = 0; e < E; ++e)
-#pragma unroll
-                    for (int e2 = 0; e2 <= e; ++e2) sv[SSMQ_PK(e, e2)] += tj[e] * fx[e2][j];
-#pragma unroll
-                for (int i = 0; i < E * (E + 1) / 2; ++i) SSMQ_PIN_T(sv[i]);
-                SSMQ_FENCE_T();
-            }
-        }
-        const double den = TP ? 1.0 / (cp.tp_nu - 2.0 + (double)N) : 0.0;
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-#pragma unroll
-            for (int e2 = 0; e2 <= e; ++e2) {
-                const bool use = (e == e2) || (cp.emv_mode == SSMQ_EMV_BROADCAST);
-                double em = use ? c[cl.emv + e * E + e2] : 0.0;
-                if (TP) em = (cp.tp_nu - 2.0 + sv[TP ? SSMQ_PK(e, e2) : 0]) * den * em;
-                double v = cv[SSMQ_PK(e, e2)] - mf[e] * mf[e2] + em;
-                v = v * cp.cov_scale + cp.cadd[e * E + e2];
-                out.cov(e, e2, v);
-                if (e2 == e) SSMQ_FENCE_T();   // one output row per scheduling region (bounds live SGPRs)
-            }
     } else {
         // ---- classical centred form, diagonal covariance weights -----------------------------------------------
 #pragma unroll
@@ -309,12 +327,30 @@ struct GlobalSink {
     double *mean_f, *cov_f, *cov_fx;
     int64_t ld;
     uint32_t b;
-    __device__ __forceinline__ void mean(int e, double v) { mean_f[e * ld + b] = v; }
+    // SSMQ_DIAG_* : timing-only diagnostic builds (tools/ab.sh); never defined in the product build.
+    __device__ __forceinline__ void keep(double v) { asm volatile("" ::"v"(v)); }
+    __device__ __forceinline__ void mean(int e, double v) {
+#ifdef SSMQ_DIAG_NOSTORE_ALL
+        keep(v);
+#else
+        mean_f[e * ld + b] = v;
+#endif
+    }
     __device__ __forceinline__ void cov(int e, int e2, double v) {
+#if defined(SSMQ_DIAG_NOSTORE_ALL) || defined(SSMQ_DIAG_NOSTORE_COV)
+        keep(v);
+#else
         cov_f[(e * E + e2) * ld + b] = v;
         if (e2 != e) cov_f[(e2 * E + e) * ld + b] = v;
+#endif
     }
-    __device__ __forceinline__ void ccov(int e, int d, double v) { cov_fx[(e * D + d) * ld + b] = v; }
+    __device__ __forceinline__ void ccov(int e, int d, double v) {
+#ifdef SSMQ_DIAG_NOSTORE_ALL
+        keep(v);
+#else
+        cov_fx[(e * D + d) * ld + b] = v;
+#endif
+    }
 };
 
 // __launch_bounds__(64, 2): at least two waves per SIMD, i.e. at most 256 registers per lane.  The D = E = 6, N = 13
@@ -324,14 +360,32 @@ template <int D, int E, int N, int F, int FORM, int TP, int SEL>
 __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs a) {
     const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;  // 32-bit lane offset: plane base stays scalar
     if ((int64_t)b >= a.B) return;
+    if (a.stagger_sleeps > 0) {
+        // Wave stagger: every wave of a launch starts in the load phase, computes, then stores, so HBM idles while the
+        // ALUs work and vice versa.  Delaying part of the waves lets their memory phases fall into the others' compute.
+        bool late = false;
+        if (a.stagger_mode == 1) late = (int)blockIdx.x >= a.stagger_arg;          // blocks dispatched last
+        if (a.stagger_mode == 2) late = ((int)blockIdx.x / a.stagger_arg) & 1;    // alternating groups of blocks
+        if (late)
+            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int64_t ld = a.ld;
     double m[D], L[D * (D + 1) / 2];
+#ifdef SSMQ_DIAG_NOLOAD
+#pragma unroll
+    for (int d = 0; d < D; ++d) m[d] = 6500.0 + 1e-7 * (double)b + d;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[SSMQ_PK(i, j)] = (i == j) ? 1e-4 : 1e-9 * (double)(b & 255);
+#else
 #pragma unroll
     for (int d = 0; d < D; ++d) m[d] = a.mean[d * ld + b];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) L[SSMQ_PK(i, j)] = a.cov[(i * D + j) * ld + b];
+#endif
     const double t = a.time[a.time_stride ? b : 0];
 
     CoreParams cp{(cdouble_p)a.consts, (cdouble_p)a.cov_add, a.emv_mode, a.tp_nu, a.cov_scale, a.ccov_scale};

@@ -49,6 +49,7 @@ struct ApplyArgs {
     int32_t emv_mode;
     double tp_nu;
     double cov_scale, ccov_scale;   // 1.0 except inside Studentian filters (ssinf.py:672-693)
+    int32_t stagger_mode, stagger_arg, stagger_sleeps;   // experimental wave stagger (see k_apply_small)
     FPar fp;
 };
 
