@@ -1,12 +1,14 @@
 // C ABI of libssmq (include/ssmq.h): device plumbing, transform handles, kernel dispatch.  No CPU fallback exists
 // behind these entry points: every compute call ends in a HIP kernel launch or returns an error.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
 #include "ssmq_host.h"
+#include "ssmq_apply_small.h"
 
 namespace ssmq {
 
@@ -53,7 +55,7 @@ const SmallEntry *small_table_b(int *n);
 const SmallEntry *small_table_c(int *n);
 const SmallEntry *small_table_d(int *n);
 
-const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int sel) {
+const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int sel, int opt) {
     typedef const SmallEntry *(*tab_fn)(int *);
     static const tab_fn tabs[] = {small_table_a, small_table_b, small_table_c, small_table_d};
     for (tab_fn t : tabs) {
@@ -61,7 +63,7 @@ const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int
         const SmallEntry *e = t(&n);
         for (int i = 0; i < n; ++i)
             if (e[i].fid == fid && e[i].D == D && e[i].E == E && e[i].N == N && e[i].form == form && e[i].tp == tp &&
-                e[i].sel == sel)
+                e[i].sel == sel && e[i].opt == opt)
                 return &e[i];
     }
     return nullptr;
@@ -146,6 +148,56 @@ static int upload_consts(ssmq_transform *h) {
                 w[cw.iK + i * N + j] = h->iK[i * N + j];
             }
     }
+    // ---- optional fast paths (ssmq_apply_small.h: SSMQ_OPT_LDL / SSMQ_OPT_UT), each verified before it is offered ----
+    h->opt_mask = 0;
+    if (!sigma) {
+        // Wc = U diag(d) U', unit lower U, no pivoting; accepted only if the factorisation reproduces Wc to 1e-14
+        std::vector<double> U((size_t)N * N, 0.0), dd(N, 0.0), A(h->Wc);
+        bool ok = true;
+        double wmax = 0.0;
+        for (double v : A) wmax = std::max(wmax, std::fabs(v));
+        for (int j = 0; j < N && ok; ++j) {
+            double dj = A[j * N + j];
+            for (int k = 0; k < j; ++k) dj -= U[j * N + k] * U[j * N + k] * dd[k];
+            if (!(std::fabs(dj) > 1e-13 * wmax)) ok = false;
+            dd[j] = dj;
+            U[j * N + j] = 1.0;
+            for (int i = j + 1; i < N && ok; ++i) {
+                double v = 0.5 * (A[i * N + j] + A[j * N + i]);
+                for (int k = 0; k < j; ++k) v -= U[i * N + k] * U[j * N + k] * dd[k];
+                U[i * N + j] = v / dj;
+            }
+        }
+        double err = 0.0;
+        for (int i = 0; i < N && ok; ++i)
+            for (int j = 0; j < N; ++j) {
+                double v = 0.0;
+                for (int k = 0; k <= std::min(i, j); ++k) v += U[i * N + k] * dd[k] * U[j * N + k];
+                err = std::max(err, std::fabs(v - A[i * N + j]));
+            }
+        if (ok && err <= 1e-14 * wmax && !getenv("SSMQ_NO_FASTPATH")) {
+            h->opt_mask |= SSMQ_OPT_LDL;
+            for (int j = 0; j < N; ++j) {
+                s[cs.ldlD + j] = dd[j];
+                for (int i = 0; i < N; ++i) s[cs.ldlU + j * N + i] = U[i * N + j];   // column j contiguous
+            }
+        }
+    }
+    if (N == 2 * D + 1 && !getenv("SSMQ_NO_FASTPATH")) {
+        const double cc = h->xi[0 * N + 1];
+        bool ut = cc > 0.0;
+        for (int d = 0; d < D && ut; ++d)
+            for (int n = 0; n < N; ++n) {
+                double want = 0.0;
+                if (n == 1 + d) want = cc;
+                if (n == 1 + D + d) want = -cc;
+                if (h->xi[d * N + n] != want) ut = false;
+            }
+        if (ut) {
+            h->opt_mask |= SSMQ_OPT_UT;
+            s[cs.utc] = cc;
+        }
+    }
     SSMQ_HIP(hipMemcpyAsync(h->d_small, s.data(), sizeof(double) * cs.total, hipMemcpyHostToDevice, stream()));
     SSMQ_HIP(hipMemcpyAsync(h->d_wide, w.data(), sizeof(double) * cw.total, hipMemcpyHostToDevice, stream()));
     SSMQ_HIP(hipStreamSynchronize(stream()));
@@ -210,7 +262,12 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     if (rc) return rc;
     const int tp = h->tp_nu > 0.0 ? 1 : 0;
     const int sel = sel_pattern(f, fi.din);
-    const SmallEntry *se = sel >= 0 ? find_small(f->id, h->D, h->E, h->N, h->form, tp, sel) : nullptr;
+    const SmallEntry *se = nullptr;
+    if (sel >= 0) {
+        // best available fast path first (TP keeps the dense covariance form; see SSMQ_OPT_* in ssmq_apply_small.h)
+        const int want[4] = {h->opt_mask & (tp ? SSMQ_OPT_UT : 3), h->opt_mask & SSMQ_OPT_UT, h->opt_mask & SSMQ_OPT_LDL & (tp ? 0 : 1), 0};
+        for (int k = 0; k < 4 && !se; ++k) se = find_small(f->id, h->D, h->E, h->N, h->form, tp, sel, want[k]);
+    }
     if (kernel_name) *kernel_name = se ? se->name : "k_apply_wide";
     if (dry_run) return SSMQ_OK;
     if (B <= 0) return SSMQ_OK;
@@ -226,8 +283,6 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         a.cov_add = d_cov_add ? d_cov_add : h->d_small + const_layout(h->D, h->E, h->N, h->form).zero; a.B = B; a.ld = ld;
         a.time_stride = d_time ? time_stride : 0; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
         a.cov_scale = cov_scale; a.ccov_scale = ccov_scale;
-        a.stagger_mode = a.stagger_arg = a.stagger_sleeps = 0;
-        if (const char *ev = getenv("SSMQ_STAGGER")) sscanf(ev, "%d,%d,%d", &a.stagger_mode, &a.stagger_arg, &a.stagger_sleeps);
         fill_fpar(f, &a.fp);
         return hip_fail(se->fn(a, stream()), se->name);
     }

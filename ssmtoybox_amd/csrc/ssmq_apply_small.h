@@ -82,9 +82,19 @@ struct CoreParams {
     double cov_scale, ccov_scale;
 };
 
+// Optional fast paths, selected by the host per transform handle (both verified there before use):
+//   SSMQ_OPT_LDL  the covariance quadratic form fx Wc fx' is evaluated through Wc = U diag(d) U' (unit lower U, factored
+//                 on the host in fp64 without pivoting and accepted only if U diag(d) U' reproduces Wc to 1e-14):
+//                 g_j = fx u_j costs N - 1 - j FMAs per row instead of N, i.e. E N (N - 1) / 2 instead of E N^2.
+//   SSMQ_OPT_UT   the unit points are [0 | c I | -c I] (unscented / fully-symmetric degree 3 / spherical-radial with a
+//                 centre point): x_n = m +- c L[:, k] needs one FMA per coordinate instead of a row of L times xi_n.
+// Either changes only the order of floating-point operations (differences of a few ulp of the intermediate sums).
+#define SSMQ_OPT_LDL 1
+#define SSMQ_OPT_UT 2
+
 // m: mean; L: in = packed lower triangle of cov, out = its Cholesky factor.  Returns false if cov is not PD (results
 // are then garbage; the caller writes NaN).  Sink interface: mean(e, v), cov(e, e2, v) for e2 <= e, ccov(e, d, v).
-template <int D, int E, int N, int F, int FORM, int TP, int SEL, bool NEED_CCOV, class Sink>
+template <int D, int E, int N, int F, int FORM, int TP, int SEL, bool NEED_CCOV, int OPT, class Sink>
 __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], double (&L)[D * (D + 1) / 2], double t,
                                                       const FPar &fp, const CoreParams &cp, Sink &out) {
     constexpr ConstLayout cl = const_layout(D, E, N, FORM);
@@ -104,28 +114,40 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
     Fun fn;
     fn.init(t, fp);
 
+    constexpr bool kUT = (OPT & SSMQ_OPT_UT) != 0 && N == 2 * D + 1;
+    const double utc = kUT ? c[cl.utc] : 0.0;
     double fx[E][N];
     SBuf<D> xic;
-    sload(xic, c + cl.xi);
-    SSMQ_SPIN_T(xic);
+    if (!kUT) {
+        sload(xic, c + cl.xi);
+        SSMQ_SPIN_T(xic);
+    }
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         SBuf<D> xin;
-        if (n + 1 < N) sload(xin, c + cl.xi + (n + 1) * D);
+        if (!kUT && n + 1 < N) sload(xin, c + cl.xi + (n + 1) * D);
         double x[D];
+        if (kUT) {
+            // point 0: the mean; point 1 + k: m + c L[:, k]; point 1 + D + k: m - c L[:, k]   (L lower triangular)
+            const int k = (n == 0) ? 0 : (n - 1) % D;
+            const double sc = (n == 0) ? 0.0 : ((n - 1) < D ? utc : -utc);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            double s = m[d];
+            for (int d = 0; d < D; ++d) x[d] = (n != 0 && d >= k) ? m[d] + L[SSMQ_PK(d >= k ? d : k, k)] * sc : m[d];
+        } else {
 #pragma unroll
-            for (int k = 0; k <= d; ++k) s += L[SSMQ_PK(d, k)] * xic.v[k];
-            x[d] = s;
+            for (int d = 0; d < D; ++d) {
+                double s = m[d];
+#pragma unroll
+                for (int k = 0; k <= d; ++k) s += L[SSMQ_PK(d, k)] * xic.v[k];
+                x[d] = s;
+            }
         }
         double xs[DIN], o[E];
         select_inputs<D, DIN, SEL>(x, xs);
         fn.template eval<E>(xs, o);
 #pragma unroll
         for (int e = 0; e < E; ++e) fx[e][n] = o[e];
-        if (n + 1 < N) {
+        if (!kUT && n + 1 < N) {
             SSMQ_SPIN_T(xin);
             xic = xin;
         }
@@ -193,6 +215,55 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                 }
             }
         }
+        constexpr bool kLDL = (OPT & SSMQ_OPT_LDL) != 0 && !TP;
+        if (kLDL) {
+            // ---- covariance through Wc = U diag(d) U':  fx Wc fx' = sum_j d_j g_j g_j',  g_j = fx u_j -------------------
+            double cv[E * (E + 1) / 2];
+#pragma unroll
+            for (int i = 0; i < E * (E + 1) / 2; ++i) cv[i] = 0.0;
+            SBuf<N> ucur;
+            sload(ucur, SSMQ_LAUNDER_T(c) + cl.ldlU);
+            SSMQ_SPIN_T(ucur);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                SBuf<N> unext;
+                if (j + 1 < N) sload(unext, SSMQ_LAUNDER_T(c) + cl.ldlU + (j + 1) * N);
+                const double dj = c[cl.ldlD + j];
+                double g[E], dg[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    double sacc = fx[e][j];
+#pragma unroll
+                    for (int i = 0; i < N; ++i)   // constant bounds + predicate: a (j + 1 .. N) loop is not unrolled
+                        if (i > j) sacc += fx[e][i] * ucur.v[i];
+                    g[e] = sacc;
+                    dg[e] = sacc * dj;
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int e2 = 0; e2 <= e; ++e2) cv[SSMQ_PK(e, e2)] += dg[e] * g[e2];
+#pragma unroll
+                for (int i = 0; i < E * (E + 1) / 2; ++i) SSMQ_PIN_T(cv[i]);
+                if (j + 1 < N) {
+                    SSMQ_SPIN_T(unext);
+                    ucur = unext;
+                }
+                SSMQ_FENCE_T();
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+#pragma unroll
+                for (int e2 = 0; e2 <= e; ++e2) {
+                    const bool use = (e == e2) || (cp.emv_mode == SSMQ_EMV_BROADCAST);
+                    const double em = use ? c[cl.emv + e * E + e2] : 0.0;
+                    double v = cv[SSMQ_PK(e, e2)] - mf[e] * mf[e2] + em;
+                    v = v * cp.cov_scale + cp.cadd[e * E + e2];
+                    out.cov(e, e2, v);
+                }
+                SSMQ_FENCE_T();
+            }
+        } else {
         // ---- covariance: (fx Wc) fx' - mean mean' + emv, TWO OUTPUT ROWS AT A TIME -------------------------------
         // Rows (e0, e0 + 1) are accumulated over all columns j of Wc and stored as soon as they are complete, so the
         // E*E covariance stores of a wave are spread over the whole stage instead of forming a burst at its end (with
@@ -272,6 +343,7 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
             }
             SSMQ_FENCE_T();
         }
+        }   // !kLDL
     } else {
         // ---- classical centred form, diagonal covariance weights -----------------------------------------------
 #pragma unroll
@@ -300,8 +372,14 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
                 for (int d = 0; d < D; ++d) {
                     // x_n - mean exactly as the reference forms it: (mean + L xi_n) - mean   (mtran.py:139,148)
                     double s = m[d];
+                    if (kUT) {
+                        const int k = (n == 0) ? 0 : (n - 1) % D;
+                        const double sc = (n == 0) ? 0.0 : ((n - 1) < D ? utc : -utc);
+                        if (n != 0 && d >= k) s = m[d] + L[SSMQ_PK(d >= k ? d : k, k)] * sc;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k <= d; ++k) s += L[SSMQ_PK(d, k)] * c[cl.xi + n * D + k];
+                        for (int k = 0; k <= d; ++k) s += L[SSMQ_PK(d, k)] * c[cl.xi + n * D + k];
+                    }
                     const double dx = s - m[d];
 #pragma unroll
                     for (int e = 0; e < E; ++e) cx[e][d] += (fx[e][n] * c[cl.Wc + n]) * dx;
@@ -356,19 +434,10 @@ struct GlobalSink {
 // __launch_bounds__(64, 2): at least two waves per SIMD, i.e. at most 256 registers per lane.  The D = E = 6, N = 13
 // kernel needs ~270 without the bound (one wave per SIMD, no latency hiding at all); with it hipcc spills 8 registers
 // and B = 1e5 trajectories (1563 waves) are all resident at once.
-template <int D, int E, int N, int F, int FORM, int TP, int SEL>
+template <int D, int E, int N, int F, int FORM, int TP, int SEL, int OPT>
 __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs a) {
     const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;  // 32-bit lane offset: plane base stays scalar
     if ((int64_t)b >= a.B) return;
-    if (a.stagger_sleeps > 0) {
-        // Wave stagger: every wave of a launch starts in the load phase, computes, then stores, so HBM idles while the
-        // ALUs work and vice versa.  Delaying part of the waves lets their memory phases fall into the others' compute.
-        bool late = false;
-        if (a.stagger_mode == 1) late = (int)blockIdx.x >= a.stagger_arg;          // blocks dispatched last
-        if (a.stagger_mode == 2) late = ((int)blockIdx.x / a.stagger_arg) & 1;    // alternating groups of blocks
-        if (late)
-            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int64_t ld = a.ld;
     double m[D], L[D * (D + 1) / 2];
 #ifdef SSMQ_DIAG_NOLOAD
@@ -390,7 +459,7 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs 
 
     CoreParams cp{(cdouble_p)a.consts, (cdouble_p)a.cov_add, a.emv_mode, a.tp_nu, a.cov_scale, a.ccov_scale};
     GlobalSink<D, E> sink{a.mean_f, a.cov_f, a.cov_fx, ld, b};
-    const bool ok = moment_transform_core<D, E, N, F, FORM, TP, SEL, true>(m, L, t, a.fp, cp, sink);
+    const bool ok = moment_transform_core<D, E, N, F, FORM, TP, SEL, true, OPT>(m, L, t, a.fp, cp, sink);
     a.status[b] = ok ? 0 : 1;
     if (!ok) {
         // the reference raises LinAlgError here (bq/bqmtran.py:98); a batch marks the item and poisons its outputs
@@ -406,10 +475,10 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs 
     }
 }
 
-template <int D, int E, int N, int F, int FORM, int TP, int SEL>
+template <int D, int E, int N, int F, int FORM, int TP, int SEL, int OPT>
 inline hipError_t launch_apply_small(const ApplyArgs &a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + kSmallBlock - 1) / kSmallBlock);
-    hipLaunchKernelGGL((k_apply_small<D, E, N, F, FORM, TP, SEL>), dim3(grid), dim3(kSmallBlock), 0, s, a);
+    hipLaunchKernelGGL((k_apply_small<D, E, N, F, FORM, TP, SEL, OPT>), dim3(grid), dim3(kSmallBlock), 0, s, a);
     return hipGetLastError();
 }
 

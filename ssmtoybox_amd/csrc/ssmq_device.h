@@ -19,7 +19,7 @@ struct FPar {
 // Offsets (in doubles) into a transform's constant block in HBM; every thread reads it with wave-uniform addresses,
 // so the loads are scalar (s_load) and the block stays in the scalar cache / L2.
 struct ConstLayout {
-    int32_t xi, wm, Wc, Wcc, emv, iK, zero, total;
+    int32_t xi, wm, Wc, Wcc, emv, iK, zero, ldlU, ldlD, utc, total;
 };
 __host__ __device__ constexpr inline ConstLayout const_layout(int D, int E, int N, int form) {
     ConstLayout c{};
@@ -30,7 +30,11 @@ __host__ __device__ constexpr inline ConstLayout const_layout(int D, int E, int 
     c.emv = c.Wcc + D * N;
     c.iK = c.emv + E * E;
     c.zero = c.iK + N * N;   // E*E zeros: the default `cov_add`, so that the kernels add it unconditionally
-    c.total = c.zero + E * E;
+    // optional fast-path data (see SSMQ_OPT_* in ssmq_apply_small.h)
+    c.ldlU = c.zero + E * E;   // [N][N]: column j of the unit lower factor U of Wc = U diag(d) U', contiguous
+    c.ldlD = c.ldlU + N * N;   // [N]
+    c.utc = c.ldlD + N;        // [2]: scale c of unscented-type points [0 | c I | -c I]
+    c.total = c.utc + 2;
     return c;
 }
 
@@ -49,7 +53,6 @@ struct ApplyArgs {
     int32_t emv_mode;
     double tp_nu;
     double cov_scale, ccov_scale;   // 1.0 except inside Studentian filters (ssinf.py:672-693)
-    int32_t stagger_mode, stagger_arg, stagger_sleeps;   // experimental wave stagger (see k_apply_small)
     FPar fp;
 };
 

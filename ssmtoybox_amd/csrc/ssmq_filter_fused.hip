@@ -86,13 +86,13 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
         }
         // ---- time update: predictive state moments, + G Q G' (ssinf.py:276-279) ----------------------------------
         RegSinkNoCross<D, D> pr;
-        bool ok = moment_transform_core<D, D, ND, FD, FORM, TP, 0, false>(m, Pl, t, a.fd, cpd, pr);
+        bool ok = moment_transform_core<D, D, ND, FD, FORM, TP, 0, false, 0>(m, Pl, t, a.fd, cpd, pr);
         // ---- predictive measurement moments, + R (ssinf.py:287-291) ------------------------------------------------
         double L2[D * (D + 1) / 2];
 #pragma unroll
         for (int i = 0; i < D * (D + 1) / 2; ++i) L2[i] = pr.cv[i];
         RegSink<D, Y> ob;
-        ok = moment_transform_core<D, Y, NO, FO, FORM, TP, SELO, true>(pr.mf, L2, t, a.fo, cpo, ob) && ok;
+        ok = moment_transform_core<D, Y, NO, FO, FORM, TP, SELO, true, 0>(pr.mf, L2, t, a.fo, cpo, ob) && ok;
         // ---- measurement update (ssinf.py:321-323) ---------------------------------------------------------------------
         double S[Y * (Y + 1) / 2];
 #pragma unroll

@@ -13,6 +13,7 @@ struct ssmq_transform {
     std::vector<double> xi, wm, Wc, Wcc, emv, iK;
     // device constant blocks: `small` = transposed layout of ssmq_apply_small.h, `wide` = natural layout
     double *d_small, *d_wide;
+    int opt_mask;   // SSMQ_OPT_* fast paths this handle's constants qualify for (decided in upload_consts)
 };
 
 namespace ssmq {
@@ -33,11 +34,11 @@ void fill_fpar(const ssmq_integrand *f, FPar *fp);
 // dispatch table of the register-resident kernels (ssmq_apply_small_*.hip)
 typedef hipError_t (*small_launch_fn)(const ApplyArgs &, hipStream_t);
 struct SmallEntry {
-    int fid, D, E, N, form, tp, sel;
+    int fid, D, E, N, form, tp, sel, opt;
     small_launch_fn fn;
     const char *name;
 };
-const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int sel);
+const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int sel, int opt);
 void register_small(const SmallEntry *entries, int n);
 
 // fused filter kernels (ssmq_filter.hip)

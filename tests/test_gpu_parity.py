@@ -408,6 +408,34 @@ def test_gpq_d6_full_batch(amd, ell):
     assert np.allclose(mf[:1000, 5], x6.dot(w['wm']), rtol=1e-12, atol=1e-14)
 
 
+def test_fast_paths_match_dense(amd, monkeypatch):
+    """SSMQ_OPT_LDL / SSMQ_OPT_UT kernels (chosen per handle on the host) against the dense kernels and the oracle."""
+    from ssmtoybox_amd import ssmod as sm
+    B = 4096
+    means, covs = synthetic_reentry6(B)
+    f6 = sm.ReentryVehicle2DBiasTransition(dt=0.1).dyn_eval
+    f5 = sm.ReentryVehicle2DTransition(dt=0.1).dyn_eval
+    h5 = sm.Radar2DMeasurement(sm.GaussRV(2), 5).meas_eval
+    cases = [(lambda: amd.GaussianProcessTransform(6, 6, gp_par(6, 3.0)), f6, 6, 'OPT=3'),
+             (lambda: amd.GaussianProcessTransform(5, 5, gp_par(5, 25.0)), f5, 5, 'OPT=3'),
+             (lambda: amd.StudentTProcessTransform(5, 5, gp_par(5, 3.0)), f5, 5, 'OPT=2'),
+             (lambda: amd.UnscentedTransform(5), f5, 5, 'OPT=2'),
+             (lambda: amd.GaussianProcessTransform(5, 2, gp_par(5, 3.0)), h5, 5, 'OPT=3'),
+             (lambda: amd.GaussianProcessTransform(5, 5, gp_par(5, 3.0), 'rbf', 'sr'), f5, 5, 'OPT=0')]
+    for make, f, d, tag in cases:
+        monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)
+        tf = make()
+        assert tag in tf.kernel_name(f), tf.kernel_name(f)
+        fast = tf.apply_batch(f, means[:, :d], covs[:, :d, :d], 0.0)
+        monkeypatch.setenv('SSMQ_NO_FASTPATH', '1')
+        tf2 = make()
+        assert 'OPT=0' in tf2.kernel_name(f)
+        dense = tf2.apply_batch(f, means[:, :d], covs[:, :d, :d], 0.0)
+        monkeypatch.delenv('SSMQ_NO_FASTPATH')
+        for i in range(0, B, 97):
+            assert_moments_close([a[i] for a in fast], [a[i] for a in dense], covs[i, :d, :d], what=(tag, i))
+
+
 def test_ungm_gpq_full_batch(amd):
     """Config C2 shape: D = 1, N = 3, B = 1e4, per-trajectory time index."""
     from ssmtoybox_amd import ssmod as sm
