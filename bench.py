@@ -67,6 +67,34 @@ def simulate_ungm(B, T, seed):
     return x[1:], y
 
 
+def simulate_reentry(B, T, seed, bias_state=False):
+    """Synthetic reentry-vehicle trajectories + radar measurements (tests/test_ssinf.py:53-63 setup of the reference),
+    vectorised over the batch; `bias_state` appends the pass-through sixth state of this build's 6-D variant.
+    Returns x (D, T, B), y (2, T, B), m0, P0, Q (noise cov), G (noise gain), R."""
+    rng = np.random.default_rng(seed)
+    m0 = np.array([6500.4, 349.14, -1.8093, -6.7967, 0.6932] + ([0.0] if bias_state else []))
+    p0 = np.array([1e-6, 1e-6, 1e-6, 1e-6, 1.0] + ([1e-2] if bias_state else []))
+    qd = np.array([2.4064e-5, 2.4064e-5, 1e-6] + ([1e-6] if bias_state else []))
+    rd = np.array([1e-6, 0.17e-6])
+    D, nq = m0.size, qd.size
+    G = np.vstack((np.zeros((2, nq)), np.eye(nq)))
+    x = m0[:, None] + np.sqrt(p0)[:, None] * rng.standard_normal((D, B))
+    xs, ys = np.zeros((D, T, B)), np.zeros((2, T, B))
+    dt, r0, h0, gm0, b0 = 0.1, 6374.0, 13.406, 3.9860e5, -0.59783
+    for k in range(T):
+        b = b0 * np.exp(x[4])
+        rr, vv = np.hypot(x[0], x[1]), np.hypot(x[2], x[3])
+        dr = b * np.exp((r0 - rr) / h0) * vv
+        gr = -gm0 / rr ** 3
+        xn = x.copy()
+        xn[0], xn[1] = x[0] + dt * x[2], x[1] + dt * x[3]
+        xn[2], xn[3] = x[2] + dt * (dr * x[2] + gr * x[0]), x[3] + dt * (dr * x[3] + gr * x[1])
+        x = xn + G.dot(np.sqrt(qd)[:, None] * rng.standard_normal((nq, B)))
+        xs[:, k] = x
+        ys[:, k] = np.stack((np.hypot(x[0], x[1]), np.arctan2(x[1], x[0]))) + np.sqrt(rd)[:, None] * rng.standard_normal((2, B))
+    return xs, ys, m0, np.diag(p0), np.diag(qd), G, np.diag(rd)
+
+
 def synthetic_reentry6(B, seed):
     """reentry-shaped 6-D batch of means / covariances."""
     rng = np.random.default_rng(seed)
@@ -79,44 +107,59 @@ def synthetic_reentry6(B, seed):
     return means, 0.5 * (covs + covs.transpose(0, 2, 1))
 
 
-class UngmFilterBench:
-    """GPQ-Kalman on UNGM, B trajectories, T steps, everything resident on the device."""
+class FilterBench:
+    """A sigma-point / BQ Kalman filter on B trajectories, T steps, everything resident on the device.
+    workload: 'ungm' (BASELINE configs[1]: GPQ-Kalman, D = 1, N = 3) | 'reentry5' (configs[2] with the reference's 5-D
+    model, N = 11) | 'reentry6' (the synthetic 6-D variant, N = 13); filt: 'gpqkf' | 'ukf'."""
 
-    def __init__(self, amd, B, T, seed):
+    def __init__(self, amd, B, T, seed, workload='ungm', filt='gpqkf'):
         from ssmtoybox_amd import _lib, ssmod, ssinf
+        from ssmtoybox_amd.mtran import resolve_integrand
         self._lib = _lib
-        self.B, self.T, self.D, self.Y = B, T, 1, 1
-        self.ld = (B + 63) // 64 * 64
-        self.x_true, y = simulate_ungm(B, T, seed)
-        dyn = ssmod.UNGMTransition(ssmod.GaussRV(1), ssmod.GaussRV(1, cov=np.array([[10.0]])))
-        obs = ssmod.UNGMMeasurement(ssmod.GaussRV(1), 1)
-        par = np.array([[1.0, 3.0]])
-        self.alg = ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut')
-        ld = self.ld
-        ybuf = np.zeros((T, 1, ld))
-        ybuf[:, 0, :B] = y
+        self.B, self.T = B, T
+        self.ld = ld = (B + 63) // 64 * 64
+        if workload == 'ungm':
+            self.x_true, y = simulate_ungm(B, T, seed)
+            self.x_true, y = self.x_true[None], y[None]
+            m0, P0 = np.zeros(1), np.eye(1)
+            dyn = ssmod.UNGMTransition(ssmod.GaussRV(1), ssmod.GaussRV(1, cov=np.array([[10.0]])))
+            obs = ssmod.UNGMMeasurement(ssmod.GaussRV(1), 1)
+            ell = 3.0
+        else:
+            bias = workload == 'reentry6'
+            self.x_true, y, m0, P0, Q, G, R = simulate_reentry(B, T, seed, bias)
+            cls = ssmod.ReentryVehicle2DBiasTransition if bias else ssmod.ReentryVehicle2DTransition
+            dyn = cls(ssmod.GaussRV(m0.size, m0, P0), ssmod.GaussRV(Q.shape[0], cov=Q))
+            obs = ssmod.Radar2DMeasurement(ssmod.GaussRV(2, cov=R), m0.size)
+            ell = 3.0
+        self.D, self.Y = dyn.dim_state, obs.dim_out
+        D, Y = self.D, self.Y
+        if filt == 'ukf':
+            self.alg = ssinf.UnscentedKalman(dyn, obs)
+        else:
+            par = np.array([[1.0] + [ell] * D])
+            self.alg = ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut')
+        ybuf = np.zeros((T, Y, ld))
+        ybuf[:, :, :B] = y.transpose(1, 0, 2)
         self.d_y = _lib.DeviceBuffer(ybuf.nbytes)
         self.d_y.upload(ybuf)
-        m0 = np.zeros((1, ld))
-        P0 = np.ones((1, ld))
-        self.d_m0, self.d_P0 = _lib.DeviceBuffer(m0.nbytes), _lib.DeviceBuffer(P0.nbytes)
-        self.d_m0.upload(m0)
-        self.d_P0.upload(P0)
-        self.d_fm = _lib.DeviceBuffer(8 * T * ld)
-        self.d_fP = _lib.DeviceBuffer(8 * T * ld)
+        mb = np.zeros((D, ld))
+        mb[:] = m0[:, None]
+        Pb = np.zeros((D * D, ld))
+        Pb[:] = P0.reshape(-1, 1)
+        self.d_m0, self.d_P0 = _lib.DeviceBuffer(mb.nbytes), _lib.DeviceBuffer(Pb.nbytes)
+        self.d_m0.upload(mb)
+        self.d_P0.upload(Pb)
+        self.d_fm = _lib.DeviceBuffer(8 * T * D * ld)
+        self.d_fP = _lib.DeviceBuffer(8 * T * D * D * ld)
         self.d_st = _lib.DeviceBuffer(4 * ld)
-        from ssmtoybox_amd.mtran import resolve_integrand
         self.f_dyn, _ = resolve_integrand(dyn.dyn_eval)
         self.f_obs, _ = resolve_integrand(obs.meas_eval)
-        self.h_dyn = self.alg.tf_dyn._handle_for(1)
-        self.h_obs = self.alg.tf_obs._handle_for(1)
-        self.gqg, self.pg = _lib.as_c(np.array([[10.0]]))
-        self.rr, self.pr = _lib.as_c(np.array([[1.0]]))
-        buf = ctypes.create_string_buffer(512)
-        _lib.check(_lib.load().ssmq_filter_kernel_name(ctypes.c_void_p(self.h_dyn), ctypes.byref(self.f_dyn),
-                                                       ctypes.c_void_p(self.h_obs), ctypes.byref(self.f_obs), buf, 512),
-                   'ssmq_filter_kernel_name')
-        self.kernel = buf.value.decode()
+        self.h_dyn = self.alg.tf_dyn._handle_for(D)
+        self.h_obs = self.alg.tf_obs._handle_for(Y)
+        self.gqg, self.pg = _lib.as_c(self.alg.G.dot(self.alg.q_cov).dot(self.alg.G.T))
+        self.rr, self.pr = _lib.as_c(self.alg.r_cov)
+        self.kernel = self.alg.kernel_name()
 
     def step(self):
         lib = self._lib.load()
@@ -128,9 +171,11 @@ class UngmFilterBench:
             'ssmq_filter_forward_dev')
 
     def results(self):
-        fm = self.d_fm.download((self.T, self.ld))[:, :self.B]
-        fP = self.d_fP.download((self.T, self.ld))[:, :self.B]
-        st = self.d_st.download((self.ld,), dtype=np.int32)[:self.B]
+        """Filtered means (D, T, B), covariances (D, D, T, B), status (B,)."""
+        T, D, ld, B = self.T, self.D, self.ld, self.B
+        fm = self.d_fm.download((T, D, ld))[:, :, :B].transpose(1, 0, 2)
+        fP = self.d_fP.download((T, D, D, ld))[:, :, :, :B].transpose(1, 2, 0, 3)
+        st = self.d_st.download((ld,), dtype=np.int32)[:B]
         return fm, fP, st
 
     def bytes_per_pass(self):
@@ -241,10 +286,13 @@ def cpu_baseline_ungm(B, T, seed, tf, budget_s=12.0, max_threads=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=10000, help='MC trajectories per GPU')
     ap.add_argument('--time-steps', type=int, default=100)
+    ap.add_argument('--workload', default='ungm', choices=['ungm', 'reentry5', 'reentry6'],
+                    help="'ungm' is the headline (BASELINE configs[1]); the others are extra measurements")
+    ap.add_argument('--filter', default='gpqkf', choices=['gpqkf', 'ukf'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-mt6', action='store_true')
     args = ap.parse_args()
@@ -275,7 +323,7 @@ def main():
             dist.barrier()
 
     B, T = args.batch, args.time_steps
-    wl = UngmFilterBench(amd, B, T, seed=1 + rank)
+    wl = FilterBench(amd, B, T, seed=1 + rank, workload=args.workload, filt=args.filter)
     for _ in range(args.warmup):
         wl.step()
     barrier_sync()
@@ -298,7 +346,7 @@ def main():
     from ssmtoybox_amd import mcshard
     fm, fP, st = wl.results()
     ok = st == 0
-    loc = mcshard.local_error_sums(wl.x_true[None], fm[None], fP[None, None], ok)
+    loc = mcshard.local_error_sums(wl.x_true, fm, fP, ok)
     agg = mcshard.finalize(mcshard.allreduce_sums(loc, dist))
     rmse, nll = agg['rmse_total'], float(agg['nll_avg'].mean())
 
@@ -309,18 +357,23 @@ def main():
         bytes_pass = wl.bytes_per_pass()
         ach = bytes_pass / (pass_ms_dev * 1e-3) / 1e9
         out = {
-            'metric': 'filter steps/sec (batched MC) for GPQ-Kalman UNGM', 'value': value, 'unit': 'filter steps/s',
+            'metric': 'filter steps/sec (batched MC) for GPQ-Kalman UNGM' if args.workload == 'ungm' and
+            args.filter == 'gpqkf' else 'filter steps/sec (batched MC), {} {}'.format(args.filter, args.workload),
+            'value': value, 'unit': 'filter steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'GaussianProcessTransform (RBF, UT points) GPQ-Kalman on UNGM, D=1, N=3, '
-                                   '{} MC trajectories per GPU x T={} time steps per pass (BASELINE configs[1])'.format(B, T),
+            'config': {'workload': ('GaussianProcessTransform (RBF, UT points) GPQ-Kalman on UNGM, D=1, N=3, '
+                                    '{} MC trajectories per GPU x T={} time steps per pass (BASELINE configs[1])'.format(B, T))
+                       if args.workload == 'ungm' and args.filter == 'gpqkf' else
+                       '{} on {} (D={}, Y={}), {} MC trajectories per GPU x T={}'.format(args.filter, args.workload, wl.D,
+                                                                                       wl.Y, B, T),
                        'mc_per_gpu': B, 'time_steps': T, 'parallelism': 'mc-shard x{}'.format(world)},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(wl.kernel),
                          'kernel': wl.kernel,
                          'bytes_per_launch': bytes_pass, 'ms_per_launch': pass_ms_dev,
-                         'note': 'fp64-ALU / latency bound at B=1e4 (157 waves on 1024 SIMDs), not HBM bound: '
-                                 'SURVEY.md 7-4'},
+                         'note': 'the fused time loop is a serial recursion per trajectory: fp64-ALU / latency bound '
+                                 '(at B=1e4: 157 waves for 1024 SIMDs), not HBM bound - SURVEY.md 7-4, DESIGN.md 3.4'},
             'rmse': rmse, 'nll': nll, 'trajectories_aggregated': int(agg['count']),
             'failed_trajectories_rank0': int((~ok).sum()),
         }
@@ -334,12 +387,12 @@ def main():
                                'bytes_per_launch': b_alg, 'bytes_moved_per_launch': b_mov, 'ms_per_launch': ms,
                                'transforms_per_s': mt.B / (ms * 1e-3), 'max_scaled_err_vs_oracle': err,
                                'workload': 'batched GPQ moment transform, D=E=6, N=13, B=1e5, 4 rotating buffer sets'}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and args.workload == 'ungm' and args.filter == 'gpqkf':
         cb, (cpu_fm, cpu_st) = cpu_baseline_ungm(B, T, seed=1 + rank, tf=wl.alg.tf_dyn)
         out['cpu_baseline'] = cb
         # the GPU pass and the CPU port ran the same trajectories: cross-check them
         good = (st == 0) & (cpu_st == 0)
-        rel = np.abs(fm[:, good] - cpu_fm[:, good]) / np.max(np.abs(cpu_fm[:, good]))
+        rel = np.abs(fm[0][:, good] - cpu_fm[:, good]) / np.max(np.abs(cpu_fm[:, good]))
         # identical weights and measurements; the UNGM recursion amplifies rounding differences along a trajectory
         # (uncentred covariance, bq/bqmtran.py:199), hence median and max over the 1e6 filtered means
         out['rel_diff_vs_cpu_port'] = {'median': float(np.median(rel)), 'p99': float(np.quantile(rel, 0.99)),

@@ -47,8 +47,8 @@ struct RegSinkNoCross {
     __device__ __forceinline__ void ccov(int, int, double) {}
 };
 
-template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
-__global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(const FusedArgs a) {
+template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT>
+__global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FORM_SIGMA)) ? 1 : 2)) void k_filter_fused(const FusedArgs a) {
     if ((int)threadIdx.x >= a.lpw) return;
     const uint32_t b = blockIdx.x * a.lpw + threadIdx.x;
     if ((int64_t)b >= a.B) return;
@@ -86,13 +86,13 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
         }
         // ---- time update: predictive state moments, + G Q G' (ssinf.py:276-279) ----------------------------------
         RegSinkNoCross<D, D> pr;
-        bool ok = moment_transform_core<D, D, ND, FD, FORM, TP, 0, false, 0>(m, Pl, t, a.fd, cpd, pr);
+        bool ok = moment_transform_core<D, D, ND, FD, FORM, TP, 0, false, OPT>(m, Pl, t, a.fd, cpd, pr);
         // ---- predictive measurement moments, + R (ssinf.py:287-291) ------------------------------------------------
         double L2[D * (D + 1) / 2];
 #pragma unroll
         for (int i = 0; i < D * (D + 1) / 2; ++i) L2[i] = pr.cv[i];
         RegSink<D, Y> ob;
-        ok = moment_transform_core<D, Y, NO, FO, FORM, TP, SELO, true, 0>(pr.mf, L2, t, a.fo, cpo, ob) && ok;
+        ok = moment_transform_core<D, Y, NO, FO, FORM, TP, SELO, true, OPT>(pr.mf, L2, t, a.fo, cpo, ob) && ok;
         // ---- measurement update (ssinf.py:321-323) ---------------------------------------------------------------------
         double S[Y * (Y + 1) / 2];
 #pragma unroll
@@ -167,35 +167,43 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : 2)) void k_filter_fused(
     a.status[b] = agg;
 }
 
-template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
+template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT>
 static hipError_t launch_fused(const FusedArgs &a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + a.lpw - 1) / a.lpw);
-    hipLaunchKernelGGL((k_filter_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO>), dim3(grid), dim3(kSmallBlock), 0, s, a);
+    hipLaunchKernelGGL((k_filter_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT>), dim3(grid), dim3(kSmallBlock), 0, s, a);
     return hipGetLastError();
 }
 
 typedef hipError_t (*fused_fn)(const FusedArgs &, hipStream_t);
 struct FusedEntry {
-    int fd, fo, D, Y, ND, NO, form, tp, selo;
+    int fd, fo, D, Y, ND, NO, form, tp, selo, opt;
     fused_fn fn;
     const char *name;
 };
 
-#define SSMQ_FUSED_ONE(FD, FO, D, Y, ND, NO, FORM, TP, SELO)                                   \
-    {FD, FO, D, Y, ND, NO, FORM, TP, SELO, &launch_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO>, \
-     "k_filter_fused<D=" #D ",Y=" #Y ",ND=" #ND ",NO=" #NO "," #FD "," #FO "," #FORM ",TP=" #TP ",SELO=" #SELO ">"}
-#define SSMQ_FUSED(FD, FO, D, Y, N, SELO)                                   \
-    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 0, SELO),              \
-    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 1, SELO),              \
-    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_SIGMA, 0, SELO)
+#define SSMQ_FUSED_ONE(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT)                                   \
+    {FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT, &launch_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT>, \
+     "k_filter_fused<D=" #D ",Y=" #Y ",ND=" #ND ",NO=" #NO "," #FD "," #FO "," #FORM ",TP=" #TP ",SELO=" #SELO \
+     ",OPT=" #OPT ">"}
+#define SSMQ_FUSED(FD, FO, D, Y, N, SELO)                                      \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 0, SELO, 0),              \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 1, SELO, 0),              \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_SIGMA, 0, SELO, 0)
+// larger shapes: also with the LDL' / unscented-point fast paths of ssmq_apply_small.h
+#define SSMQ_FUSED_FAST(FD, FO, D, Y, N, SELO)                                 \
+    SSMQ_FUSED(FD, FO, D, Y, N, SELO),                                         \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 0, SELO, 3),              \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 1, SELO, 2),              \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_SIGMA, 0, SELO, 2)
 
 static const FusedEntry kFused[] = {
     SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 2, 0),
     SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 0),
     SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 5, 0),
     SSMQ_FUSED(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 5, 0),
-    SSMQ_FUSED(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
-    SSMQ_FUSED(SSMQ_F_REENTRY2D_BIAS_DYN, SSMQ_F_RADAR2D_MEAS, 6, 2, 13, 0),
+    SSMQ_FUSED_FAST(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
+    SSMQ_FUSED_FAST(SSMQ_F_REENTRY2D_BIAS_DYN, SSMQ_F_RADAR2D_MEAS, 6, 2, 13, 0),
+    SSMQ_FUSED_FAST(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 11, 1),
 };
 
 // Returns 1 if a fused kernel was launched, 0 if none exists for this combination, < 0 on error.
@@ -206,9 +214,12 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
                      const double *d_sscale, double student_dof) {
     if (hd->form != ho->form || (hd->tp_nu > 0.0) != (ho->tp_nu > 0.0) || sel_obs < 0 || fd->n_idx > 0) return 0;
     const int tp = hd->tp_nu > 0.0 ? 1 : 0;
+    const int both = hd->opt_mask & ho->opt_mask;
+    const int want[2] = {both & (tp || hd->form == SSMQ_FORM_SIGMA ? SSMQ_OPT_UT : 3), 0};
+    for (int w = 0; w < 2; ++w)
     for (const FusedEntry &e : kFused) {
         if (e.fd == fd->id && e.fo == fo->id && e.D == hd->D && e.Y == ho->E && e.ND == hd->N && e.NO == ho->N &&
-            e.form == hd->form && e.tp == tp && e.selo == sel_obs) {
+            e.form == hd->form && e.tp == tp && e.selo == sel_obs && e.opt == want[w]) {
             if (name) *name = e.name;
             if (dry_run) return 1;
             FusedArgs a;
