@@ -48,6 +48,7 @@ void fill_fpar(const ssmq_integrand *f, FPar *fp) {
     fp->n_idx = std::max(0, std::min<int>(f->n_idx, SSMQ_MAX_FIDX));
     for (int i = 0; i < fp->n_par; ++i) fp->p[i] = f->par[i];
     for (int i = 0; i < fp->n_idx; ++i) fp->idx[i] = f->idx[i];
+    fp->ttab = nullptr;
 }
 
 const SmallEntry *small_table_a(int *n);
@@ -256,7 +257,7 @@ static int check_integrand(const ssmq_transform *h, const ssmq_integrand *f, FIn
 int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
                    const double *d_cov, const double *d_time, int time_stride, double *d_mean_f, double *d_cov_f,
                    double *d_cov_fx, int32_t *d_status, const double *d_cov_add, const char **kernel_name,
-                   bool dry_run, double cov_scale = 1.0, double ccov_scale = 1.0) {
+                   bool dry_run, double cov_scale = 1.0, double ccov_scale = 1.0, const double *ttab = nullptr) {
     FInfo fi;
     int rc = check_integrand(h, f, &fi);
     if (rc) return rc;
@@ -284,6 +285,7 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         a.time_stride = d_time ? time_stride : 0; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
         a.cov_scale = cov_scale; a.ccov_scale = ccov_scale;
         fill_fpar(f, &a.fp);
+        a.fp.ttab = ttab;
         return hip_fail(se->fn(a, stream()), se->name);
     }
     if (wide_lds_bytes(h->D, h->E, h->N) > 160 * 1024 - 64) {
@@ -299,6 +301,7 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     a.mean_f = d_mean_f; a.cov_f = d_cov_f; a.cov_fx = d_cov_fx; a.es_out = ld; a.bs_mf = a.bs_cf = a.bs_cfx = 1;
     a.status = d_status;
     fill_fpar(f, &a.fp);
+    a.fp.ttab = ttab;
     return hip_fail(launch_apply_wide(a, B, stream()), "k_apply_wide");
 }
 
@@ -700,7 +703,7 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
                      const ssmq_integrand *fo, int sel_obs, int64_t B, int64_t ld, int T, const double *d_y,
                      const double *d_m0, const double *d_P0, const double *d_gqg, const double *d_rr, double *d_fm,
                      double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run,
-                     const double *d_sscale, double student_dof);
+                     const double *d_sscale, double student_dof, const double *d_ttab_dyn, const double *d_ttab_obs);
 }
 
 namespace {
@@ -714,7 +717,7 @@ struct FilterCache {
     hipGraphExec_t exec = nullptr;
     std::vector<uint64_t> key;
     std::vector<double> gqg, rr, ss;
-    int T = -1;
+    int T = -1, fid_dyn = -1, fid_obs = -1;
     bool consts_ok = false;
     void drop_graph() {
         if (exec) hipGraphExecDestroy(exec);
@@ -749,7 +752,7 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
     if (B == 0 || T == 0) return SSMQ_OK;
     hipStream_t s = stream();
     // workspace carve-up (doubles first, then the two int32 status planes)
-    const size_t n_dbl = (size_t)ld * (D + 3 * D * D + Y + Y * Y + Y * D) + 2 * (size_t)T + D * D + Y * Y;
+    const size_t n_dbl = (size_t)ld * (D + 3 * D * D + Y + Y * Y + Y * D) + 4 * (size_t)T + D * D + Y * Y;
     const size_t need = sizeof(double) * n_dbl + 2 * sizeof(int32_t) * (size_t)ld;
     if (g_fc.ws_bytes < need) {
         g_fc.drop_graph();
@@ -770,6 +773,8 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
     double *smat = w; w += (size_t)ld * D * D;   // Studentian: rescaled scale matrix fed to the next time update
     double *tvec = w; w += T;
     double *svec = w; w += T;
+    double *ttab_d = w; w += T;   // time tables of the two integrands (UNGM: 8 cos(1.2 k)), see time_table()
+    double *ttab_o = w; w += T;
     double *gqg = w; w += D * D;
     double *rr = w; w += Y * Y;
     int32_t *st_a = (int32_t *)w, *st_b = st_a + ld;
@@ -796,7 +801,10 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
     { uint64_t v; memcpy(&v, &h_dyn->tp_nu, 8); key.push_back(v); memcpy(&v, &h_obs->tp_nu, 8); key.push_back(v);
       memcpy(&v, &student_dof, 8); key.push_back(v); key.push_back(sscale ? 1 : 0); }
 
-    if (!(g_fc.consts_ok && g_fc.gqg == hg && g_fc.rr == hr && g_fc.T == T && g_fc.ss == hs)) {
+    std::vector<double> htd(T), hto(T);
+    const bool has_td = time_table(f_dyn->id, T, htd.data()), has_to = time_table(f_obs->id, T, hto.data());
+    if (!(g_fc.consts_ok && g_fc.gqg == hg && g_fc.rr == hr && g_fc.T == T && g_fc.ss == hs &&
+          g_fc.fid_dyn == f_dyn->id && g_fc.fid_obs == f_obs->id)) {
         g_fc.drop_graph();
         std::vector<double> tv(T);
         for (int k = 0; k < T; ++k) tv[k] = (double)k;  // both transforms of step k + 1 use time index k (ssinf.py:104)
@@ -804,7 +812,11 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
         SSMQ_HIP(hipMemcpyAsync(gqg, hg.data(), sizeof(double) * D * D, hipMemcpyHostToDevice, s));
         SSMQ_HIP(hipMemcpyAsync(rr, hr.data(), sizeof(double) * Y * Y, hipMemcpyHostToDevice, s));
         SSMQ_HIP(hipMemcpyAsync(svec, hs.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
+        if (has_td) SSMQ_HIP(hipMemcpyAsync(ttab_d, htd.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
+        if (has_to) SSMQ_HIP(hipMemcpyAsync(ttab_o, hto.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
         SSMQ_HIP(hipStreamSynchronize(s));
+        g_fc.fid_dyn = f_dyn->id;
+        g_fc.fid_obs = f_obs->id;
         g_fc.ss = hs;
         g_fc.gqg = hg;
         g_fc.rr = hr;
@@ -821,7 +833,8 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
             return SSMQ_E_ARG;
         }
         rc = try_launch_fused(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), B, ld, T, d_y, d_m0, d_P0, gqg,
-                              rr, d_fm, d_fP, d_status, s, nullptr, false, sscale ? svec : nullptr, student_dof);
+                              rr, d_fm, d_fP, d_status, s, nullptr, false, sscale ? svec : nullptr, student_dof,
+                              has_td ? ttab_d : nullptr, has_to ? ttab_o : nullptr);
         if (rc < 0) return rc;
         if (rc == 1) return SSMQ_OK;
     }
@@ -838,10 +851,10 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
                 C_xx = d_pC + (int64_t)k * D * D * ld;
             }
             rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec + k, 0, m_pr, P_pr, C_xx, st_a, gqg, nullptr, false,
-                                hs[k], 1.0);
+                                hs[k], 1.0, has_td ? ttab_d : nullptr);
             if (!rc)
                 rc = apply_dev_impl(h_obs, f_obs, B, ld, m_pr, P_pr, tvec + k, 0, y_mean, P_y, P_yx, st_b, rr, nullptr,
-                                    false, hs[k], hs[k]);
+                                    false, hs[k], hs[k], has_to ? ttab_o : nullptr);
             if (!rc)
                 rc = launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, d_y + (int64_t)k * Y * ld,
                                              d_fm + (int64_t)k * D * ld, d_fP + (int64_t)k * D * D * ld, d_status,
@@ -924,7 +937,7 @@ extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_i
     int rc = getenv("SSMQ_NO_FUSED") ? 0
                                      : try_launch_fused(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), 0, 0, 0,
                                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                        nullptr, nullptr, &name, true, nullptr, 0.0);
+                                                        nullptr, nullptr, &name, true, nullptr, 0.0, nullptr, nullptr);
     if (rc < 0) return rc;
     snprintf(buf, len, "%s", rc == 1 ? name : "hipGraph of 3 T launches (apply dyn | apply obs | k_kalman_update)");
     return SSMQ_OK;

@@ -8,12 +8,17 @@
 
 namespace ssmq {
 
+typedef const __attribute__((address_space(4))) double *cdouble_p;   // constant address space: scalar loads
+
 // Integrand constants as they travel in the kernel-argument segment (wave-uniform -> SGPRs).
 struct FPar {
     double p[SSMQ_MAX_FPAR];
     int32_t idx[SSMQ_MAX_FIDX];
     int32_t n_idx;
     int32_t n_par;
+    // Optional table of the integrand's time-dependent constant for integer times 0..T-1 (filter loops: the time index is
+    // the step counter), filled on the host by time_table(); null = evaluate the transcendental on the device.
+    const double *ttab;
 };
 
 // Offsets (in doubles) into a transform's constant block in HBM; every thread reads it with wave-uniform addresses,
@@ -58,8 +63,6 @@ struct ApplyArgs {
 
 // Transform constants are read through the constant address space: wave-uniform constant-space loads are always
 // selected as scalar loads (s_load), even after the kernel has started storing its outputs.
-typedef const __attribute__((address_space(4))) double *cdouble_p;
-
 #define SSMQ_PK(i, j) ((i) * ((i) + 1) / 2 + (j))  // packed lower-triangular index, j <= i
 
 // In-register lower Cholesky of a packed symmetric matrix, column by column with reciprocal scaling, the operation
@@ -100,7 +103,9 @@ template <>
 struct Fn<SSMQ_F_UNGM_DYN> {
     static constexpr int DIN = 1;
     double c;
-    __device__ __forceinline__ void init(double t, const FPar &) { c = 8.0 * cos(1.2 * t); }
+    __device__ __forceinline__ void init(double t, const FPar &p) {
+        c = p.ttab ? ((cdouble_p)p.ttab)[(int)t] : 8.0 * cos(1.2 * t);
+    }
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {
         o[0] = 0.5 * x[0] + 25.0 * (x[0] / (1.0 + x[0] * x[0])) + c;
@@ -119,7 +124,9 @@ template <>
 struct Fn<SSMQ_F_UNGMNA_DYN> {
     static constexpr int DIN = 2;
     double c;
-    __device__ __forceinline__ void init(double t, const FPar &) { c = cos(1.2 * t); }
+    __device__ __forceinline__ void init(double t, const FPar &p) {
+        c = p.ttab ? ((cdouble_p)p.ttab)[(int)t] : cos(1.2 * t);
+    }
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {
         o[0] = 0.5 * x[0] + 25.0 * (x[0] / (1.0 + x[0] * x[0])) + 8.0 * x[1] * c;
@@ -302,6 +309,20 @@ struct Fn<SSMQ_F_CV_DYN> {
         o[3] = x[3];
     }
 };
+
+// Host: the time-dependent constant of integrand `id` for times 0..T-1 (what Fn<id>::init would compute), or false if the
+// integrand has none.  Evaluated with the host libm in fp64 - the reference evaluates np.cos on the host as well.
+__host__ inline bool time_table(int id, int T, double *out) {
+    if (id == SSMQ_F_UNGM_DYN) {
+        for (int k = 0; k < T; ++k) out[k] = 8.0 * cos(1.2 * (double)k);
+        return true;
+    }
+    if (id == SSMQ_F_UNGMNA_DYN) {
+        for (int k = 0; k < T; ++k) out[k] = cos(1.2 * (double)k);
+        return true;
+    }
+    return false;
+}
 
 // Host-visible table: inputs read / outputs produced by each integrand (0 = "set by the transform's E").
 struct FInfo {

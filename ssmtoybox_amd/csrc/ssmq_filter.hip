@@ -36,28 +36,36 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
     for (int i = 0; i < Y; ++i)
 #pragma unroll
         for (int j = 0; j < Y; ++j) Py[i][j] = a.P_y[(i * Y + j) * ld + b];
-    bool ok = chol_packed<Y>(S);
+    bool ok;
     // X = P_y^-1 P_yx, column by column (forward then backward substitution); gain[d][i] = X[i][d]
     double G[D][Y];
+    if (Y == 1) {
+        // scalar measurement: one division instead of factor + two substitutions (same shortcut as k_filter_fused)
+        ok = S[0] > 0.0;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        double v[Y];
+        for (int d = 0; d < D; ++d) G[d][0] = a.P_yx[d * ld + b] / S[0];
+    } else {
+        ok = chol_packed<Y>(S);
 #pragma unroll
-        for (int i = 0; i < Y; ++i) {
-            double s = a.P_yx[(i * D + d) * ld + b];
+        for (int d = 0; d < D; ++d) {
+            double v[Y];
 #pragma unroll
-            for (int k = 0; k < i; ++k) s -= S[SSMQ_PK(i, k)] * v[k];
-            v[i] = s / S[SSMQ_PK(i, i)];
+            for (int i = 0; i < Y; ++i) {
+                double s = a.P_yx[(i * D + d) * ld + b];
+#pragma unroll
+                for (int k = 0; k < i; ++k) s -= S[SSMQ_PK(i, k)] * v[k];
+                v[i] = s / S[SSMQ_PK(i, i)];
+            }
+#pragma unroll
+            for (int i = Y - 1; i >= 0; --i) {
+                double s = v[i];
+#pragma unroll
+                for (int k = i + 1; k < Y; ++k) s -= S[SSMQ_PK(k, i)] * v[k];
+                v[i] = s / S[SSMQ_PK(i, i)];
+            }
+#pragma unroll
+            for (int i = 0; i < Y; ++i) G[d][i] = v[i];
         }
-#pragma unroll
-        for (int i = Y - 1; i >= 0; --i) {
-            double s = v[i];
-#pragma unroll
-            for (int k = i + 1; k < Y; ++k) s -= S[SSMQ_PK(k, i)] * v[k];
-            v[i] = s / S[SSMQ_PK(i, i)];
-        }
-#pragma unroll
-        for (int i = 0; i < Y; ++i) G[d][i] = v[i];
     }
     double dy[Y];
 #pragma unroll
@@ -74,13 +82,17 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
     if (a.student_dof > 0.0) {
         // delta = chol(P_y)^-1 (y - y_mean)   (ssinf.py:729-731)
         double dl[Y], dd = 0.0;
+        if (Y == 1) {
+            dd = dy[0] * dy[0] / S[0];
+        } else {
 #pragma unroll
-        for (int i = 0; i < Y; ++i) {
-            double s = dy[i];
+            for (int i = 0; i < Y; ++i) {
+                double s = dy[i];
 #pragma unroll
-            for (int k = 0; k < i; ++k) s -= S[SSMQ_PK(i, k)] * dl[k];
-            dl[i] = s / S[SSMQ_PK(i, i)];
-            dd += dl[i] * dl[i];
+                for (int k = 0; k < i; ++k) s -= S[SSMQ_PK(i, k)] * dl[k];
+                dl[i] = s / S[SSMQ_PK(i, i)];
+                dd += dl[i] * dl[i];
+            }
         }
         sc2 = (a.student_dof + dd) / (a.student_dof + (double)Y);
     }

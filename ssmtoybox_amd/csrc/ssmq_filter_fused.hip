@@ -97,40 +97,53 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
         double S[Y * (Y + 1) / 2];
 #pragma unroll
         for (int i = 0; i < Y * (Y + 1) / 2; ++i) S[i] = ob.cv[i];
-        ok = chol_packed<Y>(S) && ok;
         double G[D][Y];
+        if (Y == 1) {
+            // scalar measurement: P_y^-1 P_yx is one division; the factor-and-two-substitutions route of cho_solve
+            // (sqrt + two divisions by it) would only lengthen the serial dependency chain of the time loop
+            ok = (S[0] > 0.0) && ok;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            double v[Y];
+            for (int d = 0; d < D; ++d) G[d][0] = ob.cx[0][d] / S[0];
+        } else {
+            ok = chol_packed<Y>(S) && ok;
 #pragma unroll
-            for (int i = 0; i < Y; ++i) {
-                double s = ob.cx[i][d];
+            for (int d = 0; d < D; ++d) {
+                double v[Y];
 #pragma unroll
-                for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * v[q];
-                v[i] = s / S[SSMQ_PK(i, i)];
+                for (int i = 0; i < Y; ++i) {
+                    double s = ob.cx[i][d];
+#pragma unroll
+                    for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * v[q];
+                    v[i] = s / S[SSMQ_PK(i, i)];
+                }
+#pragma unroll
+                for (int i = Y - 1; i >= 0; --i) {
+                    double s = v[i];
+#pragma unroll
+                    for (int q = i + 1; q < Y; ++q) s -= S[SSMQ_PK(q, i)] * v[q];
+                    v[i] = s / S[SSMQ_PK(i, i)];
+                }
+#pragma unroll
+                for (int i = 0; i < Y; ++i) G[d][i] = v[i];
             }
-#pragma unroll
-            for (int i = Y - 1; i >= 0; --i) {
-                double s = v[i];
-#pragma unroll
-                for (int q = i + 1; q < Y; ++q) s -= S[SSMQ_PK(q, i)] * v[q];
-                v[i] = s / S[SSMQ_PK(i, i)];
-            }
-#pragma unroll
-            for (int i = 0; i < Y; ++i) G[d][i] = v[i];
         }
         if (agg == 0 && !ok) agg = k + 1;
         const bool good = (agg == 0);
         double sc2 = 1.0;
         if (a.student_dof > 0.0) {   // (dof + delta'delta) / (dof + Y), delta = chol(S)^-1 (y - y_mean)  (ssinf.py:729-733)
             double dl[Y], dd = 0.0;
+            if (Y == 1) {
+                const double dy0 = ycur[0] - ob.mf[0];
+                dd = dy0 * dy0 / S[0];
+            } else {
 #pragma unroll
-            for (int i = 0; i < Y; ++i) {
-                double s = ycur[i] - ob.mf[i];
+                for (int i = 0; i < Y; ++i) {
+                    double s = ycur[i] - ob.mf[i];
 #pragma unroll
-                for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * dl[q];
-                dl[i] = s / S[SSMQ_PK(i, i)];
-                dd += dl[i] * dl[i];
+                    for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * dl[q];
+                    dl[i] = s / S[SSMQ_PK(i, i)];
+                    dd += dl[i] * dl[i];
+                }
             }
             sc2 = (a.student_dof + dd) / (a.student_dof + (double)Y);
         }
@@ -211,7 +224,7 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
                      const ssmq_integrand *fo, int sel_obs, int64_t B, int64_t ld, int T, const double *d_y,
                      const double *d_m0, const double *d_P0, const double *d_gqg, const double *d_rr, double *d_fm,
                      double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run,
-                     const double *d_sscale, double student_dof) {
+                     const double *d_sscale, double student_dof, const double *d_ttab_dyn, const double *d_ttab_obs) {
     if (hd->form != ho->form || (hd->tp_nu > 0.0) != (ho->tp_nu > 0.0) || sel_obs < 0 || fd->n_idx > 0) return 0;
     const int tp = hd->tp_nu > 0.0 ? 1 : 0;
     const int both = hd->opt_mask & ho->opt_mask;
@@ -234,6 +247,8 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
             }
             fill_fpar(fd, &a.fd);
             fill_fpar(fo, &a.fo);
+            a.fd.ttab = d_ttab_dyn;
+            a.fo.ttab = d_ttab_obs;
             int rc = hip_fail(e.fn(a, s), e.name);
             return rc ? rc : 1;
         }
