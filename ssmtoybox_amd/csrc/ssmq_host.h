@@ -39,9 +39,8 @@ struct SmallEntry {
     const char *name;
 };
 const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int sel, int opt);
-void register_small(const SmallEntry *entries, int n);
 
-// fused filter kernels (ssmq_filter.hip)
+// measurement update (ssmq_filter.hip)
 int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
                          const double *y_mean, const double *P_y, const double *P_yx, const double *y, double *m_fi,
                          double *P_fi, int32_t *status, hipStream_t s);
