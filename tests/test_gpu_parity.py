@@ -479,3 +479,88 @@ def test_bsq_d10(amd, golden):
             fx = np.apply_along_axis(f, 0, means[i][:, None] + chol.dot(pts), None)
             ref = orc.moments_bq(fx, chol, w['wm'], w['Wc'], w['Wcc'], w['model_var'])
             assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=(tag, i))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# edge cases of the batch interface
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B', [1, 2, 63, 64, 65, 127, 1000])
+def test_ragged_batch_sizes(amd, B):
+    """Batch sizes around the wave width; every trajectory's result equals its single-call result bit for bit."""
+    from ssmtoybox_amd import ssmod as sm
+    rng = np.random.default_rng(B)
+    tf = amd.GaussianProcessTransform(2, 2, gp_par(2, 3.0))
+    f = sm.Pendulum2DTransition(dt=0.01).dyn_eval
+    means = rng.standard_normal((B, 2))
+    a = rng.standard_normal((B, 2, 2))
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(2)
+    mf, cf, cfx = tf.apply_batch(f, means, covs, 0.0)
+    w = dict(wm=tf.wm, Wc=tf.Wc, Wcc=tf.Wcc, model_var=tf.model.model_var)
+    for i in sorted({0, B // 2, B - 1}):
+        one = tf.apply(f, means[i], covs[i], np.atleast_1d(0))
+        assert np.array_equal(one[0], mf[i]) and np.array_equal(one[1], cf[i]) and np.array_equal(one[2], cfx[i])
+        ref = orc.apply_bq(orc.F_PENDULUM_DYN, means[i], covs[i], 0, orc.points_ut(2), w, (0.01,))
+        assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=(B, i))
+
+
+def test_device_resident_api_with_padded_pitch(amd):
+    """ssmq_apply_batch_dev on SoA planes whose pitch ld is larger than B; padding lanes are never touched."""
+    from ssmtoybox_amd import _lib, ssmod as sm
+    B, ld, D = 1000, 1280, 5
+    means, covs = synthetic_reentry6(B)
+    means, covs = means[:, :D], covs[:, :D, :D]
+    tf = amd.UnscentedTransform(D)
+    f = sm.ReentryVehicle2DTransition(dt=0.1).dyn_eval
+    mean, cov = _lib.SoA.from_host(means, ld), _lib.SoA.from_host(covs, ld)
+    mf, cf, cfx = _lib.SoA(D, B, ld), _lib.SoA(D * D, B, ld), _lib.SoA(D * D, B, ld)
+    sentinel = np.full((D * D, ld), 7.25)
+    for buf in (cf, cfx):
+        buf.buf.upload(sentinel)
+    st = _lib.DeviceBuffer(4 * ld)
+    tbuf = _lib.DeviceBuffer(8)
+    tbuf.upload(np.zeros(1))
+    tf.apply_batch_dev(f, mean, cov, tbuf, mf, cf, cfx, st, 0)
+    _lib.sync()
+    ref = tf.apply_batch(f, means, covs, 0.0)
+    assert np.array_equal(mf.to_host(), ref[0]) and np.array_equal(cf.to_host((D, D)), ref[1])
+    assert np.array_equal(cfx.to_host((D, D)), ref[2])
+    planes = cf.buf.download((D * D, ld))
+    assert np.all(planes[:, B:] == 7.25)                       # nothing written beyond the batch
+    assert not st.download((ld,), dtype=np.int32)[:B].any()
+
+
+def test_weights_can_be_replaced_after_construction(amd):
+    """The reference's research scripts assign tf.wm / tf.Wc / tf.Wcc / model.model_var after construction; the device
+    constants must follow (research/tpq/tpq_ungm.py:114-124, research/bsq/bsq_tracking.py:276-281)."""
+    from ssmtoybox_amd import ssmod as sm
+    f = sm.UNGMTransition().dyn_eval
+    tf = amd.GaussianProcessTransform(1, 1, np.array([[1.0, 3.0]]))
+    m, P = np.array([0.3]), np.array([[2.0]])
+    a = tf.apply(f, m, P, np.atleast_1d(2))
+    w = orc.gp_weights([1.0, 0.7], orc.points_ut(1))
+    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
+    b = tf.apply(f, m, P, np.atleast_1d(2))
+    ref = orc.apply_bq(orc.F_UNGM_DYN, m, P, 2, orc.points_ut(1), w)
+    assert not np.allclose(a[1], b[1])
+    assert_moments_close(b, ref, P)
+    tf.model.model_var = np.array([[0.5]])                      # matrix-valued model variance
+    c = tf.apply(f, m, P, np.atleast_1d(2))
+    assert np.isclose(c[1][0, 0] - b[1][0, 0], 0.5 - w['model_var'])
+    # apply(..., kern_par) re-computes the weights on the device (bq/bqmtran.py:93-95)
+    d = tf.apply(f, m, P, np.atleast_1d(2), np.array([[1.0, 0.7]]))
+    assert rel_err(tf.wm, w['wm']) < 1e-10 and rel_err(d[0], b[0]) < 1e-10
+
+
+def test_theta_batched_weights_large(amd):
+    """One launch, 512 parameter rows (the length-scale sweeps of research/bsq/bsq_ungm.py:190-282)."""
+    from ssmtoybox_amd.bq.bqkern import device_gp_weights
+    pts = orc.points_ut(3)
+    ells = np.linspace(0.5, 6.0, 512)
+    pars = np.column_stack((np.ones(512), ells, ells, ells))
+    w = device_gp_weights(pts, pars)
+    assert w['wm'].shape == (512, 7) and not w['status'].any()
+    for i in (0, 100, 511):
+        ref = orc.gp_weights(pars[i], pts)
+        cond = np.linalg.cond(orc.rbf_eval(pars[i], pts, scaling=False) + 1e-8 * np.eye(7))
+        assert rel_err(w['wm'][i], ref['wm']) < max(1e-10, 64 * cond * 2.2e-16)
+        assert rel_err(w['Wc'][i], ref['Wc']) < max(1e-10, 8 * cond ** 2 * 2.2e-16)
