@@ -307,7 +307,8 @@ def main():
         import torch.distributed as dist
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl')
+        # 'nccl' is RCCL on ROCm; SSMQ_BENCH_BACKEND=gloo lets several ranks share one GPU for rehearsals
+        dist.init_process_group(os.environ.get('SSMQ_BENCH_BACKEND', 'nccl'))
 
     import ssmtoybox_amd as amd
     if amd.device_count() < 1:
@@ -338,7 +339,7 @@ def main():
     pass_ms_dev = ev0.elapsed_ms(ev1) / max(args.steps, 1)
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
