@@ -327,18 +327,22 @@ def main():
     wl = FilterBench(amd, B, T, seed=1 + rank, workload=args.workload, filt=args.filter)
     for _ in range(args.warmup):
         wl.step()
-    barrier_sync()
+    barrier_sync()                      # common start: barrier + device synchronisation on every rank
     ev0, ev1 = _lib.Event(), _lib.Event()
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
         wl.step()
     ev1.record()
-    barrier_sync()
-    elapsed = time.perf_counter() - t0
-    pass_ms_dev = ev0.elapsed_ms(ev1) / max(args.steps, 1)
+    _lib.sync()                         # this rank's K steps are complete ...
     if dist is not None:
         import torch
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pass_ms_dev = ev0.elapsed_ms(ev1) / max(args.steps, 1)
+    if dist is not None:                # ... closing barrier; the job's time is the slowest rank's
+        import torch
+        dist.barrier()
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
