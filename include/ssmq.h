@@ -217,6 +217,21 @@ int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, 
                             double *d_fm, double *d_fP, int32_t *d_status);
 
 /*
+ * Forward pass of a Gaussian filter whose transition and / or measurement model takes its noise as an argument
+ * (ssinf.py:271-272 and 282-283: mean <- [mean; noise_mean], cov <- blockdiag(cov, noise_cov) before each transform;
+ * ssinf.py:294-295: cross-covariances trimmed to the first dim_state columns).
+ *   dq > 0: non-additive dynamics, q_mean [dq], q_cov [dq*dq] host, h_dyn is a (dim_state + dq -> dim_state) transform;
+ *   dq = 0: additive dynamics, q_cov is G Q G' [dim_state^2] (or NULL for none), q_mean ignored.
+ *   dr likewise for the measurement model (h_obs: dim_state + dr -> Y; dr = 0: r_cov is R [Y*Y]).
+ * Buffers and status as ssmq_filter_forward_dev.  Synchronous; runs as a launch loop (5 T launches).
+ */
+int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                const ssmq_integrand *f_obs, int dim_state, int64_t B, int64_t ld, int T,
+                                const double *d_y, const double *d_m0, const double *d_P0, const double *q_mean,
+                                const double *q_cov, int dq, const double *r_mean, const double *r_cov, int dr,
+                                double *d_fm, double *d_fP, int32_t *d_status);
+
+/*
  * Forward pass + Rauch-Tung-Striebel backward pass (ssinf.py:120-147, 325-344): as ssmq_filter_forward_dev, and
  * additionally d_sm [T][D][ld], d_sP [T][D*D][ld] smoothed moments.  The reference's indexing is kept: the recursion
  * starts at the last filtered estimate and leaves the last two smoothed steps equal to the filtered ones.  Synchronous.

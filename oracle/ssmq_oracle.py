@@ -597,6 +597,39 @@ def gaussian_filter(y, m0, P0, Qn, Rn, G, tf_dyn, tf_obs):
     return fm, fP, pm, pP, pC
 
 
+def gaussian_filter_aug(y, m0, P0, q_mean, Qn, r_mean, Rn, G, tf_dyn, tf_obs, dyn_additive, obs_additive):
+    """Forward pass of a Gaussian filter whose models may take the noise as an argument.  ssinf.py:254-323:
+    non-additive model -> the transform sees [mean; noise_mean], blockdiag(cov, noise_cov) (:271-272, :282-283) and
+    the cross-covariance is cut to the first dim_state columns (:294-295); additive model -> noise covariance added
+    after the transform (:278-279, :290-291).  Raises LinAlgError where the reference does."""
+    dim, steps = m0.shape[0], y.shape[1]
+    fm, fP = np.zeros((dim, steps)), np.zeros((dim, dim, steps))
+    m, P = m0.copy(), P0.copy()
+
+    def aug(mean, cov, nm, nc):
+        da = mean.shape[0] + nm.shape[0]
+        ca = np.zeros((da, da))
+        ca[:mean.shape[0], :mean.shape[0]] = cov
+        ca[mean.shape[0]:, mean.shape[0]:] = nc
+        return np.concatenate((mean, nm)), ca
+
+    for k in range(steps):
+        if dyn_additive:
+            m_pr, P_pr, _ = tf_dyn(m, P, k)
+            P_pr = P_pr + G.dot(Qn).dot(G.T)
+        else:
+            m_pr, P_pr, _ = tf_dyn(*aug(m, P, q_mean, Qn), k)
+        if obs_additive:
+            y_mean, P_y, P_yx = tf_obs(m_pr, P_pr, k)
+            P_y = P_y + Rn
+        else:
+            y_mean, P_y, P_yx = tf_obs(*aug(m_pr, P_pr, r_mean, Rn), k)
+        P_yx = P_yx[:, :dim]
+        m, P = kalman_update(m_pr, P_pr, y_mean, P_y, P_yx, y[:, k])
+        fm[:, k], fP[..., k] = m, P
+    return fm, fP
+
+
 def student_scale_sequence(steps, dim_y, x0_dof, q_dof, r_dof, dof=4.0, fixed_dof=True):
     """(dof_pr - 2) / dof_pr used by each time update of a Studentian filter; the filtered dof grows by dim_y per
     measurement update (ssinf.py:652-660, 735-736), so the sequence depends on the degrees of freedom only."""

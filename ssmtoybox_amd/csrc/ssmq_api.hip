@@ -695,7 +695,9 @@ namespace ssmq {
 int launch_kalman_update_ex(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
                             const double *y_mean, const double *P_y, const double *P_yx, const double *y,
                             double *m_fi, double *P_fi, int32_t *status, const int32_t *st_a, const int32_t *st_b,
-                            int step, hipStream_t s, double student_dof, double *smat_out);
+                            int step, hipStream_t s, double student_dof, double *smat_out, int Dx);
+int launch_augment(const double *m, const double *P, const double *nmean, const double *ncov, double *ma, double *Pa,
+                   int D, int Dn, int64_t B, int64_t ld, hipStream_t s);
 }
 
 namespace ssmq {
@@ -858,7 +860,7 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
             if (!rc)
                 rc = launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, d_y + (int64_t)k * Y * ld,
                                              d_fm + (int64_t)k * D * ld, d_fP + (int64_t)k * D * D * ld, d_status,
-                                             st_a, st_b, k, s, student_dof, smat);
+                                             st_a, st_b, k, s, student_dof, smat, 0);
         }
         hipGraph_t g = nullptr;
         hipError_t ce = hipStreamEndCapture(s, &g);
@@ -881,6 +883,104 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
                                        double *d_fm, double *d_fP, int32_t *d_status) {
     return filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, GQG, R, d_fm, d_fP, d_status,
                                nullptr, 0.0);
+}
+
+// Filters whose models take the noise as an argument (ssinf.py:271-272, 282-283, 294-295): the moments are augmented with
+// the noise statistics before each transform and the cross-covariance is cut back to the state columns. Plain launch
+// loop (augment | apply | augment | apply | update per step); no fused kernel and no graph cache for this path yet.
+extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                           const ssmq_integrand *f_obs, int dim_state, int64_t B, int64_t ld, int T,
+                                           const double *d_y, const double *d_m0, const double *d_P0,
+                                           const double *q_mean, const double *q_cov, int dq, const double *r_mean,
+                                           const double *r_cov, int dr, double *d_fm, double *d_fP,
+                                           int32_t *d_status) {
+    if (!h_dyn || !h_obs || !f_dyn || !f_obs || dim_state <= 0 || dq < 0 || dr < 0 || B < 0 || ld < B || T < 0 || !d_y ||
+        !d_m0 || !d_P0 || !d_fm || !d_fP || !d_status || (dq > 0 && (!q_mean || !q_cov)) ||
+        (dr > 0 && (!r_mean || !r_cov))) {
+        set_error("filter_forward_aug: bad argument");
+        return SSMQ_E_ARG;
+    }
+    const int D = dim_state, Da = D + dq, Do = D + dr, Y = h_obs->E;
+    if (h_dyn->D != Da || h_dyn->E != D || h_obs->D != Do) {
+        set_error("filter_forward_aug: transforms must be (dim_state + dq -> dim_state) and (dim_state + dr -> dim_y)");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0 || T == 0) return SSMQ_OK;
+    hipStream_t s = stream();
+    DevBuf ws, st;
+    const size_t n_noise = (size_t)dq + (dq ? (size_t)dq * dq : (size_t)D * D) + dr + (dr ? (size_t)dr * dr : (size_t)Y * Y);
+    const size_t n_dbl = (size_t)ld * (Da + Da * Da + D + D * D + D * Da + Do + Do * Do + Y + Y * Y + Y * Do) + 3 * (size_t)T +
+                         n_noise;
+    if ((rc = ws.alloc(sizeof(double) * n_dbl)) || (rc = st.alloc(2 * sizeof(int32_t) * (size_t)ld))) return rc;
+    double *w = ws.d();
+    double *ma = w; w += (size_t)ld * Da;
+    double *Pa = w; w += (size_t)ld * Da * Da;
+    double *m_pr = w; w += (size_t)ld * D;
+    double *P_pr = w; w += (size_t)ld * D * D;
+    double *C_xx = w; w += (size_t)ld * D * Da;
+    double *mo = w; w += (size_t)ld * Do;
+    double *Po = w; w += (size_t)ld * Do * Do;
+    double *y_mean = w; w += (size_t)ld * Y;
+    double *P_y = w; w += (size_t)ld * Y * Y;
+    double *P_yx = w; w += (size_t)ld * Y * Do;
+    double *tvec = w; w += T;
+    double *ttab_d = w; w += T;
+    double *ttab_o = w; w += T;
+    double *d_qm = w; w += dq;
+    double *d_qc = w; w += dq ? (size_t)dq * dq : (size_t)D * D;
+    double *d_rm = w; w += dr;
+    double *d_rc = w; w += dr ? (size_t)dr * dr : (size_t)Y * Y;
+    int32_t *st_a = (int32_t *)st.p, *st_b = st_a + ld;
+
+    std::vector<double> tv(T), htd(T), hto(T);
+    for (int k = 0; k < T; ++k) tv[k] = (double)k;   // both transforms of step k + 1 use time index k (ssinf.py:104)
+    const bool has_td = time_table(f_dyn->id, T, htd.data()), has_to = time_table(f_obs->id, T, hto.data());
+    SSMQ_HIP(hipMemcpyAsync(tvec, tv.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
+    if (has_td) SSMQ_HIP(hipMemcpyAsync(ttab_d, htd.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
+    if (has_to) SSMQ_HIP(hipMemcpyAsync(ttab_o, hto.data(), sizeof(double) * T, hipMemcpyHostToDevice, s));
+    std::vector<double> zq((size_t)D * D, 0.0), zr((size_t)Y * Y, 0.0);
+    if (dq) SSMQ_HIP(hipMemcpyAsync(d_qm, q_mean, sizeof(double) * dq, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(d_qc, q_cov ? q_cov : zq.data(), sizeof(double) * (dq ? (size_t)dq * dq : (size_t)D * D),
+                            hipMemcpyHostToDevice, s));
+    if (dr) SSMQ_HIP(hipMemcpyAsync(d_rm, r_mean, sizeof(double) * dr, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(d_rc, r_cov ? r_cov : zr.data(), sizeof(double) * (dr ? (size_t)dr * dr : (size_t)Y * Y),
+                            hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, s));
+    SSMQ_HIP(hipStreamSynchronize(s));   // the host staging vectors above go out of scope with this call
+
+    for (int k = 0; k < T && !rc; ++k) {
+        const double *m_in = k == 0 ? d_m0 : d_fm + (int64_t)(k - 1) * D * ld;
+        const double *P_in = k == 0 ? d_P0 : d_fP + (int64_t)(k - 1) * D * D * ld;
+        if (dq) {
+            rc = launch_augment(m_in, P_in, d_qm, d_qc, ma, Pa, D, dq, B, ld, s);
+            if (!rc)
+                rc = apply_dev_impl(h_dyn, f_dyn, B, ld, ma, Pa, tvec + k, 0, m_pr, P_pr, C_xx, st_a, nullptr, nullptr, false,
+                                    1.0, 1.0, has_td ? ttab_d : nullptr);
+        } else {
+            rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec + k, 0, m_pr, P_pr, C_xx, st_a, d_qc, nullptr, false,
+                                1.0, 1.0, has_td ? ttab_d : nullptr);
+        }
+        if (rc) break;
+        if (dr) {
+            rc = launch_augment(m_pr, P_pr, d_rm, d_rc, mo, Po, D, dr, B, ld, s);
+            if (!rc)
+                rc = apply_dev_impl(h_obs, f_obs, B, ld, mo, Po, tvec + k, 0, y_mean, P_y, P_yx, st_b, nullptr, nullptr, false,
+                                    1.0, 1.0, has_to ? ttab_o : nullptr);
+        } else {
+            rc = apply_dev_impl(h_obs, f_obs, B, ld, m_pr, P_pr, tvec + k, 0, y_mean, P_y, P_yx, st_b, d_rc, nullptr, false,
+                                1.0, 1.0, has_to ? ttab_o : nullptr);
+        }
+        if (!rc)
+            rc = launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, d_y + (int64_t)k * Y * ld,
+                                         d_fm + (int64_t)k * D * ld, d_fP + (int64_t)k * D * D * ld, d_status, st_a, st_b,
+                                         k, s, 0.0, nullptr, Do);
+    }
+    hipError_t se = hipStreamSynchronize(s);   // workspace is released on return
+    if (rc) return rc;
+    SSMQ_HIP(se);
+    return SSMQ_OK;
 }
 
 namespace ssmq {

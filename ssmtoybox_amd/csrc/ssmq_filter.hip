@@ -19,6 +19,7 @@ struct UpdArgs {
     // "covariance" P_fi the rescaled scale matrix (dof + delta'delta) / (dof + Y) * P_fi is written to smat_out
     double student_dof;
     double *smat_out;
+    int32_t Dx;   // columns of P_yx (> D when the measurement transform ran on a noise-augmented state: the first D are used)
 };
 
 template <int D, int Y>
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
         // scalar measurement: one division instead of factor + two substitutions (same shortcut as k_filter_fused)
         ok = S[0] > 0.0;
 #pragma unroll
-        for (int d = 0; d < D; ++d) G[d][0] = a.P_yx[d * ld + b] / S[0];
+        for (int d = 0; d < D; ++d) G[d][0] = a.P_yx[d * ld + b] / S[0];   // (Y == 1: row 0 only)
     } else {
         ok = chol_packed<Y>(S);
 #pragma unroll
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
             double v[Y];
 #pragma unroll
             for (int i = 0; i < Y; ++i) {
-                double s = a.P_yx[(i * D + d) * ld + b];
+                double s = a.P_yx[(i * a.Dx + d) * ld + b];
 #pragma unroll
                 for (int k = 0; k < i; ++k) s -= S[SSMQ_PK(i, k)] * v[k];
                 v[i] = s / S[SSMQ_PK(i, i)];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update_generic(const UpdAr
     }
     for (int d = 0; d < D; ++d) {
         for (int i = 0; i < Y; ++i) {
-            double s = a.P_yx[(i * D + d) * ld + b];
+            double s = a.P_yx[(i * a.Dx + d) * ld + b];
             for (int k = 0; k < i; ++k) s -= S[i * Y + k] * v[k];
             v[i] = s / S[i * Y + i];
         }
@@ -213,8 +214,9 @@ static void launch_upd(const UpdArgs &a, hipStream_t s) {
 int launch_kalman_update_ex(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
                             const double *y_mean, const double *P_y, const double *P_yx, const double *y,
                             double *m_fi, double *P_fi, int32_t *status, const int32_t *st_a, const int32_t *st_b,
-                            int step, hipStream_t s, double student_dof, double *smat_out) {
-    UpdArgs a{m_pr, P_pr, y_mean, P_y, P_yx, y, m_fi, P_fi, status, st_a, st_b, B, ld, step, D, Y, student_dof, smat_out};
+                            int step, hipStream_t s, double student_dof, double *smat_out, int Dx) {
+    UpdArgs a{m_pr, P_pr, y_mean, P_y, P_yx, y, m_fi, P_fi, status, st_a, st_b, B, ld, step, D, Y, student_dof, smat_out,
+              Dx > 0 ? Dx : D};
 #define SSMQ_UPD(d, y_)                  \
     if (D == d && Y == y_) {             \
         launch_upd<d, y_>(a, s);         \
@@ -242,9 +244,34 @@ int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr
                          const double *y_mean, const double *P_y, const double *P_yx, const double *y, double *m_fi,
                          double *P_fi, int32_t *status, hipStream_t s) {
     return launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, y, m_fi, P_fi, status, nullptr, nullptr,
-                                   0, s, 0.0, nullptr);
+                                   0, s, 0.0, nullptr, 0);
 }
 
+
+// ---- noise augmentation for non-additive models (ssinf.py:271-272, 282-283) -----------------------------------------
+// [m; noise_mean], blockdiag(P, noise_cov): plain copy kernel, one trajectory per lane, planes written whole.
+__global__ __launch_bounds__(kUpdBlock) void k_augment(const double *m, const double *P, const double *nmean,
+                                                       const double *ncov, double *ma, double *Pa, int D, int Dn,
+                                                       int64_t B, int64_t ld) {
+    const uint32_t b = blockIdx.x * kUpdBlock + threadIdx.x;
+    if ((int64_t)b >= B) return;
+    const int Da = D + Dn;
+    for (int i = 0; i < Da; ++i) ma[(int64_t)i * ld + b] = i < D ? m[(int64_t)i * ld + b] : nmean[i - D];
+    for (int i = 0; i < Da; ++i)
+        for (int j = 0; j < Da; ++j) {
+            double v = 0.0;
+            if (i < D && j < D) v = P[((int64_t)i * D + j) * ld + b];
+            else if (i >= D && j >= D) v = ncov[(i - D) * Dn + (j - D)];
+            Pa[((int64_t)i * Da + j) * ld + b] = v;
+        }
+}
+
+int launch_augment(const double *m, const double *P, const double *nmean, const double *ncov, double *ma, double *Pa,
+                   int D, int Dn, int64_t B, int64_t ld, hipStream_t s) {
+    const unsigned grid = (unsigned)((B + kUpdBlock - 1) / kUpdBlock);
+    hipLaunchKernelGGL(k_augment, dim3(grid), dim3(kUpdBlock), 0, s, m, P, nmean, ncov, ma, Pa, D, Dn, B, ld);
+    return hip_fail(hipGetLastError(), "k_augment");
+}
 
 // ---- Rauch-Tung-Striebel backward pass (ssinf.py:120-147, 325-344) ---------------------------------------------------
 // One trajectory per lane, run-time loop over time.  Index convention: arrays hold steps 1..T of the reference's

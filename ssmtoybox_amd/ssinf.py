@@ -1,5 +1,5 @@
 """
-Callers of the moment-transform path kept on the device: additive-noise Gaussian filters (reference:
+Callers of the moment-transform path kept on the device: Gaussian filters (reference:
 ssmtoybox/ssinf.py:215-323, 347-552) running B independent trajectories per kernel launch.
 
 `forward_pass(data)` keeps the reference's one-trajectory signature; `forward_pass_batch(data)` takes
@@ -10,8 +10,9 @@ Per time step k = 1..T (both transforms use time index k - 1: ssinf.py:104, 276-
     dyn transform, + G Q G'   ->   obs transform, + R   ->   Kalman update (ssinf.py:297-323)
 all inside `ssmq_filter_forward_dev` (ssmtoybox_amd/csrc); nothing is computed in NumPy.
 `StudentianInference` (ssinf.py:555-736) runs the same loop with the reference's scale-matrix bookkeeping
-(`ssmq_student_filter_forward_dev`); `backward_pass*` is the RTS smoother (`ssmq_filter_smooth_dev`).  Marginalised
-inference and non-additive noise are not covered.
+(`ssmq_student_filter_forward_dev`); `backward_pass*` is the RTS smoother (`ssmq_filter_smooth_dev`).  Models that take
+their noise as an argument (UNGMNA, CTRS; ssinf.py:271-295) go through `ssmq_filter_forward_aug_dev` (forward pass only).
+Marginalised inference is not covered.
 """
 import ctypes
 
@@ -25,13 +26,11 @@ from .ssmod import TransitionModel, MeasurementModel
 
 
 class GaussianInference:
-    """Additive-noise Gaussian filter (ssinf.py:215-323)."""
+    """Gaussian filter (ssinf.py:215-323)."""
 
     def __init__(self, mod_dyn, mod_obs, tf_dyn, tf_obs):
         assert isinstance(mod_dyn, TransitionModel) and isinstance(mod_obs, MeasurementModel)
         assert isinstance(tf_dyn, MomentTransform) and isinstance(tf_obs, MomentTransform)
-        if not (mod_dyn.noise_additive and mod_obs.noise_additive):
-            raise NotImplementedError('the device filter loop covers additive-noise models')
         self.mod_dyn, self.mod_obs, self.tf_dyn, self.tf_obs = mod_dyn, mod_obs, tf_dyn, tf_obs
         self.x0_mean, self.x0_cov = mod_dyn.init_rv.get_stats()
         self.q_mean, self.q_cov = mod_dyn.noise_rv.get_stats()
@@ -48,8 +47,14 @@ class GaussianInference:
         self.status = None
         self._data = None
 
+    @property
+    def _additive(self):
+        return self.mod_dyn.noise_additive and self.mod_obs.noise_additive
+
     def kernel_name(self):
         """Which kernel(s) the device filter loop runs for this filter (one fused kernel, or a replayed hipGraph)."""
+        if not self._additive:
+            return 'launch loop of 5 T launches (k_augment | apply dyn | k_augment | apply obs | k_kalman_update)'
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
         f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
         buf = ctypes.create_string_buffer(512)
@@ -65,6 +70,8 @@ class GaussianInference:
         return fm[..., 0], fP[..., 0]
 
     def _launch(self, lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st):
+        if not self._additive:
+            return self._launch_aug(lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st)
         gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
         rr, pr = _lib.as_c(self.r_cov)
         _lib.check(lib.ssmq_filter_forward_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
@@ -72,6 +79,29 @@ class GaussianInference:
                                                ctypes.c_void_p(d_m0.ptr), ctypes.c_void_p(d_P0.ptr), pg, pr,
                                                ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
                                                ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_forward_dev')
+
+    def _launch_aug(self, lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st):
+        """Noise enters the model functions: augmented moments per transform (ssinf.py:271-272, 282-283, 294-295)."""
+        if self.mod_dyn.noise_additive:
+            dq, (qm, pqm) = 0, (None, None)
+            qc, pqc = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
+        else:
+            dq = int(np.atleast_1d(self.q_mean).shape[0])
+            qm, pqm = _lib.as_c(np.atleast_1d(self.q_mean))
+            qc, pqc = _lib.as_c(np.atleast_2d(self.q_cov))
+        if self.mod_obs.noise_additive:
+            dr, (rm, prm) = 0, (None, None)
+            rc, prc = _lib.as_c(self.r_cov)
+        else:
+            dr = int(np.atleast_1d(self.r_mean).shape[0])
+            rm, prm = _lib.as_c(np.atleast_1d(self.r_mean))
+            rc, prc = _lib.as_c(np.atleast_2d(self.r_cov))
+        _lib.check(lib.ssmq_filter_forward_aug_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
+                                                   ctypes.byref(f_obs), self.mod_dyn.dim_state, B, ld, T,
+                                                   ctypes.c_void_p(d_y.ptr), ctypes.c_void_p(d_m0.ptr),
+                                                   ctypes.c_void_p(d_P0.ptr), pqm, pqc, dq, prm, prc, dr,
+                                                   ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
+                                                   ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_forward_aug_dev')
 
     def _initial_cov(self):
         return self.x0_cov
@@ -117,6 +147,8 @@ class GaussianInference:
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
         f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
         h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
+        if smooth and not self._additive:
+            raise NotImplementedError('the device smoother covers additive-noise models')
         if smooth:
             d_sm, d_sP = _lib.DeviceBuffer(8 * T * D * ld), _lib.DeviceBuffer(8 * T * D * D * ld)
             gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))

@@ -369,8 +369,67 @@ def g5_student():
     save('g5_student', **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G6: filters on non-additive-noise models (ssinf.py:271-272, 282-283, 294-295: augmented moments, trimmed cross-covs)
+# ---------------------------------------------------------------------------------------------------------------
+def g6_nonadditive():
+    out = {}
+    steps, seeds = 60, 6
+    # a zero initial mean makes this model degenerate for every symmetric rule (m_pr = 0 up to rounding, P_y ~ 1e-66 and
+    # the gain a ratio of rounding errors), so the prior is centred at 1
+    x0, q, r = GaussRV(1, mean=np.array([1.0])), GaussRV(1, cov=np.array([[10.0]])), GaussRV(1)
+    dyn, obs = ssmod.UNGMNATransition(x0, q), ssmod.UNGMNAMeasurement(r, 1)
+    np.random.seed(99)
+    x = dyn.simulate_discrete(steps, seeds)
+    y = obs.simulate_measurements(x)
+    out['ungmna_x'], out['ungmna_y'] = x, y
+    par = np.array([[1.0, 3.0, 3.0]])
+    algs = {'ukf': ssinf.UnscentedKalman(dyn, obs), 'ckf': ssinf.CubatureKalman(dyn, obs),
+            'gpqkf': ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut')}
+    for name, alg in algs.items():
+        fm, fc = np.full((1, steps, seeds), np.nan), np.full((1, 1, steps, seeds), np.nan)
+        okm = np.ones(seeds, dtype=bool)
+        for s in range(seeds):
+            try:     # the reference raises LinAlgError when a predictive covariance loses positive definiteness
+                fm[..., s], fc[..., s] = alg.forward_pass(y[..., s])
+            except np.linalg.LinAlgError:
+                okm[s] = False
+            alg.reset()
+        out['ungmna_' + name + '_fm'], out['ungmna_' + name + '_fc'], out['ungmna_' + name + '_ok'] = fm, fc, okm
+    # zero-mean prior + cubature rule: P_y is exactly 0 at the first step and the reference raises for every trajectory
+    dyn0 = ssmod.UNGMNATransition(GaussRV(1), q)
+    alg = ssinf.CubatureKalman(dyn0, obs)
+    ok0 = np.ones(seeds, dtype=bool)
+    for s in range(seeds):
+        try:
+            alg.forward_pass(y[..., s])
+        except np.linalg.LinAlgError:
+            ok0[s] = False
+        alg.reset()
+    out['ungmna0_ckf_ok'] = ok0
+    # CTRS (non-additive dynamics, 5 states + 2 noise inputs) with additive radar (tests/test_ssinf.py:84-92 setup)
+    # prior away from the origin: at a zero mean the radar's bearing atan2(0, +-0) and the model's `x[4] == 0` branch
+    # make the first step a function of the sign of rounding errors
+    x0 = GaussRV(5, mean=np.array([10.0, 10.0, 5.0, 0.3, 0.1]), cov=0.1 * np.eye(5))
+    q = GaussRV(2, cov=np.diag([0.1, 0.1 * np.pi]))
+    r = GaussRV(2, cov=np.diag([0.3, 0.03]))
+    dyn, obs = ssmod.ConstantTurnRateSpeed(x0, q), ssmod.Radar2DMeasurement(r, 5)
+    np.random.seed(98)
+    seeds = 4
+    x = dyn.simulate_discrete(steps, seeds)
+    y = obs.simulate_measurements(x)
+    out['ctrs_x'], out['ctrs_y'], out['ctrs_m0'] = x, y, x0.mean
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    fm, fc = np.zeros((5, steps, seeds)), np.zeros((5, 5, steps, seeds))
+    for s in range(seeds):
+        fm[..., s], fc[..., s] = alg.forward_pass(y[..., s])
+        alg.reset()
+    out['ctrs_ukf_fm'], out['ctrs_ukf_fc'] = fm, fc
+    save('g6_nonadditive', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6']
     if 'g1' in which:
         g1_points()
     if 'g2' in which:
@@ -381,3 +440,5 @@ if __name__ == '__main__':
         g4_filters()
     if 'g5' in which:
         g5_student()
+    if 'g6' in which:
+        g6_nonadditive()

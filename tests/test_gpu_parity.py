@@ -363,6 +363,54 @@ def test_reentry_ukf_golden(amd, golden):
     assert rel_err(fP, g['rer_ukf_fc']) < 1e-6
 
 
+@pytest.mark.parametrize('name', ['ukf', 'ckf', 'gpqkf'])
+def test_ungmna_filter_golden(amd, golden, name):
+    """Noise as a model argument (ssinf.py:271-295): augmented moments, trimmed cross-covariance."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g6_nonadditive')
+    y = g['ungmna_y']
+    q = sm.GaussRV(1, cov=np.array([[10.0]]))
+    dyn = sm.UNGMNATransition(sm.GaussRV(1, mean=np.array([1.0])), q)
+    obs = sm.UNGMNAMeasurement(sm.GaussRV(1), 1)
+    par = np.array([[1.0, 3.0, 3.0]])
+    mk = {'ukf': lambda d: ssinf.UnscentedKalman(d, obs), 'ckf': lambda d: ssinf.CubatureKalman(d, obs),
+          'gpqkf': lambda d: ssinf.GaussianProcessKalman(d, obs, par, par, 'rbf', 'ut')}[name]
+    alg = mk(dyn)
+    fm, fP = alg.forward_pass_batch(y)
+    assert g['ungmna_' + name + '_ok'].all() and not alg.status.any()
+    assert rel_err(fm, g['ungmna_' + name + '_fm']) < 1e-8, name
+    assert rel_err(fP, g['ungmna_' + name + '_fc']) < 1e-8, name
+    with pytest.raises(NotImplementedError):
+        alg.backward_pass_batch()
+    if name == 'ckf':
+        # zero-mean prior: the cubature rule has no centre point, so m_pr = 0 and the measurement 0.05 r x^2 gets
+        # P_y = 0 exactly at the first step - the reference raises LinAlgError for every trajectory (golden mask)
+        assert not g['ungmna0_ckf_ok'].any()
+        alg0 = mk(sm.UNGMNATransition(sm.GaussRV(1), q))
+        alg0.forward_pass_batch(y, raise_on_failure=False)
+        assert np.array_equal(alg0.status, np.ones(y.shape[2], dtype=np.int32))      # 1 + first failing step (0)
+        with pytest.raises(np.linalg.LinAlgError):
+            alg0.forward_pass_batch(y)
+
+
+def test_ctrs_radar_ukf_golden(amd, golden):
+    """Non-additive dynamics (5 states + 2 noise inputs, D = 7 transform) with an additive radar."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g6_nonadditive')
+    y = g['ctrs_y']
+    dyn = sm.ConstantTurnRateSpeed(sm.GaussRV(5, mean=g['ctrs_m0'], cov=0.1 * np.eye(5)),
+                                   sm.GaussRV(2, cov=np.diag([0.1, 0.1 * np.pi])))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=np.diag([0.3, 0.03])), 5)
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    fm, fP = alg.forward_pass_batch(y)
+    assert rel_err(fm, g['ctrs_ukf_fm']) < 1e-9
+    assert rel_err(fP, g['ctrs_ukf_fc']) < 1e-9
+    # ragged batch through the same loop: 130 copies of the four trajectories
+    yy = np.tile(y, (1, 1, 33))[..., :130]
+    fm2, _ = alg.forward_pass_batch(yy)
+    assert np.array_equal(fm2[..., :4], fm) and np.array_equal(fm2[..., 128:130], fm[..., :2])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # full-size batches (BASELINE.json configs): oracle on a sample + size-independent properties
 # ---------------------------------------------------------------------------------------------------------------
