@@ -143,6 +143,10 @@ class FilterBench:
         ybuf[:, :, :B] = y.transpose(1, 0, 2)
         self.d_y = _lib.DeviceBuffer(ybuf.nbytes)
         self.d_y.upload(ybuf)
+        xbuf = np.zeros((T, D, ld))                 # true states, same planes as the filter output (error sums)
+        xbuf[:, :, :B] = self.x_true.transpose(1, 0, 2)
+        self.d_x = _lib.DeviceBuffer(xbuf.nbytes)
+        self.d_x.upload(xbuf)
         mb = np.zeros((D, ld))
         mb[:] = m0[:, None]
         Pb = np.zeros((D * D, ld))
@@ -348,11 +352,14 @@ def main():
         elapsed = float(tt.item())
 
     # final aggregation: per-time-step error sums -> RMSE / NLL (the path's only collective)
+    # phase 1: sums reduced on the device from the filter's output buffers, one all-reduce; phase 2: log credibility
+    # ratio against the GLOBAL per-step MSE matrix, a second all-reduce
     from ssmtoybox_amd import mcshard
-    fm, fP, st = wl.results()
-    ok = st == 0
-    loc = mcshard.local_error_sums(wl.x_true, fm, fP, ok)
+    ok = wl.d_st.download((wl.ld,), dtype=np.int32)[:B] == 0
+    loc = mcshard.device_error_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, wl.d_st)
     agg = mcshard.finalize(mcshard.allreduce_sums(loc, dist))
+    lcr = mcshard.finalize_lcr(mcshard.allreduce_sums(
+        mcshard.device_lcr_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, agg['mse'], wl.d_st), dist))
     rmse, nll = agg['rmse_total'], float(agg['nll_avg'].mean())
 
     out = None
@@ -379,7 +386,8 @@ def main():
                          'bytes_per_launch': bytes_pass, 'ms_per_launch': pass_ms_dev,
                          'note': 'the fused time loop is a serial recursion per trajectory: fp64-ALU / latency bound '
                                  '(at B=1e4: 157 waves for 1024 SIMDs), not HBM bound - SURVEY.md 7-4, DESIGN.md 3.4'},
-            'rmse': rmse, 'nll': nll, 'trajectories_aggregated': int(agg['count']),
+            'rmse': rmse, 'nll': nll, 'inclination_indicator': float(np.mean(lcr)),
+            'trajectories_aggregated': int(agg['count']),
             'failed_trajectories_rank0': int((~ok).sum()),
         }
     if rank == 0 and not args.no_mt6:

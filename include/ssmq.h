@@ -242,6 +242,28 @@ int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, s
                            double *d_fP, double *d_sm, double *d_sP, int32_t *d_status);
 
 /*
+ * Error statistics of B filtered trajectories against the true states, summed over the Monte-Carlo axis on the device
+ * (utils.py:18-38 squared_error, :41-64 mse_matrix, :123-148 neg_log_likelihood; aggregated per time step as
+ * research/tpq/tpq_base.py:154-160 does).  d_x, d_fm [T][D][ld], d_fP [T][D*D][ld] (the filter's output buffers),
+ * d_status [ld] or NULL (nonzero = trajectory excluded).  sums: host [T][W], W = ssmq_error_sums_width(D) = D*D+D+4:
+ *   se[D] sum (x-m)^2 | rmse sum ||x-m|| | nll sum | mse[D*D] sum (x-m)(x-m)' | n_ok | n_pd
+ * n_ok = trajectories counted, n_pd = those whose P at this step is positive definite (only they enter the nll sum; the
+ * reference's slogdet formula has no meaning otherwise).  Sums, not means: ranks add them (one all-reduce) before
+ * dividing.  Deterministic summation order.  Synchronous.
+ */
+int ssmq_error_sums_width(int D);
+int ssmq_error_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm, const double *d_fP,
+                        const int32_t *d_status, double *sums);
+/*
+ * Second phase: sums of the log credibility ratio 10 (log10 dx'P^-1 dx - log10 dx'M^-1 dx) (utils.py:66-120) against
+ * the GLOBAL per-step MSE matrices mse [T][D*D] (host; regularisation, e.g. + 1e-6 I of research/tpq/tpq_base.py:161,
+ * already added).  sums: host [T][2] = lcr sum | n counted (status 0 and P positive definite; the reference's SVD
+ * fallback for an indefinite P, utils.py:426-432, is not reproduced - such trajectories are left out and counted out).
+ */
+int ssmq_lcr_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm, const double *d_fP,
+                      const int32_t *d_status, const double *mse, double *sums);
+
+/*
  * Forward pass of a Studentian filter (ssinf.py:555-736: StudentianInference._time_update / _measurement_update) for B
  * trajectories.  Same loop as ssmq_filter_forward_dev with the reference's scale-matrix bookkeeping:
  *   transforms are fed the SCALE matrix; scale[k] * cov_f (+ G q_smat G') and scale[k] * (cov_f, cov_fx) (+ r_smat)

@@ -686,3 +686,83 @@ def rts_smoother(fm, fP, pm, pP, pC):
         Ps = fP[..., k - 1] + gain.dot(Ps - pP[..., k]).dot(gain.T)
         sm[:, k - 1], sP[..., k - 1] = ms, Ps
     return sm, sP
+
+
+# --------------------------------------------------------------------------------------------------------------
+# performance metrics (utils.py:18-148) and their Monte-Carlo aggregation (research/tpq/tpq_base.py:154-172)
+# --------------------------------------------------------------------------------------------------------------
+
+def squared_error(x, m):
+    """utils.py:18-38."""
+    return (x - m) ** 2
+
+
+def mse_matrix(x, m):
+    """Sample mean-square-error matrix of one time step.  utils.py:41-64.  x, m: (D, M)."""
+    dx = x - m
+    return dx.dot(dx.T) / m.shape[1]
+
+
+def neg_log_likelihood(x, m, P):
+    """utils.py:123-148 (sign * logdet of slogdet, explicit inverse)."""
+    dx = x - m
+    sign, logdet = np.linalg.slogdet(P)
+    return 0.5 * (sign * logdet + dx.dot(np.linalg.inv(P)).dot(dx) + x.shape[0] * np.log(2 * np.pi))
+
+
+def mat_sqrt(a):
+    """Cholesky factor, or u sqrt(s) from an SVD when `a` is not positive definite.  utils.py:412-433."""
+    try:
+        return np.linalg.cholesky(a)
+    except np.linalg.LinAlgError:
+        u, sv, _ = np.linalg.svd(a)
+        return u.dot(np.diag(np.sqrt(sv)))
+
+
+def log_cred_ratio(x, m, P, mse):
+    """utils.py:66-120."""
+    dx = x - m
+    a = np.linalg.solve(mat_sqrt(P), dx)
+    b = np.linalg.solve(mat_sqrt(mse), dx)
+    return 10 * (np.log10(a.dot(a)) - np.log10(b.dot(b)))
+
+
+def error_sums(x, fm, fP, ok=None):
+    """Per-time-step SUMS over the trajectories with ok[b] (the quantities research/tpq/tpq_base.py:154-160 averages):
+    x, fm (D, T, B); fP (D, D, T, B).  Returns dict se (T, D), rmse (T,), nll (T,), mse (T, D, D), n_ok (T,), n_pd (T,)
+    - the layout of ssmq_error_sums_dev.  The nll sum runs over positive-definite P only."""
+    D, T, B = fm.shape
+    ok = np.ones(B, dtype=bool) if ok is None else np.asarray(ok, dtype=bool)
+    se, rmse, nll, mse = np.zeros((T, D)), np.zeros(T), np.zeros(T), np.zeros((T, D, D))
+    n_ok, n_pd = np.zeros(T), np.zeros(T)
+    for k in range(T):
+        for b in np.flatnonzero(ok):
+            dx = x[:, k, b] - fm[:, k, b]
+            se[k] += squared_error(x[:, k, b], fm[:, k, b])
+            rmse[k] += np.sqrt(dx.dot(dx))
+            mse[k] += np.outer(dx, dx)
+            n_ok[k] += 1
+            try:
+                np.linalg.cholesky(fP[..., k, b])
+            except np.linalg.LinAlgError:
+                continue
+            nll[k] += neg_log_likelihood(x[:, k, b], fm[:, k, b], fP[..., k, b])
+            n_pd[k] += 1
+    return dict(se=se, rmse=rmse, nll=nll, mse=mse, n_ok=n_ok, n_pd=n_pd)
+
+
+def lcr_sums(x, fm, fP, mse_global, ok=None):
+    """Per-time-step sums of the log credibility ratio against the given (T, D, D) MSE matrices, over trajectories with
+    ok[b] and positive-definite P (layout of ssmq_lcr_sums_dev): dict lcr (T,), n (T,)."""
+    D, T, B = fm.shape
+    ok = np.ones(B, dtype=bool) if ok is None else np.asarray(ok, dtype=bool)
+    lcr, n = np.zeros(T), np.zeros(T)
+    for k in range(T):
+        for b in np.flatnonzero(ok):
+            try:
+                np.linalg.cholesky(fP[..., k, b])
+            except np.linalg.LinAlgError:
+                continue
+            lcr[k] += log_cred_ratio(x[:, k, b], fm[:, k, b], fP[..., k, b], mse_global[k])
+            n[k] += 1
+    return dict(lcr=lcr, n=n)

@@ -117,6 +117,11 @@ _PROTOTYPES = {
                                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                        c_double_p, c_double_p, c_double_p, ctypes.c_double,
                                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'ssmq_error_sums_width': (ctypes.c_int, [ctypes.c_int]),
+    'ssmq_error_sums_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p]),
+    'ssmq_lcr_sums_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p]),
     'ssmq_filter_kernel_name': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
                                                ctypes.POINTER(Integrand), ctypes.c_char_p, ctypes.c_int]),
 }

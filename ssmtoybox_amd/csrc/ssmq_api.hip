@@ -1028,6 +1028,55 @@ extern "C" int ssmq_student_filter_forward_dev(ssmq_transform *h_dyn, const ssmq
                                scale, dof);
 }
 
+namespace ssmq {
+int metrics_values_per_step(int D);
+int metrics_chunks(int64_t B);
+int launch_metrics(int phase, int D, int64_t B, int64_t ld, int T, const double *x, const double *fm, const double *fP,
+                   const int32_t *status, const double *mse, double *partial, double *out, hipStream_t s);
+}
+
+static int metrics_impl(int phase, int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm,
+                        const double *d_fP, const int32_t *d_status, const double *mse, double *sums) {
+    if (D < 1 || D > SSMQ_MAX_DIM || B < 0 || ld < B || T < 0 || !d_x || !d_fm || !d_fP || !sums || (phase == 2 && !mse)) {
+        set_error("error_sums: bad argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int NV = phase == 1 ? metrics_values_per_step(D) : 2;
+    if (T == 0) return SSMQ_OK;
+    if (B == 0) {
+        memset(sums, 0, sizeof(double) * (size_t)T * NV);
+        return SSMQ_OK;
+    }
+    hipStream_t s = stream();
+    DevBuf partial, out, dm;
+    if ((rc = partial.alloc(sizeof(double) * (size_t)T * metrics_chunks(B) * NV)) ||
+        (rc = out.alloc(sizeof(double) * (size_t)T * NV)) || (rc = dm.alloc(sizeof(double) * (size_t)T * D * D)))
+        return rc;
+    if (phase == 2) SSMQ_HIP(hipMemcpyAsync(dm.p, mse, sizeof(double) * (size_t)T * D * D, hipMemcpyHostToDevice, s));
+    rc = launch_metrics(phase, D, B, ld, T, d_x, d_fm, d_fP, d_status, dm.d(), partial.d(), out.d(), s);
+    if (rc) {
+        hipStreamSynchronize(s);
+        return rc;
+    }
+    SSMQ_HIP(hipMemcpyAsync(sums, out.p, sizeof(double) * (size_t)T * NV, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    return SSMQ_OK;
+}
+
+extern "C" int ssmq_error_sums_width(int D) { return D >= 1 && D <= SSMQ_MAX_DIM ? metrics_values_per_step(D) : SSMQ_E_ARG; }
+
+extern "C" int ssmq_error_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm,
+                                   const double *d_fP, const int32_t *d_status, double *sums) {
+    return metrics_impl(1, D, B, ld, T, d_x, d_fm, d_fP, d_status, nullptr, sums);
+}
+
+extern "C" int ssmq_lcr_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm,
+                                 const double *d_fP, const int32_t *d_status, const double *mse, double *sums) {
+    return metrics_impl(2, D, B, ld, T, d_x, d_fm, d_fP, d_status, mse, sums);
+}
+
 extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,
                                        const ssmq_transform *h_obs, const ssmq_integrand *f_obs, char *buf, int len) {
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || !buf || len <= 0) return SSMQ_E_ARG;

@@ -4,13 +4,18 @@ error sums - the only collective of the path.
 
 Trajectories never interact inside the moment-transform / filter path (the reference loops `for imc in range(mc)`,
 research/tpq/tpq_base.py:187-189), so each rank owns a contiguous slice of the MC index and no data-path collective
-exists.  Phase 1 all-reduces per-time-step sums (squared error, RMSE, NLL, MSE matrix, count); phase 2 - only if the
+exists.  Phase 1 all-reduces per-time-step sums (squared error, RMSE, NLL, MSE matrix, counts) that a reduction kernel
+produced from the filter's own output buffers; phase 2 - only if the
 log-credibility ratio is wanted, because it needs the GLOBAL MSE matrix per step (utils.py:113-120 via
 research/tpq/tpq_base.py:167-169) - all-reduces the LCR sums.  Messages are a few KB: latency-bound, one fused
 all-reduce per phase.  `dist` is `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
 tests) or None for a single process.
 """
+import ctypes
+
 import numpy as np
+
+from . import _lib
 
 
 def shard_bounds(total, rank, world):
@@ -20,24 +25,34 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def local_error_sums(x_true, fm, fP, ok=None):
-    """Per-time-step sums over this rank's trajectories.
-    x_true, fm: (D, T, B); fP: (D, D, T, B); ok: (B,) bool mask of trajectories that did not fail.
+def device_error_sums(D, B, ld, T, d_x, d_fm, d_fP, d_status=None):
+    """Phase-1 sums of this rank's trajectories, reduced on the device (`ssmq_error_sums_dev`).
+    d_x, d_fm: DeviceBuffer planes [T][D][ld]; d_fP [T][D*D][ld] (the buffers the filter wrote); d_status [ld] or None.
     Returns a dict of arrays: se (T, D) squared error (utils.py:18-38), rmse (T,) sum of ||x - m|| (the quantity
     research/tpq/tpq_base.py:158-159 averages), nll (T,) negative log-likelihood (utils.py:123-148), mse (T, D, D) outer
-    products (utils.py:41-64), count ()."""
-    D, T, B = fm.shape
-    ok = np.ones(B, dtype=bool) if ok is None else np.asarray(ok, dtype=bool)
-    dx = (x_true - fm)[:, :, ok]                                   # (D, T, b)
-    P = fP[:, :, :, ok].transpose(2, 3, 0, 1)                      # (T, b, D, D)
-    se = (dx ** 2).sum(axis=2).T
-    rmse = np.sqrt((dx ** 2).sum(axis=0)).sum(axis=1)
-    mse = np.einsum('itb,jtb->tij', dx, dx)
-    d = dx.transpose(1, 2, 0)                                      # (T, b, D)
-    sol = np.linalg.solve(P, d[..., None])[..., 0]
-    sign, logdet = np.linalg.slogdet(P)
-    nll = (0.5 * (sign * logdet + (d * sol).sum(axis=-1) + D * np.log(2 * np.pi))).sum(axis=1)
-    return dict(se=se, rmse=rmse, nll=nll, mse=mse, count=np.array(float(ok.sum())))
+    products (utils.py:41-64), n_ok (T,) trajectories counted, n_pd (T,) of them with positive-definite P (nll terms)."""
+    lib = _lib.load()
+    W = lib.ssmq_error_sums_width(D)
+    sums, ps = _lib.out_c((T, W))
+    _lib.check(lib.ssmq_error_sums_dev(D, B, ld, T, ctypes.c_void_p(d_x.ptr), ctypes.c_void_p(d_fm.ptr),
+                                       ctypes.c_void_p(d_fP.ptr), ctypes.c_void_p(d_status.ptr if d_status else None),
+                                       ps), 'ssmq_error_sums_dev')
+    return dict(se=sums[:, :D].copy(), rmse=sums[:, D].copy(), nll=sums[:, D + 1].copy(),
+                mse=sums[:, D + 2:D + 2 + D * D].reshape(T, D, D).copy(), n_ok=sums[:, D + 2 + D * D].copy(),
+                n_pd=sums[:, D + 3 + D * D].copy())
+
+
+def device_lcr_sums(D, B, ld, T, d_x, d_fm, d_fP, mse_global, d_status=None, reg=1e-6):
+    """Phase 2 (`ssmq_lcr_sums_dev`): sums over this rank's trajectories of the log credibility ratio (utils.py:66-120)
+    per time step, given the GLOBAL MSE matrices (T, D, D) (+ reg I as research/tpq/tpq_base.py:161-167 does).
+    Returns dict lcr (T,), n (T,)."""
+    lib = _lib.load()
+    M, pM = _lib.as_c(np.asarray(mse_global, dtype=np.float64) + reg * np.eye(D))
+    sums, ps = _lib.out_c((T, 2))
+    _lib.check(lib.ssmq_lcr_sums_dev(D, B, ld, T, ctypes.c_void_p(d_x.ptr), ctypes.c_void_p(d_fm.ptr),
+                                     ctypes.c_void_p(d_fP.ptr), ctypes.c_void_p(d_status.ptr if d_status else None),
+                                     pM, ps), 'ssmq_lcr_sums_dev')
+    return dict(lcr=sums[:, 0].copy(), n=sums[:, 1].copy())
 
 
 def _pack(sums, keys):
@@ -68,21 +83,15 @@ def allreduce_sums(sums, dist=None, device=None):
 
 
 def finalize(total):
-    """Global averages from all-reduced sums: rmse_avg (T,), nll_avg (T,), mse (T, D, D), rmse_total ()."""
-    n = max(float(total['count']), 1.0)
+    """Global averages from all-reduced phase-1 sums: rmse_avg (T,), nll_avg (T,), mse (T, D, D), rmse_total (),
+    count () trajectories aggregated."""
+    n = np.maximum(total['n_ok'], 1.0)
     T = total['rmse'].shape[0]
-    return dict(rmse_avg=total['rmse'] / n, nll_avg=total['nll'] / n, mse=total['mse'] / n,
-                rmse_total=float(np.sqrt(total['se'].sum() / (n * T))), count=n)
+    return dict(rmse_avg=total['rmse'] / n, nll_avg=total['nll'] / np.maximum(total['n_pd'], 1.0),
+                mse=total['mse'] / n[:, None, None], rmse_total=float(np.sqrt(total['se'].sum() / max(total['n_ok'].sum(), 1.0))),
+                count=float(total['n_ok'].max()) if T else 0.0)
 
 
-def local_lcr_sums(x_true, fm, fP, mse_global, ok=None, reg=1e-6):
-    """Phase 2: sums over this rank's trajectories of the log credibility ratio (utils.py:66-120) per time step, given the
-    global MSE matrices (+ reg I as research/tpq/tpq_base.py:161-167 does).  Returns dict(lcr (T,))."""
-    D, T, B = fm.shape
-    ok = np.ones(B, dtype=bool) if ok is None else np.asarray(ok, dtype=bool)
-    dx = (x_true - fm)[:, :, ok].transpose(1, 2, 0)                # (T, b, D)
-    P = fP[:, :, :, ok].transpose(2, 3, 0, 1)
-    M = mse_global + reg * np.eye(D)
-    a = (dx * np.linalg.solve(P, dx[..., None])[..., 0]).sum(axis=-1)
-    b = (dx * np.linalg.solve(M[:, None], dx[..., None])[..., 0]).sum(axis=-1)
-    return dict(lcr=(10 * (np.log10(a) - np.log10(b))).sum(axis=1))
+def finalize_lcr(total):
+    """Average log credibility ratio per time step (the inclination indicator's summand) from all-reduced phase-2 sums."""
+    return total['lcr'] / np.maximum(total['n'], 1.0)

@@ -428,8 +428,36 @@ def g6_nonadditive():
     save('g6_nonadditive', **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G7: performance metrics (utils.py:18-148) on filter-shaped data, aggregated as research/tpq/tpq_base.py:154-172 does
+# ---------------------------------------------------------------------------------------------------------------
+def g7_metrics():
+    from ssmtoybox.utils import squared_error, mse_matrix, log_cred_ratio, neg_log_likelihood
+    out = {}
+    rng = np.random.default_rng(7)
+    for tag, D, T, M in (('d1', 1, 100, 8), ('d3', 3, 12, 16), ('d6', 6, 5, 24)):
+        x = rng.standard_normal((D, T, M)) * 3.0
+        m = x + rng.standard_normal((D, T, M)) * 0.7
+        a = rng.standard_normal((D, D, T, M)) / np.sqrt(D)
+        P = np.einsum('ijtm,kjtm->iktm', a, a) + 0.3 * np.eye(D)[:, :, None, None]
+        se = squared_error(x, m)
+        mse = np.empty((D, D, T))
+        nll, lcr = np.empty((T, M)), np.empty((T, M))
+        reg = 1e-6 * np.eye(D)
+        for k in range(T):
+            mse[..., k] = mse_matrix(x[:, k, :], m[:, k, :])
+            for i in range(M):
+                nll[k, i] = neg_log_likelihood(x[:, k, i], m[:, k, i], P[..., k, i])
+                lcr[k, i] = log_cred_ratio(x[:, k, i], m[:, k, i], P[..., k, i], mse[..., k] + reg)
+        rmse = np.sqrt(((x - m) ** 2).sum(axis=0))        # tpq_base.py:158
+        for key, val in (('x', x), ('m', m), ('P', P), ('se', se), ('mse', mse), ('nll', nll), ('lcr', lcr),
+                         ('rmse', rmse)):
+            out[tag + '_' + key] = val
+    save('g7_metrics', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
     if 'g1' in which:
         g1_points()
     if 'g2' in which:
@@ -442,3 +470,5 @@ if __name__ == '__main__':
         g5_student()
     if 'g6' in which:
         g6_nonadditive()
+    if 'g7' in which:
+        g7_metrics()

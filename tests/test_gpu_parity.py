@@ -412,6 +412,113 @@ def test_ctrs_radar_ukf_golden(amd, golden):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# error statistics reduced on the device (utils.py:18-148 aggregated as research/tpq/tpq_base.py:154-172)
+# ---------------------------------------------------------------------------------------------------------------
+def _planes(a, ld):
+    """(D, T, B) or (D, D, T, B) -> DeviceBuffer of planes [T][D..][ld]."""
+    from ssmtoybox_amd import _lib
+    B = a.shape[-1]
+    t_ax = a.ndim - 2
+    src = np.moveaxis(a, t_ax, 0).reshape(a.shape[t_ax], -1, B)
+    buf = np.zeros((src.shape[0], src.shape[1], ld))
+    buf[:, :, :B] = src
+    d = _lib.DeviceBuffer(buf.nbytes)
+    d.upload(buf)
+    return d
+
+
+@pytest.mark.parametrize('tag', ['d1', 'd3', 'd6'])
+def test_error_sums_golden(amd, golden, tag):
+    from ssmtoybox_amd import mcshard, _lib
+    g = golden('g7_metrics')
+    x, m, P = g[tag + '_x'], g[tag + '_m'], g[tag + '_P']
+    D, T, M = m.shape
+    ld = 64
+    d_x, d_m, d_P = _planes(x, ld), _planes(m, ld), _planes(P, ld)
+    s1 = mcshard.device_error_sums(D, M, ld, T, d_x, d_m, d_P)
+    assert np.allclose(s1['se'], g[tag + '_se'].sum(axis=2).T, rtol=1e-12)
+    assert np.allclose(s1['rmse'], g[tag + '_rmse'].sum(axis=1), rtol=1e-12)
+    assert np.allclose(s1['nll'], g[tag + '_nll'].sum(axis=1), rtol=1e-11)
+    assert np.allclose(s1['mse'] / M, g[tag + '_mse'].transpose(2, 0, 1), rtol=1e-11, atol=1e-13)
+    assert np.all(s1['n_ok'] == M) and np.all(s1['n_pd'] == M)
+    s2 = mcshard.device_lcr_sums(D, M, ld, T, d_x, d_m, d_P, s1['mse'] / M)
+    assert np.allclose(s2['lcr'], g[tag + '_lcr'].sum(axis=1), rtol=1e-9, atol=1e-9) and np.all(s2['n'] == M)
+    # status mask: trajectory 1 failed in the filter -> left out of every sum, as the oracle does
+    st = np.zeros(ld, dtype=np.int32)
+    st[1] = 3
+    d_st = _lib.DeviceBuffer(st.nbytes)
+    d_st.upload(st)
+    ok = st[:M] == 0
+    s3, o3 = mcshard.device_error_sums(D, M, ld, T, d_x, d_m, d_P, d_st), orc.error_sums(x, m, P, ok)
+    for k in ('se', 'rmse', 'nll', 'mse', 'n_ok', 'n_pd'):
+        assert np.allclose(s3[k], o3[k], rtol=1e-11, atol=1e-12), k
+    for buf in (d_x, d_m, d_P, d_st):
+        buf.free()
+
+
+def test_error_sums_large_batch_properties(amd):
+    """Size-independent checks at a ragged B that spans several reduction chunks: additivity over a split of the batch,
+    indefinite covariances counted out, determinism."""
+    from ssmtoybox_amd import mcshard
+    rng = np.random.default_rng(11)
+    D, T, B = 5, 3, 5003
+    ld = (B + 63) // 64 * 64
+    x = rng.standard_normal((D, T, B))
+    m = x + 0.5 * rng.standard_normal((D, T, B))
+    a = rng.standard_normal((D, D, T, B)) / np.sqrt(D)
+    P = np.einsum('ijtb,kjtb->iktb', a, a) + 0.2 * np.eye(D)[:, :, None, None]
+    bad = rng.choice(B, 17, replace=False)
+    P[..., 1, bad] = -np.eye(D)[:, :, None]
+    d_x, d_m, d_P = _planes(x, ld), _planes(m, ld), _planes(P, ld)
+    s = mcshard.device_error_sums(D, B, ld, T, d_x, d_m, d_P)
+    s_again = mcshard.device_error_sums(D, B, ld, T, d_x, d_m, d_P)
+    assert all(np.array_equal(s[k], s_again[k]) for k in s)
+    assert np.array_equal(s['n_pd'], [B, B - 17, B]) and np.all(s['n_ok'] == B)
+    dx = x - m
+    assert np.allclose(s['se'], (dx ** 2).sum(axis=2).T, rtol=1e-12)
+    assert np.allclose(s['mse'], np.einsum('itb,jtb->tij', dx, dx), rtol=1e-11, atol=1e-9)
+    sample = rng.choice(B, 40, replace=False)
+    o = orc.error_sums(x[..., sample], m[..., sample], P[..., sample])
+    dd = [_planes(v[..., sample], 64) for v in (x, m, P)]
+    ssub = mcshard.device_error_sums(D, 40, 64, T, *dd)
+    for k in o:
+        assert np.allclose(ssub[k], o[k], rtol=1e-11, atol=1e-12), k
+    # additivity: sums of two halves (separate launches over sub-batches) = sums of the whole
+    h = 2500
+    d1 = [_planes(v[..., :h], (h + 63) // 64 * 64) for v in (x, m, P)]
+    d2 = [_planes(v[..., h:], (B - h + 63) // 64 * 64) for v in (x, m, P)]
+    sa = mcshard.device_error_sums(D, h, (h + 63) // 64 * 64, T, *d1)
+    sb = mcshard.device_error_sums(D, B - h, (B - h + 63) // 64 * 64, T, *d2)
+    for k in s:
+        assert np.allclose(sa[k] + sb[k], s[k], rtol=1e-12, atol=1e-12), k
+    mse = s['mse'] / B
+    l_all = mcshard.device_lcr_sums(D, B, ld, T, d_x, d_m, d_P, mse)
+    la = mcshard.device_lcr_sums(D, h, (h + 63) // 64 * 64, T, *d1, mse)
+    lb = mcshard.device_lcr_sums(D, B - h, (B - h + 63) // 64 * 64, T, *d2, mse)
+    assert np.allclose(la['lcr'] + lb['lcr'], l_all['lcr'], rtol=1e-11) and np.array_equal(l_all['n'], [B, B - 17, B])
+    osub = orc.lcr_sums(x[..., sample], m[..., sample], P[..., sample], mse + 1e-6 * np.eye(D))
+    lsub = mcshard.device_lcr_sums(D, 40, 64, T, *dd, mse)
+    assert np.allclose(lsub['lcr'], osub['lcr'], rtol=1e-10) and np.array_equal(lsub['n'], osub['n'])
+
+
+def test_error_sums_generic_dimension(amd):
+    """D = 10 takes the run-time-sized kernel."""
+    from ssmtoybox_amd import mcshard
+    rng = np.random.default_rng(12)
+    D, T, B = 10, 2, 70
+    x = rng.standard_normal((D, T, B))
+    m = x + 0.5 * rng.standard_normal((D, T, B))
+    a = rng.standard_normal((D, D, T, B)) / np.sqrt(D)
+    P = np.einsum('ijtb,kjtb->iktb', a, a) + 0.2 * np.eye(D)[:, :, None, None]
+    dd = [_planes(v, 128) for v in (x, m, P)]
+    s, o = mcshard.device_error_sums(D, B, 128, T, *dd), orc.error_sums(x, m, P)
+    for k in o:
+        assert np.allclose(s[k], o[k], rtol=1e-11, atol=1e-12), k
+    l, ol = mcshard.device_lcr_sums(D, B, 128, T, *dd, s['mse'] / B), orc.lcr_sums(x, m, P, s['mse'] / B + 1e-6 * np.eye(D))
+    assert np.allclose(l['lcr'], ol['lcr'], rtol=1e-10) and np.array_equal(l['n'], ol['n'])
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # full-size batches (BASELINE.json configs): oracle on a sample + size-independent properties
 # ---------------------------------------------------------------------------------------------------------------
 def synthetic_reentry6(B, seed=2):

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: MC trajectories sharded over 2 ranks (gloo), error sums all-reduced, against the single-process
-result.  The per-rank filter here is the C oracle (no GPU in this test); what is under test is the sharding and the
-two-phase aggregation that bench.py uses unchanged with backend nccl (RCCL)."""
+result.  The per-rank filter and the per-rank error sums come from the oracle here (no GPU in this test; on the GPU box
+they are `ssmq_filter_forward_dev` and `ssmq_error_sums_dev` / `ssmq_lcr_sums_dev`); what is under test is the sharding
+and the two-phase aggregation that bench.py uses unchanged with backend nccl (RCCL)."""
 import os
 import socket
 
@@ -41,12 +42,13 @@ def _worker(rank, world, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import ssmq_oracle as orc
     x, fm, fP, ok = _study()
     lo, hi = mcshard.shard_bounds(fm.shape[2], rank, world)
-    loc = mcshard.local_error_sums(x[..., lo:hi], fm[..., lo:hi], fP[..., lo:hi], ok[lo:hi])
+    loc = orc.error_sums(x[..., lo:hi], fm[..., lo:hi], fP[..., lo:hi], ok[lo:hi])
     tot = mcshard.finalize(mcshard.allreduce_sums(loc, dist))
-    lcr = mcshard.allreduce_sums(mcshard.local_lcr_sums(x[..., lo:hi], fm[..., lo:hi], fP[..., lo:hi], tot['mse'],
-                                                        ok[lo:hi]), dist)
+    lcr = mcshard.allreduce_sums(orc.lcr_sums(x[..., lo:hi], fm[..., lo:hi], fP[..., lo:hi],
+                                              tot['mse'] + 1e-6 * np.eye(fm.shape[0]), ok[lo:hi]), dist)
     if rank == 0:
         q.put((tot, lcr))
     dist.barrier()
@@ -55,14 +57,15 @@ def _worker(rank, world, port, q):
 
 def test_two_rank_aggregation_matches_single_process():
     import torch.multiprocessing as mp
+    from oracle import ssmq_oracle as orc
     x, fm, fP, ok = _study()
-    ref = mcshard.finalize(mcshard.local_error_sums(x, fm, fP, ok))
-    ref_lcr = mcshard.local_lcr_sums(x, fm, fP, ref['mse'], ok)
+    ref = mcshard.finalize(orc.error_sums(x, fm, fP, ok))
+    ref_lcr = orc.lcr_sums(x, fm, fP, ref['mse'] + 1e-6 * np.eye(fm.shape[0]), ok)
     # direct formulas of the reference's metrics on the same data (utils.py:18-148)
     assert np.isclose(ref['rmse_avg'][5], np.mean(np.sqrt(((x - fm) ** 2).sum(axis=0))[5]))
     d = (x - fm)[0, 7, 0]
     p = fP[0, 0, 7, 0]
-    assert np.isclose(mcshard.local_error_sums(x[..., :1], fm[..., :1], fP[..., :1])['nll'][7],
+    assert np.isclose(orc.error_sums(x[..., :1], fm[..., :1], fP[..., :1])['nll'][7],
                       0.5 * (np.log(p) + d * d / p + np.log(2 * np.pi)))
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -80,4 +83,5 @@ def test_two_rank_aggregation_matches_single_process():
     for k in ('rmse_avg', 'nll_avg', 'mse'):
         assert np.allclose(tot[k], ref[k], rtol=1e-12, atol=1e-12), k
     assert np.isclose(tot['rmse_total'], ref['rmse_total'], rtol=1e-12) and tot['count'] == ref['count']
-    assert np.allclose(lcr['lcr'], ref_lcr['lcr'], rtol=1e-10, atol=1e-10)
+    assert np.allclose(lcr['lcr'], ref_lcr['lcr'], rtol=1e-10, atol=1e-10) and np.array_equal(lcr['n'], ref_lcr['n'])
+    assert mcshard.finalize_lcr(lcr).shape == (fm.shape[1],)
