@@ -8,7 +8,9 @@
 // trajectory per lane - so each thread streams its trajectory's D + D + D*D doubles of a time step with 512-B wave
 // accesses and nothing is copied to the host except [T][NV] sums.  Reduction order is fixed (thread-serial over a
 // strided slice, wave shuffle tree, LDS across waves, then a second kernel over the partials in index order): results
-// are deterministic and independent of launch timing.  HBM-bound: 8 (2 D + D^2) bytes per trajectory and step.
+// are deterministic and independent of launch timing.  HBM-bound: algorithmic 8 (2 D + D^2) bytes per trajectory and
+// step; the kernels move 8 (2 D + D (D + 1) / 2) - only the lower triangle of P is read (the Cholesky factor needs no
+// more, as LAPACK 'L' under the filters) and only the lower triangle of the outer products is accumulated.
 #include "ssmq_host.h"
 
 namespace ssmq {
@@ -85,15 +87,97 @@ struct MetArgs {
     int32_t D, T, chunks;
 };
 
-// phase 1 values per time step: se[D] | rmse | nll | mse[D*D] | n_ok | n_pd
-template <int DT>
+// block-wide sums with a compile-time count (accumulators stay in registers)
+template <int NV>
+__device__ __forceinline__ void block_sums_fixed(const double (&acc)[NV], double *sh, double *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const double s = wave_sum(acc[v]);
+        if (lane == 0) sh[wave * NV + v] = s;
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < NV; v += kMetBlock) {
+        double s = 0.0;
+        for (int w = 0; w < kMetBlock / 64; ++w) s += sh[w * NV + v];
+        out[v] = s;
+    }
+}
+
+// |L^-1 dx|^2 with L packed lower
+template <int D>
+__device__ __forceinline__ double whitened_norm2_packed(const double (&L)[D * (D + 1) / 2], const double (&dx)[D]) {
+    double v[D];
+    double q = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double s = dx[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[SSMQ_PK(i, k)] * v[k];
+        v[i] = s / L[SSMQ_PK(i, i)];
+        q += v[i] * v[i];
+    }
+    return q;
+}
+
+// phase 1 values per time step (output): se[D] | rmse | nll | mse[D*D] | n_ok | n_pd.
+// Compile-time D: accumulators se[D], rmse, nll, lower triangle of the outer products, two counts - all in registers;
+// the partial row is written in the packed order and expanded by k_reduce_partials.
+template <int D>
 __global__ __launch_bounds__(kMetBlock) void k_error_sums(MetArgs a) {
-    const int D = DT > 0 ? DT : a.D;
-    const int NV = met_nv(D);
+    constexpr int TRI = D * (D + 1) / 2, NA = D + 2 + TRI + 2;
     const int t = blockIdx.y;
     extern __shared__ double sh[];
-    double acc[DT > 0 ? met_nv(DT) : met_nv(kMetMaxD)];
-    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    double acc[NA];
+#pragma unroll
+    for (int v = 0; v < NA; ++v) acc[v] = 0.0;
+    const double *x = a.x + (int64_t)t * D * a.ld, *fm = a.fm + (int64_t)t * D * a.ld;
+    const double *fP = a.fP + (int64_t)t * D * D * a.ld;
+    // 32-bit lane index against wave-uniform plane pointers: loads take the (SGPR base + VGPR offset) form and no
+    // 64-bit address is kept per plane
+    const uint32_t base = blockIdx.x * (uint32_t)(kMetBlock * kMetPerThread) + threadIdx.x;
+    for (int r = 0; r < kMetPerThread; ++r) {
+        const uint32_t b = base + (uint32_t)r * kMetBlock;
+        if ((int64_t)b >= a.B) break;
+        if (a.status && a.status[b] != 0) continue;
+        double dx[D], L[TRI];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) L[SSMQ_PK(i, j)] = fP[((int64_t)i * D + j) * a.ld + b];
+        double n2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            dx[d] = x[(int64_t)d * a.ld + b] - fm[(int64_t)d * a.ld + b];
+            acc[d] += dx[d] * dx[d];
+            n2 += dx[d] * dx[d];
+        }
+        acc[D] += sqrt(n2);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) acc[D + 2 + SSMQ_PK(i, j)] += dx[i] * dx[j];
+        acc[D + 2 + TRI] += 1.0;
+        // negative log-likelihood (utils.py:143-148) for positive-definite P: log det = 2 sum log L_ii
+        if (chol_packed<D>(L)) {
+            double logdet = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) logdet += log(L[SSMQ_PK(i, i)]);
+            const double q = whitened_norm2_packed<D>(L, dx);
+            acc[D + 1] += 0.5 * (2.0 * logdet + q + D * 1.8378770664093453 /* log(2 pi) */);
+            acc[D + 3 + TRI] += 1.0;
+        }
+    }
+    block_sums_fixed<NA>(acc, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * NA);
+}
+
+// run-time D (> 6): dense arrays in scratch, same packed partial row
+__global__ __launch_bounds__(kMetBlock) void k_error_sums_generic(MetArgs a) {
+    const int D = a.D, TRI = D * (D + 1) / 2, NA = D + 2 + TRI + 2;
+    const int t = blockIdx.y;
+    extern __shared__ double sh[];
+    double acc[kMetMaxD + 2 + kMetMaxD * (kMetMaxD + 1) / 2 + 2];
+    for (int v = 0; v < NA; ++v) acc[v] = 0.0;
     const double *x = a.x + (int64_t)t * D * a.ld, *fm = a.fm + (int64_t)t * D * a.ld;
     const double *fP = a.fP + (int64_t)t * D * D * a.ld;
     const int64_t base = (int64_t)blockIdx.x * kMetBlock * kMetPerThread;
@@ -101,7 +185,7 @@ __global__ __launch_bounds__(kMetBlock) void k_error_sums(MetArgs a) {
         const int64_t b = base + (int64_t)r * kMetBlock + threadIdx.x;
         if (b >= a.B) break;
         if (a.status && a.status[b] != 0) continue;
-        double dx[DT > 0 ? DT : kMetMaxD], P[DT > 0 ? DT * DT : kMetMaxD * kMetMaxD];
+        double dx[kMetMaxD], P[kMetMaxD * kMetMaxD];
         double n2 = 0.0;
         for (int d = 0; d < D; ++d) {
             dx[d] = x[(int64_t)d * a.ld + b] - fm[(int64_t)d * a.ld + b];
@@ -110,72 +194,124 @@ __global__ __launch_bounds__(kMetBlock) void k_error_sums(MetArgs a) {
         }
         acc[D] += sqrt(n2);
         for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) {
-                acc[D + 2 + i * D + j] += dx[i] * dx[j];
+            for (int j = 0; j <= i; ++j) {
+                acc[D + 2 + SSMQ_PK(i, j)] += dx[i] * dx[j];
                 P[i * D + j] = fP[((int64_t)i * D + j) * a.ld + b];
             }
-        acc[D + 2 + D * D] += 1.0;
-        // negative log-likelihood (utils.py:143-148) for positive-definite P: log det = 2 sum log L_ii
-        if (chol_dense<DT>(P, D)) {
+        acc[D + 2 + TRI] += 1.0;
+        if (chol_dense<0>(P, D)) {
             double logdet = 0.0;
             for (int i = 0; i < D; ++i) logdet += log(P[i * D + i]);
-            const double q = whitened_norm2<DT>(P, dx, D);
-            acc[D + 1] += 0.5 * (2.0 * logdet + q + D * 1.8378770664093453 /* log(2 pi) */);
-            acc[D + 3 + D * D] += 1.0;
+            const double q = whitened_norm2<0>(P, dx, D);
+            acc[D + 1] += 0.5 * (2.0 * logdet + q + D * 1.8378770664093453);
+            acc[D + 3 + TRI] += 1.0;
         }
     }
-    block_sums(acc, NV, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * NV);
+    block_sums(acc, NA, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * NA);
 }
 
 // phase 2 values per time step: lcr | n counted
-template <int DT>
+template <int D>
 __global__ __launch_bounds__(kMetBlock) void k_lcr_sums(MetArgs a) {
-    const int D = DT > 0 ? DT : a.D;
+    constexpr int TRI = D * (D + 1) / 2;
     const int t = blockIdx.y;
     extern __shared__ double sh[];
     double acc[2] = {0.0, 0.0};
     const double *x = a.x + (int64_t)t * D * a.ld, *fm = a.fm + (int64_t)t * D * a.ld;
     const double *fP = a.fP + (int64_t)t * D * D * a.ld;
-    // the step's MSE matrix is the same for every trajectory: factor it once per thread from L2 / scalar cache
-    double M[DT > 0 ? DT * DT : kMetMaxD * kMetMaxD];
+    // the step's MSE matrix is the same for every trajectory: wave-uniform loads, factored once per thread
+    double M[TRI];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) M[SSMQ_PK(i, j)] = a.mse[(int64_t)t * D * D + i * D + j];
+    const bool m_ok = chol_packed<D>(M);
+    const uint32_t base = blockIdx.x * (uint32_t)(kMetBlock * kMetPerThread) + threadIdx.x;
+    for (int r = 0; r < kMetPerThread && m_ok; ++r) {
+        const uint32_t b = base + (uint32_t)r * kMetBlock;
+        if ((int64_t)b >= a.B) break;
+        if (a.status && a.status[b] != 0) continue;
+        double dx[D], L[TRI];
+#pragma unroll
+        for (int d = 0; d < D; ++d) dx[d] = x[(int64_t)d * a.ld + b] - fm[(int64_t)d * a.ld + b];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) L[SSMQ_PK(i, j)] = fP[((int64_t)i * D + j) * a.ld + b];
+        if (!chol_packed<D>(L)) continue;      // the reference falls back to an SVD square root here (utils.py:426-432)
+        const double qa = whitened_norm2_packed<D>(L, dx), qb = whitened_norm2_packed<D>(M, dx);
+        acc[0] += 10.0 * (log10(qa) - log10(qb));
+        acc[1] += 1.0;
+    }
+    block_sums_fixed<2>(acc, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * 2);
+}
+
+__global__ __launch_bounds__(kMetBlock) void k_lcr_sums_generic(MetArgs a) {
+    const int D = a.D;
+    const int t = blockIdx.y;
+    extern __shared__ double sh[];
+    double acc[2] = {0.0, 0.0};
+    const double *x = a.x + (int64_t)t * D * a.ld, *fm = a.fm + (int64_t)t * D * a.ld;
+    const double *fP = a.fP + (int64_t)t * D * D * a.ld;
+    double M[kMetMaxD * kMetMaxD];
     for (int i = 0; i < D * D; ++i) M[i] = a.mse[(int64_t)t * D * D + i];
-    const bool m_ok = chol_dense<DT>(M, D);
+    const bool m_ok = chol_dense<0>(M, D);
     const int64_t base = (int64_t)blockIdx.x * kMetBlock * kMetPerThread;
     for (int r = 0; r < kMetPerThread && m_ok; ++r) {
         const int64_t b = base + (int64_t)r * kMetBlock + threadIdx.x;
         if (b >= a.B) break;
         if (a.status && a.status[b] != 0) continue;
-        double dx[DT > 0 ? DT : kMetMaxD], P[DT > 0 ? DT * DT : kMetMaxD * kMetMaxD];
+        double dx[kMetMaxD], P[kMetMaxD * kMetMaxD];
         for (int d = 0; d < D; ++d) dx[d] = x[(int64_t)d * a.ld + b] - fm[(int64_t)d * a.ld + b];
-        for (int i = 0; i < D * D; ++i) P[i] = fP[(int64_t)i * a.ld + b];
-        if (!chol_dense<DT>(P, D)) continue;      // the reference falls back to an SVD square root here (utils.py:426-432)
-        const double qa = whitened_norm2<DT>(P, dx, D), qb = whitened_norm2<DT>(M, dx, D);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j <= i; ++j) P[i * D + j] = fP[((int64_t)i * D + j) * a.ld + b];
+        if (!chol_dense<0>(P, D)) continue;
+        const double qa = whitened_norm2<0>(P, dx, D), qb = whitened_norm2<0>(M, dx, D);
         acc[0] += 10.0 * (log10(qa) - log10(qb));
         acc[1] += 1.0;
     }
     block_sums(acc, 2, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * 2);
 }
 
-// out[t][v] = sum over chunks, in chunk order
-__global__ void k_reduce_partials(const double *partial, double *out, int chunks, int NV, int total) {
+// out[t][v] = sum over chunks, in chunk order.  D > 0: phase-1 rows, partials hold the outer products as a packed
+// lower triangle (NA values per row) and the output row is the full layout of met_nv(D) values.
+__global__ void k_reduce_partials(const double *partial, double *out, int chunks, int NV, int total, int D) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int t = i / NV, v = i % NV;
+    int NA = NV, src = v;
+    if (D > 0) {
+        const int TRI = D * (D + 1) / 2;
+        NA = D + 2 + TRI + 2;
+        if (v >= D + 2 && v < D + 2 + D * D) {
+            const int r = (v - D - 2) / D, c = (v - D - 2) % D;
+            src = D + 2 + (r >= c ? SSMQ_PK(r, c) : SSMQ_PK(c, r));
+        } else if (v >= D + 2 + D * D) {
+            src = v - D * D + TRI;
+        }
+    }
     double s = 0.0;
-    for (int c = 0; c < chunks; ++c) s += partial[((int64_t)t * chunks + c) * NV + v];
+    for (int c = 0; c < chunks; ++c) s += partial[((int64_t)t * chunks + c) * NA + src];
     out[i] = s;
 }
 
 template <int DT>
 hipError_t launch_phase(const MetArgs &a, int phase, hipStream_t s) {
     const int D = DT > 0 ? DT : a.D;
-    const int NV = phase == 1 ? met_nv(D) : 2;
+    const int NV = phase == 1 ? met_nv(D) : 2;       // upper bound of the packed row
     const size_t lds = sizeof(double) * (kMetBlock / 64) * NV;
     dim3 grid((unsigned)a.chunks, (unsigned)a.T);
-    if (phase == 1)
-        hipLaunchKernelGGL(k_error_sums<DT>, grid, dim3(kMetBlock), lds, s, a);
-    else
-        hipLaunchKernelGGL(k_lcr_sums<DT>, grid, dim3(kMetBlock), lds, s, a);
+    if constexpr (DT > 0) {
+        if (phase == 1)
+            hipLaunchKernelGGL(k_error_sums<DT>, grid, dim3(kMetBlock), lds, s, a);
+        else
+            hipLaunchKernelGGL(k_lcr_sums<DT>, grid, dim3(kMetBlock), lds, s, a);
+    } else {
+        if (phase == 1)
+            hipLaunchKernelGGL(k_error_sums_generic, grid, dim3(kMetBlock), lds, s, a);
+        else
+            hipLaunchKernelGGL(k_lcr_sums_generic, grid, dim3(kMetBlock), lds, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -201,7 +337,8 @@ int launch_metrics(int phase, int D, int64_t B, int64_t ld, int T, const double 
     }
     if (e != hipSuccess) return hip_fail(e, phase == 1 ? "k_error_sums" : "k_lcr_sums");
     const int NV = phase == 1 ? met_nv(D) : 2, total = T * NV;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((total + 255) / 256), dim3(256), 0, s, partial, out, a.chunks, NV, total);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((total + 255) / 256), dim3(256), 0, s, partial, out, a.chunks, NV, total,
+                       phase == 1 ? D : 0);
     return hip_fail(hipGetLastError(), "k_reduce_partials");
 }
 
