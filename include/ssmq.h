@@ -242,6 +242,25 @@ int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, s
                            double *d_fP, double *d_sm, double *d_sP, int32_t *d_status);
 
 /*
+ * theta-batched filter step for GP-quadrature transforms whose kernel parameters are re-drawn per item - the inner
+ * evaluation of the marginalised filter (ssinf.py:1117-1151 _state_posterior_moments, :1153-1198 _param_log_likelihood;
+ * re-weighting bq/bqmtran.py:93-95).  For item i = 0..P-1:
+ *   weights(par_dyn[i]) -> dyn transform at `time` (+ GQG) -> weights(par_obs[i]) -> obs transform at `time` (+ R)
+ *   -> Kalman update with y -> post_mean[i][D], post_cov[i][D*D], loglik[i] = log N(y | y_mean, P_y).
+ * h_dyn / h_obs supply shapes, sigma points and the emv mode (their own weights are not used; GP models only, additive
+ * noise).  par_dyn, par_obs: host [P][1+D] = [alpha, ell_1..ell_D] (already exponentiated).  mean [D] / cov [D*D] when
+ * shared_state = 1, else [P][D] / [P][D*D]; y [Y] when shared_y = 1, else [P][Y].  GQG [D*D], R [Y*Y] host or NULL.
+ * status[i] (may be NULL): bit 0 K_dyn not positive definite, bit 1 K_obs, bit 2 cov (Cholesky in the dyn transform),
+ * bit 3 predictive cov, bit 4 P_y.  Returns 0, or 1 + index of the first item with a nonzero status.  Synchronous;
+ * the weights never leave the device (k_weights writes per-item constant blocks that k_apply_wide reads in place).
+ */
+int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                       const ssmq_integrand *f_obs, int64_t P, const double *par_dyn, const double *par_obs,
+                       double jitter, const double *mean, const double *cov, int shared_state, const double *y,
+                       int shared_y, double time, const double *GQG, const double *R, double *post_mean,
+                       double *post_cov, double *loglik, int32_t *status);
+
+/*
  * Error statistics of B filtered trajectories against the true states, summed over the Monte-Carlo axis on the device
  * (utils.py:18-38 squared_error, :41-64 mse_matrix, :123-148 neg_log_likelihood; aggregated per time step as
  * research/tpq/tpq_base.py:154-160 does).  d_x, d_fm [T][D][ld], d_fP [T][D*D][ld] (the filter's output buffers),

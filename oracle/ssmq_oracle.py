@@ -766,3 +766,34 @@ def lcr_sums(x, fm, fP, mse_global, ok=None):
             lcr[k] += log_cred_ratio(x[:, k, b], fm[:, k, b], fP[..., k, b], mse_global[k])
             n[k] += 1
     return dict(lcr=lcr, n=n)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# marginalised GP-quadrature filter: one theta-conditioned step (ssinf.py:1117-1198)
+# --------------------------------------------------------------------------------------------------------------
+
+def gauss_logpdf(y, mean, cov):
+    """log N(y | mean, cov) (scipy.stats.multivariate_normal.logpdf at ssinf.py:1198), Cholesky route."""
+    L = np.linalg.cholesky(cov)
+    v = np.linalg.solve(L, y - mean)
+    return -0.5 * (v.dot(v) + 2 * np.log(np.diag(L)).sum() + y.shape[0] * np.log(2 * np.pi))
+
+
+def marginal_theta_step(par_dyn, par_obs, m, P, y, t, fid_dyn, fid_obs, pts_dyn, pts_obs, GQG, R, p_dyn=(), p_obs=(),
+                        emv_broadcast=False):
+    """State posterior N(x_k | y_1:k, theta) and log N(y_k | y_1:k-1, theta) for ONE set of kernel parameters
+    (`_state_posterior_moments` ssinf.py:1117-1151, `_param_log_likelihood` :1153-1198): both transforms are
+    re-weighted with the given parameters (bq/bqmtran.py:93-95), time index `t` for both.
+    emv_broadcast: the marginalised filter builds its transforms with dim_out = 1 (ssinf.py:1290-1291), so
+    model_var * I_out is a 1 x 1 array broadcast over the whole covariance."""
+    def tf(fid, mean, cov, pts, par, p):
+        w = gp_weights(np.atleast_2d(par), pts)
+        mf, cf, cfx = apply_bq(fid, mean, cov, t, pts, dict(w, model_var=0.0), p)
+        E = mf.shape[0]
+        return mf, cf + (w['model_var'] * (np.ones((E, E)) if emv_broadcast else np.eye(E))), cfx
+    m_pr, P_pr, _ = tf(fid_dyn, m, P, pts_dyn, par_dyn, p_dyn)
+    P_pr = P_pr + GQG
+    y_mean, P_y, P_yx = tf(fid_obs, m_pr, P_pr, pts_obs, par_obs, p_obs)
+    P_y = P_y + R
+    mean, cov = kalman_update(m_pr, P_pr, y_mean, P_y, P_yx, y)
+    return mean, cov, gauss_logpdf(y, y_mean, P_y)

@@ -117,6 +117,11 @@ _PROTOTYPES = {
                                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                        c_double_p, c_double_p, c_double_p, ctypes.c_double,
                                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'ssmq_gp_theta_step': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
+                                          ctypes.POINTER(Integrand), ctypes.c_int64, c_double_p, c_double_p,
+                                          ctypes.c_double, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int,
+                                          ctypes.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                          c_int32_p]),
     'ssmq_error_sums_width': (ctypes.c_int, [ctypes.c_int]),
     'ssmq_error_sums_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p]),

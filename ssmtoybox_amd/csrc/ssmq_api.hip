@@ -1077,6 +1077,133 @@ extern "C" int ssmq_lcr_sums_dev(int D, int64_t B, int64_t ld, int T, const doub
     return metrics_impl(2, D, B, ld, T, d_x, d_fm, d_fP, d_status, mse, sums);
 }
 
+namespace ssmq {
+int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double *d_par, int P, double jitter,
+                           double *d_consts, int32_t *d_status);
+int launch_gauss_logpdf(int Y, int64_t B, int64_t ld, const double *y, const double *y_mean, const double *P_y,
+                        double *out, hipStream_t s);
+}
+
+namespace {
+__global__ void k_merge_theta_status(const int32_t *w_dyn, const int32_t *w_obs, const int32_t *t_dyn, const int32_t *t_obs,
+                                     const int32_t *upd, int32_t *out, int64_t P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    out[i] = (w_dyn[i] ? 1 : 0) | (w_obs[i] ? 2 : 0) | (t_dyn[i] ? 4 : 0) | (t_obs[i] ? 8 : 0) | (upd[i] ? 16 : 0);
+}
+}  // namespace
+
+// One filter step per parameter item: weights(theta_dyn) -> dyn transform -> + GQG -> weights(theta_obs) -> obs transform
+// -> + R -> measurement update and log N(y | y_mean, P_y).  Everything between the host arrays stays on the device.
+extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                  const ssmq_integrand *f_obs, int64_t P, const double *par_dyn, const double *par_obs,
+                                  double jitter, const double *mean, const double *cov, int shared_state,
+                                  const double *y, int shared_y, double time, const double *GQG, const double *R,
+                                  double *post_mean, double *post_cov, double *loglik, int32_t *status) {
+    if (!h_dyn || !h_obs || !f_dyn || !f_obs || P < 0 || P > 0x7fffffff || !par_dyn || !par_obs || !mean || !cov || !y ||
+        !post_mean || !post_cov || !loglik) {
+        set_error("gp_theta_step: bad argument");
+        return SSMQ_E_ARG;
+    }
+    const int D = h_dyn->D, Y = h_obs->E, Nd = h_dyn->N, No = h_obs->N;
+    if (h_dyn->E != D || h_obs->D != D || h_dyn->form != SSMQ_FORM_BQ || h_obs->form != SSMQ_FORM_BQ ||
+        h_dyn->tp_nu > 0.0 || h_obs->tp_nu > 0.0) {
+        set_error("gp_theta_step: needs GP-quadrature transforms D -> D and D -> Y (additive-noise models)");
+        return SSMQ_E_ARG;
+    }
+    FInfo fid, fio;
+    int rc = check_integrand(h_dyn, f_dyn, &fid);
+    if (rc || (rc = check_integrand(h_obs, f_obs, &fio))) return rc;
+    if (wide_lds_bytes(D, D, Nd) > 160 * 1024 - 64 || wide_lds_bytes(D, Y, No) > 160 * 1024 - 64) {
+        set_error("gp_theta_step: shape too large for the LDS-resident generic kernel");
+        return SSMQ_E_UNSUPPORTED;
+    }
+    if ((rc = ensure_device())) return rc;
+    if (P == 0) return SSMQ_OK;
+    hipStream_t s = stream();
+    const int64_t ld = (P + 63) / 64 * 64;
+    const WideLayout cld = wide_layout(D, D, Nd, SSMQ_FORM_BQ), clo = wide_layout(D, Y, No, SSMQ_FORM_BQ);
+    const int64_t ns = shared_state ? 1 : P, ny = shared_y ? 1 : P;
+    DevBuf xid, xio, pard, paro, cd, co, min_, cin, yin, ysoa, gq, rr, st, tt, work, aos;
+    // SoA work planes: m_pr D | P_pr D*D | C_xx D*D | y_mean Y | P_y Y*Y | P_yx Y*D | m_fi D | P_fi D*D | loglik 1
+    const size_t n_pl = (size_t)D + 3 * (size_t)D * D + Y + (size_t)Y * Y + (size_t)Y * D + D + 1;
+    if ((rc = xid.alloc(sizeof(double) * D * Nd)) || (rc = xio.alloc(sizeof(double) * D * No)) ||
+        (rc = pard.alloc(sizeof(double) * P * (1 + D))) || (rc = paro.alloc(sizeof(double) * P * (1 + D))) ||
+        (rc = cd.alloc(sizeof(double) * P * cld.total)) || (rc = co.alloc(sizeof(double) * P * clo.total)) ||
+        (rc = min_.alloc(sizeof(double) * ns * D)) || (rc = cin.alloc(sizeof(double) * ns * D * D)) ||
+        (rc = yin.alloc(sizeof(double) * P * Y)) || (rc = ysoa.alloc(sizeof(double) * ld * Y)) ||
+        (rc = gq.alloc(sizeof(double) * D * D)) || (rc = rr.alloc(sizeof(double) * Y * Y)) ||
+        (rc = st.alloc(sizeof(int32_t) * 6 * ld)) || (rc = tt.alloc(sizeof(double))) ||
+        (rc = work.alloc(sizeof(double) * ld * n_pl)) || (rc = aos.alloc(sizeof(double) * P * ((size_t)D + D * D))))
+        return rc;
+    std::vector<double> zg((size_t)D * D, 0.0), zr((size_t)Y * Y, 0.0), ybuf;
+    SSMQ_HIP(hipMemcpyAsync(xid.p, h_dyn->xi.data(), sizeof(double) * D * Nd, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(xio.p, h_obs->xi.data(), sizeof(double) * D * No, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(pard.p, par_dyn, sizeof(double) * P * (1 + D), hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(paro.p, par_obs, sizeof(double) * P * (1 + D), hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(min_.p, mean, sizeof(double) * ns * D, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(cin.p, cov, sizeof(double) * ns * D * D, hipMemcpyHostToDevice, s));
+    if (shared_y) {   // replicate on the host: the update kernels read one measurement plane set per item
+        ybuf.resize((size_t)P * Y);
+        for (int64_t i = 0; i < P; ++i)
+            for (int k = 0; k < Y; ++k) ybuf[(size_t)i * Y + k] = y[k];
+    }
+    SSMQ_HIP(hipMemcpyAsync(yin.p, shared_y ? ybuf.data() : y, sizeof(double) * P * Y, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(gq.p, GQG ? GQG : zg.data(), sizeof(double) * D * D, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(rr.p, R ? R : zr.data(), sizeof(double) * Y * Y, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(tt.p, &time, sizeof(double), hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemsetAsync(st.p, 0, sizeof(int32_t) * 6 * ld, s));
+    int32_t *st_wd = (int32_t *)st.p, *st_wo = st_wd + ld, *st_td = st_wo + ld, *st_to = st_td + ld, *st_up = st_to + ld,
+            *st_all = st_up + ld;
+    if ((rc = ssmq_aos_to_soa(yin.d(), ysoa.d(), Y, P, ld))) return rc;
+    if ((rc = gp_weights_wide_consts(D, D, Nd, xid.d(), pard.d(), (int)P, jitter, cd.d(), st_wd))) return rc;
+    if ((rc = gp_weights_wide_consts(D, Y, No, xio.d(), paro.d(), (int)P, jitter, co.d(), st_wo))) return rc;
+    double *w = work.d();
+    double *m_pr = w; w += ld * D;
+    double *P_pr = w; w += ld * D * D;
+    double *C_xx = w; w += ld * D * D;
+    double *y_mean = w; w += ld * Y;
+    double *P_y = w; w += ld * Y * Y;
+    double *P_yx = w; w += ld * Y * D;
+    double *m_fi = w; w += ld * D;
+    double *P_fi = w; w += ld * D * D;
+    double *ll = w;
+    WideArgs a;
+    memset(&a, 0, sizeof(a));
+    a.D = D; a.E = D; a.N = Nd; a.form = SSMQ_FORM_BQ; a.mode = SSMQ_WIDE_FULL; a.fid = f_dyn->id; a.time_stride = 0;
+    a.emv_mode = h_dyn->emv_mode; a.tp_nu = 0.0; a.cov_scale = a.ccov_scale = 1.0;
+    a.consts = cd.d(); a.consts_stride = cld.total; a.cov_add = gq.d();
+    a.mean = min_.d(); a.cov = cin.d(); a.time = tt.d(); a.es_in = 1; a.bs_mean = shared_state ? 0 : D;
+    a.bs_cov = shared_state ? 0 : (int64_t)D * D;
+    a.mean_f = m_pr; a.cov_f = P_pr; a.cov_fx = C_xx; a.es_out = ld; a.bs_mf = a.bs_cf = a.bs_cfx = 1; a.status = st_td;
+    fill_fpar(f_dyn, &a.fp);
+    if ((rc = hip_fail(launch_apply_wide(a, P, s), "k_apply_wide(theta, dyn)"))) return rc;
+    a.E = Y; a.N = No; a.fid = f_obs->id; a.emv_mode = h_obs->emv_mode; a.consts = co.d(); a.consts_stride = clo.total;
+    a.cov_add = rr.d(); a.mean = m_pr; a.cov = P_pr; a.es_in = ld; a.bs_mean = a.bs_cov = 1;
+    a.mean_f = y_mean; a.cov_f = P_y; a.cov_fx = P_yx; a.status = st_to;
+    fill_fpar(f_obs, &a.fp);
+    if ((rc = hip_fail(launch_apply_wide(a, P, s), "k_apply_wide(theta, obs)"))) return rc;
+    if ((rc = launch_kalman_update(D, Y, P, ld, m_pr, P_pr, y_mean, P_y, P_yx, ysoa.d(), m_fi, P_fi, st_up, s))) return rc;
+    if ((rc = launch_gauss_logpdf(Y, P, ld, ysoa.d(), y_mean, P_y, ll, s))) return rc;
+    hipLaunchKernelGGL(k_merge_theta_status, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, st_wd, st_wo, st_td, st_to,
+                       st_up, st_all, P);
+    if ((rc = hip_fail(hipGetLastError(), "k_merge_theta_status"))) return rc;
+    if ((rc = ssmq_soa_to_aos(m_fi, aos.d(), D, P, ld))) return rc;
+    if ((rc = ssmq_soa_to_aos(P_fi, aos.d() + P * D, D * D, P, ld))) return rc;
+    SSMQ_HIP(hipMemcpyAsync(post_mean, aos.d(), sizeof(double) * P * D, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(post_cov, aos.d() + P * D, sizeof(double) * P * D * D, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(loglik, ll, sizeof(double) * P, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> hst(P);
+    SSMQ_HIP(hipMemcpyAsync(hst.data(), st_all, sizeof(int32_t) * P, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    int first = 0;
+    for (int64_t i = 0; i < P; ++i) {
+        if (status) status[i] = hst[i];
+        if (hst[i] && !first) first = (int)std::min<int64_t>(i + 1, 0x7fffffff);
+    }
+    return first;
+}
+
 extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,
                                        const ssmq_transform *h_obs, const ssmq_integrand *f_obs, char *buf, int len) {
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || !buf || len <= 0) return SSMQ_E_ARG;

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
     double *sC = sS + E * E;        // E*E   fx Wc fx'
     double *sg = sC + E * E;        // E*D
     __shared__ int s_ok;
-    const double *c = a.consts;
+    const double *c = a.consts + b * a.consts_stride;   // per-trajectory weights: theta-batched callers
     const WideLayout cl = wide_layout(D, E, N, a.form);
     const double nan = __builtin_nan("");
 

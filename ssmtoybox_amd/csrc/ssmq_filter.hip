@@ -248,6 +248,51 @@ int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr
 }
 
 
+// ---- log N(y | y_mean, P_y) per trajectory (scipy multivariate_normal.logpdf as used at ssinf.py:1198) ----------------
+// Cholesky route: -(delta' P_y^-1 delta + log det P_y + Y log 2 pi) / 2; NaN where P_y is not positive definite.
+__global__ __launch_bounds__(kUpdBlock) void k_gauss_logpdf(const double *y, const double *y_mean, const double *P_y,
+                                                            double *out, int Y, int64_t B, int64_t ld) {
+    const uint32_t b = blockIdx.x * kUpdBlock + threadIdx.x;
+    if ((int64_t)b >= B) return;
+    double S[SSMQ_MAX_DIM * SSMQ_MAX_DIM], v[SSMQ_MAX_DIM];
+    for (int i = 0; i < Y; ++i)
+        for (int j = 0; j <= i; ++j) S[i * Y + j] = P_y[((int64_t)i * Y + j) * ld + b];
+    bool ok = true;
+    double logdet = 0.0, q = 0.0;
+    for (int j = 0; j < Y; ++j) {
+        double ajj = S[j * Y + j];
+        for (int k = 0; k < j; ++k) ajj -= S[j * Y + k] * S[j * Y + k];
+        ok = ok && (ajj > 0.0);
+        ajj = sqrt(ajj);
+        S[j * Y + j] = ajj;
+        logdet += log(ajj);
+        const double r = 1.0 / ajj;
+        for (int i = j + 1; i < Y; ++i) {
+            double s = S[i * Y + j];
+            for (int k = 0; k < j; ++k) s -= S[i * Y + k] * S[j * Y + k];
+            S[i * Y + j] = s * r;
+        }
+    }
+    for (int i = 0; i < Y; ++i) {
+        double s = y[(int64_t)i * ld + b] - y_mean[(int64_t)i * ld + b];
+        for (int k = 0; k < i; ++k) s -= S[i * Y + k] * v[k];
+        v[i] = s / S[i * Y + i];
+        q += v[i] * v[i];
+    }
+    out[b] = ok ? -0.5 * (q + 2.0 * logdet + Y * 1.8378770664093453) : __builtin_nan("");
+}
+
+int launch_gauss_logpdf(int Y, int64_t B, int64_t ld, const double *y, const double *y_mean, const double *P_y,
+                        double *out, hipStream_t s) {
+    if (Y < 1 || Y > SSMQ_MAX_DIM) {
+        set_error("logpdf: Y out of range");
+        return SSMQ_E_ARG;
+    }
+    const unsigned grid = (unsigned)((B + kUpdBlock - 1) / kUpdBlock);
+    hipLaunchKernelGGL(k_gauss_logpdf, dim3(grid), dim3(kUpdBlock), 0, s, y, y_mean, P_y, out, Y, B, ld);
+    return hip_fail(hipGetLastError(), "k_gauss_logpdf");
+}
+
 // ---- noise augmentation for non-additive models (ssinf.py:271-272, 282-283) -----------------------------------------
 // [m; noise_mean], blockdiag(P, noise_cov): plain copy kernel, one trajectory per lane, planes written whole.
 __global__ __launch_bounds__(kUpdBlock) void k_augment(const double *m, const double *P, const double *nmean,

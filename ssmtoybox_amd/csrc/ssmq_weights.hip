@@ -14,6 +14,7 @@
 #include <cstring>
 #include <vector>
 #include "ssmq_host.h"
+#include "ssmq_wide.h"
 
 namespace ssmq {
 
@@ -579,6 +580,56 @@ static int weights_impl(int D, int N, const double *xi, const double *par, int P
         if (st[i] && !first) first = i + 1;
     }
     return first;
+}
+
+// ---- theta-batched GP weights that stay on the device ----------------------------------------------------------------
+// consts[p] = WideLayout block of item p: xi' | wm | Wc | Wcc | emv = model_var * I_E | iK   (ssmq_wide.h)
+__global__ void k_pack_wide_consts(int D, int E, int N, const double *xi, const double *wm, const double *Wc,
+                                   const double *Wcc, const double *iK, const double *mv, double *consts) {
+    const WideLayout cl = wide_layout(D, E, N, SSMQ_FORM_BQ);
+    const int64_t p = blockIdx.x;
+    double *c = consts + p * cl.total;
+    for (int i = threadIdx.x; i < D * N; i += blockDim.x) c[cl.xiT + i] = xi[(i % D) * N + i / D];   // [N][D]
+    for (int i = threadIdx.x; i < N; i += blockDim.x) c[cl.wm + i] = wm[p * N + i];
+    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
+        c[cl.Wc + i] = Wc[p * N * N + i];
+        c[cl.iK + i] = iK[p * N * N + i];
+    }
+    for (int i = threadIdx.x; i < D * N; i += blockDim.x) c[cl.Wcc + i] = Wcc[p * D * N + i];
+    for (int i = threadIdx.x; i < E * E; i += blockDim.x) c[cl.emv + i] = mv[p];   // mode DIAG / BROADCAST picks entries
+}
+
+// d_xi [D][N], d_par [P][1+D] device; d_consts [P][wide_layout(D, E, N, BQ).total], d_status [P] device outputs.
+// Synchronous (the temporaries are released on return).
+int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double *d_par, int P, double jitter,
+                           double *d_consts, int32_t *d_status) {
+    hipStream_t s = stream();
+    const size_t nn = (size_t)N * N;
+    const int64_t work_stride = (int64_t)(10 * nn + 4 * (size_t)N + (size_t)D * N + 2 * N + 64);
+    DBuf dwm, dWc, dWcc, diK, dq, dQ, dR, dmv, div, dwork, dz;
+    int rc;
+    if ((rc = dwm.alloc(sizeof(double) * P * N)) || (rc = dWc.alloc(sizeof(double) * P * nn)) ||
+        (rc = dWcc.alloc(sizeof(double) * P * D * N)) || (rc = diK.alloc(sizeof(double) * P * nn)) ||
+        (rc = dq.alloc(sizeof(double) * P * N)) || (rc = dQ.alloc(sizeof(double) * P * nn)) ||
+        (rc = dR.alloc(sizeof(double) * P * D * N)) || (rc = dmv.alloc(sizeof(double) * P)) ||
+        (rc = div.alloc(sizeof(double) * P)) || (rc = dwork.alloc(sizeof(double) * (size_t)P * work_stride)) ||
+        (rc = dz.alloc(sizeof(double) * (D + 2))))
+        return rc;
+    SSMQ_HIP(hipMemsetAsync(dQ.p, 0, sizeof(double) * P * nn, s));
+    WgtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.D = D; a.N = N; a.P = P; a.NB = 0; a.jitter = jitter; a.use_lds = (N <= 64) ? 1 : 0;
+    a.xi = d_xi; a.par = d_par; a.mulind = (const int32_t *)dz.p; a.px = dz.d(); a.xpx = dz.d(); a.pxpx = dz.d();
+    a.wm = dwm.d(); a.Wc = dWc.d(); a.Wcc = dWcc.d(); a.iK = diK.d(); a.q = dq.d(); a.Q = dQ.d(); a.R = dR.d();
+    a.mv = dmv.d(); a.iv = div.d(); a.status = d_status; a.work = dwork.d(); a.work_stride = work_stride;
+    const size_t lds = a.use_lds ? sizeof(double) * 2 * nn : 0;
+    hipLaunchKernelGGL(k_weights, dim3(P), dim3(kWgtBlock), lds, s, a);
+    if ((rc = hip_fail(hipGetLastError(), "k_weights"))) return rc;
+    hipLaunchKernelGGL(k_pack_wide_consts, dim3(P), dim3(64), 0, s, D, E, N, d_xi, dwm.d(), dWc.d(), dWcc.d(), diK.d(),
+                       dmv.d(), d_consts);
+    if ((rc = hip_fail(hipGetLastError(), "k_pack_wide_consts"))) return rc;
+    SSMQ_HIP(hipStreamSynchronize(s));
+    return SSMQ_OK;
 }
 
 }  // namespace ssmq

@@ -32,6 +32,7 @@ struct WideArgs {
     int32_t D, E, N, form, mode, fid, time_stride, emv_mode;
     double tp_nu, cov_scale, ccov_scale;
     const double *consts;   // WideLayout block
+    int64_t consts_stride;  // doubles between the blocks of consecutive trajectories (0: one block for the batch)
     const double *cov_add;  // [E*E] or null
     // inputs: element e of trajectory b at ptr[e * es_in + b * bs_*]
     const double *mean, *cov, *time;

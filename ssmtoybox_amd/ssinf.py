@@ -12,7 +12,8 @@ all inside `ssmq_filter_forward_dev` (ssmtoybox_amd/csrc); nothing is computed i
 `StudentianInference` (ssinf.py:555-736) runs the same loop with the reference's scale-matrix bookkeeping
 (`ssmq_student_filter_forward_dev`); `backward_pass*` is the RTS smoother (`ssmq_filter_smooth_dev`).  Models that take
 their noise as an argument (UNGMNA, CTRS; ssinf.py:271-295) go through `ssmq_filter_forward_aug_dev` (forward pass only).
-Marginalised inference is not covered.
+`MarginalInference` (ssinf.py:1034-1292) evaluates its theta-conditioned steps on the device (`ssmq_gp_theta_step`); the
+BFGS optimiser stays on the host as in the reference.
 """
 import ctypes
 
@@ -311,3 +312,156 @@ class StudentProcessStudent(StudentianInference):
         t_dyn = StudentTProcessTransform(dyn.dim_in, 1, kern_par_dyn, 'rbf', 'fs', pp_dyn, nu=dof_tp)
         t_obs = StudentTProcessTransform(obs.dim_in, 1, kern_par_obs, 'rbf', 'fs', pp_obs, nu=dof_tp)
         super().__init__(dyn, obs, t_dyn, t_obs, dof, fixed_dof)
+
+
+class MarginalInference(GaussianInference):
+    """Gaussian filter with the moment-transform (kernel) parameters marginalised (ssinf.py:1034-1273; the reference
+    calls it experimental).  Per measurement: Laplace approximation of the log-parameter posterior (BFGS on
+    -log N(y | m_y(theta), P_y(theta)) - log N(theta | prior)), then a spherical-radial rule over that posterior mixing
+    the theta-conditioned state posteriors.  Every evaluation "weights(theta) -> two transforms -> update" runs on the
+    device through `ssmq_gp_theta_step`, batched over theta: one call per finite-difference gradient
+    (param_dim + 1 items) and one per marginalisation (2 param_dim items).  The optimiser itself is SciPy on the host, as
+    in the reference.  Additive-noise models and GP-quadrature transforms only.
+
+    Reference quirks kept: the measurement update evaluates both transforms at time index k, not k - 1
+    (ssinf.py:112 passes k); the mixture covariance is the weighted sum of the conditional covariances, without the
+    spread-of-the-means term (ssinf.py:1114-1115)."""
+
+    def __init__(self, dyn, obs, tf_dyn, tf_obs, par_mean=None, par_cov=None):
+        super().__init__(dyn, obs, tf_dyn, tf_obs)
+        if not self._additive:
+            raise NotImplementedError('the device theta-step covers additive-noise models')
+        self.param_dyn_dim = self.mod_dyn.dim_in + 1
+        self.param_obs_dim = self.mod_obs.dim_state + 1
+        self.param_dim = self.param_dyn_dim + self.param_obs_dim
+        self.param_prior_mean = np.zeros(self.param_dim) if par_mean is None else np.asarray(par_mean, dtype=float)
+        self.param_prior_cov = np.eye(self.param_dim) if par_cov is None else np.asarray(par_cov, dtype=float)
+        self.param_mean, self.param_cov = self.param_prior_mean, self.param_prior_cov
+        self.param_jitter = 1e-8 * np.eye(self.param_dim)
+        self.param_upts = SphericalRadialTransform.unit_sigma_points(self.param_dim)
+        self.param_wts = SphericalRadialTransform.weights(self.param_dim)
+        self.param_pts_num = self.param_upts.shape[1]
+        self.x_mean_fi, self.x_cov_fi = self.x0_mean, self.x0_cov
+        self.fd_step = 1.4901161193847656e-08      # SciPy's default forward-difference step for BFGS
+
+    def reset(self):
+        super().reset()
+        self.param_mean, self.param_cov = self.param_prior_mean, self.param_prior_cov
+        self.x_mean_fi, self.x_cov_fi = self.x0_mean, self.x0_cov
+
+    def theta_step(self, theta, mean, cov, y, time):
+        """theta (P, param_dim) log-parameters; mean (D,) / cov (D, D) shared by all items or (P, D) / (P, D, D);
+        y (Y,) or (P, Y).  Returns conditional posterior means (P, D), covariances (P, D, D), log-likelihoods (P,) and
+        the status flags (P,) of `ssmq_gp_theta_step`."""
+        lib = _lib.load()
+        theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+        P = theta.shape[0]
+        D = self.mod_dyn.dim_state
+        pd, ppd = _lib.as_c(np.exp(theta[:, :self.param_dyn_dim]))
+        po, ppo = _lib.as_c(np.exp(theta[:, self.param_dyn_dim:]))
+        mean, pm = _lib.as_c(mean)
+        cov, pc = _lib.as_c(cov)
+        y, py = _lib.as_c(y)
+        f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
+        f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
+        h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
+        gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
+        rr, pr = _lib.as_c(self.r_cov)
+        om, pom = _lib.out_c((P, D))
+        oc, poc = _lib.out_c((P, D, D))
+        ll, pll = _lib.out_c((P,))
+        st = np.zeros(P, dtype=np.int32)
+        _lib.check(lib.ssmq_gp_theta_step(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
+                                          ctypes.byref(f_obs), P, ppd, ppo, float(self.tf_dyn.model.kernel.jitter), pm,
+                                          pc, 1 if mean.ndim == 1 else 0, py, 1 if y.ndim == 1 else 0, float(time), pg,
+                                          pr, pom, poc, pll, st.ctypes.data_as(_lib.c_int32_p)), 'ssmq_gp_theta_step')
+        return om, oc, ll, st
+
+    def _param_log_prior(self, theta):
+        """log N(theta | param_mean, param_cov) (ssinf.py:1200-1218); host arithmetic on param_dim numbers."""
+        d = np.atleast_2d(theta) - self.param_mean
+        L = np.linalg.cholesky(self.param_cov)
+        v = np.linalg.solve(L, d.T)
+        return -0.5 * ((v ** 2).sum(axis=0) + 2 * np.log(np.diag(L)).sum() + self.param_dim * np.log(2 * np.pi))
+
+    def _param_log_likelihood(self, theta, y, k):
+        """ssinf.py:1153-1198 for one or many theta rows."""
+        ll = self.theta_step(theta, self.x_mean_fi, self.x_cov_fi, y, k)[2]
+        return ll if np.ndim(theta) == 2 else float(ll[0])
+
+    def _param_neg_log_posterior(self, theta, y, k):
+        """ssinf.py:1220-1241."""
+        val = -self._param_log_likelihood(theta, y, k) - self._param_log_prior(theta)
+        return val if np.ndim(theta) == 2 else float(val[0])
+
+    def _param_objective_and_gradient(self, theta, y, k):
+        """Objective and its forward-difference gradient from ONE theta-batched device call (param_dim + 1 items)."""
+        pts = np.vstack((theta, theta + self.fd_step * np.eye(self.param_dim)))
+        val = self._param_neg_log_posterior(pts, y, k)
+        val = np.where(np.isfinite(val), val, np.inf)
+        return float(val[0]), (val[1:] - val[0]) / ((theta + self.fd_step) - theta)
+
+    def _param_posterior_moments(self, y, k):
+        """Laplace approximation of the parameter posterior (ssinf.py:1243-1273)."""
+        from scipy.optimize import minimize
+        res = minimize(self._param_objective_and_gradient, self.param_mean, (y, k), method='BFGS', jac=True)
+        self.param_mean, self.param_cov = res.x, res.hess_inv + self.param_jitter
+
+    def _state_posterior_moments(self, theta, y, k):
+        """ssinf.py:1117-1151."""
+        m, c, _, st = self.theta_step(theta, self.x_mean_fi, self.x_cov_fi, y, k)
+        if st.any():
+            raise np.linalg.LinAlgError('Matrix is not positive definite (theta item {}, flags {})'.format(
+                int(np.flatnonzero(st)[0]), int(st[np.flatnonzero(st)[0]])))
+        return (m, c) if np.ndim(theta) == 2 else (m[0], c[0])
+
+    def _measurement_update(self, y, time=None):
+        """ssinf.py:1083-1115: all 2 param_dim theta points in one device call."""
+        self._param_posterior_moments(y, time)
+        chol = np.linalg.cholesky(self.param_cov)
+        param_pts = self.param_mean[:, None] + chol.dot(self.param_upts)
+        mean, cov = self._state_posterior_moments(param_pts.T, y, time)
+        self.x_mean_fi = np.einsum('ji,j->i', mean, self.param_wts)
+        self.x_cov_fi = np.einsum('kij,k->ij', cov, self.param_wts)
+
+    def forward_pass(self, data):
+        """data (dim_y, T) -> (D, T), (D, D, T).  ssinf.py:66-118: the generic time update of step k is overwritten by
+        the theta-conditioned ones inside the measurement update, so only the latter is run."""
+        data = np.asarray(data, dtype=np.float64)
+        T = data.shape[1]
+        D = self.mod_dyn.dim_state
+        fm, fP = np.zeros((D, T)), np.zeros((D, D, T))
+        for k in range(1, T + 1):
+            self._measurement_update(data[:, k - 1], k)
+            fm[:, k - 1], fP[..., k - 1] = self.x_mean_fi, self.x_cov_fi
+        self.fi_mean, self.fi_cov = fm, fP
+        return fm, fP
+
+    def forward_pass_batch(self, data, **kwargs):
+        """One trajectory after another: the Laplace step is a sequential host optimiser per trajectory."""
+        data = np.asarray(data, dtype=np.float64)
+        out = []
+        for b in range(data.shape[2]):
+            self.reset()
+            out.append(self.forward_pass(data[..., b]))
+        self.fi_mean = np.stack([o[0] for o in out], axis=-1)
+        self.fi_cov = np.stack([o[1] for o in out], axis=-1)
+        return self.fi_mean, self.fi_cov
+
+    def backward_pass_batch(self):
+        raise NotImplementedError('no smoother for the marginalised filter on the device path')
+
+    def kernel_name(self):
+        return 'per theta batch: k_weights x2 | k_pack_wide_consts x2 | k_apply_wide x2 | k_kalman_update | k_gauss_logpdf'
+
+
+class MarginalizedGaussianProcessKalman(MarginalInference):
+    """ssinf.py:1276-1292.  The transforms are built with dim_out = 1 as in the reference, so model_var * I_out is
+    broadcast over the whole covariance."""
+
+    def __init__(self, dyn, obs, kernel='rbf', points='ut', point_hyp=None, par_mean=None, par_cov=None):
+        kpar_dyn = np.ones((1, dyn.dim_in + 1))
+        kpar_obs = np.ones((1, obs.dim_state + 1))
+        t_dyn = GaussianProcessTransform(dyn.dim_in, 1, kpar_dyn, kernel, points, point_hyp)
+        t_obs = GaussianProcessTransform(obs.dim_state, 1, kpar_obs, kernel, points, point_hyp)
+        super().__init__(dyn, obs, t_dyn, t_obs, par_mean, par_cov)

@@ -456,8 +456,73 @@ def g7_metrics():
     save('g7_metrics', **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G8: marginalised GP-quadrature Kalman filter (ssinf.py:1034-1292): theta-conditioned step + a short forward pass
+# ---------------------------------------------------------------------------------------------------------------
+def g8_marginal():
+    out = {}
+    rng = np.random.default_rng(8)
+    # UNGM (tests/test_ssinf.py:272-276 setup), 'sr' and 'ut' points
+    dyn = ssmod.UNGMTransition(GaussRV(1, cov=np.atleast_2d(1.0)), GaussRV(1, cov=np.atleast_2d(10.0)))
+    obs = ssmod.UNGMMeasurement(GaussRV(1, cov=np.atleast_2d(1.0)), 1)
+    for pts in ('sr', 'ut'):
+        alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', pts)
+        n = 12
+        theta = 0.7 * rng.standard_normal((n, alg.param_dim))
+        m = rng.standard_normal((n, 1)) * 3
+        P = 0.5 + rng.random((n, 1, 1)) * 4
+        y = rng.standard_normal((n, 1)) * 3
+        k = rng.integers(0, 50, n)
+        pm, pc, ll = np.zeros((n, 1)), np.zeros((n, 1, 1)), np.zeros(n)
+        for i in range(n):
+            alg.x_mean_fi, alg.x_cov_fi = m[i].copy(), P[i].copy()
+            ll[i] = alg._param_log_likelihood(theta[i], y[i], int(k[i]))
+            pm[i], pc[i] = alg._state_posterior_moments(theta[i], y[i], int(k[i]))
+        tag = 'ungm_' + pts + '_'
+        for key, val in (('theta', theta), ('m', m), ('P', P), ('y', y), ('k', k), ('pm', pm), ('pc', pc), ('ll', ll)):
+            out[tag + key] = val
+    # pendulum (tests/test_ssinf.py:278-284): D = 2, the dim_out = 1 transforms broadcast model_var over the covariance
+    dt = 0.01
+    dyn = ssmod.Pendulum2DTransition(GaussRV(2, np.array([1.5, 0]), 0.01 * np.eye(2)),
+                                     GaussRV(2, cov=np.array([[dt ** 3 / 3, dt ** 2 / 2], [dt ** 2 / 2, dt]])), dt)
+    obs = ssmod.Pendulum2DMeasurement(GaussRV(1, cov=np.atleast_2d(0.1)), 2)
+    alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'sr')
+    n = 10
+    theta = 0.5 * rng.standard_normal((n, alg.param_dim))
+    m = np.array([1.5, 0.0]) + 0.3 * rng.standard_normal((n, 2))
+    a = rng.standard_normal((n, 2, 2)) * 0.1
+    P = np.einsum('nij,nkj->nik', a, a) + 0.01 * np.eye(2)
+    y = np.sin(m[:, :1]) + 0.3 * rng.standard_normal((n, 1))
+    pm, pc, ll = np.zeros((n, 2)), np.zeros((n, 2, 2)), np.zeros(n)
+    for i in range(n):
+        alg.x_mean_fi, alg.x_cov_fi = m[i].copy(), P[i].copy()
+        ll[i] = alg._param_log_likelihood(theta[i], y[i], 3)
+        pm[i], pc[i] = alg._state_posterior_moments(theta[i], y[i], 3)
+    for key, val in (('theta', theta), ('m', m), ('P', P), ('y', y), ('pm', pm), ('pc', pc), ('ll', ll),
+                     ('Q', dyn.noise_rv.cov), ('R', obs.noise_rv.cov)):
+        out['pend_' + key] = val
+    # a short UNGM forward pass, step by step as StateSpaceInference.forward_pass does (ssinf.py:101-112), recording the
+    # Laplace parameter posterior; BFGS on finite differences: downstream comparisons are loose by nature
+    dyn = ssmod.UNGMTransition(GaussRV(1, cov=np.atleast_2d(1.0)), GaussRV(1, cov=np.atleast_2d(10.0)))
+    obs = ssmod.UNGMMeasurement(GaussRV(1, cov=np.atleast_2d(1.0)), 1)
+    np.random.seed(88)
+    steps = 12
+    x = dyn.simulate_discrete(steps, 1)
+    yy = obs.simulate_measurements(x)[..., 0]
+    alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'sr')
+    fm, fc = np.zeros((1, steps)), np.zeros((1, 1, steps))
+    tm, tc = np.zeros((alg.param_dim, steps)), np.zeros((alg.param_dim, alg.param_dim, steps))
+    for kk in range(1, steps + 1):
+        alg._time_update(kk - 1)
+        alg._measurement_update(yy[:, kk - 1], kk)
+        fm[:, kk - 1], fc[..., kk - 1] = alg.x_mean_fi, alg.x_cov_fi
+        tm[:, kk - 1], tc[..., kk - 1] = alg.param_mean, alg.param_cov
+    out['fwd_y'], out['fwd_x'], out['fwd_fm'], out['fwd_fc'], out['fwd_tm'], out['fwd_tc'] = yy, x[..., 0], fm, fc, tm, tc
+    save('g8_marginal', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
     if 'g1' in which:
         g1_points()
     if 'g2' in which:
@@ -472,3 +537,5 @@ if __name__ == '__main__':
         g6_nonadditive()
     if 'g7' in which:
         g7_metrics()
+    if 'g8' in which:
+        g8_marginal()

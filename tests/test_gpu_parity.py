@@ -412,6 +412,96 @@ def test_ctrs_radar_ukf_golden(amd, golden):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# marginalised GP-quadrature filter: theta-batched step on the device (ssinf.py:1034-1292)
+# ---------------------------------------------------------------------------------------------------------------
+def _marginal_models(tag, g):
+    from ssmtoybox_amd import ssmod as sm
+    if tag.startswith('ungm'):
+        dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+        obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+        return dyn, obs, tag.split('_')[1]
+    dyn = sm.Pendulum2DTransition(sm.GaussRV(2, np.array([1.5, 0]), 0.01 * np.eye(2)), sm.GaussRV(2, cov=g['pend_Q']), 0.01)
+    obs = sm.Pendulum2DMeasurement(sm.GaussRV(1, cov=g['pend_R']), 2)
+    return dyn, obs, 'sr'
+
+
+@pytest.mark.parametrize('tag', ['ungm_sr', 'ungm_ut', 'pend'])
+def test_marginal_theta_step_golden(amd, golden, tag):
+    from ssmtoybox_amd import ssinf
+    g = golden('g8_marginal')
+    dyn, obs, pts = _marginal_models(tag, g)
+    alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', pts)
+    th, m, P, y = g[tag + '_theta'], g[tag + '_m'], g[tag + '_P'], g[tag + '_y']
+    n = th.shape[0]
+    ks = g[tag + '_k'] if tag.startswith('ungm') else np.full(n, 3)
+    pm, pc, ll = np.zeros_like(g[tag + '_pm']), np.zeros_like(g[tag + '_pc']), np.zeros(n)
+    for k in np.unique(ks):          # one device call per time index, items with their own state and measurement
+        sel = np.flatnonzero(ks == k)
+        pm[sel], pc[sel], ll[sel], st = alg.theta_step(th[sel], m[sel], P[sel], y[sel], int(k))
+        assert not st.any()
+    assert rel_err(pm, g[tag + '_pm']) < 1e-9
+    assert rel_err(pc, g[tag + '_pc']) < 1e-8
+    assert np.max(np.abs(ll - g[tag + '_ll']) / np.maximum(1.0, np.abs(g[tag + '_ll']))) < 1e-9
+    # shared state / measurement (the marginalisation call pattern) = the same items one by one
+    pm2, pc2, ll2, _ = alg.theta_step(th, m[0], P[0], y[0], int(ks[0]))
+    one = alg.theta_step(th[3], m[0], P[0], y[0], int(ks[0]))
+    assert np.array_equal(pm2[3], one[0][0]) and np.array_equal(pc2[3], one[1][0]) and ll2[3] == one[2][0]
+    alg.x_mean_fi, alg.x_cov_fi = m[0], P[0]
+    assert alg._param_log_likelihood(th[3], y[0], int(ks[0])) == ll2[3]
+
+
+def test_marginal_theta_step_batch_vs_oracle(amd):
+    """1000 parameter items in one call (k_weights with one workgroup per item feeding k_apply_wide in place)."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    dt = 0.01
+    Q = np.array([[dt ** 3 / 3, dt ** 2 / 2], [dt ** 2 / 2, dt]])
+    dyn = sm.Pendulum2DTransition(sm.GaussRV(2, np.array([1.5, 0]), 0.01 * np.eye(2)), sm.GaussRV(2, cov=Q), dt)
+    obs = sm.Pendulum2DMeasurement(sm.GaussRV(1, cov=np.array([[0.1]])), 2)
+    alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'ut')
+    rng = np.random.default_rng(5)
+    n = 1000
+    th = 0.5 * rng.standard_normal((n, alg.param_dim))
+    m = np.array([1.5, 0.0]) + 0.3 * rng.standard_normal((n, 2))
+    a = rng.standard_normal((n, 2, 2)) * 0.1
+    P = np.einsum('nij,nkj->nik', a, a) + 0.01 * np.eye(2)
+    y = np.sin(m[:, :1]) + 0.3 * rng.standard_normal((n, 1))
+    pm, pc, ll, st = alg.theta_step(th, m, P, y, 7)
+    assert not st.any()
+    pts = orc.points_ut(2)
+    for i in rng.choice(n, 25, replace=False):
+        om, oc, ol = orc.marginal_theta_step(np.exp(th[i, :3]), np.exp(th[i, 3:]), m[i], P[i], y[i], 7, orc.F_PENDULUM_DYN,
+                                             orc.F_PENDULUM_MEAS, pts, pts, Q, 0.1 * np.eye(1), (dt,), (),
+                                             emv_broadcast=True)
+        assert rel_err(pm[i], om) < 1e-9 and rel_err(pc[i], oc) < 1e-8 and abs(ll[i] - ol) < 1e-9 * max(1, abs(ol)), i
+    # a covariance that is not positive definite is flagged (bit 2) on its item only
+    P2 = P.copy()
+    P2[17] = -np.eye(2)
+    st2 = alg.theta_step(th, m, P2, y, 7)[3]
+    assert st2[17] & 4 and not np.delete(st2, 17).any()
+
+
+def test_marginal_filter_forward_pass(amd, golden):
+    """Whole marginalised filter on a short UNGM sequence.  BFGS on finite differences of a 1e-13-accurate objective:
+    the optimiser path, not the device arithmetic, limits how closely two implementations agree."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g8_marginal')
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'sr')
+    fm, fP = alg.forward_pass(g['fwd_y'])
+    assert fm.shape == g['fwd_fm'].shape and np.all(np.isfinite(fm)) and np.all(fP > 0)
+    err_m = np.abs(fm - g['fwd_fm']) / np.maximum(1.0, np.abs(g['fwd_fm']))
+    err_P = np.abs(fP - g['fwd_fc']) / np.maximum(1.0, np.abs(g['fwd_fc']))
+    print('marginal forward pass: max rel diff mean %.3e cov %.3e' % (err_m.max(), err_P.max()))
+    assert err_m[:, 0].max() < 1e-4 and err_P[..., 0].max() < 1e-4       # first step: same start, same optimum
+    assert np.median(err_m) < 1e-2 and np.median(err_P) < 1e-2
+    # the Laplace posterior of the last step is a valid covariance
+    assert np.all(np.linalg.eigvalsh(alg.param_cov) > 0)
+    fm2, _ = alg.forward_pass_batch(g['fwd_y'][..., None])
+    assert np.array_equal(fm2[..., 0], fm)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # error statistics reduced on the device (utils.py:18-148 aggregated as research/tpq/tpq_base.py:154-172)
 # ---------------------------------------------------------------------------------------------------------------
 def _planes(a, ld):
