@@ -261,6 +261,23 @@ int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_
                        double *post_cov, double *loglik, int32_t *status);
 
 /*
+ * Synthetic trajectories and measurements generated on the device, in the filter's plane layout
+ * (TransitionModel.simulate_discrete ssmod.py:168-199, MeasurementModel.simulate_measurements ssmod.py:1011-1039):
+ *   x[0] = x0_mean + x0_chol z;  x[k] = dyn_fcn(x[k-1], q[k-1], k-1);  y[k] = meas_fcn(x[k], r[k], k+1),
+ *   q = q_mean + q_chol z, r = r_mean + r_chol z (lower Cholesky factors, host arrays; means may be NULL = 0).
+ * Additive dynamics add G q (G [D*dq] host, NULL = eye(D, dq)); non-additive models get the noise as integrand input.
+ * Outputs d_x [T][D][ld], d_y [T][Y][ld].  Random numbers: Philox4x32-10 keyed by `seed`, counter = (traj_offset + b,
+ * step, purpose, pair) + Box-Muller, so a trajectory depends on its GLOBAL index only (shard with traj_offset).
+ * f_obs = NULL: states only (d_y unused); f_dyn = NULL: measurements of the GIVEN states d_x (simulate_measurements(x)).
+ * Parity with np.random is statistical; the generator itself is restated in oracle/ (known-answer vectors).  Synchronous.
+ */
+int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, int D, int Y, int dq, int dr,
+                      int dyn_additive, int obs_additive, int64_t B, int64_t ld, int T, const double *x0_mean,
+                      const double *x0_chol, const double *q_mean, const double *q_chol, const double *G,
+                      const double *r_mean, const double *r_chol, uint64_t seed, uint64_t traj_offset, double *d_x,
+                      double *d_y);
+
+/*
  * Error statistics of B filtered trajectories against the true states, summed over the Monte-Carlo axis on the device
  * (utils.py:18-38 squared_error, :41-64 mse_matrix, :123-148 neg_log_likelihood; aggregated per time step as
  * research/tpq/tpq_base.py:154-160 does).  d_x, d_fm [T][D][ld], d_fP [T][D*D][ld] (the filter's output buffers),

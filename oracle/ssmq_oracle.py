@@ -797,3 +797,72 @@ def marginal_theta_step(par_dyn, par_obs, m, P, y, t, fid_dyn, fid_obs, pts_dyn,
     P_y = P_y + R
     mean, cov = kalman_update(m_pr, P_pr, y_mean, P_y, P_yx, y)
     return mean, cov, gauss_logpdf(y, y_mean, P_y)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# synthetic trajectories (ssmod.py:168-199, 1011-1039) with the build's counter-based generator
+# --------------------------------------------------------------------------------------------------------------
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11).  ctr: four and
+    key: two arrays (or ints) of 32-bit words; returns four uint64 arrays holding 32-bit words.  Pinned by the Random123
+    known-answer vectors in tests/test_oracle_golden.py."""
+    c = [np.asarray(v, dtype=np.uint64) & np.uint64(0xffffffff) for v in ctr]
+    k = [np.asarray(v, dtype=np.uint64) & np.uint64(0xffffffff) for v in key]
+    m32 = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k[0], p1 & m32, (p0 >> np.uint64(32)) ^ c[3] ^ k[1], p0 & m32]
+        k = [(k[0] + np.uint64(0x9E3779B9)) & m32, (k[1] + np.uint64(0xBB67AE85)) & m32]
+    return c
+
+
+def normal_pair(seed, traj, step, tag):
+    """Two standard normals per (global trajectory index, time step, tag): Box-Muller on two 53-bit uniforms built from
+    one Philox block, exactly as ssmq_simulate.hip does."""
+    traj = np.asarray(traj, dtype=np.uint64)
+    c = philox4x32_10([traj, traj >> np.uint64(32), np.full(traj.shape, step, dtype=np.uint64),
+                       np.full(traj.shape, tag, dtype=np.uint64)], [seed & 0xffffffff, (seed >> 32) & 0xffffffff])
+    u1 = ((((c[0] >> np.uint64(5)) << np.uint64(26)) | (c[1] >> np.uint64(6))).astype(np.float64) + 0.5) / 2.0 ** 53
+    u2 = ((((c[2] >> np.uint64(5)) << np.uint64(26)) | (c[3] >> np.uint64(6))).astype(np.float64) + 0.5) / 2.0 ** 53
+    r = np.sqrt(-2.0 * np.log(u1))
+    return r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)
+
+
+def gauss_vectors(seed, traj, step, purpose, mean, chol):
+    """mean + chol z for every trajectory in `traj`: (n, B)."""
+    n = mean.shape[0]
+    z = np.zeros((n, np.size(traj)))
+    for j in range(0, n, 2):
+        z0, z1 = normal_pair(seed, traj, step, (purpose << 16) | (j >> 1))
+        z[j] = z0
+        if j + 1 < n:
+            z[j + 1] = z1
+    return mean[:, None] + chol.dot(z)
+
+
+def simulate(fid_dyn, fid_obs, steps, B, x0_mean, x0_cov, q_mean, q_cov, r_mean, r_cov, G=None, p_dyn=(), p_obs=(),
+             dyn_additive=True, obs_additive=True, state_index=None, seed=0, traj_offset=0):
+    """x (D, steps, B), y (Y, steps, B):  x[0] ~ N(x0);  x[k] = dyn_fcn(x[k-1], q[k-1], k-1) (ssmod.py:196-198);
+    y[k] = meas_fcn(x[k], r[k], k+1) (ssmod.py:1036-1038).  Additive models: f(x) + G q / h(x) + r."""
+    D, dq, dr = x0_mean.shape[0], q_mean.shape[0], r_mean.shape[0]
+    G = np.eye(D, dq) if G is None else G
+    traj = np.arange(B, dtype=np.uint64) + np.uint64(traj_offset)
+    L0, Lq, Lr = np.linalg.cholesky(x0_cov), np.linalg.cholesky(q_cov), np.linalg.cholesky(r_cov)
+    x = gauss_vectors(seed, traj, 0, 0, x0_mean, L0)
+    xs, ys = [], []
+    for k in range(steps):
+        xs.append(x)
+        r = gauss_vectors(seed, traj, k, 2, r_mean, Lr)
+        xa = x if obs_additive else np.vstack((x, r))
+        sel = xa if state_index is None else xa[np.asarray(state_index)]
+        h = np.stack([integrand(fid_obs, sel[:, b], k + 1, p_obs) for b in range(B)], axis=1)
+        ys.append(h + r if obs_additive else h)
+        if k + 1 == steps:
+            break
+        q = gauss_vectors(seed, traj, k, 1, q_mean, Lq)
+        xa = x if dyn_additive else np.vstack((x, q))
+        f = np.stack([integrand(fid_dyn, xa[:, b], k, p_dyn) for b in range(B)], axis=1)
+        x = f + G.dot(q) if dyn_additive else f
+    return np.stack(xs, axis=1), np.stack(ys, axis=1)

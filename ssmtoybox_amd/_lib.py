@@ -122,6 +122,11 @@ _PROTOTYPES = {
                                           ctypes.c_double, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int,
                                           ctypes.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                           c_int32_p]),
+    'ssmq_simulate_dev': (ctypes.c_int, [ctypes.POINTER(Integrand), ctypes.POINTER(Integrand), ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
+                                         c_double_p, c_double_p, c_double_p, ctypes.c_uint64, ctypes.c_uint64,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
     'ssmq_error_sums_width': (ctypes.c_int, [ctypes.c_int]),
     'ssmq_error_sums_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p]),

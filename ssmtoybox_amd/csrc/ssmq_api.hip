@@ -1204,6 +1204,74 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     return first;
 }
 
+namespace ssmq {
+int launch_simulate(int mode, int D, int Y, int dq, int dr, int dyn_additive, int obs_additive, int T, int64_t B,
+                    int64_t ld, uint64_t seed, uint64_t traj_offset, const ssmq_integrand *f_dyn,
+                    const ssmq_integrand *f_obs, const double *d_consts, double *d_x, double *d_y, hipStream_t s);
+}
+
+extern "C" int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, int D, int Y, int dq, int dr,
+                                 int dyn_additive, int obs_additive, int64_t B, int64_t ld, int T,
+                                 const double *x0_mean, const double *x0_chol, const double *q_mean,
+                                 const double *q_chol, const double *G, const double *r_mean, const double *r_chol,
+                                 uint64_t seed, uint64_t traj_offset, double *d_x, double *d_y) {
+    const int mode = (f_dyn ? 1 : 0) | (f_obs ? 2 : 0);
+    if (!mode || D < 1 || D > SSMQ_MAX_DIM || B < 0 || ld < B || T < 0 || !d_x || (f_dyn && (!x0_mean || !x0_chol || !q_chol ||
+        dq < 1 || dq > SSMQ_MAX_DIM)) || (f_obs && (!r_chol || !d_y || Y < 1 || Y > SSMQ_MAX_DIM || dr < 1 || dr > SSMQ_MAX_DIM))) {
+        set_error("simulate: bad argument");
+        return SSMQ_E_ARG;
+    }
+    if (!f_dyn) dq = 0;
+    if (!f_obs) { dr = 0; Y = 0; }
+    FInfo fid, fio;
+    if (f_dyn) {
+        const int in_dyn = D + (dyn_additive ? 0 : dq);
+        if (!integrand_info(f_dyn->id, &fid) || fid.din > in_dyn || fid.dout != D || in_dyn > SSMQ_MAX_FIDX ||
+            f_dyn->n_idx != 0) {
+            set_error("simulate: transition integrand / dimension mismatch (state + noise inputs must fit SSMQ_MAX_FIDX)");
+            return SSMQ_E_ARG;
+        }
+    }
+    if (f_obs) {
+        const int in_obs = D + (obs_additive ? 0 : dr);
+        if (!integrand_info(f_obs->id, &fio) || (fio.dout ? fio.dout : Y) != Y || (obs_additive && dr != Y) ||
+            f_obs->n_idx > SSMQ_MAX_FIDX || f_obs->n_idx < 0 || (f_obs->n_idx == 0 && (fio.din > in_obs || in_obs > SSMQ_MAX_FIDX))) {
+            set_error("simulate: measurement integrand / dimension mismatch");
+            return SSMQ_E_ARG;
+        }
+        for (int k = 0; k < f_obs->n_idx; ++k)
+            if (f_obs->idx[k] < 0 || f_obs->idx[k] >= in_obs) {
+                set_error("simulate: measurement state index out of range");
+                return SSMQ_E_ARG;
+            }
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0 || T == 0) return SSMQ_OK;
+    std::vector<double> hc;
+    auto put = [&](const double *p, size_t n, int eye_cols = 0) {
+        for (size_t i = 0; i < n; ++i)
+            hc.push_back(p ? p[i] : (eye_cols && (int)(i / eye_cols) == (int)(i % eye_cols) ? 1.0 : 0.0));
+    };
+    put(f_dyn ? x0_mean : nullptr, D);
+    put(f_dyn ? x0_chol : nullptr, (size_t)D * D);
+    put(q_mean, dq);
+    put(q_chol, (size_t)dq * dq);
+    put(G, (size_t)D * dq, dq);     // default noise gain eye(D, dq)  (ssmod.py:52)
+    put(r_mean, dr);
+    put(r_chol, (size_t)dr * dr);
+    DevBuf dc;
+    if ((rc = dc.alloc(sizeof(double) * hc.size()))) return rc;
+    hipStream_t s = stream();
+    SSMQ_HIP(hipMemcpyAsync(dc.p, hc.data(), sizeof(double) * hc.size(), hipMemcpyHostToDevice, s));
+    rc = launch_simulate(mode, D, Y, dq, dr, dyn_additive, obs_additive, T, B, ld, seed, traj_offset, f_dyn, f_obs, dc.d(),
+                         d_x, d_y, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (rc) return rc;
+    SSMQ_HIP(e);
+    return SSMQ_OK;
+}
+
 extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,
                                        const ssmq_transform *h_obs, const ssmq_integrand *f_obs, char *buf, int len) {
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || !buf || len <= 0) return SSMQ_E_ARG;

@@ -10,34 +10,6 @@
 
 namespace ssmq {
 
-__device__ __forceinline__ void eval_integrand(int id, const double *xs, double t, const FPar &fp, double *o) {
-#define SSMQ_CASE(F)                      \
-    case F: {                             \
-        Fn<F> fn;                         \
-        fn.init(t, fp);                   \
-        fn.template eval<SSMQ_MAX_FIDX>(xs, o); \
-    } break;
-    switch (id) {
-        SSMQ_CASE(SSMQ_F_UNGM_DYN)
-        SSMQ_CASE(SSMQ_F_UNGM_MEAS)
-        SSMQ_CASE(SSMQ_F_UNGMNA_DYN)
-        SSMQ_CASE(SSMQ_F_UNGMNA_MEAS)
-        SSMQ_CASE(SSMQ_F_PENDULUM_DYN)
-        SSMQ_CASE(SSMQ_F_PENDULUM_MEAS)
-        SSMQ_CASE(SSMQ_F_REENTRY1D_DYN)
-        SSMQ_CASE(SSMQ_F_RANGE_MEAS)
-        SSMQ_CASE(SSMQ_F_REENTRY2D_DYN)
-        SSMQ_CASE(SSMQ_F_RADAR2D_MEAS)
-        SSMQ_CASE(SSMQ_F_CT_DYN)
-        SSMQ_CASE(SSMQ_F_BEARING_MEAS)
-        SSMQ_CASE(SSMQ_F_CTRS_DYN)
-        SSMQ_CASE(SSMQ_F_CV_DYN)
-        SSMQ_CASE(SSMQ_F_REENTRY2D_BIAS_DYN)
-        default: break;
-    }
-#undef SSMQ_CASE
-}
-
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -310,6 +310,35 @@ struct Fn<SSMQ_F_CV_DYN> {
     }
 };
 
+// Integrand chosen at run time (generic kernels): xs holds the leading SSMQ_MAX_FIDX inputs, o up to SSMQ_MAX_DIM outputs.
+__device__ __forceinline__ void eval_integrand(int id, const double *xs, double t, const FPar &fp, double *o) {
+#define SSMQ_CASE(F)                      \
+    case F: {                             \
+        Fn<F> fn;                         \
+        fn.init(t, fp);                   \
+        fn.template eval<SSMQ_MAX_FIDX>(xs, o); \
+    } break;
+    switch (id) {
+        SSMQ_CASE(SSMQ_F_UNGM_DYN)
+        SSMQ_CASE(SSMQ_F_UNGM_MEAS)
+        SSMQ_CASE(SSMQ_F_UNGMNA_DYN)
+        SSMQ_CASE(SSMQ_F_UNGMNA_MEAS)
+        SSMQ_CASE(SSMQ_F_PENDULUM_DYN)
+        SSMQ_CASE(SSMQ_F_PENDULUM_MEAS)
+        SSMQ_CASE(SSMQ_F_REENTRY1D_DYN)
+        SSMQ_CASE(SSMQ_F_RANGE_MEAS)
+        SSMQ_CASE(SSMQ_F_REENTRY2D_DYN)
+        SSMQ_CASE(SSMQ_F_RADAR2D_MEAS)
+        SSMQ_CASE(SSMQ_F_CT_DYN)
+        SSMQ_CASE(SSMQ_F_BEARING_MEAS)
+        SSMQ_CASE(SSMQ_F_CTRS_DYN)
+        SSMQ_CASE(SSMQ_F_CV_DYN)
+        SSMQ_CASE(SSMQ_F_REENTRY2D_BIAS_DYN)
+        default: break;
+    }
+#undef SSMQ_CASE
+}
+
 // Host: the time-dependent constant of integrand `id` for times 0..T-1 (what Fn<id>::init would compute), or false if the
 // integrand has none.  Evaluated with the host libm in fp64 - the reference evaluates np.cos on the host as well.
 __host__ inline bool time_table(int id, int T, double *out) {

@@ -5,8 +5,12 @@ to its device integrand (include/ssmq.h `enum ssmq_integrand_id`) so that a mome
 
 Only what the moment-transform path needs is here: dimensions, noise additivity, noise gain, the integrand descriptor and
 a NumPy evaluation of the same formula for callers that want function values on the host (it is never used by
-`apply()`).  Simulators, Jacobians and random variables of the reference are out of scope.
+`apply()`).  `simulate_discrete` / `simulate_measurements` (ssmod.py:168-199, 1011-1039) run on the device
+(`ssmq_simulate_dev`: counter-based Philox generator, so results match the reference's np.random streams only
+statistically); Jacobians and the Student / mixture random variables' samplers stay in the reference.
 """
+import ctypes
+
 import numpy as np
 
 from . import _lib
@@ -38,6 +42,36 @@ class StudentRV:
         return self.mean, self.scale, self.dof
 
 
+def _gauss_stats(rv, what):
+    """Mean and lower Cholesky factor of a Gaussian random variable (the device simulator draws mean + L z)."""
+    if not isinstance(rv, GaussRV):
+        raise NotImplementedError('device simulation needs a GaussRV for ' + what)
+    return np.ascontiguousarray(rv.mean, dtype=np.float64), np.ascontiguousarray(np.linalg.cholesky(rv.cov))
+
+
+def simulate_dev(dyn, obs, steps, mc_sims, seed=0, traj_offset=0):
+    """States and measurements of `mc_sims` trajectories generated on the device, left there in the filter's layout:
+    returns (d_x, d_y, ld) with d_x planes [steps][D][ld], d_y [steps][Y][ld] (DeviceBuffers; caller frees).
+    x[0] ~ init_rv, x[k] = dyn_fcn(x[k-1], q[k-1], k-1), y[k] = meas_fcn(x[k], r[k], k+1) (ssmod.py:168-199, 1011-1039).
+    Trajectory b uses the random stream of global index traj_offset + b."""
+    lib = _lib.load()
+    D, Y = dyn.dim_state, obs.dim_out
+    ld = (mc_sims + 63) // 64 * 64
+    m0, L0 = _gauss_stats(dyn.init_rv, 'the initial state')
+    qm, Lq = _gauss_stats(dyn.noise_rv, 'the process noise')
+    rm, Lr = _gauss_stats(obs.noise_rv, 'the measurement noise')
+    G = np.ascontiguousarray(dyn.noise_gain, dtype=np.float64)
+    f_dyn, _ = dyn.device_integrand()
+    f_obs, _ = obs.device_integrand()
+    d_x, d_y = _lib.DeviceBuffer(8 * steps * D * ld), _lib.DeviceBuffer(8 * steps * Y * ld)
+    p = lambda a: a.ctypes.data_as(_lib.c_double_p)
+    _lib.check(lib.ssmq_simulate_dev(ctypes.byref(f_dyn), ctypes.byref(f_obs), D, Y, qm.size, rm.size,
+                                     1 if dyn.noise_additive else 0, 1 if obs.noise_additive else 0, mc_sims, ld, steps,
+                                     p(m0), p(L0), p(qm), p(Lq), p(G), p(rm), p(Lr), seed, traj_offset,
+                                     ctypes.c_void_p(d_x.ptr), ctypes.c_void_p(d_y.ptr)), 'ssmq_simulate_dev')
+    return d_x, d_y, ld
+
+
 class TransitionModel:
     """x_{k+1} = f(x_k, q_k, k)   (ssmod.py:10-244)."""
     dim_state = None
@@ -60,6 +94,25 @@ class TransitionModel:
 
     def dyn_fcn(self, x, q, time):
         raise NotImplementedError
+
+    def simulate_discrete(self, steps, mc_sims=1, seed=0, traj_offset=0):
+        """(dim_state, steps, mc_sims) state trajectories (ssmod.py:168-199), generated on the device.  The reference
+        draws from the global np.random state; here the stream is named by `seed` (and the trajectory's global index)."""
+        lib = _lib.load()
+        D = self.dim_state
+        ld = (mc_sims + 63) // 64 * 64
+        m0, L0 = _gauss_stats(self.init_rv, 'the initial state')
+        qm, Lq = _gauss_stats(self.noise_rv, 'the process noise')
+        G = np.ascontiguousarray(self.noise_gain, dtype=np.float64)
+        f_dyn, _ = self.device_integrand()
+        d_x = _lib.DeviceBuffer(8 * steps * D * ld)
+        p = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        _lib.check(lib.ssmq_simulate_dev(ctypes.byref(f_dyn), None, D, 0, qm.size, 0, 1 if self.noise_additive else 0, 1,
+                                         mc_sims, ld, steps, p(m0), p(L0), p(qm), p(Lq), p(G), None, None, seed,
+                                         traj_offset, ctypes.c_void_p(d_x.ptr), None), 'ssmq_simulate_dev')
+        x = d_x.download((steps, D, ld))[:, :, :mc_sims].transpose(1, 0, 2)
+        d_x.free()
+        return np.ascontiguousarray(x)
 
     def dyn_eval(self, xq, time, dx=False):
         """Noise-additivity-aware evaluation (ssmod.py:129-166): additive models are evaluated at zero noise."""
@@ -246,6 +299,30 @@ class MeasurementModel:
 
     def meas_fcn(self, x, r, time):
         raise NotImplementedError
+
+    def simulate_measurements(self, x, seed=0, traj_offset=0):
+        """(dim_out, steps, mc_sims) measurements of the given states x (dim_state, steps, mc_sims), y[k] taken at time
+        k + 1 (ssmod.py:1011-1039), generated on the device."""
+        lib = _lib.load()
+        x = np.asarray(x, dtype=np.float64)
+        D, steps, mc_sims = x.shape
+        Y = self.dim_out
+        ld = (mc_sims + 63) // 64 * 64
+        rm, Lr = _gauss_stats(self.noise_rv, 'the measurement noise')
+        f_obs, _ = self.device_integrand()
+        xb = np.zeros((steps, D, ld))
+        xb[:, :, :mc_sims] = x.transpose(1, 0, 2)
+        d_x, d_y = _lib.DeviceBuffer(xb.nbytes), _lib.DeviceBuffer(8 * steps * Y * ld)
+        d_x.upload(xb)
+        p = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        _lib.check(lib.ssmq_simulate_dev(None, ctypes.byref(f_obs), D, Y, 0, rm.size, 1, 1 if self.noise_additive else 0,
+                                         mc_sims, ld, steps, None, None, None, None, None, p(rm), p(Lr), seed,
+                                         traj_offset, ctypes.c_void_p(d_x.ptr), ctypes.c_void_p(d_y.ptr)),
+                   'ssmq_simulate_dev')
+        y = d_y.download((steps, Y, ld))[:, :, :mc_sims].transpose(1, 0, 2)
+        d_x.free()
+        d_y.free()
+        return np.ascontiguousarray(y)
 
     def meas_eval(self, xr, time, dx=False):
         """ssmod.py:960-1009."""

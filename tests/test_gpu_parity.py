@@ -502,6 +502,117 @@ def test_marginal_filter_forward_pass(amd, golden):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# simulators on the device (ssmod.py:168-199, 1011-1039), counter-based generator
+# ---------------------------------------------------------------------------------------------------------------
+def _sim_models(name):
+    from ssmtoybox_amd import ssmod as sm
+    if name == 'ungm':
+        dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+        obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+        return dyn, obs, dict(fid_dyn=orc.F_UNGM_DYN, fid_obs=orc.F_UNGM_MEAS)
+    if name == 'ungmna':
+        dyn = sm.UNGMNATransition(sm.GaussRV(1, mean=np.array([1.0])), sm.GaussRV(1, cov=np.array([[10.0]])))
+        obs = sm.UNGMNAMeasurement(sm.GaussRV(1), 1)
+        return dyn, obs, dict(fid_dyn=orc.F_UNGMNA_DYN, fid_obs=orc.F_UNGMNA_MEAS, dyn_additive=False, obs_additive=False)
+    if name == 'reentry':
+        m0 = np.array([6500.4, 349.14, -1.8093, -6.7967, 0.6932])
+        P0 = np.diag([1e-6, 1e-6, 1e-6, 1e-6, 1.0])
+        dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, m0, P0), sm.GaussRV(3, cov=np.diag([2.4064e-5, 2.4064e-5, 1e-6])))
+        obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=np.diag([1e-6, 0.17e-6])), 5, radar_loc=[6374.0, 0.0])
+        return dyn, obs, dict(fid_dyn=orc.F_REENTRY2D_DYN, fid_obs=orc.F_RADAR2D_MEAS, p_dyn=(0.1,), p_obs=(6374.0, 0.0),
+                              G=dyn.noise_gain)
+    a = np.array([[0.5, 0.1], [0.1, 0.3]])
+    dyn = sm.ConstantTurnRateSpeed(sm.GaussRV(5, mean=np.array([10.0, 10.0, 5.0, 0.3, 0.1]), cov=0.1 * np.eye(5)),
+                                   sm.GaussRV(2, cov=a))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=np.diag([0.3, 0.03])), 5)
+    return dyn, obs, dict(fid_dyn=orc.F_CTRS_DYN, fid_obs=orc.F_RADAR2D_MEAS, p_dyn=(0.05,), p_obs=(0.0, 0.0),
+                          dyn_additive=False)
+
+
+def _download_sim(d_x, d_y, ld, D, Y, T, B):
+    x = d_x.download((T, D, ld))[:, :, :B].transpose(1, 0, 2)
+    y = d_y.download((T, Y, ld))[:, :, :B].transpose(1, 0, 2)
+    d_x.free()
+    d_y.free()
+    return x, y
+
+
+@pytest.mark.parametrize('name', ['ungm', 'ungmna', 'reentry', 'ctrs'])
+def test_simulate_matches_generator_restatement(amd, name):
+    from ssmtoybox_amd import ssmod as sm
+    dyn, obs, kw = _sim_models(name)
+    T, B, seed, off = 6, 130, 20261003, 5000000000       # the offset exercises the high counter word
+    d_x, d_y, ld = sm.simulate_dev(dyn, obs, T, B, seed=seed, traj_offset=off)
+    x, y = _download_sim(d_x, d_y, ld, dyn.dim_state, obs.dim_out, T, B)
+    ox, oy = orc.simulate(steps=T, B=B, x0_mean=dyn.init_rv.mean, x0_cov=dyn.init_rv.cov, q_mean=dyn.noise_rv.mean,
+                          q_cov=dyn.noise_rv.cov, r_mean=obs.noise_rv.mean, r_cov=obs.noise_rv.cov, seed=seed,
+                          traj_offset=off, **kw)
+    assert np.array_equal(x[:, 0] != 0, ox[:, 0] != 0)
+    assert rel_err(x[:, 0], ox[:, 0]) < 1e-13            # initial draw: generator + Box-Muller only
+    # six steps of UNGM amplify a last-bit difference of log / sincos by up to 25^5
+    assert rel_err(x, ox) < 1e-8 and rel_err(y, oy) < 1e-8, name
+    # sharding invariance: two shards with their global offsets reproduce the whole batch bit for bit
+    h = 70
+    xa, ya = _download_sim(*sm.simulate_dev(dyn, obs, T, h, seed=seed, traj_offset=off), dyn.dim_state, obs.dim_out, T, h)
+    xb, yb = _download_sim(*sm.simulate_dev(dyn, obs, T, B - h, seed=seed, traj_offset=off + h), dyn.dim_state,
+                           obs.dim_out, T, B - h)
+    assert np.array_equal(np.concatenate((xa, xb), axis=2), x) and np.array_equal(np.concatenate((ya, yb), axis=2), y)
+    # the reference's two-call interface gives the same numbers
+    x2 = dyn.simulate_discrete(T, B, seed=seed, traj_offset=off)
+    y2 = obs.simulate_measurements(x2, seed=seed, traj_offset=off)
+    assert np.array_equal(x2, x) and np.array_equal(y2, y)
+    assert not np.array_equal(dyn.simulate_discrete(T, B, seed=seed + 1, traj_offset=off), x)
+
+
+def test_simulate_long_run_one_step_residuals(amd):
+    """T = 100: every step obeys x[k] = f(x[k-1], k-1) + G q[k-1], y[k] = h(x[k], k+1) + r[k] with the generator's
+    q, r (a check that does not suffer from the chaotic amplification of whole-trajectory comparisons)."""
+    from ssmtoybox_amd import ssmod as sm
+    dyn, obs, _ = _sim_models('ungm')
+    T, B, seed = 100, 256, 99
+    x, y = _download_sim(*sm.simulate_dev(dyn, obs, T, B, seed=seed), 1, 1, T, B)
+    traj = np.arange(B)
+    for k in (0, 1, 37, 98):
+        q = orc.gauss_vectors(seed, traj, k, 1, np.zeros(1), np.sqrt(10.0) * np.eye(1))
+        f = 0.5 * x[0, k] + 25 * x[0, k] / (1 + x[0, k] ** 2) + 8 * np.cos(1.2 * k)
+        assert np.allclose(x[0, k + 1], f + q[0], rtol=1e-12, atol=1e-12)
+    for k in (0, 50, 99):
+        r = orc.gauss_vectors(seed, traj, k, 2, np.zeros(1), np.eye(1))
+        assert np.allclose(y[0, k], 0.05 * x[0, k] ** 2 + r[0], rtol=1e-12, atol=1e-12)
+
+
+def test_simulate_statistics_match_numpy_streams(amd):
+    """Statistical parity with an np.random simulation of the same model (what the reference's simulators draw from):
+    per-step mean and variance of states and measurements over 2e5 trajectories agree within sampling error."""
+    from ssmtoybox_amd import ssmod as sm
+    dyn, obs, _ = _sim_models('ungm')
+    T, B = 12, 200000
+    x, y = _download_sim(*sm.simulate_dev(dyn, obs, T, B, seed=7), 1, 1, T, B)
+    rng = np.random.default_rng(123)
+    xr = np.zeros((T, B))
+    xr[0] = rng.standard_normal(B)
+    for k in range(1, T):
+        xr[k] = 0.5 * xr[k - 1] + 25 * xr[k - 1] / (1 + xr[k - 1] ** 2) + 8 * np.cos(1.2 * (k - 1)) + \
+            np.sqrt(10.0) * rng.standard_normal(B)
+    yr = 0.05 * xr ** 2 + rng.standard_normal((T, B))
+    for dev, ref in ((x[0], xr), (y[0], yr)):
+        se_mean = np.sqrt((dev.var(axis=1) + ref.var(axis=1)) / B)
+        assert np.all(np.abs(dev.mean(axis=1) - ref.mean(axis=1)) < 5 * se_mean)
+        m4 = ((ref - ref.mean(axis=1, keepdims=True)) ** 4).mean(axis=1)
+        se_var = np.sqrt(2 * (m4 - ref.var(axis=1) ** 2) / B)
+        assert np.all(np.abs(dev.var(axis=1) - ref.var(axis=1)) < 5 * se_var)
+    # a filter run on device-generated data behaves like on host-generated data
+    from ssmtoybox_amd import ssinf
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    fm, _ = alg.forward_pass_batch(y[:, :, :5000], raise_on_failure=False)
+    fr, _ = alg.forward_pass_batch(yr[None, :, :5000], raise_on_failure=False)
+    # NB the reference's convention: y[k] belongs to x[k] although the filter's first prediction runs from the prior
+    e_dev = np.sqrt(np.nanmean((fm[0] - x[0, :, :5000]) ** 2))
+    e_ref = np.sqrt(np.nanmean((fr[0] - xr[:, :5000]) ** 2))
+    assert abs(e_dev - e_ref) < 0.1 * e_ref
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # error statistics reduced on the device (utils.py:18-148 aggregated as research/tpq/tpq_base.py:154-172)
 # ---------------------------------------------------------------------------------------------------------------
 def _planes(a, ld):
