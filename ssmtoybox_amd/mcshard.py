@@ -33,6 +33,8 @@ def device_error_sums(D, B, ld, T, d_x, d_fm, d_fP, d_status=None):
     products (utils.py:41-64), n_ok (T,) trajectories counted, n_pd (T,) of them with positive-definite P (nll terms)."""
     lib = _lib.load()
     W = lib.ssmq_error_sums_width(D)
+    if W < 0:
+        raise _lib.SsmqError('ssmq_error_sums_width: dimension {} out of range'.format(D))
     sums, ps = _lib.out_c((T, W))
     _lib.check(lib.ssmq_error_sums_dev(D, B, ld, T, ctypes.c_void_p(d_x.ptr), ctypes.c_void_p(d_fm.ptr),
                                        ctypes.c_void_p(d_fP.ptr), ctypes.c_void_p(d_status.ptr if d_status else None),

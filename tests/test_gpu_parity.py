@@ -719,6 +719,38 @@ def test_error_sums_generic_dimension(amd):
     assert np.allclose(l['lcr'], ol['lcr'], rtol=1e-10) and np.array_equal(l['n'], ol['n'])
 
 
+def test_empty_inputs_of_the_caller_side_entry_points(amd):
+    """B = 0 / T = 0 / P = 0 through the entry points around the path: no launch, no error, well-formed outputs."""
+    from ssmtoybox_amd import ssinf, ssmod as sm, mcshard, _lib
+    dyn = sm.UNGMNATransition(sm.GaussRV(1, mean=np.array([1.0])), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMNAMeasurement(sm.GaussRV(1), 1)
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    fm, fP = alg.forward_pass_batch(np.zeros((1, 5, 0)))
+    assert fm.shape == (1, 5, 0) and fP.shape == (1, 1, 5, 0)
+    fm, fP = alg.forward_pass_batch(np.zeros((1, 0, 3)))
+    assert fm.shape == (1, 0, 3)
+    d = _lib.DeviceBuffer(8)
+    s = mcshard.device_error_sums(2, 0, 0, 4, d, d, d)
+    assert s['se'].shape == (4, 2) and not s['se'].any() and not s['n_ok'].any()
+    assert mcshard.device_error_sums(2, 0, 0, 0, d, d, d)['mse'].shape == (0, 2, 2)
+    assert mcshard.device_lcr_sums(2, 0, 0, 4, d, d, d, np.tile(np.eye(2), (4, 1, 1)))['lcr'].shape == (4,)
+    d.free()
+    dyn2 = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs2 = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    assert dyn2.simulate_discrete(5, 0).shape == (1, 5, 0) and dyn2.simulate_discrete(0, 3).shape == (1, 0, 3)
+    assert obs2.simulate_measurements(np.zeros((1, 4, 0))).shape == (1, 4, 0)
+    mg = ssinf.MarginalizedGaussianProcessKalman(dyn2, obs2, 'rbf', 'sr')
+    pm, pc, ll, st = mg.theta_step(np.zeros((0, mg.param_dim)), np.zeros(1), np.eye(1), np.zeros(1), 0)
+    assert pm.shape == (0, 1) and pc.shape == (0, 1, 1) and ll.shape == (0,) and st.shape == (0,)
+    # argument errors come back as SsmqError, not as a crash
+    d = _lib.DeviceBuffer(8 * 64 * 8)
+    with pytest.raises(_lib.SsmqError):
+        mcshard.device_error_sums(2, 10, 5, 1, d, d, d)          # pitch smaller than the batch
+    with pytest.raises(_lib.SsmqError):
+        mcshard.device_error_sums(40, 10, 64, 1, d, d, d)        # dimension above SSMQ_MAX_DIM
+    d.free()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # full-size batches (BASELINE.json configs): oracle on a sample + size-independent properties
 # ---------------------------------------------------------------------------------------------------------------
