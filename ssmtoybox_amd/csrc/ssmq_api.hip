@@ -751,7 +751,11 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
     }
     int rc = ensure_device();
     if (rc) return rc;
-    if (B == 0 || T == 0) return SSMQ_OK;
+    if (B == 0) return SSMQ_OK;
+    if (T == 0) {   // nothing to filter: every trajectory is trivially fine
+        SSMQ_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, stream()));
+        return SSMQ_OK;
+    }
     hipStream_t s = stream();
     // workspace carve-up (doubles first, then the two int32 status planes)
     const size_t n_dbl = (size_t)ld * (D + 3 * D * D + Y + Y * Y + Y * D) + 4 * (size_t)T + D * D + Y * Y;
@@ -907,8 +911,13 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
     }
     int rc = ensure_device();
     if (rc) return rc;
-    if (B == 0 || T == 0) return SSMQ_OK;
+    if (B == 0) return SSMQ_OK;
     hipStream_t s = stream();
+    if (T == 0) {
+        SSMQ_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, s));
+        SSMQ_HIP(hipStreamSynchronize(s));
+        return SSMQ_OK;
+    }
     DevBuf ws, st;
     const size_t n_noise = (size_t)dq + (dq ? (size_t)dq * dq : (size_t)D * D) + dr + (dr ? (size_t)dr * dr : (size_t)Y * Y);
     const size_t n_dbl = (size_t)ld * (Da + Da * Da + D + D * D + D * Da + Do + Do * Do + Y + Y * Y + Y * Do) + 3 * (size_t)T +
@@ -998,7 +1007,12 @@ extern "C" int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integran
     }
     int rc = ensure_device();
     if (rc) return rc;
-    if (B == 0 || T == 0) return SSMQ_OK;
+    if (B == 0) return SSMQ_OK;
+    if (T == 0) {
+        if (d_status) SSMQ_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, stream()));
+        SSMQ_HIP(hipStreamSynchronize(stream()));
+        return SSMQ_OK;
+    }
     const int D = h_dyn->D;
     DevBuf pm, pP, pC;
     if ((rc = pm.alloc(sizeof(double) * (size_t)T * D * ld)) || (rc = pP.alloc(sizeof(double) * (size_t)T * D * D * ld)) ||

@@ -65,6 +65,46 @@ struct ApplyArgs {
 // selected as scalar loads (s_load), even after the kernel has started storing its outputs.
 #define SSMQ_PK(i, j) ((i) * ((i) + 1) / 2 + (j))  // packed lower-triangular index, j <= i
 
+// Square root, reciprocal square root and quotient for operands in the normal range (covariance pivots, 1 + x^2, ...).
+// hipcc expands sqrt() / operator/ on doubles into the same v_rsq_f64 / v_rcp_f64 + FMA refinement, wrapped in range
+// rescaling (v_div_scale / v_div_fmas / v_div_fixup, ldexp + class tests: 7-8 more instructions and 2-4 more steps on the
+// dependent chain each).  The recursions of the fused filter are bound by exactly that chain, so the hot callers use
+// these: results within 1 ulp of the correctly rounded ones for |x| in [2^-500, 2^500]; a non-positive pivot still
+// comes out NaN / flagged.  SSMQ_IEEE_DIVSQRT=1 at build time restores the compiler's sequences.
+#ifndef SSMQ_IEEE_DIVSQRT
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    s = g;
+    const double r2 = fma(-h, g, 0.5);   // h -> 1 / (2 sqrt x) once more, against the final g
+    h = fma(h, r2, h);
+    rs = h + h;
+}
+__device__ __forceinline__ double div_nr(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    const double q = a * r;
+    e = fma(-b, q, a);
+    return fma(e, r, q);
+}
+#else
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
+    s = sqrt(x);
+    rs = 1.0 / s;
+}
+__device__ __forceinline__ double div_nr(double a, double b) { return a / b; }
+#endif
+
 // In-register lower Cholesky of a packed symmetric matrix, column by column with reciprocal scaling, the operation
 // order of LAPACK dpotf2 'L' that numpy.linalg.cholesky ends in (bq/bqmtran.py:98).  Returns false at the first
 // non-positive (or NaN) pivot - where the reference raises LinAlgError.
@@ -77,9 +117,9 @@ __device__ __forceinline__ bool chol_packed(double (&L)[D * (D + 1) / 2]) {
 #pragma unroll
         for (int k = 0; k < j; ++k) ajj -= L[SSMQ_PK(j, k)] * L[SSMQ_PK(j, k)];
         ok = ok && (ajj > 0.0);
-        ajj = sqrt(ajj);
+        double r;
+        sqrt_rsqrt(ajj, ajj, r);
         L[SSMQ_PK(j, j)] = ajj;
-        const double r = 1.0 / ajj;
 #pragma unroll
         for (int i = j + 1; i < D; ++i) {
             double s = L[SSMQ_PK(i, j)];
@@ -108,7 +148,7 @@ struct Fn<SSMQ_F_UNGM_DYN> {
     }
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {
-        o[0] = 0.5 * x[0] + 25.0 * (x[0] / (1.0 + x[0] * x[0])) + c;
+        o[0] = 0.5 * x[0] + 25.0 * div_nr(x[0], 1.0 + x[0] * x[0]) + c;
     }
 };
 template <>
@@ -129,7 +169,7 @@ struct Fn<SSMQ_F_UNGMNA_DYN> {
     }
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {
-        o[0] = 0.5 * x[0] + 25.0 * (x[0] / (1.0 + x[0] * x[0])) + 8.0 * x[1] * c;
+        o[0] = 0.5 * x[0] + 25.0 * div_nr(x[0], 1.0 + x[0] * x[0]) + 8.0 * x[1] * c;
     }
 };
 template <>

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
         // scalar measurement: one division instead of factor + two substitutions (same shortcut as k_filter_fused)
         ok = S[0] > 0.0;
 #pragma unroll
-        for (int d = 0; d < D; ++d) G[d][0] = a.P_yx[d * ld + b] / S[0];   // (Y == 1: row 0 only)
+        for (int d = 0; d < D; ++d) G[d][0] = div_nr(a.P_yx[d * ld + b], S[0]);   // (Y == 1: row 0 only)
     } else {
         ok = chol_packed<Y>(S);
 #pragma unroll
@@ -55,14 +55,14 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
                 double s = a.P_yx[(i * a.Dx + d) * ld + b];
 #pragma unroll
                 for (int k = 0; k < i; ++k) s -= S[SSMQ_PK(i, k)] * v[k];
-                v[i] = s / S[SSMQ_PK(i, i)];
+                v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
             }
 #pragma unroll
             for (int i = Y - 1; i >= 0; --i) {
                 double s = v[i];
 #pragma unroll
                 for (int k = i + 1; k < Y; ++k) s -= S[SSMQ_PK(k, i)] * v[k];
-                v[i] = s / S[SSMQ_PK(i, i)];
+                v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
             }
 #pragma unroll
             for (int i = 0; i < Y; ++i) G[d][i] = v[i];
@@ -84,14 +84,14 @@ __global__ __launch_bounds__(kUpdBlock) void k_kalman_update(const UpdArgs a) {
         // delta = chol(P_y)^-1 (y - y_mean)   (ssinf.py:729-731)
         double dl[Y], dd = 0.0;
         if (Y == 1) {
-            dd = dy[0] * dy[0] / S[0];
+            dd = div_nr(dy[0] * dy[0], S[0]);
         } else {
 #pragma unroll
             for (int i = 0; i < Y; ++i) {
                 double s = dy[i];
 #pragma unroll
                 for (int k = 0; k < i; ++k) s -= S[SSMQ_PK(i, k)] * dl[k];
-                dl[i] = s / S[SSMQ_PK(i, i)];
+                dl[i] = div_nr(s, S[SSMQ_PK(i, i)]);
                 dd += dl[i] * dl[i];
             }
         }
@@ -378,14 +378,14 @@ __global__ __launch_bounds__(kUpdBlock) void k_rts_backward(const RtsArgs a) {
                 double s = a.pC[((int64_t)k * D * D + i * D + d) * ld + b];
 #pragma unroll
                 for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * v[q];
-                v[i] = s / S[SSMQ_PK(i, i)];
+                v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
             }
 #pragma unroll
             for (int i = D - 1; i >= 0; --i) {
                 double s = v[i];
 #pragma unroll
                 for (int q = i + 1; q < D; ++q) s -= S[SSMQ_PK(q, i)] * v[q];
-                v[i] = s / S[SSMQ_PK(i, i)];
+                v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
             }
 #pragma unroll
             for (int i = 0; i < D; ++i) G[d][i] = v[i];

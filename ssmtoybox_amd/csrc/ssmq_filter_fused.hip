@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
             // (sqrt + two divisions by it) would only lengthen the serial dependency chain of the time loop
             ok = (S[0] > 0.0) && ok;
 #pragma unroll
-            for (int d = 0; d < D; ++d) G[d][0] = ob.cx[0][d] / S[0];
+            for (int d = 0; d < D; ++d) G[d][0] = div_nr(ob.cx[0][d], S[0]);
         } else {
             ok = chol_packed<Y>(S) && ok;
 #pragma unroll
@@ -114,14 +114,14 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
                     double s = ob.cx[i][d];
 #pragma unroll
                     for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * v[q];
-                    v[i] = s / S[SSMQ_PK(i, i)];
+                    v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
                 }
 #pragma unroll
                 for (int i = Y - 1; i >= 0; --i) {
                     double s = v[i];
 #pragma unroll
                     for (int q = i + 1; q < Y; ++q) s -= S[SSMQ_PK(q, i)] * v[q];
-                    v[i] = s / S[SSMQ_PK(i, i)];
+                    v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
                 }
 #pragma unroll
                 for (int i = 0; i < Y; ++i) G[d][i] = v[i];
@@ -134,14 +134,14 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
             double dl[Y], dd = 0.0;
             if (Y == 1) {
                 const double dy0 = ycur[0] - ob.mf[0];
-                dd = dy0 * dy0 / S[0];
+                dd = div_nr(dy0 * dy0, S[0]);
             } else {
 #pragma unroll
                 for (int i = 0; i < Y; ++i) {
                     double s = ycur[i] - ob.mf[i];
 #pragma unroll
                     for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * dl[q];
-                    dl[i] = s / S[SSMQ_PK(i, i)];
+                    dl[i] = div_nr(s, S[SSMQ_PK(i, i)]);
                     dd += dl[i] * dl[i];
                 }
             }
