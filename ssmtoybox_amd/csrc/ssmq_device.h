@@ -66,11 +66,14 @@ struct ApplyArgs {
 #define SSMQ_PK(i, j) ((i) * ((i) + 1) / 2 + (j))  // packed lower-triangular index, j <= i
 
 // Square root, reciprocal square root and quotient for operands in the normal range (covariance pivots, 1 + x^2, ...).
-// hipcc expands sqrt() / operator/ on doubles into the same v_rsq_f64 / v_rcp_f64 + FMA refinement, wrapped in range
-// rescaling (v_div_scale / v_div_fmas / v_div_fixup, ldexp + class tests: 7-8 more instructions and 2-4 more steps on the
-// dependent chain each).  The recursions of the fused filter are bound by exactly that chain, so the hot callers use
-// these: results within 1 ulp of the correctly rounded ones for |x| in [2^-500, 2^500]; a non-positive pivot still
-// comes out NaN / flagged.  SSMQ_IEEE_DIVSQRT=1 at build time restores the compiler's sequences.
+// hipcc expands sqrt() / operator/ on doubles into v_rsq_f64 / v_rcp_f64 + FMA refinement wrapped in range rescaling
+// (v_div_scale / v_div_fmas / v_div_fixup, ldexp + class tests) with two refinement rounds: 12 instructions per
+// division, 17 per square root, most of them on the dependent chain.  Measured on gfx950 (tools/micro/rcp_acc.hip):
+// both seeds are accurate to 2^-24.2, so ONE Newton / Goldschmidt round (2^-48) plus the residual correction already
+// lands on the correctly rounded result - bit-identical to the compiler's sequence on 5e7 operands in [1e-6, 1e9].
+// The recursions of the fused filter are bound by exactly this chain, so the hot callers use these (6 and 8
+// instructions).  Valid for |x| in [2^-500, 2^500]; a non-positive pivot still comes out NaN / flagged.
+// SSMQ_IEEE_DIVSQRT=1 at build time restores the compiler's sequences.
 #ifndef SSMQ_IEEE_DIVSQRT
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
     const double y = __builtin_amdgcn_rsq(x);
@@ -78,9 +81,7 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
-    double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    d = fma(-g, g, x);
+    const double d = fma(-g, g, x);
     g = fma(d, h, g);
     s = g;
     const double r2 = fma(-h, g, 0.5);   // h -> 1 / (2 sqrt x) once more, against the final g
@@ -90,8 +91,6 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs) {
 __device__ __forceinline__ double div_nr(double a, double b) {
     double r = __builtin_amdgcn_rcp(b);
     double e = fma(-b, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-b, r, 1.0);
     r = fma(r, e, r);
     const double q = a * r;
     e = fma(-b, q, a);
