@@ -232,8 +232,8 @@ struct ReentryCore {
         // exp((R0 - R) / H0) are one exp of the summed argument, and R, 1 / R^3 come from one reciprocal square root
         // (differences from the reference's evaluation order are a few ulp, far inside the 1e-10 parity bar).
         const double r2 = x[0] * x[0] + x[1] * x[1];
-        const double ir = rsqrt(r2);
-        const double rr = r2 * ir;
+        double rr, ir;          // the radius is never near zero on this model (Earth radius 6374): normal-range helper
+        sqrt_rsqrt(r2, rr, ir);
         const double vv = sqrt(x[2] * x[2] + x[3] * x[3]);
         const double dr = b0 * exp(x[4] + (r0 - rr) * (1.0 / h0)) * vv;
         const double gr = -gm0 * (ir * ir * ir);
