@@ -404,6 +404,7 @@ def main():
         cb, (cpu_fm, cpu_st) = cpu_baseline_ungm(B, T, seed=1 + rank, tf=wl.alg.tf_dyn)
         out['cpu_baseline'] = cb
         # the GPU pass and the CPU port ran the same trajectories: cross-check them
+        fm, _, st = wl.results()
         good = (st == 0) & (cpu_st == 0)
         rel = np.abs(fm[0][:, good] - cpu_fm[:, good]) / np.max(np.abs(cpu_fm[:, good]))
         # identical weights and measurements; the UNGM recursion amplifies rounding differences along a trajectory

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -q -m gpu -x --timeout 300 > gpurun_out/pytest_q.log 2>&1; rc=$?; tail -3 gpurun_out/pytest_q.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/bench_q.json 2> gpurun_out/bench_q.err || { tail -5 gpurun_out/bench_q.err; exit 1; }
+timeout -k 10 300 python bench.py > gpurun_out/bench_q.json 2> gpurun_out/bench_q.err || { tail -5 gpurun_out/bench_q.err; exit 1; }
 python - <<'PY'
 import json
 d = json.load(open('gpurun_out/bench_q.json'))
