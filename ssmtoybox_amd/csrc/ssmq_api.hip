@@ -719,7 +719,8 @@ struct FilterCache {
     hipGraphExec_t exec = nullptr;
     std::vector<uint64_t> key;
     std::vector<double> gqg, rr, ss;
-    int T = -1, fid_dyn = -1, fid_obs = -1;
+    int T = -1, fid_dyn = -1, fid_obs = -1, D = -1, Y = -1;
+    int64_t ld = -1;          // the constants sit behind the ld-sized planes: a new pitch moves them
     bool consts_ok = false;
     void drop_graph() {
         if (exec) hipGraphExecDestroy(exec);
@@ -810,7 +811,7 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
     std::vector<double> htd(T), hto(T);
     const bool has_td = time_table(f_dyn->id, T, htd.data()), has_to = time_table(f_obs->id, T, hto.data());
     if (!(g_fc.consts_ok && g_fc.gqg == hg && g_fc.rr == hr && g_fc.T == T && g_fc.ss == hs &&
-          g_fc.fid_dyn == f_dyn->id && g_fc.fid_obs == f_obs->id)) {
+          g_fc.fid_dyn == f_dyn->id && g_fc.fid_obs == f_obs->id && g_fc.ld == ld && g_fc.D == D && g_fc.Y == Y)) {
         g_fc.drop_graph();
         std::vector<double> tv(T);
         for (int k = 0; k < T; ++k) tv[k] = (double)k;  // both transforms of step k + 1 use time index k (ssinf.py:104)
@@ -827,6 +828,9 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
         g_fc.gqg = hg;
         g_fc.rr = hr;
         g_fc.T = T;
+        g_fc.ld = ld;
+        g_fc.D = D;
+        g_fc.Y = Y;
         g_fc.consts_ok = true;
     }
     // one fused kernel for the whole time loop when this (models, shapes, form) combination has one (it does not keep

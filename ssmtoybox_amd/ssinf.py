@@ -119,6 +119,36 @@ class GaussianInference:
         self.forward_pass_batch(self._data, smooth=True)
         return self.sm_mean, self.sm_cov
 
+    def forward_pass_dev(self, d_y, B, ld, T):
+        """Filter measurements that are already on the device (planes [T][dim_y][ld], e.g. from `ssmod.simulate_dev`)
+        and leave the results there: returns DeviceBuffers (d_fm [T][D][ld], d_fP [T][D*D][ld], d_status [ld]) for
+        `mcshard.device_error_sums`; the caller frees them.  Every trajectory starts from the model's initial moments."""
+        lib = _lib.load()
+        D = self.mod_dyn.dim_state
+        mrow = np.ascontiguousarray(np.repeat(np.asarray(self.x0_mean, dtype=np.float64).reshape(D, 1), 64, axis=1))
+        Prow = np.ascontiguousarray(np.repeat(np.asarray(self._initial_cov(), dtype=np.float64).reshape(D * D, 1), 64,
+                                              axis=1))
+        d_m0, d_P0 = _lib.DeviceBuffer(8 * D * ld), _lib.DeviceBuffer(8 * D * D * ld)
+        for host, dev, n in ((mrow, d_m0, D), (Prow, d_P0, D * D)):       # one 64-lane tile per plane, doubled on the device
+            for e in range(n):
+                dev.upload(host[e], byte_offset=8 * e * ld)
+                done = 64
+                while done < ld:
+                    step = min(done, ld - done)
+                    _lib.check(lib.ssmq_memcpy_d2d(dev.at(8 * (e * ld + done)), dev.at(8 * e * ld),
+                                                   ctypes.c_size_t(8 * step)), 'ssmq_memcpy_d2d')
+                    done += step
+        d_fm, d_fP = _lib.DeviceBuffer(8 * T * D * ld), _lib.DeviceBuffer(8 * T * D * D * ld)
+        d_st = _lib.DeviceBuffer(4 * ld)
+        f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
+        f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
+        h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
+        self._launch(lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st)
+        _lib.sync()
+        d_m0.free()
+        d_P0.free()
+        return d_fm, d_fP, d_st
+
     def forward_pass_batch(self, data, x0_mean=None, x0_cov=None, raise_on_failure=True, smooth=False):
         """data (dim_y, T, B).  Optional per-trajectory initial moments x0_mean (B, D), x0_cov (B, D, D)."""
         lib = _lib.load()

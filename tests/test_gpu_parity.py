@@ -7,6 +7,8 @@ Bar: 1e-10 relative in fp64 (scales defined in tests/_cases.py: moment_scales); 
 reproducible only to cond(K) eps / cond(K)^2 eps and are checked against that.
 All tests need a real MI355X.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -915,6 +917,112 @@ def test_device_resident_api_with_padded_pitch(amd):
     planes = cf.buf.download((D * D, ld))
     assert np.all(planes[:, B:] == 7.25)                       # nothing written beyond the batch
     assert not st.download((ld,), dtype=np.int32)[:B].any()
+
+
+def test_sixteen_million_trajectories_64bit_offsets(amd):
+    """Maximum-size case: B = 1.6e7 at D = E = 6 (5.4 GB in, 10 GB out; element offsets inside one buffer pass 2^32
+    bytes).  The batch is a 65 536-trajectory block tiled on the device; every sampled tile must reproduce the block's
+    own result bit for bit, first to last lane."""
+    from ssmtoybox_amd import _lib, ssmod as sm
+    lib = _lib.load()
+    D, b0, B = 6, 65536, 16000000
+    means, covs = synthetic_reentry6(b0, seed=4)
+    tf = amd.GaussianProcessTransform(6, 6, np.array([[1.0] + [3.0] * 6]), 'rbf', 'ut')
+    f = sm.ReentryVehicle2DBiasTransition(dt=0.1).dyn_eval
+    small = [_lib.SoA.from_host(means), _lib.SoA.from_host(covs)]
+    big = [_lib.SoA(D, B), _lib.SoA(D * D, B)]
+    assert big[1].ld == B and 8 * 35 * B > 2 ** 32
+    tiles = [(lo, min(b0, B - lo)) for lo in range(0, B, b0)]
+    for src, dst in zip(small, big):
+        for e in range(src.n):
+            for lo, n in tiles:
+                _lib.check(lib.ssmq_memcpy_d2d(dst.buf.at(8 * (e * dst.ld + lo)), src.buf.at(8 * e * src.ld),
+                                               ctypes.c_size_t(8 * n)), 'ssmq_memcpy_d2d')
+    tbuf = _lib.DeviceBuffer(8)
+    tbuf.upload(np.zeros(1))
+
+    def run(inp, nb):
+        out = [_lib.SoA(D, nb), _lib.SoA(D * D, nb), _lib.SoA(D * D, nb)]
+        st = _lib.DeviceBuffer(4 * out[0].ld)
+        tf.apply_batch_dev(f, inp[0], inp[1], tbuf, out[0], out[1], out[2], st, 0)
+        _lib.sync()
+        first = ctypes.c_int64(-1)
+        _lib.check(lib.ssmq_status_first(ctypes.c_void_p(st.ptr), nb, ctypes.byref(first)), 'ssmq_status_first')
+        assert first.value < 0
+        st.free()
+        return out
+    ref = [o.buf.download((o.n, o.ld)) for o in run(small, b0)]
+    out = run(big, B)
+    for lo, n in (tiles[0], tiles[len(tiles) // 2], tiles[-2], tiles[-1]):
+        for o, r in zip(out, ref):
+            for e in (0, o.n // 2, o.n - 1):
+                got = o.buf.download((n,), byte_offset=8 * (e * o.ld + lo))
+                assert np.array_equal(got, r[e, :n]), (lo, e)
+    for buf in small + big + out:
+        buf.buf.free()
+
+
+def test_filter_calls_with_changing_batch_size(amd, golden):
+    """The filter loop keeps its workspace and constants between calls: a call with another batch size (another pitch,
+    hence another carve-up of the workspace) must not leave the next one with stale constants."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    y = golden('g4_filters')['ungm_y']                     # (1, T, 8)
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    par = np.array([[1.0, 3.0]])
+    for alg in (ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut'), ssinf.GaussHermiteKalman(dyn, obs, deg=5)):
+        first = alg.forward_pass_batch(y)
+        alg.forward_pass_batch(np.tile(y, (1, 1, 700)))    # 5600 trajectories: larger pitch, workspace regrown
+        again = alg.forward_pass_batch(y)
+        assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+        one = alg.forward_pass_batch(y[..., :1])
+        assert np.array_equal(one[0][..., 0], first[0][..., 0])
+
+
+def test_device_resident_study_at_scale(amd):
+    """Simulate -> filter -> error statistics without touching the host, B = 6.4e6 UNGM trajectories x T = 100
+    (5 GB per buffer: plane offsets pass 2^32 bytes).  Trajectories are named by their global index, so the first and
+    the last 65 536 of the big run must equal two small runs bit for bit, and the sums of the two halves of a mid-size
+    run must add up."""
+    from ssmtoybox_amd import ssinf, ssmod as sm, mcshard
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    par = np.array([[1.0, 3.0]])
+    alg = ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut')
+    T, B, b0, seed = 100, 6400000, 65536, 31
+    assert 8 * T * B > 2 ** 32
+
+    def study(nb, offset):
+        d_x, d_y, ld = sm.simulate_dev(dyn, obs, T, nb, seed=seed, traj_offset=offset)
+        d_fm, d_fP, d_st = alg.forward_pass_dev(d_y, nb, ld, T)
+        return dict(x=d_x, y=d_y, fm=d_fm, fP=d_fP, st=d_st, ld=ld, nb=nb)
+
+    def free(r):
+        for k in ('x', 'y', 'fm', 'fP', 'st'):
+            r[k].free()
+    big = study(B, 0)
+    s_big = mcshard.device_error_sums(1, B, big['ld'], T, big['x'], big['fm'], big['fP'], big['st'])
+    assert np.all(s_big['n_ok'] + (B - s_big['n_ok'][0]) == B) and s_big['n_ok'][0] > 0.99 * B
+    for offset in (0, B - b0):
+        small = study(b0, offset)
+        for key in ('y', 'fm', 'fP'):
+            for t in (0, T // 2, T - 1):
+                a = big[key].download((b0,), byte_offset=8 * (t * big['ld'] + offset))
+                assert np.array_equal(a, small[key].download((b0,), byte_offset=8 * t * small['ld']),
+                                      equal_nan=True), (key, t, offset)
+        sa = big['st'].download((b0,), dtype=np.int32, byte_offset=4 * offset)
+        assert np.array_equal(sa, small['st'].download((b0,), dtype=np.int32))
+        free(small)
+    free(big)
+    # additivity of the device sums over a split by global index
+    whole, lo, hi = study(200000, 0), study(120000, 0), study(80000, 120000)
+    sums = [mcshard.device_error_sums(1, r['nb'], r['ld'], T, r['x'], r['fm'], r['fP'], r['st']) for r in (whole, lo, hi)]
+    for k in sums[0]:
+        assert np.allclose(sums[1][k] + sums[2][k], sums[0][k], rtol=1e-11, atol=1e-9), k
+    rm = mcshard.finalize(sums[0])['rmse_total']
+    assert 5.0 < rm < 20.0          # the known behaviour of this filter on UNGM (bench.py reports ~12.4)
+    for r in (whole, lo, hi):
+        free(r)
 
 
 def test_weights_can_be_replaced_after_construction(amd):
