@@ -124,3 +124,19 @@ def test_product_never_imports_oracle():
             if fn.endswith(('.py', '.hip', '.h', '.cpp')):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert 'ssmq_oracle' not in src and 'from oracle' not in src and 'import oracle' not in src, fn
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ssmq.h is the C ABI: it must compile as C99 (no C++ constructs, no torch / HIP types in signatures)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / 't.c'
+    src.write_text('#include "ssmq.h"\nint main(void) { return ssmq_version() == 0; }\n')
+    res = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(root, 'include'),
+                          '-c', str(src), '-o', str(tmp_path / 't.o')], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    hdr = open(os.path.join(root, 'include', 'ssmq.h')).read()
+    assert 'torch' not in hdr and 'hipStream' not in hdr and 'at::' not in hdr
