@@ -261,6 +261,20 @@ int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_
                        double *post_cov, double *loglik, int32_t *status);
 
 /*
+ * Unit sigma-point sets and classical quadrature weights, host code (no device needed):
+ *   SSMQ_PTS_UT  unscented, 2D+1 points    mtran.py:234-293   par = [kappa, alpha, beta]   (NaN / missing: max(3-D,0), 1, 2)
+ *   SSMQ_PTS_SR  spherical-radial, 2D      mtran.py:171-204   par = []
+ *   SSMQ_PTS_GH  Gauss-Hermite, degree^D   mtran.py:315-360   par = [degree]               (default 3)
+ *   SSMQ_PTS_FS  fully symmetric Student   mtran.py:405-578   par = [degree 3|5, kappa, dof] (defaults 3, max(3-D,0), 4)
+ * BQ models use the points only (bq/bqmod.py:340-382).  ssmq_points_count returns N (or < 0); ssmq_points fills
+ * xi [D*N] (row-major (D, N), the reference's column order), wm [N] mean weights, wc [N] covariance weights (any may be
+ * NULL) and returns N.
+ */
+enum ssmq_point_kind { SSMQ_PTS_UT = 0, SSMQ_PTS_SR = 1, SSMQ_PTS_GH = 2, SSMQ_PTS_FS = 3 };
+int ssmq_points_count(int kind, int D, const double *par, int n_par);
+int ssmq_points(int kind, int D, const double *par, int n_par, double *xi, double *wm, double *wc);
+
+/*
  * Synthetic trajectories and measurements generated on the device, in the filter's plane layout
  * (TransitionModel.simulate_discrete ssmod.py:168-199, MeasurementModel.simulate_measurements ssmod.py:1011-1039):
  *   x[0] = x0_mean + x0_chol z;  x[k] = dyn_fcn(x[k-1], q[k-1], k-1);  y[k] = meas_fcn(x[k], r[k], k+1),

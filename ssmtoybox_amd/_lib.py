@@ -122,6 +122,9 @@ _PROTOTYPES = {
                                           ctypes.c_double, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int,
                                           ctypes.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                           c_int32_p]),
+    'ssmq_points_count': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int]),
+    'ssmq_points': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, c_double_p,
+                                   c_double_p]),
     'ssmq_simulate_dev': (ctypes.c_int, [ctypes.POINTER(Integrand), ctypes.POINTER(Integrand), ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p,

@@ -140,3 +140,52 @@ def test_header_is_plain_c(tmp_path):
     assert res.returncode == 0, res.stderr
     hdr = open(os.path.join(root, 'include', 'ssmq.h')).read()
     assert 'torch' not in hdr and 'hipStream' not in hdr and 'at::' not in hdr
+
+
+def test_c_abi_point_sets_match_reference(golden):
+    """ssmq_points (host code inside libssmq: runs without a GPU) against the reference's point sets and weights (G1)."""
+    from ssmtoybox_amd import _lib
+    lib = _lib.load()
+    g = golden('g1_points')
+    nan = float('nan')
+
+    def rule(kind, d, par):
+        par = np.asarray(par, dtype=np.float64)
+        pp = par.ctypes.data_as(_lib.c_double_p) if par.size else None
+        n = lib.ssmq_points_count(kind, d, pp, par.size)
+        assert n > 0
+        xi, wm, wc = np.empty((d, n)), np.empty(n), np.empty(n)
+        assert lib.ssmq_points(kind, d, pp, par.size, xi.ctypes.data_as(_lib.c_double_p),
+                               wm.ctypes.data_as(_lib.c_double_p), wc.ctypes.data_as(_lib.c_double_p)) == n
+        return xi, wm, wc
+    UT, SR, GH, FS = 0, 1, 2, 3
+    for d in (1, 2, 3, 5, 6, 10):
+        for kappa in (None, 0.0, 2.0):
+            tag = 'ut_d{}_k{}'.format(d, 'none' if kappa is None else int(kappa))
+            xi, wm, wc = rule(UT, d, [] if kappa is None else [kappa])
+            assert np.array_equal(xi, g[tag + '_pts']) and np.array_equal(wm, g[tag + '_wm'])
+            assert np.array_equal(wc, g[tag + '_wc'])
+        xi, wm, wc = rule(UT, d, [1.0, 0.5, 1.0])
+        assert np.array_equal(xi, g['ut_d{}_a05_pts'.format(d)]) and np.array_equal(wm, g['ut_d{}_a05_wm'.format(d)])
+        assert np.array_equal(wc, g['ut_d{}_a05_wc'.format(d)])
+        xi, wm, _ = rule(SR, d, [])
+        assert np.array_equal(xi, g['sr_d{}_pts'.format(d)]) and np.array_equal(wm, g['sr_d{}_w'.format(d)])
+        for deg in (3, 5):
+            xi, wm, _ = rule(FS, d, [deg])
+            assert np.array_equal(xi, g['fs_d{}_deg{}_pts'.format(d, deg)])
+            assert np.allclose(wm, g['fs_d{}_deg{}_w'.format(d, deg)], rtol=1e-14, atol=0)
+        xi, wm, _ = rule(FS, d, [5, nan, 7.0])
+        assert np.array_equal(xi, g['fs_d{}_deg5_dof7_pts'.format(d)])
+        assert np.allclose(wm, g['fs_d{}_deg5_dof7_w'.format(d)], rtol=1e-14, atol=0)
+        xi, wm, _ = rule(FS, d, [3, 1.0, 6.0])
+        assert np.array_equal(xi, g['fs_d{}_deg3_k1_pts'.format(d)]) and np.array_equal(wm, g['fs_d{}_deg3_k1_w'.format(d)])
+    for d, degs in ((1, (3, 5, 7)), (2, (3, 5, 7)), (3, (3, 5)), (5, (3,))):
+        for deg in degs:
+            xi, wm, _ = rule(GH, d, [deg])
+            # the reference takes the roots from numpy's companion-matrix eigenvalues; two root finders agree to ~1e-15
+            assert np.allclose(xi, g['gh_d{}_deg{}_pts'.format(d, deg)], rtol=0, atol=4e-15)
+            assert np.allclose(wm, g['gh_d{}_deg{}_w'.format(d, deg)], rtol=1e-13, atol=0)
+            assert abs(wm.sum() - 1) < 1e-14
+    # argument errors
+    assert lib.ssmq_points_count(9, 2, None, 0) < 0 and lib.ssmq_points_count(UT, 0, None, 0) < 0
+    assert lib.ssmq_points_count(GH, 10, np.array([7.0]).ctypes.data_as(_lib.c_double_p), 1) < 0     # 7^10 points
