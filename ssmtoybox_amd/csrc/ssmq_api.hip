@@ -199,6 +199,16 @@ static int upload_consts(ssmq_transform *h) {
             s[cs.utc] = cc;
         }
     }
+    std::vector<double> wpad;
+    const int np = sigma ? 0 : gemm_mfma_padded(N);
+    if (np && !getenv("SSMQ_NO_MFMA")) {
+        wpad.assign((size_t)np * np, 0.0);
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) wpad[(size_t)i * np + j] = h->Wc[i * N + j];
+        if (!h->d_wc_pad) SSMQ_HIP(hipMalloc(&h->d_wc_pad, sizeof(double) * np * np));
+        h->np_pad = np;
+        SSMQ_HIP(hipMemcpyAsync(h->d_wc_pad, wpad.data(), sizeof(double) * np * np, hipMemcpyHostToDevice, stream()));
+    }
     SSMQ_HIP(hipMemcpyAsync(h->d_small, s.data(), sizeof(double) * cs.total, hipMemcpyHostToDevice, stream()));
     SSMQ_HIP(hipMemcpyAsync(h->d_wide, w.data(), sizeof(double) * cw.total, hipMemcpyHostToDevice, stream()));
     SSMQ_HIP(hipStreamSynchronize(stream()));
@@ -254,6 +264,29 @@ static int check_integrand(const ssmq_transform *h, const ssmq_integrand *f, FIn
     return SSMQ_OK;
 }
 
+// Grow-only scratch of the matrix-core route (asynchronous callers cannot own temporaries): FX and T = FX Wc as
+// (B E) x NP row-major, the Cholesky factors [B][D][D].
+constexpr int64_t kGemmMinRows = 256;
+static void *g_gemm_ws = nullptr;
+static size_t g_gemm_ws_bytes = 0;
+static int gemm_scratch(int64_t M, int NP, int64_t B, int D, double **fx, double **tt, double **chol) {
+    const size_t n_fx = (size_t)M * NP, need = sizeof(double) * (2 * n_fx + (size_t)B * D * D);
+    if (g_gemm_ws_bytes < need) {
+        if (g_gemm_ws) {
+            SSMQ_HIP(hipStreamSynchronize(stream()));
+            hipFree(g_gemm_ws);
+        }
+        g_gemm_ws = nullptr;
+        g_gemm_ws_bytes = 0;
+        SSMQ_HIP(hipMalloc(&g_gemm_ws, need));
+        g_gemm_ws_bytes = need;
+    }
+    *fx = (double *)g_gemm_ws;
+    *tt = *fx + n_fx;
+    *chol = *tt + n_fx;
+    return SSMQ_OK;
+}
+
 int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
                    const double *d_cov, const double *d_time, int time_stride, double *d_mean_f, double *d_cov_f,
                    double *d_cov_fx, int32_t *d_status, const double *d_cov_add, const char **kernel_name,
@@ -302,6 +335,19 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     a.status = d_status;
     fill_fpar(f, &a.fp);
     a.fp.ttab = ttab;
+    if (h->d_wc_pad && h->form == SSMQ_FORM_BQ && B * h->E >= kGemmMinRows) {
+        // large point set: integrand values of the whole batch -> one GEMM on the matrix cores -> per-trajectory rest
+        const int NP = h->np_pad;
+        const int64_t M = B * h->E;
+        double *fx, *tt, *chol;
+        if ((rc = gemm_scratch(M, NP, B, h->D, &fx, &tt, &chol))) return rc;
+        WideArgs e = a;
+        e.mode = SSMQ_WIDE_EVAL; e.fx_ld = NP; e.fx_out = fx; e.chol_out = chol;
+        if ((rc = hip_fail(launch_apply_wide(e, B, stream()), "k_apply_wide(eval)"))) return rc;
+        if ((rc = launch_fxwc_mfma(NP, fx, h->d_wc_pad, tt, M, NP, NP, stream()))) return rc;
+        a.mode = SSMQ_WIDE_FX; a.fx_ld = NP; a.fx_in = fx; a.t_in = tt; a.chol_in = chol; a.status = nullptr;
+        return hip_fail(launch_apply_wide(a, B, stream()), "k_apply_wide(fx + T)");
+    }
     return hip_fail(launch_apply_wide(a, B, stream()), "k_apply_wide");
 }
 
@@ -508,6 +554,7 @@ void ssmq_transform_destroy(ssmq_transform *h) {
     if (!h) return;
     if (h->d_small) hipFree(h->d_small);
     if (h->d_wide) hipFree(h->d_wide);
+    if (h->d_wc_pad) hipFree(h->d_wc_pad);
     delete h;
 }
 
@@ -666,6 +713,18 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
     a.consts = h->d_wide; a.mean = dm.d(); a.chol_in = dl.d(); a.fx_in = dfx.d(); a.x_in = dx.d();
     a.mean_f = omf.d(); a.cov_f = ocf.d(); a.cov_fx = ocfx.d(); a.es_out = 1; a.bs_mf = E; a.bs_cf = E * E;
     a.bs_cfx = E * D;
+    DevBuf fxp, ttp;
+    if (h->d_wc_pad && h->form == SSMQ_FORM_BQ && B * E >= kGemmMinRows) {
+        // matrix-core route: rows re-pitched to the padded column count, T = FX Wc for the whole batch, then the rest
+        const int NP = h->np_pad;
+        const int64_t M = B * E;
+        if ((rc = fxp.alloc(sizeof(double) * M * NP)) || (rc = ttp.alloc(sizeof(double) * M * NP))) return rc;
+        SSMQ_HIP(hipMemsetAsync(fxp.p, 0, sizeof(double) * M * NP, s));
+        SSMQ_HIP(hipMemcpy2DAsync(fxp.p, sizeof(double) * NP, dfx.p, sizeof(double) * N, sizeof(double) * N, M,
+                                  hipMemcpyDeviceToDevice, s));
+        if ((rc = launch_fxwc_mfma(NP, fxp.d(), h->d_wc_pad, ttp.d(), M, NP, NP, s))) return rc;
+        a.fx_ld = NP; a.fx_in = fxp.d(); a.t_in = ttp.d();
+    }
     if ((rc = hip_fail(launch_apply_wide(a, B, s), "k_apply_wide(fx)"))) return rc;
     SSMQ_HIP(hipMemcpyAsync(mean_f, omf.p, sizeof(double) * B * E, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipMemcpyAsync(cov_f, ocf.p, sizeof(double) * B * E * E, hipMemcpyDeviceToHost, s));

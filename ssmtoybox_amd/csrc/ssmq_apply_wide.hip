@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
                 for (int k = 0; k <= d; ++k) s += sL[d * D + k] * c[cl.xiT + n * D + k];
                 sx[d * N + n] = s;
             }
-            if (a.mode == SSMQ_WIDE_FULL) {
+            if (a.mode == SSMQ_WIDE_FULL || a.mode == SSMQ_WIDE_EVAL) {
                 double xs[SSMQ_MAX_FIDX], o[SSMQ_MAX_DIM];
 #pragma unroll
                 for (int k = 0; k < SSMQ_MAX_FIDX; ++k) {
@@ -86,6 +86,15 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             }
         }
         __syncthreads();
+        if (a.mode == SSMQ_WIDE_EVAL) {
+            // integrand values as (b E + e)-th row of the batch matrix, zero-padded to the GEMM's column count
+            const int64_t fl = a.fx_ld ? a.fx_ld : N;
+            for (int e = 0; e < E; ++e)
+                for (int n = lane; n < fl; n += kWideBlock)
+                    a.fx_out[((int64_t)b * E + e) * fl + n] = n < N ? (s_ok ? sfx[e * N + n] : nan) : 0.0;
+            for (int i = lane; i < D * D; i += kWideBlock) a.chol_out[b * D * D + i] = s_ok ? sL[i] : nan;
+            return;
+        }
         if (a.mode == SSMQ_WIDE_POINTS) {
             // outputs in the reference layout: x [b][D][N], chol [b][D][D]
             for (int i = lane; i < D * N; i += kWideBlock) a.x_out[b * D * N + i] = s_ok ? sx[i] : nan;
@@ -95,7 +104,10 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
     } else {
         // reductions only: L, fx (and x, mean for the centred form) come from the caller, reference layout
         for (int i = lane; i < D * D; i += kWideBlock) sL[i] = a.chol_in[b * D * D + i];
-        for (int i = lane; i < E * N; i += kWideBlock) sfx[i] = a.fx_in[b * E * N + i];
+        {
+            const int64_t fl = a.fx_ld ? a.fx_ld : N;
+            for (int i = lane; i < E * N; i += kWideBlock) sfx[i] = a.fx_in[((int64_t)b * E + i / N) * fl + i % N];
+        }
         if (a.form == SSMQ_FORM_SIGMA) {
             for (int i = lane; i < D * N; i += kWideBlock) sx[i] = a.x_in[b * D * N + i];
             for (int d = lane; d < D; d += kWideBlock) sm[d] = a.mean[b * D + d];
@@ -118,11 +130,17 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
 
     if (a.form == SSMQ_FORM_BQ) {
         // ---- 4. T = fx Wc; cov = T fx' - mean mean' + emv -------------------------------------------------------
-        for (int idx = lane; idx < E * N; idx += kWideBlock) {
-            const int e = idx / N, j = idx % N;
-            double s = 0.0;
-            for (int i = 0; i < N; ++i) s += sfx[e * N + i] * c[cl.Wc + (int64_t)i * N + j];
-            sT[idx] = s;
+        if (a.t_in) {      // fx Wc came from the matrix-core GEMM over the whole batch
+            const int64_t fl = a.fx_ld ? a.fx_ld : N;
+            for (int idx = lane; idx < E * N; idx += kWideBlock)
+                sT[idx] = a.t_in[((int64_t)b * E + idx / N) * fl + idx % N];
+        } else {
+            for (int idx = lane; idx < E * N; idx += kWideBlock) {
+                const int e = idx / N, j = idx % N;
+                double s = 0.0;
+                for (int i = 0; i < N; ++i) s += sfx[e * N + i] * c[cl.Wc + (int64_t)i * N + j];
+                sT[idx] = s;
+            }
         }
         __syncthreads();
         for (int idx = lane; idx < E * E; idx += kWideBlock) {

@@ -14,6 +14,9 @@ struct ssmq_transform {
     // device constant blocks: `small` = transposed layout of ssmq_apply_small.h, `wide` = natural layout
     double *d_small, *d_wide;
     int opt_mask;   // SSMQ_OPT_* fast paths this handle's constants qualify for (decided in upload_consts)
+    // matrix-core route for large point sets (ssmq_gemm_mfma.hip): Wc zero-padded to np_pad x np_pad, or null
+    double *d_wc_pad = nullptr;
+    int np_pad = 0;
 };
 
 namespace ssmq {
@@ -39,6 +42,10 @@ struct SmallEntry {
     const char *name;
 };
 const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int sel, int opt);
+
+// batch GEMM fx Wc on the matrix cores (ssmq_gemm_mfma.hip)
+int gemm_mfma_padded(int N);
+int launch_fxwc_mfma(int NP, const double *A, const double *Bm, double *T, int64_t M, int lda, int ldt, hipStream_t s);
 
 // measurement update (ssmq_filter.hip)
 int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,

@@ -9,7 +9,8 @@ constexpr int kWideBlock = 64;
 enum WideMode {
     SSMQ_WIDE_FULL = 0,    // chol + sigma points + built-in integrand + moments
     SSMQ_WIDE_POINTS = 1,  // chol + sigma points, written out for a host-evaluated integrand
-    SSMQ_WIDE_FX = 2       // moments from caller-supplied integrand values
+    SSMQ_WIDE_FX = 2,      // moments from caller-supplied integrand values
+    SSMQ_WIDE_EVAL = 3     // chol + sigma points + built-in integrand, values written out (first pass of the GEMM route)
 };
 
 // Second constant block of a transform, natural (row-major, untransposed) layout.
@@ -44,6 +45,11 @@ struct WideArgs {
     // split entry points (reference layout, trajectory-major)
     double *x_out, *chol_out;
     const double *chol_in, *fx_in, *x_in;
+    // GEMM route (ssmq_gemm_mfma.hip): integrand values as rows of pitch fx_ld (0 = N, unpadded), written by the EVAL
+    // pass (fx_out, zero beyond column N) and read back by the FX pass together with t_in = fx Wc
+    int64_t fx_ld;
+    double *fx_out;
+    const double *t_in;
     FPar fp;
 };
 

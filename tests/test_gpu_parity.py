@@ -871,6 +871,46 @@ def test_bsq_d10(amd, golden):
             assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=(tag, i))
 
 
+@pytest.mark.parametrize('N,E,B', [(201, 10, 64), (201, 7, 37), (120, 5, 60), (250, 3, 100), (201, 10, 2500)])
+def test_matrix_core_route_exact_on_integers(amd, monkeypatch, N, E, B):
+    """fx Wc through v_mfma_f64_16x16x4_f64 (ssmq_gemm_mfma.hip): with small-integer operands every product and sum
+    is exact in fp64, so the moments must equal integer arithmetic exactly - any slip in the operand / accumulator lane
+    maps, the k permutation, the zero padding or the ragged last row block shows up as a wrong integer.  Also equal to
+    the generic kernel's result (SSMQ_NO_MFMA=1) bit for bit."""
+    from ssmtoybox_amd import _lib
+    lib = _lib.load()
+    D = 3
+    rng = np.random.default_rng(N + E + B)
+    xi = rng.integers(-3, 4, (D, N)).astype(float)
+    wm = rng.integers(-2, 3, N).astype(float)
+    Wc = rng.integers(-3, 4, (N, N)).astype(float)
+    Wc = Wc + Wc.T
+    Wcc = rng.integers(-2, 3, (D, N)).astype(float)
+    fx = rng.integers(-4, 5, (B, E, N)).astype(float)
+    chol = np.tile(np.tril(rng.integers(1, 4, (D, D))).astype(float), (B, 1, 1))
+    mean_i = np.einsum('ben,n->be', fx, wm)
+    cov_i = np.einsum('ben,nm,bfm->bef', fx, Wc, fx) - mean_i[:, :, None] * mean_i[:, None, :] + 5.0 * np.eye(E)
+    ccov_i = np.einsum('ben,dn,bjd->bej', fx, Wcc, chol)
+    assert np.abs(cov_i).max() < 2 ** 50
+
+    def run():
+        h = lib.ssmq_transform_create(D, E, N, 0, _lib.as_c(xi)[1], _lib.as_c(wm)[1], _lib.as_c(Wc)[1], _lib.as_c(Wcc)[1],
+                                      _lib.as_c(5.0 * np.eye(E))[1], 0, 0.0, None)
+        assert h
+        mf, cf, cfx = np.empty((B, E)), np.empty((B, E, E)), np.empty((B, E, D))
+        f, pf = _lib.as_c(fx)
+        c, pc = _lib.as_c(chol)
+        _lib.check(lib.ssmq_apply_fx_batch(ctypes.c_void_p(h), B, pc, None, None, pf, _lib.as_c(mf)[1], _lib.as_c(cf)[1],
+                                           _lib.as_c(cfx)[1]), 'ssmq_apply_fx_batch')
+        lib.ssmq_transform_destroy(ctypes.c_void_p(h))
+        return mf, cf, cfx
+    got = run()
+    assert np.array_equal(got[0], mean_i) and np.array_equal(got[1], cov_i) and np.array_equal(got[2], ccov_i)
+    monkeypatch.setenv('SSMQ_NO_MFMA', '1')
+    ref = run()
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # edge cases of the batch interface
 # ---------------------------------------------------------------------------------------------------------------
