@@ -400,6 +400,13 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 }
 
 // Sink of the stand-alone kernel: every element goes straight to its SoA plane.
+// Results are written once and not read again by this kernel: non-temporal stores keep them from displacing the inputs
+// in L2 / Infinity Cache and measured 22.9 -> 20.0 us on the D = E = 6 launch (SSMQ_TEMPORAL_STORE=1 restores plain stores)
+#ifndef SSMQ_TEMPORAL_STORE
+#define SSMQ_STORE(dst, v) __builtin_nontemporal_store((v), &(dst))
+#else
+#define SSMQ_STORE(dst, v) (dst) = (v)
+#endif
 template <int D, int E>
 struct GlobalSink {
     double *mean_f, *cov_f, *cov_fx;
@@ -411,22 +418,22 @@ struct GlobalSink {
 #ifdef SSMQ_DIAG_NOSTORE_ALL
         keep(v);
 #else
-        mean_f[e * ld + b] = v;
+        SSMQ_STORE(mean_f[e * ld + b], v);
 #endif
     }
     __device__ __forceinline__ void cov(int e, int e2, double v) {
 #if defined(SSMQ_DIAG_NOSTORE_ALL) || defined(SSMQ_DIAG_NOSTORE_COV)
         keep(v);
 #else
-        cov_f[(e * E + e2) * ld + b] = v;
-        if (e2 != e) cov_f[(e2 * E + e) * ld + b] = v;
+        SSMQ_STORE(cov_f[(e * E + e2) * ld + b], v);
+        if (e2 != e) SSMQ_STORE(cov_f[(e2 * E + e) * ld + b], v);
 #endif
     }
     __device__ __forceinline__ void ccov(int e, int d, double v) {
 #ifdef SSMQ_DIAG_NOSTORE_ALL
         keep(v);
 #else
-        cov_fx[(e * D + d) * ld + b] = v;
+        SSMQ_STORE(cov_fx[(e * D + d) * ld + b], v);
 #endif
     }
 };

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
 #pragma unroll
             for (int i = 0; i < Y; ++i) s += G[d][i] * (ycur[i] - ob.mf[i]);
             m[d] = good ? pr.mf[d] + s : nan;
-            a.fm[((int64_t)k * D + d) * ld + b] = m[d];
+            SSMQ_STORE(a.fm[((int64_t)k * D + d) * ld + b], m[d]);
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
                 for (int j = 0; j < Y; ++j) s += w[j] * G[d2][j];
                 double p = pr.cv[d >= d2 ? SSMQ_PK(d, d2) : SSMQ_PK(d2, d)] - s;
                 p = good ? p : nan;
-                a.fP[((int64_t)k * D * D + d * D + d2) * ld + b] = p;
+                SSMQ_STORE(a.fP[((int64_t)k * D * D + d * D + d2) * ld + b], p);
                 if (d2 <= d) Pl[SSMQ_PK(d, d2)] = sc2 * p;   // next Cholesky reads the lower triangle only (LAPACK 'L')
             }
         }

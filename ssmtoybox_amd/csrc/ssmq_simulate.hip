@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kSimBlock) void k_simulate(const SimArgs a) {
     if (gen_x) gauss_vector(a, traj, 0u, 0u, D, m0, L0, aug);
     for (int k = 0; k < a.T; ++k) {
         for (int d = 0; d < D; ++d) {
-            if (gen_x) a.x[((int64_t)k * D + d) * a.ld + b] = aug[d];
+            if (gen_x) __builtin_nontemporal_store(aug[d], &a.x[((int64_t)k * D + d) * a.ld + b]);   // written once, streamed
             else aug[d] = a.x[((int64_t)k * D + d) * a.ld + b];
         }
         if (gen_y) {
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(kSimBlock) void k_simulate(const SimArgs a) {
             for (int e = 0; e < SSMQ_MAX_DIM; ++e) o[e] = 0.0;
             eval_integrand(a.fid_obs, xs, (double)(k + 1), a.fo, o);
             for (int e = 0; e < Y; ++e)
-                a.y[((int64_t)k * Y + e) * a.ld + b] = o[e] + ((a.obs_additive && e < dr) ? nz[e] : 0.0);
+                __builtin_nontemporal_store(o[e] + ((a.obs_additive && e < dr) ? nz[e] : 0.0),
+                                            &a.y[((int64_t)k * Y + e) * a.ld + b]);
         }
         if (k + 1 == a.T || !gen_x) continue;
         // next state from x[k] with noise q[k] at time k (ssmod.py:196-198)
