@@ -401,7 +401,8 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 
 // Sink of the stand-alone kernel: every element goes straight to its SoA plane.
 // Results are written once and not read again by this kernel: non-temporal stores keep them from displacing the inputs
-// in L2 / Infinity Cache and measured 22.9 -> 20.0 us on the D = E = 6 launch (SSMQ_TEMPORAL_STORE=1 restores plain stores)
+// in L2 / Infinity Cache and measured 22.9 -> 20.0 us on the D = E = 6 launch (SSMQ_TEMPORAL_STORE=1 restores plain stores;
+// non-temporal LOADS of the inputs made no difference)
 #ifndef SSMQ_TEMPORAL_STORE
 #define SSMQ_STORE(dst, v) __builtin_nontemporal_store((v), &(dst))
 #else
