@@ -12,7 +12,7 @@ __global__ __launch_bounds__(64) void k_mem(const double *in, double *out, long 
     const unsigned b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
     double v[NIN];
-    if (MODE == 0) {          // SoA planes
+    if (MODE == 0 || MODE == 2) {          // SoA planes
 #pragma unroll
         for (int e = 0; e < NIN; ++e) v[e] = in[e * ld + b];
     } else {                  // tile-blocked: [tile][e][64]
@@ -23,7 +23,10 @@ __global__ __launch_bounds__(64) void k_mem(const double *in, double *out, long 
     double s = 0.0;
 #pragma unroll
     for (int e = 0; e < NIN; ++e) s += v[e];
-    if (MODE == 0) {
+    if (MODE == 2) {          // SoA planes, non-temporal stores
+#pragma unroll
+        for (int e = 0; e < NOUT; ++e) __builtin_nontemporal_store(s + e, &out[e * ld + b]);
+    } else if (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < NOUT; ++e) out[e * ld + b] = s + e;
     } else {
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(64) void k_mem(const double *in, double *out, long 
 }
 
 // paired planes: element pair (2k, 2k+1) of trajectory b at ((k * ld) + b) * 2 -> 16 bytes per lane per access
-template <int NIN2, int NOUT2>
+template <int NIN2, int NOUT2, int NT = 0>
 __global__ __launch_bounds__(64) void k_mem16(const double2 *in, double2 *out, long B, long ld) {
     const unsigned b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
@@ -45,7 +48,14 @@ __global__ __launch_bounds__(64) void k_mem16(const double2 *in, double2 *out, l
 #pragma unroll
     for (int e = 0; e < NIN2; ++e) s += v[e].x + v[e].y;
 #pragma unroll
-    for (int e = 0; e < NOUT2; ++e) out[e * ld + b] = make_double2(s + e, s - e);
+    for (int e = 0; e < NOUT2; ++e) {
+        if (NT) {
+            __builtin_nontemporal_store(s + e, &out[e * ld + b].x);
+            __builtin_nontemporal_store(s - e, &out[e * ld + b].y);
+        } else {
+            out[e * ld + b] = make_double2(s + e, s - e);
+        }
+    }
 }
 
 template <int NIN2, int NOUT2>
@@ -113,6 +123,8 @@ static int run(const char *name, long B, int sets) {
 int main() {
     const long B = 100000;
     run<27, 78, 0>("SoA   read 27 + write 78", B, 4);
+    run<27, 78, 2>("SoA   read 27 + write 78 NT", B, 4);
+    run<1, 78, 2>("SoA   write 78 only NT", B, 4);
     run<27, 78, 1>("tiled read 27 + write 78", B, 4);
     run<27, 1, 0>("SoA   read 27 only", B, 4);
     run<27, 1, 1>("tiled read 27 only", B, 4);
