@@ -765,6 +765,12 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
                      const double *d_m0, const double *d_P0, const double *d_gqg, const double *d_rr, double *d_fm,
                      double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run,
                      const double *d_sscale, double student_dof, const double *d_ttab_dyn, const double *d_ttab_obs);
+int try_launch_fused_aug(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho,
+                         const ssmq_integrand *fo, int sel_obs, int D, int dq, int dr, int64_t B, int64_t ld, int T,
+                         const double *d_y, const double *d_m0, const double *d_P0, const double *d_add_dyn,
+                         const double *d_add_obs, const double *d_noise, double *d_fm, double *d_fP, int32_t *d_status,
+                         hipStream_t s, const char **name, bool dry_run, const double *d_ttab_dyn,
+                         const double *d_ttab_obs);
 }
 
 namespace {
@@ -1021,6 +1027,36 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
                             hipMemcpyHostToDevice, s));
     SSMQ_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t) * ld, s));
     SSMQ_HIP(hipStreamSynchronize(s));   // the host staging vectors above go out of scope with this call
+
+    // one kernel for the whole time loop when this combination has an instantiation (ssmq_filter_fused.hip)
+    if (!getenv("SSMQ_NO_FUSED")) {
+        FInfo fio;
+        if (!integrand_info(f_obs->id, &fio)) {
+            set_error("unknown integrand id");
+            return SSMQ_E_ARG;
+        }
+        // noise block q_mean | q_cov | r_mean | r_cov and the additive terms (zeros for a non-additive model)
+        std::vector<double> hn, ha((size_t)D * D + (size_t)Y * Y, 0.0);
+        for (int i = 0; i < dq; ++i) hn.push_back(q_mean[i]);
+        for (int i = 0; i < dq * dq; ++i) hn.push_back(q_cov[i]);
+        for (int i = 0; i < dr; ++i) hn.push_back(r_mean[i]);
+        for (int i = 0; i < dr * dr; ++i) hn.push_back(r_cov[i]);
+        hn.push_back(0.0);
+        if (!dq && q_cov) for (int i = 0; i < D * D; ++i) ha[i] = q_cov[i];
+        if (!dr && r_cov) for (int i = 0; i < Y * Y; ++i) ha[(size_t)D * D + i] = r_cov[i];
+        DevBuf dn, da;
+        if ((rc = dn.alloc(sizeof(double) * hn.size())) || (rc = da.alloc(sizeof(double) * ha.size()))) return rc;
+        SSMQ_HIP(hipMemcpyAsync(dn.p, hn.data(), sizeof(double) * hn.size(), hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(da.p, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice, s));
+        rc = try_launch_fused_aug(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), D, dq, dr, B, ld, T, d_y, d_m0,
+                                  d_P0, da.d(), da.d() + (size_t)D * D, dn.d(), d_fm, d_fP, d_status, s, nullptr, false,
+                                  has_td ? ttab_d : nullptr, has_to ? ttab_o : nullptr);
+        hipError_t e = hipStreamSynchronize(s);
+        if (rc < 0) return rc;
+        SSMQ_HIP(e);
+        if (rc == 1) return SSMQ_OK;
+        rc = 0;
+    }
 
     for (int k = 0; k < T && !rc; ++k) {
         const double *m_in = k == 0 ? d_m0 : d_fm + (int64_t)(k - 1) * D * ld;

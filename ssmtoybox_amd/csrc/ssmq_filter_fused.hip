@@ -219,6 +219,196 @@ static const FusedEntry kFused[] = {
     SSMQ_FUSED_FAST(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 11, 1),
 };
 
+// ---- models that take their noise as an argument (ssinf.py:271-272, 282-283, 294-295) -------------------------------------
+// Same time loop with the inputs of either transform augmented in registers: [m; noise_mean], blockdiag(P, noise_cov)
+// (the Cholesky of a block-diagonal matrix is block-diagonal, so the augmented factor costs nothing extra), and the
+// measurement cross-covariance cut back to the state columns.  A separate kernel so that the additive-noise kernels
+// above - the measured ones - compile exactly as before.  DQ / DR = 0 means that model is additive (G Q G' / R added).
+struct AugArgs {
+    const double *y, *m0, *P0;
+    double *fm, *fP;
+    int32_t *status;
+    const double *c_dyn, *c_obs;
+    const double *add_dyn, *add_obs;   // [D*D] / [Y*Y]: G Q G' / R for an additive model, zeros otherwise
+    const double *noise;               // q_mean[DQ] | q_cov[DQ*DQ] | r_mean[DR] | r_cov[DR*DR]
+    int64_t B, ld;
+    int32_t T, emv_dyn, emv_obs;
+    double nu_dyn, nu_obs;
+    FPar fd, fo;
+};
+
+template <int D, int DN>
+__device__ __forceinline__ void augment(const double (&m)[D], const double *Pl, cdouble_p nmean, cdouble_p ncov,
+                                        double (&ma)[D + DN], double (&Pa)[(D + DN) * (D + DN + 1) / 2]) {
+#pragma unroll
+    for (int i = 0; i < D + DN; ++i) {
+        ma[i] = i < D ? m[i < D ? i : 0] : nmean[i - D];
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double v = 0.0;
+            if (i < D) v = Pl[SSMQ_PK(i, j)];
+            else if (j >= D) v = ncov[(i - D) * DN + (j - D)];
+            Pa[SSMQ_PK(i, j)] = v;
+        }
+    }
+}
+
+template <int D, int Y, int DQ, int DR, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
+__global__ __launch_bounds__(kSmallBlock, (D + DQ >= 5 ? 1 : 2)) void k_filter_fused_aug(const AugArgs a) {
+    constexpr int DA = D + DQ, DO = D + DR;
+    const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;
+    if ((int64_t)b >= a.B) return;
+    const int64_t ld = a.ld;
+    double m[D], Pl[D * (D + 1) / 2];
+#pragma unroll
+    for (int d = 0; d < D; ++d) m[d] = a.m0[d * ld + b];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Pl[SSMQ_PK(i, j)] = a.P0[(i * D + j) * ld + b];
+    const CoreParams cpd{(cdouble_p)a.c_dyn, (cdouble_p)a.add_dyn, a.emv_dyn, a.nu_dyn, 1.0, 1.0};
+    const CoreParams cpo{(cdouble_p)a.c_obs, (cdouble_p)a.add_obs, a.emv_obs, a.nu_obs, 1.0, 1.0};
+    const cdouble_p qm = (cdouble_p)a.noise, qc = qm + DQ, rm = qc + DQ * DQ, rc = rm + DR;
+    const double nan = __builtin_nan("");
+    int32_t agg = 0;
+#pragma unroll 1
+    for (int k = 0; k < a.T; ++k) {
+        const double t = (double)k;   // both transforms of step k + 1 use time index k (ssinf.py:104, 276-288)
+        double yk[Y];
+#pragma unroll
+        for (int i = 0; i < Y; ++i) yk[i] = a.y[((int64_t)k * Y + i) * ld + b];
+        double ma[DA], Pa[DA * (DA + 1) / 2];
+        augment<D, DQ>(m, Pl, qm, qc, ma, Pa);
+        RegSinkNoCross<DA, D> pr;
+        bool ok = moment_transform_core<DA, D, ND, FD, FORM, TP, 0, false, 0>(ma, Pa, t, a.fd, cpd, pr);
+        double mo[DO], Po[DO * (DO + 1) / 2];
+        augment<D, DR>(pr.mf, pr.cv, rm, rc, mo, Po);
+        RegSink<DO, Y> ob;
+        ok = moment_transform_core<DO, Y, NO, FO, FORM, TP, SELO, true, 0>(mo, Po, t, a.fo, cpo, ob) && ok;
+        double S[Y * (Y + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < Y * (Y + 1) / 2; ++i) S[i] = ob.cv[i];
+        double G[D][Y];
+        if (Y == 1) {
+            ok = (S[0] > 0.0) && ok;
+#pragma unroll
+            for (int d = 0; d < D; ++d) G[d][0] = div_nr(ob.cx[0][d], S[0]);   // state columns only (ssinf.py:294)
+        } else {
+            ok = chol_packed<Y>(S) && ok;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                double v[Y];
+#pragma unroll
+                for (int i = 0; i < Y; ++i) {
+                    double s = ob.cx[i][d];
+#pragma unroll
+                    for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * v[q];
+                    v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
+                }
+#pragma unroll
+                for (int i = Y - 1; i >= 0; --i) {
+                    double s = v[i];
+#pragma unroll
+                    for (int q = i + 1; q < Y; ++q) s -= S[SSMQ_PK(q, i)] * v[q];
+                    v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
+                }
+#pragma unroll
+                for (int i = 0; i < Y; ++i) G[d][i] = v[i];
+            }
+        }
+        if (agg == 0 && !ok) agg = k + 1;
+        const bool good = (agg == 0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < Y; ++i) s += G[d][i] * (yk[i] - ob.mf[i]);
+            m[d] = good ? pr.mf[d] + s : nan;
+            SSMQ_STORE(a.fm[((int64_t)k * D + d) * ld + b], m[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            double w[Y];
+#pragma unroll
+            for (int j = 0; j < Y; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < Y; ++i) s += G[d][i] * ob.cv[i >= j ? SSMQ_PK(i, j) : SSMQ_PK(j, i)];
+                w[j] = s;
+            }
+#pragma unroll
+            for (int d2 = 0; d2 < D; ++d2) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < Y; ++j) s += w[j] * G[d2][j];
+                double p = pr.cv[d >= d2 ? SSMQ_PK(d, d2) : SSMQ_PK(d2, d)] - s;
+                p = good ? p : nan;
+                SSMQ_STORE(a.fP[((int64_t)k * D * D + d * D + d2) * ld + b], p);
+                if (d2 <= d) Pl[SSMQ_PK(d, d2)] = p;
+            }
+        }
+    }
+    a.status[b] = agg;
+}
+
+template <int D, int Y, int DQ, int DR, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
+static hipError_t launch_fused_aug(const AugArgs &a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.B + kSmallBlock - 1) / kSmallBlock);
+    hipLaunchKernelGGL((k_filter_fused_aug<D, Y, DQ, DR, ND, NO, FD, FO, FORM, TP, SELO>), dim3(grid), dim3(kSmallBlock), 0, s,
+                       a);
+    return hipGetLastError();
+}
+
+typedef hipError_t (*aug_fn)(const AugArgs &, hipStream_t);
+struct AugEntry {
+    int fd, fo, D, Y, DQ, DR, ND, NO, form, tp, selo;
+    aug_fn fn;
+    const char *name;
+};
+#define SSMQ_AUG_ONE(FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO)                                               \
+    {FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO, &launch_fused_aug<D, Y, DQ, DR, ND, NO, FD, FO, FORM, TP, SELO>, \
+     "k_filter_fused_aug<D=" #D ",Y=" #Y ",DQ=" #DQ ",DR=" #DR ",ND=" #ND ",NO=" #NO "," #FD "," #FO "," #FORM ",TP=" #TP ">"}
+#define SSMQ_AUG(FD, FO, D, Y, DQ, DR, ND, NO, SELO)                          \
+    SSMQ_AUG_ONE(FD, FO, D, Y, DQ, DR, ND, NO, SSMQ_FORM_BQ, 0, SELO),        \
+    SSMQ_AUG_ONE(FD, FO, D, Y, DQ, DR, ND, NO, SSMQ_FORM_BQ, 1, SELO),        \
+    SSMQ_AUG_ONE(FD, FO, D, Y, DQ, DR, ND, NO, SSMQ_FORM_SIGMA, 0, SELO)
+
+static const AugEntry kAug[] = {
+    SSMQ_AUG(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 4, 4, 0),      // spherical-radial points in 2-D
+    SSMQ_AUG(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 5, 5, 0),      // unscented points in 2-D
+    SSMQ_AUG_ONE(SSMQ_F_CTRS_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 2, 0, 15, 11, SSMQ_FORM_SIGMA, 0, 0),
+};
+
+// as try_launch_fused, for filters whose models take the noise as an argument; d_noise: q_mean | q_cov | r_mean | r_cov
+int try_launch_fused_aug(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho,
+                         const ssmq_integrand *fo, int sel_obs, int D, int dq, int dr, int64_t B, int64_t ld, int T,
+                         const double *d_y, const double *d_m0, const double *d_P0, const double *d_add_dyn,
+                         const double *d_add_obs, const double *d_noise, double *d_fm, double *d_fP, int32_t *d_status,
+                         hipStream_t s, const char **name, bool dry_run, const double *d_ttab_dyn,
+                         const double *d_ttab_obs) {
+    if (hd->form != ho->form || (hd->tp_nu > 0.0) != (ho->tp_nu > 0.0) || sel_obs < 0 || fd->n_idx > 0) return 0;
+    const int tp = hd->tp_nu > 0.0 ? 1 : 0;
+    for (const AugEntry &e : kAug) {
+        if (e.fd == fd->id && e.fo == fo->id && e.D == D && e.Y == ho->E && e.DQ == dq && e.DR == dr && e.ND == hd->N &&
+            e.NO == ho->N && e.form == hd->form && e.tp == tp && e.selo == sel_obs) {
+            if (name) *name = e.name;
+            if (dry_run) return 1;
+            AugArgs a;
+            a.y = d_y; a.m0 = d_m0; a.P0 = d_P0; a.fm = d_fm; a.fP = d_fP; a.status = d_status;
+            a.c_dyn = hd->d_small; a.c_obs = ho->d_small; a.add_dyn = d_add_dyn; a.add_obs = d_add_obs;
+            a.noise = d_noise; a.B = B; a.ld = ld; a.T = T; a.emv_dyn = hd->emv_mode; a.emv_obs = ho->emv_mode;
+            a.nu_dyn = hd->tp_nu; a.nu_obs = ho->tp_nu;
+            fill_fpar(fd, &a.fd);
+            fill_fpar(fo, &a.fo);
+            a.fd.ttab = d_ttab_dyn;
+            a.fo.ttab = d_ttab_obs;
+            int rc = hip_fail(e.fn(a, s), e.name);
+            return rc ? rc : 1;
+        }
+    }
+    return 0;
+}
+
 // Returns 1 if a fused kernel was launched, 0 if none exists for this combination, < 0 on error.
 int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho,
                      const ssmq_integrand *fo, int sel_obs, int64_t B, int64_t ld, int T, const double *d_y,

@@ -55,7 +55,8 @@ class GaussianInference:
     def kernel_name(self):
         """Which kernel(s) the device filter loop runs for this filter (one fused kernel, or a replayed hipGraph)."""
         if not self._additive:
-            return 'launch loop of 5 T launches (k_augment | apply dyn | k_augment | apply obs | k_kalman_update)'
+            return ('k_filter_fused_aug (one kernel for the time loop) where instantiated, else a launch loop of 5 T '
+                    'launches (k_augment | apply dyn | k_augment | apply obs | k_kalman_update)')
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
         f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
         buf = ctypes.create_string_buffer(512)

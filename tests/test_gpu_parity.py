@@ -395,6 +395,38 @@ def test_ungmna_filter_golden(amd, golden, name):
             alg0.forward_pass_batch(y)
 
 
+def test_nonadditive_fused_matches_launch_loop(amd, golden, monkeypatch):
+    """k_filter_fused_aug against the loop of stand-alone kernels (SSMQ_NO_FUSED=1) on the same data."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g6_nonadditive')
+    q = sm.GaussRV(1, cov=np.array([[10.0]]))
+    dyn = sm.UNGMNATransition(sm.GaussRV(1, mean=np.array([1.0])), q)
+    obs = sm.UNGMNAMeasurement(sm.GaussRV(1), 1)
+    par = np.array([[1.0, 3.0, 3.0]])
+    y = np.tile(g['ungmna_y'], (1, 1, 40))[..., :200]
+    for alg in (ssinf.UnscentedKalman(dyn, obs), ssinf.CubatureKalman(dyn, obs),
+                ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut'),
+                ssinf.StudentProcessKalman(dyn, obs, par, par, 'rbf', 'ut')):
+        fm, fP = alg.forward_pass_batch(y, raise_on_failure=False)
+        st = alg.status.copy()
+        monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+        fm2, fP2 = alg.forward_pass_batch(y, raise_on_failure=False)
+        monkeypatch.delenv('SSMQ_NO_FUSED')
+        assert np.array_equal(st, alg.status)
+        ok = st == 0
+        assert rel_err(fm[..., ok], fm2[..., ok]) < 1e-11 and rel_err(fP[..., ok], fP2[..., ok]) < 1e-11, type(alg).__name__
+    dyn = sm.ConstantTurnRateSpeed(sm.GaussRV(5, mean=g['ctrs_m0'], cov=0.1 * np.eye(5)),
+                                   sm.GaussRV(2, cov=np.diag([0.1, 0.1 * np.pi])))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=np.diag([0.3, 0.03])), 5)
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    yy = np.tile(g['ctrs_y'], (1, 1, 25))
+    fm, fP = alg.forward_pass_batch(yy)
+    monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+    fm2, fP2 = alg.forward_pass_batch(yy)
+    monkeypatch.delenv('SSMQ_NO_FUSED')
+    assert rel_err(fm, fm2) < 1e-11 and rel_err(fP, fP2) < 1e-10
+
+
 def test_ctrs_radar_ukf_golden(amd, golden):
     """Non-additive dynamics (5 states + 2 noise inputs, D = 7 transform) with an additive radar."""
     from ssmtoybox_amd import ssinf, ssmod as sm
