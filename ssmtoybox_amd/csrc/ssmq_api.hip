@@ -987,22 +987,11 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
         SSMQ_HIP(hipStreamSynchronize(s));
         return SSMQ_OK;
     }
-    DevBuf ws, st;
+    // small constants first (time tables, noise statistics); the plane workspace only if the launch loop is needed
+    DevBuf cs;
     const size_t n_noise = (size_t)dq + (dq ? (size_t)dq * dq : (size_t)D * D) + dr + (dr ? (size_t)dr * dr : (size_t)Y * Y);
-    const size_t n_dbl = (size_t)ld * (Da + Da * Da + D + D * D + D * Da + Do + Do * Do + Y + Y * Y + Y * Do) + 3 * (size_t)T +
-                         n_noise;
-    if ((rc = ws.alloc(sizeof(double) * n_dbl)) || (rc = st.alloc(2 * sizeof(int32_t) * (size_t)ld))) return rc;
-    double *w = ws.d();
-    double *ma = w; w += (size_t)ld * Da;
-    double *Pa = w; w += (size_t)ld * Da * Da;
-    double *m_pr = w; w += (size_t)ld * D;
-    double *P_pr = w; w += (size_t)ld * D * D;
-    double *C_xx = w; w += (size_t)ld * D * Da;
-    double *mo = w; w += (size_t)ld * Do;
-    double *Po = w; w += (size_t)ld * Do * Do;
-    double *y_mean = w; w += (size_t)ld * Y;
-    double *P_y = w; w += (size_t)ld * Y * Y;
-    double *P_yx = w; w += (size_t)ld * Y * Do;
+    if ((rc = cs.alloc(sizeof(double) * (3 * (size_t)T + n_noise)))) return rc;
+    double *w = cs.d();
     double *tvec = w; w += T;
     double *ttab_d = w; w += T;
     double *ttab_o = w; w += T;
@@ -1010,7 +999,6 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
     double *d_qc = w; w += dq ? (size_t)dq * dq : (size_t)D * D;
     double *d_rm = w; w += dr;
     double *d_rc = w; w += dr ? (size_t)dr * dr : (size_t)Y * Y;
-    int32_t *st_a = (int32_t *)st.p, *st_b = st_a + ld;
 
     std::vector<double> tv(T), htd(T), hto(T);
     for (int k = 0; k < T; ++k) tv[k] = (double)k;   // both transforms of step k + 1 use time index k (ssinf.py:104)
@@ -1057,6 +1045,22 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
         if (rc == 1) return SSMQ_OK;
         rc = 0;
     }
+
+    DevBuf ws, st;
+    const size_t n_dbl = (size_t)ld * (Da + Da * Da + D + D * D + D * Da + Do + Do * Do + Y + Y * Y + Y * Do);
+    if ((rc = ws.alloc(sizeof(double) * n_dbl)) || (rc = st.alloc(2 * sizeof(int32_t) * (size_t)ld))) return rc;
+    w = ws.d();
+    double *ma = w; w += (size_t)ld * Da;
+    double *Pa = w; w += (size_t)ld * Da * Da;
+    double *m_pr = w; w += (size_t)ld * D;
+    double *P_pr = w; w += (size_t)ld * D * D;
+    double *C_xx = w; w += (size_t)ld * D * Da;
+    double *mo = w; w += (size_t)ld * Do;
+    double *Po = w; w += (size_t)ld * Do * Do;
+    double *y_mean = w; w += (size_t)ld * Y;
+    double *P_y = w; w += (size_t)ld * Y * Y;
+    double *P_yx = w; w += (size_t)ld * Y * Do;
+    int32_t *st_a = (int32_t *)st.p, *st_b = st_a + ld;
 
     for (int k = 0; k < T && !rc; ++k) {
         const double *m_in = k == 0 ? d_m0 : d_fm + (int64_t)(k - 1) * D * ld;
