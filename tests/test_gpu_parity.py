@@ -938,6 +938,19 @@ def test_matrix_core_route_exact_on_integers(amd, monkeypatch, N, E, B):
         return mf, cf, cfx
     got = run()
     assert np.array_equal(got[0], mean_i) and np.array_equal(got[1], cov_i) and np.array_equal(got[2], ccov_i)
+    if B == 64:
+        # replacing the weights of a live handle refreshes the padded copy the GEMM reads
+        h = lib.ssmq_transform_create(D, E, N, 0, _lib.as_c(xi)[1], _lib.as_c(wm)[1], _lib.as_c(Wc)[1], _lib.as_c(Wcc)[1],
+                                      _lib.as_c(5.0 * np.eye(E))[1], 0, 0.0, None)
+        Wc2 = Wc + np.diag(np.arange(N, dtype=float) % 3)
+        _lib.check(lib.ssmq_transform_update(ctypes.c_void_p(h), None, None, _lib.as_c(Wc2)[1], None, None, 0, 0.0, None),
+                   'ssmq_transform_update')
+        mf, cf, cfx = np.empty((B, E)), np.empty((B, E, E)), np.empty((B, E, D))
+        _lib.check(lib.ssmq_apply_fx_batch(ctypes.c_void_p(h), B, _lib.as_c(chol)[1], None, None, _lib.as_c(fx)[1],
+                                           _lib.as_c(mf)[1], _lib.as_c(cf)[1], _lib.as_c(cfx)[1]), 'ssmq_apply_fx_batch')
+        lib.ssmq_transform_destroy(ctypes.c_void_p(h))
+        cov2 = np.einsum('ben,nm,bfm->bef', fx, Wc2, fx) - mean_i[:, :, None] * mean_i[:, None, :] + 5.0 * np.eye(E)
+        assert np.array_equal(cf, cov2)
     monkeypatch.setenv('SSMQ_NO_MFMA', '1')
     ref = run()
     assert all(np.array_equal(a, b) for a, b in zip(got, ref))
