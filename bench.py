@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+F64_MFMA_PEAK_TF = 78.6  # MI355X fp64 matrix peak = 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (equals the fp64 vector peak)
 
 
 def pmc_traffic(kernel_name):
@@ -185,6 +186,58 @@ class FilterBench:
     def bytes_per_pass(self):
         # bytes_step = 8 (dim_y + D + D^2) per filter step, filter outputs stored every step
         return 8 * (self.Y + self.D + self.D * self.D) * self.B * self.T
+
+
+class C5GemmBench:
+    """The GEMM-shaped stage of the Bayes-Sard transform at D = E = 10 with the fully-symmetric degree-5 rule (N = 201,
+    BASELINE config C5): T = FX Wc for B = 1e4 trajectories, (B E) x 208 x 208 on the matrix cores, integrand values
+    resident in HBM (synthetic, the reference has no 10-D model)."""
+
+    def __init__(self, amd, B, seed):
+        from ssmtoybox_amd import _lib
+        from ssmtoybox_amd.bq.bqmod import n_sum_k
+        self._lib = _lib
+        lib = _lib.load()
+        mi = np.hstack([n_sum_k(10, k) for k in range(3)])
+        self.tf = amd.BayesSardTransform(10, 10, np.array([[1.0] + [3.0] * 10]), mi, 'fs', {'degree': 5})
+        self.h = self.tf._handle_for(10)
+        npad = ctypes.c_int(0)
+        lib.ssmq_fxwc_batch_dev(ctypes.c_void_p(self.h), 0, None, 0, None, 0, ctypes.byref(npad))
+        self.N, self.NP, self.M = self.tf.wm.shape[0], npad.value, B * 10
+        if not self.NP:
+            raise RuntimeError('no matrix-core instantiation for N = {}'.format(self.N))
+        rng = np.random.default_rng(seed)
+        self.fx = np.zeros((self.M, self.NP))
+        self.fx[:, :self.N] = rng.standard_normal((self.M, self.N))
+        self.d_fx, self.d_t = _lib.DeviceBuffer(self.fx.nbytes), _lib.DeviceBuffer(self.fx.nbytes)
+        self.d_fx.upload(self.fx)
+
+    def launch(self):
+        self._lib.check(self._lib.load().ssmq_fxwc_batch_dev(ctypes.c_void_p(self.h), self.M, ctypes.c_void_p(self.d_fx.ptr),
+                                                             self.NP, ctypes.c_void_p(self.d_t.ptr), self.NP, None),
+                        'ssmq_fxwc_batch_dev')
+
+    def check(self):
+        """Sampled rows against the NumPy product (a check, not the oracle: the oracle covers the whole transform)."""
+        self.launch()
+        self._lib.sync()
+        t = self.d_t.download((self.M, self.NP))
+        rows = np.arange(0, self.M, max(1, self.M // 257))
+        ref = self.fx[rows, :self.N].dot(self.tf.Wc)
+        scale = np.abs(self.fx[rows, :self.N]).dot(np.abs(self.tf.Wc)).max()
+        return float(np.abs(t[rows, :self.N] - ref).max() / scale)
+
+    def measure(self, warmup=5, iters=50):
+        for _ in range(warmup):
+            self.launch()
+        self._lib.sync()
+        e0, e1 = self._lib.Event(), self._lib.Event()
+        e0.record()
+        for _ in range(iters):
+            self.launch()
+        e1.record()
+        ms = e0.elapsed_ms(e1) / iters
+        return ms, 2.0 * self.M * self.NP * self.NP
 
 
 class Mt6Bench:
@@ -400,6 +453,16 @@ def main():
                                'bytes_per_launch': b_alg, 'bytes_moved_per_launch': b_mov, 'ms_per_launch': ms,
                                'transforms_per_s': mt.B / (ms * 1e-3), 'max_scaled_err_vs_oracle': err,
                                'workload': 'batched GPQ moment transform, D=E=6, N=13, B=1e5, 4 rotating buffer sets'}
+    if rank == 0 and not args.no_mt6:
+        c5 = C5GemmBench(amd, 10000, seed=5)
+        err = c5.check()
+        ms, flop = c5.measure()
+        tf_s = flop / (ms * 1e-3) / 1e12
+        out['roofline_c5'] = {'bound': 'mfma', 'achieved': tf_s, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                              'frac': tf_s / F64_MFMA_PEAK_TF, 'traffic': None, 'kernel': 'k_fxwc_mfma<13,1>',
+                              'flop_per_launch': flop, 'ms_per_launch': ms, 'max_scaled_err_vs_numpy': err,
+                              'workload': 'T = FX Wc of the Bayes-Sard transform, D=E=10, N=201 (padded 208), B=1e4: '
+                                          '(1e5 x 208) x (208 x 208), v_mfma_f64_16x16x4_f64'}
     if rank == 0 and not args.no_cpu_baseline and args.workload == 'ungm' and args.filter == 'gpqkf':
         cb, (cpu_fm, cpu_st) = cpu_baseline_ungm(B, T, seed=1 + rank, tf=wl.alg.tf_dyn)
         out['cpu_baseline'] = cb

@@ -194,6 +194,17 @@ int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, co
 int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const double *mean, const double *x,
                         const double *fx, double *mean_f, double *cov_f, double *cov_fx);
 
+/*
+ * T = FX Wc for M = B E rows of integrand values that are already on the device: the GEMM-shaped stage of
+ * fx Wc fx' (bq/bqmtran.py:199) for large point sets, on the matrix cores (v_mfma_f64_16x16x4_f64).  Row r of d_fx is
+ * the integrand output e of trajectory b with r = b E + e, pitch ld_fx >= NP doubles (even), columns N..NP-1 ZERO,
+ * NP = N rounded up to 16; d_t gets the same shape with pitch ld_t.  *n_padded (may be NULL) returns NP, 0 when the
+ * handle has no instantiation (then SSMQ_E_UNSUPPORTED; ssmq_apply_batch* fall back to the generic kernel themselves).
+ * Asynchronous on the library stream.
+ */
+int ssmq_fxwc_batch_dev(ssmq_transform *h, int64_t M, const double *d_fx, int64_t ld_fx, double *d_t, int64_t ld_t,
+                        int *n_padded);
+
 /* ---- callers of the path kept on the device (filter recursion) ------------------------------- */
 /*
  * Gaussian measurement update for B trajectories (ssinf.py:297-323): gain = (P_y^-1 P_yx)' by Cholesky,

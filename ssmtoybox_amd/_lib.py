@@ -94,6 +94,8 @@ _PROTOTYPES = {
     'ssmq_sigma_points_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
                                                c_double_p, c_int32_p]),
     'ssmq_apply_fx_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [c_double_p] * 7),
+    'ssmq_fxwc_batch_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                           ctypes.c_int64, ctypes.POINTER(ctypes.c_int)]),
     'ssmq_kalman_update_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64] +
                                [ctypes.c_void_p] * 9),
     'ssmq_filter_forward_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,

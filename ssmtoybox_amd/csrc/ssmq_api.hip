@@ -733,6 +733,28 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
     return SSMQ_OK;
 }
 
+// T = FX Wc on the matrix cores for device-resident integrand values (the GEMM-shaped stage of a large-N BQ transform)
+int ssmq_fxwc_batch_dev(ssmq_transform *h, int64_t M, const double *d_fx, int64_t ld_fx, double *d_t, int64_t ld_t,
+                        int *n_padded) {
+    if (!h || M < 0 || (M > 0 && (!d_fx || !d_t))) {
+        set_error("fxwc_batch: bad argument");
+        return SSMQ_E_ARG;
+    }
+    if (n_padded) *n_padded = h->np_pad;
+    if (!h->d_wc_pad) {
+        set_error("fxwc_batch: this transform has no matrix-core instantiation (BQ form, N in 113..128, 193..208, 241..256)");
+        return SSMQ_E_UNSUPPORTED;
+    }
+    if (M == 0) return SSMQ_OK;
+    if (ld_fx < h->np_pad || ld_t < h->np_pad || ld_fx > 0x7fffffff || ld_t > 0x7fffffff || (ld_fx & 1)) {
+        set_error("fxwc_batch: row pitches must be even and at least the padded point count");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    return launch_fxwc_mfma(h->np_pad, d_fx, h->d_wc_pad, d_t, M, (int)ld_fx, (int)ld_t, stream());
+}
+
 // ---- filter recursion around the path ---------------------------------------------------------------------------------
 int ssmq_kalman_update_dev(int D, int Y, int64_t B, int64_t ld, const double *d_m_pr, const double *d_P_pr,
                            const double *d_y_mean, const double *d_P_y, const double *d_P_yx, const double *d_y,
