@@ -142,6 +142,16 @@ int ssmq_weights_bs(int D, int N, const double *xi, const double *par, int P, do
                     double *wm, double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R,
                     double *model_var, double *integral_var, int32_t *status);
 
+/*
+ * Expected model variance and integral variance of the Bayes-Sard model as BayesSardModel.exp_model_variance /
+ * integral_variance compute them (bq/bqmod.py:995-1050; the length-scale sweeps of research/bsq/bsq_ungm.py:244-282):
+ * the general formulas  alpha^2 (1 - tr(Q iK) + tr(B (V' iK V)^-1)),  kbar - q' iK q + b' (V' iK V)^-1 b  for every
+ * point set, with NO jitter on V' iK V - which is not what bq_weights() returns beside the weights (ssmq_weights_bs).
+ * theta-batched: par [P][1+D], outputs model_var [P], integral_var [P] (either may be NULL), status [P] as above.
+ */
+int ssmq_variances_bs(int D, int N, const double *xi, const double *par, int P, double jitter, const int32_t *mulind,
+                      int NB, double *model_var, double *integral_var, int32_t *status);
+
 /* ---- transform handle --------------------------------------------------------------------------------------- */
 /*
  * Upload the constants of one moment transform (what BQTransform.__init__ / SigmaPointTransform.__init__ keep as

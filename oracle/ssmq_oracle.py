@@ -427,6 +427,23 @@ def bs_weights(par, x, mi, jitter=1e-8):
                 integral_var=integral_var, px=px, xpx=xpx, pxpx=pxpx, kxpx=kxpx, V=V)
 
 
+def bs_variances(par, x, mi, jitter=1e-8):
+    """BayesSardModel.exp_model_variance / integral_variance (bq/bqmod.py:995-1050): the general-branch formulas for any
+    point set, and V' iK V inverted WITHOUT jitter - not the numbers bq_weights() returns beside the weights."""
+    par = np.atleast_2d(np.asarray(par, dtype=float))
+    alpha = par[0, 0]
+    iK = rbf_inv(par, x, jitter, scaling=False)
+    q, Q = rbf_q(par, x), rbf_Q(par, par, x)
+    V = vandermonde(mi, x)
+    px, pxpx, kxpx = poly_px(mi), poly_pxpx(mi), poly_kxpx(par, mi, x)
+    Z = V.T.dot(iK)
+    iG = chol_inverse(Z.dot(V))
+    B = Z.dot(Q).dot(Z.T) + pxpx - Z.dot(kxpx) - kxpx.T.dot(Z.T)
+    b = Z.dot(q) - px
+    return (alpha ** 2 * (1 - np.trace(Q.dot(iK)) + np.trace(B.dot(iG))),
+            rbf_kbar(par) - q.dot(iK).dot(q) + b.dot(iG).dot(b))
+
+
 # --------------------------------------------------------------------------------------------------------------
 # integrands (a4): closed-form functions of ssmod.py, additive-noise evaluation (zero noise) unless noted
 # --------------------------------------------------------------------------------------------------------------

@@ -76,6 +76,8 @@ _PROTOTYPES = {
                                        ctypes.c_double] + [c_double_p] * 9 + [c_int32_p]),
     'ssmq_weights_bs': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int,
                                        ctypes.c_double, c_int32_p, ctypes.c_int] + [c_double_p] * 9 + [c_int32_p]),
+    'ssmq_variances_bs': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_double,
+                                         c_int32_p, ctypes.c_int, c_double_p, c_double_p, c_int32_p]),
     'ssmq_transform_create': (ctypes.c_void_p, [ctypes.c_int] * 4 + [c_double_p] * 5 + [ctypes.c_int, ctypes.c_double,
                                                                                        c_double_p]),
     'ssmq_transform_update': (ctypes.c_int, [ctypes.c_void_p] + [c_double_p] * 5 + [ctypes.c_int, ctypes.c_double,

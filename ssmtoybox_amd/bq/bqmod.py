@@ -180,3 +180,43 @@ class BayesSardModel(Model):
         self.model_var = float(out['mv'][0][0])
         self.integral_var = float(out['iv'][0][0])
         return out['wm'][0], out['Wc'][0], out['Wcc'][0], self.model_var, self.integral_var
+
+    def _variances(self, pars, multi_ind=None):
+        """theta-batched (model_var, integral_var) with the semantics of the reference's stand-alone methods
+        (`ssmq_variances_bs`): pars (P, 1 + D)."""
+        if not isinstance(multi_ind, np.ndarray):
+            multi_ind = self.mulind
+        lib = _lib.load()
+        x, px = _lib.as_c(self.points)
+        p, pp = _lib.as_c(np.atleast_2d(np.asarray(pars, dtype=np.float64)))
+        mi = np.ascontiguousarray(multi_ind, dtype=np.int32)
+        D, N = x.shape
+        P = p.shape[0]
+        if p.shape[1] != D + 1:
+            raise ValueError('kernel parameters must have 1 + dim entries per row')
+        mv, pmv = _lib.out_c((P,))
+        iv, piv = _lib.out_c((P,))
+        st = np.zeros(P, dtype=np.int32)
+        rc = _lib.check(lib.ssmq_variances_bs(D, N, px, pp, P, float(self.kernel.jitter),
+                                              mi.ctypes.data_as(_lib.c_int32_p), mi.shape[1], pmv, piv,
+                                              st.ctypes.data_as(_lib.c_int32_p)), 'ssmq_variances_bs')
+        if rc > 0:
+            raise np.linalg.LinAlgError('Bayes-Sard variances: matrix not positive definite (parameter row {}, code {})'
+                                        .format(rc - 1, int(st[rc - 1])))
+        return mv, iv
+
+    def exp_model_variance(self, par, mulind=None):
+        """bq/bqmod.py:995-1026 (not the value bq_weights() returns: no jitter on V' iK V, general formula always)."""
+        return float(self._variances(self.kernel.get_parameters(par)[:1], mulind)[0][0])
+
+    def integral_variance(self, par, mulind=None):
+        """bq/bqmod.py:1028-1050."""
+        return float(self._variances(self.kernel.get_parameters(par)[:1], mulind)[1][0])
+
+    def exp_model_variance_batch(self, pars, mulind=None):
+        """Length-scale sweeps (research/bsq/bsq_ungm.py:244-282) in one launch: pars (P, 1 + D) -> (P,)."""
+        return self._variances(pars, mulind)[0]
+
+    def integral_variance_batch(self, pars, mulind=None):
+        return self._variances(pars, mulind)[1]
+

@@ -22,6 +22,8 @@ constexpr int kWgtBlock = 256;
 
 struct WgtArgs {
     int32_t D, N, P, NB, bs, use_lds;
+    int32_t var_mode;   // 1: BayesSardModel.exp_model_variance / integral_variance semantics (bq/bqmod.py:995-1050): always
+                        // the general formulas, no jitter on V' iK V; weights are still written but are not the reference's
     double jitter;
     const double *xi;       // [D][N]
     const double *par;      // [P][1+D]
@@ -329,7 +331,8 @@ __global__ __launch_bounds__(kWgtBlock) void k_weights(const WgtArgs a) {
     bsync();
     gemm(Z, N, V, NB, true, iK, N, false, NB, N, N);        // Z = V' iK
     gemm(G, NB, Z, N, false, V, NB, false, NB, NB, N);      // G = Z V
-    for (int i = tid; i < NB; i += kWgtBlock) G[i * NB + i] += 1e-8;
+    if (!a.var_mode)
+        for (int i = tid; i < NB; i += kWgtBlock) G[i * NB + i] += 1e-8;
     bsync();
     const bool pd2 = chol_block(G, NB, &s_flag);
     if (!pd2) {
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(kWgtBlock) void k_weights(const WgtArgs a) {
     }
     chol_inverse(G, iG, NB);                                 // cho_solve(cho_factor(.), I): not symmetrised
     const double ks2 = alpha * alpha;
-    if (NB == N) {
+    if (NB == N && !a.var_mode) {
         // pi-unisolvent points: weights from the inverse Vandermonde matrix only (:952-961)
         double *Vc = T1, *iV = T2;
         for (int idx = tid; idx < N * N; idx += kWgtBlock) Vc[idx] = V[idx];
@@ -506,8 +509,8 @@ struct DBuf {
 };
 }  // namespace
 
-static int weights_impl(int D, int N, const double *xi, const double *par, int P, double jitter, const int32_t *mulind,
-                        int NB, double *wm, double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R,
+static int weights_impl(int var_mode, int D, int N, const double *xi, const double *par, int P, double jitter,
+                        const int32_t *mulind, int NB, double *wm, double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R,
                         double *model_var, double *integral_var, int32_t *status) {
     if (D < 1 || D > SSMQ_MAX_DIM || N < 1 || N > SSMQ_MAX_PTS || P < 1 || !xi || !par || NB < 0 || NB > N ||
         (NB > 0 && !mulind)) {
@@ -551,7 +554,7 @@ static int weights_impl(int D, int N, const double *xi, const double *par, int P
     }
     WgtArgs a;
     memset(&a, 0, sizeof(a));
-    a.D = D; a.N = N; a.P = P; a.NB = NB; a.jitter = jitter; a.use_lds = (N <= 64) ? 1 : 0;
+    a.D = D; a.N = N; a.P = P; a.NB = NB; a.jitter = jitter; a.use_lds = (N <= 64) ? 1 : 0; a.var_mode = var_mode;
     a.xi = dxi.d(); a.par = dpar.d(); a.mulind = (const int32_t *)dmi.p; a.px = dpx.d(); a.xpx = dxpx.d();
     a.pxpx = dpxpx.d(); a.wm = dwm.d(); a.Wc = dWc.d(); a.Wcc = dWcc.d(); a.iK = diK.d(); a.q = dq.d(); a.Q = dQ.d();
     a.R = dR.d(); a.mv = dmv.d(); a.iv = div.d(); a.status = (int32_t *)dst.p; a.work = dwork.d();
@@ -637,7 +640,7 @@ int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double
 extern "C" int ssmq_weights_gp(int D, int N, const double *xi, const double *par, int P, double jitter, double *wm,
                                double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R, double *model_var,
                                double *integral_var, int32_t *status) {
-    return ssmq::weights_impl(D, N, xi, par, P, jitter, nullptr, 0, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var,
+    return ssmq::weights_impl(0, D, N, xi, par, P, jitter, nullptr, 0, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var,
                               status);
 }
 
@@ -649,6 +652,17 @@ extern "C" int ssmq_weights_bs(int D, int N, const double *xi, const double *par
         ssmq::set_error("weights_bs: NB must be >= 1");
         return SSMQ_E_ARG;
     }
-    return ssmq::weights_impl(D, N, xi, par, P, jitter, mulind, NB, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var,
+    return ssmq::weights_impl(0, D, N, xi, par, P, jitter, mulind, NB, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var,
                               status);
+}
+
+extern "C" int ssmq_variances_bs(int D, int N, const double *xi, const double *par, int P, double jitter,
+                                 const int32_t *mulind, int NB, double *model_var, double *integral_var,
+                                 int32_t *status) {
+    if (NB < 1) {
+        ssmq::set_error("variances_bs: NB must be >= 1");
+        return SSMQ_E_ARG;
+    }
+    return ssmq::weights_impl(1, D, N, xi, par, P, jitter, mulind, NB, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, model_var, integral_var, status);
 }

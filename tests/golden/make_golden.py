@@ -521,8 +521,36 @@ def g8_marginal():
     save('g8_marginal', **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G9: length-scale sweeps of the Bayes-Sard expected model variance (research/bsq/bsq_ungm.py:240-282) and of the GP one
+# ---------------------------------------------------------------------------------------------------------------
+def g9_sweeps():
+    out = {}
+    ls = np.logspace(-1.0, 1.5, 14)
+    mi1 = np.array([[0, 1, 2]])
+    tf = BayesSardTransform(1, 1, np.array([[1, 1]]), mi1, point_str='ut')
+    out['ls'] = ls
+    out['bs1_emv'] = np.array([tf.model.exp_model_variance(np.array([[1.0, el]]), mi1) for el in ls])
+    out['bs1_ivar'] = np.array([tf.model.integral_variance(np.array([[1.0, el]]), mi1) for el in ls])
+    mi2 = np.hstack((np.zeros((2, 1)), np.eye(2), 2 * np.eye(2))).astype(int)
+    tf = BayesSardTransform(2, 1, np.array([[1, 1, 1]]), mi2, point_str='ut')
+    ls2 = ls[::2]
+    out['ls2'], out['bs2_mi'] = ls2, mi2
+    out['bs2_emv'] = np.array([[tf.model.exp_model_variance(np.array([[1.0, a, b]]), mi2) for b in ls2] for a in ls2])
+    # general branch (fewer basis functions than points): 5 UT points in 2-D, total degree <= 1 (3 functions)
+    mi3 = np.hstack((np.zeros((2, 1)), np.eye(2))).astype(int)
+    tf = BayesSardTransform(2, 1, np.array([[1, 1, 1]]), mi3, point_str='ut')
+    out['bs3_mi'] = mi3
+    out['bs3_emv'] = np.array([[tf.model.exp_model_variance(np.array([[1.0, a, b]]), mi3) for b in ls2] for a in ls2])
+    out['bs3_ivar'] = np.array([[tf.model.integral_variance(np.array([[1.0, a, b]]), mi3) for b in ls2] for a in ls2])
+    tg = GaussianProcessTransform(2, 1, np.array([[1, 1, 1]]), point_str='ut')
+    out['gp2_emv'] = np.array([[tg.model.exp_model_variance(np.array([[1.0, a, b]])) for b in ls2] for a in ls2])
+    out['gp2_ivar'] = np.array([[tg.model.integral_variance(np.array([[1.0, a, b]])) for b in ls2] for a in ls2])
+    save('g9_sweeps', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
     if 'g1' in which:
         g1_points()
     if 'g2' in which:
@@ -539,3 +567,5 @@ if __name__ == '__main__':
         g7_metrics()
     if 'g8' in which:
         g8_marginal()
+    if 'g9' in which:
+        g9_sweeps()

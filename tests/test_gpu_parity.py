@@ -233,6 +233,40 @@ def test_bs_weights_golden(amd, golden, case):
     assert abs(tf.model.integral_var - g[t + '_iv']) < 1e-6
 
 
+def test_variance_sweeps_golden(amd, golden):
+    """Length-scale sweeps (research/bsq/bsq_ungm.py:244-282): the whole grid in ONE theta-batched launch, against the
+    reference's exp_model_variance / integral_variance values."""
+    g = golden('g9_sweeps')
+    ls, ls2 = g['ls'], g['ls2']
+    tf = amd.BayesSardTransform(1, 1, np.array([[1.0, 1.0]]), np.array([[0, 1, 2]]), 'ut')
+    pars = np.column_stack((np.ones(ls.size), ls))
+    emv, ivar = tf.model.exp_model_variance_batch(pars), tf.model.integral_variance_batch(pars)
+    # the long end of the sweep has cond(K) ~ 1 / jitter = 1e8: absolute agreement at the kernel's unit scale
+    assert np.abs(emv - g['bs1_emv']).max() < 2e-8 and np.abs(ivar - g['bs1_ivar']).max() < 2e-8
+    short = ls < 3.0
+    assert np.abs(emv - g['bs1_emv'])[short].max() < 1e-12
+    assert abs(tf.model.exp_model_variance(np.array([[1.0, ls[3]]])) - g['bs1_emv'][3]) < 1e-12
+    assert abs(tf.model.integral_variance(np.array([[1.0, ls[3]]])) - g['bs1_ivar'][3]) < 1e-12
+    grid = np.array([[1.0, a, b] for a in ls2 for b in ls2])
+    for tag in ('bs2', 'bs3'):
+        tf = amd.BayesSardTransform(2, 1, np.array([[1.0, 1.0, 1.0]]), g[tag + '_mi'], 'ut')
+        emv = tf.model.exp_model_variance_batch(grid).reshape(ls2.size, ls2.size)
+        assert np.abs(emv - g[tag + '_emv']).max() < 2e-8, tag
+        assert np.abs(emv - g[tag + '_emv'])[:4, :4].max() < 1e-11, tag
+    iv = tf.model.integral_variance_batch(grid).reshape(ls2.size, ls2.size)
+    assert np.abs(iv - g['bs3_ivar']).max() < 2e-8
+    tg = amd.GaussianProcessTransform(2, 1, np.array([[1.0, 1.0, 1.0]]), 'rbf', 'ut')
+    w = tg.model.bq_weights_batch(grid)
+    assert np.abs(w['model_var'].reshape(ls2.size, -1) - g['gp2_emv']).max() < 2e-8
+    assert np.abs(w['integral_var'].reshape(ls2.size, -1) - g['gp2_ivar']).max() < 2e-8
+    # a 100 x 100 grid as in the reference's 2-D demo: 1e4 parameter rows, one launch, all finite and in range
+    big = np.logspace(-1, 1, 100)
+    grid = np.array([[1.0, a, b] for a in big for b in big])
+    tf = amd.BayesSardTransform(2, 1, np.array([[1.0, 1.0, 1.0]]), g['bs2_mi'], 'ut')
+    emv = tf.model.exp_model_variance_batch(grid)
+    assert emv.shape == (10000,) and np.all(np.isfinite(emv)) and emv.max() < 4.0 and emv.min() > -1e-6
+
+
 def test_bs_reproduces_classical_rules(amd):
     # the reference's known-answer tests (tests/test_bqmod.py:368-459) on the device path
     one = np.array([[1.0, 1.0]])
