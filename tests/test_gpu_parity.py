@@ -990,6 +990,56 @@ def test_matrix_core_route_exact_on_integers(amd, monkeypatch, N, E, B):
     assert all(np.array_equal(a, b) for a, b in zip(got, ref))
 
 
+def test_random_shapes_against_oracle(amd):
+    """Sweep of run-time shapes through the generic kernel's split entry points (sigma points out, reductions in): random
+    D, E, N, random weights (not from any quadrature rule), BQ / BQ + t-process variance / centred form."""
+    from ssmtoybox_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(2026)
+    for trial in range(40):
+        D, E, N = int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(1, 45))
+        form = int(rng.integers(0, 2))
+        tp = (form == 0) and bool(rng.integers(0, 2))
+        B = int(rng.integers(1, 70))
+        xi = rng.standard_normal((D, N))
+        wm = rng.standard_normal(N) / N
+        Wc = rng.standard_normal((N, N)) / N
+        Wc = Wc + Wc.T
+        wcd = rng.random(N) / N
+        Wcc = rng.standard_normal((D, N)) / N
+        emv = np.diag(rng.random(E))
+        iK = rng.standard_normal((N, N))
+        iK = iK.dot(iK.T) / N
+        h = lib.ssmq_transform_create(D, E, N, form, _lib.as_c(xi)[1], _lib.as_c(wm)[1],
+                                      _lib.as_c(wcd if form else Wc)[1], None if form else _lib.as_c(Wcc)[1],
+                                      _lib.as_c(emv)[1], 0, 4.0 if tp else 0.0, _lib.as_c(iK)[1] if tp else None)
+        assert h, (D, E, N, form)
+        means = rng.standard_normal((B, D))
+        a = rng.standard_normal((B, D, D)) / np.sqrt(D)
+        covs = np.einsum('bij,bkj->bik', a, a) + 0.2 * np.eye(D)
+        x, chol = np.empty((B, D, N)), np.empty((B, D, D))
+        st = np.zeros(B, dtype=np.int32)
+        assert lib.ssmq_sigma_points_batch(ctypes.c_void_p(h), B, _lib.as_c(means)[1], _lib.as_c(covs)[1], _lib.as_c(x)[1],
+                                           _lib.as_c(chol)[1], st.ctypes.data_as(_lib.c_int32_p)) == 0
+        fx = rng.standard_normal((B, E, N)) + np.sin(x[:, :1, :])          # any values: the reductions are linear algebra
+        mf, cf, cfx = np.empty((B, E)), np.empty((B, E, E)), np.empty((B, E, D))
+        _lib.check(lib.ssmq_apply_fx_batch(ctypes.c_void_p(h), B, _lib.as_c(chol)[1], _lib.as_c(means)[1], _lib.as_c(x)[1],
+                                           _lib.as_c(fx)[1], _lib.as_c(mf)[1], _lib.as_c(cf)[1], _lib.as_c(cfx)[1]),
+                   'ssmq_apply_fx_batch')
+        lib.ssmq_transform_destroy(ctypes.c_void_p(h))
+        for b in range(0, B, max(1, B // 5)):
+            L = np.linalg.cholesky(covs[b])
+            assert np.allclose(chol[b], L, rtol=1e-13, atol=1e-14) and np.allclose(x[b], means[b][:, None] + L.dot(xi),
+                                                                                 rtol=1e-13, atol=1e-13)
+            if form:
+                ref = orc.moments_sigma(fx[b], x[b], means[b], wm, wcd)
+            else:
+                ed = orc.tp_emv_diag(fx[b], iK, np.diag(emv), 4.0) if tp else np.diag(emv)
+                ref = orc.moments_bq(fx[b], chol[b], wm, Wc, Wcc, ed)
+            for got, want in zip((mf[b], cf[b], cfx[b]), ref):
+                assert np.allclose(got, want, rtol=1e-11, atol=1e-11 * max(1.0, np.abs(want).max())), (trial, D, E, N, form, tp)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # edge cases of the batch interface
 # ---------------------------------------------------------------------------------------------------------------
