@@ -126,6 +126,25 @@ class FilterBench:
             dyn = ssmod.UNGMTransition(ssmod.GaussRV(1), ssmod.GaussRV(1, cov=np.array([[10.0]])))
             obs = ssmod.UNGMMeasurement(ssmod.GaussRV(1), 1)
             ell = 3.0
+        elif workload == 'ct':
+            # BASELINE configs[3]: coordinated-turn dynamics (5 states), four bearing sensors (tests/test_ssinf.py:66-82
+            # of the reference); data from the device simulator (Gaussian noise; the filter under test is the t-process one)
+            m0 = np.array([1000, 300, 1000, 0, np.deg2rad(-3.0)])
+            P0 = np.diag([100, 10, 100, 10, 0.1])
+            dt, r1, r2 = 0.1, 0.1, 1.75e-4
+            A = np.array([[dt ** 3 / 3, dt ** 2 / 2], [dt ** 2 / 2, dt]])
+            Q = np.zeros((5, 5))
+            Q[:2, :2], Q[2:4, 2:4], Q[4, 4] = r1 * A, r1 * A, r2 * dt
+            sensors = np.vstack((1000 * np.eye(2), -1000 * np.eye(2))).astype(float)
+            dyn = ssmod.CoordinatedTurnTransition(ssmod.GaussRV(5, m0, P0), ssmod.GaussRV(5, cov=Q), dt=dt)
+            obs = ssmod.BearingMeasurement(ssmod.GaussRV(4, cov=10e-3 * np.eye(4)), 5, state_index=[0, 2],
+                                           sensor_pos=sensors)
+            d_x, d_y, _ = ssmod.simulate_dev(dyn, obs, T, B, seed=seed)
+            self.x_true = d_x.download((T, 5, ld))[:, :, :B].transpose(1, 0, 2)
+            y = d_y.download((T, 4, ld))[:, :, :B].transpose(1, 0, 2)
+            d_x.free()
+            d_y.free()
+            ell = 100.0
         else:
             bias = workload == 'reentry6'
             self.x_true, y, m0, P0, Q, G, R = simulate_reentry(B, T, seed, bias)
@@ -137,6 +156,9 @@ class FilterBench:
         D, Y = self.D, self.Y
         if filt == 'ukf':
             self.alg = ssinf.UnscentedKalman(dyn, obs)
+        elif filt == 'tpqkf':
+            par = np.array([[1.0] + [ell] * (D - 1) + [1.0]]) if workload == 'ct' else np.array([[1.0] + [ell] * D])
+            self.alg = ssinf.StudentProcessKalman(dyn, obs, par, par)
         else:
             par = np.array([[1.0] + [ell] * D])
             self.alg = ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut')
@@ -347,9 +369,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=10000, help='MC trajectories per GPU')
     ap.add_argument('--time-steps', type=int, default=100)
-    ap.add_argument('--workload', default='ungm', choices=['ungm', 'reentry5', 'reentry6'],
+    ap.add_argument('--workload', default='ungm', choices=['ungm', 'reentry5', 'reentry6', 'ct'],
                     help="'ungm' is the headline (BASELINE configs[1]); the others are extra measurements")
-    ap.add_argument('--filter', default='gpqkf', choices=['gpqkf', 'ukf'])
+    ap.add_argument('--filter', default='gpqkf', choices=['gpqkf', 'ukf', 'tpqkf'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-mt6', action='store_true')
     args = ap.parse_args()
