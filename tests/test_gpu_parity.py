@@ -990,6 +990,38 @@ def test_matrix_core_route_exact_on_integers(amd, monkeypatch, N, E, B):
     assert all(np.array_equal(a, b) for a, b in zip(got, ref))
 
 
+def test_extreme_covariance_scales(amd):
+    """The register kernels take square roots and reciprocals of the Cholesky pivots with a one-round refinement of
+    v_rsq_f64 / v_rcp_f64 (csrc/ssmq_device.h) instead of the compiler's range-rescaled sequences: covariances scaled by
+    2^+-900 (1e+-271, far beyond any model of the reference) must still go through a linear model exactly as the
+    unscaled ones do, up to the power of two."""
+    from ssmtoybox_amd import ssmod as sm
+    rng = np.random.default_rng(77)
+    B = 200
+    means = np.zeros((B, 4))      # zero mean: the points are +-c L columns, whatever the scale (no absorption into m)
+    a = rng.standard_normal((B, 4, 4)) / 2
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(4)
+    model = sm.ConstantVelocity(dt=0.5)
+    f = model.dyn_eval
+    A = np.array([[1, 0.5, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0.5], [0, 0, 0, 1]])
+    tf = amd.UnscentedTransform(4)
+    assert 'k_apply_small' in tf.kernel_name(f)
+    base = tf.apply_batch(f, means, covs, 0.0)
+    assert np.allclose(base[1], np.einsum('ij,bjk,lk->bil', A, covs, A), rtol=1e-12, atol=1e-13)   # linear: UT is exact
+    for k in (-900, 900):
+        sc = 2.0 ** k
+        got = tf.apply_batch(f, means, covs * sc, 0.0)
+        # centred form on a linear map: covariance and cross-covariance scale with the input covariance exactly
+        assert np.allclose(got[1] / sc, base[1], rtol=1e-12, atol=1e-13)
+        assert np.allclose(got[2] / sc, base[2], rtol=1e-12, atol=1e-13)
+        assert np.abs(got[0]).max() <= 1e-12 * np.sqrt(sc)          # sums of +-c L columns: zero up to rounding
+    tg = amd.GaussianProcessTransform(4, 4, np.array([[1.0, 3.0, 3.0, 3.0, 3.0]]), 'rbf', 'ut')
+    assert 'k_apply_small' in tg.kernel_name(f)
+    for k in (-900, 0, 600):
+        got = tg.apply_batch(f, means, covs * 2.0 ** k, 0.0)
+        assert all(np.all(np.isfinite(g)) for g in got), k
+
+
 def test_random_shapes_against_oracle(amd):
     """Sweep of run-time shapes through the generic kernel's split entry points (sigma points out, reductions in): random
     D, E, N, random weights (not from any quadrature rule), BQ / BQ + t-process variance / centred form."""
