@@ -290,7 +290,8 @@ static int gemm_scratch(int64_t M, int NP, int64_t B, int D, double **fx, double
 int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
                    const double *d_cov, const double *d_time, int time_stride, double *d_mean_f, double *d_cov_f,
                    double *d_cov_fx, int32_t *d_status, const double *d_cov_add, const char **kernel_name,
-                   bool dry_run, double cov_scale = 1.0, double ccov_scale = 1.0, const double *ttab = nullptr) {
+                   bool dry_run, double cov_scale = 1.0, double ccov_scale = 1.0, const double *ttab = nullptr,
+                   bool stream_out = true) {
     FInfo fi;
     int rc = check_integrand(h, f, &fi);
     if (rc) return rc;
@@ -317,6 +318,7 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         a.cov_add = d_cov_add ? d_cov_add : h->d_small + const_layout(h->D, h->E, h->N, h->form).zero; a.B = B; a.ld = ld;
         a.time_stride = d_time ? time_stride : 0; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
         a.cov_scale = cov_scale; a.ccov_scale = ccov_scale;
+        a.stream_out = stream_out ? 1 : 0;
         fill_fpar(f, &a.fp);
         a.fp.ttab = ttab;
         return hip_fail(se->fn(a, stream()), se->name);
@@ -948,10 +950,10 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
                 C_xx = d_pC + (int64_t)k * D * D * ld;
             }
             rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec + k, 0, m_pr, P_pr, C_xx, st_a, gqg, nullptr, false,
-                                hs[k], 1.0, has_td ? ttab_d : nullptr);
+                                hs[k], 1.0, has_td ? ttab_d : nullptr, false);
             if (!rc)
                 rc = apply_dev_impl(h_obs, f_obs, B, ld, m_pr, P_pr, tvec + k, 0, y_mean, P_y, P_yx, st_b, rr, nullptr,
-                                    false, hs[k], hs[k], has_to ? ttab_o : nullptr);
+                                    false, hs[k], hs[k], has_to ? ttab_o : nullptr, false);
             if (!rc)
                 rc = launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, d_y + (int64_t)k * Y * ld,
                                              d_fm + (int64_t)k * D * ld, d_fP + (int64_t)k * D * D * ld, d_status,
@@ -1091,20 +1093,20 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
             rc = launch_augment(m_in, P_in, d_qm, d_qc, ma, Pa, D, dq, B, ld, s);
             if (!rc)
                 rc = apply_dev_impl(h_dyn, f_dyn, B, ld, ma, Pa, tvec + k, 0, m_pr, P_pr, C_xx, st_a, nullptr, nullptr, false,
-                                    1.0, 1.0, has_td ? ttab_d : nullptr);
+                                    1.0, 1.0, has_td ? ttab_d : nullptr, false);
         } else {
             rc = apply_dev_impl(h_dyn, f_dyn, B, ld, m_in, P_in, tvec + k, 0, m_pr, P_pr, C_xx, st_a, d_qc, nullptr, false,
-                                1.0, 1.0, has_td ? ttab_d : nullptr);
+                                1.0, 1.0, has_td ? ttab_d : nullptr, false);
         }
         if (rc) break;
         if (dr) {
             rc = launch_augment(m_pr, P_pr, d_rm, d_rc, mo, Po, D, dr, B, ld, s);
             if (!rc)
                 rc = apply_dev_impl(h_obs, f_obs, B, ld, mo, Po, tvec + k, 0, y_mean, P_y, P_yx, st_b, nullptr, nullptr, false,
-                                    1.0, 1.0, has_to ? ttab_o : nullptr);
+                                    1.0, 1.0, has_to ? ttab_o : nullptr, false);
         } else {
             rc = apply_dev_impl(h_obs, f_obs, B, ld, m_pr, P_pr, tvec + k, 0, y_mean, P_y, P_yx, st_b, d_rc, nullptr, false,
-                                1.0, 1.0, has_to ? ttab_o : nullptr);
+                                1.0, 1.0, has_to ? ttab_o : nullptr, false);
         }
         if (!rc)
             rc = launch_kalman_update_ex(D, Y, B, ld, m_pr, P_pr, y_mean, P_y, P_yx, d_y + (int64_t)k * Y * ld,

@@ -400,41 +400,49 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 }
 
 // Sink of the stand-alone kernel: every element goes straight to its SoA plane.
-// Results are written once and not read again by this kernel: non-temporal stores keep them from displacing the inputs
-// in L2 / Infinity Cache and measured 22.9 -> 20.0 us on the D = E = 6 launch (SSMQ_TEMPORAL_STORE=1 restores plain stores;
-// non-temporal LOADS of the inputs made no difference)
+// Stand-alone transforms write their results once and nobody re-reads them soon: non-temporal stores keep them from
+// displacing the inputs in L2 / Infinity Cache (22.9 -> 19.4 us on the D = E = 6 launch; non-temporal LOADS of the
+// inputs made no difference).  Inside a filter's launch loop the next kernel reads the outputs right back, and there
+// plain stores are 8 % faster (reentry UKF, B = 1e5) - hence two instantiations of the fast-path kernels, chosen at launch
+// (a run-time branch around every store cost the whole gain: it splits the unrolled body into ~80 basic blocks).
+// The fused filter kernels always stream (SSMQ_STORE).
 #ifndef SSMQ_TEMPORAL_STORE
 #define SSMQ_STORE(dst, v) __builtin_nontemporal_store((v), &(dst))
 #else
 #define SSMQ_STORE(dst, v) (dst) = (v)
 #endif
-template <int D, int E>
+template <int D, int E, bool NTS>
 struct GlobalSink {
     double *mean_f, *cov_f, *cov_fx;
     int64_t ld;
     uint32_t b;
+    template <typename T>
+    __device__ __forceinline__ static void put(T &dst, T v) {
+        if constexpr (NTS) SSMQ_STORE(dst, v);
+        else dst = v;
+    }
     // SSMQ_DIAG_* : timing-only diagnostic builds (tools/ab.sh); never defined in the product build.
     __device__ __forceinline__ void keep(double v) { asm volatile("" ::"v"(v)); }
     __device__ __forceinline__ void mean(int e, double v) {
 #ifdef SSMQ_DIAG_NOSTORE_ALL
         keep(v);
 #else
-        SSMQ_STORE(mean_f[e * ld + b], v);
+        put(mean_f[e * ld + b], v);
 #endif
     }
     __device__ __forceinline__ void cov(int e, int e2, double v) {
 #if defined(SSMQ_DIAG_NOSTORE_ALL) || defined(SSMQ_DIAG_NOSTORE_COV)
         keep(v);
 #else
-        SSMQ_STORE(cov_f[(e * E + e2) * ld + b], v);
-        if (e2 != e) SSMQ_STORE(cov_f[(e2 * E + e) * ld + b], v);
+        put(cov_f[(e * E + e2) * ld + b], v);
+        if (e2 != e) put(cov_f[(e2 * E + e) * ld + b], v);
 #endif
     }
     __device__ __forceinline__ void ccov(int e, int d, double v) {
 #ifdef SSMQ_DIAG_NOSTORE_ALL
         keep(v);
 #else
-        SSMQ_STORE(cov_fx[(e * D + d) * ld + b], v);
+        put(cov_fx[(e * D + d) * ld + b], v);
 #endif
     }
 };
@@ -442,7 +450,7 @@ struct GlobalSink {
 // __launch_bounds__(64, 2): at least two waves per SIMD, i.e. at most 256 registers per lane.  The D = E = 6, N = 13
 // kernel needs ~270 without the bound (one wave per SIMD, no latency hiding at all); with it hipcc spills 8 registers
 // and B = 1e5 trajectories (1563 waves) are all resident at once.
-template <int D, int E, int N, int F, int FORM, int TP, int SEL, int OPT>
+template <int D, int E, int N, int F, int FORM, int TP, int SEL, int OPT, bool NTS = false>
 __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs a) {
     const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;  // 32-bit lane offset: plane base stays scalar
     if ((int64_t)b >= a.B) return;
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs 
     const double t = a.time[a.time_stride ? b : 0];
 
     CoreParams cp{(cdouble_p)a.consts, (cdouble_p)a.cov_add, a.emv_mode, a.tp_nu, a.cov_scale, a.ccov_scale};
-    GlobalSink<D, E> sink{a.mean_f, a.cov_f, a.cov_fx, ld, b};
+    GlobalSink<D, E, NTS> sink{a.mean_f, a.cov_f, a.cov_fx, ld, b};
     const bool ok = moment_transform_core<D, E, N, F, FORM, TP, SEL, true, OPT>(m, L, t, a.fp, cp, sink);
     a.status[b] = ok ? 0 : 1;
     if (!ok) {
@@ -486,7 +494,13 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs 
 template <int D, int E, int N, int F, int FORM, int TP, int SEL, int OPT>
 inline hipError_t launch_apply_small(const ApplyArgs &a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + kSmallBlock - 1) / kSmallBlock);
-    hipLaunchKernelGGL((k_apply_small<D, E, N, F, FORM, TP, SEL, OPT>), dim3(grid), dim3(kSmallBlock), 0, s, a);
+    if constexpr (OPT != 0) {   // the bandwidth-bound shapes: streaming stores for stand-alone calls (a.stream_out)
+        if (a.stream_out) {
+            hipLaunchKernelGGL((k_apply_small<D, E, N, F, FORM, TP, SEL, OPT, true>), dim3(grid), dim3(kSmallBlock), 0, s, a);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((k_apply_small<D, E, N, F, FORM, TP, SEL, OPT, false>), dim3(grid), dim3(kSmallBlock), 0, s, a);
     return hipGetLastError();
 }
 

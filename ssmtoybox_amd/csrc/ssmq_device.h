@@ -58,6 +58,8 @@ struct ApplyArgs {
     int32_t emv_mode;
     double tp_nu;
     double cov_scale, ccov_scale;   // 1.0 except inside Studentian filters (ssinf.py:672-693)
+    int32_t stream_out;             // 1: the outputs are final (non-temporal stores); 0: the next kernel of a filter loop
+                                    // reads them right back, keep them in L2 / Infinity Cache
     FPar fp;
 };
 
