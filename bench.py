@@ -261,6 +261,34 @@ class C5GemmBench:
         ms = e0.elapsed_ms(e1) / iters
         return ms, 2.0 * self.M * self.NP * self.NP
 
+    def measure_full_transform(self, B, warmup=3, iters=20):
+        """The whole D = 10 transform with the device-evaluated synthetic model (ssmod.Smooth10DTransition): Cholesky +
+        points + integrand pass, the GEMM, the per-trajectory rest - three launches, moments resident in HBM."""
+        from ssmtoybox_amd import ssmod
+        _lib = self._lib
+        rng = np.random.default_rng(6)
+        means = rng.standard_normal((B, 10))
+        a = rng.standard_normal((B, 10, 10)) / np.sqrt(10)
+        covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(10)
+        f = ssmod.Smooth10DTransition().dyn_eval
+        mean, cov = _lib.SoA.from_host(means), _lib.SoA.from_host(covs)
+        mf, cf, cfx = _lib.SoA(10, B), _lib.SoA(100, B), _lib.SoA(100, B)
+        st = _lib.DeviceBuffer(4 * mean.ld)
+        tbuf = _lib.DeviceBuffer(8)
+        tbuf.upload(np.zeros(1))
+        for _ in range(warmup):
+            self.tf.apply_batch_dev(f, mean, cov, tbuf, mf, cf, cfx, st, 0)
+        _lib.sync()
+        e0, e1 = _lib.Event(), _lib.Event()
+        e0.record()
+        for _ in range(iters):
+            self.tf.apply_batch_dev(f, mean, cov, tbuf, mf, cf, cfx, st, 0)
+        e1.record()
+        ms = e0.elapsed_ms(e1) / iters
+        for buf in (mean, cov, mf, cf, cfx):
+            buf.buf.free()
+        return ms
+
 
 class Mt6Bench:
     """Batched GPQ moment transform, D = E = 6, N = 13, B = 1e5, rotating buffer sets (> 256 MB in total so that the
@@ -479,10 +507,12 @@ def main():
         c5 = C5GemmBench(amd, 10000, seed=5)
         err = c5.check()
         ms, flop = c5.measure()
+        ms_full = c5.measure_full_transform(10000)
         tf_s = flop / (ms * 1e-3) / 1e12
         out['roofline_c5'] = {'bound': 'mfma', 'achieved': tf_s, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
                               'frac': tf_s / F64_MFMA_PEAK_TF, 'traffic': None, 'kernel': 'k_fxwc_mfma<13,1>',
                               'flop_per_launch': flop, 'ms_per_launch': ms, 'max_scaled_err_vs_numpy': err,
+                              'full_transform_ms': ms_full, 'full_transforms_per_s': 10000 / (ms_full * 1e-3),
                               'workload': 'T = FX Wc of the Bayes-Sard transform, D=E=10, N=201 (padded 208), B=1e4: '
                                           '(1e5 x 208) x (208 x 208), v_mfma_f64_16x16x4_f64'}
     if rank == 0 and not args.no_cpu_baseline and args.workload == 'ungm' and args.filter == 'gpqkf':

@@ -61,7 +61,10 @@ enum ssmq_integrand_id {
     SSMQ_F_BEARING_MEAS = 12,     /* ssmod.py:1189-1195 par: S x (sx, sy) in 2 out S (S = n_par / 2 <= 8) */
     SSMQ_F_CTRS_DYN = 13,         /* ssmod.py:755-774   par: dt, input [x(5), q(2)]  in 7 out 5          */
     SSMQ_F_CV_DYN = 14,           /* ssmod.py:839-846   par: dt           in 4 out 4                     */
-    SSMQ_F_REENTRY2D_BIAS_DYN = 15 /* this build's synthetic 6-D case: reentry-2D + pass-through state, in 6 out 6 */
+    SSMQ_F_REENTRY2D_BIAS_DYN = 15, /* this build's synthetic 6-D case: reentry-2D + pass-through state, in 6 out 6 */
+    SSMQ_F_SMOOTH10D_DYN = 16      /* this build's synthetic 10-D case (the reference has no model above 7 inputs; Bayes-Sard
+                                      quadrature at D = 10 is BASELINE config 5): out[i] = sin(x[i]) + x[5+i]^2,
+                                      out[5+i] = x[5+i] cos(x[i]), i = 0..4; in 10 out 10; no state index */
 };
 
 /* One integrand = id + constants + optional sub-state selection (MeasurementModel.state_index, ssmod.py:990-991):

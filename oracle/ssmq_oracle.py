@@ -451,7 +451,7 @@ def bs_variances(par, x, mi, jitter=1e-8):
 F_UNGM_DYN, F_UNGM_MEAS, F_UNGMNA_DYN, F_UNGMNA_MEAS = 1, 2, 3, 4
 F_PENDULUM_DYN, F_PENDULUM_MEAS, F_REENTRY1D_DYN, F_RANGE_MEAS = 5, 6, 7, 8
 F_REENTRY2D_DYN, F_RADAR2D_MEAS, F_CT_DYN, F_BEARING_MEAS = 9, 10, 11, 12
-F_CTRS_DYN, F_CV_DYN, F_REENTRY2D_BIAS_DYN = 13, 14, 15
+F_CTRS_DYN, F_CV_DYN, F_REENTRY2D_BIAS_DYN, F_SMOOTH10D_DYN = 13, 14, 15, 16
 
 
 def integrand(fid, x, t, p=()):
@@ -520,6 +520,8 @@ def integrand(fid, x, t, p=()):
     if fid == F_CV_DYN:
         dt = p[0]
         return np.array([x[0] + dt * x[1], x[1], x[2] + dt * x[3], x[3]])
+    if fid == F_SMOOTH10D_DYN:    # this build's synthetic 10-D case (Bayes-Sard quadrature at D = 10)
+        return np.concatenate((np.sin(x[:5]) + x[5:10] ** 2, x[5:10] * np.cos(x[:5])))
     raise ValueError(fid)
 
 

@@ -21,7 +21,7 @@ EMV_DIAG, EMV_BROADCAST = 0, 1
 F_UNGM_DYN, F_UNGM_MEAS, F_UNGMNA_DYN, F_UNGMNA_MEAS = 1, 2, 3, 4
 F_PENDULUM_DYN, F_PENDULUM_MEAS, F_REENTRY1D_DYN, F_RANGE_MEAS = 5, 6, 7, 8
 F_REENTRY2D_DYN, F_RADAR2D_MEAS, F_CT_DYN, F_BEARING_MEAS = 9, 10, 11, 12
-F_CTRS_DYN, F_CV_DYN, F_REENTRY2D_BIAS_DYN = 13, 14, 15
+F_CTRS_DYN, F_CV_DYN, F_REENTRY2D_BIAS_DYN, F_SMOOTH10D_DYN = 13, 14, 15, 16
 
 
 class SsmqError(RuntimeError):

@@ -1367,16 +1367,16 @@ extern "C" int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integra
     FInfo fid, fio;
     if (f_dyn) {
         const int in_dyn = D + (dyn_additive ? 0 : dq);
-        if (!integrand_info(f_dyn->id, &fid) || fid.din > in_dyn || fid.dout != D || in_dyn > SSMQ_MAX_FIDX ||
+        if (!integrand_info(f_dyn->id, &fid) || fid.din > in_dyn || fid.dout != D || in_dyn > kMaxIntegrandIn ||
             f_dyn->n_idx != 0) {
-            set_error("simulate: transition integrand / dimension mismatch (state + noise inputs must fit SSMQ_MAX_FIDX)");
+            set_error("simulate: transition integrand / dimension mismatch (state + noise inputs: at most 16)");
             return SSMQ_E_ARG;
         }
     }
     if (f_obs) {
         const int in_obs = D + (obs_additive ? 0 : dr);
         if (!integrand_info(f_obs->id, &fio) || (fio.dout ? fio.dout : Y) != Y || (obs_additive && dr != Y) ||
-            f_obs->n_idx > SSMQ_MAX_FIDX || f_obs->n_idx < 0 || (f_obs->n_idx == 0 && (fio.din > in_obs || in_obs > SSMQ_MAX_FIDX))) {
+            f_obs->n_idx > SSMQ_MAX_FIDX || f_obs->n_idx < 0 || (f_obs->n_idx == 0 && (fio.din > in_obs || in_obs > kMaxIntegrandIn))) {
             set_error("simulate: measurement integrand / dimension mismatch");
             return SSMQ_E_ARG;
         }

@@ -71,9 +71,9 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
                 sx[d * N + n] = s;
             }
             if (a.mode == SSMQ_WIDE_FULL || a.mode == SSMQ_WIDE_EVAL) {
-                double xs[SSMQ_MAX_FIDX], o[SSMQ_MAX_DIM];
+                double xs[kMaxIntegrandIn], o[SSMQ_MAX_DIM];
 #pragma unroll
-                for (int k = 0; k < SSMQ_MAX_FIDX; ++k) {
+                for (int k = 0; k < kMaxIntegrandIn; ++k) {
                     const int src = a.fp.n_idx > 0 ? (k < a.fp.n_idx ? a.fp.idx[k] : 0) : (k < D ? k : 0);
                     xs[k] = sx[src * N + n];
                 }

@@ -264,6 +264,21 @@ struct Fn<SSMQ_F_REENTRY2D_BIAS_DYN> : ReentryCore {
     }
 };
 template <>
+struct Fn<SSMQ_F_SMOOTH10D_DYN> {
+    static constexpr int DIN = 10;
+    __device__ __forceinline__ void init(double, const FPar &) {}
+    template <int E>
+    __device__ __forceinline__ void eval(const double *x, double *o) const {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            double sn, cs;
+            sincos(x[i], &sn, &cs);
+            o[i] = sn + x[5 + i] * x[5 + i];
+            o[5 + i] = x[5 + i] * cs;
+        }
+    }
+};
+template <>
 struct Fn<SSMQ_F_RADAR2D_MEAS> {
     static constexpr int DIN = 2;
     double lx, ly;
@@ -351,7 +366,9 @@ struct Fn<SSMQ_F_CV_DYN> {
     }
 };
 
-// Integrand chosen at run time (generic kernels): xs holds the leading SSMQ_MAX_FIDX inputs, o up to SSMQ_MAX_DIM outputs.
+// Integrand chosen at run time (generic kernels): xs holds the integrand's inputs (kMaxIntegrandIn of them: up to
+// SSMQ_MAX_FIDX selected through a state index, or the leading ones), o up to SSMQ_MAX_DIM outputs.
+constexpr int kMaxIntegrandIn = 16;
 __device__ __forceinline__ void eval_integrand(int id, const double *xs, double t, const FPar &fp, double *o) {
 #define SSMQ_CASE(F)                      \
     case F: {                             \
@@ -375,6 +392,7 @@ __device__ __forceinline__ void eval_integrand(int id, const double *xs, double 
         SSMQ_CASE(SSMQ_F_CTRS_DYN)
         SSMQ_CASE(SSMQ_F_CV_DYN)
         SSMQ_CASE(SSMQ_F_REENTRY2D_BIAS_DYN)
+        SSMQ_CASE(SSMQ_F_SMOOTH10D_DYN)
         default: break;
     }
 #undef SSMQ_CASE
@@ -416,6 +434,7 @@ __host__ inline bool integrand_info(int id, FInfo *o) {
         case SSMQ_F_CTRS_DYN: *o = {7, 5, false}; return true;
         case SSMQ_F_CV_DYN: *o = {4, 4, false}; return true;
         case SSMQ_F_REENTRY2D_BIAS_DYN: *o = {6, 6, false}; return true;
+        case SSMQ_F_SMOOTH10D_DYN: *o = {10, 10, false}; return true;
         default: return false;
     }
 }

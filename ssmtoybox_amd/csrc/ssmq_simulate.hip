@@ -16,7 +16,7 @@ namespace ssmq {
 namespace {
 
 constexpr int kSimBlock = 64;
-constexpr int kSimMaxAug = SSMQ_MAX_FIDX;   // state + noise inputs an integrand can read
+constexpr int kSimMaxAug = kMaxIntegrandIn;   // state + noise inputs an integrand can read
 
 struct SimArgs {
     int32_t D, Y, dq, dr, dyn_additive, obs_additive, T, fid_dyn, fid_obs;

@@ -211,6 +211,16 @@ class ReentryVehicle2DBiasTransition(ReentryVehicle2DTransition):
         return np.array(self._core(x) + [x[5]]) + self.noise_gain.dot(q)
 
 
+class Smooth10DTransition(TransitionModel):
+    """This build's synthetic 10-D model (not in the reference, whose models stop at 7 inputs): a smooth map for the
+    Bayes-Sard quadrature configuration at D = 10 that the device can evaluate itself,
+    out[i] = sin(x[i]) + x[5+i]^2, out[5+i] = x[5+i] cos(x[i]), i = 0..4."""
+    dim_state, dim_noise, noise_additive, _fid = 10, 10, True, _lib.F_SMOOTH10D_DYN
+
+    def dyn_fcn(self, x, q, time):
+        return np.concatenate((np.sin(x[:5]) + x[5:10] ** 2, x[5:10] * np.cos(x[:5]))) + self.noise_gain.dot(q)
+
+
 class CoordinatedTurnTransition(TransitionModel):
     """ssmod.py:587-696."""
     dim_state, dim_noise, noise_additive, _fid = 5, 5, True, _lib.F_CT_DYN

@@ -1072,6 +1072,38 @@ def test_random_shapes_against_oracle(amd):
                 assert np.allclose(got, want, rtol=1e-11, atol=1e-11 * max(1.0, np.abs(want).max())), (trial, D, E, N, form, tp)
 
 
+def test_bsq_d10_device_integrand(amd, golden):
+    """Config C5 without the host in the loop: the synthetic 10-D model evaluated on the device, N = 21 (generic kernel)
+    and N = 201 (EVAL pass -> matrix-core GEMM -> FX pass), against the oracle with the reference's weights injected,
+    and against the host-callable route of the same function."""
+    from ssmtoybox_amd import ssmod as sm
+    g = golden('g2_bs_weights')
+    rng = np.random.default_rng(19)
+    B = 96
+    means = rng.standard_normal((B, 10))
+    a = rng.standard_normal((B, 10, 10)) / np.sqrt(10)
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(10)
+    model = sm.Smooth10DTransition()
+    for tag, pstr, ppar in (('d10_ut', 'ut', None), ('d10_fs5_td2', 'fs', {'degree': 5})):
+        t = 'bs_' + tag
+        tf = amd.BayesSardTransform(10, 10, gp_par(10, 3.0), g[t + '_mi'], pstr, ppar)
+        w = dict(wm=g[t + '_wm'], Wc=g[t + '_Wc'], Wcc=g[t + '_Wcc'], model_var=float(g[t + '_mv']))
+        tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
+        assert tf.kernel_name(model.dyn_eval) == 'k_apply_wide'
+        mf, cf, cfx = tf.apply_batch(model.dyn_eval, means, covs, 0.0)
+        for i in range(0, B, 9):
+            ref = orc.apply_bq(orc.F_SMOOTH10D_DYN, means[i], covs[i], 0.0, g[t + '_pts'], w)
+            assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=(tag, i))
+        host = tf.apply_batch(lambda x, par: model.dyn_fcn(x, np.zeros(10), 0), means, covs, 0.0)
+        for dev_arr, host_arr in zip((mf, cf, cfx), host):
+            assert np.allclose(dev_arr, host_arr, rtol=1e-11, atol=1e-11 * np.abs(host_arr).max()), tag
+        # a covariance that is not positive definite is flagged and poisoned, the others are untouched
+        bad = covs.copy()
+        bad[5] = -np.eye(10)
+        m2, c2, x2, st = tf.apply_batch(model.dyn_eval, means, bad, 0.0, return_status=True)
+        assert st[5] != 0 and not np.delete(st, 5).any() and np.all(np.isnan(c2[5])) and np.array_equal(c2[6], cf[6])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # edge cases of the batch interface
 # ---------------------------------------------------------------------------------------------------------------

@@ -11,5 +11,5 @@ print('UNGM fused: %.3e steps/s  %.1f us/pass  frac %.4f' % (d['value'], 1e3 * d
 m = d['roofline_mt6']
 print('mt6: %.2f us  %.1f GB/s  frac %.4f  err %.2e' % (1e3 * m['ms_per_launch'], m['achieved'], m['frac'], m['max_scaled_err_vs_oracle']))
 c = d['roofline_c5']
-print('c5 gemm: %.1f us  %.1f TFLOP/s  frac %.3f  err %.1e' % (1e3 * c['ms_per_launch'], c['achieved'], c['frac'], c['max_scaled_err_vs_numpy']))
+print('c5 gemm: %.1f us  %.1f TFLOP/s  frac %.3f  err %.1e  | whole D=10 N=201 transform B=1e4: %.2f ms' % (1e3 * c['ms_per_launch'], c['achieved'], c['frac'], c['max_scaled_err_vs_numpy'], c['full_transform_ms']))
 PY
