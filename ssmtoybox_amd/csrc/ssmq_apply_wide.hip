@@ -16,7 +16,34 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
+// E rows of N values each, row pitch fl in global memory (one contiguous E * fl block), to a dense [E][N] LDS image.
+// Eight independent loads are in flight per lane before the first LDS store: one load at a time costs a full memory
+// round trip per 64 values (the FX pass of the N = 201 case spent most of its time right here).
+template <int BLOCK>
+__device__ __forceinline__ void rows_to_lds(const double *__restrict__ src, int64_t fl, int E, int N, double *dst, int lane) {
+    const int64_t total = (int64_t)E * fl;
+    for (int64_t base = 0; base < total; base += 8 * BLOCK) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t i = base + q * BLOCK + lane;
+            v[q] = i < total ? src[i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t i = base + q * BLOCK + lane;
+            if (i < total) {
+                const int e = (int)(i / fl), n = (int)(i - (int64_t)e * fl);
+                if (n < N) dst[e * N + n] = v[q];
+            }
+        }
+    }
+}
+
+// BLOCK = 64 (one wave: small shapes, many trajectories per CU) or 256 (large point sets: the LDS footprint allows only
+// ~3 trajectories per CU, so each one must bring its own four waves or the CU idles behind LDS / memory latency)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_apply_wide(const WideArgs a) {
     extern __shared__ __align__(16) double lds[];
     const int D = a.D, E = a.E, N = a.N;
     const int lane = threadIdx.x;
@@ -37,34 +64,41 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
 
     // ---- 1. inputs -> LDS, Cholesky --------------------------------------------------------------------------
     if (a.mode != SSMQ_WIDE_FX) {
-        for (int d = lane; d < D; d += kWideBlock) sm[d] = a.mean[d * a.es_in + b * a.bs_mean];
-        for (int i = lane; i < D * D; i += kWideBlock) {
+        for (int d = lane; d < D; d += BLOCK) sm[d] = a.mean[d * a.es_in + b * a.bs_mean];
+        for (int i = lane; i < D * D; i += BLOCK) {
             const int r = i / D, cc = i % D;
             sL[i] = (cc <= r) ? a.cov[(int64_t)i * a.es_in + b * a.bs_cov] : 0.0;
         }
         __syncthreads();
-        if (lane == 0) {
+        // right-looking Cholesky across the wave: column j is scaled by all lanes, the trailing block updated by all
+        // lanes (the subtractions reach every element in the order k = 0, 1, ... of the left-looking dot products, so
+        // the factor is the same to the bit); a serial lane-0 loop costs ~D^3 / 3 dependent LDS round trips
+        {
             bool ok = true;
             for (int j = 0; j < D; ++j) {
-                double ajj = sL[j * D + j];
-                for (int k = 0; k < j; ++k) ajj -= sL[j * D + k] * sL[j * D + k];
+                const double ajj = sL[j * D + j];
                 ok = ok && (ajj > 0.0);
-                ajj = sqrt(ajj);
-                sL[j * D + j] = ajj;
-                const double r = 1.0 / ajj;
-                for (int i = j + 1; i < D; ++i) {
-                    double s = sL[i * D + j];
-                    for (int k = 0; k < j; ++k) s -= sL[i * D + k] * sL[j * D + k];
-                    sL[i * D + j] = s * r;
+                const double ljj = sqrt(ajj), r = 1.0 / ljj;
+                __syncthreads();
+                if (lane == 0) sL[j * D + j] = ljj;
+                for (int i = j + 1 + lane; i < D; i += BLOCK) sL[i * D + j] *= r;
+                __syncthreads();
+                const int m = D - j - 1;
+                for (int idx = lane; idx < m * m; idx += BLOCK) {
+                    const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+                    if (k <= i) sL[i * D + k] -= sL[i * D + j] * sL[k * D + j];
                 }
+                __syncthreads();
             }
-            s_ok = ok ? 1 : 0;
-            if (a.status) a.status[b] = ok ? 0 : 1;
+            if (lane == 0) {
+                s_ok = ok ? 1 : 0;
+                if (a.status) a.status[b] = ok ? 0 : 1;
+            }
         }
         __syncthreads();
         // ---- 2. sigma points and integrand -----------------------------------------------------------------------
         const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
-        for (int n = lane; n < N; n += kWideBlock) {
+        for (int n = lane; n < N; n += BLOCK) {
             for (int d = 0; d < D; ++d) {
                 double s = sm[d];
                 for (int k = 0; k <= d; ++k) s += sL[d * D + k] * c[cl.xiT + n * D + k];
@@ -90,27 +124,27 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             // integrand values as (b E + e)-th row of the batch matrix, zero-padded to the GEMM's column count
             const int64_t fl = a.fx_ld ? a.fx_ld : N;
             for (int e = 0; e < E; ++e)
-                for (int n = lane; n < fl; n += kWideBlock)
+                for (int n = lane; n < fl; n += BLOCK)
                     a.fx_out[((int64_t)b * E + e) * fl + n] = n < N ? (s_ok ? sfx[e * N + n] : nan) : 0.0;
-            for (int i = lane; i < D * D; i += kWideBlock) a.chol_out[b * D * D + i] = s_ok ? sL[i] : nan;
+            for (int i = lane; i < D * D; i += BLOCK) a.chol_out[b * D * D + i] = s_ok ? sL[i] : nan;
             return;
         }
         if (a.mode == SSMQ_WIDE_POINTS) {
             // outputs in the reference layout: x [b][D][N], chol [b][D][D]
-            for (int i = lane; i < D * N; i += kWideBlock) a.x_out[b * D * N + i] = s_ok ? sx[i] : nan;
-            for (int i = lane; i < D * D; i += kWideBlock) a.chol_out[b * D * D + i] = s_ok ? sL[i] : nan;
+            for (int i = lane; i < D * N; i += BLOCK) a.x_out[b * D * N + i] = s_ok ? sx[i] : nan;
+            for (int i = lane; i < D * D; i += BLOCK) a.chol_out[b * D * D + i] = s_ok ? sL[i] : nan;
             return;
         }
     } else {
         // reductions only: L, fx (and x, mean for the centred form) come from the caller, reference layout
-        for (int i = lane; i < D * D; i += kWideBlock) sL[i] = a.chol_in[b * D * D + i];
+        for (int i = lane; i < D * D; i += BLOCK) sL[i] = a.chol_in[b * D * D + i];
         {
             const int64_t fl = a.fx_ld ? a.fx_ld : N;
-            for (int i = lane; i < E * N; i += kWideBlock) sfx[i] = a.fx_in[((int64_t)b * E + i / N) * fl + i % N];
+            rows_to_lds<BLOCK>(a.fx_in + (int64_t)b * E * fl, fl, E, N, sfx, lane);
         }
         if (a.form == SSMQ_FORM_SIGMA) {
-            for (int i = lane; i < D * N; i += kWideBlock) sx[i] = a.x_in[b * D * N + i];
-            for (int d = lane; d < D; d += kWideBlock) sm[d] = a.mean[b * D + d];
+            for (int i = lane; i < D * N; i += BLOCK) sx[i] = a.x_in[b * D * N + i];
+            for (int d = lane; d < D; d += BLOCK) sm[d] = a.mean[b * D + d];
         }
         if (lane == 0) s_ok = 1;
         __syncthreads();
@@ -119,23 +153,22 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
 #define OUT_ADDR(ptr, e, bs) ptr[(int64_t)(e) * a.es_out + b * (bs)]
 
     // ---- 3. mean ---------------------------------------------------------------------------------------------
-    for (int e = 0; e < E; ++e) {
+    for (int e = lane >> 6; e < E; e += BLOCK / 64) {      // one wave per output row
         double s = 0.0;
-        for (int n = lane; n < N; n += kWideBlock) s += sfx[e * N + n] * c[cl.wm + n];
+        for (int n = lane & 63; n < N; n += 64) s += sfx[e * N + n] * c[cl.wm + n];
         s = wave_sum(s);
-        if (lane == 0) smf[e] = s;
+        if ((lane & 63) == 0) smf[e] = s;
     }
     __syncthreads();
-    for (int e = lane; e < E; e += kWideBlock) OUT_ADDR(a.mean_f, e, a.bs_mf) = ok ? smf[e] : nan;
+    for (int e = lane; e < E; e += BLOCK) OUT_ADDR(a.mean_f, e, a.bs_mf) = ok ? smf[e] : nan;
 
     if (a.form == SSMQ_FORM_BQ) {
         // ---- 4. T = fx Wc; cov = T fx' - mean mean' + emv -------------------------------------------------------
         if (a.t_in) {      // fx Wc came from the matrix-core GEMM over the whole batch
             const int64_t fl = a.fx_ld ? a.fx_ld : N;
-            for (int idx = lane; idx < E * N; idx += kWideBlock)
-                sT[idx] = a.t_in[((int64_t)b * E + idx / N) * fl + idx % N];
+            rows_to_lds<BLOCK>(a.t_in + (int64_t)b * E * fl, fl, E, N, sT, lane);
         } else {
-            for (int idx = lane; idx < E * N; idx += kWideBlock) {
+            for (int idx = lane; idx < E * N; idx += BLOCK) {
                 const int e = idx / N, j = idx % N;
                 double s = 0.0;
                 for (int i = 0; i < N; ++i) s += sfx[e * N + i] * c[cl.Wc + (int64_t)i * N + j];
@@ -143,22 +176,26 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             }
         }
         __syncthreads();
-        for (int idx = lane; idx < E * E; idx += kWideBlock) {
-            const int e = idx / E, e2 = idx % E;
+        // (fx Wc) fx' is symmetric (Wc is): lower triangle only, mirrored - as the register kernels do
+        for (int idx = lane; idx < E * (E + 1) / 2; idx += BLOCK) {
+            int e = 0;
+            while ((e + 1) * (e + 2) / 2 <= idx) ++e;
+            const int e2 = idx - e * (e + 1) / 2;
             double s = 0.0;
             for (int j = 0; j < N; ++j) s += sT[e * N + j] * sfx[e2 * N + j];
-            sC[idx] = s;
+            sC[e * E + e2] = s;
+            sC[e2 * E + e] = s;
         }
         __syncthreads();
         if (a.tp_nu > 0.0) {
-            for (int idx = lane; idx < E * N; idx += kWideBlock) {
+            for (int idx = lane; idx < E * N; idx += BLOCK) {
                 const int e = idx / N, j = idx % N;
                 double s = 0.0;
                 for (int i = 0; i < N; ++i) s += sfx[e * N + i] * c[cl.iK + (int64_t)i * N + j];
                 sT[idx] = s;
             }
             __syncthreads();
-            for (int idx = lane; idx < E * E; idx += kWideBlock) {
+            for (int idx = lane; idx < E * E; idx += BLOCK) {
                 const int e = idx / E, e2 = idx % E;
                 double s = 0.0;
                 for (int j = 0; j < N; ++j) s += sT[e * N + j] * sfx[e2 * N + j];
@@ -166,7 +203,7 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             }
             __syncthreads();
         }
-        for (int idx = lane; idx < E * E; idx += kWideBlock) {
+        for (int idx = lane; idx < E * E; idx += BLOCK) {
             const int e = idx / E, e2 = idx % E;
             const bool use = (e == e2) || (a.emv_mode == SSMQ_EMV_BROADCAST);
             double em = use ? c[cl.emv + idx] : 0.0;
@@ -176,14 +213,14 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? v : nan;
         }
         // ---- 5. cross-covariance (fx Wcc') L' ------------------------------------------------------------------
-        for (int idx = lane; idx < E * D; idx += kWideBlock) {
+        for (int idx = lane; idx < E * D; idx += BLOCK) {
             const int e = idx / D, d = idx % D;
             double s = 0.0;
             for (int n = 0; n < N; ++n) s += sfx[e * N + n] * c[cl.Wcc + d * N + n];
             sg[idx] = s;
         }
         __syncthreads();
-        for (int idx = lane; idx < E * D; idx += kWideBlock) {
+        for (int idx = lane; idx < E * D; idx += BLOCK) {
             const int e = idx / D, j = idx % D;
             double s = 0.0;
             for (int d = 0; d <= j; ++d) s += sg[e * D + d] * sL[j * D + d];
@@ -191,9 +228,9 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
         }
     } else {
         // ---- classical centred form (mtran.py:141-149), Wc = diag(wc) -------------------------------------------
-        for (int idx = lane; idx < E * N; idx += kWideBlock) sfx[idx] -= smf[idx / N];
+        for (int idx = lane; idx < E * N; idx += BLOCK) sfx[idx] -= smf[idx / N];
         __syncthreads();
-        for (int idx = lane; idx < E * E; idx += kWideBlock) {
+        for (int idx = lane; idx < E * E; idx += BLOCK) {
             const int e = idx / E, e2 = idx % E;
             double s = 0.0;
             for (int n = 0; n < N; ++n) s += (sfx[e * N + n] * c[cl.Wc + n]) * sfx[e2 * N + n];
@@ -201,7 +238,7 @@ __global__ __launch_bounds__(kWideBlock) void k_apply_wide(const WideArgs a) {
             if (a.cov_add) s += a.cov_add[idx];
             OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? s : nan;
         }
-        for (int idx = lane; idx < E * D; idx += kWideBlock) {
+        for (int idx = lane; idx < E * D; idx += BLOCK) {
             const int e = idx / D, d = idx % D;
             double s = 0.0;
             for (int n = 0; n < N; ++n) s += (sfx[e * N + n] * c[cl.Wc + n]) * (sx[d * N + n] - sm[d]);
@@ -219,12 +256,18 @@ hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s) {
     const size_t lds = wide_lds_bytes(a.D, a.E, a.N);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_apply_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)k_apply_wide<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 64);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_apply_wide<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 64);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_apply_wide, dim3((unsigned)B), dim3(kWideBlock), lds, s, a);
+    if ((int64_t)a.E * a.N >= 1024 && !getenv("SSMQ_WIDE_ONE_WAVE"))
+        hipLaunchKernelGGL(k_apply_wide<256>, dim3((unsigned)B), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(k_apply_wide<64>, dim3((unsigned)B), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
