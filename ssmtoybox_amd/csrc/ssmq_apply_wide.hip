@@ -48,11 +48,14 @@ __global__ __launch_bounds__(BLOCK) void k_apply_wide(const WideArgs a) {
     const int D = a.D, E = a.E, N = a.N;
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
+    // LDS image; the pass-specific parts are left out where a pass does not touch them (wide_lds_bytes_for): fewer
+    // bytes = more trajectories resident per CU
+    const bool need_x = a.mode != SSMQ_WIDE_FX || a.form == SSMQ_FORM_SIGMA;
     double *sL = lds;               // D*D   lower factor, row-major, zeros above the diagonal
     double *sm = sL + D * D;        // D
-    double *sx = sm + D;            // D*N   sigma points
-    double *sfx = sx + D * N;       // E*N   integrand values (centred in place for the SIGMA form)
-    double *sT = sfx + E * N;       // E*N   fx Wc  (then fx iK for the TP model variance)
+    double *sx = sm + D;            // D*N   sigma points (not in the FX pass of the BQ form)
+    double *sfx = sx + (need_x ? D * N : 0);   // E*N   integrand values (centred in place for the SIGMA form)
+    double *sT = sfx + E * N;       // E*N   fx Wc  (then fx iK for the TP model variance); from here on: not in EVAL / POINTS
     double *smf = sT + E * N;       // E
     double *sS = smf + E;           // E*E   TP quadratic form
     double *sC = sS + E * E;        // E*E   fx Wc fx'
@@ -252,8 +255,17 @@ size_t wide_lds_bytes(int D, int E, int N) {
     return sizeof(double) * (size_t)(D * D + D + D * N + 2 * E * N + E + 2 * E * E + E * D);
 }
 
+// what one pass really needs (same carve-up as the kernel)
+static size_t wide_lds_bytes_for(const WideArgs &a) {
+    const size_t D = a.D, E = a.E, N = a.N;
+    const bool need_x = a.mode != SSMQ_WIDE_FX || a.form == SSMQ_FORM_SIGMA;
+    size_t n = D * D + D + (need_x ? D * N : 0) + E * N;
+    if (a.mode != SSMQ_WIDE_EVAL && a.mode != SSMQ_WIDE_POINTS) n += E * N + E + 2 * E * E + E * D;
+    return sizeof(double) * n;
+}
+
 hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s) {
-    const size_t lds = wide_lds_bytes(a.D, a.E, a.N);
+    const size_t lds = wide_lds_bytes_for(a);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_apply_wide<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
