@@ -22,6 +22,28 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <int BLOCK>
 __device__ __forceinline__ void rows_to_lds(const double *__restrict__ src, int64_t fl, int E, int N, double *dst, int lane) {
     const int64_t total = (int64_t)E * fl;
+    if ((fl & 1) == 0 && (((uintptr_t)src) & 15) == 0 && total <= 16 * 2 * BLOCK) {
+        // the whole block as 16-byte loads, ALL of them in flight before the first LDS store: one memory round trip
+        // for up to 32 * BLOCK doubles (the GEMM route's 10 x 208 rows: 9 loads per lane)
+        const double2 *s2 = (const double2 *)src;
+        const int64_t pairs = total / 2;
+        double2 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t i = (int64_t)q * BLOCK + lane;
+            v[q] = i < pairs ? s2[i] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t i = (int64_t)q * BLOCK + lane;
+            if (i < pairs) {
+                const int e = (int)((2 * i) / fl), n = (int)(2 * i - (int64_t)e * fl);     // fl even: a pair never straddles rows
+                if (n < N) dst[e * N + n] = v[q].x;
+                if (n + 1 < N) dst[e * N + n + 1] = v[q].y;
+            }
+        }
+        return;
+    }
     for (int64_t base = 0; base < total; base += 8 * BLOCK) {
         double v[8];
 #pragma unroll
@@ -102,9 +124,15 @@ __global__ __launch_bounds__(BLOCK) void k_apply_wide(const WideArgs a) {
         // ---- 2. sigma points and integrand -----------------------------------------------------------------------
         const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
         for (int n = lane; n < N; n += BLOCK) {
+            double xin[SSMQ_MAX_DIM];              // point n's coordinates: D independent loads, one round trip (PMC,
+                                                   // tools/pmc_wide.sh: the pass waited on 55 dependent loads per point)
+#pragma unroll
+            for (int k = 0; k < SSMQ_MAX_DIM; ++k) xin[k] = k < D ? c[cl.xiT + n * D + k] : 0.0;
             for (int d = 0; d < D; ++d) {
                 double s = sm[d];
-                for (int k = 0; k <= d; ++k) s += sL[d * D + k] * c[cl.xiT + n * D + k];
+#pragma unroll
+                for (int k = 0; k < SSMQ_MAX_DIM; ++k)
+                    if (k <= d) s += sL[d * D + k] * xin[k];
                 sx[d * N + n] = s;
             }
             if (a.mode == SSMQ_WIDE_FULL || a.mode == SSMQ_WIDE_EVAL) {
