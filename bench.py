@@ -493,7 +493,8 @@ def main():
             'trajectories_aggregated': int(agg['count']),
             'failed_trajectories_rank0': int((~ok).sum()),
         }
-    if rank == 0 and not args.no_mt6:
+    single = world == 1      # the single-kernel legs and the CPU baseline belong to the N = 1 run only
+    if rank == 0 and single and not args.no_mt6:
         mt = Mt6Bench(amd, 100000, seed=2)
         err = mt.check()
         ms, b_alg, b_mov = mt.measure()
@@ -503,7 +504,7 @@ def main():
                                'bytes_per_launch': b_alg, 'bytes_moved_per_launch': b_mov, 'ms_per_launch': ms,
                                'transforms_per_s': mt.B / (ms * 1e-3), 'max_scaled_err_vs_oracle': err,
                                'workload': 'batched GPQ moment transform, D=E=6, N=13, B=1e5, 4 rotating buffer sets'}
-    if rank == 0 and not args.no_mt6:
+    if rank == 0 and single and not args.no_mt6:
         c5 = C5GemmBench(amd, 10000, seed=5)
         err = c5.check()
         ms, flop = c5.measure()
@@ -515,7 +516,7 @@ def main():
                               'full_transform_ms': ms_full, 'full_transforms_per_s': 10000 / (ms_full * 1e-3),
                               'workload': 'T = FX Wc of the Bayes-Sard transform, D=E=10, N=201 (padded 208), B=1e4: '
                                           '(1e5 x 208) x (208 x 208), v_mfma_f64_16x16x4_f64'}
-    if rank == 0 and not args.no_cpu_baseline and args.workload == 'ungm' and args.filter == 'gpqkf':
+    if rank == 0 and single and not args.no_cpu_baseline and args.workload == 'ungm' and args.filter == 'gpqkf':
         cb, (cpu_fm, cpu_st) = cpu_baseline_ungm(B, T, seed=1 + rank, tf=wl.alg.tf_dyn)
         out['cpu_baseline'] = cb
         # the GPU pass and the CPU port ran the same trajectories: cross-check them
