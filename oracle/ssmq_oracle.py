@@ -14,7 +14,12 @@ It is a plain restatement, written from the reference's published algorithm, of 
     GP / TP / BS weights  bq/bqmod.py:495-523, 893-992, 1132-1160
     moment transforms     bq/bqmtran.py:60-109, 158-223, 394-415 ; mtran.py:105-149
     integrands            ssmod.py (closed-form dynamics / measurement functions)
-    Gaussian / Student filter recursions   ssinf.py:66-118, 254-323, 634-736
+    Gaussian / Student filter recursions   ssinf.py:66-118, 254-323, 634-736 (non-additive noise :271-295, RTS :120-147)
+    marginalised-filter theta step         ssinf.py:1117-1198
+    performance metrics                    utils.py:18-148 (aggregation research/tpq/tpq_base.py:154-172)
+    BS model / integral variance           bq/bqmod.py:995-1050
+    simulators                             ssmod.py:168-199, 1011-1039, with THIS BUILD's counter-based generator
+                                           (Philox4x32-10, pinned by the Random123 known-answer vectors)
 
 Parity pinning: every function here is checked in tests/test_oracle_golden.py against golden vectors that were
 produced by importing the reference itself in the build container (tests/golden/make_golden.py; fixtures
