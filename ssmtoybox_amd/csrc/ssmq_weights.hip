@@ -18,7 +18,9 @@
 
 namespace ssmq {
 
-constexpr int kWgtBlock = 256;
+// workgroup size: 256 threads per parameter row, 1024 for large point sets (N > 64: one row keeps a whole CU busy with
+// L2-latency-bound loops, so it takes all the waves the CU can give); device code strides by the actual block size
+#define kWgtBlock ((int)blockDim.x)
 
 struct WgtArgs {
     int32_t D, N, P, NB, bs, use_lds;
@@ -146,13 +148,14 @@ __device__ bool lu_inverse(double *A, double *X, int n, int *piv, int *flag) {
 }
 
 __device__ double block_sum(double v, double *red) {
-    // 256 threads -> one value (to every thread)
+    // all threads of the block -> one value (to every thread); waves added in index order
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     bsync();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     bsync();
-    const double s = red[0] + red[1] + red[2] + red[3];
+    double s = 0.0;
+    for (int w = 0; w < kWgtBlock / 64; ++w) s += red[w];
     bsync();
     return s;
 }
@@ -163,9 +166,10 @@ __device__ double ipow(double x, int k) {
     return r;
 }
 
-__global__ __launch_bounds__(kWgtBlock) void k_weights(const WgtArgs a) {
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     extern __shared__ __align__(16) double lds[];
-    __shared__ double s_sil[SSMQ_MAX_DIM], s_red[4];
+    __shared__ double s_sil[SSMQ_MAX_DIM], s_red[16];
     __shared__ int s_flag, s_piv;
     const int D = a.D, N = a.N, NB = a.NB, p = blockIdx.x, tid = threadIdx.x;
     const double *par = a.par + (int64_t)p * (1 + D);
@@ -560,7 +564,10 @@ static int weights_impl(int var_mode, int D, int N, const double *xi, const doub
     a.R = dR.d(); a.mv = dmv.d(); a.iv = div.d(); a.status = (int32_t *)dst.p; a.work = dwork.d();
     a.work_stride = work_stride;
     const size_t lds = a.use_lds ? sizeof(double) * 2 * nn : 0;
-    hipLaunchKernelGGL(k_weights, dim3(P), dim3(kWgtBlock), lds, s, a);
+    if (N > 64)
+        hipLaunchKernelGGL(k_weights<1024>, dim3(P), dim3(1024), lds, s, a);
+    else
+        hipLaunchKernelGGL(k_weights<256>, dim3(P), dim3(256), lds, s, a);
     if ((rc = hip_fail(hipGetLastError(), "k_weights"))) return rc;
 #define SSMQ_D2H(host, dev, count) \
     if (host) SSMQ_HIP(hipMemcpyAsync(host, dev.p, sizeof(*host) * (count), hipMemcpyDeviceToHost, s));
@@ -626,7 +633,10 @@ int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double
     a.wm = dwm.d(); a.Wc = dWc.d(); a.Wcc = dWcc.d(); a.iK = diK.d(); a.q = dq.d(); a.Q = dQ.d(); a.R = dR.d();
     a.mv = dmv.d(); a.iv = div.d(); a.status = d_status; a.work = dwork.d(); a.work_stride = work_stride;
     const size_t lds = a.use_lds ? sizeof(double) * 2 * nn : 0;
-    hipLaunchKernelGGL(k_weights, dim3(P), dim3(kWgtBlock), lds, s, a);
+    if (N > 64)
+        hipLaunchKernelGGL(k_weights<1024>, dim3(P), dim3(1024), lds, s, a);
+    else
+        hipLaunchKernelGGL(k_weights<256>, dim3(P), dim3(256), lds, s, a);
     if ((rc = hip_fail(hipGetLastError(), "k_weights"))) return rc;
     hipLaunchKernelGGL(k_pack_wide_consts, dim3(P), dim3(64), 0, s, D, E, N, d_xi, dwm.d(), dWc.d(), dWcc.d(), diK.d(),
                        dmv.d(), d_consts);
