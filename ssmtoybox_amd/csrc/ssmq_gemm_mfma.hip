@@ -42,21 +42,20 @@ __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const
 
     // software pipeline: the next block's slab of Wc and A fragments are loaded into registers BEFORE the MFMA loop of
     // the current block and parked in LDS / renamed after it, so the L2 latency hides behind the matrix instructions
-    constexpr int PER = (16 * NP + kGemmBlock - 1) / kGemmBlock;     // slab elements per thread
+    constexpr int PER = 16 * NP / kGemmBlock;     // slab elements per thread: 16 * 16 NT / 256 = NT exactly, no tail
+    static_assert(PER * kGemmBlock == 16 * NP, "slab size must be a multiple of the block size");
     double breg[PER], a[RT][4], an[RT][4];
     auto load_b = [&](int kb) {
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int i = threadIdx.x + q * kGemmBlock;
-            breg[q] = i < 16 * NP ? Bm[(int64_t)kb * 16 * NP + i] : 0.0;     // rows 16 kb .. 16 kb + 15 are contiguous
-        }
+        for (int q = 0; q < PER; ++q)     // rows 16 kb .. 16 kb + 15 are contiguous
+            breg[q] = Bm[(int64_t)kb * 16 * NP + threadIdx.x + q * kGemmBlock];
     };
     auto park_b = [&](int buf) {
         double *dst = lds + buf * 16 * LB;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int i = threadIdx.x + q * kGemmBlock;
-            if (i < 16 * NP) dst[(i / NP) * LB + i % NP] = breg[q];
+            dst[(i / NP) * LB + i % NP] = breg[q];
         }
     };
     auto load_a = [&](int kb, double (&dst)[RT][4]) {
