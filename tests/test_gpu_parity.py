@@ -156,6 +156,34 @@ def test_apply_python_callable(amd, golden):
             assert_moments_close(got, ref, covs[i], what=(key, i))
 
 
+def test_reference_property_tests(amd):
+    """The reference's own assertions on apply() (tests/test_bqmtran.py:66-104): GPQ on UNGM and pendulum at the
+    standard normal with time 1.0 gives a symmetric positive-definite covariance and I_out of shape (dim, dim); the
+    Bayes-Sard transform of polar -> cartesian (a Python callable) gives a positive-definite covariance."""
+    from ssmtoybox_amd import ssmod as sm
+    models = [sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]]))),
+              sm.Pendulum2DTransition(sm.GaussRV(2), sm.GaussRV(2), 0.01)]
+    for mod in models:
+        dim = mod.dim_in
+        ker_par = np.hstack((np.ones((1, 1)), 3 * np.ones((1, dim))))
+        tf = amd.GaussianProcessTransform(dim, dim, ker_par)
+        tmean, tcov, tccov = tf.apply(mod.dyn_eval, np.zeros(dim), np.eye(dim), np.atleast_1d(1.0))
+        assert tf.I_out.shape == (dim, dim) and tmean.shape == (dim,) and tccov.shape == (dim, dim)
+        np.linalg.cholesky(tcov)
+        assert np.allclose(tcov, tcov.T)
+        tcov += 1.0                                        # outputs are fresh, writable arrays (ssinf.py:279 does +=)
+
+    def polar2cartesian(x, pars):
+        return x[0] * np.array([np.cos(x[1]), np.sin(x[1])])
+    alpha_ut = np.array([[0, 1, 0, 2, 0], [0, 0, 1, 0, 2]])
+    mt = amd.BayesSardTransform(2, 2, np.array([[1.0, 1, 1]]), multi_ind=alpha_ut, point_str='ut')
+    mean_out, cov_out, cc = mt.apply(polar2cartesian, np.array([1, np.pi / 2]), np.diag([0.05 ** 2, (np.pi / 10) ** 2]),
+                                     np.atleast_1d(0))
+    assert mt.I_out.shape == (2, 2)
+    np.linalg.cholesky(cov_out)
+    assert abs(mean_out[0]) < 1e-12 and 0.9 < mean_out[1] < 1.0      # E[r sin(th)] a little below 1
+
+
 def test_not_positive_definite(amd):
     from ssmtoybox_amd import ssmod as sm
     tf = amd.UnscentedTransform(2)
