@@ -156,6 +156,20 @@ def test_apply_python_callable(amd, golden):
             assert_moments_close(got, ref, covs[i], what=(key, i))
 
 
+def test_reference_variance_sign_tests(amd):
+    """tests/test_bqmtran.py:48-64 of the reference: model and integral variance stay non-negative for "numerically
+    unpleasant settings" - and equal the oracle's values there."""
+    ker_par = np.array([[1.0, 3.0, 3.0]])
+    tf = amd.GaussianProcessTransform(2, 1, ker_par, point_str='sr')
+    pts = orc.points_sr(2)
+    emv = tf.model.exp_model_variance(ker_par)
+    assert emv >= 0 and abs(emv - orc.gp_weights(ker_par, pts)['model_var']) < 1e-12
+    for par in ([1, 600, 6], [1.1, 600, 6]):
+        ivar = tf.model.integral_variance(par)
+        ref = orc.gp_weights(np.array([par], dtype=float), pts)['integral_var']
+        assert ivar >= 0 and abs(ivar - ref) < 1e-9 * max(1.0, abs(ref)), par
+
+
 def test_reference_property_tests(amd):
     """The reference's own assertions on apply() (tests/test_bqmtran.py:66-104): GPQ on UNGM and pendulum at the
     standard normal with time 1.0 gives a symmetric positive-definite covariance and I_out of shape (dim, dim); the
