@@ -170,6 +170,30 @@ def test_reference_variance_sign_tests(amd):
         assert ivar >= 0 and abs(ivar - ref) < 1e-9 * max(1.0, abs(ref)), par
 
 
+def test_reference_quadratic_form_routes(amd):
+    """tests/test_mult_dot_einsum.py:56-105 of the reference: Y iK Q iK Y' of the 5-D reentry integrand by plain products
+    and by the Cholesky-whitened route agree; here additionally with what the device kernel forms (cov + m m' - emv I)."""
+    from ssmtoybox_amd import ssmod as sm
+    mean_in = np.array([6500.4, 349.14, 1.8093, 6.7967, 0.6932])
+    cov_in = np.diag([1e-6, 1e-6, 1e-6, 1e-6, 1])
+    model = sm.ReentryVehicle2DTransition(sm.GaussRV(5, mean_in, cov_in), sm.GaussRV(3))
+    ker_par = np.hstack((np.ones((1, 1)), 25 * np.ones((1, 5))))
+    tf = amd.GaussianProcessTransform(5, 5, ker_par, point_str='sr')
+    x = mean_in[:, None] + np.linalg.cholesky(cov_in).dot(tf.model.points)
+    Y = np.stack([orc.integrand(orc.F_REENTRY2D_DYN, x[:, n], 1.0, (0.1,)) for n in range(x.shape[1])], axis=1)
+    iK, Q = tf.model.iK, tf.model.Q
+    C1 = Y.dot(iK.dot(Q).dot(iK)).dot(Y.T)
+    C2 = np.einsum('ab,bc,cd', Y, np.einsum('ab,bc,cd', iK, Q, iK), Y.T)
+    assert np.allclose(C1, C2)
+    K = orc.rbf_eval(ker_par, tf.model.points) + 1e-8 * np.eye(Q.shape[0])
+    bet = np.linalg.solve(np.linalg.cholesky(K), Y.T).T.dot(np.linalg.solve(np.linalg.cholesky(K), np.linalg.cholesky(Q)))
+    C3 = bet.dot(bet.T)
+    assert np.allclose(C1, C3, rtol=1e-5)
+    mf, cf, _ = tf.apply(model.dyn_eval, mean_in, cov_in, np.atleast_1d(1.0))
+    C_dev = cf + np.outer(mf, mf) - tf.model.model_var * np.eye(5)
+    assert np.abs(C_dev - C1).max() < 1e-9 * np.abs(C1).max()
+
+
 def test_reference_property_tests(amd):
     """The reference's own assertions on apply() (tests/test_bqmtran.py:66-104): GPQ on UNGM and pendulum at the
     standard normal with time 1.0 gives a symmetric positive-definite covariance and I_out of shape (dim, dim); the
