@@ -794,7 +794,7 @@ int try_launch_fused_aug(const ssmq_transform *hd, const ssmq_integrand *fd, con
                          const double *d_y, const double *d_m0, const double *d_P0, const double *d_add_dyn,
                          const double *d_add_obs, const double *d_noise, double *d_fm, double *d_fP, int32_t *d_status,
                          hipStream_t s, const char **name, bool dry_run, const double *d_ttab_dyn,
-                         const double *d_ttab_obs);
+                         const double *d_ttab_obs, double *d_pm, double *d_pP, double *d_pC);
 }
 
 namespace {
@@ -937,6 +937,19 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
         if (rc < 0) return rc;
         if (rc == 1) return SSMQ_OK;
     }
+    if (!getenv("SSMQ_NO_FUSED") && keep_pred && !sscale && student_dof == 0.0) {
+        // smoother: the time loop in one kernel that also leaves the predictive moments of every step in HBM
+        FInfo fio;
+        if (!integrand_info(f_obs->id, &fio)) {
+            set_error("unknown integrand id");
+            return SSMQ_E_ARG;
+        }
+        rc = try_launch_fused_aug(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), D, 0, 0, B, ld, T, d_y, d_m0, d_P0,
+                                  gqg, rr, gqg, d_fm, d_fP, d_status, s, nullptr, false, has_td ? ttab_d : nullptr,
+                                  has_to ? ttab_o : nullptr, d_pm, d_pP, d_pC);
+        if (rc < 0) return rc;
+        if (rc == 1) return SSMQ_OK;
+    }
     if (!(g_fc.exec && g_fc.key == key)) {
         g_fc.drop_graph();
         SSMQ_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1062,7 +1075,7 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
         SSMQ_HIP(hipMemcpyAsync(da.p, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice, s));
         rc = try_launch_fused_aug(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), D, dq, dr, B, ld, T, d_y, d_m0,
                                   d_P0, da.d(), da.d() + (size_t)D * D, dn.d(), d_fm, d_fP, d_status, s, nullptr, false,
-                                  has_td ? ttab_d : nullptr, has_to ? ttab_o : nullptr);
+                                  has_td ? ttab_d : nullptr, has_to ? ttab_o : nullptr, nullptr, nullptr, nullptr);
         hipError_t e = hipStreamSynchronize(s);
         if (rc < 0) return rc;
         SSMQ_HIP(e);

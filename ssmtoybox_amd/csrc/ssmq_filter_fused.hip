@@ -9,6 +9,7 @@
 // 325-344) and is not formed in the forward pass.
 #include <cstdlib>
 #include "ssmq_apply_small.h"
+#include <type_traits>
 #include "ssmq_host.h"
 
 namespace ssmq {
@@ -231,6 +232,8 @@ struct AugArgs {
     const double *c_dyn, *c_obs;
     const double *add_dyn, *add_obs;   // [D*D] / [Y*Y]: G Q G' / R for an additive model, zeros otherwise
     const double *noise;               // q_mean[DQ] | q_cov[DQ*DQ] | r_mean[DR] | r_cov[DR*DR]
+    double *pm, *pP, *pC;              // KEEP: predictive mean / covariance / dynamics cross-covariance of every step
+                                       // ([T][D][ld], [T][D*D][ld] x 2) for the RTS pass (ssinf.py:105-107)
     int64_t B, ld;
     int32_t T, emv_dyn, emv_obs;
     double nu_dyn, nu_obs;
@@ -253,9 +256,10 @@ __device__ __forceinline__ void augment(const double (&m)[D], const double *Pl, 
     }
 }
 
-template <int D, int Y, int DQ, int DR, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
+template <int D, int Y, int DQ, int DR, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, bool KEEP = false>
 __global__ __launch_bounds__(kSmallBlock, (D + DQ >= 5 ? 1 : 2)) void k_filter_fused_aug(const AugArgs a) {
     constexpr int DA = D + DQ, DO = D + DR;
+    static_assert(!KEEP || (DQ == 0 && DR == 0), "the smoother covers additive-noise models");
     const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;
     if ((int64_t)b >= a.B) return;
     const int64_t ld = a.ld;
@@ -279,8 +283,19 @@ __global__ __launch_bounds__(kSmallBlock, (D + DQ >= 5 ? 1 : 2)) void k_filter_f
         for (int i = 0; i < Y; ++i) yk[i] = a.y[((int64_t)k * Y + i) * ld + b];
         double ma[DA], Pa[DA * (DA + 1) / 2];
         augment<D, DQ>(m, Pl, qm, qc, ma, Pa);
-        RegSinkNoCross<DA, D> pr;
-        bool ok = moment_transform_core<DA, D, ND, FD, FORM, TP, 0, false, 0>(ma, Pa, t, a.fd, cpd, pr);
+        typename std::conditional<KEEP, RegSink<DA, D>, RegSinkNoCross<DA, D>>::type pr;
+        bool ok = moment_transform_core<DA, D, ND, FD, FORM, TP, 0, KEEP, 0>(ma, Pa, t, a.fd, cpd, pr);
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                a.pm[((int64_t)k * D + d) * ld + b] = pr.mf[d];
+#pragma unroll
+                for (int d2 = 0; d2 < D; ++d2) {
+                    a.pP[((int64_t)k * D * D + d * D + d2) * ld + b] = pr.cv[d >= d2 ? SSMQ_PK(d, d2) : SSMQ_PK(d2, d)];
+                    a.pC[((int64_t)k * D * D + d * D + d2) * ld + b] = pr.cx[d][d2];
+                }
+            }
+        }
         double mo[DO], Po[DO * (DO + 1) / 2];
         augment<D, DR>(pr.mf, pr.cv, rm, rc, mo, Po);
         RegSink<DO, Y> ob;
@@ -351,23 +366,31 @@ __global__ __launch_bounds__(kSmallBlock, (D + DQ >= 5 ? 1 : 2)) void k_filter_f
     a.status[b] = agg;
 }
 
-template <int D, int Y, int DQ, int DR, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO>
+template <int D, int Y, int DQ, int DR, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, bool KEEP>
 static hipError_t launch_fused_aug(const AugArgs &a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + kSmallBlock - 1) / kSmallBlock);
-    hipLaunchKernelGGL((k_filter_fused_aug<D, Y, DQ, DR, ND, NO, FD, FO, FORM, TP, SELO>), dim3(grid), dim3(kSmallBlock), 0, s,
-                       a);
+    hipLaunchKernelGGL((k_filter_fused_aug<D, Y, DQ, DR, ND, NO, FD, FO, FORM, TP, SELO, KEEP>), dim3(grid), dim3(kSmallBlock), 0,
+                       s, a);
     return hipGetLastError();
 }
 
 typedef hipError_t (*aug_fn)(const AugArgs &, hipStream_t);
 struct AugEntry {
-    int fd, fo, D, Y, DQ, DR, ND, NO, form, tp, selo;
+    int fd, fo, D, Y, DQ, DR, ND, NO, form, tp, selo, keep;
     aug_fn fn;
     const char *name;
 };
-#define SSMQ_AUG_ONE(FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO)                                               \
-    {FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO, &launch_fused_aug<D, Y, DQ, DR, ND, NO, FD, FO, FORM, TP, SELO>, \
+#define SSMQ_AUG_ONE(FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO)                                                        \
+    {FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO, 0, &launch_fused_aug<D, Y, DQ, DR, ND, NO, FD, FO, FORM, TP, SELO, false>, \
      "k_filter_fused_aug<D=" #D ",Y=" #Y ",DQ=" #DQ ",DR=" #DR ",ND=" #ND ",NO=" #NO "," #FD "," #FO "," #FORM ",TP=" #TP ">"}
+// additive models, predictive moments kept for the smoother
+#define SSMQ_KEEP_ONE(FD, FO, D, Y, N, FORM, TP, SELO)                                                            \
+    {FD, FO, D, Y, 0, 0, N, N, FORM, TP, SELO, 1, &launch_fused_aug<D, Y, 0, 0, N, N, FD, FO, FORM, TP, SELO, true>, \
+     "k_filter_fused_keep<D=" #D ",Y=" #Y ",N=" #N "," #FD "," #FO "," #FORM ",TP=" #TP ">"}
+#define SSMQ_KEEP(FD, FO, D, Y, N, SELO)                     \
+    SSMQ_KEEP_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO),   \
+    SSMQ_KEEP_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 1, SELO),   \
+    SSMQ_KEEP_ONE(FD, FO, D, Y, N, SSMQ_FORM_SIGMA, 0, SELO)
 #define SSMQ_AUG(FD, FO, D, Y, DQ, DR, ND, NO, SELO)                          \
     SSMQ_AUG_ONE(FD, FO, D, Y, DQ, DR, ND, NO, SSMQ_FORM_BQ, 0, SELO),        \
     SSMQ_AUG_ONE(FD, FO, D, Y, DQ, DR, ND, NO, SSMQ_FORM_BQ, 1, SELO),        \
@@ -377,6 +400,10 @@ static const AugEntry kAug[] = {
     SSMQ_AUG(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 4, 4, 0),      // spherical-radial points in 2-D
     SSMQ_AUG(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 5, 5, 0),      // unscented points in 2-D
     SSMQ_AUG_ONE(SSMQ_F_CTRS_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 2, 0, 15, 11, SSMQ_FORM_SIGMA, 0, 0),
+    SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 2, 0),
+    SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 0),
+    SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 5, 0),
+    SSMQ_KEEP(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 5, 0),
 };
 
 // as try_launch_fused, for filters whose models take the noise as an argument; d_noise: q_mean | q_cov | r_mean | r_cov
@@ -385,15 +412,17 @@ int try_launch_fused_aug(const ssmq_transform *hd, const ssmq_integrand *fd, con
                          const double *d_y, const double *d_m0, const double *d_P0, const double *d_add_dyn,
                          const double *d_add_obs, const double *d_noise, double *d_fm, double *d_fP, int32_t *d_status,
                          hipStream_t s, const char **name, bool dry_run, const double *d_ttab_dyn,
-                         const double *d_ttab_obs) {
+                         const double *d_ttab_obs, double *d_pm, double *d_pP, double *d_pC) {
+    const int keep = (d_pm && d_pP && d_pC) ? 1 : 0;
     if (hd->form != ho->form || (hd->tp_nu > 0.0) != (ho->tp_nu > 0.0) || sel_obs < 0 || fd->n_idx > 0) return 0;
     const int tp = hd->tp_nu > 0.0 ? 1 : 0;
     for (const AugEntry &e : kAug) {
         if (e.fd == fd->id && e.fo == fo->id && e.D == D && e.Y == ho->E && e.DQ == dq && e.DR == dr && e.ND == hd->N &&
-            e.NO == ho->N && e.form == hd->form && e.tp == tp && e.selo == sel_obs) {
+            e.NO == ho->N && e.form == hd->form && e.tp == tp && e.selo == sel_obs && e.keep == keep) {
             if (name) *name = e.name;
             if (dry_run) return 1;
             AugArgs a;
+            a.pm = d_pm; a.pP = d_pP; a.pC = d_pC;
             a.y = d_y; a.m0 = d_m0; a.P0 = d_P0; a.fm = d_fm; a.fP = d_fP; a.status = d_status;
             a.c_dyn = hd->d_small; a.c_obs = ho->d_small; a.add_dyn = d_add_dyn; a.add_obs = d_add_obs;
             a.noise = d_noise; a.B = B; a.ld = ld; a.T = T; a.emv_dyn = hd->emv_mode; a.emv_obs = ho->emv_mode;

@@ -412,6 +412,18 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
     fm2, fP2 = alg.forward_pass_batch(y)
     monkeypatch.delenv('SSMQ_NO_FUSED')
     assert rel_err(fm, fm2) < 1e-11 and rel_err(fP, fP2) < 1e-7
+    # smoother: forward pass that keeps the predictive moments, as one kernel and as the launch loop
+    y = np.repeat(g['ungm_y'], 40, axis=2)[..., :300]
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    for alg in (ssinf.GaussianProcessKalman(dyn, obs, par, par), ssinf.UnscentedKalman(dyn, obs),
+                ssinf.StudentProcessKalman(dyn, obs, par, par)):
+        alg.forward_pass_batch(y)
+        s1, S1 = alg.backward_pass_batch()
+        monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+        s2, S2 = alg.backward_pass_batch()
+        monkeypatch.delenv('SSMQ_NO_FUSED')
+        assert rel_err(s1, s2) < 1e-12 and rel_err(S1, S2) < 1e-12, type(alg).__name__
 
 
 def test_student_filters_golden(amd, golden, monkeypatch):
