@@ -404,6 +404,7 @@ static const AugEntry kAug[] = {
     SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 0),
     SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 5, 0),
     SSMQ_KEEP(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 5, 0),
+    SSMQ_KEEP(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
 };
 
 // as try_launch_fused, for filters whose models take the noise as an argument; d_noise: q_mean | q_cov | r_mean | r_cov

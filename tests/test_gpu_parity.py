@@ -424,6 +424,16 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
         s2, S2 = alg.backward_pass_batch()
         monkeypatch.delenv('SSMQ_NO_FUSED')
         assert rel_err(s1, s2) < 1e-12 and rel_err(S1, S2) < 1e-12, type(alg).__name__
+    y = g['rer_y']
+    dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, g['rer_m0'], g['rer_P0']), sm.GaussRV(3, cov=g['rer_Q']))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=g['rer_R']), 5)
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    alg.forward_pass_batch(y)
+    s1, S1 = alg.backward_pass_batch()
+    monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+    s2, S2 = alg.backward_pass_batch()
+    monkeypatch.delenv('SSMQ_NO_FUSED')
+    assert rel_err(s1, s2) < 1e-10 and rel_err(S1, S2) < 1e-6
 
 
 def test_student_filters_golden(amd, golden, monkeypatch):
