@@ -247,7 +247,9 @@ int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, 
  *   dq > 0: non-additive dynamics, q_mean [dq], q_cov [dq*dq] host, h_dyn is a (dim_state + dq -> dim_state) transform;
  *   dq = 0: additive dynamics, q_cov is G Q G' [dim_state^2] (or NULL for none), q_mean ignored.
  *   dr likewise for the measurement model (h_obs: dim_state + dr -> Y; dr = 0: r_cov is R [Y*Y]).
- * Buffers and status as ssmq_filter_forward_dev.  Synchronous; runs as a launch loop (5 T launches).
+ * Buffers and status as ssmq_filter_forward_dev.  Synchronous; one fused kernel where this (models, shapes, form)
+ * combination has an instantiation (UNGMNA with 4 / 5 points, CTRS + radar with unscented points), else a launch loop
+ * of 5 T launches.
  */
 int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
                                 const ssmq_integrand *f_obs, int dim_state, int64_t B, int64_t ld, int T,
@@ -259,6 +261,8 @@ int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_d
  * Forward pass + Rauch-Tung-Striebel backward pass (ssinf.py:120-147, 325-344): as ssmq_filter_forward_dev, and
  * additionally d_sm [T][D][ld], d_sP [T][D*D][ld] smoothed moments.  The reference's indexing is kept: the recursion
  * starts at the last filtered estimate and leaves the last two smoothed steps equal to the filtered ones.  Synchronous.
+ * The forward pass that keeps the predictive moments is one kernel for the UNGM / pendulum / reentry (5, 2, 11) shapes,
+ * else the launch loop (hipGraph).
  */
 int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
                            const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
