@@ -332,6 +332,8 @@ struct RtsArgs {
     int32_t T;
 };
 
+// every element of the five input sequences is read exactly once and the outputs are written once: streaming accesses
+#define RTS_LD(src) __builtin_nontemporal_load(&(src))
 template <int D>
 __global__ __launch_bounds__(kUpdBlock) void k_rts_backward(const RtsArgs a) {
     const uint32_t b = blockIdx.x * kUpdBlock + threadIdx.x;
@@ -359,13 +361,14 @@ __global__ __launch_bounds__(kUpdBlock) void k_rts_backward(const RtsArgs a) {
         // predictive moments of reference index k + 1 = element k here; filtered moments of index k = element k - 1
         double S[D * (D + 1) / 2], mp[D], Pp[D][D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) mp[d] = a.pm[((int64_t)k * D + d) * ld + b];
+        for (int d = 0; d < D; ++d) mp[d] = RTS_LD(a.pm[((int64_t)k * D + d) * ld + b]);
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                Pp[i][j] = a.pP[((int64_t)k * D * D + i * D + j) * ld + b];
-                if (j <= i) S[SSMQ_PK(i, j)] = Pp[i][j];
+            for (int j = 0; j <= i; ++j) {     // the forward pass wrote a symmetric matrix: lower triangle, mirrored
+                Pp[i][j] = RTS_LD(a.pP[((int64_t)k * D * D + i * D + j) * ld + b]);
+                Pp[j][i] = Pp[i][j];
+                S[SSMQ_PK(i, j)] = Pp[i][j];
             }
         allok = chol_packed<D>(S) && allok;
         // gain = (P_pr^-1 C)'  -> G[d][i] = X[i][d], X = P_pr^-1 C, C = cross-covariance (D_out x D_in)
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(kUpdBlock) void k_rts_backward(const RtsArgs a) {
             double v[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                double s = a.pC[((int64_t)k * D * D + i * D + d) * ld + b];
+                double s = RTS_LD(a.pC[((int64_t)k * D * D + i * D + d) * ld + b]);
 #pragma unroll
                 for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * v[q];
                 v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(kUpdBlock) void k_rts_backward(const RtsArgs a) {
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < D; ++i) s += G[d][i] * (ms[i] - mp[i]);
-            mn[d] = a.fm[((int64_t)(k - 1) * D + d) * ld + b] + s;
+            mn[d] = RTS_LD(a.fm[((int64_t)(k - 1) * D + d) * ld + b]) + s;
         }
         // P_s = P_f + G (P_s_next - P_pr) G'
 #pragma unroll
@@ -414,23 +417,24 @@ __global__ __launch_bounds__(kUpdBlock) void k_rts_backward(const RtsArgs a) {
                 double s = 0.0;
 #pragma unroll
                 for (int j = 0; j < D; ++j) s += w[j] * G[d2][j];
-                Pn[d][d2] = a.fP[((int64_t)(k - 1) * D * D + d * D + d2) * ld + b] + s;
+                Pn[d][d2] = RTS_LD(a.fP[((int64_t)(k - 1) * D * D + d * D + d2) * ld + b]) + s;
             }
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             ms[d] = mn[d];
-            a.sm[((int64_t)(k - 1) * D + d) * ld + b] = mn[d];
+            __builtin_nontemporal_store(mn[d], &a.sm[((int64_t)(k - 1) * D + d) * ld + b]);
 #pragma unroll
             for (int d2 = 0; d2 < D; ++d2) {
                 Ps[d][d2] = Pn[d][d2];
-                a.sP[((int64_t)(k - 1) * D * D + d * D + d2) * ld + b] = Pn[d][d2];
+                __builtin_nontemporal_store(Pn[d][d2], &a.sP[((int64_t)(k - 1) * D * D + d * D + d2) * ld + b]);
             }
         }
     }
     if (!allok) a.status[b] |= (1 << 30);
 }
 
+#undef RTS_LD
 template <int D>
 static void launch_rts(const RtsArgs &a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + kUpdBlock - 1) / kUpdBlock);

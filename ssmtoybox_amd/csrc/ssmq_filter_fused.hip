@@ -288,11 +288,11 @@ __global__ __launch_bounds__(kSmallBlock, (D + DQ >= 5 ? 1 : 2)) void k_filter_f
         if constexpr (KEEP) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                a.pm[((int64_t)k * D + d) * ld + b] = pr.mf[d];
+                SSMQ_STORE(a.pm[((int64_t)k * D + d) * ld + b], pr.mf[d]);
 #pragma unroll
                 for (int d2 = 0; d2 < D; ++d2) {
-                    a.pP[((int64_t)k * D * D + d * D + d2) * ld + b] = pr.cv[d >= d2 ? SSMQ_PK(d, d2) : SSMQ_PK(d2, d)];
-                    a.pC[((int64_t)k * D * D + d * D + d2) * ld + b] = pr.cx[d][d2];
+                    SSMQ_STORE(a.pP[((int64_t)k * D * D + d * D + d2) * ld + b], pr.cv[d >= d2 ? SSMQ_PK(d, d2) : SSMQ_PK(d2, d)]);
+                    SSMQ_STORE(a.pC[((int64_t)k * D * D + d * D + d2) * ld + b], pr.cx[d][d2]);
                 }
             }
         }
