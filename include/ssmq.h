@@ -135,6 +135,14 @@ int ssmq_weights_gp(int D, int N, const double *xi, const double *par, int P, do
                     double *wm, double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R,
                     double *model_var, double *integral_var, int32_t *status);
 /*
+ * Student-t process model: the same weights as ssmq_weights_gp (StudentTProcessModel inherits bq_weights,
+ * bq/bqmod.py:1060-1130); model_var / integral_var are the GP values, which the t-process rescales with the integrand
+ * values at transform time (bq/bqmod.py:1132-1190; tp_nu / tp_iK of ssmq_transform_create).
+ */
+int ssmq_weights_tp(int D, int N, const double *xi, const double *par, int P, double jitter, double *wm, double *Wc,
+                    double *Wcc, double *iK, double *q, double *Q, double *R, double *model_var, double *integral_var,
+                    int32_t *status);
+/*
  * Bayes-Sard quadrature weights.  Replaces BayesSardModel.bq_weights (bq/bqmod.py:893-992) with _exp_x_px / _exp_x_xpx
  * / _exp_x_pxpx / _exp_x_kxpx (bq/bqmod.py:635-797) and utils.vandermonde (utils.py:478-502).
  *   mulind [D*NB]  multi-indices, row-major (D, NB), NB <= N; NB == N selects the unisolvent branch (:952-961).

@@ -74,6 +74,8 @@ _PROTOTYPES = {
     'ssmq_status_first': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     'ssmq_weights_gp': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int,
                                        ctypes.c_double] + [c_double_p] * 9 + [c_int32_p]),
+    'ssmq_weights_tp': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int,
+                                       ctypes.c_double] + [c_double_p] * 9 + [c_int32_p]),
     'ssmq_weights_bs': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int,
                                        ctypes.c_double, c_int32_p, ctypes.c_int] + [c_double_p] * 9 + [c_int32_p]),
     'ssmq_variances_bs': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_double,

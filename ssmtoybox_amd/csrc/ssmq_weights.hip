@@ -654,6 +654,15 @@ extern "C" int ssmq_weights_gp(int D, int N, const double *xi, const double *par
                               status);
 }
 
+// The Student-t process model integrates with the SAME weights as the GP model (StudentTProcessModel inherits
+// GaussianProcessModel.bq_weights, bq/bqmod.py:1060-1130); only its model / integral variance are rescaled by the data
+// (bq/bqmod.py:1132-1190), which the transform kernels do per trajectory (tp_nu, tp_iK of ssmq_transform_create).
+extern "C" int ssmq_weights_tp(int D, int N, const double *xi, const double *par, int P, double jitter, double *wm,
+                               double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R, double *model_var,
+                               double *integral_var, int32_t *status) {
+    return ssmq_weights_gp(D, N, xi, par, P, jitter, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var, status);
+}
+
 extern "C" int ssmq_weights_bs(int D, int N, const double *xi, const double *par, int P, double jitter,
                                const int32_t *mulind, int NB, double *wm, double *Wc, double *Wcc, double *iK,
                                double *q, double *Q, double *R, double *model_var, double *integral_var,
