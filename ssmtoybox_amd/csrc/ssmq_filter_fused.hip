@@ -215,6 +215,8 @@ static const FusedEntry kFused[] = {
     SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 0),
     SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 5, 0),
     SSMQ_FUSED(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 5, 0),
+    SSMQ_FUSED(SSMQ_F_REENTRY1D_DYN, SSMQ_F_RANGE_MEAS, 3, 1, 7, 0),          // tests/test_ssinf.py:40-50 of the reference
+    SSMQ_FUSED(SSMQ_F_CV_DYN, SSMQ_F_RADAR2D_MEAS, 4, 2, 9, 0),               // constant velocity + radar (Student filters)
     SSMQ_FUSED_FAST(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
     SSMQ_FUSED_FAST(SSMQ_F_REENTRY2D_BIAS_DYN, SSMQ_F_RADAR2D_MEAS, 6, 2, 13, 0),
     SSMQ_FUSED_FAST(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 11, 1),

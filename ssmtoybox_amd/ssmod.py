@@ -46,7 +46,17 @@ def _gauss_stats(rv, what):
     """Mean and lower Cholesky factor of a Gaussian random variable (the device simulator draws mean + L z)."""
     if not isinstance(rv, GaussRV):
         raise NotImplementedError('device simulation needs a GaussRV for ' + what)
-    return np.ascontiguousarray(rv.mean, dtype=np.float64), np.ascontiguousarray(np.linalg.cholesky(rv.cov))
+    cov = np.atleast_2d(np.asarray(rv.cov, dtype=np.float64))
+    try:
+        L = np.linalg.cholesky(cov)
+    except np.linalg.LinAlgError:
+        # positive SEMI-definite (e.g. a noise-free model): any A with A A' = cov serves; make it lower triangular
+        lam, V = np.linalg.eigh(0.5 * (cov + cov.T))
+        if lam.min() < -1e-12 * max(1.0, abs(lam).max()):
+            raise
+        A = V * np.sqrt(np.clip(lam, 0.0, None))
+        L = np.linalg.qr(A.T)[1].T
+    return np.ascontiguousarray(rv.mean, dtype=np.float64), np.ascontiguousarray(L)
 
 
 def simulate_dev(dyn, obs, steps, mc_sims, seed=0, traj_offset=0):

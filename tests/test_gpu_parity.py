@@ -471,8 +471,30 @@ def test_student_filters_golden(amd, golden, monkeypatch):
                               sm.StudentRV(2, scale=np.diag([50.0, 5.0]), dof=1000.0), dt=0.5)
     obs = sm.Radar2DMeasurement(sm.StudentRV(2, scale=np.diag([50.0, 0.4e-6]), dof=4.0), 4)
     alg = ssinf.FullySymmetricStudent(dyn, obs)
+    assert 'k_filter_fused<D=4,Y=2' in alg.kernel_name()
     fm, fP = alg.forward_pass_batch(y)
     assert rel_err(fm, g['cv_fss_fm']) < 1e-9 and rel_err(fP, g['cv_fss_fc']) < 1e-6
+    monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+    fm2, fP2 = alg.forward_pass_batch(y)
+    monkeypatch.delenv('SSMQ_NO_FUSED')
+    assert rel_err(fm, fm2) < 1e-11 and rel_err(fP, fP2) < 1e-9
+    # reentry-1D + range (tests/test_ssinf.py:40-50 of the reference): fused (3, 1, 7) kernel against the launch loop
+    m0, P0 = np.array([90.0, 6.0, 1.7]), np.diag([0.3048 ** 2, 1.2192 ** 2, 10.0])
+    dyn = sm.ReentryVehicle1DTransition(sm.GaussRV(3, m0, P0), sm.GaussRV(3, cov=np.zeros((3, 3))))
+    obs = sm.RangeMeasurement(sm.GaussRV(1, cov=np.array([[0.03048 ** 2]])), 3)
+    xs, ys, _ = sm.simulate_dev(dyn, obs, 30, 500, seed=4)
+    yy = ys.download((30, 1, 512))[:, :, :500].transpose(1, 0, 2)
+    xs.free()
+    ys.free()
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    assert 'k_filter_fused<D=3,Y=1' in alg.kernel_name()
+    fm, fP = alg.forward_pass_batch(yy, raise_on_failure=False)
+    st = alg.status.copy()
+    monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+    fm2, fP2 = alg.forward_pass_batch(yy, raise_on_failure=False)
+    monkeypatch.delenv('SSMQ_NO_FUSED')
+    ok = (st == 0) & (alg.status == 0)
+    assert ok.mean() > 0.9 and rel_err(fm[..., ok], fm2[..., ok]) < 1e-10 and rel_err(fP[..., ok], fP2[..., ok]) < 1e-8
 
 
 def test_reentry_ukf_golden(amd, golden):
