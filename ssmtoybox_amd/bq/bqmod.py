@@ -16,20 +16,23 @@ from .bqkern import RBFGauss, device_gp_weights
 
 
 def n_sum_k(n, k):
-    """All n-tuples of non-negative integers summing to k, in the reference's column order (utils.py:459-475)."""
+    """Multi-indices of total degree k as columns of an (n, .) integer array, in the column order the reference's
+    `utils.n_sum_k` produces (utils.py:459-475) - the order fixes the column order of the Vandermonde matrix and with
+    it the Bayes-Sard weights.  Built degree by degree: level 1 is e_0 .. e_{n-1}; level d + 1 raises the first n - 1
+    columns of level d by every e_j with j >= the column's position, then raises every remaining column by e_{n-1}.
+    For k <= 2 that enumerates all n-tuples summing to k in lexicographic order of the index pair; for k >= 3 it is the
+    reference's (incomplete) set, kept as is (pinned by tests/golden/g1_points.npz: nsumk_*)."""
+    if k < 0:
+        raise ValueError('k must be non-negative')
     if k == 0:
         return np.zeros((n, 1), dtype=int)
-    if k == 1:
-        return np.eye(n, dtype=int)
-    a = n_sum_k(n, k - 1)
-    eye = np.eye(n, dtype=int)
-    temp = np.zeros((n, (n * (1 + n) // 2) - 1), dtype=int)
-    t = 0
-    for i in range(n - 1):
-        for j in range(i, n):
-            temp[:, t] = a[:, i] + eye[:, j]
-            t += 1
-    return np.hstack((temp, a[:, n - 1:] + eye[:, -1, None]))
+    unit = [tuple(int(r == j) for r in range(n)) for j in range(n)]
+    level = list(unit)
+    for _ in range(k - 1):
+        head = [tuple(a + b for a, b in zip(level[i], unit[j])) for i in range(n - 1) for j in range(i, n)]
+        tail = [tuple(a + b for a, b in zip(col, unit[n - 1])) for col in level[n - 1:]]
+        level = head + tail
+    return np.array(level, dtype=int).T.reshape(n, -1)
 
 
 class Model:

@@ -24,6 +24,12 @@ int hip_fail(hipError_t e, const char *what) {
     return SSMQ_E_HIP;
 }
 
+// Process-wide caches that hold memory / graphs of ONE device (the matrix-core scratch, the filter workspace with its
+// captured launch loop, per-function attributes): dropped when the calling thread's current device changes, so that a
+// workspace or graph of the previous device is never used from the new device's stream.  The library keeps one stream
+// and one set of caches: one device at a time per process, calls serialised by the caller (include/ssmq.h).
+void reset_device_caches();
+
 int ensure_device() {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -34,6 +40,14 @@ int ensure_device() {
     int dev = 0;
     SSMQ_HIP(hipGetDevice(&dev));
     if (g_stream == nullptr || g_stream_dev != dev) {
+        if (g_stream != nullptr) {          // leaving a device: finish its work, release what was cached on it
+            hipSetDevice(g_stream_dev);
+            hipStreamSynchronize(g_stream);
+            reset_device_caches();
+            hipStreamDestroy(g_stream);
+            g_stream = nullptr;
+            SSMQ_HIP(hipSetDevice(dev));
+        }
         SSMQ_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
         g_stream_dev = dev;
     }
@@ -116,6 +130,7 @@ __global__ void k_status_first(const int32_t *st, int64_t B, unsigned long long 
 }
 
 static int upload_consts(ssmq_transform *h) {
+    ++h->generation;   // part of the filter loop's graph key: new constants never replay a graph captured for old ones
     const int D = h->D, E = h->E, N = h->N;
     const bool sigma = h->form == SSMQ_FORM_SIGMA;
     const ConstLayout cs = const_layout(D, E, N, h->form);
@@ -285,6 +300,11 @@ static int gemm_scratch(int64_t M, int NP, int64_t B, int D, double **fx, double
     *tt = *fx + n_fx;
     *chol = *tt + n_fx;
     return SSMQ_OK;
+}
+static void drop_gemm_scratch() {
+    if (g_gemm_ws) hipFree(g_gemm_ws);
+    g_gemm_ws = nullptr;
+    g_gemm_ws_bytes = 0;
 }
 
 int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
@@ -820,7 +840,24 @@ struct FilterCache {
     }
 };
 FilterCache g_fc;
+// drops the captured loop on every exit of a scope whose temporaries the graph points into
+struct GraphDropGuard {
+    ~GraphDropGuard() { g_fc.drop_graph(); }
+};
 }  // namespace
+
+namespace ssmq {
+void reset_wide_attributes();
+void reset_device_caches() {
+    g_fc.drop_graph();
+    g_fc.consts_ok = false;
+    if (g_fc.ws) hipFree(g_fc.ws);
+    g_fc.ws = nullptr;
+    g_fc.ws_bytes = 0;
+    drop_gemm_scratch();
+    reset_wide_attributes();
+}
+}  // namespace ssmq
 
 // sscale (host, [T]) / student_dof: Studentian recursion (ssinf.py:634-736); null / 0 for the Gaussian filters.
 static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
@@ -894,6 +931,11 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
     key.push_back(((uint64_t)D << 48) | ((uint64_t)Y << 32) | ((uint64_t)h_dyn->N << 16) | (uint64_t)h_obs->N);
     key.push_back(((uint64_t)h_dyn->form << 1) | (uint64_t)h_obs->form);
     key.push_back((uint64_t)(uintptr_t)h_obs->d_small);
+    // which kernel variant apply_dev_impl picks depends on the fast paths the handle's CURRENT constants qualify for:
+    // ssmq_transform_update keeps the block addresses but may withdraw SSMQ_OPT_LDL (and zero its factors)
+    key.push_back(((uint64_t)(uint32_t)h_dyn->opt_mask << 32) | (uint64_t)(uint32_t)h_obs->opt_mask);
+    key.push_back(((uint64_t)(uint32_t)h_dyn->np_pad << 32) | (uint64_t)(uint32_t)h_obs->np_pad);
+    key.push_back(((uint64_t)h_dyn->generation << 32) ^ (uint64_t)h_obs->generation);
     { uint64_t v; memcpy(&v, &h_dyn->tp_nu, 8); key.push_back(v); memcpy(&v, &h_obs->tp_nu, 8); key.push_back(v);
       memcpy(&v, &student_dof, 8); key.push_back(v); key.push_back(sscale ? 1 : 0); }
 
@@ -1158,12 +1200,16 @@ extern "C" int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integran
     if ((rc = pm.alloc(sizeof(double) * (size_t)T * D * ld)) || (rc = pP.alloc(sizeof(double) * (size_t)T * D * D * ld)) ||
         (rc = pC.alloc(sizeof(double) * (size_t)T * D * D * ld)))
         return rc;
+    // a captured launch loop points into pm / pP / pC, which are released when this call returns - on every path
+    GraphDropGuard drop_on_exit;
     rc = filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, GQG, R, d_fm, d_fP, d_status,
                              nullptr, 0.0, pm.d(), pP.d(), pC.d());
     if (rc) return rc;
     rc = launch_rts_backward(D, B, ld, T, d_fm, d_fP, pm.d(), pP.d(), pC.d(), d_sm, d_sP, d_status, stream());
-    if (rc) return rc;
-    g_fc.drop_graph();   // the captured loop points into the buffers that are released below
+    if (rc) {
+        hipStreamSynchronize(stream());
+        return rc;
+    }
     SSMQ_HIP(hipStreamSynchronize(stream()));
     return SSMQ_OK;
 }

@@ -292,9 +292,12 @@ static size_t wide_lds_bytes_for(const WideArgs &a) {
     return sizeof(double) * n;
 }
 
+// hipFuncSetAttribute is per device: ensure_device() clears the flag when the current device changes
+static bool attr_set = false;
+void reset_wide_attributes() { attr_set = false; }
+
 hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s) {
     const size_t lds = wide_lds_bytes_for(a);
-    static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_apply_wide<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 64);

@@ -17,6 +17,7 @@ struct ssmq_transform {
     // matrix-core route for large point sets (ssmq_gemm_mfma.hip): Wc zero-padded to np_pad x np_pad, or null
     double *d_wc_pad = nullptr;
     int np_pad = 0;
+    uint32_t generation = 0;   // bumped by every upload of constants (create / update)
 };
 
 namespace ssmq {

@@ -36,6 +36,43 @@ def rel_err(a, b):
     return num / den if den > 0 else num
 
 
+def cov_err(P, Pref, mask=None):
+    """Entry-scaled covariance error: max |P_ij - Pref_ij| / sqrt(|Pref_ii Pref_jj|), matrix axes first ((D, D, ...)).
+    A norm-wise error would be blind to the small blocks of an ill-scaled covariance (reentry: 1e-6-sized position /
+    velocity variances next to an O(1) one).  mask (shape of the trailing axes) selects the items compared."""
+    P, Pref = np.asarray(P, dtype=float), np.asarray(Pref, dtype=float)
+    D = Pref.shape[0]
+    d = np.sqrt(np.abs(Pref[np.arange(D), np.arange(D)]))          # (D, ...)
+    e = np.abs(P - Pref) / (d[:, None] * d[None, :])
+    if mask is not None:
+        e = e[:, :, mask]
+    return float(np.max(e)) if e.size else 0.0
+
+
+def mean_err(m, mref, mask=None):
+    """Row-scaled mean error: max_i max |m_i - mref_i| / max |mref_i| (state axis first): every state component against
+    its own magnitude, not against the largest one."""
+    m, mref = np.asarray(m, dtype=float), np.asarray(mref, dtype=float)
+    if mask is not None:
+        m, mref = m[:, mask], mref[:, mask]
+    if mref.size == 0:
+        return 0.0
+    ax = tuple(range(1, mref.ndim))
+    den = np.max(np.abs(mref), axis=ax)
+    num = np.max(np.abs(m - mref), axis=ax)
+    return float(np.max(np.where(den > 0, num / np.where(den > 0, den, 1.0), num)))
+
+
+# measured value / bar of every recorded comparison of a test session (tests/conftest.py writes them to
+# gpurun_out/parity_stats.json so that the tolerances in the tests can be traced to what actually holds)
+STATS = []
+
+
+def within(value, tol, what):
+    STATS.append((str(what), float(value), float(tol)))
+    return bool(value < tol)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # tolerance of one moment transform against the NumPy reference (north star: 1e-10 relative, fp64)
 # ---------------------------------------------------------------------------------------------------------------

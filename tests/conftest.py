@@ -23,3 +23,16 @@ def golden():
             cache[name] = dict(np.load(os.path.join(gdir, name + '.npz')))
         return cache[name]
     return load
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Dump the recorded (what, measured, bar) triples of the parity tests (tests/_cases.py::within)."""
+    import json
+    try:
+        from tests._cases import STATS
+    except Exception:
+        return
+    out = os.path.join(ROOT, 'gpurun_out')
+    if STATS and os.path.isdir(out):
+        with open(os.path.join(out, 'parity_stats.json'), 'w') as f:
+            json.dump([dict(what=w, measured=v, bar=t) for w, v, t in STATS], f, indent=1)

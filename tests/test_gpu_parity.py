@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import ssmq_oracle as orc
-from tests._cases import MODELS, SIGMA_TF, BQ_TF, SENSORS, assert_moments_close, rel_err, RTOL
+from tests._cases import MODELS, SIGMA_TF, BQ_TF, SENSORS, assert_moments_close, rel_err, RTOL, cov_err, mean_err, within
 from tests.golden.make_golden_cases import GP_CASES, BS_CASES, gp_par
 
 pytestmark = pytest.mark.gpu
@@ -370,14 +370,14 @@ def test_ungm_filter_golden(amd, golden, name):
     fm, fP = alg.forward_pass_batch(y)                 # all seeds in one batch
     k = 'ungm_' + name
     assert rel_err(fm, g[k + '_fm']) < 1e-8, name      # 100 steps amplify weight round-off ~900x
-    assert rel_err(fP, g[k + '_fc']) < 1e-8, name
+    assert within(cov_err(fP, g[k + '_fc']), 1e-7, 'ungm %s fP vs reference' % name), name
     # the reference's one-trajectory interface
     fm1, fP1 = alg.forward_pass(y[..., 0])
     assert np.array_equal(fm1, fm[..., 0]) and np.array_equal(fP1, fP[..., 0])
     # RTS smoother (backward_pass), including the reference's indexing quirk at the last two steps
     fm, fP = alg.forward_pass_batch(y)
     sm, sP = alg.backward_pass_batch()
-    assert rel_err(sm, g[k + '_sm']) < 1e-8 and rel_err(sP, g[k + '_sc']) < 1e-8, name
+    assert rel_err(sm, g[k + '_sm']) < 1e-8 and within(cov_err(sP, g[k + '_sc']), 1e-7, 'ungm %s sP vs reference' % name), name
     assert np.array_equal(sm[:, -2:], fm[:, -2:]) and np.array_equal(alg.fi_mean, fm)
 
 
@@ -400,7 +400,7 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
         fm3, fP3 = alg.forward_pass_batch(y)          # second call replays the captured graph
         monkeypatch.delenv('SSMQ_NO_FUSED')
         assert np.array_equal(fm2, fm3) and np.array_equal(fP2, fP3)
-        assert rel_err(fm, fm2) < 1e-12 and rel_err(fP, fP2) < 1e-12
+        assert rel_err(fm, fm2) < 1e-12 and within(cov_err(fP, fP2), 1e-11, 'ungm fused vs loop fP ' + type(alg).__name__)
     # reentry: fused (5, 2, 11) kernel against the loop of stand-alone kernels
     y = g['rer_y']
     dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, g['rer_m0'], g['rer_P0']), sm.GaussRV(3, cov=g['rer_Q']))
@@ -411,7 +411,8 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     fm2, fP2 = alg.forward_pass_batch(y)
     monkeypatch.delenv('SSMQ_NO_FUSED')
-    assert rel_err(fm, fm2) < 1e-11 and rel_err(fP, fP2) < 1e-7
+    assert within(mean_err(fm, fm2), 1e-9, 'reentry ukf fused vs loop fm (row-scaled)')
+    assert within(cov_err(fP, fP2), 1e-3, 'reentry ukf fused vs loop fP (entry-scaled)')
     # smoother: forward pass that keeps the predictive moments, as one kernel and as the launch loop
     y = np.repeat(g['ungm_y'], 40, axis=2)[..., :300]
     dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
@@ -423,7 +424,7 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
         monkeypatch.setenv('SSMQ_NO_FUSED', '1')
         s2, S2 = alg.backward_pass_batch()
         monkeypatch.delenv('SSMQ_NO_FUSED')
-        assert rel_err(s1, s2) < 1e-12 and rel_err(S1, S2) < 1e-12, type(alg).__name__
+        assert rel_err(s1, s2) < 1e-12 and within(cov_err(S1, S2), 1e-11, 'ungm smoother fused vs loop ' + type(alg).__name__)
     y = g['rer_y']
     dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, g['rer_m0'], g['rer_P0']), sm.GaussRV(3, cov=g['rer_Q']))
     obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=g['rer_R']), 5)
@@ -433,7 +434,8 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     s2, S2 = alg.backward_pass_batch()
     monkeypatch.delenv('SSMQ_NO_FUSED')
-    assert rel_err(s1, s2) < 1e-10 and rel_err(S1, S2) < 1e-6
+    assert within(mean_err(s1, s2), 1e-9, 'reentry ukf smoother fused vs loop sm (row-scaled)')
+    assert within(cov_err(S1, S2), 1e-3, 'reentry ukf smoother fused vs loop sP (entry-scaled)')
 
 
 def test_student_filters_golden(amd, golden, monkeypatch):
@@ -454,7 +456,7 @@ def test_student_filters_golden(amd, golden, monkeypatch):
             monkeypatch.delenv('SSMQ_NO_FUSED', raising=False)
         assert ('hipGraph' if no_fused else 'k_filter_fused') in alg.kernel_name()
         fm, fP = alg.forward_pass_batch(y)
-        assert rel_err(fm, g['ungm_fss_fm']) < 1e-9 and rel_err(fP, g['ungm_fss_fc']) < 1e-9, no_fused
+        assert rel_err(fm, g['ungm_fss_fm']) < 1e-9 and within(cov_err(fP, g['ungm_fss_fc']), 1e-8, 'ungm fss fP vs reference'), no_fused
     monkeypatch.delenv('SSMQ_NO_FUSED', raising=False)
     kp = np.atleast_2d(np.ones(2))
     alg = ssinf.StudentProcessStudent(dyn, obs, kp, kp)
@@ -464,7 +466,7 @@ def test_student_filters_golden(amd, golden, monkeypatch):
         tf.wm, tf.Wc, tf.Wcc = g[k + '_wm'], g[k + '_Wc'], g[k + '_Wcc']
         tf.model.model_var, tf.model.iK = float(g[k + '_mv']), g[k + '_iK']
     fm, fP = alg.forward_pass_batch(y)
-    assert rel_err(fm, g['ungm_tpqs_fm']) < 1e-8 and rel_err(fP, g['ungm_tpqs_fc']) < 1e-8
+    assert rel_err(fm, g['ungm_tpqs_fm']) < 1e-8 and within(cov_err(fP, g['ungm_tpqs_fc']), 1e-7, 'ungm tpqs fP vs reference')
     # constant velocity + radar
     y = g['cv_y']
     dyn = sm.ConstantVelocity(sm.StudentRV(4, g['cv_m0'], g['cv_P0'], 1000.0),
@@ -473,11 +475,12 @@ def test_student_filters_golden(amd, golden, monkeypatch):
     alg = ssinf.FullySymmetricStudent(dyn, obs)
     assert 'k_filter_fused<D=4,Y=2' in alg.kernel_name()
     fm, fP = alg.forward_pass_batch(y)
-    assert rel_err(fm, g['cv_fss_fm']) < 1e-9 and rel_err(fP, g['cv_fss_fc']) < 1e-6
+    assert within(mean_err(fm, g['cv_fss_fm']), 1e-8, 'cv fss fm vs reference (row-scaled)')
+    assert within(cov_err(fP, g['cv_fss_fc']), 1e-5, 'cv fss fP vs reference (entry-scaled)')
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     fm2, fP2 = alg.forward_pass_batch(y)
     monkeypatch.delenv('SSMQ_NO_FUSED')
-    assert rel_err(fm, fm2) < 1e-11 and rel_err(fP, fP2) < 1e-9
+    assert within(mean_err(fm, fm2), 1e-10, 'cv fss fused vs loop fm') and within(cov_err(fP, fP2), 1e-7, 'cv fss fused vs loop fP')
     # reentry-1D + range (tests/test_ssinf.py:40-50 of the reference): fused (3, 1, 7) kernel against the launch loop
     m0, P0 = np.array([90.0, 6.0, 1.7]), np.diag([0.3048 ** 2, 1.2192 ** 2, 10.0])
     dyn = sm.ReentryVehicle1DTransition(sm.GaussRV(3, m0, P0), sm.GaussRV(3, cov=np.zeros((3, 3))))
@@ -494,7 +497,8 @@ def test_student_filters_golden(amd, golden, monkeypatch):
     fm2, fP2 = alg.forward_pass_batch(yy, raise_on_failure=False)
     monkeypatch.delenv('SSMQ_NO_FUSED')
     ok = (st == 0) & (alg.status == 0)
-    assert ok.mean() > 0.9 and rel_err(fm[..., ok], fm2[..., ok]) < 1e-10 and rel_err(fP[..., ok], fP2[..., ok]) < 1e-8
+    assert ok.mean() > 0.9 and within(mean_err(fm[..., ok], fm2[..., ok]), 1e-9, 'reentry1d fused vs loop fm')
+    assert within(cov_err(fP[..., ok], fP2[..., ok]), 1e-6, 'reentry1d fused vs loop fP')
 
 
 def test_reentry_ukf_golden(amd, golden):
@@ -505,8 +509,8 @@ def test_reentry_ukf_golden(amd, golden):
     obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=g['rer_R']), 5)
     alg = ssinf.UnscentedKalman(dyn, obs)
     fm, fP = alg.forward_pass_batch(y)
-    assert rel_err(fm, g['rer_ukf_fm']) < 1e-9
-    assert rel_err(fP, g['rer_ukf_fc']) < 1e-6
+    assert within(mean_err(fm, g['rer_ukf_fm']), 1e-8, 'reentry ukf fm vs reference (row-scaled)')
+    assert within(cov_err(fP, g['rer_ukf_fc']), 1e-3, 'reentry ukf fP vs reference (entry-scaled)')
 
 
 @pytest.mark.parametrize('name', ['ukf', 'ckf', 'gpqkf'])
@@ -525,7 +529,7 @@ def test_ungmna_filter_golden(amd, golden, name):
     fm, fP = alg.forward_pass_batch(y)
     assert g['ungmna_' + name + '_ok'].all() and not alg.status.any()
     assert rel_err(fm, g['ungmna_' + name + '_fm']) < 1e-8, name
-    assert rel_err(fP, g['ungmna_' + name + '_fc']) < 1e-8, name
+    assert within(cov_err(fP, g['ungmna_' + name + '_fc']), 1e-7, 'ungmna %s fP vs reference' % name), name
     with pytest.raises(NotImplementedError):
         alg.backward_pass_batch()
     if name == 'ckf':
@@ -558,7 +562,8 @@ def test_nonadditive_fused_matches_launch_loop(amd, golden, monkeypatch):
         monkeypatch.delenv('SSMQ_NO_FUSED')
         assert np.array_equal(st, alg.status)
         ok = st == 0
-        assert rel_err(fm[..., ok], fm2[..., ok]) < 1e-11 and rel_err(fP[..., ok], fP2[..., ok]) < 1e-11, type(alg).__name__
+        assert rel_err(fm[..., ok], fm2[..., ok]) < 1e-11, type(alg).__name__
+        assert within(cov_err(fP[..., ok], fP2[..., ok]), 1e-10, 'ungmna fused vs loop fP ' + type(alg).__name__)
     dyn = sm.ConstantTurnRateSpeed(sm.GaussRV(5, mean=g['ctrs_m0'], cov=0.1 * np.eye(5)),
                                    sm.GaussRV(2, cov=np.diag([0.1, 0.1 * np.pi])))
     obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=np.diag([0.3, 0.03])), 5)
@@ -568,7 +573,7 @@ def test_nonadditive_fused_matches_launch_loop(amd, golden, monkeypatch):
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     fm2, fP2 = alg.forward_pass_batch(yy)
     monkeypatch.delenv('SSMQ_NO_FUSED')
-    assert rel_err(fm, fm2) < 1e-11 and rel_err(fP, fP2) < 1e-10
+    assert within(mean_err(fm, fm2), 1e-10, 'ctrs fused vs loop fm') and within(cov_err(fP, fP2), 1e-8, 'ctrs fused vs loop fP')
 
 
 def test_ctrs_radar_ukf_golden(amd, golden):
@@ -581,8 +586,8 @@ def test_ctrs_radar_ukf_golden(amd, golden):
     obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=np.diag([0.3, 0.03])), 5)
     alg = ssinf.UnscentedKalman(dyn, obs)
     fm, fP = alg.forward_pass_batch(y)
-    assert rel_err(fm, g['ctrs_ukf_fm']) < 1e-9
-    assert rel_err(fP, g['ctrs_ukf_fc']) < 1e-9
+    assert within(mean_err(fm, g['ctrs_ukf_fm']), 1e-8, 'ctrs ukf fm vs reference (row-scaled)')
+    assert within(cov_err(fP, g['ctrs_ukf_fc']), 1e-7, 'ctrs ukf fP vs reference (entry-scaled)')
     # ragged batch through the same loop: 130 copies of the four trajectories
     yy = np.tile(y, (1, 1, 33))[..., :130]
     fm2, _ = alg.forward_pass_batch(yy)
@@ -1405,6 +1410,49 @@ def test_theta_batched_weights_large(amd):
         assert rel_err(w['Wc'][i], ref['Wc']) < max(1e-10, 8 * cond ** 2 * 2.2e-16)
 
 
+def test_launch_loop_graph_follows_weight_updates(amd, golden, monkeypatch):
+    """The launch-loop path caches its 3 T launches as a hipGraph.  Replacing a transform's weights keeps the handle and
+    its constant-block addresses, but may change WHICH kernel variant qualifies (the LDL' fast path is withdrawn and its
+    factors zeroed when the new Wc fails the acceptance test): the next pass must re-capture, not replay the stale
+    variant.  Checked against a freshly built filter holding the same weights."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g4_filters')
+    y = np.tile(g['rer_y'], (1, 1, 16))[:, :30]
+    dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, g['rer_m0'], g['rer_P0']), sm.GaussRV(3, cov=g['rer_Q']))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=g['rer_R']), 5)
+    mi = g['rer_bsqkf_mi']
+
+    def make():
+        a = ssinf.BayesSardKalman(dyn, obs, g['rer_bsqkf_par_dyn'], g['rer_bsqkf_par_obs'], mi, mi, 'ut')
+        a.tf_dyn.model.model_var = 2e-6 * np.eye(5)
+        a.tf_obs.model.model_var = 0 * np.eye(2)
+        return a
+    monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+    alg = make()
+    f_dyn = dyn.dyn_eval
+    assert 'OPT=3' in alg.tf_dyn.kernel_name(f_dyn) and 'hipGraph' in alg.kernel_name()
+    fm1, fP1 = alg.forward_pass_batch(y, raise_on_failure=False)
+    fm1b, _ = alg.forward_pass_batch(y, raise_on_failure=False)          # replay of the captured loop
+    assert np.array_equal(fm1, fm1b, equal_nan=True)
+    # an asymmetric 1e-10-sized perturbation: same filter for all practical purposes, but Wc no longer equals its
+    # (symmetric) U diag(d) U' factorisation to 1e-14, so the LDL' variant is withdrawn
+    Wc2 = alg.tf_dyn.Wc.copy()
+    Wc2[1, 0] += 1e-10 * np.max(np.abs(Wc2))
+    alg.tf_dyn.Wc = Wc2
+    assert 'OPT=2' in alg.tf_dyn.kernel_name(f_dyn)
+    fm2, fP2 = alg.forward_pass_batch(y, raise_on_failure=False)
+    fresh = make()
+    fresh.tf_dyn.Wc = Wc2
+    fm3, fP3 = fresh.forward_pass_batch(y, raise_on_failure=False)
+    assert np.array_equal(fm2, fm3, equal_nan=True) and np.array_equal(fP2, fP3, equal_nan=True)
+    ok = (alg.status == 0)
+    assert ok.mean() > 0.9 and np.all(np.isfinite(fm2[..., ok]))
+    # and back: the original weights give the original pass again
+    alg.tf_dyn.Wc = fresh.tf_dyn.Wc * 0 + make().tf_dyn.Wc
+    fm4, _ = alg.forward_pass_batch(y, raise_on_failure=False)
+    assert np.array_equal(fm4, fm1, equal_nan=True)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs as full-size parity cases: device filter loop vs the C oracle on the same trajectories
 # ---------------------------------------------------------------------------------------------------------------
@@ -1450,15 +1498,40 @@ def test_config2_ungm_gpqkf_1e4(amd):
     _compare_filter(fm, fP, alg.status, cfm.transpose(2, 1, 0), cfP.transpose(2, 3, 1, 0), cst)
 
 
-def test_config3_reentry_filters_1e5(amd):
-    """BASELINE configs[2] at one GPU's share of the work (1e5 MC runs on the 6-D reentry-shaped model, 2e4 on the
-    reference's 5-D model).  A GPQ-Kalman *trajectory* cannot be compared on this model: the uncentred covariance
-    fx Wc fx' - m m' subtracts 4e7-sized terms to get 1e-6-sized variances, so every implementation - the reference
-    included, whose author calls GPQKF fragile here (research/gpq/gpq_tracking.py:590-592) - follows its own rounding
-    noise and loses positive definiteness at a different step.  What is pinned instead: the GPQ transform itself at
-    B = 1e5 (test_gpq_d6_full_batch), that the device loop flags (not hides) those failures, and full trajectories of the
-    filters that are stable on this model: the unscented filter and the Bayes-Sard filter in the configuration of the
-    reference's own reentry study (research/bsq/bsq_tracking.py:263-281)."""
+def _compare_filter_prefix(fm, fP, st, cfm, cfP, cst, T, what, tol_status=0.002, tol_m=1e-9, tol_P1=1e-9, tol_P=None):
+    """Two runs of a filter that loses positive definiteness (status = 1 + first failing step): the failing step has to
+    agree (fraction of differing trajectories < tol_status) and the steps BEFORE the first failure of either run are
+    compared entry-wise: mean rows against their magnitude, covariance entries against sqrt(P_ii P_jj).  Layouts
+    (D, T, b) / (D, D, T, b).  Returns the measured figures."""
+    st, cst = np.asarray(st), np.asarray(cst)
+    nd, nc = np.where(st > 0, st - 1, T), np.where(cst > 0, cst - 1, T)     # completed steps
+    n_ok = np.minimum(nd, nc)
+    mask = np.arange(T)[:, None] < n_ok[None, :]                              # (T, b)
+    differ = float(np.mean(st != cst))
+    # nothing may be reported for a step at or after the failure (NaN poison), everything before it is finite
+    assert np.all(np.isfinite(fm[:, np.arange(T)[:, None] < nd[None, :]]))
+    assert np.all(np.isnan(fm[:, np.arange(T)[:, None] >= nd[None, :]]))
+    em = mean_err(fm, cfm, mask)
+    m1 = np.zeros_like(mask)
+    m1[0] = mask[0]
+    eP1 = cov_err(fP, cfP, m1)
+    eP = cov_err(fP, cfP, mask)
+    assert within(differ, tol_status, what + ': fraction of trajectories whose failing step differs')
+    assert within(em, tol_m, what + ': pre-failure means (row-scaled)')
+    assert within(eP1, tol_P1, what + ': first-step covariance (entry-scaled)')
+    if tol_P is not None:
+        assert within(eP, tol_P, what + ': pre-failure covariances (entry-scaled)')
+    return differ, em, eP1, eP, float(np.median(n_ok))
+
+
+@pytest.mark.parametrize('ell', [3.0, 25.0])
+def test_config3_gpqkf_reentry6_1e5_vs_oracle(amd, ell, monkeypatch):
+    """BASELINE configs[2]: GPQ-Kalman on the 6-D reentry-shaped model, 1e5 MC runs (one GPU's share), the fused time
+    loop against the C oracle with IDENTICAL weights.  The recursion is not stable on this model (the uncentred
+    covariance fx Wc fx' - m m' cancels 4e7-sized terms into 1e-6-sized variances; the reference's author calls GPQKF
+    fragile here, research/gpq/gpq_tracking.py:590-592, and the reference itself raises LinAlgError at step 1 on the
+    5-D model at its own l = 25), so what is pinned is what is well defined: the step at which each trajectory fails, and
+    every moment before that step."""
     from oracle import c_oracle as co
     from bench import simulate_reentry
     from ssmtoybox_amd import ssinf, ssmod as sm
@@ -1466,13 +1539,58 @@ def test_config3_reentry_filters_1e5(amd):
     x, y, m0, P0, Q, G, R = simulate_reentry(B, T, 12, True)
     dyn = sm.ReentryVehicle2DBiasTransition(sm.GaussRV(6, m0, P0), sm.GaussRV(4, cov=Q))
     obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=R), 6)
-    gpq = ssinf.GaussianProcessKalman(dyn, obs, np.array([[1.0] + [3.0] * 6]), np.array([[1.0] + [3.0] * 6]))
-    assert 'k_filter_fused<D=6,Y=2' in gpq.kernel_name()
-    with pytest.raises(np.linalg.LinAlgError):
-        gpq.forward_pass_batch(y[:, :, :4096])
-    fm, fP = gpq.forward_pass_batch(y[:, :, :4096], raise_on_failure=False)
-    bad = gpq.status != 0
-    assert bad.mean() > 0.5 and np.all(np.isnan(fm[:, -1, bad])) and np.all(np.isfinite(fm[:, :, ~bad]))
+    par = np.array([[1.0] + [ell] * 6])
+    gpq = ssinf.GaussianProcessKalman(dyn, obs, par, par)
+    td, k1 = _c_bq_transform(gpq.tf_dyn, 6, co.Integrand.make(orc.F_REENTRY2D_BIAS_DYN, (0.1,)))
+    to, k2 = _c_bq_transform(gpq.tf_obs, 2, co.Integrand.make(orc.F_RADAR2D_MEAS, (0.0, 0.0)))
+    GQG = G.dot(Q).dot(G.T)
+    cst = np.zeros(B, dtype=np.int32)
+    ysub = 20000                                   # oracle in slices: bounds the host memory of the (B, T, D, D) output
+    res = {}
+    for fast in (True, False):                     # LDL' / unscented-point fast-path kernel, then the dense kernel
+        if fast:
+            monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)
+        else:
+            monkeypatch.setenv('SSMQ_NO_FASTPATH', '1')
+            gpq = ssinf.GaussianProcessKalman(dyn, obs, par, par)
+        assert 'k_filter_fused<D=6,Y=2' in gpq.kernel_name()
+        if fast:
+            with pytest.raises(np.linalg.LinAlgError):
+                gpq.forward_pass_batch(y[:, :, :4096])
+        fm, fP = gpq.forward_pass_batch(y, raise_on_failure=False)
+        st = gpq.status.copy()
+        worst = [0.0] * 4
+        n_med = []
+        for lo in range(0, B, ysub):
+            sl = slice(lo, lo + ysub)
+            cfm, cfP, c1 = co.filter_forward(td, to, np.ascontiguousarray(y[:, :, sl].transpose(2, 1, 0)), m0, P0, GQG,
+                                             R, threads=16)
+            cst[sl] = c1
+            # the failing step is compared over the whole batch below; slices only bound the moment comparison
+            r = _compare_filter_prefix(fm[:, :, sl], fP[:, :, :, sl], st[sl], cfm.transpose(2, 1, 0),
+                                       cfP.transpose(2, 3, 1, 0), c1, T, 'configs[2] GPQKF l=%g %s slice %d' %
+                                       (ell, 'fast' if fast else 'dense', lo), tol_status=1.0, tol_m=1e-9, tol_P1=1e-6)
+            worst = [max(a, b) for a, b in zip(worst, r[:4])]
+            n_med.append(r[4])
+        differ = float(np.mean(st != cst))
+        res[fast] = (differ, worst, float(np.mean(n_med)), float(np.mean(st > 0)), float(np.mean(cst > 0)))
+        assert within(differ, 0.002, 'configs[2] GPQKF l=%g %s: failing step differs (B=1e5)' % (ell, 'fast' if fast else 'dense'))
+    monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)
+    print('configs[2] GPQKF l=%g:' % ell, res)
+
+
+def test_config3_reentry_filters_1e5(amd):
+    """BASELINE configs[2], the filters that ARE stable on the reentry model: the unscented filter on the 6-D variant
+    (1e5 MC runs on the device, a 4000-trajectory sample against the C oracle) and the Bayes-Sard filter on the
+    reference's 5-D model in the configuration of the reference's own reentry study
+    (research/bsq/bsq_tracking.py:263-281).  The GPQ-Kalman loop is test_config3_gpqkf_reentry6_1e5_vs_oracle."""
+    from oracle import c_oracle as co
+    from bench import simulate_reentry
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    B, T = 100000, 50
+    x, y, m0, P0, Q, G, R = simulate_reentry(B, T, 12, True)
+    dyn = sm.ReentryVehicle2DBiasTransition(sm.GaussRV(6, m0, P0), sm.GaussRV(4, cov=Q))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=R), 6)
     # unscented filter, all 1e5 trajectories on the device, a 4000-trajectory sample against the oracle
     alg = ssinf.UnscentedKalman(dyn, obs)
     assert 'k_filter_fused<D=6,Y=2' in alg.kernel_name()
@@ -1485,8 +1603,8 @@ def test_config3_reentry_filters_1e5(amd):
     cfm, cfP, cst = co.filter_forward(td, to, np.ascontiguousarray(y[:, :, idx].transpose(2, 1, 0)), m0, P0,
                                       G.dot(Q).dot(G.T), R, threads=8)
     assert not cst.any() and not alg.status.any()
-    assert rel_err(fm[:, :, idx], cfm.transpose(2, 1, 0)) < 1e-9
-    assert rel_err(fP[:, :, :, idx], cfP.transpose(2, 3, 1, 0)) < 1e-5     # 1e-6-sized covariances of 6.5e3-sized states
+    assert within(mean_err(fm[:, :, idx], cfm.transpose(2, 1, 0)), 1e-8, 'configs[2] UKF 6-D fm vs oracle (row-scaled)')
+    assert within(cov_err(fP[:, :, :, idx], cfP.transpose(2, 3, 1, 0)), 1e-3, 'configs[2] UKF 6-D fP vs oracle (entry-scaled)')
     rmse = np.sqrt(np.mean((fm[:2] - x[:2]) ** 2))
     assert rmse < 0.2       # sanity only: the filter tracks (position error, km)
     # Bayes-Sard filter on the reference's 5-D model as its reentry study configures it
@@ -1508,7 +1626,11 @@ def test_config3_reentry_filters_1e5(amd):
     good = (bsq.status[:2000] == 0) & (cst == 0)
     assert good.mean() > 0.95
     # unisolvent Bayes-Sard weights reproduce the UT rule: stable, but the covariance is still the uncentred form
-    assert rel_err(fm[:, :, :2000][:, :, good], cfm.transpose(2, 1, 0)[:, :, good]) < 1e-6
+    assert within(mean_err(fm[:, :, :2000][:, :, good], cfm.transpose(2, 1, 0)[:, :, good]), 1e-5,
+                  'configs[2] BSQKF 5-D fm vs oracle (row-scaled)')
+    _compare_filter_prefix(fm[:, :, :2000], fP[:, :, :, :2000], bsq.status[:2000], cfm.transpose(2, 1, 0),
+                           cfP.transpose(2, 3, 1, 0), cst, T, 'configs[2] BSQKF 5-D', tol_status=0.05, tol_m=1e-5,
+                           tol_P1=1e-2)
 
 
 def test_config4_tpq_ct_bearing_1e4(amd):

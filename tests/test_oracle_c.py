@@ -5,7 +5,7 @@ import pytest
 
 from oracle import ssmq_oracle as orc
 from oracle import c_oracle as co
-from tests._cases import MODELS, SIGMA_TF, BQ_TF, assert_moments_close, rel_err
+from tests._cases import MODELS, SIGMA_TF, BQ_TF, assert_moments_close, rel_err, cov_err, mean_err
 
 
 def _c_transform(g, name, tname, din, dout, fid, p, sidx):
@@ -61,7 +61,7 @@ def test_c_filter_golden(golden):
     fm, fP, st = co.filter_forward(td, to, y.transpose(2, 1, 0), np.zeros(1), one, 10.0 * one, one, threads=2)
     assert not st.any()
     assert rel_err(fm.transpose(2, 1, 0), g['ungm_gpqkf_fm']) < 1e-9
-    assert rel_err(fP.transpose(2, 3, 1, 0), g['ungm_gpqkf_fc']) < 1e-9
+    assert cov_err(fP.transpose(2, 3, 1, 0), g['ungm_gpqkf_fc']) < 1e-8
     # reentry UKF
     y = g['rer_y']
     pts = orc.points_ut(5)
@@ -72,8 +72,10 @@ def test_c_filter_golden(golden):
     fm, fP, st = co.filter_forward(td, to, y.transpose(2, 1, 0), g['rer_m0'], g['rer_P0'],
                                    G.dot(g['rer_Q']).dot(G.T), g['rer_R'])
     assert not st.any()
-    assert rel_err(fm.transpose(2, 1, 0), g['rer_ukf_fm']) < 1e-9
-    assert rel_err(fP.transpose(2, 3, 1, 0), g['rer_ukf_fc']) < 1e-6
+    # every state row against its own magnitude, every covariance entry against sqrt(P_ii P_jj): the 1e-6-sized
+    # position / velocity blocks count as much as the O(1) variance of the ballistic parameter (measured 6e-10 / 1.5e-9)
+    assert mean_err(fm.transpose(2, 1, 0), g['rer_ukf_fm']) < 1e-8
+    assert cov_err(fP.transpose(2, 3, 1, 0), g['rer_ukf_fc']) < 1e-8
 
 
 def test_c_not_pd():
