@@ -63,6 +63,17 @@ def mean_err(m, mref, mask=None):
     return float(np.max(np.where(den > 0, num / np.where(den > 0, den, 1.0), num)))
 
 
+def mean_err_sigma(m, mref, Pref, mask=None):
+    """Mean error in standard deviations: max |m_i - mref_i| / sqrt(Pref_ii), layouts (D, ...) / (D, D, ...) - the scale
+    on which a difference between two filters matters, and independent of the magnitude of the state."""
+    m, mref, Pref = np.asarray(m, dtype=float), np.asarray(mref, dtype=float), np.asarray(Pref, dtype=float)
+    D = mref.shape[0]
+    e = np.abs(m - mref) / np.sqrt(np.abs(Pref[np.arange(D), np.arange(D)]))
+    if mask is not None:
+        e = e[:, mask]
+    return float(np.max(e)) if e.size else 0.0
+
+
 # measured value / bar of every recorded comparison of a test session (tests/conftest.py writes them to
 # gpurun_out/parity_stats.json so that the tolerances in the tests can be traced to what actually holds)
 STATS = []

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import ssmq_oracle as orc
-from tests._cases import MODELS, SIGMA_TF, BQ_TF, SENSORS, assert_moments_close, rel_err, RTOL, cov_err, mean_err, within
+from tests._cases import MODELS, SIGMA_TF, BQ_TF, SENSORS, assert_moments_close, rel_err, RTOL, cov_err, mean_err, mean_err_sigma, within
 from tests.golden.make_golden_cases import GP_CASES, BS_CASES, gp_par
 
 pytestmark = pytest.mark.gpu
@@ -370,14 +370,14 @@ def test_ungm_filter_golden(amd, golden, name):
     fm, fP = alg.forward_pass_batch(y)                 # all seeds in one batch
     k = 'ungm_' + name
     assert rel_err(fm, g[k + '_fm']) < 1e-8, name      # 100 steps amplify weight round-off ~900x
-    assert within(cov_err(fP, g[k + '_fc']), 1e-7, 'ungm %s fP vs reference' % name), name
+    assert within(cov_err(fP, g[k + '_fc']), 5e-9, 'ungm %s fP vs reference' % name), name
     # the reference's one-trajectory interface
     fm1, fP1 = alg.forward_pass(y[..., 0])
     assert np.array_equal(fm1, fm[..., 0]) and np.array_equal(fP1, fP[..., 0])
     # RTS smoother (backward_pass), including the reference's indexing quirk at the last two steps
     fm, fP = alg.forward_pass_batch(y)
     sm, sP = alg.backward_pass_batch()
-    assert rel_err(sm, g[k + '_sm']) < 1e-8 and within(cov_err(sP, g[k + '_sc']), 1e-7, 'ungm %s sP vs reference' % name), name
+    assert rel_err(sm, g[k + '_sm']) < 1e-8 and within(cov_err(sP, g[k + '_sc']), 5e-9, 'ungm %s sP vs reference' % name), name
     assert np.array_equal(sm[:, -2:], fm[:, -2:]) and np.array_equal(alg.fi_mean, fm)
 
 
@@ -411,8 +411,8 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     fm2, fP2 = alg.forward_pass_batch(y)
     monkeypatch.delenv('SSMQ_NO_FUSED')
-    assert within(mean_err(fm, fm2), 1e-9, 'reentry ukf fused vs loop fm (row-scaled)')
-    assert within(cov_err(fP, fP2), 1e-3, 'reentry ukf fused vs loop fP (entry-scaled)')
+    assert within(mean_err(fm, fm2), 1e-12, 'reentry ukf fused vs loop fm (row-scaled)')
+    assert within(cov_err(fP, fP2), 1e-11, 'reentry ukf fused vs loop fP (entry-scaled)')
     # smoother: forward pass that keeps the predictive moments, as one kernel and as the launch loop
     y = np.repeat(g['ungm_y'], 40, axis=2)[..., :300]
     dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
@@ -434,8 +434,8 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     s2, S2 = alg.backward_pass_batch()
     monkeypatch.delenv('SSMQ_NO_FUSED')
-    assert within(mean_err(s1, s2), 1e-9, 'reentry ukf smoother fused vs loop sm (row-scaled)')
-    assert within(cov_err(S1, S2), 1e-3, 'reentry ukf smoother fused vs loop sP (entry-scaled)')
+    assert within(mean_err(s1, s2), 1e-8, 'reentry ukf smoother fused vs loop sm (row-scaled)')
+    assert within(cov_err(S1, S2), 2e-8, 'reentry ukf smoother fused vs loop sP (entry-scaled)')
 
 
 def test_student_filters_golden(amd, golden, monkeypatch):
@@ -456,7 +456,7 @@ def test_student_filters_golden(amd, golden, monkeypatch):
             monkeypatch.delenv('SSMQ_NO_FUSED', raising=False)
         assert ('hipGraph' if no_fused else 'k_filter_fused') in alg.kernel_name()
         fm, fP = alg.forward_pass_batch(y)
-        assert rel_err(fm, g['ungm_fss_fm']) < 1e-9 and within(cov_err(fP, g['ungm_fss_fc']), 1e-8, 'ungm fss fP vs reference'), no_fused
+        assert rel_err(fm, g['ungm_fss_fm']) < 1e-9 and within(cov_err(fP, g['ungm_fss_fc']), 1e-10, 'ungm fss fP vs reference'), no_fused
     monkeypatch.delenv('SSMQ_NO_FUSED', raising=False)
     kp = np.atleast_2d(np.ones(2))
     alg = ssinf.StudentProcessStudent(dyn, obs, kp, kp)
@@ -466,7 +466,7 @@ def test_student_filters_golden(amd, golden, monkeypatch):
         tf.wm, tf.Wc, tf.Wcc = g[k + '_wm'], g[k + '_Wc'], g[k + '_Wcc']
         tf.model.model_var, tf.model.iK = float(g[k + '_mv']), g[k + '_iK']
     fm, fP = alg.forward_pass_batch(y)
-    assert rel_err(fm, g['ungm_tpqs_fm']) < 1e-8 and within(cov_err(fP, g['ungm_tpqs_fc']), 1e-7, 'ungm tpqs fP vs reference')
+    assert rel_err(fm, g['ungm_tpqs_fm']) < 1e-8 and within(cov_err(fP, g['ungm_tpqs_fc']), 1e-10, 'ungm tpqs fP vs reference')
     # constant velocity + radar
     y = g['cv_y']
     dyn = sm.ConstantVelocity(sm.StudentRV(4, g['cv_m0'], g['cv_P0'], 1000.0),
@@ -475,12 +475,12 @@ def test_student_filters_golden(amd, golden, monkeypatch):
     alg = ssinf.FullySymmetricStudent(dyn, obs)
     assert 'k_filter_fused<D=4,Y=2' in alg.kernel_name()
     fm, fP = alg.forward_pass_batch(y)
-    assert within(mean_err(fm, g['cv_fss_fm']), 1e-8, 'cv fss fm vs reference (row-scaled)')
-    assert within(cov_err(fP, g['cv_fss_fc']), 1e-5, 'cv fss fP vs reference (entry-scaled)')
+    assert within(mean_err(fm, g['cv_fss_fm']), 1e-12, 'cv fss fm vs reference (row-scaled)')
+    assert within(cov_err(fP, g['cv_fss_fc']), 1e-10, 'cv fss fP vs reference (entry-scaled)')
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     fm2, fP2 = alg.forward_pass_batch(y)
     monkeypatch.delenv('SSMQ_NO_FUSED')
-    assert within(mean_err(fm, fm2), 1e-10, 'cv fss fused vs loop fm') and within(cov_err(fP, fP2), 1e-7, 'cv fss fused vs loop fP')
+    assert within(mean_err(fm, fm2), 1e-12, 'cv fss fused vs loop fm') and within(cov_err(fP, fP2), 1e-10, 'cv fss fused vs loop fP')
     # reentry-1D + range (tests/test_ssinf.py:40-50 of the reference): fused (3, 1, 7) kernel against the launch loop
     m0, P0 = np.array([90.0, 6.0, 1.7]), np.diag([0.3048 ** 2, 1.2192 ** 2, 10.0])
     dyn = sm.ReentryVehicle1DTransition(sm.GaussRV(3, m0, P0), sm.GaussRV(3, cov=np.zeros((3, 3))))
@@ -497,8 +497,8 @@ def test_student_filters_golden(amd, golden, monkeypatch):
     fm2, fP2 = alg.forward_pass_batch(yy, raise_on_failure=False)
     monkeypatch.delenv('SSMQ_NO_FUSED')
     ok = (st == 0) & (alg.status == 0)
-    assert ok.mean() > 0.9 and within(mean_err(fm[..., ok], fm2[..., ok]), 1e-9, 'reentry1d fused vs loop fm')
-    assert within(cov_err(fP[..., ok], fP2[..., ok]), 1e-6, 'reentry1d fused vs loop fP')
+    assert ok.mean() > 0.9 and within(mean_err(fm[..., ok], fm2[..., ok]), 1e-12, 'reentry1d fused vs loop fm')
+    assert within(cov_err(fP[..., ok], fP2[..., ok]), 1e-12, 'reentry1d fused vs loop fP')
 
 
 def test_reentry_ukf_golden(amd, golden):
@@ -510,7 +510,7 @@ def test_reentry_ukf_golden(amd, golden):
     alg = ssinf.UnscentedKalman(dyn, obs)
     fm, fP = alg.forward_pass_batch(y)
     assert within(mean_err(fm, g['rer_ukf_fm']), 1e-8, 'reentry ukf fm vs reference (row-scaled)')
-    assert within(cov_err(fP, g['rer_ukf_fc']), 1e-3, 'reentry ukf fP vs reference (entry-scaled)')
+    assert within(cov_err(fP, g['rer_ukf_fc']), 2e-8, 'reentry ukf fP vs reference (entry-scaled)')
 
 
 @pytest.mark.parametrize('name', ['ukf', 'ckf', 'gpqkf'])
@@ -529,7 +529,7 @@ def test_ungmna_filter_golden(amd, golden, name):
     fm, fP = alg.forward_pass_batch(y)
     assert g['ungmna_' + name + '_ok'].all() and not alg.status.any()
     assert rel_err(fm, g['ungmna_' + name + '_fm']) < 1e-8, name
-    assert within(cov_err(fP, g['ungmna_' + name + '_fc']), 1e-7, 'ungmna %s fP vs reference' % name), name
+    assert within(cov_err(fP, g['ungmna_' + name + '_fc']), 1e-11, 'ungmna %s fP vs reference' % name), name
     with pytest.raises(NotImplementedError):
         alg.backward_pass_batch()
     if name == 'ckf':
@@ -563,7 +563,7 @@ def test_nonadditive_fused_matches_launch_loop(amd, golden, monkeypatch):
         assert np.array_equal(st, alg.status)
         ok = st == 0
         assert rel_err(fm[..., ok], fm2[..., ok]) < 1e-11, type(alg).__name__
-        assert within(cov_err(fP[..., ok], fP2[..., ok]), 1e-10, 'ungmna fused vs loop fP ' + type(alg).__name__)
+        assert within(cov_err(fP[..., ok], fP2[..., ok]), 1e-13, 'ungmna fused vs loop fP ' + type(alg).__name__)
     dyn = sm.ConstantTurnRateSpeed(sm.GaussRV(5, mean=g['ctrs_m0'], cov=0.1 * np.eye(5)),
                                    sm.GaussRV(2, cov=np.diag([0.1, 0.1 * np.pi])))
     obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=np.diag([0.3, 0.03])), 5)
@@ -573,7 +573,7 @@ def test_nonadditive_fused_matches_launch_loop(amd, golden, monkeypatch):
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     fm2, fP2 = alg.forward_pass_batch(yy)
     monkeypatch.delenv('SSMQ_NO_FUSED')
-    assert within(mean_err(fm, fm2), 1e-10, 'ctrs fused vs loop fm') and within(cov_err(fP, fP2), 1e-8, 'ctrs fused vs loop fP')
+    assert within(mean_err(fm, fm2), 1e-11, 'ctrs fused vs loop fm') and within(cov_err(fP, fP2), 1e-10, 'ctrs fused vs loop fP')
 
 
 def test_ctrs_radar_ukf_golden(amd, golden):
@@ -586,8 +586,8 @@ def test_ctrs_radar_ukf_golden(amd, golden):
     obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=np.diag([0.3, 0.03])), 5)
     alg = ssinf.UnscentedKalman(dyn, obs)
     fm, fP = alg.forward_pass_batch(y)
-    assert within(mean_err(fm, g['ctrs_ukf_fm']), 1e-8, 'ctrs ukf fm vs reference (row-scaled)')
-    assert within(cov_err(fP, g['ctrs_ukf_fc']), 1e-7, 'ctrs ukf fP vs reference (entry-scaled)')
+    assert within(mean_err(fm, g['ctrs_ukf_fm']), 1e-11, 'ctrs ukf fm vs reference (row-scaled)')
+    assert within(cov_err(fP, g['ctrs_ukf_fc']), 1e-10, 'ctrs ukf fP vs reference (entry-scaled)')
     # ragged batch through the same loop: 130 copies of the four trajectories
     yy = np.tile(y, (1, 1, 33))[..., :130]
     fm2, _ = alg.forward_pass_batch(yy)
@@ -1439,7 +1439,7 @@ def test_launch_loop_graph_follows_weight_updates(amd, golden, monkeypatch):
     Wc2 = alg.tf_dyn.Wc.copy()
     Wc2[1, 0] += 1e-10 * np.max(np.abs(Wc2))
     alg.tf_dyn.Wc = Wc2
-    assert 'OPT=2' in alg.tf_dyn.kernel_name(f_dyn)
+    assert 'OPT=3' not in alg.tf_dyn.kernel_name(f_dyn)       # the dense kernel (no BQ instantiation with only the point-set fast path)
     fm2, fP2 = alg.forward_pass_batch(y, raise_on_failure=False)
     fresh = make()
     fresh.tf_dyn.Wc = Wc2
@@ -1498,40 +1498,68 @@ def test_config2_ungm_gpqkf_1e4(amd):
     _compare_filter(fm, fP, alg.status, cfm.transpose(2, 1, 0), cfP.transpose(2, 3, 1, 0), cst)
 
 
-def _compare_filter_prefix(fm, fP, st, cfm, cfP, cst, T, what, tol_status=0.002, tol_m=1e-9, tol_P1=1e-9, tol_P=None):
-    """Two runs of a filter that loses positive definiteness (status = 1 + first failing step): the failing step has to
-    agree (fraction of differing trajectories < tol_status) and the steps BEFORE the first failure of either run are
-    compared entry-wise: mean rows against their magnitude, covariance entries against sqrt(P_ii P_jj).  Layouts
-    (D, T, b) / (D, D, T, b).  Returns the measured figures."""
+def _compare_filter_prefix(fm, fP, st, cfm, cfP, cst, T, what, tol_m=1e-9, tol_P=1e-9):
+    """Two runs of a filter that may lose positive definiteness (status = 1 + first failing step): every step BEFORE the
+    first failure of either run is compared entry-wise - means in standard deviations (|dm_i| / sqrt(P_ii)), covariance
+    entries against sqrt(P_ii P_jj).  Layouts (D, T, b) / (D, D, T, b).  Returns (mean error, covariance error)."""
     st, cst = np.asarray(st), np.asarray(cst)
     nd, nc = np.where(st > 0, st - 1, T), np.where(cst > 0, cst - 1, T)     # completed steps
-    n_ok = np.minimum(nd, nc)
-    mask = np.arange(T)[:, None] < n_ok[None, :]                              # (T, b)
-    differ = float(np.mean(st != cst))
-    # nothing may be reported for a step at or after the failure (NaN poison), everything before it is finite
+    mask = np.arange(T)[:, None] < np.minimum(nd, nc)[None, :]                # (T, b)
+    # nothing is reported for a step at or after the failure (NaN poison), everything before it is finite
     assert np.all(np.isfinite(fm[:, np.arange(T)[:, None] < nd[None, :]]))
     assert np.all(np.isnan(fm[:, np.arange(T)[:, None] >= nd[None, :]]))
-    em = mean_err(fm, cfm, mask)
-    m1 = np.zeros_like(mask)
-    m1[0] = mask[0]
-    eP1 = cov_err(fP, cfP, m1)
+    em = mean_err_sigma(fm, cfm, cfP, mask)
     eP = cov_err(fP, cfP, mask)
-    assert within(differ, tol_status, what + ': fraction of trajectories whose failing step differs')
-    assert within(em, tol_m, what + ': pre-failure means (row-scaled)')
-    assert within(eP1, tol_P1, what + ': first-step covariance (entry-scaled)')
-    if tol_P is not None:
-        assert within(eP, tol_P, what + ': pre-failure covariances (entry-scaled)')
-    return differ, em, eP1, eP, float(np.median(n_ok))
+    assert within(em, tol_m, what + ': pre-failure means (in standard deviations)')
+    assert within(eP, tol_P, what + ': pre-failure covariances (entry-scaled)')
+    return em, eP
+
+
+def _failing_matrix_singularity(st, fm, fP, idx, y, m0, P0, GQG, R, pts, wd, wo, f_dyn, p_dyn, f_obs, p_obs):
+    """For the sampled trajectories: restart the NumPy oracle from the device's own state one step before the device
+    reported its failure and return, per trajectory, |lambda_min| / lambda_max of the matrix whose factorisation the step
+    needs next and that is closest to singular (input covariance, predictive covariance, innovation covariance).
+    ~0 means that matrix is numerically singular: whether a Cholesky factorisation 'succeeds' is then decided by the
+    last bits of the rounding, i.e. by the order of the floating-point operations, in any implementation."""
+    out = []
+    for b in idx:
+        k = int(st[b]) - 1
+        m, P = (m0, P0) if k == 0 else (fm[:, k - 1, b], fP[:, :, k - 1, b])
+        ratios = []
+
+        def ratio(a):
+            ev = np.linalg.eigvalsh(0.5 * (a + a.T))
+            ratios.append(float(np.min(np.abs(ev)) / np.max(np.abs(ev))) if ev[0] > 0 else 0.0)
+            return ev[0] > 0
+        if ratio(P):
+            try:
+                pm, pP, _ = orc.apply_bq(f_dyn, m, P, float(k), pts, wd, p_dyn)
+                pP = pP + GQG
+                if ratio(pP):
+                    ym, S, _ = orc.apply_bq(f_obs, pm, pP, float(k), pts, wo, p_obs)
+                    ratio(S + R)
+            except np.linalg.LinAlgError:
+                ratios.append(0.0)
+        out.append(min(ratios))
+    return np.array(out)
 
 
 @pytest.mark.parametrize('ell', [3.0, 25.0])
 def test_config3_gpqkf_reentry6_1e5_vs_oracle(amd, ell, monkeypatch):
     """BASELINE configs[2]: GPQ-Kalman on the 6-D reentry-shaped model, 1e5 MC runs (one GPU's share), the fused time
-    loop against the C oracle with IDENTICAL weights.  The recursion is not stable on this model (the uncentred
-    covariance fx Wc fx' - m m' cancels 4e7-sized terms into 1e-6-sized variances; the reference's author calls GPQKF
-    fragile here, research/gpq/gpq_tracking.py:590-592, and the reference itself raises LinAlgError at step 1 on the
-    5-D model at its own l = 25), so what is pinned is what is well defined: the step at which each trajectory fails, and
-    every moment before that step."""
+    loop against the C oracle with IDENTICAL weights - both kernel variants (LDL' / unscented-point fast path, dense).
+
+    What this recursion is on this model (measured, tools/c3_gpq_stats.py; the reference's author calls GPQKF fragile
+    here, research/gpq/gpq_tracking.py:590-592, and the reference itself raises LinAlgError at step 1 on the 5-D model at
+    its own l = 25): the GP weights do not sum to one, so the uncentred covariance fx Wc fx' - m m' (bq/bqmtran.py:199)
+    of a 6.5e3-sized state is (1'Wc 1 - 1) m m' + O(1e-6): a numerically RANK-ONE matrix.
+      * l = 25: every trajectory fails at step 1, in the device loop, in the C oracle and in the reference - asserted.
+      * l = 3: all runs are finite for 1-3 steps and then hit a Cholesky factorisation of a numerically singular matrix;
+        which step that is depends on the last bits (device fast path / device dense / C oracle agree on the step for
+        only 31-42 % of the trajectories among EACH OTHER, within +-1 step for 78-87 %).  So the failing step itself
+        cannot be pinned.  Pinned instead, on all 1e5 trajectories: every moment of every step before the first failure
+        (entry-wise, 1e-9), the poisoning / flagging of the rest, the distribution of the failing step, and - on a sample -
+        that the matrix the device gave up on is numerically singular in the oracle's arithmetic too."""
     from oracle import c_oracle as co
     from bench import simulate_reentry
     from ssmtoybox_amd import ssinf, ssmod as sm
@@ -1540,43 +1568,44 @@ def test_config3_gpqkf_reentry6_1e5_vs_oracle(amd, ell, monkeypatch):
     dyn = sm.ReentryVehicle2DBiasTransition(sm.GaussRV(6, m0, P0), sm.GaussRV(4, cov=Q))
     obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=R), 6)
     par = np.array([[1.0] + [ell] * 6])
-    gpq = ssinf.GaussianProcessKalman(dyn, obs, par, par)
-    td, k1 = _c_bq_transform(gpq.tf_dyn, 6, co.Integrand.make(orc.F_REENTRY2D_BIAS_DYN, (0.1,)))
-    to, k2 = _c_bq_transform(gpq.tf_obs, 2, co.Integrand.make(orc.F_RADAR2D_MEAS, (0.0, 0.0)))
     GQG = G.dot(Q).dot(G.T)
-    cst = np.zeros(B, dtype=np.int32)
-    ysub = 20000                                   # oracle in slices: bounds the host memory of the (B, T, D, D) output
-    res = {}
-    for fast in (True, False):                     # LDL' / unscented-point fast-path kernel, then the dense kernel
+    cfm = cfP = cst = None
+    for fast in (True, False):
+        tag = 'configs[2] GPQKF l=%g %s' % (ell, 'fast' if fast else 'dense')
         if fast:
             monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)
         else:
             monkeypatch.setenv('SSMQ_NO_FASTPATH', '1')
-            gpq = ssinf.GaussianProcessKalman(dyn, obs, par, par)
-        assert 'k_filter_fused<D=6,Y=2' in gpq.kernel_name()
+        gpq = ssinf.GaussianProcessKalman(dyn, obs, par, par)
+        assert ('OPT=3' if fast else 'OPT=0') in gpq.kernel_name() and 'k_filter_fused<D=6,Y=2' in gpq.kernel_name()
         if fast:
             with pytest.raises(np.linalg.LinAlgError):
                 gpq.forward_pass_batch(y[:, :, :4096])
         fm, fP = gpq.forward_pass_batch(y, raise_on_failure=False)
         st = gpq.status.copy()
-        worst = [0.0] * 4
-        n_med = []
-        for lo in range(0, B, ysub):
-            sl = slice(lo, lo + ysub)
-            cfm, cfP, c1 = co.filter_forward(td, to, np.ascontiguousarray(y[:, :, sl].transpose(2, 1, 0)), m0, P0, GQG,
-                                             R, threads=16)
-            cst[sl] = c1
-            # the failing step is compared over the whole batch below; slices only bound the moment comparison
-            r = _compare_filter_prefix(fm[:, :, sl], fP[:, :, :, sl], st[sl], cfm.transpose(2, 1, 0),
-                                       cfP.transpose(2, 3, 1, 0), c1, T, 'configs[2] GPQKF l=%g %s slice %d' %
-                                       (ell, 'fast' if fast else 'dense', lo), tol_status=1.0, tol_m=1e-9, tol_P1=1e-6)
-            worst = [max(a, b) for a, b in zip(worst, r[:4])]
-            n_med.append(r[4])
-        differ = float(np.mean(st != cst))
-        res[fast] = (differ, worst, float(np.mean(n_med)), float(np.mean(st > 0)), float(np.mean(cst > 0)))
-        assert within(differ, 0.002, 'configs[2] GPQKF l=%g %s: failing step differs (B=1e5)' % (ell, 'fast' if fast else 'dense'))
+        if cst is None:
+            td, k1 = _c_bq_transform(gpq.tf_dyn, 6, co.Integrand.make(orc.F_REENTRY2D_BIAS_DYN, (0.1,)))
+            to, k2 = _c_bq_transform(gpq.tf_obs, 2, co.Integrand.make(orc.F_RADAR2D_MEAS, (0.0, 0.0)))
+            cfm, cfP, cst = co.filter_forward(td, to, np.ascontiguousarray(y.transpose(2, 1, 0)), m0, P0, GQG, R,
+                                              threads=16)
+            cfm, cfP = cfm.transpose(2, 1, 0), cfP.transpose(2, 3, 1, 0)
+        _compare_filter_prefix(fm, fP, st, cfm, cfP, cst, T, tag)
+        if ell == 25.0:
+            assert np.all(st == 1) and np.all(cst == 1)           # as the reference: LinAlgError in the first step
+            continue
+        nd, nc = np.where(st > 0, st, T + 1), np.where(cst > 0, cst, T + 1)
+        assert within(abs(np.median(nd) - np.median(nc)), 0.5, tag + ': |median failing step - oracle median|')
+        assert within(1.0 - np.mean(np.abs(nd - nc) <= 1), 0.3, tag + ': failing step differs by more than one')
+        assert within(abs(np.mean(st == 0) - np.mean(cst == 0)), 2e-3, tag + ': surviving fraction vs oracle')
+        # the matrix the device could not factor is numerically singular when the oracle recomputes it from the device's
+        # own previous state
+        wd = dict(wm=gpq.tf_dyn.wm, Wc=gpq.tf_dyn.Wc, Wcc=gpq.tf_dyn.Wcc, model_var=gpq.tf_dyn.model.model_var)
+        wo = dict(wm=gpq.tf_obs.wm, Wc=gpq.tf_obs.Wc, Wcc=gpq.tf_obs.Wcc, model_var=gpq.tf_obs.model.model_var)
+        idx = np.random.default_rng(5).choice(np.flatnonzero(st > 0), 300, replace=False)
+        r = _failing_matrix_singularity(st, fm, fP, idx, y, m0, P0, GQG, R, gpq.tf_dyn.model.points, wd, wo,
+                                        orc.F_REENTRY2D_BIAS_DYN, (0.1,), orc.F_RADAR2D_MEAS, (0.0, 0.0))
+        assert within(float(np.max(r)), 1e-9, tag + ': |lambda_min| / lambda_max of the matrix that failed to factor')
     monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)
-    print('configs[2] GPQKF l=%g:' % ell, res)
 
 
 def test_config3_reentry_filters_1e5(amd):
@@ -1604,7 +1633,7 @@ def test_config3_reentry_filters_1e5(amd):
                                       G.dot(Q).dot(G.T), R, threads=8)
     assert not cst.any() and not alg.status.any()
     assert within(mean_err(fm[:, :, idx], cfm.transpose(2, 1, 0)), 1e-8, 'configs[2] UKF 6-D fm vs oracle (row-scaled)')
-    assert within(cov_err(fP[:, :, :, idx], cfP.transpose(2, 3, 1, 0)), 1e-3, 'configs[2] UKF 6-D fP vs oracle (entry-scaled)')
+    assert within(cov_err(fP[:, :, :, idx], cfP.transpose(2, 3, 1, 0)), 2e-8, 'configs[2] UKF 6-D fP vs oracle (entry-scaled)')
     rmse = np.sqrt(np.mean((fm[:2] - x[:2]) ** 2))
     assert rmse < 0.2       # sanity only: the filter tracks (position error, km)
     # Bayes-Sard filter on the reference's 5-D model as its reentry study configures it
@@ -1626,11 +1655,11 @@ def test_config3_reentry_filters_1e5(amd):
     good = (bsq.status[:2000] == 0) & (cst == 0)
     assert good.mean() > 0.95
     # unisolvent Bayes-Sard weights reproduce the UT rule: stable, but the covariance is still the uncentred form
-    assert within(mean_err(fm[:, :, :2000][:, :, good], cfm.transpose(2, 1, 0)[:, :, good]), 1e-5,
+    assert within(mean_err(fm[:, :, :2000][:, :, good], cfm.transpose(2, 1, 0)[:, :, good]), 1e-2,
                   'configs[2] BSQKF 5-D fm vs oracle (row-scaled)')
     _compare_filter_prefix(fm[:, :, :2000], fP[:, :, :, :2000], bsq.status[:2000], cfm.transpose(2, 1, 0),
-                           cfP.transpose(2, 3, 1, 0), cst, T, 'configs[2] BSQKF 5-D', tol_status=0.05, tol_m=1e-5,
-                           tol_P1=1e-2)
+                           cfP.transpose(2, 3, 1, 0), cst, T, 'configs[2] BSQKF 5-D', tol_m=0.2, tol_P=0.2)   # measured 4e-2 / 5e-2: the
+    # uncentred form's own noise level on this model (NumPy oracle vs the reference: 2.4e-2, tests/test_oracle_golden.py)
 
 
 def test_config4_tpq_ct_bearing_1e4(amd):
