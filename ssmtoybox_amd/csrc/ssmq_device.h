@@ -19,6 +19,10 @@ struct FPar {
     // Optional table of the integrand's time-dependent constant for integer times 0..T-1 (filter loops: the time index is
     // the step counter), filled on the host by time_table(); null = evaluate the transcendental on the device.
     const double *ttab;
+    // Fused time loops fetch the table entry of the NEXT step while the current one computes and hand it over here
+    // (use_tval = 1): the value ttab[(int) t] without a load on the step's dependency chain.  Zero from the host.
+    double tval;
+    int32_t use_tval;
 };
 
 // Offsets (in doubles) into a transform's constant block in HBM; every thread reads it with wave-uniform addresses,
@@ -168,7 +172,7 @@ struct Fn<SSMQ_F_UNGM_DYN> {
     static constexpr int DIN = 1;
     double c;
     __device__ __forceinline__ void init(double t, const FPar &p) {
-        c = p.ttab ? ((cdouble_p)p.ttab)[(int)t] : 8.0 * cos(1.2 * t);
+        c = p.use_tval ? p.tval : (p.ttab ? ((cdouble_p)p.ttab)[(int)t] : 8.0 * cos(1.2 * t));
     }
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {
@@ -189,7 +193,7 @@ struct Fn<SSMQ_F_UNGMNA_DYN> {
     static constexpr int DIN = 2;
     double c;
     __device__ __forceinline__ void init(double t, const FPar &p) {
-        c = p.ttab ? ((cdouble_p)p.ttab)[(int)t] : cos(1.2 * t);
+        c = p.use_tval ? p.tval : (p.ttab ? ((cdouble_p)p.ttab)[(int)t] : cos(1.2 * t));
     }
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {

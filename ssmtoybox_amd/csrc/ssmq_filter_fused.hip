@@ -48,7 +48,16 @@ struct RegSinkNoCross {
     __device__ __forceinline__ void ccov(int, int, double) {}
 };
 
-template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT>
+// Integrands whose time dependence is a per-step constant tabulated on the host (time_table() in ssmq_device.h): the
+// fused loops fetch the entry of the next step one step ahead instead of loading (or re-evaluating) it on the chain.
+template <int F> struct HasTimeTable { static constexpr bool value = false; };
+template <> struct HasTimeTable<SSMQ_F_UNGM_DYN> { static constexpr bool value = true; };
+template <> struct HasTimeTable<SSMQ_F_UNGMNA_DYN> { static constexpr bool value = true; };
+
+// STU: -1 Gaussian or Studentian recursion decided at run time (a.sscale / a.student_dof), 0 / 1 fixed at compile time
+// (scalar-state kernels: on a 105-instruction step the run-time form costs two branches, three multiplications by a
+// scale of one and their operand moves - 5 us of a 43 us pass).
+template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT, int STU = -1>
 __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FORM_SIGMA)) ? 1 : 2)) void k_filter_fused(const FusedArgs a) {
     if ((int)threadIdx.x >= a.lpw) return;
     const uint32_t b = blockIdx.x * a.lpw + threadIdx.x;
@@ -64,36 +73,65 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
     CoreParams cpd{(cdouble_p)a.c_dyn, (cdouble_p)a.gqg, a.emv_dyn, a.nu_dyn, 1.0, 1.0};
     CoreParams cpo{(cdouble_p)a.c_obs, (cdouble_p)a.rr, a.emv_obs, a.nu_obs, 1.0, 1.0};
     const cdouble_p ssc = (cdouble_p)a.sscale;
+    const bool stu_scale = STU < 0 ? ssc != nullptr : STU == 1;          // ssinf.py:672-693
+    const bool stu_update = STU < 0 ? a.student_dof > 0.0 : STU == 1;    // ssinf.py:729-733
+    // scalar state and measurement: failures are carried by NaN instead of per-step selects (see the update below)
+    constexpr bool kScalar = (D == 1 && Y == 1);
     const double nan = __builtin_nan("");
-    int32_t agg = 0;
-    double ynext[Y];   // the measurement of step k + 1 is requested one step ahead: its HBM latency hides behind step k
+    int32_t agg = 0;       // !kScalar: 1 + first failing step;  kScalar: number of steps completed without a NaN
+    double ynext[Y];       // the measurement of step k + 1 is requested one step ahead: its HBM latency hides behind step k
 #pragma unroll
     for (int i = 0; i < Y; ++i) ynext[i] = a.y[(int64_t)i * ld + b];
+    // Per-step scalars (time-table entries of the integrands, the Studentian scale) are requested one step ahead as
+    // well: consumed in the step that loads them they put a scalar-cache round trip on the chain of every step.
+    FPar fd = a.fd, fo = a.fo;
+    constexpr bool kTTd = HasTimeTable<FD>::value, kTTo = HasTimeTable<FO>::value;
+    const cdouble_p ttd = (cdouble_p)a.fd.ttab, tto = (cdouble_p)a.fo.ttab;   // host: non-null when kTTd / kTTo
+    double tdn = 0.0, ton = 0.0, scn = 1.0;
+    if constexpr (kTTd) { tdn = ttd[0]; fd.use_tval = 1; }
+    if constexpr (kTTo) { ton = tto[0]; fo.use_tval = 1; }
+    if (stu_scale) scn = ssc[0];
+    // Everything requested so far has to have ARRIVED before the loop is entered: hipcc's wait-count insertion merges the
+    // loop-entry state into the loop header, and a vector load still pending there (m0, P0: used by the first step
+    // only) leaves an s_waitcnt vmcnt(n) in the body that - memory operations retire in order - makes EVERY iteration
+    // wait for the acknowledgement of the stores its predecessor has just issued.
+#pragma unroll
+    for (int d = 0; d < D; ++d) pin_v(m[d]);
+#pragma unroll
+    for (int i = 0; i < D * (D + 1) / 2; ++i) pin_v(Pl[i]);
+#pragma unroll
+    for (int i = 0; i < Y; ++i) pin_v(ynext[i]);
 #pragma unroll 1
     for (int k = 0; k < a.T; ++k) {
         const double t = (double)k;  // both transforms of step k + 1 use time index k (ssinf.py:104, 276-288)
         double ycur[Y];
 #pragma unroll
         for (int i = 0; i < Y; ++i) ycur[i] = ynext[i];
-        if (k + 1 < a.T) {
+        if constexpr (kTTd) fd.tval = tdn;
+        if constexpr (kTTo) fo.tval = ton;
+        const double sc = scn;
+        {   // next step's inputs; the last step re-requests its own (no branch in the loop body)
+            const int kn = (k + 1 < a.T) ? k + 1 : k;
 #pragma unroll
-            for (int i = 0; i < Y; ++i) ynext[i] = a.y[((int64_t)(k + 1) * Y + i) * ld + b];
+            for (int i = 0; i < Y; ++i) ynext[i] = a.y[((int64_t)kn * Y + i) * ld + b];
+            if constexpr (kTTd) tdn = ttd[kn];
+            if constexpr (kTTo) ton = tto[kn];
+            if (stu_scale) scn = ssc[kn];
         }
-        if (ssc) {   // Studentian: transformed covariances become scale matrices before the noise term (ssinf.py:672-693)
-            const double sc = ssc[k];
+        if (stu_scale) {   // Studentian: transformed covariances become scale matrices before the noise term (ssinf.py:672-693)
             cpd.cov_scale = sc;
             cpo.cov_scale = sc;
             cpo.ccov_scale = sc;
         }
         // ---- time update: predictive state moments, + G Q G' (ssinf.py:276-279) ----------------------------------
         RegSinkNoCross<D, D> pr;
-        bool ok = moment_transform_core<D, D, ND, FD, FORM, TP, 0, false, OPT>(m, Pl, t, a.fd, cpd, pr);
+        bool ok = moment_transform_core<D, D, ND, FD, FORM, TP, 0, false, OPT, RegSinkNoCross<D, D>>(m, Pl, t, fd, cpd, pr);
         // ---- predictive measurement moments, + R (ssinf.py:287-291) ------------------------------------------------
         double L2[D * (D + 1) / 2];
 #pragma unroll
         for (int i = 0; i < D * (D + 1) / 2; ++i) L2[i] = pr.cv[i];
         RegSink<D, Y> ob;
-        ok = moment_transform_core<D, Y, NO, FO, FORM, TP, SELO, true, OPT>(pr.mf, L2, t, a.fo, cpo, ob) && ok;
+        ok = moment_transform_core<D, Y, NO, FO, FORM, TP, SELO, true, OPT, RegSink<D, Y>>(pr.mf, L2, t, fo, cpo, ob) && ok;
         // ---- measurement update (ssinf.py:321-323) ---------------------------------------------------------------------
         double S[Y * (Y + 1) / 2];
 #pragma unroll
@@ -102,7 +140,17 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
         if (Y == 1) {
             // scalar measurement: P_y^-1 P_yx is one division; the factor-and-two-substitutions route of cho_solve
             // (sqrt + two divisions by it) would only lengthen the serial dependency chain of the time loop
-            ok = (S[0] > 0.0) && ok;
+            if constexpr (kScalar) {
+                // A non-positive (or NaN) covariance turns into NaN by itself in the square root of the next transform
+                // (sqrt_rsqrt: rsq of a negative number, 0 * inf) and from there into every later result of the
+                // trajectory; the one failure that does not is P_y <= 0, so that one is poisoned here - ONE select on
+                // the high word instead of four on the results, and no flag logic on the step's chain.
+                int hi = __double2hiint(S[0]);
+                hi = (S[0] > 0.0) ? hi : 0x7ff80000;
+                S[0] = __hiloint2double(hi, __double2loint(S[0]));
+            } else {
+                ok = (S[0] > 0.0) && ok;
+            }
 #pragma unroll
             for (int d = 0; d < D; ++d) G[d][0] = div_nr(ob.cx[0][d], S[0]);
         } else {
@@ -128,10 +176,10 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
                 for (int i = 0; i < Y; ++i) G[d][i] = v[i];
             }
         }
-        if (agg == 0 && !ok) agg = k + 1;
-        const bool good = (agg == 0);
+        if (!kScalar && agg == 0 && !ok) agg = k + 1;
+        const bool good = kScalar || (agg == 0);
         double sc2 = 1.0;
-        if (a.student_dof > 0.0) {   // (dof + delta'delta) / (dof + Y), delta = chol(S)^-1 (y - y_mean)  (ssinf.py:729-733)
+        if (stu_update) {   // (dof + delta'delta) / (dof + Y), delta = chol(S)^-1 (y - y_mean)  (ssinf.py:729-733)
             double dl[Y], dd = 0.0;
             if (Y == 1) {
                 const double dy0 = ycur[0] - ob.mf[0];
@@ -174,35 +222,53 @@ __global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FO
                 double p = pr.cv[d >= d2 ? SSMQ_PK(d, d2) : SSMQ_PK(d2, d)] - s;
                 p = good ? p : nan;
                 SSMQ_STORE(a.fP[((int64_t)k * D * D + d * D + d2) * ld + b], p);
+                if (kScalar) agg += (p == p) ? 1 : 0;   // a NaN never goes away again: counts the steps completed
                 if (d2 <= d) Pl[SSMQ_PK(d, d2)] = sc2 * p;   // next Cholesky reads the lower triangle only (LAPACK 'L')
             }
         }
     }
+    if (kScalar) agg = (agg == a.T) ? 0 : agg + 1;
     a.status[b] = agg;
 }
 
-template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT>
+template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT, int STU>
 static hipError_t launch_fused(const FusedArgs &a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + a.lpw - 1) / a.lpw);
-    hipLaunchKernelGGL((k_filter_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT>), dim3(grid), dim3(kSmallBlock), 0, s, a);
+    hipLaunchKernelGGL((k_filter_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, STU>), dim3(grid), dim3(kSmallBlock), 0, s, a);
     return hipGetLastError();
 }
 
 typedef hipError_t (*fused_fn)(const FusedArgs &, hipStream_t);
 struct FusedEntry {
     int fd, fo, D, Y, ND, NO, form, tp, selo, opt;
-    fused_fn fn;
+    fused_fn fn[2];   // [Studentian]; shapes with the recursion type decided at run time fill fn[0] only
     const char *name;
 };
 
-#define SSMQ_FUSED_ONE(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT)                                   \
-    {FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT, &launch_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT>, \
-     "k_filter_fused<D=" #D ",Y=" #Y ",ND=" #ND ",NO=" #NO "," #FD "," #FO "," #FORM ",TP=" #TP ",SELO=" #SELO \
-     ",OPT=" #OPT ">"}
+#define SSMQ_FUSED_NAME(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT)                                              \
+    "k_filter_fused<D=" #D ",Y=" #Y ",ND=" #ND ",NO=" #NO "," #FD "," #FO "," #FORM ",TP=" #TP ",SELO=" #SELO \
+    ",OPT=" #OPT ">"
+#define SSMQ_FUSED_FN(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT, STU) \
+    &launch_fused<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, STU>
+#define SSMQ_FUSED_ONE(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT)                                        \
+    {FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT,                                                         \
+     {SSMQ_FUSED_FN(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT, -1), nullptr},                           \
+     SSMQ_FUSED_NAME(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT)}
+// scalar state: recursion type fixed at compile time
+#define SSMQ_FUSED_ONE_S(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT)                                      \
+    {FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT,                                                         \
+     {SSMQ_FUSED_FN(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT, 0),                                      \
+      SSMQ_FUSED_FN(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT, 1)},                                     \
+     SSMQ_FUSED_NAME(FD, FO, D, Y, ND, NO, FORM, TP, SELO, OPT)}
 #define SSMQ_FUSED(FD, FO, D, Y, N, SELO)                                      \
     SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 0, SELO, 0),              \
     SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 1, SELO, 0),              \
     SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_SIGMA, 0, SELO, 0)
+// scalar-state models (D = Y = 1)
+#define SSMQ_FUSED_S(FD, FO, N)                                                \
+    SSMQ_FUSED_ONE_S(FD, FO, 1, 1, N, N, SSMQ_FORM_BQ, 0, 0, 0),               \
+    SSMQ_FUSED_ONE_S(FD, FO, 1, 1, N, N, SSMQ_FORM_BQ, 1, 0, 0),               \
+    SSMQ_FUSED_ONE_S(FD, FO, 1, 1, N, N, SSMQ_FORM_SIGMA, 0, 0, 0)
 // larger shapes: also with the LDL' / unscented-point fast paths of ssmq_apply_small.h
 #define SSMQ_FUSED_FAST(FD, FO, D, Y, N, SELO)                                 \
     SSMQ_FUSED(FD, FO, D, Y, N, SELO),                                         \
@@ -210,16 +276,20 @@ struct FusedEntry {
     SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 1, SELO, 2),              \
     SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_SIGMA, 0, SELO, 2)
 
+static bool HasTimeTableRT(int fid) { return fid == SSMQ_F_UNGM_DYN || fid == SSMQ_F_UNGMNA_DYN; }
+
 static const FusedEntry kFused[] = {
-    SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 2, 0),
-    SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 0),
-    SSMQ_FUSED(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 5, 0),
+    SSMQ_FUSED_S(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 2),
+    SSMQ_FUSED_S(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 3),
+    SSMQ_FUSED_S(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 5),
+#ifndef SSMQ_FUSED_UNGM_ONLY   // tools/build_variant.sh: quick builds for A/B timing of the UNGM kernels
     SSMQ_FUSED(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 5, 0),
     SSMQ_FUSED(SSMQ_F_REENTRY1D_DYN, SSMQ_F_RANGE_MEAS, 3, 1, 7, 0),          // tests/test_ssinf.py:40-50 of the reference
     SSMQ_FUSED(SSMQ_F_CV_DYN, SSMQ_F_RADAR2D_MEAS, 4, 2, 9, 0),               // constant velocity + radar (Student filters)
     SSMQ_FUSED_FAST(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
     SSMQ_FUSED_FAST(SSMQ_F_REENTRY2D_BIAS_DYN, SSMQ_F_RADAR2D_MEAS, 6, 2, 13, 0),
     SSMQ_FUSED_FAST(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 11, 1),
+#endif
 };
 
 // ---- models that take their noise as an argument (ssinf.py:271-272, 282-283, 294-295) -------------------------------------
@@ -277,6 +347,11 @@ __global__ __launch_bounds__(kSmallBlock, (D + DQ >= 5 ? 1 : 2)) void k_filter_f
     const cdouble_p qm = (cdouble_p)a.noise, qc = qm + DQ, rm = qc + DQ * DQ, rc = rm + DR;
     const double nan = __builtin_nan("");
     int32_t agg = 0;
+    // the initial moments have to have arrived before the loop is entered (see k_filter_fused)
+#pragma unroll
+    for (int d = 0; d < D; ++d) pin_v(m[d]);
+#pragma unroll
+    for (int i = 0; i < D * (D + 1) / 2; ++i) pin_v(Pl[i]);
 #pragma unroll 1
     for (int k = 0; k < a.T; ++k) {
         const double t = (double)k;   // both transforms of step k + 1 use time index k (ssinf.py:104, 276-288)
@@ -400,6 +475,7 @@ struct AugEntry {
 
 static const AugEntry kAug[] = {
     SSMQ_AUG(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 4, 4, 0),      // spherical-radial points in 2-D
+#ifndef SSMQ_FUSED_UNGM_ONLY
     SSMQ_AUG(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 5, 5, 0),      // unscented points in 2-D
     SSMQ_AUG_ONE(SSMQ_F_CTRS_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 2, 0, 15, 11, SSMQ_FORM_SIGMA, 0, 0),
     SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 2, 0),
@@ -407,6 +483,7 @@ static const AugEntry kAug[] = {
     SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 5, 0),
     SSMQ_KEEP(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 5, 0),
     SSMQ_KEEP(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
+#endif
 };
 
 // as try_launch_fused, for filters whose models take the noise as an argument; d_noise: q_mean | q_cov | r_mean | r_cov
@@ -455,7 +532,12 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
     for (const FusedEntry &e : kFused) {
         if (e.fd == fd->id && e.fo == fo->id && e.D == hd->D && e.Y == ho->E && e.ND == hd->N && e.NO == ho->N &&
             e.form == hd->form && e.tp == tp && e.selo == sel_obs && e.opt == want[w]) {
-            if (name) *name = e.name;
+            const int stu = (d_sscale != nullptr && student_dof > 0.0) ? 1 : 0;
+            if ((d_sscale != nullptr) != (student_dof > 0.0)) return 0;   // never produced by the entry points
+            fused_fn fn = e.fn[stu] ? e.fn[stu] : e.fn[0];
+            const char *kname = e.name;
+            if (HasTimeTableRT(fd->id) && !d_ttab_dyn && !dry_run) return 0;   // the kernels read the table
+            if (name) *name = kname;
             if (dry_run) return 1;
             FusedArgs a;
             a.y = d_y; a.m0 = d_m0; a.P0 = d_P0; a.fm = d_fm; a.fP = d_fP; a.status = d_status;
@@ -471,7 +553,7 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
             fill_fpar(fo, &a.fo);
             a.fd.ttab = d_ttab_dyn;
             a.fo.ttab = d_ttab_obs;
-            int rc = hip_fail(e.fn(a, s), e.name);
+            int rc = hip_fail(fn(a, s), kname);
             return rc ? rc : 1;
         }
     }
