@@ -12,8 +12,13 @@ timed region; filtered means / covariances of every step are written to HBM (for
 Launch:  python bench.py [--gpus N --steps K --warmup W]          (N = 1)
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 Independent MC trajectories shard across ranks with no data-path collective (weak scaling: B per GPU fixed); the only
-collective is the final all-reduce of the per-step squared-error sums (RCCL via torch.distributed, N > 1 only).
-PyTorch is used for nothing else; compute goes python -> ctypes -> libssmq.so (HIP).
+collective is the final all-reduce of the per-step error sums: RCCL behind the C ABI (ssmq_allreduce_sum), rendezvous
+from the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT).  No PyTorch in this process; compute
+goes python -> ctypes -> libssmq.so (HIP).  (SSMQ_BENCH_BACKEND=gloo swaps in a torch.distributed gloo group for
+rehearsals with several ranks on one GPU.)
+
+The N = 1 run also carries the other BASELINE configs as extra blocks of the same JSON line (roofline_mt6, roofline_c3,
+roofline_c4, roofline_c5), each with the C oracle timed beside it (cpu_baseline, a bounded sample).
 """
 import argparse
 import ctypes
@@ -28,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+CLOCK_HZ = 2.4e9          # MI355X peak engine clock
 F64_MFMA_PEAK_TF = 78.6  # MI355X fp64 matrix peak = 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (equals the fp64 vector peak)
 
 
@@ -154,8 +160,17 @@ class FilterBench:
             ell = 3.0
         self.D, self.Y = dyn.dim_state, obs.dim_out
         D, Y = self.D, self.Y
+        self.y_host, self.m0, self.P0 = y, np.asarray(m0, dtype=float), np.asarray(P0, dtype=float)
         if filt == 'ukf':
             self.alg = ssinf.UnscentedKalman(dyn, obs)
+        elif filt == 'bsqkf':
+            # the reference's reentry study (research/bsq/bsq_tracking.py:263-281): unisolvent multi-index [0 | I | 2I],
+            # model variances overwritten
+            mi = np.hstack((np.zeros((D, 1)), np.eye(D), 2 * np.eye(D))).astype(int)
+            self.alg = ssinf.BayesSardKalman(dyn, obs, np.array([[1.0] + [1.0] * D]),
+                                             np.array([[1.0, 0.9, 0.9] + [1e4] * (D - 2)]), mi, mi, 'ut')
+            self.alg.tf_dyn.model.model_var = 2e-6 * np.eye(D)
+            self.alg.tf_obs.model.model_var = 0 * np.eye(Y)
         elif filt == 'tpqkf':
             par = np.array([[1.0] + [ell] * (D - 1) + [1.0]]) if workload == 'ct' else np.array([[1.0] + [ell] * D])
             self.alg = ssinf.StudentProcessKalman(dyn, obs, par, par)
@@ -209,6 +224,10 @@ class FilterBench:
         # bytes_step = 8 (dim_y + D + D^2) per filter step, filter outputs stored every step
         return 8 * (self.Y + self.D + self.D * self.D) * self.B * self.T
 
+    def free(self):
+        for b in (self.d_y, self.d_x, self.d_m0, self.d_P0, self.d_fm, self.d_fP, self.d_st):
+            b.free()
+
 
 class C5GemmBench:
     """The GEMM-shaped stage of the Bayes-Sard transform at D = E = 10 with the fully-symmetric degree-5 rule (N = 201,
@@ -233,6 +252,7 @@ class C5GemmBench:
         self.fx[:, :self.N] = rng.standard_normal((self.M, self.N))
         self.d_fx, self.d_t = _lib.DeviceBuffer(self.fx.nbytes), _lib.DeviceBuffer(self.fx.nbytes)
         self.d_fx.upload(self.fx)
+        self.gemm_kernel = 'k_fxwc_mfma<13,1>'
 
     def launch(self):
         self._lib.check(self._lib.load().ssmq_fxwc_batch_dev(ctypes.c_void_p(self.h), self.M, ctypes.c_void_p(self.d_fx.ptr),
@@ -261,7 +281,7 @@ class C5GemmBench:
         ms = e0.elapsed_ms(e1) / iters
         return ms, 2.0 * self.M * self.NP * self.NP
 
-    def measure_full_transform(self, B, warmup=3, iters=20):
+    def measure_full_transform(self, B, with_cpu=True, warmup=3, iters=20):
         """The whole D = 10 transform with the device-evaluated synthetic model (ssmod.Smooth10DTransition): Cholesky +
         points + integrand pass, the GEMM, the per-trajectory rest - three launches, moments resident in HBM."""
         from ssmtoybox_amd import ssmod
@@ -287,7 +307,12 @@ class C5GemmBench:
         ms = e0.elapsed_ms(e1) / iters
         for buf in (mean, cov, mf, cf, cfx):
             buf.buf.free()
-        return ms
+        cb = None
+        if with_cpu:
+            ns = 512          # ~0.3 ms per transform and core at N = 201: a bounded sample of the same inputs
+            cb = cpu_baseline_apply(self.tf, _lib.F_SMOOTH10D_DYN, (), 10, 10, means[:ns], covs[:ns], 4.0,
+                                    'the D=E=10, N=201 Bayes-Sard transform (whole transform, not only the GEMM)')
+        return ms, cb
 
 
 class Mt6Bench:
@@ -336,6 +361,13 @@ class Mt6Bench:
         bytes_moved = 8 * (6 + 21 + 6 + 36 + 36) * self.B        # what the kernel actually reads + writes (lower tri. in)
         return ms, bytes_alg, bytes_moved
 
+    def free(self):
+        for s_ in self.sets:
+            for b in s_[:5]:
+                b.buf.free()
+            s_[5].free()
+        self.time.free()
+
     def check(self):
         """Parity of set 0 against the oracle on a sample (bench is not a test, but never report an unchecked number)."""
         from oracle import ssmq_oracle as orc
@@ -355,39 +387,160 @@ class Mt6Bench:
         return float(worst)
 
 
-def cpu_baseline_ungm(B, T, seed, tf, budget_s=12.0, max_threads=16):
-    """The oracle's C restatement of the same filter pass on the host cores (kind "port"), bounded to ~budget_s.
-    It is handed the very weights the GPU run used (tf.wm / Wc / Wcc / model_var as produced by the HIP weights kernel),
-    so the cross-check below compares the filter arithmetic, not two evaluations of an ill-conditioned inverse."""
-    from oracle import ssmq_oracle as orc
+def host_cores(max_threads=16):
+    """Host threads the CPU baseline may use: this process's CPU share, at most 16 (a 1-GPU box's share)."""
     from oracle import c_oracle as co
-    pts = orc.points_ut(1)
-    w = dict(wm=tf.wm, Wc=tf.Wc, Wcc=tf.Wcc, model_var=tf.model.model_var)
-    one = np.ones((1, 1))
-    td, k1 = co.make_transform(0, 1, 1, pts, w['wm'], w['Wc'], w['Wcc'], w['model_var'] * one,
-                               integrand=co.Integrand.make(orc.F_UNGM_DYN))
-    to, k2 = co.make_transform(0, 1, 1, pts, w['wm'], w['Wc'], w['Wcc'], w['model_var'] * one,
-                               integrand=co.Integrand.make(orc.F_UNGM_MEAS))
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = min(cores, co.max_threads(), max_threads)   # a 1-GPU box's CPU share is 16 cores
-    _, y = simulate_ungm(B, T, seed)
-    yb = np.ascontiguousarray(y.T[:, :, None])
+    return min(cores, co.max_threads(), max_threads)
+
+
+def c_port_transforms(wl):
+    """The filter of a FilterBench as transform blocks of the C oracle (oracle/ssmq_oracle.c), with the very weights
+    the device run uses (BQ: tf.wm / Wc / Wcc / model_var as the HIP weights kernel produced them): what is compared and
+    timed is the filter arithmetic, not two evaluations of an ill-conditioned inverse."""
+    from oracle import c_oracle as co
+    from ssmtoybox_amd.mtran import SigmaPointTransform
+    out = []
+    for tf, integ, E in ((wl.alg.tf_dyn, wl.f_dyn, wl.D), (wl.alg.tf_obs, wl.f_obs, wl.Y)):
+        ci = co.Integrand.make(integ.id, [integ.par[i] for i in range(integ.n_par)],
+                               [integ.idx[i] for i in range(integ.n_idx)] if integ.n_idx else None)
+        if isinstance(tf, SigmaPointTransform):
+            out.append(co.make_transform(1, tf.unit_sp.shape[0], E, tf.unit_sp, tf.wm, np.diag(tf.Wc).copy(),
+                                         integrand=ci))
+        else:
+            mv = tf.model.model_var
+            bc = 1 if tf.I_out.shape[0] != E else 0            # dim_out = 1 transforms broadcast the model variance
+            emv = (np.asarray(mv, dtype=float) * np.ones((E, E))) if np.ndim(mv) == 0 else np.asarray(mv, dtype=float)
+            nu = float(getattr(tf.model, 'nu', 0.0) or 0.0) if type(tf).__name__.startswith('StudentT') else 0.0
+            out.append(co.make_transform(0, tf.model.points.shape[0], E, tf.model.points, tf.wm, tf.Wc, tf.Wcc, emv, bc,
+                                         nu, tf.model.iK if nu > 0 else None, ci))
+    return out
+
+
+def cpu_baseline_filter(wl, B_sample, budget_s, what):
+    """The C oracle's restatement of the same filter pass on the host cores (kind "port"), OpenMP over trajectories, on
+    the first B_sample trajectories of the device run, repeated for ~budget_s.  Returns (record, fm (D, T, b), status)."""
+    from oracle import c_oracle as co
+    (td, k1), (to, k2) = c_port_transforms(wl)
+    cores = host_cores()
+    T = wl.T
+    yb = np.ascontiguousarray(wl.y_host[:, :, :B_sample].transpose(2, 1, 0))
+    GQG = wl.alg.G.dot(wl.alg.q_cov).dot(wl.alg.G.T)
     t0 = time.perf_counter()
-    fm, fP, st = co.filter_forward(td, to, yb, np.zeros(1), one, 10.0 * one, one, threads=cores)
+    fm, fP, st = co.filter_forward(td, to, yb, wl.m0, wl.P0, GQG, wl.alg.r_cov, threads=cores)
     dt = time.perf_counter() - t0
     passes, total = 1, dt
     while total + dt < budget_s and passes < 2000:
         t0 = time.perf_counter()
-        co.filter_forward(td, to, yb, np.zeros(1), one, 10.0 * one, one, threads=cores)
+        co.filter_forward(td, to, yb, wl.m0, wl.P0, GQG, wl.alg.r_cov, threads=cores)
         total += time.perf_counter() - t0
         passes += 1
-    rate = passes * B * T / total
-    return {'value': rate, 'unit': 'filter steps/s', 'cores': cores, 'kind': 'port',
-            'sample': '{} passes of B={} x T={} UNGM GPQ-Kalman, oracle/ssmq_oracle.c, OpenMP over trajectories, '
-                      '{:.1f} s'.format(passes, B, T, total)}, (fm[:, :, 0].T, st)
+    rec = {'value': passes * B_sample * T / total, 'unit': 'filter steps/s', 'cores': cores, 'kind': 'port',
+           'sample': '{} passes of the first {} trajectories x T={} of {}, oracle/ssmq_oracle.c, OpenMP over '
+                     'trajectories, {:.1f} s'.format(passes, B_sample, T, what, total)}
+    return rec, fm.transpose(2, 1, 0), fP.transpose(2, 3, 1, 0), st
+
+
+def cpu_baseline_apply(tf, integ_id, integ_par, D, E, means, covs, budget_s, what):
+    """One batched moment transform in the C oracle (same weights as the device handle), on the host cores."""
+    from oracle import c_oracle as co
+    cores = host_cores()
+    mv = tf.model.model_var
+    emv = (np.asarray(mv, dtype=float) * np.ones((E, E))) if np.ndim(mv) == 0 else np.asarray(mv, dtype=float)
+    t, keep = co.make_transform(0, D, E, tf.model.points, tf.wm, tf.Wc, tf.Wcc, emv,
+                                integrand=co.Integrand.make(integ_id, integ_par))
+    t0 = time.perf_counter()
+    co.apply_batch(t, means, covs, 0.0, threads=cores)
+    dt = time.perf_counter() - t0
+    passes, total = 1, dt
+    while total + dt < budget_s and passes < 2000:
+        t0 = time.perf_counter()
+        co.apply_batch(t, means, covs, 0.0, threads=cores)
+        total += time.perf_counter() - t0
+        passes += 1
+    return {'value': passes * means.shape[0] / total, 'unit': 'transforms/s', 'cores': cores, 'kind': 'port',
+            'sample': '{} passes of {} transforms of {}, oracle/ssmq_oracle.c, OpenMP over trajectories, {:.1f} s'.format(
+                passes, means.shape[0], what, total)}
+
+
+def pmc_issue(kernel_prefix='k_filter_fused'):
+    """SQ counters of the headline kernel from the committed summary (profiles/r02_fused_sq.csv: rocprofv3 --pmc passes of
+    tools/pmc_fused.sh; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles, MI355X_MICROARCH.md)."""
+    import csv
+    path = os.path.join(ROOT, 'profiles', 'r02_fused_sq.csv')
+    try:
+        rows = {r['counter']: float(r['mean_per_launch']) for r in csv.DictReader(open(path)) if kernel_prefix in r['kernel']}
+    except (OSError, KeyError, ValueError):
+        return None
+    need = ('SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAVES', 'SQ_ACTIVE_INST_VALU', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY',
+            'SQ_INSTS_SALU')
+    return rows if all(k in rows for k in need) else None
+
+
+def timed_passes(wl, warmup, iters):
+    for _ in range(warmup):
+        wl.step()
+    wl._lib.sync()
+    e0, e1 = wl._lib.Event(), wl._lib.Event()
+    e0.record()
+    for _ in range(iters):
+        wl.step()
+    e1.record()
+    return e0.elapsed_ms(e1) / iters
+
+
+def filter_leg(amd, workload, filt, B, T, seed, cpu_sample, cpu_budget, what, with_cpu=True):
+    """One extra filter workload: device-resident passes timed with HIP events, algorithmic bytes 8 (Y + D + D^2) per
+    filter step, trajectories that fail are counted; the C port timed beside it on a sample and used to
+    cross-check the device result on the same trajectories."""
+    wl = FilterBench(amd, B, T, seed, workload, filt)
+    ms = timed_passes(wl, 3, 20)
+    fm, fP, st = wl.results()
+    ach = wl.bytes_per_pass() / (ms * 1e-3) / 1e9
+    rec = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+           'traffic': pmc_traffic(wl.kernel), 'kernel': wl.kernel, 'bytes_per_launch': wl.bytes_per_pass(),
+           'ms_per_launch': ms, 'filter_steps_per_s': B * T / (ms * 1e-3), 'failed_trajectories': int((st != 0).sum()),
+           'workload': what}
+    if with_cpu:
+        cb, cfm, cfP, cst = cpu_baseline_filter(wl, cpu_sample, cpu_budget, what)
+        rec['cpu_baseline'] = cb
+        good = (st[:cpu_sample] == 0) & (cst == 0)
+        rec['status_equal_vs_cpu_port'] = float(np.mean((st[:cpu_sample] == 0) == (cst == 0)))
+        if good.any():
+            # filtered means of the same trajectories, device vs C port, in standard deviations of the filter's own
+            # covariance (|dm_i| / sqrt(P_ii)): scale-free, and meaningful for states whose mean is zero
+            D = wl.D
+            sd = np.sqrt(np.abs(cfP[np.arange(D), np.arange(D)][:, :, good]))
+            rel = np.max(np.abs(fm[:, :, :cpu_sample][:, :, good] - cfm[:, :, good]) / sd, axis=0)
+            rec['mean_diff_vs_cpu_port_in_sigmas'] = {'median': float(np.median(rel)), 'p99': float(np.quantile(rel, 0.99)),
+                                                      'first_step_max': float(rel[0].max())}
+    wl.free()
+    return rec
+
+
+def make_comm():
+    """Communicator from the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*): RCCL behind the C ABI
+    (default; no PyTorch), or SSMQ_BENCH_BACKEND=gloo - a torch.distributed gloo group, for rehearsals with several ranks
+    on one GPU or none.  Returns (comm, rank, world, local_rank)."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('SSMQ_BENCH_BACKEND', 'rccl')
+    from ssmtoybox_amd import mcshard, _lib
+    ndev = max(_lib.device_count(), 1)
+    local_rank %= ndev
+    _lib.set_device(local_rank)
+    launched = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
+    if not launched:
+        return mcshard.SingleComm(), 0, 1, local_rank
+    if backend == 'gloo':
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+        return mcshard.TorchComm(dist), rank, world, local_rank
+    return mcshard.RcclComm(rank, world, force=os.environ.get('SSMQ_BENCH_FORCE_RCCL') == '1'), rank, world, local_rank
 
 
 def main():
@@ -399,42 +552,22 @@ def main():
     ap.add_argument('--time-steps', type=int, default=100)
     ap.add_argument('--workload', default='ungm', choices=['ungm', 'reentry5', 'reentry6', 'ct'],
                     help="'ungm' is the headline (BASELINE configs[1]); the others are extra measurements")
-    ap.add_argument('--filter', default='gpqkf', choices=['gpqkf', 'ukf', 'tpqkf'])
+    ap.add_argument('--filter', default='gpqkf', choices=['gpqkf', 'ukf', 'tpqkf', 'bsqkf'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-mt6', action='store_true')
+    ap.add_argument('--no-mt6', action='store_true', help='skip the single-kernel / other-config legs of the N = 1 run')
     args = ap.parse_args()
-
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
-        # launched by torch.distributed.run: one rank per GPU; RCCL ("nccl" on ROCm) only for barriers + the final reduce
-        import torch
-        import torch.distributed as dist
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
-        # 'nccl' is RCCL on ROCm; SSMQ_BENCH_BACKEND=gloo lets several ranks share one GPU for rehearsals
-        dist.init_process_group(os.environ.get('SSMQ_BENCH_BACKEND', 'nccl'))
 
     import ssmtoybox_amd as amd
     if amd.device_count() < 1:
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
-    amd.set_device(local_rank)
-    from ssmtoybox_amd import _lib
-
-    def barrier_sync():
-        _lib.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+    from ssmtoybox_amd import _lib, mcshard
+    comm, rank, world, local_rank = make_comm()
 
     B, T = args.batch, args.time_steps
     wl = FilterBench(amd, B, T, seed=1 + rank, workload=args.workload, filt=args.filter)
     for _ in range(args.warmup):
         wl.step()
-    barrier_sync()                      # common start: barrier + device synchronisation on every rank
+    comm.barrier()                      # common start: device synchronisation + barrier on every rank
     ev0, ev1 = _lib.Event(), _lib.Event()
     t0 = time.perf_counter()
     ev0.record()
@@ -442,58 +575,87 @@ def main():
         wl.step()
     ev1.record()
     _lib.sync()                         # this rank's K steps are complete ...
-    if dist is not None:
-        import torch
-        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     pass_ms_dev = ev0.elapsed_ms(ev1) / max(args.steps, 1)
-    if dist is not None:                # ... closing barrier; the job's time is the slowest rank's
-        import torch
-        dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    comm.barrier()                      # ... closing barrier; the job's time is the slowest rank's
+    elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
 
     # final aggregation: per-time-step error sums -> RMSE / NLL (the path's only collective)
     # phase 1: sums reduced on the device from the filter's output buffers, one all-reduce; phase 2: log credibility
     # ratio against the GLOBAL per-step MSE matrix, a second all-reduce
-    from ssmtoybox_amd import mcshard
-    ok = wl.d_st.download((wl.ld,), dtype=np.int32)[:B] == 0
     loc = mcshard.device_error_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, wl.d_st)
-    agg = mcshard.finalize(mcshard.allreduce_sums(loc, dist))
+    agg = mcshard.finalize(mcshard.allreduce_sums(loc, comm))
     lcr = mcshard.finalize_lcr(mcshard.allreduce_sums(
-        mcshard.device_lcr_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, agg['mse'], wl.d_st), dist))
+        mcshard.device_lcr_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, agg['mse'], wl.d_st), comm))
     rmse, nll = agg['rmse_total'], float(agg['nll_avg'].mean())
 
     out = None
+    headline = args.workload == 'ungm' and args.filter == 'gpqkf'
     if rank == 0:
         steps_total = world * B * T * args.steps
         value = steps_total / elapsed
         bytes_pass = wl.bytes_per_pass()
         ach = bytes_pass / (pass_ms_dev * 1e-3) / 1e9
         out = {
-            'metric': 'filter steps/sec (batched MC) for GPQ-Kalman UNGM' if args.workload == 'ungm' and
-            args.filter == 'gpqkf' else 'filter steps/sec (batched MC), {} {}'.format(args.filter, args.workload),
+            'metric': 'filter steps/sec (batched MC) for GPQ-Kalman UNGM' if headline else
+            'filter steps/sec (batched MC), {} {}'.format(args.filter, args.workload),
             'value': value, 'unit': 'filter steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': ('GaussianProcessTransform (RBF, UT points) GPQ-Kalman on UNGM, D=1, N=3, '
                                     '{} MC trajectories per GPU x T={} time steps per pass (BASELINE configs[1])'.format(B, T))
-                       if args.workload == 'ungm' and args.filter == 'gpqkf' else
+                       if headline else
                        '{} on {} (D={}, Y={}), {} MC trajectories per GPU x T={}'.format(args.filter, args.workload, wl.D,
                                                                                        wl.Y, B, T),
-                       'mc_per_gpu': B, 'time_steps': T, 'parallelism': 'mc-shard x{}'.format(world)},
+                       'mc_per_gpu': B, 'time_steps': T, 'parallelism': 'mc-shard x{}'.format(world),
+                       'collective': type(comm).__name__},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(wl.kernel),
                          'kernel': wl.kernel,
                          'bytes_per_launch': bytes_pass, 'ms_per_launch': pass_ms_dev,
-                         'note': 'the fused time loop is a serial recursion per trajectory: fp64-ALU / latency bound '
-                                 '(at B=1e4: 157 waves for 1024 SIMDs), not HBM bound - SURVEY.md 7-4, DESIGN.md 3.4'},
+                         'note': 'the contract\'s HBM figure; this kernel is a serial recursion per trajectory and is '
+                                 'bound by what ONE wave per SIMD can issue (157 waves for 1024 SIMDs at B=1e4), see '
+                                 'roofline_issue and DESIGN.md 3.4'},
             'rmse': rmse, 'nll': nll, 'inclination_indicator': float(np.mean(lcr)),
             'trajectories_aggregated': int(agg['count']),
-            'failed_trajectories_rank0': int((~ok).sum()),
+            # what the averages above leave out (summed over ranks, worst time step): failed filters / not-PD covariances
+            'excluded_failed_trajectories': int(agg['excluded_failed'].max()) if T else 0,
+            'excluded_not_pd_covariances': int(agg['excluded_not_pd'].max()) if T else 0,
         }
-    single = world == 1      # the single-kernel legs and the CPU baseline belong to the N = 1 run only
+        pm = pmc_issue()
+        if headline and pm:
+            waves = pm['SQ_WAVES']
+            valu_wave = pm['SQ_INSTS_VALU'] / waves
+            peak = CLOCK_HZ / 4.0       # one fp64 VALU instruction per 4 cycles per SIMD
+            achieved = valu_wave / (pass_ms_dev * 1e-3)
+            out['roofline_issue'] = {
+                'bound': 'fp64-issue', 'unit': 'VALU instructions/s per wave (one wave per SIMD)',
+                'achieved': achieved, 'peak': peak, 'frac': achieved / peak, 'kernel': wl.kernel,
+                'valu_instructions_per_wave_per_step': valu_wave / T,
+                'salu_instructions_per_wave_per_step': pm['SQ_INSTS_SALU'] / waves / T,
+                'pmc': {'source': 'profiles/r02_fused_sq.csv (rocprofv3 --pmc, tools/pmc_fused.sh)',
+                        'frac_valu_x4_over_wave_cycles': pm['SQ_INSTS_VALU'] / pm['SQ_WAVE_CYCLES'],
+                        'active_inst_valu_over_wave_cycles': pm['SQ_ACTIVE_INST_VALU'] / pm['SQ_WAVE_CYCLES'],
+                        'wait_any_over_wave_cycles': pm['SQ_WAIT_ANY'] / pm['SQ_WAVE_CYCLES'],
+                        'wait_inst_any_over_wave_cycles': pm['SQ_WAIT_INST_ANY'] / pm['SQ_WAVE_CYCLES'],
+                        'waves': waves, 'simds': 1024},
+                'note': 'achieved uses this run\'s HIP-event launch time and the instruction count of the committed PMC '
+                        'pass; measured on this chip one wave issues a dependent fp64 instruction every 6.5 cycles and '
+                        'independent ones every 5.2 (tools/micro/fp64_lat.hip), so frac 0.62-0.77 is the ceiling of a '
+                        'single-wave recursion'}
+    single = world == 1      # the single-kernel legs and the CPU baselines belong to the N = 1 run only
+    with_cpu = not args.no_cpu_baseline
+    if rank == 0 and single and with_cpu and headline:
+        cb, cpu_fm, _, cpu_st = cpu_baseline_filter(wl, B, 8.0, 'UNGM GPQ-Kalman (configs[1])')
+        out['cpu_baseline'] = cb
+        # the GPU pass and the CPU port ran the same trajectories: cross-check them
+        fm, _, st = wl.results()
+        good = (st == 0) & (cpu_st == 0)
+        rel = np.abs(fm[0][:, good] - cpu_fm[0][:, good]) / np.max(np.abs(cpu_fm[0][:, good]))
+        # identical weights and measurements; the UNGM recursion amplifies rounding differences along a trajectory
+        # (uncentred covariance, bq/bqmtran.py:199), hence median and max over the 1e6 filtered means
+        out['rel_diff_vs_cpu_port'] = {'median': float(np.median(rel)), 'p99': float(np.quantile(rel, 0.99)),
+                                       'max': float(rel.max())}
     if rank == 0 and single and not args.no_mt6:
         mt = Mt6Bench(amd, 100000, seed=2)
         err = mt.check()
@@ -503,35 +665,49 @@ def main():
                                'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(mt.kernel), 'kernel': mt.kernel,
                                'bytes_per_launch': b_alg, 'bytes_moved_per_launch': b_mov, 'ms_per_launch': ms,
                                'transforms_per_s': mt.B / (ms * 1e-3), 'max_scaled_err_vs_oracle': err,
-                               'workload': 'batched GPQ moment transform, D=E=6, N=13, B=1e5, 4 rotating buffer sets'}
+                               'workload': 'batched GPQ moment transform, D=E=6, N=13, B=1e5, 4 rotating buffer sets '
+                                           '(north_star target; BASELINE configs[2] transform shape)'}
+        if with_cpu:
+            means, covs = mt.host
+            out['roofline_mt6']['cpu_baseline'] = cpu_baseline_apply(
+                mt.tf, mt.model._fid, (0.1,), 6, 6, means[:50000], covs[:50000], 3.0, 'the D=E=6 GPQ transform')
+        mt.free()
+    if rank == 0 and single and not args.no_mt6:
+        # BASELINE configs[2]: the filters that are stable on the reentry model (the GPQ-Kalman recursion itself fails
+        # within three steps on every trajectory, in the reference as here: tests/test_gpu_parity.py::test_config3_gpqkf_*)
+        out['roofline_c3'] = {
+            'ukf_reentry5': filter_leg(amd, 'reentry5', 'ukf', 100000, 50, 31, 4000, 3.0,
+                                       'UKF, reentry 5-D + radar (the reference\'s model), B=1e5 x T=50', with_cpu),
+            'bsqkf_reentry5': filter_leg(amd, 'reentry5', 'bsqkf', 100000, 50, 32, 4000, 3.0,
+                                         'Bayes-Sard Kalman (research/bsq/bsq_tracking.py set-up), reentry 5-D + radar, '
+                                         'B=1e5 x T=50', with_cpu),
+            'ukf_reentry6': filter_leg(amd, 'reentry6', 'ukf', 100000, 50, 33, 4000, 3.0,
+                                       'UKF, reentry-shaped 6-D + radar (BASELINE state-dim 6), B=1e5 x T=50', with_cpu),
+        }
+        # BASELINE configs[3]: t-process quadrature Kalman filter, 5-D coordinated turn + four bearing sensors
+        out['roofline_c4'] = filter_leg(amd, 'ct', 'tpqkf', 10000, 20, 34, 2000, 3.0,
+                                        'TPQ-Kalman (StudentProcessKalman), coordinated turn 5-D + 4 bearings, B=1e4 x T=20',
+                                        with_cpu)
     if rank == 0 and single and not args.no_mt6:
         c5 = C5GemmBench(amd, 10000, seed=5)
         err = c5.check()
         ms, flop = c5.measure()
-        ms_full = c5.measure_full_transform(10000)
+        ms_full, cb5 = c5.measure_full_transform(10000, with_cpu)
         tf_s = flop / (ms * 1e-3) / 1e12
         out['roofline_c5'] = {'bound': 'mfma', 'achieved': tf_s, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                              'frac': tf_s / F64_MFMA_PEAK_TF, 'traffic': None, 'kernel': 'k_fxwc_mfma<13,1>',
+                              'frac': tf_s / F64_MFMA_PEAK_TF, 'traffic': None, 'kernel': c5.gemm_kernel,
                               'flop_per_launch': flop, 'ms_per_launch': ms, 'max_scaled_err_vs_numpy': err,
                               'full_transform_ms': ms_full, 'full_transforms_per_s': 10000 / (ms_full * 1e-3),
-                              'workload': 'T = FX Wc of the Bayes-Sard transform, D=E=10, N=201 (padded 208), B=1e4: '
-                                          '(1e5 x 208) x (208 x 208), v_mfma_f64_16x16x4_f64'}
-    if rank == 0 and single and not args.no_cpu_baseline and args.workload == 'ungm' and args.filter == 'gpqkf':
-        cb, (cpu_fm, cpu_st) = cpu_baseline_ungm(B, T, seed=1 + rank, tf=wl.alg.tf_dyn)
-        out['cpu_baseline'] = cb
-        # the GPU pass and the CPU port ran the same trajectories: cross-check them
-        fm, _, st = wl.results()
-        good = (st == 0) & (cpu_st == 0)
-        rel = np.abs(fm[0][:, good] - cpu_fm[:, good]) / np.max(np.abs(cpu_fm[:, good]))
-        # identical weights and measurements; the UNGM recursion amplifies rounding differences along a trajectory
-        # (uncentred covariance, bq/bqmtran.py:199), hence median and max over the 1e6 filtered means
-        out['rel_diff_vs_cpu_port'] = {'median': float(np.median(rel)), 'p99': float(np.quantile(rel, 0.99)),
-                                       'max': float(rel.max())}
+                              'workload': 'Bayes-Sard transform, D=E=10, fully-symmetric DEGREE-5 rule N=201 (padded 208) '
+                                          'standing in for BASELINE configs[4]\'s 7th-degree rule - the reference has '
+                                          'degree 3 and 5 only (mtran.py:392) - B=1e4: (1e5 x 208) x (208 x 208) on '
+                                          'v_mfma_f64_16x16x4_f64'}
+        if cb5:
+            out['roofline_c5']['cpu_baseline'] = cb5
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    wl.free()
+    comm.close()
 
 
 if __name__ == '__main__':

@@ -368,6 +368,26 @@ int ssmq_student_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand 
 int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
                             const ssmq_integrand *f_obs, char *buf, int len);
 
+/*
+ * The path's only collective: independent Monte-Carlo trajectories shard across ranks, one process per
+ * GPU, and only the per-time-step error sums are added at the end (the reference loops `for imc in range(mc)` in one
+ * process and averages with numpy: research/tpq/tpq_base.py:154-172, utils.py:113-120).  RCCL over xGMI, opened at run
+ * time; nothing else in this library depends on it.
+ *   ssmq_comm_unique_id  rank 0: 128-byte id (ncclGetUniqueId) to be handed to every rank out of band
+ *   ssmq_comm_init       every rank, after ssmq_set_device: joins the communicator (world = 1 with id = NULL: no RCCL)
+ *   ssmq_allreduce_sum / _max   host buffer of n doubles, reduced in place over all ranks (synchronous)
+ *   ssmq_comm_barrier    drains this rank's stream, then a one-element all-reduce
+ * One communicator per process; calls are collective and must be issued in the same order on every rank.
+ */
+int ssmq_comm_unique_id(char *id, int len);
+int ssmq_comm_init(int rank, int world, const char *id, int len);
+int ssmq_comm_rank(void);
+int ssmq_comm_world(void);
+int ssmq_allreduce_sum(double *buf, int64_t n);
+int ssmq_allreduce_max(double *buf, int64_t n);
+int ssmq_comm_barrier(void);
+int ssmq_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

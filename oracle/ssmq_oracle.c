@@ -29,7 +29,8 @@
 enum {
     F_UNGM_DYN = 1, F_UNGM_MEAS, F_UNGMNA_DYN, F_UNGMNA_MEAS, F_PENDULUM_DYN, F_PENDULUM_MEAS, F_REENTRY1D_DYN,
     F_RANGE_MEAS, F_REENTRY2D_DYN, F_RADAR2D_MEAS, F_CT_DYN, F_BEARING_MEAS, F_CTRS_DYN, F_CV_DYN,
-    F_REENTRY2D_BIAS_DYN
+    F_REENTRY2D_BIAS_DYN,
+    F_SMOOTH10D_DYN
 };
 
 typedef struct {
@@ -157,6 +158,12 @@ static int eval_integrand(const orc_integrand *f, const double *xin, double t, d
             o[2] = x[2] + p[0] * x[3];
             o[3] = x[3];
             return 4;
+        case F_SMOOTH10D_DYN: /* this build's synthetic 10-D integrand; the reference has none */
+            for (int i = 0; i < 5; ++i) {
+                o[i] = sin(x[i]) + x[5 + i] * x[5 + i];
+                o[5 + i] = x[5 + i] * cos(x[i]);
+            }
+            return 10;
         default: return 0;
     }
 }

@@ -143,6 +143,14 @@ _PROTOTYPES = {
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p]),
     'ssmq_filter_kernel_name': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
                                                ctypes.POINTER(Integrand), ctypes.c_char_p, ctypes.c_int]),
+    'ssmq_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    'ssmq_comm_init': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
+    'ssmq_comm_rank': (ctypes.c_int, []),
+    'ssmq_comm_world': (ctypes.c_int, []),
+    'ssmq_allreduce_sum': (ctypes.c_int, [c_double_p, ctypes.c_int64]),
+    'ssmq_allreduce_max': (ctypes.c_int, [c_double_p, ctypes.c_int64]),
+    'ssmq_comm_barrier': (ctypes.c_int, []),
+    'ssmq_comm_destroy': (ctypes.c_int, []),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOTYPES))

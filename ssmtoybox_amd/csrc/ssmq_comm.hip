@@ -1,0 +1,171 @@
+// The path's only collective: sums of the Monte-Carlo error statistics over the ranks of one job, one
+// process per GPU, RCCL over xGMI - behind the C ABI, no PyTorch.  A few KB per call: latency-bound, so the buffer goes
+// host -> device -> ncclAllReduce -> host on the library's stream and the call returns the reduced values.
+//
+// librccl is opened at run time (dlopen) by the first ssmq_comm_* call: the compute entry points of libssmq carry no
+// dependency on it, and single-process users never load it.
+#include <dlfcn.h>
+#include <unistd.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "ssmq_host.h"
+
+namespace {
+
+constexpr int kIdBytes = 128;   // NCCL_UNIQUE_ID_BYTES
+struct UniqueId { char internal[kIdBytes]; };
+typedef void *comm_t;
+enum { kSum = 0, kMax = 2, kFloat64 = 8 };   // ncclSum / ncclMax / ncclFloat64 of rccl.h
+
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(comm_t *, int, UniqueId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+comm_t g_comm = nullptr;
+int g_rank = 0, g_world = 1;
+double *g_dbuf = nullptr;
+size_t g_dbuf_n = 0;
+
+int load_rccl() {
+    if (g_rccl.lib) return SSMQ_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) {
+        ssmq::set_error(std::string("ssmq_comm: cannot open librccl: ") + dlerror());
+        return SSMQ_E_UNSUPPORTED;
+    }
+    g_rccl.GetUniqueId = (int (*)(UniqueId *))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(comm_t *, int, UniqueId, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, comm_t, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(comm_t))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        ssmq::set_error("ssmq_comm: librccl lacks a required symbol");
+        dlclose(h);
+        return SSMQ_E_UNSUPPORTED;
+    }
+    g_rccl.lib = h;
+    return SSMQ_OK;
+}
+
+int nccl_fail(int rc, const char *what) {
+    if (rc == 0) return SSMQ_OK;
+    ssmq::set_error(std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+    return SSMQ_E_HIP;
+}
+
+int allreduce(double *buf, int64_t n, int op) {
+    if (!buf || n < 0) {
+        ssmq::set_error("ssmq_allreduce: bad argument");
+        return SSMQ_E_ARG;
+    }
+    if (n == 0) return SSMQ_OK;
+    if (!g_comm) {   // no communicator: fine for a single process, an error for a rank that never joined
+        if (g_world == 1) return SSMQ_OK;
+        ssmq::set_error("ssmq_allreduce: ssmq_comm_init has not been called");
+        return SSMQ_E_ARG;
+    }
+    int rc = ssmq::ensure_device();
+    if (rc) return rc;
+    hipStream_t s = ssmq::stream();
+    if (g_dbuf_n < (size_t)n) {
+        if (g_dbuf) hipFree(g_dbuf);
+        g_dbuf = nullptr;
+        g_dbuf_n = 0;
+        SSMQ_HIP(hipMalloc(&g_dbuf, sizeof(double) * (size_t)n));
+        g_dbuf_n = (size_t)n;
+    }
+    SSMQ_HIP(hipMemcpyAsync(g_dbuf, buf, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    if ((rc = nccl_fail(g_rccl.AllReduce(g_dbuf, g_dbuf, (size_t)n, kFloat64, op, g_comm, s), "ncclAllReduce"))) return rc;
+    SSMQ_HIP(hipMemcpyAsync(buf, g_dbuf, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    return SSMQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssmq_comm_unique_id(char *id, int len) {
+    if (!id || len < kIdBytes) {
+        ssmq::set_error("ssmq_comm_unique_id: buffer of at least 128 bytes required");
+        return SSMQ_E_ARG;
+    }
+    int rc = load_rccl();
+    if (rc) return rc;
+    UniqueId u;
+    memset(&u, 0, sizeof(u));
+    if ((rc = nccl_fail(g_rccl.GetUniqueId(&u), "ncclGetUniqueId"))) return rc;
+    memcpy(id, u.internal, kIdBytes);
+    return SSMQ_OK;
+}
+
+int ssmq_comm_init(int rank, int world, const char *id, int len) {
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && (!id || len < kIdBytes))) {
+        ssmq::set_error("ssmq_comm_init: bad rank / world / id");
+        return SSMQ_E_ARG;
+    }
+    if (g_comm) {
+        ssmq::set_error("ssmq_comm_init: a communicator already exists (ssmq_comm_destroy first)");
+        return SSMQ_E_ARG;
+    }
+    g_rank = rank;
+    g_world = world;
+    if (world == 1 && !id) return SSMQ_OK;   // single process: every reduction is the identity, RCCL is not loaded
+    int rc = ssmq::ensure_device();           // the communicator binds to the calling thread's current device
+    if (rc) return rc;
+    if ((rc = load_rccl())) return rc;
+    UniqueId u;
+    memcpy(u.internal, id, kIdBytes);
+    // RCCL prints a version banner on stdout while the communicator is created; callers own stdout (bench.py prints one
+    // JSON line there), so it is sent to stderr for the duration of the call
+    fflush(stdout);
+    const int saved = dup(STDOUT_FILENO);
+    if (saved >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
+    const int nrc = g_rccl.CommInitRank(&g_comm, world, u, rank);
+    fflush(stdout);
+    if (saved >= 0) {
+        dup2(saved, STDOUT_FILENO);
+        close(saved);
+    }
+    return nccl_fail(nrc, "ncclCommInitRank");
+}
+
+int ssmq_comm_rank(void) { return g_rank; }
+int ssmq_comm_world(void) { return g_world; }
+
+int ssmq_allreduce_sum(double *buf, int64_t n) { return allreduce(buf, n, kSum); }
+int ssmq_allreduce_max(double *buf, int64_t n) { return allreduce(buf, n, kMax); }
+
+int ssmq_comm_barrier(void) {
+    double one = 1.0;
+    int rc = ssmq::ensure_device();
+    if (rc) return rc;
+    SSMQ_HIP(hipStreamSynchronize(ssmq::stream()));
+    return allreduce(&one, 1, kSum);
+}
+
+int ssmq_comm_destroy(void) {
+    int rc = SSMQ_OK;
+    if (g_comm) {
+        hipStreamSynchronize(ssmq::stream());
+        rc = nccl_fail(g_rccl.CommDestroy(g_comm), "ncclCommDestroy");
+        g_comm = nullptr;
+    }
+    if (g_dbuf) hipFree(g_dbuf);
+    g_dbuf = nullptr;
+    g_dbuf_n = 0;
+    g_rank = 0;
+    g_world = 1;
+    return rc;
+}
+
+}  // extern "C"

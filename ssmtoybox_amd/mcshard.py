@@ -5,13 +5,19 @@ error sums - the only collective of the path.
 Trajectories never interact inside the moment-transform / filter path (the reference loops `for imc in range(mc)`,
 research/tpq/tpq_base.py:187-189), so each rank owns a contiguous slice of the MC index and no data-path collective
 exists.  Phase 1 all-reduces per-time-step sums (squared error, RMSE, NLL, MSE matrix, counts) that a reduction kernel
-produced from the filter's own output buffers; phase 2 - only if the
-log-credibility ratio is wanted, because it needs the GLOBAL MSE matrix per step (utils.py:113-120 via
-research/tpq/tpq_base.py:167-169) - all-reduces the LCR sums.  Messages are a few KB: latency-bound, one fused
-all-reduce per phase.  `dist` is `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
-tests) or None for a single process.
+produced from the filter's own output buffers; phase 2 - only if the log-credibility ratio is wanted, because it needs
+the GLOBAL MSE matrix per step (utils.py:113-120 via research/tpq/tpq_base.py:167-169) - all-reduces the LCR sums.
+Messages are a few KB: latency-bound, one fused all-reduce per phase.
+
+The collective itself is `ssmq_allreduce_sum` of the C ABI: RCCL over xGMI, opened by libssmq at run time, no PyTorch
+(`RcclComm`).  Rendezvous needs only the launcher's environment (RANK, WORLD_SIZE, MASTER_PORT): rank 0 creates the
+128-byte RCCL id and leaves it in a file that the other ranks of the node pick up.  `TorchComm` wraps a
+`torch.distributed` process group instead - used by the CPU tests (gloo, no GPU, no RCCL) and for rehearsals with several
+ranks on one GPU.
 """
 import ctypes
+import os
+import time
 
 import numpy as np
 
@@ -25,12 +31,155 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# communicators
+# ---------------------------------------------------------------------------------------------------------------
+class SingleComm:
+    """One process: every reduction is the identity."""
+    rank, world = 0, 1
+
+    def allreduce_sum(self, flat):
+        return flat
+
+    def allreduce_max(self, flat):
+        return flat
+
+    def barrier(self):
+        if _lib.device_count() > 0:
+            _lib.sync()
+
+    def close(self):
+        pass
+
+
+def _id_file(rank_env=None):
+    """Where rank 0 leaves the RCCL id for the other ranks of this launch.  All ranks of one node are children of one
+    launcher process, so (parent pid, MASTER_PORT) names the launch; SSMQ_RCCL_ID_FILE overrides."""
+    explicit = os.environ.get('SSMQ_RCCL_ID_FILE')
+    if explicit:
+        return explicit
+    tmp = os.environ.get('TMPDIR', '/tmp')
+    return os.path.join(tmp, 'ssmq_rccl_{}_{}_{}.id'.format(os.getppid(), os.environ.get('MASTER_PORT', '0'),
+                                                         os.environ.get('TORCHELASTIC_RUN_ID', 'none')))
+
+
+class RcclComm:
+    """RCCL communicator behind the C ABI (ssmq_comm_*).  One per process; the device must be selected first."""
+
+    def __init__(self, rank, world, id_file=None, timeout_s=300.0, force=False):
+        """force: create an RCCL communicator even for world = 1 (rehearsal of the RCCL path on one GPU)."""
+        lib = _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        self._file = id_file or _id_file()
+        self._rccl = self.world > 1 or force
+        buf = ctypes.create_string_buffer(128)
+        if self._rccl:
+            if self.rank == 0:
+                _lib.check(lib.ssmq_comm_unique_id(buf, 128), 'ssmq_comm_unique_id')
+                tmp = self._file + '.tmp{}'.format(os.getpid())
+                with open(tmp, 'wb') as f:
+                    f.write(buf.raw)
+                os.replace(tmp, self._file)          # atomic: readers see all 128 bytes or no file
+            else:
+                t0 = time.time()
+                while True:
+                    try:
+                        # a file left behind by an earlier launch that happened to share (ppid, port) is older than this
+                        # process: ignore it
+                        if os.path.getmtime(self._file) >= _process_start_time() - 1.0:
+                            with open(self._file, 'rb') as f:
+                                raw = f.read()
+                            if len(raw) == 128:
+                                break
+                    except OSError:
+                        pass
+                    if time.time() - t0 > timeout_s:
+                        raise _lib.SsmqError('RCCL rendezvous: no id file {} after {} s'.format(self._file, timeout_s))
+                    time.sleep(0.01)
+                buf = ctypes.create_string_buffer(raw, 128)
+        _lib.check(lib.ssmq_comm_init(self.rank, self.world, buf if self._rccl else None, 128), 'ssmq_comm_init')
+
+    def _reduce(self, fn, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float64).copy()
+        if self._rccl and flat.size:
+            _lib.check(fn(flat.ctypes.data_as(_lib.c_double_p), flat.size), 'ssmq_allreduce')
+        return flat
+
+    def allreduce_sum(self, flat):
+        return self._reduce(_lib.load().ssmq_allreduce_sum, flat)
+
+    def allreduce_max(self, flat):
+        return self._reduce(_lib.load().ssmq_allreduce_max, flat)
+
+    def barrier(self):
+        _lib.check(_lib.load().ssmq_comm_barrier(), 'ssmq_comm_barrier')
+
+    def close(self):
+        self.barrier()                                # nobody is still looking for the id file
+        _lib.check(_lib.load().ssmq_comm_destroy(), 'ssmq_comm_destroy')
+        if self.rank == 0 and self._rccl:
+            try:
+                os.unlink(self._file)
+            except OSError:
+                pass
+
+
+def _process_start_time():
+    try:
+        return os.stat('/proc/{}'.format(os.getppid())).st_ctime
+    except OSError:
+        return 0.0
+
+
+class TorchComm:
+    """A torch.distributed process group as the communicator (CPU tests over gloo; rehearsals)."""
+
+    def __init__(self, dist, device=None):
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device or ('cuda' if dist.get_backend() == 'nccl' else 'cpu')
+
+    def _reduce(self, flat, op):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float64).copy()).to(self.device)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=op)
+        return t.cpu().numpy()
+
+    def allreduce_sum(self, flat):
+        return self._reduce(flat, self.dist.ReduceOp.SUM)
+
+    def allreduce_max(self, flat):
+        return self._reduce(flat, self.dist.ReduceOp.MAX)
+
+    def barrier(self):
+        if _lib.device_count() > 0:
+            _lib.sync()
+        self.dist.barrier()
+
+    def close(self):
+        self.dist.barrier()
+
+
+def _as_comm(comm):
+    """None -> single process; an object with is_initialized() (torch.distributed) -> TorchComm; else as given."""
+    if comm is None:
+        return SingleComm()
+    if hasattr(comm, 'is_initialized'):
+        return TorchComm(comm) if comm.is_initialized() else SingleComm()
+    return comm
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device-side sums of this rank's trajectories
+# ---------------------------------------------------------------------------------------------------------------
 def device_error_sums(D, B, ld, T, d_x, d_fm, d_fP, d_status=None):
     """Phase-1 sums of this rank's trajectories, reduced on the device (`ssmq_error_sums_dev`).
     d_x, d_fm: DeviceBuffer planes [T][D][ld]; d_fP [T][D*D][ld] (the buffers the filter wrote); d_status [ld] or None.
     Returns a dict of arrays: se (T, D) squared error (utils.py:18-38), rmse (T,) sum of ||x - m|| (the quantity
     research/tpq/tpq_base.py:158-159 averages), nll (T,) negative log-likelihood (utils.py:123-148), mse (T, D, D) outer
-    products (utils.py:41-64), n_ok (T,) trajectories counted, n_pd (T,) of them with positive-definite P (nll terms)."""
+    products (utils.py:41-64), n_ok (T,) trajectories counted, n_pd (T,) of them with positive-definite P (nll terms),
+    n_all (T,) trajectories this rank ran (so that what was left out is known after the reduction)."""
     lib = _lib.load()
     W = lib.ssmq_error_sums_width(D)
     if W < 0:
@@ -41,7 +190,7 @@ def device_error_sums(D, B, ld, T, d_x, d_fm, d_fP, d_status=None):
                                        ps), 'ssmq_error_sums_dev')
     return dict(se=sums[:, :D].copy(), rmse=sums[:, D].copy(), nll=sums[:, D + 1].copy(),
                 mse=sums[:, D + 2:D + 2 + D * D].reshape(T, D, D).copy(), n_ok=sums[:, D + 2 + D * D].copy(),
-                n_pd=sums[:, D + 3 + D * D].copy())
+                n_pd=sums[:, D + 3 + D * D].copy(), n_all=np.full(T, float(B)))
 
 
 def device_lcr_sums(D, B, ld, T, d_x, d_fm, d_fP, mse_global, d_status=None, reg=1e-6):
@@ -70,28 +219,37 @@ def _unpack(flat, sums, keys):
     return out
 
 
-def allreduce_sums(sums, dist=None, device=None):
-    """Sum a dict of arrays over all ranks with ONE all-reduce of the packed buffer."""
+def allreduce_sums(sums, comm=None):
+    """Sum a dict of arrays over all ranks with ONE all-reduce of the packed buffer.  comm: RcclComm / TorchComm /
+    an initialised torch.distributed module / None (single process)."""
+    comm = _as_comm(comm)
     keys = sorted(sums)
-    flat = _pack(sums, keys)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        import torch
-        if device is None:
-            device = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-        t = torch.from_numpy(flat.copy()).to(device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        flat = t.cpu().numpy()
-    return _unpack(flat, sums, keys)
+    return _unpack(comm.allreduce_sum(_pack(sums, keys)), sums, keys)
 
 
-def finalize(total):
-    """Global averages from all-reduced phase-1 sums: rmse_avg (T,), nll_avg (T,), mse (T, D, D), rmse_total (),
-    count () trajectories aggregated."""
+def finalize(total, strict=False):
+    """Global averages from all-reduced phase-1 sums: rmse_avg (T,), nll_avg (T,), mse (T, D, D), rmse_total (), count ()
+    trajectories aggregated, and what was LEFT OUT of them: excluded_failed (T,) trajectories whose filter had failed
+    (lost positive definiteness: the reference raises LinAlgError there and has no result for the run at all),
+    excluded_not_pd (T,) finished trajectories whose filtered covariance at that step is not positive definite (no NLL
+    term).  The reference averages over all runs (utils.py:123-148 via research/tpq/tpq_base.py:154-172), so an average
+    taken over fewer runs is not the same statistic: with strict=True the averages of a step with exclusions are NaN."""
     n = np.maximum(total['n_ok'], 1.0)
     T = total['rmse'].shape[0]
-    return dict(rmse_avg=total['rmse'] / n, nll_avg=total['nll'] / np.maximum(total['n_pd'], 1.0),
-                mse=total['mse'] / n[:, None, None], rmse_total=float(np.sqrt(total['se'].sum() / max(total['n_ok'].sum(), 1.0))),
-                count=float(total['n_ok'].max()) if T else 0.0)
+    n_all = total.get('n_all', total['n_ok'])
+    out = dict(rmse_avg=total['rmse'] / n, nll_avg=total['nll'] / np.maximum(total['n_pd'], 1.0),
+               mse=total['mse'] / n[:, None, None],
+               rmse_total=float(np.sqrt(total['se'].sum() / max(total['n_ok'].sum(), 1.0))),
+               count=float(total['n_ok'].max()) if T else 0.0,
+               excluded_failed=n_all - total['n_ok'], excluded_not_pd=total['n_ok'] - total['n_pd'])
+    if strict:
+        bad = out['excluded_failed'] > 0
+        out['rmse_avg'] = np.where(bad, np.nan, out['rmse_avg'])
+        out['mse'] = np.where(bad[:, None, None], np.nan, out['mse'])
+        out['nll_avg'] = np.where(bad | (out['excluded_not_pd'] > 0), np.nan, out['nll_avg'])
+        if bad.any():
+            out['rmse_total'] = float('nan')
+    return out
 
 
 def finalize_lcr(total):

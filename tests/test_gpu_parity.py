@@ -8,6 +8,7 @@ reproducible only to cond(K) eps / cond(K)^2 eps and are checked
 All tests need a real MI355X.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -1451,6 +1452,25 @@ def test_launch_loop_graph_follows_weight_updates(amd, golden, monkeypatch):
     alg.tf_dyn.Wc = fresh.tf_dyn.Wc * 0 + make().tf_dyn.Wc
     fm4, _ = alg.forward_pass_batch(y, raise_on_failure=False)
     assert np.array_equal(fm4, fm1, equal_nan=True)
+
+
+def test_rccl_communicator_single_rank(amd, tmp_path):
+    """The collective of the path through the C ABI (ssmq_comm_* / ssmq_allreduce_*: RCCL opened by libssmq at run
+    time, no PyTorch), with a real RCCL communicator of one rank: rendezvous file, sum / max, barrier, teardown."""
+    from ssmtoybox_amd import mcshard
+    idf = str(tmp_path / 'rccl.id')
+    comm = mcshard.RcclComm(0, 1, id_file=idf, force=True)
+    assert os.path.getsize(idf) == 128
+    v = np.arange(1000, dtype=float) * 0.5 - 3.0
+    assert np.array_equal(comm.allreduce_sum(v), v) and np.array_equal(comm.allreduce_max(v), v)
+    sums = dict(a=np.ones((3, 2)), b=np.arange(4.0))
+    tot = mcshard.allreduce_sums(sums, comm)
+    assert np.array_equal(tot['a'], sums['a']) and np.array_equal(tot['b'], sums['b'])
+    comm.barrier()
+    comm.close()
+    assert not os.path.exists(idf)
+    with pytest.raises(Exception):
+        mcshard.RcclComm(1, 1)            # rank out of range: refused by ssmq_comm_init
 
 
 # ---------------------------------------------------------------------------------------------------------------
