@@ -223,6 +223,17 @@ static int upload_consts(ssmq_transform *h) {
         if (!h->d_wc_pad) SSMQ_HIP(hipMalloc(&h->d_wc_pad, sizeof(double) * np * np));
         h->np_pad = np;
         SSMQ_HIP(hipMemcpyAsync(h->d_wc_pad, wpad.data(), sizeof(double) * np * np, hipMemcpyHostToDevice, stream()));
+        // X = [Wc | Wcc'] for the route whose GEMM epilogue forms both covariances (row k: row k of Wc, then
+        // Wcc[0..D)[k]): T = FX Wc exactly as the other kernels form it, also for a Wc that is not symmetric to the last bit
+        const int nx = np + 16;
+        std::vector<double> xpad((size_t)np * nx, 0.0);
+        for (int k = 0; k < N; ++k) {
+            for (int j = 0; j < N; ++j) xpad[(size_t)k * nx + j] = h->Wc[k * N + j];
+            for (int d = 0; d < D && d < 16; ++d) xpad[(size_t)k * nx + np + d] = h->Wcc[d * N + k];
+        }
+        if (!h->d_wcx_pad) SSMQ_HIP(hipMalloc(&h->d_wcx_pad, sizeof(double) * np * nx));
+        SSMQ_HIP(hipMemcpyAsync(h->d_wcx_pad, xpad.data(), sizeof(double) * np * nx, hipMemcpyHostToDevice, stream()));
+        SSMQ_HIP(hipStreamSynchronize(stream()));   // xpad goes out of scope
     }
     SSMQ_HIP(hipMemcpyAsync(h->d_small, s.data(), sizeof(double) * cs.total, hipMemcpyHostToDevice, stream()));
     SSMQ_HIP(hipMemcpyAsync(h->d_wide, w.data(), sizeof(double) * cw.total, hipMemcpyHostToDevice, stream()));
@@ -284,8 +295,10 @@ static int check_integrand(const ssmq_transform *h, const ssmq_integrand *f, FIn
 constexpr int64_t kGemmMinRows = 256;
 static void *g_gemm_ws = nullptr;
 static size_t g_gemm_ws_bytes = 0;
-static int gemm_scratch(int64_t M, int NP, int64_t B, int D, double **fx, double **tt, double **chol) {
-    const size_t n_fx = (size_t)M * NP, need = sizeof(double) * (2 * n_fx + (size_t)B * D * D);
+static int gemm_scratch(int64_t M, int NP, int64_t B, int D, double **fx, double **tt, double **chol, bool fused = false) {
+    // three-pass route: FX | T | factors; two-pass route: FX | transformed means as rows | factors
+    const size_t n_fx = (size_t)M * NP, n_t = fused ? (size_t)M : n_fx,
+                 need = sizeof(double) * (n_fx + n_t + (size_t)B * D * D);
     if (g_gemm_ws_bytes < need) {
         if (g_gemm_ws) {
             SSMQ_HIP(hipStreamSynchronize(stream()));
@@ -298,7 +311,7 @@ static int gemm_scratch(int64_t M, int NP, int64_t B, int D, double **fx, double
     }
     *fx = (double *)g_gemm_ws;
     *tt = *fx + n_fx;
-    *chol = *tt + n_fx;
+    *chol = *tt + n_t;
     return SSMQ_OK;
 }
 static void drop_gemm_scratch() {
@@ -362,6 +375,19 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         const int NP = h->np_pad;
         const int64_t M = B * h->E;
         double *fx, *tt, *chol;
+        if (h->tp_nu <= 0.0 && h->d_wcx_pad && fxwc_cov_supported(h->E) && h->D <= 16 && !getenv("SSMQ_NO_FUSED_COV")) {
+            // two passes: (1) one wave per trajectory: factor, points, integrand values, mean; (2) the GEMM whose
+            // epilogue forms the covariance and the cross-covariance from its accumulators
+            if ((rc = gemm_scratch(M, NP, B, h->D, &fx, &tt, &chol, true))) return rc;
+            double *mrow = tt;
+            WideArgs e = a;
+            e.fx_ld = NP; e.fx_out = fx; e.mrow_out = mrow; e.chol_out = chol;
+            if ((rc = hip_fail(launch_eval_wave(e, B, stream()), "k_eval_wave"))) return rc;
+            const WideLayout wl = wide_layout(h->D, h->E, h->N, h->form);
+            return launch_fxwc_cov_mfma(NP, fx, h->d_wcx_pad, M, NP, mrow, chol, h->d_wide + wl.emv,
+                                        h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, d_cov_add, cov_scale, ccov_scale, h->E,
+                                        h->D, d_cov_f, d_cov_fx, ld, 1, 1, stream());
+        }
         if ((rc = gemm_scratch(M, NP, B, h->D, &fx, &tt, &chol))) return rc;
         WideArgs e = a;
         e.mode = SSMQ_WIDE_EVAL; e.fx_ld = NP; e.fx_out = fx; e.chol_out = chol;
@@ -577,6 +603,7 @@ void ssmq_transform_destroy(ssmq_transform *h) {
     if (h->d_small) hipFree(h->d_small);
     if (h->d_wide) hipFree(h->d_wide);
     if (h->d_wc_pad) hipFree(h->d_wc_pad);
+    if (h->d_wcx_pad) hipFree(h->d_wcx_pad);
     delete h;
 }
 
@@ -740,14 +767,26 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
         // matrix-core route: rows re-pitched to the padded column count, T = FX Wc for the whole batch, then the rest
         const int NP = h->np_pad;
         const int64_t M = B * E;
-        if ((rc = fxp.alloc(sizeof(double) * M * NP)) || (rc = ttp.alloc(sizeof(double) * M * NP))) return rc;
+        if ((rc = fxp.alloc(sizeof(double) * M * NP))) return rc;
         SSMQ_HIP(hipMemsetAsync(fxp.p, 0, sizeof(double) * M * NP, s));
         SSMQ_HIP(hipMemcpy2DAsync(fxp.p, sizeof(double) * NP, dfx.p, sizeof(double) * N, sizeof(double) * N, M,
                                   hipMemcpyDeviceToDevice, s));
-        if ((rc = launch_fxwc_mfma(NP, fxp.d(), h->d_wc_pad, ttp.d(), M, NP, NP, s))) return rc;
-        a.fx_ld = NP; a.fx_in = fxp.d(); a.t_in = ttp.d();
+        if (h->tp_nu <= 0.0 && h->d_wcx_pad && fxwc_cov_supported(E) && D <= 16 && !getenv("SSMQ_NO_FUSED_COV")) {
+            // means of the supplied values, then the GEMM whose epilogue forms both covariances (no T in memory)
+            const WideLayout wl = wide_layout(D, E, N, h->form);
+            if ((rc = launch_row_means(fxp.d(), h->d_wide + wl.wm, M, NP, N, omf.d(), s))) return rc;
+            if ((rc = launch_fxwc_cov_mfma(NP, fxp.d(), h->d_wcx_pad, M, NP, omf.d(), dl.d(), h->d_wide + wl.emv,
+                                           h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, nullptr, 1.0, 1.0, E, D, ocf.d(),
+                                           ocfx.d(), 1, (int64_t)E * E, (int64_t)E * D, s)))
+                return rc;
+            a.mode = -1;   // done
+        } else {
+            if ((rc = ttp.alloc(sizeof(double) * M * NP))) return rc;
+            if ((rc = launch_fxwc_mfma(NP, fxp.d(), h->d_wc_pad, ttp.d(), M, NP, NP, s))) return rc;
+            a.fx_ld = NP; a.fx_in = fxp.d(); a.t_in = ttp.d();
+        }
     }
-    if ((rc = hip_fail(launch_apply_wide(a, B, s), "k_apply_wide(fx)"))) return rc;
+    if (a.mode != -1 && (rc = hip_fail(launch_apply_wide(a, B, s), "k_apply_wide(fx)"))) return rc;
     SSMQ_HIP(hipMemcpyAsync(mean_f, omf.p, sizeof(double) * B * E, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipMemcpyAsync(cov_f, ocf.p, sizeof(double) * B * E * E, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipMemcpyAsync(cov_fx, ocfx.p, sizeof(double) * B * E * D, hipMemcpyDeviceToHost, s));

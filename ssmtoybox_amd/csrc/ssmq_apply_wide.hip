@@ -77,8 +77,9 @@ __global__ __launch_bounds__(BLOCK) void k_apply_wide(const WideArgs a) {
     double *sm = sL + D * D;        // D
     double *sx = sm + D;            // D*N   sigma points (not in the FX pass of the BQ form)
     double *sfx = sx + (need_x ? D * N : 0);   // E*N   integrand values (centred in place for the SIGMA form)
-    double *sT = sfx + E * N;       // E*N   fx Wc  (then fx iK for the TP model variance); from here on: not in EVAL / POINTS
-    double *smf = sT + E * N;       // E
+    const bool need_T = a.mode == SSMQ_WIDE_FULL || a.mode == SSMQ_WIDE_FX;
+    double *sT = sfx + E * N;       // E*N   fx Wc  (then fx iK for the TP model variance); FULL / FX passes only
+    double *smf = sT + (need_T ? E * N : 0);   // E; from here on: not in EVAL / POINTS
     double *sS = smf + E;           // E*E   TP quadratic form
     double *sC = sS + E * E;        // E*E   fx Wc fx'
     double *sg = sC + E * E;        // E*D
@@ -279,6 +280,120 @@ __global__ __launch_bounds__(BLOCK) void k_apply_wide(const WideArgs a) {
 #undef OUT_ADDR
 }
 
+// ---- evaluation pass of the two-pass matrix-core route: ONE WAVE per trajectory -------------------------------------------
+// Cholesky factor, sigma points, integrand values (written as rows b E + e of the batch matrix FX, zero-padded to the
+// GEMM's column count), transformed mean.  Everything the covariances need beyond that happens in the GEMM's epilogue
+// (ssmq_gemm_mfma.hip).  No workgroup barrier anywhere: the waves of a block are independent trajectories, the factor
+// lives in a 2 KB LDS slice of the wave, sigma points and integrand values never touch LDS (lane n owns point n), so a
+// CU keeps 8+ trajectories in flight instead of the 3 that the LDS image of k_apply_wide allows - that kernel spent
+// its time waiting (10 us per trajectory behind ~35 barriers and serial LDS / L2 round trips, 277 us for B = 1e4).
+constexpr int kEvalWaves = 4;
+__global__ __launch_bounds__(64 * kEvalWaves) void k_eval_wave(const WideArgs a, int64_t B) {
+    __shared__ double s_all[kEvalWaves][SSMQ_MAX_DIM * SSMQ_MAX_DIM + SSMQ_MAX_DIM];
+    const int D = a.D, E = a.E, N = a.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * kEvalWaves + wave;
+    if (b >= B) return;                         // whole waves leave
+    double *sL = s_all[wave], *sm = sL + SSMQ_MAX_DIM * SSMQ_MAX_DIM;
+    const double *c = a.consts + b * a.consts_stride;
+    const WideLayout cl = wide_layout(D, E, N, a.form);
+    const double nan = __builtin_nan("");
+    // wave-scope ordering of the LDS slice: LDS instructions of one wave execute in order, the fence keeps the compiler
+    // from moving accesses across it
+#define SSMQ_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    for (int d = lane; d < D; d += 64) sm[d] = a.mean[d * a.es_in + b * a.bs_mean];
+    for (int i = lane; i < D * D; i += 64) {
+        const int r = i / D, cc = i % D;
+        sL[i] = (cc <= r) ? a.cov[(int64_t)i * a.es_in + b * a.bs_cov] : 0.0;
+    }
+    SSMQ_WAVE_SYNC();
+    // right-looking Cholesky, the subtraction order of the left-looking dot products (as k_apply_wide: same factor)
+    bool ok = true;
+    for (int j = 0; j < D; ++j) {
+        const double ajj = sL[j * D + j];
+        ok = ok && (ajj > 0.0);
+        const double ljj = sqrt(ajj), r = 1.0 / ljj;
+        SSMQ_WAVE_SYNC();
+        if (lane == 0) sL[j * D + j] = ljj;
+        for (int i = j + 1 + lane; i < D; i += 64) sL[i * D + j] *= r;
+        SSMQ_WAVE_SYNC();
+        const int m = D - j - 1;
+        for (int idx = lane; idx < m * m; idx += 64) {
+            const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+            if (k <= i) sL[i * D + k] -= sL[i * D + j] * sL[k * D + j];
+        }
+        SSMQ_WAVE_SYNC();
+    }
+    if (lane == 0 && a.status) a.status[b] = ok ? 0 : 1;
+    for (int i = lane; i < D * D; i += 64) a.chol_out[b * D * D + i] = ok ? sL[i] : nan;
+    const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
+    const int64_t fl = a.fx_ld ? a.fx_ld : N;
+    double *rows = a.fx_out + b * E * fl;
+    double macc[SSMQ_MAX_DIM];
+#pragma unroll
+    for (int e = 0; e < SSMQ_MAX_DIM; ++e) macc[e] = 0.0;
+    for (int n0 = 0; n0 < fl; n0 += 64) {
+        const int n = n0 + lane;
+        double o[SSMQ_MAX_DIM];
+#pragma unroll
+        for (int e = 0; e < SSMQ_MAX_DIM; ++e) o[e] = 0.0;
+        if (n < N) {
+            double xin[SSMQ_MAX_DIM], x[SSMQ_MAX_DIM];
+#pragma unroll
+            for (int k = 0; k < SSMQ_MAX_DIM; ++k) xin[k] = k < D ? c[cl.xiT + n * D + k] : 0.0;
+#pragma unroll
+            for (int d = 0; d < SSMQ_MAX_DIM; ++d) {
+                double s = 0.0;
+                if (d < D) {
+                    s = sm[d];
+#pragma unroll
+                    for (int k = 0; k < SSMQ_MAX_DIM; ++k)
+                        if (k <= d) s += sL[d * D + k] * xin[k];
+                }
+                x[d] = s;
+            }
+            double xs[kMaxIntegrandIn];
+#pragma unroll
+            for (int k = 0; k < kMaxIntegrandIn; ++k) {
+                double v = x[k < SSMQ_MAX_DIM ? k : 0];
+                if (a.fp.n_idx > 0) {              // state-index selection (MeasurementModel.state_index)
+                    const int src = k < a.fp.n_idx ? a.fp.idx[k] : 0;
+                    v = x[0];
+#pragma unroll
+                    for (int q = 1; q < SSMQ_MAX_DIM; ++q) v = (src == q) ? x[q] : v;
+                }
+                xs[k] = v;
+            }
+            eval_integrand(a.fid, xs, t, a.fp, o);
+            const double w = c[cl.wm + n];
+#pragma unroll
+            for (int e = 0; e < SSMQ_MAX_DIM; ++e) macc[e] += o[e] * w;
+        }
+        if (n < fl) {
+#pragma unroll
+            for (int e = 0; e < SSMQ_MAX_DIM; ++e)
+                if (e < E) rows[(int64_t)e * fl + n] = n < N ? (ok ? o[e] : nan) : 0.0;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < SSMQ_MAX_DIM; ++e) {
+        if (e < E) {
+            const double s = wave_sum(macc[e]);
+            if (lane == 0) {
+                a.mean_f[(int64_t)e * a.es_out + b * a.bs_mf] = ok ? s : nan;
+                a.mrow_out[b * E + e] = ok ? s : nan;
+            }
+        }
+    }
+#undef SSMQ_WAVE_SYNC
+}
+
+hipError_t launch_eval_wave(const WideArgs &a, int64_t B, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_wave, dim3((unsigned)((B + kEvalWaves - 1) / kEvalWaves)), dim3(64 * kEvalWaves), 0, s, a, B);
+    return hipGetLastError();
+}
+
 size_t wide_lds_bytes(int D, int E, int N) {
     return sizeof(double) * (size_t)(D * D + D + D * N + 2 * E * N + E + 2 * E * E + E * D);
 }
@@ -288,7 +403,8 @@ static size_t wide_lds_bytes_for(const WideArgs &a) {
     const size_t D = a.D, E = a.E, N = a.N;
     const bool need_x = a.mode != SSMQ_WIDE_FX || a.form == SSMQ_FORM_SIGMA;
     size_t n = D * D + D + (need_x ? D * N : 0) + E * N;
-    if (a.mode != SSMQ_WIDE_EVAL && a.mode != SSMQ_WIDE_POINTS) n += E * N + E + 2 * E * E + E * D;
+    if (a.mode == SSMQ_WIDE_FULL || a.mode == SSMQ_WIDE_FX) n += E * N;
+    if (a.mode != SSMQ_WIDE_EVAL && a.mode != SSMQ_WIDE_POINTS) n += E + 2 * E * E + E * D;
     return sizeof(double) * n;
 }
 

@@ -17,6 +17,8 @@ struct ssmq_transform {
     // matrix-core route for large point sets (ssmq_gemm_mfma.hip): Wc zero-padded to np_pad x np_pad, or null
     double *d_wc_pad = nullptr;
     int np_pad = 0;
+    // ... and [Wc | Wcc'] as np_pad x (np_pad + 16) for the route whose GEMM epilogue forms both covariances, or null
+    double *d_wcx_pad = nullptr;
     uint32_t generation = 0;   // bumped by every upload of constants (create / update)
 };
 
@@ -47,6 +49,13 @@ const SmallEntry *find_small(int fid, int D, int E, int N, int form, int tp, int
 // batch GEMM fx Wc on the matrix cores (ssmq_gemm_mfma.hip)
 int gemm_mfma_padded(int N);
 int launch_fxwc_mfma(int NP, const double *A, const double *Bm, double *T, int64_t M, int lda, int ldt, hipStream_t s);
+// ... with the covariance of every trajectory formed in the epilogue (no T in memory)
+bool fxwc_cov_supported(int E);
+int launch_fxwc_cov_mfma(int NP, const double *A, const double *X, int64_t M, int lda, const double *mean_rows,
+                         const double *chol, const double *emv, int emv_broadcast, const double *cov_add,
+                         double cov_scale, double ccov_scale, int E, int D, double *cov_f, double *cov_fx, int64_t es,
+                         int64_t bs, int64_t bs_fx, hipStream_t s);
+int launch_row_means(const double *A, const double *wm, int64_t M, int lda, int N, double *mean_rows, hipStream_t s);
 
 // measurement update (ssmq_filter.hip)
 int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,

@@ -50,10 +50,13 @@ struct WideArgs {
     int64_t fx_ld;
     double *fx_out;
     const double *t_in;
+    double *mrow_out;       // k_eval_wave: transformed means as rows b E + e, for the GEMM epilogue
     FPar fp;
 };
 
 size_t wide_lds_bytes(int D, int E, int N);
 hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s);
+// evaluation pass of the two-pass matrix-core route, one wave per trajectory (fx_out, chol_out, mean_f, mrow_out, status)
+hipError_t launch_eval_wave(const WideArgs &a, int64_t B, hipStream_t s);
 
 }  // namespace ssmq

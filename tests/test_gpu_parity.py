@@ -1106,6 +1106,75 @@ def test_matrix_core_route_exact_on_integers(amd, monkeypatch, N, E, B):
     assert all(np.array_equal(a, b) for a, b in zip(got, ref))
 
 
+@pytest.mark.parametrize('case', ['reentry1d_gh5', 'range_gh5', 'cv_gh4', 'radar_gh4', 'ctrs_gh2', 'smooth10_fs5'])
+def test_two_pass_matrix_core_route(amd, monkeypatch, case):
+    """Large point sets with a device integrand take two passes: k_eval_wave (one wave per trajectory: factor, points,
+    integrand values, mean) and k_fxwc_cov_mfma, whose epilogue forms covariance and cross-covariance from the
+    accumulators (ssmq_gemm_mfma.hip).  Checked against the three-pass route (values and T through memory,
+    SSMQ_NO_FUSED_COV=1), the generic kernel (SSMQ_NO_MFMA=1) and the oracle, for every output dimension pattern the
+    tile / trajectory bookkeeping has (E = 1, 2, 3, 4, 5, 10), ragged batches, a weight matrix that is not symmetric,
+    additive and scaled covariances, and a batch item that is not positive definite."""
+    from ssmtoybox_amd import ssmod as sm
+    D, E, model, f, fid, p, sidx, pstr, ppar, N = {
+        'reentry1d_gh5': (3, 3, sm.ReentryVehicle1DTransition, 'dyn_eval', orc.F_REENTRY1D_DYN, (0.1,), None, 'gh', {'degree': 5}, 125),
+        'range_gh5': (3, 1, lambda: sm.RangeMeasurement(sm.GaussRV(1), 3), 'meas_eval', orc.F_RANGE_MEAS, (), None, 'gh', {'degree': 5}, 125),
+        'cv_gh4': (4, 4, lambda: sm.ConstantVelocity(sm.GaussRV(4), sm.GaussRV(2), dt=0.5), 'dyn_eval', orc.F_CV_DYN, (0.5,), None, 'gh', {'degree': 4}, 256),
+        'radar_gh4': (4, 2, lambda: sm.Radar2DMeasurement(sm.GaussRV(2), 4), 'meas_eval', orc.F_RADAR2D_MEAS, (0.0, 0.0), None, 'gh', {'degree': 4}, 256),
+        'ctrs_gh2': (7, 5, lambda: sm.ConstantTurnRateSpeed(sm.GaussRV(5), sm.GaussRV(2)), 'dyn_eval', orc.F_CTRS_DYN, (0.05,), None, 'gh', {'degree': 2}, 128),
+        'smooth10_fs5': (10, 10, sm.Smooth10DTransition, 'dyn_eval', orc.F_SMOOTH10D_DYN, (), None, 'fs', {'degree': 5}, 201),
+    }[case]
+    mdl = model()
+    fn = getattr(mdl, f)
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    tf = amd.GaussianProcessTransform(D, E, gp_par(D, 2.0), 'rbf', pstr, ppar)
+    pts = tf.model.points
+    assert pts.shape == (D, N)
+    # injected weights of moderate size (a Gaussian-process Wc at N = 256 is ill-conditioned; this test is about the
+    # arithmetic of the route, and a route must not rely on the symmetry of Wc)
+    wm = rng.standard_normal(N) / N
+    Wc = rng.standard_normal((N, N)) / N
+    Wc = 0.5 * (Wc + Wc.T) + 1e-3 * rng.standard_normal((N, N)) / N
+    Wcc = rng.standard_normal((D, N)) / N
+    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = wm, Wc, Wcc, 0.37
+    w = dict(wm=wm, Wc=Wc, Wcc=Wcc, model_var=0.37)
+    for B in (300, 1001):
+        base = np.array([90.0, 6.0, 1.7]) if D == 3 else (np.array([20.0, 1.0, 30.0, -1.0]) if D == 4 else np.zeros(D))
+        if D == 7:
+            base = np.array([1.0, 2.0, 5.0, 0.3, 0.2, 0.0, 0.0])
+        means = base + 0.3 * rng.standard_normal((B, D))
+        a = rng.standard_normal((B, D, D)) / np.sqrt(D)
+        covs = 0.05 * (np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(D))
+        covs[B // 2] = -np.eye(D)
+        monkeypatch.delenv('SSMQ_NO_FUSED_COV', raising=False)
+        monkeypatch.delenv('SSMQ_NO_MFMA', raising=False)
+        assert tf.kernel_name(fn) == 'k_apply_wide'
+        mf, cf, cfx, st = tf.apply_batch(fn, means, covs, 2.0, return_status=True)
+        monkeypatch.setenv('SSMQ_NO_FUSED_COV', '1')
+        mf3, cf3, cfx3, st3 = tf.apply_batch(fn, means, covs, 2.0, return_status=True)
+        monkeypatch.delenv('SSMQ_NO_FUSED_COV')
+        bad = B // 2
+        assert st[bad] != 0 and not np.delete(st, bad).any() and np.array_equal(st, st3)
+        assert np.all(np.isnan(mf[bad])) and np.all(np.isnan(cf[bad])) and np.all(np.isnan(cfx[bad]))
+        ok = np.arange(B) != bad
+        assert np.all(np.isfinite(cf[ok])) and np.all(np.isfinite(cfx[ok]))
+        assert np.array_equal(cf[ok], cf[ok].transpose(0, 2, 1))                      # mirrored lower triangle
+        sc = np.abs(cf3[ok]).max()
+        assert within(np.abs(mf[ok] - mf3[ok]).max() / np.abs(mf3[ok]).max(), 1e-13, case + ' two-pass vs three-pass mean')
+        assert within(np.abs(cf[ok] - cf3[ok]).max() / sc, 1e-13, case + ' two-pass vs three-pass cov')
+        assert within(np.abs(cfx[ok] - cfx3[ok]).max() / np.abs(cfx3[ok]).max(), 1e-13, case + ' two-pass vs three-pass ccov')
+        for i in (0, 1, B // 2 + 1, B - 1):
+            ref = orc.apply_bq(fid, means[i], covs[i], 2.0, pts, w, p, sidx)
+            # the oracle forms the full product; the kernels mirror the lower triangle of (fx Wc) fx'
+            rc = np.tril(ref[1]) + np.tril(ref[1], -1).T
+            assert_moments_close((mf[i], cf[i], cfx[i]), (ref[0], rc, ref[2]), covs[i], what=(case, B, i))
+    monkeypatch.setenv('SSMQ_NO_MFMA', '1')
+    tfg = amd.GaussianProcessTransform(D, E, gp_par(D, 2.0), 'rbf', pstr, ppar)
+    tfg.wm, tfg.Wc, tfg.Wcc, tfg.model.model_var = wm, Wc, Wcc, 0.37
+    mg, cg, xg = tfg.apply_batch(fn, means[:64], covs[:64], 2.0)
+    monkeypatch.delenv('SSMQ_NO_MFMA')
+    assert np.abs(cg - cf[:64]).max() / sc < 1e-13 and np.abs(xg - cfx[:64]).max() / np.abs(cfx3[ok]).max() < 1e-13
+
+
 def test_extreme_covariance_scales(amd):
     """The register kernels take square roots and reciprocals of the Cholesky pivots with a one-round refinement of
     v_rsq_f64 / v_rcp_f64 (csrc/ssmq_device.h) instead of the compiler's range-rescaled sequences: covariances scaled by

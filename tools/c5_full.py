@@ -11,4 +11,4 @@ from bench import C5GemmBench  # noqa: E402
 amd.set_device(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 c5 = C5GemmBench(amd, 64, seed=5)
-print('B=%d whole transform %.3f ms' % (B, c5.measure_full_transform(B)))
+print('B=%d whole transform %.3f ms' % (B, c5.measure_full_transform(B, False)[0]))
