@@ -135,6 +135,23 @@ int ssmq_weights_gp(int D, int N, const double *xi, const double *par, int P, do
                     double *wm, double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R,
                     double *model_var, double *integral_var, int32_t *status);
 /*
+ * The kernel-level methods of the reference as entry points of their own (the weights entry points build K, its inverse
+ * and the expectations in one kernel and need none of these):
+ *   ssmq_rbf_eval      RBFGauss.eval (bq/bqkern.py:329-343, utils.maha utils.py:385-409): K [P][N1][N2] between the
+ *                      point sets x1 [D*N1], x2 [D*N2] (NULL: x1); scaling = use alpha; diag: N1 values k(x1_i, x2_i)
+ *                      through the difference form of the reference's diag branch.
+ *   ssmq_rbf_factor    Kernel.eval_chol (bq/bqkern.py:122-142): chol [P][N][N], lower factor of K + jitter I, and / or
+ *                      Kernel.eval_inv_dot / _cho_inv (:38-64, 96-120): iK [P][N][N] = sym((K + jitter I)^-1 rhs), rhs [N][N]
+ *                      or NULL (= I; the reference symmetrises whatever it solved for, so a right-hand side is square);
+ *                      chol or iK may be NULL; status [P] / return value as ssmq_weights_gp.
+ *   ssmq_rbf_exp_kxkx  RBFGauss.exp_x_kxkx for two (possibly different) parameter rows (:366-415): Q [N][N].
+ */
+int ssmq_rbf_eval(int D, int N1, const double *x1, int N2, const double *x2, const double *par, int P, int scaling,
+                  int diag, double *K);
+int ssmq_rbf_factor(int D, int N, const double *x, const double *par, int P, int scaling, double jitter,
+                    const double *rhs, double *chol, double *iK, int32_t *status);
+int ssmq_rbf_exp_kxkx(int D, int N, const double *x, const double *par0, const double *par1, int scaling, double *Q);
+/*
  * Student-t process model: the same weights as ssmq_weights_gp (StudentTProcessModel inherits bq_weights,
  * bq/bqmod.py:1060-1130); model_var / integral_var are the GP values, which the t-process rescales with the integrand
  * values at transform time (bq/bqmod.py:1132-1190; tp_nu / tp_iK of ssmq_transform_create).

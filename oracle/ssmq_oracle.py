@@ -206,6 +206,33 @@ def rbf_eval(par, x1, x2=None, scaling=True):
     return np.exp(2 * np.log(alpha) - 0.5 * _pairwise_maha(a, b))
 
 
+def rbf_eval_diag(par, x1, x2, scaling=True):
+    """k(x1_i, x2_i) through the difference form of the `diag=True` branch.  bq/bqkern.py:338-341."""
+    alpha, sil = _split_par(par)
+    if not scaling:
+        alpha = 1.0
+    dx = sil[:, None] * x1 - sil[:, None] * x2
+    return np.exp(2 * np.log(alpha) - 0.5 * np.sum(dx * dx, axis=0))
+
+
+def rbf_chol(par, x, jitter=1e-8, scaling=True):
+    """Lower Cholesky factor of K + jitter I.  bq/bqkern.py:122-142."""
+    return np.linalg.cholesky(rbf_eval(par, x, scaling=scaling) + jitter * np.eye(x.shape[1]))
+
+
+def rbf_inv_dot(par, x, b, jitter=1e-8, scaling=True):
+    """sym((K + jitter I)^-1 b) for a square b: _cho_inv symmetrises whatever it solved for.  bq/bqkern.py:38-64, 96-120."""
+    ia = cho_solve(cho_factor(rbf_eval(par, x, scaling=scaling) + jitter * np.eye(x.shape[1])), b)
+    return 0.5 * (ia + ia.T)
+
+
+def gp_exp_model_variance(par, x, jitter=1e-8):
+    """GaussianProcessModel.exp_model_variance as a call: the inverse of the SCALED kernel matrix (eval_inv_dot's default)
+    with the unscaled Q.  bq/bqmod.py:525-528."""
+    iK = rbf_inv(par, x, jitter, scaling=True)
+    return rbf_kxx(par) * (1 - np.trace(rbf_Q(par, par, x).dot(iK)))
+
+
 def rbf_q(par, x, scaling=False):
     """Kernel mean q_n = alpha^2 det(Lam^-1 + I)^-1/2 exp(-x_n'(Lam+I)^-1 x_n / 2).  bq/bqkern.py:345-356."""
     alpha, sil = _split_par(par)

@@ -143,6 +143,12 @@ _PROTOTYPES = {
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p]),
     'ssmq_filter_kernel_name': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
                                                ctypes.POINTER(Integrand), ctypes.c_char_p, ctypes.c_int]),
+    'ssmq_rbf_eval': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, c_double_p,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p]),
+    'ssmq_rbf_factor': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_double, c_double_p, c_double_p, c_double_p, c_int32_p]),
+    'ssmq_rbf_exp_kxkx': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int,
+                                         c_double_p]),
     'ssmq_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'ssmq_comm_init': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     'ssmq_comm_rank': (ctypes.c_int, []),

@@ -68,14 +68,55 @@ class RBFGauss(Kernel):
     def _all(self, par, x):
         return device_gp_weights(x, np.atleast_2d(par)[:1], self.jitter)
 
+    @staticmethod
+    def _row(par):
+        return np.ascontiguousarray(np.atleast_2d(np.asarray(par, dtype=np.float64))[:1])
+
+    def eval(self, par, x1, x2=None, diag=False, scaling=True):
+        """Kernel matrix K[i, j] = alpha^2 exp(-maha(Lam^-1/2 x1_i, Lam^-1/2 x2_j) / 2) (bq/bqkern.py:329-343), computed
+        on the device with the reference's algebra (`ssmq_rbf_eval`)."""
+        lib = _lib.load()
+        par = self._row(par)
+        x1, p1 = _lib.as_c(x1)
+        if x2 is None:
+            x2, p2 = x1, p1
+        else:
+            x2, p2 = _lib.as_c(x2)
+        D, N1, N2 = x1.shape[0], x1.shape[1], x2.shape[1]
+        if diag:
+            assert x1.shape == x2.shape
+        K, pk = _lib.out_c((N1,) if diag else (N1, N2))
+        _lib.check(lib.ssmq_rbf_eval(D, N1, p1, N2, p2, _lib.as_c(par)[1], 1, int(bool(scaling)), int(bool(diag)), pk),
+                   'ssmq_rbf_eval')
+        return K
+
+    def _factor(self, par, x, scaling, want_chol, want_inv, rhs=None):
+        lib = _lib.load()
+        par = self._row(par)
+        x, px = _lib.as_c(x)
+        D, N = x.shape
+        L, pl = _lib.out_c((N, N)) if want_chol else (None, None)
+        iK, pi = _lib.out_c((N, N)) if want_inv else (None, None)
+        pb = None
+        if rhs is not None:
+            rhs, pb = _lib.as_c(rhs)
+            if rhs.shape != (N, N):
+                # the reference fails here too: _cho_inv symmetrises its result (bq/bqkern.py:63)
+                raise ValueError('eval_inv_dot: the right-hand side has to be (N, N), got {}'.format(rhs.shape))
+        rc = _lib.check(lib.ssmq_rbf_factor(D, N, px, _lib.as_c(par)[1], 1, int(bool(scaling)), float(self.jitter), pb, pl,
+                                            pi, None), 'ssmq_rbf_factor')
+        if rc > 0:
+            raise np.linalg.LinAlgError('Matrix is not positive definite')
+        return L, iK
+
+    def eval_chol(self, par, x, scaling=True):
+        """Lower Cholesky factor of K + jitter I (bq/bqkern.py:122-142)."""
+        return self._factor(par, x, scaling, True, False)[0]
+
     def eval_inv_dot(self, par, x, b=None, scaling=True):
-        """(K + jitter I)^-1 [b]  (bq/bqkern.py:96-120).  The device kernel forms the scaling=False inverse; with
-        scaling the inverse is divided by alpha^2 only approximately (jitter is not rescaled), so scaling=True is refused
-        rather than approximated."""
-        if scaling and float(np.atleast_2d(par)[0, 0]) != 1.0:
-            raise NotImplementedError('eval_inv_dot(scaling=True) with alpha != 1 is not on the device path')
-        iK = self._all(par, x)['iK'][0]
-        return iK if b is None else iK.dot(b)
+        """sym((K + jitter I)^-1 b) (bq/bqkern.py:96-120 with _cho_inv :38-64; b = None: the inverse itself).  The
+        reference symmetrises whatever it solved for, so a right-hand side has to be square there; the same here."""
+        return self._factor(par, x, scaling, False, True, b)[1]
 
     def exp_x_kx(self, par, x, scaling=False):
         """Kernel mean (bq/bqkern.py:345-356)."""
@@ -87,11 +128,14 @@ class RBFGauss(Kernel):
         return self._all(par, x)['R'][0]
 
     def exp_x_kxkx(self, par_0, par_1, x, scaling=False):
-        """bq/bqkern.py:366-415 for equal parameter rows (the only case on the filter path)."""
-        if not np.array_equal(np.atleast_2d(par_0), np.atleast_2d(par_1)):
-            raise NotImplementedError('exp_x_kxkx with two different parameter rows is not on the device path')
-        Q = self._all(par_0, x)['Q'][0]
-        return Q * float(np.atleast_2d(par_0)[0, 0]) ** 4 if scaling else Q
+        """E[k(x, x_i; theta_0) k(x, x_j; theta_1)] (bq/bqkern.py:366-415); the two parameter rows may differ."""
+        lib = _lib.load()
+        x, px = _lib.as_c(x)
+        D, N = x.shape
+        Q, pq = _lib.out_c((N, N))
+        _lib.check(lib.ssmq_rbf_exp_kxkx(D, N, px, _lib.as_c(self._row(par_0))[1], _lib.as_c(self._row(par_1))[1],
+                                         int(bool(scaling)), pq), 'ssmq_rbf_exp_kxkx')
+        return Q
 
     def exp_x_kxx(self, par):
         """bq/bqkern.py:417-419."""

@@ -102,12 +102,13 @@ class GaussianProcessModel(Model):
         return device_gp_weights(self.points, np.atleast_2d(pars), self.kernel.jitter)
 
     def exp_model_variance(self, par, *args):
-        """bq/bqmod.py:525-528.  The reference evaluates K with scaling here; alpha = 1 is the common case and the only
-        one on the device path."""
+        """alpha^2 (1 - tr(Q iK)) with iK the inverse of the SCALED kernel matrix (bq/bqmod.py:525-528: eval_inv_dot is
+        called with its default scaling=True there) and Q the unscaled expectation - both from the device, the trace of
+        their product on the host."""
         par = self.kernel.get_parameters(par)
-        if float(par[0, 0]) != 1.0:
-            raise NotImplementedError('exp_model_variance with alpha != 1 is not on the device path')
-        return float(device_gp_weights(self.points, par[:1], self.kernel.jitter)['model_var'][0])
+        iK = self.kernel.eval_inv_dot(par, self.points)
+        Q = self.kernel.exp_x_kxkx(par, par, self.points)
+        return float(self.kernel.exp_x_kxx(par) * (1 - np.trace(Q.dot(iK))))
 
     def integral_variance(self, par, *args):
         """bq/bqmod.py:530-535."""

@@ -11,6 +11,7 @@
 // sets (fully-symmetric degree 5 at D = 10: N = 201) factor in an L2-resident workspace with the same code.
 // The algebra follows the reference step by step (explicit inverse, symmetrisation, jitter placement) because the
 // results are only reproducible to cond(K) eps, not because it is the best-conditioned route.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include "ssmq_host.h"
@@ -645,7 +646,229 @@ int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double
     return SSMQ_OK;
 }
 
+// ---- the kernel-level methods of the reference as entry points of their own ---------------------------------------------
+// RBFGauss.eval (bq/bqkern.py:329-343 with utils.maha, utils.py:385-409), Kernel.eval_chol / eval_inv_dot / _cho_inv
+// (:38-64, 96-142) and RBFGauss.exp_x_kxkx for two different parameter rows (:366-415).  The weights kernel above needs
+// none of them separately (it builds K, its inverse and Q in one go); they exist so that callers of those methods - the
+// reference's tests, hyper-parameter studies - get device results too.
+
+// K[p][i][j] = exp(2 log(alpha) - maha(z1_i, z2_j) / 2), z = Lam^-1/2 x, maha as |a|^2 + |b|^2 - 2 a.b; diag: only
+// i == j through the difference form of the reference's `diag=True` branch.  One thread per entry.
+__global__ void k_rbf_eval(int D, int N1, int N2, const double *__restrict__ x1, const double *__restrict__ x2,
+                           const double *__restrict__ par, int scaling, int diag, double *__restrict__ K) {
+    const int p = blockIdx.y;
+    const double *pr = par + (int64_t)p * (1 + D);
+    const double la = scaling ? 2.0 * log(pr[0]) : 2.0 * log(1.0);
+    const int64_t total = diag ? N1 : (int64_t)N1 * N2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = diag ? (int)idx : (int)(idx / N2), j = diag ? (int)idx : (int)(idx % N2);
+        double na = 0.0, nb = 0.0, dot = 0.0, dd = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double sil = 1.0 / pr[1 + d];
+            const double a = sil * x1[d * N1 + i], b = sil * x2[d * N2 + j];
+            na += a * a;
+            nb += b * b;
+            dot += a * b;
+            dd += (a - b) * (a - b);
+        }
+        const double mh = diag ? dd : (na + nb) - 2.0 * dot;
+        K[(int64_t)p * total + idx] = exp(la - 0.5 * mh);
+    }
+}
+
+// X = (L L')^-1 Bm for the lower factor L (n x n) and a square right-hand side: thread per column, forward then backward
+// substitution (scipy.linalg.cho_solve)
+__device__ void chol_solve(const double *L, const double *Bm, double *X, int n) {
+    for (int c = threadIdx.x; c < n; c += kWgtBlock) {
+        for (int i = 0; i < n; ++i) {
+            double s = Bm[i * n + c];
+            for (int k = 0; k < i; ++k) s -= L[i * n + k] * X[k * n + c];
+            X[i * n + c] = s / L[i * n + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = X[i * n + c];
+            for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * X[k * n + c];
+            X[i * n + c] = s / L[i * n + i];
+        }
+    }
+    bsync();
+}
+
+// A <- K + jitter I (K as k_rbf_eval, scaling optional), factor, optional inverse / solve: one workgroup per parameter
+// row, global workspace (init-time sizes).  chol: lower factor with zeros above the diagonal (numpy.linalg.cholesky); iK
+// = sym(A^-1) (rhs null) or sym(A^-1 rhs) for a square rhs - the reference symmetrises whatever it solved for.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_rbf_factor(int D, int N, const double *__restrict__ x, const double *__restrict__ par,
+                                                       int scaling, double jitter, double *__restrict__ work, double *chol,
+                                                       double *iK, const double *__restrict__ rhs, int32_t *status) {
+    __shared__ int s_flag;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const double *pr = par + (int64_t)p * (1 + D);
+    const double la = scaling ? 2.0 * log(pr[0]) : 2.0 * log(1.0);
+    double *A = work + (int64_t)p * 2 * N * N, *X = A + (int64_t)N * N;
+    for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+        const int i = idx / N, j = idx % N;
+        double na = 0.0, nb = 0.0, dot = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double sil = 1.0 / pr[1 + d];
+            const double a = sil * x[d * N + i], b = sil * x[d * N + j];
+            na += a * a;
+            nb += b * b;
+            dot += a * b;
+        }
+        A[idx] = exp(la - 0.5 * ((na + nb) - 2.0 * dot)) + (i == j ? jitter : 0.0);
+    }
+    bsync();
+    const bool pd = chol_block(A, N, &s_flag);
+    if (tid == 0) status[p] = pd ? 0 : 1;
+    const double nan = __builtin_nan("");
+    if (chol)
+        for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+            const int i = idx / N, j = idx % N;
+            chol[(int64_t)p * N * N + idx] = pd ? (j <= i ? A[idx] : 0.0) : nan;
+        }
+    if (!iK) return;
+    if (!pd) {
+        for (int idx = tid; idx < N * N; idx += kWgtBlock) iK[(int64_t)p * N * N + idx] = nan;
+        return;
+    }
+    if (rhs) chol_solve(A, rhs, X, N);
+    else chol_inverse(A, X, N);
+    for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+        const int i = idx / N, j = idx % N;
+        iK[(int64_t)p * N * N + idx] = 0.5 * (X[i * N + j] + X[j * N + i]);
+    }
+}
+
+// Q[i][j] = det(R)^-1/2 exp(xi_i + xi'_j + maha(Lam0^-1 x_i, -Lam1^-1 x_j; R^-1) / 2), R = Lam0^-1 + Lam1^-1 + I,
+// xi = 2 log(alpha0) - |Lam0^-1/2 x_i|^2 / 2, xi' likewise with row 1 (all matrices diagonal)
+__global__ void k_rbf_kxkx(int D, int N, const double *__restrict__ x, const double *__restrict__ par0,
+                           const double *__restrict__ par1, int scaling, double *__restrict__ Q) {
+    const double la0 = scaling ? 2.0 * log(par0[0]) : 2.0 * log(1.0), la1 = scaling ? 2.0 * log(par1[0]) : 2.0 * log(1.0);
+    double det = 1.0;
+    for (int d = 0; d < D; ++d) {
+        const double s0 = 1.0 / par0[1 + d], s1 = 1.0 / par1[1 + d];
+        det *= (s0 * s0 + s1 * s1) + 1.0;
+    }
+    const double c = 1.0 / sqrt(det);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N * N; idx += gridDim.x * blockDim.x) {
+        const int i = idx / N, j = idx % N;
+        double n0 = 0.0, n1 = 0.0, m2i = 0.0, m2j = 0.0, mij = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double s0 = 1.0 / par0[1 + d], s1 = 1.0 / par1[1 + d];
+            const double il0 = s0 * s0, il1 = s1 * s1;
+            const double z0 = s0 * x[d * N + i], z1 = s1 * x[d * N + j];
+            n0 += z0 * z0;
+            n1 += z1 * z1;
+            const double v = 1.0 / ((il0 + il1) + 1.0);
+            const double yi = il0 * x[d * N + i], yj = -(il1 * x[d * N + j]);
+            m2i += (yi * v) * yi;
+            m2j += (yj * v) * yj;
+            mij += (yi * v) * yj;
+        }
+        const double mh = (m2i + m2j) - 2.0 * mij;
+        Q[idx] = c * exp(((la0 - 0.5 * n0) + (la1 - 0.5 * n1)) + 0.5 * mh);
+    }
+}
+
+static bool rbf_args_ok(int D, int N, const double *x, const double *par, int P) {
+    return D >= 1 && D <= SSMQ_MAX_DIM && N >= 1 && N <= SSMQ_MAX_PTS && P >= 1 && x && par;
+}
+
 }  // namespace ssmq
+
+extern "C" int ssmq_rbf_eval(int D, int N1, const double *x1, int N2, const double *x2, const double *par, int P,
+                             int scaling, int diag, double *K) {
+    using namespace ssmq;
+    if (!x2) { x2 = x1; N2 = N1; }
+    if (!rbf_args_ok(D, N1, x1, par, P) || N2 < 1 || N2 > SSMQ_MAX_PTS || !K || (diag && N1 != N2)) {
+        set_error("rbf_eval: bad argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = stream();
+    const size_t nout = (size_t)P * (diag ? (size_t)N1 : (size_t)N1 * N2);
+    DBuf d1, d2, dp, dk;
+    if ((rc = d1.alloc(sizeof(double) * D * N1)) || (rc = d2.alloc(sizeof(double) * D * N2)) ||
+        (rc = dp.alloc(sizeof(double) * P * (1 + D))) || (rc = dk.alloc(sizeof(double) * nout)))
+        return rc;
+    SSMQ_HIP(hipMemcpyAsync(d1.p, x1, sizeof(double) * D * N1, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(d2.p, x2, sizeof(double) * D * N2, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dp.p, par, sizeof(double) * P * (1 + D), hipMemcpyHostToDevice, s));
+    const size_t per = nout / P;
+    hipLaunchKernelGGL(k_rbf_eval, dim3((unsigned)std::min<size_t>((per + 255) / 256, 4096), P), dim3(256), 0, s, D, N1, N2, d1.d(),
+                       d2.d(), dp.d(), scaling, diag, dk.d());
+    if ((rc = hip_fail(hipGetLastError(), "k_rbf_eval"))) return rc;
+    SSMQ_HIP(hipMemcpyAsync(K, dk.p, sizeof(double) * nout, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    return SSMQ_OK;
+}
+
+extern "C" int ssmq_rbf_factor(int D, int N, const double *x, const double *par, int P, int scaling, double jitter,
+                               const double *rhs, double *chol, double *iK, int32_t *status) {
+    using namespace ssmq;
+    if (!rbf_args_ok(D, N, x, par, P) || (!chol && !iK)) {
+        set_error("rbf_factor: bad argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = stream();
+    const size_t nn = (size_t)N * N;
+    DBuf dx, dp, dw, dc, di, dst, db;
+    if ((rc = db.alloc(sizeof(double) * (rhs ? nn : 1)))) return rc;
+    if (rhs) SSMQ_HIP(hipMemcpyAsync(db.p, rhs, sizeof(double) * nn, hipMemcpyHostToDevice, s));
+    if ((rc = dx.alloc(sizeof(double) * D * N)) || (rc = dp.alloc(sizeof(double) * P * (1 + D))) ||
+        (rc = dw.alloc(sizeof(double) * 2 * nn * P)) || (rc = dc.alloc(sizeof(double) * (chol ? nn * P : 1))) ||
+        (rc = di.alloc(sizeof(double) * (iK ? nn * P : 1))) || (rc = dst.alloc(sizeof(int32_t) * P)))
+        return rc;
+    SSMQ_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * D * N, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dp.p, par, sizeof(double) * P * (1 + D), hipMemcpyHostToDevice, s));
+    if (N > 64)
+        hipLaunchKernelGGL(k_rbf_factor<1024>, dim3(P), dim3(1024), 0, s, D, N, dx.d(), dp.d(), scaling, jitter, dw.d(),
+                           chol ? dc.d() : nullptr, iK ? di.d() : nullptr, rhs ? db.d() : nullptr, (int32_t *)dst.p);
+    else
+        hipLaunchKernelGGL(k_rbf_factor<256>, dim3(P), dim3(256), 0, s, D, N, dx.d(), dp.d(), scaling, jitter, dw.d(),
+                           chol ? dc.d() : nullptr, iK ? di.d() : nullptr, rhs ? db.d() : nullptr, (int32_t *)dst.p);
+    if ((rc = hip_fail(hipGetLastError(), "k_rbf_factor"))) return rc;
+    if (chol) SSMQ_HIP(hipMemcpyAsync(chol, dc.p, sizeof(double) * nn * P, hipMemcpyDeviceToHost, s));
+    if (iK) SSMQ_HIP(hipMemcpyAsync(iK, di.p, sizeof(double) * nn * P, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> st(P);
+    SSMQ_HIP(hipMemcpyAsync(st.data(), dst.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    int first = 0;
+    for (int i = 0; i < P; ++i) {
+        if (status) status[i] = st[i];
+        if (st[i] && !first) first = i + 1;
+    }
+    return first;
+}
+
+extern "C" int ssmq_rbf_exp_kxkx(int D, int N, const double *x, const double *par0, const double *par1, int scaling,
+                                 double *Q) {
+    using namespace ssmq;
+    if (!rbf_args_ok(D, N, x, par0, 1) || !par1 || !Q) {
+        set_error("rbf_exp_kxkx: bad argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = stream();
+    DBuf dx, dp, dq;
+    if ((rc = dx.alloc(sizeof(double) * D * N)) || (rc = dp.alloc(sizeof(double) * 2 * (1 + D))) ||
+        (rc = dq.alloc(sizeof(double) * (size_t)N * N)))
+        return rc;
+    SSMQ_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * D * N, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dp.p, par0, sizeof(double) * (1 + D), hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dp.d() + 1 + D, par1, sizeof(double) * (1 + D), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_rbf_kxkx, dim3((unsigned)std::min<size_t>(((size_t)N * N + 255) / 256, 4096)), dim3(256), 0, s, D, N,
+                       dx.d(), dp.d(), dp.d() + 1 + D, scaling, dq.d());
+    if ((rc = hip_fail(hipGetLastError(), "k_rbf_kxkx"))) return rc;
+    SSMQ_HIP(hipMemcpyAsync(Q, dq.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    return SSMQ_OK;
+}
 
 extern "C" int ssmq_weights_gp(int D, int N, const double *xi, const double *par, int P, double jitter, double *wm,
                                double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R, double *model_var,

@@ -121,6 +121,27 @@ def g2_weights():
             out[t + '_iv'] = np.float64(m.integral_var)
             out[t + '_kbar'] = np.float64(k.exp_xy_kxy(par))
             out[t + '_cond'] = np.float64(np.linalg.cond(out[t + '_K'] + 1e-8 * np.eye(x.shape[1])))
+            if dim <= 6:
+                # the kernel-level methods as callables (bq/bqkern.py:96-142, 329-343, 366-415; bq/bqmod.py:525-528)
+                out[t + '_L'] = k.eval_chol(par, x, scaling=False)
+                out[t + '_Ls'] = k.eval_chol(par, x, scaling=True)
+                out[t + '_iKs'] = k.eval_inv_dot(par, x, scaling=True)
+                out[t + '_conds'] = np.float64(np.linalg.cond(out[t + '_Ks'] + 1e-8 * np.eye(x.shape[1])))
+                # a right-hand side has to be square: _cho_inv symmetrises whatever it solved for (bq/bqkern.py:63)
+                b = np.linspace(-1.0, 2.0, x.shape[1] ** 2).reshape(x.shape[1], x.shape[1])
+                out[t + '_b'], out[t + '_iKb'] = b, k.eval_inv_dot(par, x, b, scaling=False)
+                par2 = par * np.concatenate(([0.6], 1.0 + 0.25 * np.arange(1, dim + 1) / dim))[None, :]
+                out[t + '_par2'] = par2
+                out[t + '_Q01'] = k.exp_x_kxkx(par, par2, x, scaling=False)
+                out[t + '_Q01s'] = k.exp_x_kxkx(par, par2, x, scaling=True)
+                out[t + '_Qs'] = k.exp_x_kxkx(par, par, x, scaling=True)
+                out[t + '_qs'] = k.exp_x_kx(par, x, scaling=True)
+                x2 = 0.7 * x[:, ::-1][:, :max(1, x.shape[1] - 1)] + 0.1
+                out[t + '_x2'] = x2
+                out[t + '_K12'] = k.eval(par, x, x2, scaling=True)
+                out[t + '_Kdiag'] = k.eval(par, x, 0.5 * x + 0.2, diag=True, scaling=True)
+                out[t + '_emv_call'] = np.float64(m.exp_model_variance(par))
+                out[t + '_ivar_call'] = np.float64(m.integral_variance(par))
     save('g2_gp_weights', **out)
 
     out = {}
@@ -138,6 +159,12 @@ def g2_weights():
         out[t + '_pxpx'], out[t + '_kxpx'] = m._exp_x_pxpx(mi), m._exp_x_kxpx(par, mi, m.points)
         out[t + '_V'] = vandermonde(mi, m.points)
         out[t + '_iK'] = m.kernel.eval_inv_dot(par, m.points, scaling=False)
+        # condition numbers that bound how well ANY evaluation of these weights can be reproduced
+        N = m.points.shape[1]
+        out[t + '_condK'] = np.float64(np.linalg.cond(m.kernel.eval(par, m.points, scaling=False) + 1e-8 * np.eye(N)))
+        V = out[t + '_V']
+        out[t + '_condV'] = np.float64(np.linalg.cond(V))
+        out[t + '_condVKV'] = np.float64(np.linalg.cond(V.T.dot(out[t + '_iK']).dot(V) + 1e-8 * np.eye(V.shape[1])))
     save('g2_bs_weights', **out)
 
 
