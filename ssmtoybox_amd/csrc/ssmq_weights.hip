@@ -7,8 +7,16 @@
 //   GP weights  wm = q iK, Wc = iK Q iK, Wcc = R iK      bq/bqmod.py:495-523
 //   Bayes-Sard weights (unisolvent + general branch)     bq/bqmod.py:893-992, polynomial moments :635-797
 //
-// For N <= 64 the kernel matrix, its factor and the inverse are LDS-resident (2 N^2 doubles <= 64 KiB); larger point
-// sets (fully-symmetric degree 5 at D = 10: N = 201) factor in an L2-resident workspace with the same code.
+// For N <= 64 the kernel matrix, its factor and the inverse are LDS-resident (2 N^2 doubles <= 64 KiB) and one launch
+// does everything.  Larger point sets (fully-symmetric degree 5 at D = 10: N = 201) take three launches per batch of
+// parameter rows ("large point sets" below):
+//   1. k_weights<1024>, stage 1: K, then its Cholesky factor in the PACKED lower triangle (N (N + 1) / 2 doubles =
+//      162 408 bytes at N = 201) held in the CU's 160 KiB of LDS; the factor goes to the workspace;
+//   2. k_weights_inverse: the two triangular solves against I are independent per column, so the columns are dealt out
+//      to ceil(N / 16) workgroups per parameter row - each re-reads the packed factor into its LDS and keeps its 16
+//      solution columns in registers (one CU alone is instruction-bound on the 2 N^3 / 3 multiply-adds);
+//   3. k_weights<1024>, stage 2: expectations and the weight algebra, every N x N x N product through LDS tiles with
+//      4 x 4 register blocks and operands fetched one slab ahead.
 // The algebra follows the reference step by step (explicit inverse, symmetrisation, jitter placement) because the
 // results are only reproducible to cond(K) eps, not because it is the best-conditioned route.
 #include <algorithm>
@@ -25,6 +33,7 @@ namespace ssmq {
 
 struct WgtArgs {
     int32_t D, N, P, NB, bs, use_lds;
+    int32_t stage;      // 0: everything in one launch; 1: K + factor only (large point sets); 2: from the inverse onwards
     int32_t var_mode;   // 1: BayesSardModel.exp_model_variance / integral_variance semantics (bq/bqmod.py:995-1050): always
                         // the general formulas, no jitter on V' iK V; weights are still written but are not the reference's
     double jitter;
@@ -36,6 +45,7 @@ struct WgtArgs {
     int32_t *status;
     double *work;           // per-theta workspace
     int64_t work_stride;    // doubles
+    double *lpack;          // stages 1 / 2: packed Cholesky factors, N (N + 1) / 2 doubles per parameter row
 };
 
 __device__ __forceinline__ void bsync() { __syncthreads(); }
@@ -148,6 +158,201 @@ __device__ bool lu_inverse(double *A, double *X, int n, int *piv, int *flag) {
     return true;
 }
 
+// ---- large point sets (N > 64, 1024 threads) --------------------------------------------------------------------------
+#define SSMQ_PKL(i, j) ((i) * ((i) + 1) / 2 + (j))   // packed lower triangle, j <= i
+
+// Right-looking Cholesky of a packed lower triangle held in LDS (same subtraction order as chol_block: same factor).
+// Two barriers per column: every thread forms the pivot's reciprocal root itself, and the trailing update walks rows and
+// columns without an integer division per element.
+__device__ bool chol_packed_lds(double *Lp, int n, int *flag) {
+    if (threadIdx.x == 0) *flag = 1;
+    bsync();
+    for (int k = 0; k < n; ++k) {
+        const double p = Lp[SSMQ_PKL(k, k)];
+        if (!(p > 0.0)) return false;            // uniform: every thread reads the same pivot
+        const double lkk = sqrt(p), r = 1.0 / lkk;
+        bsync();                                 // everyone has read the pivot before it is overwritten
+        if (threadIdx.x == 0) Lp[SSMQ_PKL(k, k)] = lkk;
+        for (int i = k + 1 + threadIdx.x; i < n; i += kWgtBlock) Lp[SSMQ_PKL(i, k)] *= r;
+        bsync();
+        for (int i = k + 1 + (threadIdx.x >> 4); i < n; i += kWgtBlock >> 4) {
+            const double lik = Lp[SSMQ_PKL(i, k)];
+            for (int j = k + 1 + (threadIdx.x & 15); j <= i; j += 16) Lp[SSMQ_PKL(i, j)] -= lik * Lp[SSMQ_PKL(j, k)];
+        }
+        bsync();
+    }
+    return true;
+}
+
+// X = (L L')^-1 column by column - cho_solve(cho_factor(A), I): forward substitution L y = e_c, backward substitution
+// L' x = y.  Sixteen lanes (a DPP row) own a column and keep it IN REGISTERS (lane `part` holds rows part, part + 16, ...);
+// the factor is only read (packed, in LDS), so columns never synchronise with each other.  The row index of a register
+// slot is static; the one dynamic write per step (row i of the solution) goes through a switch.  n <= 16 kInvSlots.
+constexpr int kInvSlots = 16, kInvLanes = 16, kInvBlock = 256, kInvCols = kInvBlock / kInvLanes;
+__device__ __forceinline__ void slot_write(double (&x)[kInvSlots], int slot, double v) {
+    switch (slot) {
+#define SSMQ_SW(q) case q: x[q] = v; break;
+#define SSMQ_SW4(q) SSMQ_SW(q) SSMQ_SW(q + 1) SSMQ_SW(q + 2) SSMQ_SW(q + 3)
+        SSMQ_SW4(0) SSMQ_SW4(4) SSMQ_SW4(8) SSMQ_SW4(12)
+#undef SSMQ_SW4
+#undef SSMQ_SW
+        default: break;
+    }
+}
+// sum over the 16 lanes of a group (a DPP row), to every lane: two quad permutes, the mirrored half, the mirrored row
+// (DPP: no LDS round trip)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum(double v) {
+    v += dpp_f64<0xB1>(v);     // quad_perm [1, 0, 3, 2]
+    v += dpp_f64<0x4E>(v);     // quad_perm [2, 3, 0, 1]: every lane of a quad holds the quad's sum
+    v += dpp_f64<0x141>(v);    // row_half_mirror: lane i <-> 7 - i, the other quad of the half row
+    v += dpp_f64<0x140>(v);    // row_mirror: lane i <-> 15 - i, the other half
+    return v;
+}
+// grid (ceil(n / kInvCols), P): workgroup (cb, p) solves columns cb kInvCols ... of parameter row p
+__global__ __launch_bounds__(kInvBlock) void k_weights_inverse(int n, const double *__restrict__ lpack, const int32_t *status,
+                                                              double *__restrict__ work, int64_t work_stride) {
+    extern __shared__ __align__(16) double Lp[];
+    const int p = blockIdx.y;
+    if (status[p] != 0) return;                  // not positive definite: stage 2 poisons the outputs
+    const int np = n * (n + 1) / 2;
+    const double *src = lpack + (int64_t)p * np;
+    for (int idx = threadIdx.x; idx < np; idx += kInvBlock) Lp[idx] = src[idx];
+    __syncthreads();
+    double *X = work + (int64_t)p * work_stride + (int64_t)n * n;     // gX of k_weights' workspace carve-up
+    const int part = threadIdx.x & (kInvLanes - 1);
+    const int c = blockIdx.x * kInvCols + threadIdx.x / kInvLanes;
+    const bool live = c < n;                     // whole lane groups are live or not
+    double x[kInvSlots];
+#pragma unroll
+    for (int q = 0; q < kInvSlots; ++q) x[q] = 0.0;
+    // forward: y_i = (e_c[i] - sum_{k < i} L[i][k] y_k) / L[i][i]; y_k = 0 for k < c
+    for (int i = 0; i < n; ++i) {
+        // all loads of the row first (clamped index, the factor of an out-of-range term is zero), four partial sums
+        double sp[4] = {0.0, 0.0, 0.0, 0.0};
+        const int rowi = SSMQ_PKL(i, 0);
+#pragma unroll
+        for (int q = 0; q < kInvSlots; ++q) {
+            const int k = kInvLanes * q + part;
+            if (kInvLanes * q < i) {             // uniform: a whole slot beyond row i contributes nothing
+                const double l = Lp[rowi + (k < i ? k : i)];
+                sp[q & 3] += (k < i ? l : 0.0) * x[q];
+            }
+        }
+        const double s = row_sum((sp[0] + sp[1]) + (sp[2] + sp[3]));
+        const double y = (live && i >= c) ? div_nr((i == c ? 1.0 : 0.0) - s, Lp[SSMQ_PKL(i, i)]) : 0.0;
+        if ((i & (kInvLanes - 1)) == part) slot_write(x, i / kInvLanes, y);
+    }
+    // backward: x_i = (y_i - sum_{k > i} L[k][i] x_k) / L[i][i]
+    for (int i = n - 1; i >= 0; --i) {
+        double sp[4] = {0.0, 0.0, 0.0, 0.0}, yi = 0.0;
+#pragma unroll
+        for (int q = 0; q < kInvSlots; ++q) {
+            const int k = kInvLanes * q + part;
+            if (kInvLanes * q + kInvLanes - 1 >= i && kInvLanes * q < n) {   // uniform: slots entirely above row i are done
+                const bool in = k > i && k < n;
+                const int kc = in ? k : i;
+                const double l = Lp[SSMQ_PKL(kc, i)];
+                sp[q & 3] += (in ? l : 0.0) * x[q];
+                yi = (k == i) ? x[q] : yi;
+            }
+        }
+        const double s = row_sum((sp[0] + sp[1]) + (sp[2] + sp[3]));
+        yi = row_sum((i & (kInvLanes - 1)) == part ? yi : 0.0);   // y_i sits in exactly one lane of the group
+        const double v = live ? div_nr(yi - s, Lp[SSMQ_PKL(i, i)]) : 0.0;
+        if ((i & (kInvLanes - 1)) == part) slot_write(x, i / kInvLanes, v);
+    }
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < kInvSlots; ++q) {
+            const int k = kInvLanes * q + part;
+            if (k < n) X[k * n + c] = x[q];
+        }
+    }
+}
+
+// C (M x N, ldc) = op(A) op(B) through LDS tiles: 128 x 128 outputs per pass, 4 x 4 per thread (1024 threads), K in
+// slabs of 16 whose loads are issued one slab ahead (registers) so that the L2 latency hides behind the arithmetic of
+// the current slab; k ascends inside every output's sum exactly as in gemm(), so the result is bit-identical to it.
+// tile: 2 * 16 * 132 doubles of LDS.
+constexpr int kTileMN = 128, kTileK = 16, kTilePitch = kTileMN + 4;
+__device__ void gemm_tiled(double *tile, double *C, int ldc, const double *A, int lda, bool ta, const double *B, int ldb,
+                           bool tb, int M, int N, int K) {
+    double *sA = tile, *sB = tile + kTileK * kTilePitch;     // sA[k][i], sB[k][j]
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 32 threads, each 4 x 4 outputs
+    constexpr int kPer = kTileK * kTileMN / 1024;            // elements of either slab per thread (2)
+    for (int i0 = 0; i0 < M; i0 += kTileMN)
+        for (int j0 = 0; j0 < N; j0 += kTileMN) {
+            double acc[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[r][q] = 0.0;
+            double ra[kPer], rb[kPer];
+            auto fetch = [&](int k0) {
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) {
+                    const int idx = threadIdx.x + u * kWgtBlock;
+                    int kk, ii;                  // coalesced along the contiguous direction of each operand
+                    if (ta) { kk = idx / kTileMN; ii = idx % kTileMN; } else { ii = idx / kTileK; kk = idx % kTileK; }
+                    const int gi = i0 + ii, gk = k0 + kk;
+                    ra[u] = (gi < M && gk < K) ? (ta ? A[gk * lda + gi] : A[gi * lda + gk]) : 0.0;
+                    int kb, jj;
+                    if (tb) { jj = idx / kTileK; kb = idx % kTileK; } else { kb = idx / kTileMN; jj = idx % kTileMN; }
+                    const int gj = j0 + jj, gkb = k0 + kb;
+                    rb[u] = (gj < N && gkb < K) ? (tb ? B[gj * ldb + gkb] : B[gkb * ldb + gj]) : 0.0;
+                }
+            };
+            auto park = [&]() {
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) {
+                    const int idx = threadIdx.x + u * kWgtBlock;
+                    int kk, ii;
+                    if (ta) { kk = idx / kTileMN; ii = idx % kTileMN; } else { ii = idx / kTileK; kk = idx % kTileK; }
+                    sA[kk * kTilePitch + ii] = ra[u];
+                    int kb, jj;
+                    if (tb) { jj = idx / kTileK; kb = idx % kTileK; } else { kb = idx / kTileMN; jj = idx % kTileMN; }
+                    sB[kb * kTilePitch + jj] = rb[u];
+                }
+            };
+            fetch(0);
+            for (int k0 = 0; k0 < K; k0 += kTileK) {
+                bsync();                         // the previous slab has been consumed
+                park();
+                bsync();
+                if (k0 + kTileK < K) fetch(k0 + kTileK);
+#pragma unroll
+                for (int kk = 0; kk < kTileK; ++kk) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) av[r] = sA[kk * kTilePitch + ty * 4 + r];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bv[q] = sB[kk * kTilePitch + tx * 4 + q];
+                    if (k0 + kk < K) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[r][q] += av[r] * bv[q];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gi = i0 + ty * 4 + r, gj = j0 + tx * 4 + q;
+                    if (gi < M && gj < N) C[gi * ldc + gj] = acc[r][q];
+                }
+        }
+    bsync();
+}
+
 __device__ double block_sum(double v, double *red) {
     // all threads of the block -> one value (to every thread); waves added in index order
 #pragma unroll
@@ -183,8 +388,11 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     double *M2 = w; w += N * N;
     double *zs = w; w += D * N;       // length-scale-normalised points
     double *nrm = w; w += N;
-    double *A = a.use_lds ? lds : gA;
-    double *X = a.use_lds ? lds + N * N : gX;
+    const bool large = a.use_lds == 2;       // N > 64: packed factor in LDS, tiles afterwards (1024 threads)
+    double *A = a.use_lds == 1 ? lds : gA;
+    double *X = a.use_lds == 1 ? lds + N * N : gX;
+    // products: the LDS-tiled routine for large point sets (LDS is free again once the inverse exists), else the plain one
+#define GEMM(...) do { if (large) gemm_tiled(lds, __VA_ARGS__); else gemm(__VA_ARGS__); } while (0)
     double *oq = a.q + (int64_t)p * N, *oQ = a.Q + (int64_t)p * N * N, *oR = a.R + (int64_t)p * D * N;
     double *oiK = a.iK + (int64_t)p * N * N, *owm = a.wm + (int64_t)p * N, *oWc = a.Wc + (int64_t)p * N * N;
     double *oWcc = a.Wcc + (int64_t)p * D * N;
@@ -200,17 +408,32 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
         nrm[n] = s;
     }
     bsync();
+    bool pd = true;
+    if (a.stage != 2) {
     for (int idx = tid; idx < N * N; idx += kWgtBlock) {
         const int i = idx / N, j = idx % N;
+        if (large && j > i) continue;
         double dot = 0.0;
         for (int d = 0; d < D; ++d) dot += zs[d * N + i] * zs[d * N + j];
         const double mh = (nrm[i] + nrm[j]) - 2.0 * dot;
-        A[idx] = exp(0.0 - 0.5 * mh) + (i == j ? a.jitter : 0.0);
+        const double v = exp(0.0 - 0.5 * mh) + (i == j ? a.jitter : 0.0);
+        if (large) lds[SSMQ_PKL(i, j)] = v;
+        else A[idx] = v;
     }
     bsync();
     // ---- (K + jitter I)^-1 ----------------------------------------------------------------------------------------
-    const bool pd = chol_block(A, N, &s_flag);
+    pd = large ? chol_packed_lds(lds, N, &s_flag) : chol_block(A, N, &s_flag);
     if (tid == 0) a.status[p] = pd ? 0 : 1;
+    if (a.stage == 1) {      // large point sets: the factor goes to the workspace, the inverse is a launch of its own
+        if (pd) {
+            double *dst = a.lpack + (int64_t)p * (N * (N + 1) / 2);
+            for (int idx = tid; idx < N * (N + 1) / 2; idx += kWgtBlock) dst[idx] = lds[idx];
+        }
+        return;
+    }
+    } else {
+        pd = a.status[p] == 0;
+    }
     if (!pd) {
         const double nan = __builtin_nan("");
         for (int idx = tid; idx < N * N; idx += kWgtBlock) { oiK[idx] = nan; oWc[idx] = nan; oQ[idx] = nan; }
@@ -219,7 +442,7 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
         if (tid == 0) { a.mv[p] = nan; a.iv[p] = nan; }
         return;
     }
-    chol_inverse(A, X, N);
+    if (a.stage == 0) chol_inverse(A, X, N);     // stage 2: k_weights_inverse has filled X
     for (int idx = tid; idx < N * N; idx += kWgtBlock) {
         const int i = idx / N, j = idx % N;
         oiK[idx] = 0.5 * (X[i * N + j] + X[j * N + i]);
@@ -277,10 +500,10 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
 
     if (NB == 0) {
         // ---- GP weights (bq/bqmod.py:495-523) -------------------------------------------------------------------------
-        gemm(owm, N, oq, N, false, iK, N, false, 1, N, N);          // wm = q iK
-        gemm(M1, N, oQ, N, false, iK, N, false, N, N, N);           // M1 = Q iK
-        gemm(M2, N, iK, N, false, M1, N, false, N, N, N);           // M2 = iK Q iK
-        gemm(oWcc, N, oR, N, false, iK, N, false, D, N, N);         // Wcc = R iK
+        GEMM(owm, N, oq, N, false, iK, N, false, 1, N, N);          // wm = q iK
+        GEMM(M1, N, oQ, N, false, iK, N, false, N, N, N);           // M1 = Q iK
+        GEMM(M2, N, iK, N, false, M1, N, false, N, N, N);           // M2 = iK Q iK
+        GEMM(oWcc, N, oR, N, false, iK, N, false, D, N, N);         // Wcc = R iK
         for (int idx = tid; idx < N * N; idx += kWgtBlock) {
             const int i = idx / N, j = idx % N;
             oWc[idx] = 0.5 * (M2[i * N + j] + M2[j * N + i]);
@@ -293,7 +516,7 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
             a.mv[p] = (alpha * alpha) * (1.0 - tr);
             a.iv[p] = kbar - qq;
         }
-        return;
+            return;
     }
 
     // ---- Bayes-Sard weights (bq/bqmod.py:893-992) -----------------------------------------------------------------------
@@ -334,8 +557,8 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
         kx[idx] = kprod;
     }
     bsync();
-    gemm(Z, N, V, NB, true, iK, N, false, NB, N, N);        // Z = V' iK
-    gemm(G, NB, Z, N, false, V, NB, false, NB, NB, N);      // G = Z V
+    GEMM(Z, N, V, NB, true, iK, N, false, NB, N, N);        // Z = V' iK
+    GEMM(G, NB, Z, N, false, V, NB, false, NB, NB, N);      // G = Z V
     if (!a.var_mode)
         for (int i = tid; i < NB; i += kWgtBlock) G[i * NB + i] += 1e-8;
     bsync();
@@ -355,17 +578,17 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
             if (tid == 0) a.status[p] = 3;
             return;
         }
-        gemm(owm, N, a.px, NB, false, iV, N, false, 1, N, NB);              // wm = iV' px  == px' iV
-        gemm(M1, N, a.pxpx, NB, false, iV, N, false, NB, N, NB);            // pxpx iV
-        gemm(M2, N, iV, N, true, M1, N, false, N, N, NB);                   // iV' pxpx iV
-        gemm(oWcc, N, a.xpx, NB, false, iV, N, false, D, N, NB);            // xpx iV
+        GEMM(owm, N, a.px, NB, false, iV, N, false, 1, N, NB);              // wm = iV' px  == px' iV
+        GEMM(M1, N, a.pxpx, NB, false, iV, N, false, NB, N, NB);            // pxpx iV
+        GEMM(M2, N, iV, N, true, M1, N, false, N, N, NB);                   // iV' pxpx iV
+        GEMM(oWcc, N, a.xpx, NB, false, iV, N, false, D, N, NB);            // xpx iV
         for (int idx = tid; idx < N * N; idx += kWgtBlock) {
             const int i = idx / N, j = idx % N;
             oWc[idx] = 0.5 * (M2[i * N + j] + M2[j * N + i]);
         }
         // model_var = ks2 (1 - tr(kxpx' iV' + kxpx iV - pxpx iViKV));  tr(kxpx' iV') = tr(iV kxpx) = tr(kxpx iV)
-        gemm(M1, N, kx, NB, false, iV, N, false, N, N, NB);                 // kxpx iV   (N x N)
-        gemm(M2, NB, a.pxpx, NB, false, iG, NB, false, NB, NB, NB);         // pxpx iViKV
+        GEMM(M1, N, kx, NB, false, iV, N, false, N, N, NB);                 // kxpx iV   (N x N)
+        GEMM(M2, NB, a.pxpx, NB, false, iG, NB, false, NB, NB, NB);         // pxpx iViKV
         double tr = 0.0;
         for (int n = tid; n < N; n += kWgtBlock) tr += 2.0 * M1[n * N + n] - M2[n * NB + n];
         tr = block_sum(tr, s_red);
@@ -391,7 +614,7 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     double *Dm = w; w += D * NB;         // D = R Z' - xpx       (D x NB)
     double *T3 = w; w += N * N;
     double *T4 = w; w += N * N;
-    gemm(Am, NB, V, NB, false, iG, NB, false, N, NB, NB);
+    GEMM(Am, NB, V, NB, false, iG, NB, false, N, NB, NB);
     // b = Z q - px
     for (int i = tid; i < NB; i += kWgtBlock) {
         double s = 0.0;
@@ -400,16 +623,16 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     }
     bsync();
     // B = Z Q Z' + pxpx - Z kxpx - kxpx' Z'
-    gemm(T3, N, Z, N, false, oQ, N, false, NB, N, N);                       // Z Q         (NB x N)
-    gemm(T4, NB, T3, N, false, Z, N, true, NB, NB, N);                      // Z Q Z'      (NB x NB)
-    gemm(T3, NB, Z, N, false, kx, NB, false, NB, NB, N);                    // Z kxpx      (NB x NB)
+    GEMM(T3, N, Z, N, false, oQ, N, false, NB, N, N);                       // Z Q         (NB x N)
+    GEMM(T4, NB, T3, N, false, Z, N, true, NB, NB, N);                      // Z Q Z'      (NB x NB)
+    GEMM(T3, NB, Z, N, false, kx, NB, false, NB, NB, N);                    // Z kxpx      (NB x NB)
     for (int idx = tid; idx < NB * NB; idx += kWgtBlock) {
         const int i = idx / NB, j = idx % NB;
         Bm[idx] = ((T4[idx] + a.pxpx[idx]) - T3[i * NB + j]) - T3[j * NB + i];
     }
     bsync();
     // D = R Z' - xpx
-    gemm(Dm, NB, oR, N, false, Z, N, true, D, NB, N);
+    GEMM(Dm, NB, oR, N, false, Z, N, true, D, NB, N);
     for (int idx = tid; idx < D * NB; idx += kWgtBlock) Dm[idx] -= a.xpx[idx];
     bsync();
     // wm = iK (q - A b)
@@ -419,26 +642,26 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
         nrm[n] = oq[n] - s;
     }
     bsync();
-    gemm(owm, 1, iK, N, false, nrm, 1, false, N, 1, N);
+    GEMM(owm, 1, iK, N, false, nrm, 1, false, N, 1, N);
     // Wc = iK (Q - A B A') iK
-    gemm(T3, NB, Am, NB, false, Bm, NB, false, N, NB, NB);                  // A B         (N x NB)
-    gemm(T4, N, T3, NB, false, Am, NB, true, N, N, NB);                     // A B A'      (N x N)
+    GEMM(T3, NB, Am, NB, false, Bm, NB, false, N, NB, NB);                  // A B         (N x NB)
+    GEMM(T4, N, T3, NB, false, Am, NB, true, N, N, NB);                     // A B A'      (N x N)
     for (int idx = tid; idx < N * N; idx += kWgtBlock) T4[idx] = oQ[idx] - T4[idx];
     bsync();
-    gemm(M1, N, T4, N, false, iK, N, false, N, N, N);
-    gemm(M2, N, iK, N, false, M1, N, false, N, N, N);
+    GEMM(M1, N, T4, N, false, iK, N, false, N, N, N);
+    GEMM(M2, N, iK, N, false, M1, N, false, N, N, N);
     for (int idx = tid; idx < N * N; idx += kWgtBlock) {
         const int i = idx / N, j = idx % N;
         oWc[idx] = 0.5 * (M2[i * N + j] + M2[j * N + i]);
     }
     // Wcc = (R - D A') iK
-    gemm(T3, N, Dm, NB, false, Am, NB, true, D, N, NB);                     // D A'        (D x N)
+    GEMM(T3, N, Dm, NB, false, Am, NB, true, D, N, NB);                     // D A'        (D x N)
     for (int idx = tid; idx < D * N; idx += kWgtBlock) T3[idx] = oR[idx] - T3[idx];
     bsync();
-    gemm(oWcc, N, T3, N, false, iK, N, false, D, N, N);
+    GEMM(oWcc, N, T3, N, false, iK, N, false, D, N, N);
     // model_var = ks2 (1 - tr(Q iK) + tr(B iViKV)); integral_var = kbar - q' iK q + b' iViKV b
-    gemm(M1, N, oQ, N, false, iK, N, false, N, N, N);
-    gemm(T3, NB, Bm, NB, false, iG, NB, false, NB, NB, NB);
+    GEMM(M1, N, oQ, N, false, iK, N, false, N, N, N);
+    GEMM(T3, NB, Bm, NB, false, iG, NB, false, NB, NB, NB);
     double tr1 = 0.0, tr2 = 0.0, qq = 0.0, bb = 0.0;
     for (int n = tid; n < N; n += kWgtBlock) {
         tr1 += M1[n * N + n];
@@ -460,6 +683,7 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
         a.mv[p] = ks2 * (1.0 - tr1 + tr2);
         a.iv[p] = kbar - qq + bb;
     }
+#undef GEMM
 }
 
 // ---- host side: polynomial moments under N(0, I) (integer tables; bq/bqmod.py:635-731) -----------------------------
@@ -514,6 +738,55 @@ struct DBuf {
 };
 }  // namespace
 
+// Launches the weights computation for a.P parameter rows.  N <= 64: one launch, dense K and inverse resident in LDS
+// (256 threads).  Larger point sets: packed factor in LDS (stage 1, 1024 threads) | inverse by column blocks on
+// ceil(N / 16) workgroups per row | stage 2 (1024 threads, LDS tiles), while the packed triangle fits the CU's LDS
+// (N <= 201) and a column fits its lanes' registers; beyond that one launch with everything in the L2-resident workspace.
+static int launch_weights(WgtArgs &a, hipStream_t s) {
+    const int N = a.N;
+    const size_t nn = (size_t)N * N;
+    const size_t packed = sizeof(double) * ((size_t)N * (N + 1) / 2);
+    const size_t tiles = sizeof(double) * 2 * kTileK * kTilePitch;
+    const size_t lds_cap = 160 * 1024 - 512;     // static __shared__ of the kernels: < 512 bytes
+    a.stage = 0;
+    if (N <= 64) {
+        a.use_lds = 1;
+        hipLaunchKernelGGL(k_weights<256>, dim3(a.P), dim3(256), sizeof(double) * 2 * nn, s, a);
+        return hip_fail(hipGetLastError(), "k_weights");
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSMQ_HIP(hipFuncSetAttribute((const void *)k_weights<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        SSMQ_HIP(hipFuncSetAttribute((const void *)k_weights_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        attr_set = true;
+    }
+    const bool staged = packed <= lds_cap && N <= kInvLanes * kInvSlots && !getenv("SSMQ_WEIGHTS_NO_LDS");
+    if (!staged) {
+        a.use_lds = 0;
+        hipLaunchKernelGGL(k_weights<1024>, dim3(a.P), dim3(1024), 0, s, a);
+        return hip_fail(hipGetLastError(), "k_weights");
+    }
+    if (!a.lpack) {
+        set_error("weights: no buffer for the packed factors");
+        return SSMQ_E_ARG;
+    }
+    a.use_lds = 2;
+    a.stage = 1;
+    hipLaunchKernelGGL(k_weights<1024>, dim3(a.P), dim3(1024), packed, s, a);
+    int rc = hip_fail(hipGetLastError(), "k_weights(factor)");
+    if (!rc) {
+        hipLaunchKernelGGL(k_weights_inverse, dim3((N + kInvCols - 1) / kInvCols, a.P), dim3(kInvBlock), packed, s, N, a.lpack,
+                           a.status, a.work, a.work_stride);
+        rc = hip_fail(hipGetLastError(), "k_weights_inverse");
+    }
+    if (!rc) {
+        a.stage = 2;
+        hipLaunchKernelGGL(k_weights<1024>, dim3(a.P), dim3(1024), tiles, s, a);
+        rc = hip_fail(hipGetLastError(), "k_weights(algebra)");
+    }
+    return rc;
+}
+
 static int weights_impl(int var_mode, int D, int N, const double *xi, const double *par, int P, double jitter,
                         const int32_t *mulind, int NB, double *wm, double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R,
                         double *model_var, double *integral_var, int32_t *status) {
@@ -534,18 +807,29 @@ static int weights_impl(int var_mode, int D, int N, const double *xi, const doub
     const size_t nn = (size_t)N * N;
     const int64_t work_stride = (int64_t)(10 * nn + 4 * (size_t)N * std::max(NB, 1) + 2 * (size_t)std::max(NB, 1) * NB +
                                           (size_t)D * (N + NB) + 2 * N + NB + 64);
-    DBuf dxi, dpar, dmi, dpx, dxpx, dpxpx, dwm, dWc, dWcc, diK, dq, dQ, dR, dmv, div, dst, dwork;
-    if ((rc = dxi.alloc(sizeof(double) * D * N)) || (rc = dpar.alloc(sizeof(double) * P * (1 + D))) ||
-        (rc = dmi.alloc(sizeof(int32_t) * D * std::max(NB, 1))) || (rc = dpx.alloc(sizeof(double) * std::max(NB, 1))) ||
-        (rc = dxpx.alloc(sizeof(double) * D * std::max(NB, 1))) ||
-        (rc = dpxpx.alloc(sizeof(double) * std::max(NB, 1) * std::max(NB, 1))) ||
-        (rc = dwm.alloc(sizeof(double) * P * N)) || (rc = dWc.alloc(sizeof(double) * P * nn)) ||
-        (rc = dWcc.alloc(sizeof(double) * P * D * N)) || (rc = diK.alloc(sizeof(double) * P * nn)) ||
-        (rc = dq.alloc(sizeof(double) * P * N)) || (rc = dQ.alloc(sizeof(double) * P * nn)) ||
-        (rc = dR.alloc(sizeof(double) * P * D * N)) || (rc = dmv.alloc(sizeof(double) * P)) ||
-        (rc = div.alloc(sizeof(double) * P)) || (rc = dst.alloc(sizeof(int32_t) * P)) ||
-        (rc = dwork.alloc(sizeof(double) * (size_t)P * work_stride)))
-        return rc;
+    // one device allocation, carved up (a call used to spend ~0.5 ms in 17 hipMalloc / hipFree pairs)
+    struct Part { void *p = nullptr; double *d() { return (double *)p; } };
+    Part dxi, dpar, dmi, dpx, dxpx, dpxpx, dwm, dWc, dWcc, diK, dq, dQ, dR, dmv, div, dst, dwork, dlp;
+    const int nb1 = std::max(NB, 1);
+    const size_t npk = (N > 64) ? (size_t)N * (N + 1) / 2 : 0;
+    struct { Part *part; size_t bytes; } plan[] = {
+        {&dxi, sizeof(double) * D * N}, {&dpar, sizeof(double) * P * (1 + D)}, {&dmi, sizeof(int32_t) * D * nb1},
+        {&dpx, sizeof(double) * nb1}, {&dxpx, sizeof(double) * D * nb1}, {&dpxpx, sizeof(double) * nb1 * nb1},
+        {&dwm, sizeof(double) * P * N}, {&dWc, sizeof(double) * P * nn}, {&dWcc, sizeof(double) * P * D * N},
+        {&diK, sizeof(double) * P * nn}, {&dq, sizeof(double) * P * N}, {&dQ, sizeof(double) * P * nn},
+        {&dR, sizeof(double) * P * D * N}, {&dmv, sizeof(double) * P}, {&div, sizeof(double) * P},
+        {&dst, sizeof(int32_t) * P}, {&dwork, sizeof(double) * (size_t)P * work_stride}, {&dlp, sizeof(double) * P * npk}};
+    size_t total = 0;
+    for (auto &e : plan) total += (e.bytes + 255) / 256 * 256;
+    DBuf arena;
+    if ((rc = arena.alloc(total))) return rc;
+    {
+        char *base = (char *)arena.p;
+        for (auto &e : plan) {
+            e.part->p = base;
+            base += (e.bytes + 255) / 256 * 256;
+        }
+    }
     SSMQ_HIP(hipMemcpyAsync(dxi.p, xi, sizeof(double) * D * N, hipMemcpyHostToDevice, s));
     SSMQ_HIP(hipMemcpyAsync(dpar.p, par, sizeof(double) * P * (1 + D), hipMemcpyHostToDevice, s));
     SSMQ_HIP(hipMemsetAsync(dQ.p, 0, sizeof(double) * P * nn, s));
@@ -559,17 +843,13 @@ static int weights_impl(int var_mode, int D, int N, const double *xi, const doub
     }
     WgtArgs a;
     memset(&a, 0, sizeof(a));
-    a.D = D; a.N = N; a.P = P; a.NB = NB; a.jitter = jitter; a.use_lds = (N <= 64) ? 1 : 0; a.var_mode = var_mode;
+    a.D = D; a.N = N; a.P = P; a.NB = NB; a.jitter = jitter; a.var_mode = var_mode;
     a.xi = dxi.d(); a.par = dpar.d(); a.mulind = (const int32_t *)dmi.p; a.px = dpx.d(); a.xpx = dxpx.d();
     a.pxpx = dpxpx.d(); a.wm = dwm.d(); a.Wc = dWc.d(); a.Wcc = dWcc.d(); a.iK = diK.d(); a.q = dq.d(); a.Q = dQ.d();
     a.R = dR.d(); a.mv = dmv.d(); a.iv = div.d(); a.status = (int32_t *)dst.p; a.work = dwork.d();
     a.work_stride = work_stride;
-    const size_t lds = a.use_lds ? sizeof(double) * 2 * nn : 0;
-    if (N > 64)
-        hipLaunchKernelGGL(k_weights<1024>, dim3(P), dim3(1024), lds, s, a);
-    else
-        hipLaunchKernelGGL(k_weights<256>, dim3(P), dim3(256), lds, s, a);
-    if ((rc = hip_fail(hipGetLastError(), "k_weights"))) return rc;
+    a.lpack = npk ? dlp.d() : nullptr;
+    if ((rc = launch_weights(a, s))) return rc;
 #define SSMQ_D2H(host, dev, count) \
     if (host) SSMQ_HIP(hipMemcpyAsync(host, dev.p, sizeof(*host) * (count), hipMemcpyDeviceToHost, s));
     SSMQ_D2H(wm, dwm, (size_t)P * N)
@@ -626,19 +906,17 @@ int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double
         (rc = div.alloc(sizeof(double) * P)) || (rc = dwork.alloc(sizeof(double) * (size_t)P * work_stride)) ||
         (rc = dz.alloc(sizeof(double) * (D + 2))))
         return rc;
+    DBuf dlp;       // packed Cholesky factors of the staged large-N path (launch_weights)
+    if (N > 64 && (rc = dlp.alloc(sizeof(double) * (size_t)P * N * (N + 1) / 2))) return rc;
     SSMQ_HIP(hipMemsetAsync(dQ.p, 0, sizeof(double) * P * nn, s));
     WgtArgs a;
     memset(&a, 0, sizeof(a));
-    a.D = D; a.N = N; a.P = P; a.NB = 0; a.jitter = jitter; a.use_lds = (N <= 64) ? 1 : 0;
+    a.D = D; a.N = N; a.P = P; a.NB = 0; a.jitter = jitter;
     a.xi = d_xi; a.par = d_par; a.mulind = (const int32_t *)dz.p; a.px = dz.d(); a.xpx = dz.d(); a.pxpx = dz.d();
     a.wm = dwm.d(); a.Wc = dWc.d(); a.Wcc = dWcc.d(); a.iK = diK.d(); a.q = dq.d(); a.Q = dQ.d(); a.R = dR.d();
     a.mv = dmv.d(); a.iv = div.d(); a.status = d_status; a.work = dwork.d(); a.work_stride = work_stride;
-    const size_t lds = a.use_lds ? sizeof(double) * 2 * nn : 0;
-    if (N > 64)
-        hipLaunchKernelGGL(k_weights<1024>, dim3(P), dim3(1024), lds, s, a);
-    else
-        hipLaunchKernelGGL(k_weights<256>, dim3(P), dim3(256), lds, s, a);
-    if ((rc = hip_fail(hipGetLastError(), "k_weights"))) return rc;
+    a.lpack = N > 64 ? dlp.d() : nullptr;
+    if ((rc = launch_weights(a, s))) return rc;
     hipLaunchKernelGGL(k_pack_wide_consts, dim3(P), dim3(64), 0, s, D, E, N, d_xi, dwm.d(), dWc.d(), dWcc.d(), diK.d(),
                        dmv.d(), d_consts);
     if ((rc = hip_fail(hipGetLastError(), "k_pack_wide_consts"))) return rc;
