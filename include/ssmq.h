@@ -293,6 +293,16 @@ int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, s
                            const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                            const double *d_m0, const double *d_P0, const double *GQG, const double *R, double *d_fm,
                            double *d_fP, double *d_sm, double *d_sP, int32_t *d_status);
+/*
+ * The same for models that take their noise as an argument (arguments as ssmq_filter_forward_aug_dev): backward_pass of
+ * the reference does not look at the model (ssinf.py:120-147, 325-344); the cross-covariance it uses is the one that
+ * _time_update cut back to the state columns (ssinf.py:294-295).  Synchronous.
+ */
+int ssmq_filter_smooth_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                               const ssmq_integrand *f_obs, int dim_state, int64_t B, int64_t ld, int T,
+                               const double *d_y, const double *d_m0, const double *d_P0, const double *q_mean,
+                               const double *q_cov, int dq, const double *r_mean, const double *r_cov, int dr,
+                               double *d_fm, double *d_fP, double *d_sm, double *d_sP, int32_t *d_status);
 
 /*
  * theta-batched filter step for GP-quadrature transforms whose kernel parameters are re-drawn per item - the inner

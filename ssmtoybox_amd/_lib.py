@@ -113,6 +113,12 @@ _PROTOTYPES = {
                                                    ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int, c_double_p,
                                                    c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_void_p]),
+    'ssmq_filter_smooth_aug_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
+                                                  ctypes.POINTER(Integrand), ctypes.c_int, ctypes.c_int64,
+                                                  ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int, c_double_p,
+                                                  c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'ssmq_filter_smooth_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
                                               ctypes.POINTER(Integrand), ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p,

@@ -1079,12 +1079,15 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
 // Filters whose models take the noise as an argument (ssinf.py:271-272, 282-283, 294-295): the moments are augmented with
 // the noise statistics before each transform and the cross-covariance is cut back to the state columns. Plain launch
 // loop (augment | apply | augment | apply | update per step); no fused kernel and no graph cache for this path yet.
-extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
-                                           const ssmq_integrand *f_obs, int dim_state, int64_t B, int64_t ld, int T,
-                                           const double *d_y, const double *d_m0, const double *d_P0,
-                                           const double *q_mean, const double *q_cov, int dq, const double *r_mean,
-                                           const double *r_cov, int dr, double *d_fm, double *d_fP,
-                                           int32_t *d_status) {
+// d_pm / d_pP / d_pC (all or none): predictive mean [T][D][ld], covariance [T][D*D][ld] and dynamics cross-covariance of
+// every step for the RTS pass; *c_cols returns the number of columns stored per row of d_pC (D from the fused kernel,
+// D + dq from the launch loop, whose transform writes the full E x (D + dq) block: d_pC must hold T * D * (D + dq) planes).
+static int filter_forward_aug_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                   const ssmq_integrand *f_obs, int dim_state, int64_t B, int64_t ld, int T,
+                                   const double *d_y, const double *d_m0, const double *d_P0, const double *q_mean,
+                                   const double *q_cov, int dq, const double *r_mean, const double *r_cov, int dr,
+                                   double *d_fm, double *d_fP, int32_t *d_status, double *d_pm, double *d_pP,
+                                   double *d_pC, int *c_cols) {
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || dim_state <= 0 || dq < 0 || dr < 0 || B < 0 || ld < B || T < 0 || !d_y ||
         !d_m0 || !d_P0 || !d_fm || !d_fP || !d_status || (dq > 0 && (!q_mean || !q_cov)) ||
         (dr > 0 && (!r_mean || !r_cov))) {
@@ -1156,11 +1159,14 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
         SSMQ_HIP(hipMemcpyAsync(da.p, ha.data(), sizeof(double) * ha.size(), hipMemcpyHostToDevice, s));
         rc = try_launch_fused_aug(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), D, dq, dr, B, ld, T, d_y, d_m0,
                                   d_P0, da.d(), da.d() + (size_t)D * D, dn.d(), d_fm, d_fP, d_status, s, nullptr, false,
-                                  has_td ? ttab_d : nullptr, has_to ? ttab_o : nullptr, nullptr, nullptr, nullptr);
+                                  has_td ? ttab_d : nullptr, has_to ? ttab_o : nullptr, d_pm, d_pP, d_pC);
         hipError_t e = hipStreamSynchronize(s);
         if (rc < 0) return rc;
         SSMQ_HIP(e);
-        if (rc == 1) return SSMQ_OK;
+        if (rc == 1) {
+            if (c_cols) *c_cols = D;
+            return SSMQ_OK;
+        }
         rc = 0;
     }
 
@@ -1180,9 +1186,15 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
     double *P_yx = w; w += (size_t)ld * Y * Do;
     int32_t *st_a = (int32_t *)st.p, *st_b = st_a + ld;
 
+    if (c_cols) *c_cols = Da;
     for (int k = 0; k < T && !rc; ++k) {
         const double *m_in = k == 0 ? d_m0 : d_fm + (int64_t)(k - 1) * D * ld;
         const double *P_in = k == 0 ? d_P0 : d_fP + (int64_t)(k - 1) * D * D * ld;
+        if (d_pm) {      // predictive moments of every step stay in HBM for the backward pass (ssinf.py:105-107)
+            m_pr = d_pm + (int64_t)k * D * ld;
+            P_pr = d_pP + (int64_t)k * D * D * ld;
+            C_xx = d_pC + (int64_t)k * D * Da * ld;
+        }
         if (dq) {
             rc = launch_augment(m_in, P_in, d_qm, d_qc, ma, Pa, D, dq, B, ld, s);
             if (!rc)
@@ -1213,9 +1225,55 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
     return SSMQ_OK;
 }
 
+extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                           const ssmq_integrand *f_obs, int dim_state, int64_t B, int64_t ld, int T,
+                                           const double *d_y, const double *d_m0, const double *d_P0,
+                                           const double *q_mean, const double *q_cov, int dq, const double *r_mean,
+                                           const double *r_cov, int dr, double *d_fm, double *d_fP,
+                                           int32_t *d_status) {
+    return filter_forward_aug_impl(h_dyn, f_dyn, h_obs, f_obs, dim_state, B, ld, T, d_y, d_m0, d_P0, q_mean, q_cov, dq,
+                                   r_mean, r_cov, dr, d_fm, d_fP, d_status, nullptr, nullptr, nullptr, nullptr);
+}
+
 namespace ssmq {
 int launch_rts_backward(int D, int64_t B, int64_t ld, int T, const double *fm, const double *fP, const double *pm,
-                        const double *pP, const double *pC, double *sm, double *sP, int32_t *status, hipStream_t s);
+                        const double *pP, const double *pC, double *sm, double *sP, int32_t *status, hipStream_t s,
+                        int c_cols);
+}
+
+// Forward pass + RTS smoother for models that take their noise as an argument: backward_pass of the reference is model-
+// agnostic (ssinf.py:120-147, 325-344); the cross-covariance it needs is the one _time_update cut back to the state
+// columns (:294-295).  Arguments as ssmq_filter_forward_aug_dev, outputs as ssmq_filter_smooth_dev.  Synchronous.
+extern "C" int ssmq_filter_smooth_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                          const ssmq_integrand *f_obs, int dim_state, int64_t B, int64_t ld, int T,
+                                          const double *d_y, const double *d_m0, const double *d_P0,
+                                          const double *q_mean, const double *q_cov, int dq, const double *r_mean,
+                                          const double *r_cov, int dr, double *d_fm, double *d_fP, double *d_sm,
+                                          double *d_sP, int32_t *d_status) {
+    if (!h_dyn || !d_sm || !d_sP || dim_state <= 0 || dq < 0 || B < 0 || T < 0 || ld < B) {
+        set_error("filter_smooth_aug: bad argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return SSMQ_OK;
+    const int D = dim_state;
+    if (T == 0)
+        return filter_forward_aug_impl(h_dyn, f_dyn, h_obs, f_obs, D, B, ld, T, d_y, d_m0, d_P0, q_mean, q_cov, dq, r_mean,
+                                       r_cov, dr, d_fm, d_fP, d_status, nullptr, nullptr, nullptr, nullptr);
+    DevBuf pm, pP, pC;
+    if ((rc = pm.alloc(sizeof(double) * (size_t)T * D * ld)) || (rc = pP.alloc(sizeof(double) * (size_t)T * D * D * ld)) ||
+        (rc = pC.alloc(sizeof(double) * (size_t)T * D * (D + dq) * ld)))
+        return rc;
+    int c_cols = D;
+    rc = filter_forward_aug_impl(h_dyn, f_dyn, h_obs, f_obs, D, B, ld, T, d_y, d_m0, d_P0, q_mean, q_cov, dq, r_mean, r_cov,
+                                 dr, d_fm, d_fP, d_status, pm.d(), pP.d(), pC.d(), &c_cols);
+    if (rc) return rc;
+    rc = launch_rts_backward(D, B, ld, T, d_fm, d_fP, pm.d(), pP.d(), pC.d(), d_sm, d_sP, d_status, stream(), c_cols);
+    hipError_t e = hipStreamSynchronize(stream());
+    if (rc) return rc;
+    SSMQ_HIP(e);
+    return SSMQ_OK;
 }
 
 extern "C" int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
@@ -1244,7 +1302,7 @@ extern "C" int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integran
     rc = filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, GQG, R, d_fm, d_fP, d_status,
                              nullptr, 0.0, pm.d(), pP.d(), pC.d());
     if (rc) return rc;
-    rc = launch_rts_backward(D, B, ld, T, d_fm, d_fP, pm.d(), pP.d(), pC.d(), d_sm, d_sP, d_status, stream());
+    rc = launch_rts_backward(D, B, ld, T, d_fm, d_fP, pm.d(), pP.d(), pC.d(), d_sm, d_sP, d_status, stream(), D);
     if (rc) {
         hipStreamSynchronize(stream());
         return rc;

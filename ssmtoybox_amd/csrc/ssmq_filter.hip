@@ -330,6 +330,8 @@ struct RtsArgs {
     int32_t *status;             // |= (1 << 30) if a predictive covariance is not PD
     int64_t B, ld;
     int32_t T;
+    int32_t c_cols;              // columns stored per row of pC (D; D + dim_noise for a model that takes its noise as an
+                                 // argument - the smoother uses the state columns only, ssinf.py:294-295)
 };
 
 // every element of the five input sequences is read exactly once and the outputs are written once: streaming accesses
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(kUpdBlock) void k_rts_backward(const RtsArgs a) {
             double v[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                double s = RTS_LD(a.pC[((int64_t)k * D * D + i * D + d) * ld + b]);
+                double s = RTS_LD(a.pC[((int64_t)k * D * a.c_cols + i * a.c_cols + d) * ld + b]);
 #pragma unroll
                 for (int q = 0; q < i; ++q) s -= S[SSMQ_PK(i, q)] * v[q];
                 v[i] = div_nr(s, S[SSMQ_PK(i, i)]);
@@ -442,8 +444,9 @@ static void launch_rts(const RtsArgs &a, hipStream_t s) {
 }
 
 int launch_rts_backward(int D, int64_t B, int64_t ld, int T, const double *fm, const double *fP, const double *pm,
-                        const double *pP, const double *pC, double *sm, double *sP, int32_t *status, hipStream_t s) {
-    RtsArgs a{fm, fP, pm, pP, pC, sm, sP, status, B, ld, T};
+                        const double *pP, const double *pC, double *sm, double *sP, int32_t *status, hipStream_t s,
+                        int c_cols) {
+    RtsArgs a{fm, fP, pm, pP, pC, sm, sP, status, B, ld, T, c_cols > 0 ? c_cols : D};
     switch (D) {
         case 1: launch_rts<1>(a, s); break;
         case 2: launch_rts<2>(a, s); break;

@@ -331,7 +331,6 @@ __device__ __forceinline__ void augment(const double (&m)[D], const double *Pl, 
 template <int D, int Y, int DQ, int DR, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, bool KEEP = false>
 __global__ __launch_bounds__(kSmallBlock, (D + DQ >= 5 ? 1 : 2)) void k_filter_fused_aug(const AugArgs a) {
     constexpr int DA = D + DQ, DO = D + DR;
-    static_assert(!KEEP || (DQ == 0 && DR == 0), "the smoother covers additive-noise models");
     const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;
     if ((int64_t)b >= a.B) return;
     const int64_t ld = a.ld;
@@ -460,6 +459,15 @@ struct AugEntry {
 #define SSMQ_AUG_ONE(FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO)                                                        \
     {FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO, 0, &launch_fused_aug<D, Y, DQ, DR, ND, NO, FD, FO, FORM, TP, SELO, false>, \
      "k_filter_fused_aug<D=" #D ",Y=" #Y ",DQ=" #DQ ",DR=" #DR ",ND=" #ND ",NO=" #NO "," #FD "," #FO "," #FORM ",TP=" #TP ">"}
+// models that take their noise as an argument, predictive moments kept for the smoother (the cross-covariance is stored
+// with its state columns only)
+#define SSMQ_AUG_KEEP_ONE(FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO)                                                      \
+    {FD, FO, D, Y, DQ, DR, ND, NO, FORM, TP, SELO, 1, &launch_fused_aug<D, Y, DQ, DR, ND, NO, FD, FO, FORM, TP, SELO, true>, \
+     "k_filter_fused_aug_keep<D=" #D ",Y=" #Y ",DQ=" #DQ ",DR=" #DR ",ND=" #ND ",NO=" #NO "," #FD "," #FO "," #FORM ",TP=" #TP ">"}
+#define SSMQ_AUG_KEEP(FD, FO, D, Y, DQ, DR, ND, NO, SELO)                          \
+    SSMQ_AUG_KEEP_ONE(FD, FO, D, Y, DQ, DR, ND, NO, SSMQ_FORM_BQ, 0, SELO),        \
+    SSMQ_AUG_KEEP_ONE(FD, FO, D, Y, DQ, DR, ND, NO, SSMQ_FORM_BQ, 1, SELO),        \
+    SSMQ_AUG_KEEP_ONE(FD, FO, D, Y, DQ, DR, ND, NO, SSMQ_FORM_SIGMA, 0, SELO)
 // additive models, predictive moments kept for the smoother
 #define SSMQ_KEEP_ONE(FD, FO, D, Y, N, FORM, TP, SELO)                                                            \
     {FD, FO, D, Y, 0, 0, N, N, FORM, TP, SELO, 1, &launch_fused_aug<D, Y, 0, 0, N, N, FD, FO, FORM, TP, SELO, true>, \
@@ -477,6 +485,8 @@ static const AugEntry kAug[] = {
     SSMQ_AUG(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 4, 4, 0),      // spherical-radial points in 2-D
 #ifndef SSMQ_FUSED_UNGM_ONLY
     SSMQ_AUG(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 5, 5, 0),      // unscented points in 2-D
+    SSMQ_AUG_KEEP(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 4, 4, 0),
+    SSMQ_AUG_KEEP(SSMQ_F_UNGMNA_DYN, SSMQ_F_UNGMNA_MEAS, 1, 1, 1, 1, 5, 5, 0),
     SSMQ_AUG_ONE(SSMQ_F_CTRS_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 2, 0, 15, 11, SSMQ_FORM_SIGMA, 0, 0),
     SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 2, 0),
     SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 0),

@@ -82,8 +82,10 @@ class GaussianInference:
                                                ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
                                                ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_forward_dev')
 
-    def _launch_aug(self, lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st):
-        """Noise enters the model functions: augmented moments per transform (ssinf.py:271-272, 282-283, 294-295)."""
+    def _launch_aug(self, lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st, d_sm=None,
+                    d_sP=None):
+        """Noise enters the model functions: augmented moments per transform (ssinf.py:271-272, 282-283, 294-295).
+        With d_sm / d_sP the RTS smoother runs as well (`ssmq_filter_smooth_aug_dev`)."""
         if self.mod_dyn.noise_additive:
             dq, (qm, pqm) = 0, (None, None)
             qc, pqc = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
@@ -98,6 +100,15 @@ class GaussianInference:
             dr = int(np.atleast_1d(self.r_mean).shape[0])
             rm, prm = _lib.as_c(np.atleast_1d(self.r_mean))
             rc, prc = _lib.as_c(np.atleast_2d(self.r_cov))
+        if d_sm is not None:
+            _lib.check(lib.ssmq_filter_smooth_aug_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
+                                                      ctypes.byref(f_obs), self.mod_dyn.dim_state, B, ld, T,
+                                                      ctypes.c_void_p(d_y.ptr), ctypes.c_void_p(d_m0.ptr),
+                                                      ctypes.c_void_p(d_P0.ptr), pqm, pqc, dq, prm, prc, dr,
+                                                      ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
+                                                      ctypes.c_void_p(d_sm.ptr), ctypes.c_void_p(d_sP.ptr),
+                                                      ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_smooth_aug_dev')
+            return
         _lib.check(lib.ssmq_filter_forward_aug_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
                                                    ctypes.byref(f_obs), self.mod_dyn.dim_state, B, ld, T,
                                                    ctypes.c_void_p(d_y.ptr), ctypes.c_void_p(d_m0.ptr),
@@ -179,18 +190,19 @@ class GaussianInference:
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
         f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
         h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
-        if smooth and not self._additive:
-            raise NotImplementedError('the device smoother covers additive-noise models')
         if smooth:
             d_sm, d_sP = _lib.DeviceBuffer(8 * T * D * ld), _lib.DeviceBuffer(8 * T * D * D * ld)
-            gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
-            rr, pr = _lib.as_c(self.r_cov)
-            _lib.check(lib.ssmq_filter_smooth_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
-                                                  ctypes.byref(f_obs), B, ld, T, ctypes.c_void_p(d_y.ptr),
-                                                  ctypes.c_void_p(d_m0.ptr), ctypes.c_void_p(d_P0.ptr), pg, pr,
-                                                  ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
-                                                  ctypes.c_void_p(d_sm.ptr), ctypes.c_void_p(d_sP.ptr),
-                                                  ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_smooth_dev')
+            if not self._additive:
+                self._launch_aug(lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st, d_sm, d_sP)
+            else:
+                gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
+                rr, pr = _lib.as_c(self.r_cov)
+                _lib.check(lib.ssmq_filter_smooth_dev(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
+                                                      ctypes.byref(f_obs), B, ld, T, ctypes.c_void_p(d_y.ptr),
+                                                      ctypes.c_void_p(d_m0.ptr), ctypes.c_void_p(d_P0.ptr), pg, pr,
+                                                      ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
+                                                      ctypes.c_void_p(d_sm.ptr), ctypes.c_void_p(d_sP.ptr),
+                                                      ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_smooth_dev')
             self.sm_mean = np.ascontiguousarray(d_sm.download((T, D, ld))[:, :, :B].transpose(1, 0, 2))
             self.sm_cov = np.ascontiguousarray(d_sP.download((T, D, D, ld))[:, :, :, :B].transpose(1, 2, 0, 3))
             d_sm.free()

@@ -415,14 +415,19 @@ def g6_nonadditive():
             'gpqkf': ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut')}
     for name, alg in algs.items():
         fm, fc = np.full((1, steps, seeds), np.nan), np.full((1, 1, steps, seeds), np.nan)
+        sm, sc = fm.copy(), fc.copy()
         okm = np.ones(seeds, dtype=bool)
         for s in range(seeds):
             try:     # the reference raises LinAlgError when a predictive covariance loses positive definiteness
                 fm[..., s], fc[..., s] = alg.forward_pass(y[..., s])
+                # backward_pass is model-agnostic (ssinf.py:120-147): the cross-covariance it uses was cut back to the
+                # state columns in _time_update (:294-295)
+                sm[..., s], sc[..., s] = alg.backward_pass()
             except np.linalg.LinAlgError:
                 okm[s] = False
             alg.reset()
         out['ungmna_' + name + '_fm'], out['ungmna_' + name + '_fc'], out['ungmna_' + name + '_ok'] = fm, fc, okm
+        out['ungmna_' + name + '_sm'], out['ungmna_' + name + '_sc'] = sm, sc
     # zero-mean prior + cubature rule: P_y is exactly 0 at the first step and the reference raises for every trajectory
     dyn0 = ssmod.UNGMNATransition(GaussRV(1), q)
     alg = ssinf.CubatureKalman(dyn0, obs)
@@ -448,10 +453,13 @@ def g6_nonadditive():
     out['ctrs_x'], out['ctrs_y'], out['ctrs_m0'] = x, y, x0.mean
     alg = ssinf.UnscentedKalman(dyn, obs)
     fm, fc = np.zeros((5, steps, seeds)), np.zeros((5, 5, steps, seeds))
+    sm, sc = fm.copy(), fc.copy()
     for s in range(seeds):
         fm[..., s], fc[..., s] = alg.forward_pass(y[..., s])
+        sm[..., s], sc[..., s] = alg.backward_pass()
         alg.reset()
     out['ctrs_ukf_fm'], out['ctrs_ukf_fc'] = fm, fc
+    out['ctrs_ukf_sm'], out['ctrs_ukf_sc'] = sm, sc
     save('g6_nonadditive', **out)
 
 

@@ -586,8 +586,18 @@ def test_ungmna_filter_golden(amd, golden, name):
     assert g['ungmna_' + name + '_ok'].all() and not alg.status.any()
     assert rel_err(fm, g['ungmna_' + name + '_fm']) < 1e-8, name
     assert within(cov_err(fP, g['ungmna_' + name + '_fc']), 1e-11, 'ungmna %s fP vs reference' % name), name
-    with pytest.raises(NotImplementedError):
-        alg.backward_pass_batch()
+    # RTS smoother: backward_pass of the reference does not look at the model; the cross-covariance is the one cut back
+    # to the state columns (ssinf.py:120-147, 294-295).  One kernel with the predictive moments kept, and the launch loop.
+    xs, Ps = alg.backward_pass_batch()
+    assert rel_err(xs, g['ungmna_' + name + '_sm']) < 1e-8, name
+    assert within(cov_err(Ps, g['ungmna_' + name + '_sc']), 1e-9, 'ungmna %s sP vs reference' % name), name
+    assert np.array_equal(xs[:, -2:], fm[:, -2:]) and np.array_equal(alg.fi_mean, fm)
+    os.environ['SSMQ_NO_FUSED'] = '1'
+    try:
+        xs2, Ps2 = alg.backward_pass_batch()
+    finally:
+        del os.environ['SSMQ_NO_FUSED']
+    assert rel_err(xs2, xs) < 1e-11 and within(cov_err(Ps2, Ps), 1e-10, 'ungmna %s smoother fused vs loop' % name)
     if name == 'ckf':
         # zero-mean prior: the cubature rule has no centre point, so m_pr = 0 and the measurement 0.05 r x^2 gets
         # P_y = 0 exactly at the first step - the reference raises LinAlgError for every trajectory (golden mask)
@@ -644,6 +654,11 @@ def test_ctrs_radar_ukf_golden(amd, golden):
     fm, fP = alg.forward_pass_batch(y)
     assert within(mean_err(fm, g['ctrs_ukf_fm']), 1e-11, 'ctrs ukf fm vs reference (row-scaled)')
     assert within(cov_err(fP, g['ctrs_ukf_fc']), 1e-10, 'ctrs ukf fP vs reference (entry-scaled)')
+    # smoother of a model with non-additive dynamics (7-input transform, cross-covariance with 7 columns of which the RTS
+    # pass uses the 5 state columns): launch loop + k_rts_backward
+    sm, sP = alg.backward_pass_batch()
+    assert within(mean_err(sm, g['ctrs_ukf_sm']), 1e-10, 'ctrs ukf sm vs reference (row-scaled)')
+    assert within(cov_err(sP, g['ctrs_ukf_sc']), 1e-9, 'ctrs ukf sP vs reference (entry-scaled)')
     # ragged batch through the same loop: 130 copies of the four trajectories
     yy = np.tile(y, (1, 1, 33))[..., :130]
     fm2, _ = alg.forward_pass_batch(yy)
