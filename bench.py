@@ -618,9 +618,9 @@ def main():
                                  'roofline_issue and DESIGN.md 3.4'},
             'rmse': rmse, 'nll': nll, 'inclination_indicator': float(np.mean(lcr)),
             'trajectories_aggregated': int(agg['count']),
-            # what the averages above leave out (summed over ranks, worst time step): failed filters / not-PD covariances
+            # what the averages above leave out (summed over ranks, worst time step): failed filters / singular covariances
             'excluded_failed_trajectories': int(agg['excluded_failed'].max()) if T else 0,
-            'excluded_not_pd_covariances': int(agg['excluded_not_pd'].max()) if T else 0,
+            'excluded_singular_covariances': int(agg['excluded_not_pd'].max()) if T else 0,
         }
         pm = pmc_issue()
         if headline and pm:

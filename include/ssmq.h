@@ -360,9 +360,11 @@ int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, 
  * research/tpq/tpq_base.py:154-160 does).  d_x, d_fm [T][D][ld], d_fP [T][D*D][ld] (the filter's output buffers),
  * d_status [ld] or NULL (nonzero = trajectory excluded).  sums: host [T][W], W = ssmq_error_sums_width(D) = D*D+D+4:
  *   se[D] sum (x-m)^2 | rmse sum ||x-m|| | nll sum | mse[D*D] sum (x-m)(x-m)' | n_ok | n_pd
- * n_ok = trajectories counted, n_pd = those whose P at this step is positive definite (only they enter the nll sum; the
- * reference's slogdet formula has no meaning otherwise).  Sums, not means: ranks add them (one all-reduce) before
- * dividing.  Deterministic summation order.  Synchronous.
+ * n_ok = trajectories counted (status 0), n_pd = those that entered the nll sum: every trajectory whose P is nonsingular.
+ * A P that is not positive definite does not stop the reference (inv(P), sign * logdet of slogdet, utils.py:143-148):
+ * such entries are handled by a second pass with an LU factorisation, so n_pd < n_ok only for a singular P (where
+ * numpy.linalg.inv raises).  Sums, not means: ranks add them (one all-reduce) before dividing.  Deterministic summation
+ * order.  Synchronous.
  */
 int ssmq_error_sums_width(int D);
 int ssmq_error_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm, const double *d_fP,
@@ -370,8 +372,9 @@ int ssmq_error_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, 
 /*
  * Second phase: sums of the log credibility ratio 10 (log10 dx'P^-1 dx - log10 dx'M^-1 dx) (utils.py:66-120) against
  * the GLOBAL per-step MSE matrices mse [T][D*D] (host; regularisation, e.g. + 1e-6 I of research/tpq/tpq_base.py:161,
- * already added).  sums: host [T][2] = lcr sum | n counted (status 0 and P positive definite; the reference's SVD
- * fallback for an indefinite P, utils.py:426-432, is not reproduced - such trajectories are left out and counted out).
+ * already added).  sums: host [T][2] = lcr sum | n counted (status 0).  A P that is not positive definite goes through
+ * the reference's fallback, mat_sqrt = u sqrt(s) of an SVD (utils.py:426-432), i.e. the quadratic form with |P|: a second
+ * pass with a Jacobi eigen-decomposition handles those entries.
  */
 int ssmq_lcr_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm, const double *d_fP,
                       const int32_t *d_status, const double *mse, double *sums);

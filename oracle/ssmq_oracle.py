@@ -781,7 +781,8 @@ def log_cred_ratio(x, m, P, mse):
 def error_sums(x, fm, fP, ok=None):
     """Per-time-step SUMS over the trajectories with ok[b] (the quantities research/tpq/tpq_base.py:154-160 averages):
     x, fm (D, T, B); fP (D, D, T, B).  Returns dict se (T, D), rmse (T,), nll (T,), mse (T, D, D), n_ok (T,), n_pd (T,)
-    - the layout of ssmq_error_sums_dev.  The nll sum runs over positive-definite P only."""
+    - the layout of ssmq_error_sums_dev.  The nll term is the reference's formula for ANY nonsingular P (inv + slogdet,
+    utils.py:143-148); n_pd counts the entries that entered it (all but those with a singular P)."""
     D, T, B = fm.shape
     ok = np.ones(B, dtype=bool) if ok is None else np.asarray(ok, dtype=bool)
     se, rmse, nll, mse = np.zeros((T, D)), np.zeros(T), np.zeros(T), np.zeros((T, D, D))
@@ -794,26 +795,23 @@ def error_sums(x, fm, fP, ok=None):
             mse[k] += np.outer(dx, dx)
             n_ok[k] += 1
             try:
-                np.linalg.cholesky(fP[..., k, b])
+                term = neg_log_likelihood(x[:, k, b], fm[:, k, b], fP[..., k, b])
             except np.linalg.LinAlgError:
                 continue
-            nll[k] += neg_log_likelihood(x[:, k, b], fm[:, k, b], fP[..., k, b])
+            nll[k] += term
             n_pd[k] += 1
     return dict(se=se, rmse=rmse, nll=nll, mse=mse, n_ok=n_ok, n_pd=n_pd)
 
 
 def lcr_sums(x, fm, fP, mse_global, ok=None):
     """Per-time-step sums of the log credibility ratio against the given (T, D, D) MSE matrices, over trajectories with
-    ok[b] and positive-definite P (layout of ssmq_lcr_sums_dev): dict lcr (T,), n (T,)."""
+    ok[b] (layout of ssmq_lcr_sums_dev): dict lcr (T,), n (T,).  A P that is not positive definite goes through mat_sqrt's
+    SVD branch, as in the reference (utils.py:426-432)."""
     D, T, B = fm.shape
     ok = np.ones(B, dtype=bool) if ok is None else np.asarray(ok, dtype=bool)
     lcr, n = np.zeros(T), np.zeros(T)
     for k in range(T):
         for b in np.flatnonzero(ok):
-            try:
-                np.linalg.cholesky(fP[..., k, b])
-            except np.linalg.LinAlgError:
-                continue
             lcr[k] += log_cred_ratio(x[:, k, b], fm[:, k, b], fP[..., k, b], mse_global[k])
             n[k] += 1
     return dict(lcr=lcr, n=n)

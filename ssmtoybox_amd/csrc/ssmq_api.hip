@@ -1332,6 +1332,11 @@ int launch_metrics(int phase, int D, int64_t B, int64_t ld, int T, const double 
                    const int32_t *status, const double *mse, double *partial, double *out, hipStream_t s);
 }
 
+namespace ssmq {
+int launch_metrics_indef(int phase, int D, int64_t B, int64_t ld, int T, const double *x, const double *fm, const double *fP,
+                         const int32_t *status, const double *mse, double *partial, double *out, hipStream_t s);
+}
+
 static int metrics_impl(int phase, int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm,
                         const double *d_fP, const int32_t *d_status, const double *mse, double *sums) {
     if (D < 1 || D > SSMQ_MAX_DIM || B < 0 || ld < B || T < 0 || !d_x || !d_fm || !d_fP || !sums || (phase == 2 && !mse)) {
@@ -1340,7 +1345,8 @@ static int metrics_impl(int phase, int D, int64_t B, int64_t ld, int T, const do
     }
     int rc = ensure_device();
     if (rc) return rc;
-    const int NV = phase == 1 ? metrics_values_per_step(D) : 2;
+    const int NV = phase == 1 ? metrics_values_per_step(D) : 2;     // values per step handed back
+    const int NI = phase == 1 ? NV : 3;                             // ... and reduced on the device
     if (T == 0) return SSMQ_OK;
     if (B == 0) {
         memset(sums, 0, sizeof(double) * (size_t)T * NV);
@@ -1348,8 +1354,8 @@ static int metrics_impl(int phase, int D, int64_t B, int64_t ld, int T, const do
     }
     hipStream_t s = stream();
     DevBuf partial, out, dm;
-    if ((rc = partial.alloc(sizeof(double) * (size_t)T * metrics_chunks(B) * NV)) ||
-        (rc = out.alloc(sizeof(double) * (size_t)T * NV)) || (rc = dm.alloc(sizeof(double) * (size_t)T * D * D)))
+    if ((rc = partial.alloc(sizeof(double) * (size_t)T * metrics_chunks(B) * NI)) ||
+        (rc = out.alloc(sizeof(double) * (size_t)T * NI)) || (rc = dm.alloc(sizeof(double) * (size_t)T * D * D)))
         return rc;
     if (phase == 2) SSMQ_HIP(hipMemcpyAsync(dm.p, mse, sizeof(double) * (size_t)T * D * D, hipMemcpyHostToDevice, s));
     rc = launch_metrics(phase, D, B, ld, T, d_x, d_fm, d_fP, d_status, dm.d(), partial.d(), out.d(), s);
@@ -1357,8 +1363,29 @@ static int metrics_impl(int phase, int D, int64_t B, int64_t ld, int T, const do
         hipStreamSynchronize(s);
         return rc;
     }
-    SSMQ_HIP(hipMemcpyAsync(sums, out.p, sizeof(double) * (size_t)T * NV, hipMemcpyDeviceToHost, s));
+    std::vector<double> h((size_t)T * NI);
+    SSMQ_HIP(hipMemcpyAsync(h.data(), out.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipStreamSynchronize(s));
+    // entries whose covariance is not positive definite were left out by the streaming kernels (they factor P): the
+    // reference's formulas do not need a positive-definite P (utils.py:143-148, 426-432) - a second pass adds them
+    const int i_ok = D + 2 + D * D, i_cnt = phase == 1 ? i_ok + 1 : 1, i_sum = phase == 1 ? D + 1 : 0;
+    bool left_out = false;
+    for (int t = 0; t < T && !left_out; ++t)
+        left_out = phase == 1 ? h[(size_t)t * NI + i_ok] > h[(size_t)t * NI + i_cnt] : h[(size_t)t * NI + 2] > 0.0;
+    if (left_out) {
+        rc = launch_metrics_indef(phase, D, B, ld, T, d_x, d_fm, d_fP, d_status, dm.d(), partial.d(), out.d(), s);
+        std::vector<double> extra((size_t)T * 2);
+        if (!rc) rc = hip_fail(hipMemcpyAsync(extra.data(), out.p, sizeof(double) * extra.size(), hipMemcpyDeviceToHost, s), "hipMemcpyAsync");
+        hipError_t e = hipStreamSynchronize(s);
+        if (rc) return rc;
+        SSMQ_HIP(e);
+        for (int t = 0; t < T; ++t) {
+            h[(size_t)t * NI + i_sum] += extra[(size_t)t * 2];
+            h[(size_t)t * NI + i_cnt] += extra[(size_t)t * 2 + 1];
+        }
+    }
+    for (int t = 0; t < T; ++t)
+        for (int v = 0; v < NV; ++v) sums[(size_t)t * NV + v] = h[(size_t)t * NI + v];
     return SSMQ_OK;
 }
 

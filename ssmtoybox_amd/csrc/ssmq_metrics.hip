@@ -213,13 +213,13 @@ __global__ __launch_bounds__(kMetBlock) void k_error_sums_generic(MetArgs a) {
     block_sums(acc, NA, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * NA);
 }
 
-// phase 2 values per time step: lcr | n counted
+// phase 2 values per time step: lcr | n counted | n left to the second pass (P not positive definite)
 template <int D>
 __global__ __launch_bounds__(kMetBlock) void k_lcr_sums(MetArgs a) {
     constexpr int TRI = D * (D + 1) / 2;
     const int t = blockIdx.y;
     extern __shared__ double sh[];
-    double acc[2] = {0.0, 0.0};
+    double acc[3] = {0.0, 0.0, 0.0};
     const double *x = a.x + (int64_t)t * D * a.ld, *fm = a.fm + (int64_t)t * D * a.ld;
     const double *fP = a.fP + (int64_t)t * D * D * a.ld;
     // the step's MSE matrix is the same for every trajectory: wave-uniform loads, factored once per thread
@@ -241,19 +241,22 @@ __global__ __launch_bounds__(kMetBlock) void k_lcr_sums(MetArgs a) {
         for (int i = 0; i < D; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) L[SSMQ_PK(i, j)] = SSMQ_MLOAD(fP[((int64_t)i * D + j) * a.ld + b]);
-        if (!chol_packed<D>(L)) continue;      // the reference falls back to an SVD square root here (utils.py:426-432)
+        if (!chol_packed<D>(L)) {              // the reference's SVD square root (utils.py:426-432): k_indef_sums
+            acc[2] += 1.0;
+            continue;
+        }
         const double qa = whitened_norm2_packed<D>(L, dx), qb = whitened_norm2_packed<D>(M, dx);
         acc[0] += 10.0 * (log10(qa) - log10(qb));
         acc[1] += 1.0;
     }
-    block_sums_fixed<2>(acc, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * 2);
+    block_sums_fixed<3>(acc, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * 3);
 }
 
 __global__ __launch_bounds__(kMetBlock) void k_lcr_sums_generic(MetArgs a) {
     const int D = a.D;
     const int t = blockIdx.y;
     extern __shared__ double sh[];
-    double acc[2] = {0.0, 0.0};
+    double acc[3] = {0.0, 0.0, 0.0};
     const double *x = a.x + (int64_t)t * D * a.ld, *fm = a.fm + (int64_t)t * D * a.ld;
     const double *fP = a.fP + (int64_t)t * D * D * a.ld;
     double M[kMetMaxD * kMetMaxD];
@@ -268,10 +271,142 @@ __global__ __launch_bounds__(kMetBlock) void k_lcr_sums_generic(MetArgs a) {
         for (int d = 0; d < D; ++d) dx[d] = x[(int64_t)d * a.ld + b] - fm[(int64_t)d * a.ld + b];
         for (int i = 0; i < D; ++i)
             for (int j = 0; j <= i; ++j) P[i * D + j] = fP[((int64_t)i * D + j) * a.ld + b];
-        if (!chol_dense<0>(P, D)) continue;
+        if (!chol_dense<0>(P, D)) {
+            acc[2] += 1.0;
+            continue;
+        }
         const double qa = whitened_norm2<0>(P, dx, D), qb = whitened_norm2<0>(M, dx, D);
         acc[0] += 10.0 * (log10(qa) - log10(qb));
         acc[1] += 1.0;
+    }
+    block_sums(acc, 3, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * 3);
+}
+
+// ---- covariances that are not positive definite ----------------------------------------------------------------------
+// The reference's metrics do not need a positive-definite P: neg_log_likelihood uses inv(P) and sign * logdet of
+// slogdet (utils.py:143-148), log_cred_ratio's mat_sqrt falls back to u sqrt(s) of an SVD (utils.py:426-432), i.e. the
+// quadratic form with |P| = U S U'.  The streaming kernels above go through the Cholesky factor and leave such entries
+// out; when the counts say that some were left out, this kernel makes a second pass that adds exactly those terms:
+//   phase 1: 0.5 (sign log|det P| + dx' P^-1 dx + D log 2 pi) from an LU factorisation with partial pivoting of the
+//            full matrix;  phase 2: 10 (log10 dx'|P|^-1 dx - log10 dx' M^-1 dx), |P| through a Jacobi
+//            eigen-decomposition of the symmetric part (eigenvalues in absolute value).
+// Rare path, run-time D, dense arrays in scratch; same deterministic two-level reduction.  partial row: term sum | count.
+__device__ bool lu_solve_logdet(double *A, const double *rhs, double *z, int n, double *sign, double *logabs) {
+    int perm_sign = 1;
+    double la = 0.0;
+    for (int i = 0; i < n; ++i) z[i] = rhs[i];
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double best = fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; ++i)
+            if (fabs(A[i * n + k]) > best) { best = fabs(A[i * n + k]); p = i; }
+        if (!(best > 0.0)) return false;           // singular (or NaN): numpy.linalg.inv raises
+        if (p != k) {
+            for (int j = 0; j < n; ++j) { const double t = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = t; }
+            const double t = z[k]; z[k] = z[p]; z[p] = t;
+            perm_sign = -perm_sign;
+        }
+        const double piv = A[k * n + k];
+        if (piv < 0.0) perm_sign = -perm_sign;
+        la += log(fabs(piv));
+        for (int i = k + 1; i < n; ++i) {
+            const double l = A[i * n + k] / piv;
+            for (int j = k + 1; j < n; ++j) A[i * n + j] -= l * A[k * n + j];
+            z[i] -= l * z[k];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s2 = z[i];
+        for (int j = i + 1; j < n; ++j) s2 -= A[i * n + j] * z[j];
+        z[i] = s2 / A[i * n + i];
+    }
+    *sign = (double)perm_sign;
+    *logabs = la;
+    return true;
+}
+
+// dx' |S|^-1 dx for the symmetric matrix S (destroyed): cyclic Jacobi rotations, V accumulates the eigenvectors
+__device__ double abs_quadratic_form(double *S, double *V, const double *dx, int n) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag += S[i * n + i] * S[i * n + i];
+            for (int j = 0; j < i; ++j) off += S[i * n + j] * S[i * n + j];
+        }
+        if (!(off > 1e-32 * diag)) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = S[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (S[q * n + q] - S[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double skp = S[k * n + p], skq = S[k * n + q];
+                    S[k * n + p] = c * skp - sn * skq;
+                    S[k * n + q] = sn * skp + c * skq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double spk = S[p * n + k], sqk = S[q * n + k];
+                    S[p * n + k] = c * spk - sn * sqk;
+                    S[q * n + k] = sn * spk + c * sqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - sn * vkq;
+                    V[k * n + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    double q = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double u = 0.0;
+        for (int k = 0; k < n; ++k) u += V[k * n + i] * dx[k];
+        q += u * u / fabs(S[i * n + i]);
+    }
+    return q;
+}
+
+__global__ __launch_bounds__(kMetBlock) void k_indef_sums(MetArgs a, int phase) {
+    const int D = a.D;
+    const int t = blockIdx.y;
+    extern __shared__ double sh[];
+    double acc[2] = {0.0, 0.0};
+    const double *x = a.x + (int64_t)t * D * a.ld, *fm = a.fm + (int64_t)t * D * a.ld;
+    const double *fP = a.fP + (int64_t)t * D * D * a.ld;
+    double M[kMetMaxD * kMetMaxD];
+    bool m_ok = true;
+    if (phase == 2) {
+        for (int i = 0; i < D * D; ++i) M[i] = a.mse[(int64_t)t * D * D + i];
+        m_ok = chol_dense<0>(M, D);
+    }
+    const int64_t base = (int64_t)blockIdx.x * kMetBlock * kMetPerThread;
+    for (int r = 0; r < kMetPerThread && m_ok; ++r) {
+        const int64_t b = base + (int64_t)r * kMetBlock + threadIdx.x;
+        if (b >= a.B) break;
+        if (a.status && a.status[b] != 0) continue;
+        double dx[kMetMaxD], P[kMetMaxD * kMetMaxD], W[kMetMaxD * kMetMaxD], z[kMetMaxD];
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j <= i; ++j) W[i * D + j] = fP[((int64_t)i * D + j) * a.ld + b];
+        if (chol_dense<0>(W, D)) continue;          // positive definite: the streaming kernel has counted it
+        for (int d = 0; d < D; ++d) dx[d] = x[(int64_t)d * a.ld + b] - fm[(int64_t)d * a.ld + b];
+        for (int i = 0; i < D * D; ++i) P[i] = fP[(int64_t)i * a.ld + b];
+        if (phase == 1) {
+            double sign, logabs;
+            if (!lu_solve_logdet(P, dx, z, D, &sign, &logabs)) continue;
+            double q = 0.0;
+            for (int d = 0; d < D; ++d) q += dx[d] * z[d];
+            acc[0] += 0.5 * (sign * logabs + q + D * 1.8378770664093453);
+            acc[1] += 1.0;
+        } else {
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) W[i * D + j] = 0.5 * (P[i * D + j] + P[j * D + i]);
+            const double qa = abs_quadratic_form(W, P, dx, D), qb = whitened_norm2<0>(M, dx, D);
+            acc[0] += 10.0 * (log10(qa) - log10(qb));
+            acc[1] += 1.0;
+        }
     }
     block_sums(acc, 2, sh, a.partial + ((int64_t)t * a.chunks + blockIdx.x) * 2);
 }
@@ -301,7 +436,7 @@ __global__ void k_reduce_partials(const double *partial, double *out, int chunks
 template <int DT>
 hipError_t launch_phase(const MetArgs &a, int phase, hipStream_t s) {
     const int D = DT > 0 ? DT : a.D;
-    const int NV = phase == 1 ? met_nv(D) : 2;       // upper bound of the packed row
+    const int NV = phase == 1 ? met_nv(D) : 3;       // upper bound of the packed row
     const size_t lds = sizeof(double) * (kMetBlock / 64) * NV;
     dim3 grid((unsigned)a.chunks, (unsigned)a.T);
     if constexpr (DT > 0) {
@@ -319,6 +454,20 @@ hipError_t launch_phase(const MetArgs &a, int phase, hipStream_t s) {
 }
 
 }  // namespace
+
+int metrics_chunks(int64_t B);
+
+// second pass over the entries whose covariance is not positive definite: d_out [T][2] = term sum | count
+int launch_metrics_indef(int phase, int D, int64_t B, int64_t ld, int T, const double *x, const double *fm, const double *fP,
+                         const int32_t *status, const double *mse, double *partial, double *out, hipStream_t s) {
+    MetArgs a{x, fm, fP, status, mse, partial, B, ld, D, T, metrics_chunks(B)};
+    hipLaunchKernelGGL(k_indef_sums, dim3((unsigned)a.chunks, (unsigned)T), dim3(kMetBlock), sizeof(double) * (kMetBlock / 64) * 2,
+                       s, a, phase);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_indef_sums");
+    hipLaunchKernelGGL(k_reduce_partials, dim3((T * 2 + 255) / 256), dim3(256), 0, s, partial, out, a.chunks, 2, T * 2, 0);
+    return hip_fail(hipGetLastError(), "k_reduce_partials");
+}
 
 int metrics_values_per_step(int D) { return met_nv(D); }
 
@@ -339,7 +488,7 @@ int launch_metrics(int phase, int D, int64_t B, int64_t ld, int T, const double 
         default: e = launch_phase<0>(a, phase, s); break;
     }
     if (e != hipSuccess) return hip_fail(e, phase == 1 ? "k_error_sums" : "k_lcr_sums");
-    const int NV = phase == 1 ? met_nv(D) : 2, total = T * NV;
+    const int NV = phase == 1 ? met_nv(D) : 3, total = T * NV;
     hipLaunchKernelGGL(k_reduce_partials, dim3((total + 255) / 256), dim3(256), 0, s, partial, out, a.chunks, NV, total,
                        phase == 1 ? D : 0);
     return hip_fail(hipGetLastError(), "k_reduce_partials");

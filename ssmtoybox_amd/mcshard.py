@@ -178,8 +178,9 @@ def device_error_sums(D, B, ld, T, d_x, d_fm, d_fP, d_status=None):
     d_x, d_fm: DeviceBuffer planes [T][D][ld]; d_fP [T][D*D][ld] (the buffers the filter wrote); d_status [ld] or None.
     Returns a dict of arrays: se (T, D) squared error (utils.py:18-38), rmse (T,) sum of ||x - m|| (the quantity
     research/tpq/tpq_base.py:158-159 averages), nll (T,) negative log-likelihood (utils.py:123-148), mse (T, D, D) outer
-    products (utils.py:41-64), n_ok (T,) trajectories counted, n_pd (T,) of them with positive-definite P (nll terms),
-    n_all (T,) trajectories this rank ran (so that what was left out is known after the reduction)."""
+    products (utils.py:41-64), n_ok (T,) trajectories counted, n_pd (T,) of them in the nll sum (all whose P is
+    nonsingular: the reference's formula does not need a positive-definite P), n_all (T,) trajectories this rank ran
+    (so that what was left out is known after the reduction)."""
     lib = _lib.load()
     W = lib.ssmq_error_sums_width(D)
     if W < 0:
@@ -231,8 +232,8 @@ def finalize(total, strict=False):
     """Global averages from all-reduced phase-1 sums: rmse_avg (T,), nll_avg (T,), mse (T, D, D), rmse_total (), count ()
     trajectories aggregated, and what was LEFT OUT of them: excluded_failed (T,) trajectories whose filter had failed
     (lost positive definiteness: the reference raises LinAlgError there and has no result for the run at all),
-    excluded_not_pd (T,) finished trajectories whose filtered covariance at that step is not positive definite (no NLL
-    term).  The reference averages over all runs (utils.py:123-148 via research/tpq/tpq_base.py:154-172), so an average
+    excluded_not_pd (T,) finished trajectories whose filtered covariance at that step is singular (no NLL term:
+    numpy.linalg.inv raises there).  The reference averages over all runs (utils.py:123-148 via research/tpq/tpq_base.py:154-172), so an average
     taken over fewer runs is not the same statistic: with strict=True the averages of a step with exclusions are NaN."""
     n = np.maximum(total['n_ok'], 1.0)
     T = total['rmse'].shape[0]

@@ -488,6 +488,25 @@ def g7_metrics():
         for key, val in (('x', x), ('m', m), ('P', P), ('se', se), ('mse', mse), ('nll', nll), ('lcr', lcr),
                          ('rmse', rmse)):
             out[tag + '_' + key] = val
+        if tag in ('d1', 'd3'):
+            # covariances that are NOT positive definite (an eigenvalue flipped, slightly unsymmetric as a filtered
+            # covariance is): neg_log_likelihood goes through inv / slogdet, log_cred_ratio through mat_sqrt's SVD
+            # branch (utils.py:143-148, 426-432)
+            rng2 = np.random.default_rng(70 + D)        # own stream: the draws above stay what they were
+            Pi = P.copy()
+            flip = rng2.random((T, M)) < 0.25
+            for k in range(T):
+                for i in range(M):
+                    if flip[k, i]:
+                        w, v = np.linalg.eigh(Pi[..., k, i])
+                        w[rng2.integers(D)] *= -1.0
+                        Pi[..., k, i] = v.dot(np.diag(w)).dot(v.T) + 1e-13 * rng2.standard_normal((D, D))
+            nlli, lcri = np.empty((T, M)), np.empty((T, M))
+            for k in range(T):
+                for i in range(M):
+                    nlli[k, i] = neg_log_likelihood(x[:, k, i], m[:, k, i], Pi[..., k, i])
+                    lcri[k, i] = log_cred_ratio(x[:, k, i], m[:, k, i], Pi[..., k, i], mse[..., k] + reg)
+            out[tag + '_Pi'], out[tag + '_flip'], out[tag + '_nlli'], out[tag + '_lcri'] = Pi, flip, nlli, lcri
     save('g7_metrics', **out)
 
 
