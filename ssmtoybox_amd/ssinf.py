@@ -458,9 +458,14 @@ class MarginalInference(GaussianInference):
                 int(np.flatnonzero(st)[0]), int(st[np.flatnonzero(st)[0]])))
         return (m, c) if np.ndim(theta) == 2 else (m[0], c[0])
 
-    def _measurement_update(self, y, time=None):
-        """ssinf.py:1083-1115: all 2 param_dim theta points in one device call."""
-        self._param_posterior_moments(y, time)
+    def _measurement_update(self, y, time=None, laplace=None):
+        """ssinf.py:1083-1115: all 2 param_dim theta points in one device call.  laplace = (mean, cov) of the parameter
+        posterior replaces the optimiser run (a caller that has them already, e.g. to continue from another
+        implementation's iterates)."""
+        if laplace is None:
+            self._param_posterior_moments(y, time)
+        else:
+            self.param_mean, self.param_cov = np.asarray(laplace[0], dtype=float), np.asarray(laplace[1], dtype=float)
         chol = np.linalg.cholesky(self.param_cov)
         param_pts = self.param_mean[:, None] + chol.dot(self.param_upts)
         mean, cov = self._state_posterior_moments(param_pts.T, y, time)
