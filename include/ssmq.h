@@ -40,7 +40,7 @@ extern "C" {
 #define SSMQ_E_NOMEM (-4)
 
 #define SSMQ_MAX_FPAR 16 /* doubles of integrand constants */
-#define SSMQ_MAX_FIDX 8  /* state-index entries */
+#define SSMQ_MAX_FIDX 16 /* state-index entries (= SSMQ_MAX_DIM: any sub-state of any state) */
 #define SSMQ_MAX_DIM 16  /* D, E (input / output dimension of a transform) */
 #define SSMQ_MAX_PTS 1024 /* N (sigma points) */
 

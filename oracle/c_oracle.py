@@ -13,7 +13,7 @@ DP = ctypes.POINTER(ctypes.c_double)
 
 class Integrand(ctypes.Structure):
     _fields_ = [('fid', ctypes.c_int), ('npar', ctypes.c_int), ('nidx', ctypes.c_int), ('par', ctypes.c_double * 16),
-                ('idx', ctypes.c_int * 8)]
+                ('idx', ctypes.c_int * 16)]
 
     @classmethod
     def make(cls, fid, par=(), idx=None):

@@ -36,7 +36,7 @@ enum {
 typedef struct {
     int fid, npar, nidx;
     double par[16];
-    int idx[8];
+    int idx[16];
 } orc_integrand;
 
 /* lower Cholesky, LAPACK dpotf2 order (numpy.linalg.cholesky); returns 0 ok, 1 not positive definite */

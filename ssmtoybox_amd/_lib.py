@@ -13,7 +13,7 @@ c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
 SSMQ_MAX_FPAR = 16
-SSMQ_MAX_FIDX = 8
+SSMQ_MAX_FIDX = 16
 FORM_BQ, FORM_SIGMA = 0, 1
 EMV_DIAG, EMV_BROADCAST = 0, 1
 

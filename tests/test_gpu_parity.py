@@ -1273,6 +1273,42 @@ def test_two_pass_matrix_core_route(amd, monkeypatch, case):
     assert np.abs(cg - cf[:64]).max() / sc < 1e-13 and np.abs(xg - cfx[:64]).max() / np.abs(cfx3[ok]).max() < 1e-13
 
 
+def test_state_index_with_more_than_eight_entries(amd):
+    """A measurement-type integrand that reads 10 selected entries of a 13-dimensional state (state_index of 10 entries):
+    the device integrand evaluates on the selected sub-state (generic kernel), as the oracle's restatement of
+    MeasurementModel.meas_eval's state_index selection does (ssmod.py:990-991).  The reference has no model above seven
+    inputs; the 10-D synthetic model stands in."""
+    from ssmtoybox_amd import _lib
+    from oracle import c_oracle as co
+    lib = _lib.load()
+    D, E, B = 13, 10, 200
+    sidx = [12, 0, 3, 4, 7, 1, 9, 10, 2, 6]
+    rng = np.random.default_rng(23)
+    pts = orc.points_ut(D)
+    wm, wc = orc.weights_ut(D)
+    N = pts.shape[1]
+    h = lib.ssmq_transform_create(D, E, N, 1, _lib.as_c(pts)[1], _lib.as_c(wm)[1], _lib.as_c(wc)[1], None, None, 0, 0.0, None)
+    assert h
+    means = rng.standard_normal((B, D))
+    a = rng.standard_normal((B, D, D)) / np.sqrt(D)
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(D)
+    integ = _lib.Integrand.make(_lib.F_SMOOTH10D_DYN, (), sidx)
+    mf, cf, cfx = np.empty((B, E)), np.empty((B, E, E)), np.empty((B, E, D))
+    st = np.zeros(B, dtype=np.int32)
+    t0 = np.zeros(1)
+    _lib.check(lib.ssmq_apply_batch(ctypes.c_void_p(h), ctypes.byref(integ), B, _lib.as_c(means)[1], _lib.as_c(covs)[1],
+                                    _lib.as_c(t0)[1], 0, _lib.as_c(mf)[1], _lib.as_c(cf)[1], _lib.as_c(cfx)[1],
+                                    st.ctypes.data_as(_lib.c_int32_p)), 'ssmq_apply_batch')
+    lib.ssmq_transform_destroy(ctypes.c_void_p(h))
+    assert not st.any()
+    t, keep = co.make_transform(1, D, E, pts, wm, wc, integrand=co.Integrand.make(orc.F_SMOOTH10D_DYN, (), sidx))
+    omf, ocf, ocfx, ost = co.apply_batch(t, means, covs, 0.0)
+    for i in range(0, B, 7):
+        assert_moments_close((mf[i], cf[i], cfx[i]), (omf[i], ocf[i], ocfx[i]), covs[i], what=('idx10', i))
+    ref = orc.apply_sigma(orc.F_SMOOTH10D_DYN, means[0], covs[0], 0.0, pts, wm, wc, (), sidx)
+    assert_moments_close((mf[0], cf[0], cfx[0]), ref, covs[0], what='idx10 vs numpy oracle')
+
+
 def test_extreme_covariance_scales(amd):
     """The register kernels take square roots and reciprocals of the Cholesky pivots with a one-round refinement of
     v_rsq_f64 / v_rcp_f64 (csrc/ssmq_device.h) instead of the compiler's range-rescaled sequences: covariances scaled by

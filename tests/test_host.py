@@ -29,8 +29,8 @@ def test_header_symbols_exported():
 
 def test_integrand_struct_layout():
     from ssmtoybox_amd import _lib
-    # struct ssmq_integrand: 4 int32 + 16 doubles + 8 int32 = 176 bytes
-    assert ctypes.sizeof(_lib.Integrand) == 16 + 8 * 16 + 4 * 8
+    # struct ssmq_integrand: 4 int32 + 16 doubles + 16 int32 = 208 bytes
+    assert ctypes.sizeof(_lib.Integrand) == 16 + 8 * 16 + 4 * 16
     s = _lib.Integrand.make(12, (1.0, 2.0, 3.0, 4.0), (0, 2))
     assert (s.id, s.n_par, s.n_idx, s.par[3], s.idx[1]) == (12, 4, 2, 4.0, 2)
     with pytest.raises(ValueError):
