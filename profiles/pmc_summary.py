@@ -45,8 +45,10 @@ def main():
                             'fetch_factor': fr, 'write_factor': fw,
                             'note': 'bytes = counter_KiB * 1024 * factor; factor ~2 on the read side is the gfx950 '
                                     'FETCH_SIZE under-count'}}
+    out['_commit'] = os.environ.get('SSMQ_COMMIT', 'unknown')     # the tree these counters were collected on
     for (name, grid), v in fetch.items():
-        if 'k_apply_small<6' in name.replace(' ', '') or 'k_filter_fused' in name:
+        if ('k_apply_small<6' in name.replace(' ', '') or 'k_filter_fused' in name or 'k_fxwc_cov_mfma' in name or
+                'k_eval_wave' in name):
             w = write.get((name, grid), [0.0])
             rd = sum(v) / len(v) * 1024 * (fr or 2.0)
             wr = sum(w) / len(w) * 1024 * (fw or 1.0)
