@@ -466,18 +466,58 @@ def cpu_baseline_apply(tf, integ_id, integ_par, D, E, means, covs, budget_s, wha
                 passes, means.shape[0], what, total)}
 
 
-def pmc_issue(kernel_prefix='k_filter_fused'):
-    """SQ counters of the headline kernel from the committed summary (profiles/r02_fused_sq.csv: rocprofv3 --pmc passes of
-    tools/pmc_fused.sh; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles, MI355X_MICROARCH.md)."""
+def pmc_issue(kernel):
+    """SQ counters of a fused filter kernel from the committed summary (profiles/r02_fused_sq.csv: the rocprofv3 --pmc passes
+    of tools/pmc_fused.sh over this bench; SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles,
+    MI355X_MICROARCH.md).  `kernel`: the name bench.py reports (k_filter_fused<D=..,Y=..,ND=..,NO=..,..,FORM,TP=..,SELO=..,
+    OPT=..>); matched against the template arguments <D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, STU> of the profile."""
     import csv
+    import re
     path = os.path.join(ROOT, 'profiles', 'r02_fused_sq.csv')
+    if not kernel.startswith('k_filter_fused<'):
+        return None
+    nums = [int(v) for v in re.findall(r'=(\d+)', kernel)]
+    if len(nums) < 7:
+        return None
+    want = nums[:4] + [1 if 'SSMQ_FORM_SIGMA' in kernel else 0] + nums[4:7]      # D Y ND NO | FORM | TP SELO OPT
+    rows = {}
     try:
-        rows = {r['counter']: float(r['mean_per_launch']) for r in csv.DictReader(open(path)) if kernel_prefix in r['kernel']}
+        for r in csv.DictReader(open(path)):
+            if 'k_filter_fused<' not in r['kernel']:
+                continue
+            t = [int(v) for v in re.findall(r'-?\d+', r['kernel'].split('<', 1)[1].split('>')[0])]
+            if len(t) >= 10 and t[:4] + t[6:10] == want:
+                rows[r['counter']] = float(r['mean_per_launch'])
     except (OSError, KeyError, ValueError):
         return None
     need = ('SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAVES', 'SQ_ACTIVE_INST_VALU', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY',
             'SQ_INSTS_SALU')
     return rows if all(k in rows for k in need) else None
+
+
+def issue_block(kernel, T, ms_per_launch):
+    """The fused time loops are bound by fp64 VALU issue, not by HBM: instructions of the committed PMC pass against this
+    run's HIP-event launch time, per wave."""
+    pm = pmc_issue(kernel)
+    if not pm:
+        return None
+    waves = pm['SQ_WAVES']
+    valu_wave = pm['SQ_INSTS_VALU'] / waves
+    peak = CLOCK_HZ / 4.0       # one fp64 VALU instruction per 4 cycles per SIMD
+    achieved = valu_wave / (ms_per_launch * 1e-3)
+    return {'bound': 'fp64-issue', 'unit': 'VALU instructions/s per wave', 'achieved': achieved, 'peak': peak,
+            'frac': achieved / peak, 'kernel': kernel,
+            'valu_instructions_per_wave_per_step': valu_wave / T,
+            'salu_instructions_per_wave_per_step': pm['SQ_INSTS_SALU'] / waves / T,
+            'pmc': {'source': 'profiles/r02_fused_sq.csv (rocprofv3 --pmc, tools/pmc_fused.sh)',
+                    'frac_valu_x4_over_wave_cycles': pm['SQ_INSTS_VALU'] / pm['SQ_WAVE_CYCLES'],
+                    'active_inst_valu_over_wave_cycles': pm['SQ_ACTIVE_INST_VALU'] / pm['SQ_WAVE_CYCLES'],
+                    'wait_any_over_wave_cycles': pm['SQ_WAIT_ANY'] / pm['SQ_WAVE_CYCLES'],
+                    'wait_inst_any_over_wave_cycles': pm['SQ_WAIT_INST_ANY'] / pm['SQ_WAVE_CYCLES'],
+                    'waves': waves, 'simds': 1024},
+            'note': 'a wave issues one fp64 VALU instruction per 4 cycles at best; frac = this kernel\'s instructions per '
+                    'wave x 4 cycles / its launch time.  Waves beyond one per SIMD share the issue slots: with 1563 waves '
+                    'on 1024 SIMDs (B = 1e5) the SIMDs that host two set the time, frac per wave is then at most 0.5'}
 
 
 def timed_passes(wl, warmup, iters):
@@ -504,6 +544,9 @@ def filter_leg(amd, workload, filt, B, T, seed, cpu_sample, cpu_budget, what, wi
            'traffic': pmc_traffic(wl.kernel), 'kernel': wl.kernel, 'bytes_per_launch': wl.bytes_per_pass(),
            'ms_per_launch': ms, 'filter_steps_per_s': B * T / (ms * 1e-3), 'failed_trajectories': int((st != 0).sum()),
            'workload': what}
+    ib = issue_block(wl.kernel, T, ms)
+    if ib:
+        rec['issue'] = ib
     if with_cpu:
         cb, cfm, cfP, cst = cpu_baseline_filter(wl, cpu_sample, cpu_budget, what)
         rec['cpu_baseline'] = cb
@@ -622,27 +665,9 @@ def main():
             'excluded_failed_trajectories': int(agg['excluded_failed'].max()) if T else 0,
             'excluded_singular_covariances': int(agg['excluded_not_pd'].max()) if T else 0,
         }
-        pm = pmc_issue()
-        if headline and pm:
-            waves = pm['SQ_WAVES']
-            valu_wave = pm['SQ_INSTS_VALU'] / waves
-            peak = CLOCK_HZ / 4.0       # one fp64 VALU instruction per 4 cycles per SIMD
-            achieved = valu_wave / (pass_ms_dev * 1e-3)
-            out['roofline_issue'] = {
-                'bound': 'fp64-issue', 'unit': 'VALU instructions/s per wave (one wave per SIMD)',
-                'achieved': achieved, 'peak': peak, 'frac': achieved / peak, 'kernel': wl.kernel,
-                'valu_instructions_per_wave_per_step': valu_wave / T,
-                'salu_instructions_per_wave_per_step': pm['SQ_INSTS_SALU'] / waves / T,
-                'pmc': {'source': 'profiles/r02_fused_sq.csv (rocprofv3 --pmc, tools/pmc_fused.sh)',
-                        'frac_valu_x4_over_wave_cycles': pm['SQ_INSTS_VALU'] / pm['SQ_WAVE_CYCLES'],
-                        'active_inst_valu_over_wave_cycles': pm['SQ_ACTIVE_INST_VALU'] / pm['SQ_WAVE_CYCLES'],
-                        'wait_any_over_wave_cycles': pm['SQ_WAIT_ANY'] / pm['SQ_WAVE_CYCLES'],
-                        'wait_inst_any_over_wave_cycles': pm['SQ_WAIT_INST_ANY'] / pm['SQ_WAVE_CYCLES'],
-                        'waves': waves, 'simds': 1024},
-                'note': 'achieved uses this run\'s HIP-event launch time and the instruction count of the committed PMC '
-                        'pass; measured on this chip one wave issues a dependent fp64 instruction every 6.5 cycles and '
-                        'independent ones every 5.2 (tools/micro/fp64_lat.hip), so frac 0.62-0.77 is the ceiling of a '
-                        'single-wave recursion'}
+        ib = issue_block(wl.kernel, T, pass_ms_dev)
+        if ib:
+            out['roofline_issue'] = ib
     single = world == 1      # the single-kernel legs and the CPU baselines belong to the N = 1 run only
     with_cpu = not args.no_cpu_baseline
     if rank == 0 and single and with_cpu and headline:

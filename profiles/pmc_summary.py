@@ -52,7 +52,7 @@ def main():
             w = write.get((name, grid), [0.0])
             rd = sum(v) / len(v) * 1024 * (fr or 2.0)
             wr = sum(w) / len(w) * 1024 * (fw or 1.0)
-            key = name.split('(')[0].replace('void ssmq::', '').replace(' ', '')
+            key = name.replace('(anonymous namespace)::', '').split('(')[0].replace('void ssmq::', '').replace('ssmq::', '').replace(' ', '')
             out[key] = {'launches': len(v), 'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
                         'hbm_bytes_per_launch': rd + wr, 'grid': grid}
     print(json.dumps(out, indent=1))
