@@ -583,7 +583,9 @@ def make_comm():
         import torch.distributed as dist
         dist.init_process_group('gloo')
         return mcshard.TorchComm(dist), rank, world, local_rank
-    return mcshard.RcclComm(rank, world, force=os.environ.get('SSMQ_BENCH_FORCE_RCCL') == '1'), rank, world, local_rank
+    comm = mcshard.open_comm(rank, world, force_rccl=os.environ.get('SSMQ_BENCH_FORCE_RCCL') == '1',
+                             log=lambda m: sys.stderr.write(m + '\n'))
+    return comm, rank, world, local_rank
 
 
 def main():
@@ -651,7 +653,8 @@ def main():
                        '{} on {} (D={}, Y={}), {} MC trajectories per GPU x T={}'.format(args.filter, args.workload, wl.D,
                                                                                        wl.Y, B, T),
                        'mc_per_gpu': B, 'time_steps': T, 'parallelism': 'mc-shard x{}'.format(world),
-                       'collective': type(comm).__name__},
+                       'collective': type(comm).__name__ + (
+                           ' (gloo fallback: ' + comm.fallback_reason + ')' if getattr(comm, 'fallback_reason', '') else '')},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(wl.kernel),
                          'kernel': wl.kernel,

@@ -93,6 +93,8 @@ class RcclComm:
                                 break
                     except OSError:
                         pass
+                    if _fresh_content(self._file + '.st0') == b'0':
+                        raise _lib.SsmqError('RCCL rendezvous: rank 0 could not create the id')
                     if time.time() - t0 > timeout_s:
                         raise _lib.SsmqError('RCCL rendezvous: no id file {} after {} s'.format(self._file, timeout_s))
                     time.sleep(0.01)
@@ -117,11 +119,23 @@ class RcclComm:
     def close(self):
         self.barrier()                                # nobody is still looking for the id file
         _lib.check(_lib.load().ssmq_comm_destroy(), 'ssmq_comm_destroy')
-        if self.rank == 0 and self._rccl:
+        for path in ([self._file] if self.rank == 0 and self._rccl else []) + [getattr(self, 'status_file', None)]:
             try:
-                os.unlink(self._file)
+                if path:
+                    os.unlink(path)
             except OSError:
                 pass
+
+
+def _fresh_content(path):
+    """Content of a rendezvous file written by this launch (not older than the launcher), else None."""
+    try:
+        if os.path.getmtime(path) >= _process_start_time() - 1.0:
+            with open(path, 'rb') as f:
+                return f.read()
+    except OSError:
+        pass
+    return None
 
 
 def _process_start_time():
@@ -159,6 +173,52 @@ class TorchComm:
 
     def close(self):
         self.dist.barrier()
+
+
+def open_comm(rank, world, force_rccl=False, consensus_timeout_s=120.0, log=None):
+    """Communicator of a launched job: RCCL behind the C ABI; if creating it fails on ANY rank, every rank falls back to
+    a torch.distributed gloo group (the collective is a few KB at the end of the run, never the data path) and says so.
+    The ranks agree through one status file each next to the id file, so no rank is left waiting inside a collective
+    that others never entered."""
+    if world <= 1 and not force_rccl:
+        return SingleComm()
+    comm, err = None, ''
+    try:
+        comm = RcclComm(rank, world, force=force_rccl)
+    except Exception as e:                                   # noqa: BLE001 - any failure means "no RCCL on this rank"
+        err = '{}: {}'.format(type(e).__name__, e)
+    if world <= 1:
+        if comm is None:
+            raise _lib.SsmqError('RCCL communicator: ' + err)
+        return comm
+    base = _id_file()
+    with open('{}.st{}.tmp'.format(base, rank), 'wb') as f:
+        f.write(b'1' if comm is not None else b'0')
+    os.replace('{}.st{}.tmp'.format(base, rank), '{}.st{}'.format(base, rank))
+    t0, states = time.time(), {}
+    while len(states) < world and time.time() - t0 < consensus_timeout_s:
+        for r in range(world):
+            if r not in states:
+                v = _fresh_content('{}.st{}'.format(base, r))
+                if v in (b'0', b'1'):
+                    states[r] = v == b'1'
+        if len(states) < world:
+            time.sleep(0.01)
+    if len(states) == world and all(states.values()):
+        comm.status_file = '{}.st{}'.format(base, rank)
+        return comm
+    why = err or 'rank(s) {} reported no RCCL communicator'.format(
+        sorted(set(range(world)) - {r for r, ok in states.items() if ok}))
+    (log or (lambda m: None))('rank {}: RCCL unavailable ({}); all-reduce falls back to gloo'.format(rank, why))
+    import torch.distributed as dist
+    dist.init_process_group('gloo')                          # every rank is past the status files once this returns
+    try:
+        os.unlink('{}.st{}'.format(base, rank))
+    except OSError:
+        pass
+    fb = TorchComm(dist)
+    fb.fallback_reason = why
+    return fb
 
 
 def _as_comm(comm):

@@ -85,3 +85,39 @@ def test_two_rank_aggregation_matches_single_process():
     assert np.isclose(tot['rmse_total'], ref['rmse_total'], rtol=1e-12) and tot['count'] == ref['count']
     assert np.allclose(lcr['lcr'], ref_lcr['lcr'], rtol=1e-10, atol=1e-10) and np.array_equal(lcr['n'], ref_lcr['n'])
     assert mcshard.finalize_lcr(lcr).shape == (fm.shape[1],)
+
+
+def _fallback_worker(rank, world, port, idfile, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      SSMQ_RCCL_ID_FILE=idfile)
+    notes = []
+    comm = mcshard.open_comm(rank, world, log=notes.append, consensus_timeout_s=60.0)
+    out = comm.allreduce_sum(np.array([1.0 + rank, 10.0]))
+    mx = comm.allreduce_max(np.array([float(rank)]))
+    if rank == 0:
+        q.put((type(comm).__name__, getattr(comm, 'fallback_reason', ''), out, mx, notes))
+    comm.close()
+
+
+def test_launched_ranks_agree_on_gloo_when_rccl_is_unavailable(tmp_path):
+    """No GPU here, so no rank can create an RCCL communicator: both must notice (status files) and meet in a gloo group
+    instead of one of them raising while the other waits - the N > 1 launch of bench.py goes through the same function."""
+    import torch.multiprocessing as mp
+    from ssmtoybox_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip('RCCL is available on this machine; the fallback is not taken')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, str(tmp_path / 'id'), q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    name, why, out, mx, notes = q.get(timeout=180)
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    assert name == 'TorchComm' and why and notes
+    assert np.array_equal(out, [3.0, 20.0]) and np.array_equal(mx, [1.0])
