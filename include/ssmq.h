@@ -171,6 +171,21 @@ int ssmq_weights_bs(int D, int N, const double *xi, const double *par, int P, do
                     double *model_var, double *integral_var, int32_t *status);
 
 /*
+ * The polynomial expectations behind the Bayes-Sard weights as entry points of their own (ssmq_weights_bs forms them
+ * inline), for multi-indices mulind [D*NB] (row-major (D, NB)); any output may be NULL:
+ *   px [NB]       BayesSardModel._exp_x_px   (bq/bqmod.py:635-662)   E[p_q(x)]
+ *   xpx [D*NB]    BayesSardModel._exp_x_xpx  (:664-698)              E[x_e p_q(x)], with the reference's alpha_e factor
+ *   pxpx [NB*NB]  BayesSardModel._exp_x_pxpx (:700-731)              E[p_r(x) p_q(x)]
+ *   kxpx [N*NB]   BayesSardModel._exp_x_kxpx (:733-797)              E[k(x, x_n) p_q(x)] for the points x [D*N], kernel
+ *                 parameters par [1+D] (the reference's `ell = sqrt_inv_lam ** -2` kept as written)
+ *   vand [N*NB]   utils.vandermonde (utils.py:478-502)               p_q(x_n)
+ * px / xpx / pxpx are integer arithmetic on the multi-indices (host code, no device needed); kxpx / vand run on the
+ * device.
+ */
+int ssmq_bs_moments(int D, int N, const double *x, const double *par, const int32_t *mulind, int NB, double *px,
+                    double *xpx, double *pxpx, double *kxpx, double *vand);
+
+/*
  * Expected model variance and integral variance of the Bayes-Sard model as BayesSardModel.exp_model_variance /
  * integral_variance compute them (bq/bqmod.py:995-1050; the length-scale sweeps of research/bsq/bsq_ungm.py:244-282):
  * the general formulas  alpha^2 (1 - tr(Q iK) + tr(B (V' iK V)^-1)),  kbar - q' iK q + b' (V' iK V)^-1 b  for every

@@ -155,6 +155,8 @@ _PROTOTYPES = {
                                        ctypes.c_double, c_double_p, c_double_p, c_double_p, c_int32_p]),
     'ssmq_rbf_exp_kxkx': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.c_int,
                                          c_double_p]),
+    'ssmq_bs_moments': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_int32_p, ctypes.c_int,
+                                       c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     'ssmq_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'ssmq_comm_init': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     'ssmq_comm_rank': (ctypes.c_int, []),

@@ -185,6 +185,38 @@ class BayesSardModel(Model):
         self.integral_var = float(out['iv'][0][0])
         return out['wm'][0], out['Wc'][0], out['Wcc'][0], self.model_var, self.integral_var
 
+    def _moments(self, multi_ind, x=None, par=None, want=('px',)):
+        """The polynomial expectations behind the weights (`ssmq_bs_moments`), one array per name in `want`."""
+        mi = np.ascontiguousarray(multi_ind, dtype=np.int32)
+        if mi.ndim != 2:
+            raise ValueError('multi-index matrix must be (dim, num_basis)')
+        D, NB = mi.shape
+        N = 0 if x is None else np.atleast_2d(x).shape[1]
+        shapes = {'px': (NB,), 'xpx': (D, NB), 'pxpx': (NB, NB), 'kxpx': (N, NB)}
+        out = {k: _lib.out_c(shapes[k]) for k in want}
+        xs = _lib.as_c(np.atleast_2d(np.asarray(x, dtype=np.float64)))[1] if x is not None else None
+        pp = _lib.as_c(self.kernel.get_parameters(par)[:1])[1] if par is not None else None
+        ptr = lambda k: out[k][1] if k in out else None          # noqa: E731
+        _lib.check(_lib.load().ssmq_bs_moments(D, N, xs, pp, mi.ctypes.data_as(_lib.c_int32_p), NB, ptr('px'), ptr('xpx'),
+                                               ptr('pxpx'), ptr('kxpx'), None), 'ssmq_bs_moments')
+        return [out[k][0] for k in want]
+
+    def _exp_x_px(self, multi_ind):
+        """bq/bqmod.py:635-662: E[p_q(x)], (Q,)."""
+        return self._moments(multi_ind, want=('px',))[0]
+
+    def _exp_x_xpx(self, multi_ind):
+        """bq/bqmod.py:664-698: E[x p(x)'], (D, Q)."""
+        return self._moments(multi_ind, want=('xpx',))[0]
+
+    def _exp_x_pxpx(self, multi_ind):
+        """bq/bqmod.py:700-731: E[p(x) p(x)'], (Q, Q)."""
+        return self._moments(multi_ind, want=('pxpx',))[0]
+
+    def _exp_x_kxpx(self, par, multi_ind, x):
+        """bq/bqmod.py:733-797: E[k(x, x_n) p_q(x)], (N, Q), on the device."""
+        return self._moments(multi_ind, x=x, par=par, want=('kxpx',))[0]
+
     def _variances(self, pars, multi_ind=None):
         """theta-batched (model_var, integral_var) with the semantics of the reference's stand-alone methods
         (`ssmq_variances_bs`): pars (P, 1 + D)."""

@@ -57,8 +57,12 @@ template <> struct HasTimeTable<SSMQ_F_UNGMNA_DYN> { static constexpr bool value
 // STU: -1 Gaussian or Studentian recursion decided at run time (a.sscale / a.student_dof), 0 / 1 fixed at compile time
 // (scalar-state kernels: on a 105-instruction step the run-time form costs two branches, three multiplications by a
 // scale of one and their operand moves - 5 us of a 43 us pass).
+#ifndef SSMQ_FUSED_FORCE_OCC
+#define SSMQ_FUSED_FORCE_OCC 0   // A/B builds (tools/build_variant.sh): waves per SIMD requested for every instantiation
+#endif
 template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT, int STU = -1>
-__global__ __launch_bounds__(kSmallBlock, ((D >= 6 || (D >= 5 && FORM == SSMQ_FORM_SIGMA)) ? 1 : 2)) void k_filter_fused(const FusedArgs a) {
+__global__ __launch_bounds__(kSmallBlock, (SSMQ_FUSED_FORCE_OCC ? SSMQ_FUSED_FORCE_OCC
+                                           : ((D >= 6 || (D >= 5 && FORM == SSMQ_FORM_SIGMA)) ? 1 : 2))) void k_filter_fused(const FusedArgs a) {
     if ((int)threadIdx.x >= a.lpw) return;
     const uint32_t b = blockIdx.x * a.lpw + threadIdx.x;
     if ((int64_t)b >= a.B) return;

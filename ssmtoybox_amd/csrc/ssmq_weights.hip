@@ -372,6 +372,36 @@ __device__ double ipow(double x, int k) {
     return r;
 }
 
+// Entry (n, q) of the Vandermonde matrix (utils.py:478-502) and of E[k(x, x_n) p_q(x)], the closed form of
+// bq/bqmod.py:733-797; its `ell` is sqrt_inv_lam ** -2 = ell^2, reproduced as written there.  sil[d] = 1 / ell_d.
+__device__ void bs_basis_entry(int D, int N, int NB, int n, int qb, const double *__restrict__ xi,
+                               const int32_t *__restrict__ mulind, const double *sil, double &vand, double &kxpx) {
+    double v = 1.0, kprod = 1.0;
+    for (int d = 0; d < D; ++d) {
+        const int al = mulind[d * NB + qb];
+        const double x = xi[d * N + n];
+        v *= ipow(x, al);
+        const double sl = sil[d];
+        const double el = 1.0 / (sl * sl);
+        const double e1 = 1.0 + el * el;
+        const double ea = el * pow(e1, -(1.0 + al) / 2.0) * exp(-(x * x) / (2.0 * e1));
+        double eb = 0.0;
+        const double xs = x / sqrt(e1);
+        for (int m = 0; m <= al / 2; ++m) {
+            // al! / (2^m m! (al - 2m)!)
+            double num = 1.0, den = 1.0;
+            for (int t = 2; t <= al; ++t) num *= t;
+            for (int t = 0; t < m; ++t) den *= 2.0;
+            for (int t = 2; t <= m; ++t) den *= t;
+            for (int t = 2; t <= al - 2 * m; ++t) den *= t;
+            eb += (num / den) * (ipow(el, 2 * m) * ipow(xs, al - 2 * m));
+        }
+        kprod *= ea * eb;
+    }
+    vand = v;
+    kxpx = kprod;
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     extern __shared__ __align__(16) double lds[];
@@ -528,34 +558,8 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     double *T1 = w; w += N * N;
     double *T2 = w; w += N * N;
     double *bv = w; w += NB;
-    for (int idx = tid; idx < N * NB; idx += kWgtBlock) {
-        const int n = idx / NB, qb = idx % NB;
-        double v = 1.0, kprod = 1.0;
-        for (int d = 0; d < D; ++d) {
-            const int al = a.mulind[d * NB + qb];
-            const double x = a.xi[d * N + n];
-            v *= ipow(x, al);
-            // closed form of bq/bqmod.py:733-797; its `ell` is sqrt_inv_lam ** -2 = ell^2, reproduced as written there
-            const double sl = s_sil[d];
-            const double el = 1.0 / (sl * sl);
-            const double e1 = 1.0 + el * el;
-            const double ea = el * pow(e1, -(1.0 + al) / 2.0) * exp(-(x * x) / (2.0 * e1));
-            double eb = 0.0;
-            const double xs = x / sqrt(e1);
-            for (int m = 0; m <= al / 2; ++m) {
-                // al! / (2^m m! (al - 2m)!)
-                double num = 1.0, den = 1.0;
-                for (int t = 2; t <= al; ++t) num *= t;
-                for (int t = 0; t < m; ++t) den *= 2.0;
-                for (int t = 2; t <= m; ++t) den *= t;
-                for (int t = 2; t <= al - 2 * m; ++t) den *= t;
-                eb += (num / den) * (ipow(el, 2 * m) * ipow(xs, al - 2 * m));
-            }
-            kprod *= ea * eb;
-        }
-        V[idx] = v;
-        kx[idx] = kprod;
-    }
+    for (int idx = tid; idx < N * NB; idx += kWgtBlock)
+        bs_basis_entry(D, N, NB, idx / NB, idx % NB, a.xi, a.mulind, s_sil, V[idx], kx[idx]);
     bsync();
     GEMM(Z, N, V, NB, true, iK, N, false, NB, N, N);        // Z = V' iK
     GEMM(G, NB, Z, N, false, V, NB, false, NB, NB, N);      // G = Z V
@@ -1144,6 +1148,62 @@ extern "C" int ssmq_rbf_exp_kxkx(int D, int N, const double *x, const double *pa
                        dx.d(), dp.d(), dp.d() + 1 + D, scaling, dq.d());
     if ((rc = hip_fail(hipGetLastError(), "k_rbf_kxkx"))) return rc;
     SSMQ_HIP(hipMemcpyAsync(Q, dq.p, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    return SSMQ_OK;
+}
+
+// BayesSardModel._exp_x_kxpx and utils.vandermonde for an arbitrary point set (the weights kernel forms both inline)
+__global__ void k_bs_moments(int D, int N, int NB, const double *__restrict__ x, const double *__restrict__ par,
+                             const int32_t *__restrict__ mulind, double *__restrict__ vand, double *__restrict__ kxpx) {
+    __shared__ double sil[SSMQ_MAX_DIM];
+    if ((int)threadIdx.x < D) sil[threadIdx.x] = 1.0 / par[1 + threadIdx.x];
+    __syncthreads();
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)N * NB; idx += (int64_t)gridDim.x * blockDim.x) {
+        double v, k;
+        ssmq::bs_basis_entry(D, N, NB, (int)(idx / NB), (int)(idx % NB), x, mulind, sil, v, k);
+        if (vand) vand[idx] = v;
+        if (kxpx) kxpx[idx] = k;
+    }
+}
+
+extern "C" int ssmq_bs_moments(int D, int N, const double *x, const double *par, const int32_t *mulind, int NB, double *px,
+                               double *xpx, double *pxpx, double *kxpx, double *vand) {
+    using namespace ssmq;
+    if (D < 1 || D > SSMQ_MAX_DIM || NB < 1 || !mulind || N < 0 || ((kxpx || vand) && (!x || N < 1)) || (kxpx && !par)) {
+        set_error("bs_moments: bad argument");
+        return SSMQ_E_ARG;
+    }
+    for (int i = 0; i < D * NB; ++i)
+        if (mulind[i] < 0) {
+            set_error("bs_moments: negative multi-index");
+            return SSMQ_E_ARG;
+        }
+    if (px || xpx || pxpx) {     // integer arithmetic on the multi-indices: host code, as the point sets are
+        std::vector<double> a, b, c;
+        poly_moments(D, NB, mulind, a, b, c);
+        if (px) std::copy(a.begin(), a.end(), px);
+        if (xpx) std::copy(b.begin(), b.end(), xpx);
+        if (pxpx) std::copy(c.begin(), c.end(), pxpx);
+    }
+    if (!kxpx && !vand) return SSMQ_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = stream();
+    const size_t nn = (size_t)N * NB;
+    DBuf dx, dp, dm, dk, dv;
+    const double one_par[1 + SSMQ_MAX_DIM] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    if ((rc = dx.alloc(sizeof(double) * D * N)) || (rc = dp.alloc(sizeof(double) * (1 + D))) ||
+        (rc = dm.alloc(sizeof(int32_t) * D * NB)) || (kxpx && (rc = dk.alloc(sizeof(double) * nn))) ||
+        (vand && (rc = dv.alloc(sizeof(double) * nn))))
+        return rc;
+    SSMQ_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * D * N, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dp.p, par ? par : one_par, sizeof(double) * (1 + D), hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dm.p, mulind, sizeof(int32_t) * D * NB, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_bs_moments, dim3((unsigned)std::min<size_t>((nn + 255) / 256, 4096)), dim3(256), 0, s, D, N, NB, dx.d(),
+                       dp.d(), (const int32_t *)dm.p, vand ? dv.d() : nullptr, kxpx ? dk.d() : nullptr);
+    if ((rc = hip_fail(hipGetLastError(), "k_bs_moments"))) return rc;
+    if (kxpx) SSMQ_HIP(hipMemcpyAsync(kxpx, dk.p, sizeof(double) * nn, hipMemcpyDeviceToHost, s));
+    if (vand) SSMQ_HIP(hipMemcpyAsync(vand, dv.p, sizeof(double) * nn, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipStreamSynchronize(s));
     return SSMQ_OK;
 }

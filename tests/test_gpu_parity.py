@@ -406,6 +406,81 @@ def test_bs_reproduces_classical_rules(amd):
     np.linalg.cholesky(tf.Wc)
 
 
+def test_bs_polynomial_expectations_on_the_device(amd, golden):
+    """BayesSardModel._exp_x_kxpx and utils.vandermonde as callables of their own (`ssmq_bs_moments`): the reference's
+    known answer (ssmtoybox/tests/test_bqmod.py:316-326), its outputs for every Bayes-Sard golden case, and its
+    Monte-Carlo verification of all four expectations (test_bqmod.py:328-366, tolerance 5e-3 as there)."""
+    from ssmtoybox_amd import utils
+    from ssmtoybox_amd.bq.bqmod import BayesSardModel
+    model = BayesSardModel(1, np.array([[1.0, 1.0]]), multi_ind=2, point_str='ut', point_par={'kappa': 0.0})
+    mi_1d = np.array([[0, 1, 2]])
+    par_1d = np.array([[1.0, 1.0]])
+    data = np.array([[0.0, 1.0, -1.0]])
+    ke = model._exp_x_kxpx(par_1d, mi_1d, data)
+    s2, e = 2 ** 0.5, np.exp(-0.25)
+    ke_true = np.array([[1 / s2, 0, 1 / (2 * s2)], [e / s2, e / (2 * s2), 3 * e / (4 * s2)],
+                        [e / s2, -e / (2 * s2), 3 * e / (4 * s2)]])
+    assert ke.shape == (3, 3) and np.allclose(ke, ke_true, rtol=1e-14, atol=1e-16)
+    g = golden('g2_bs_weights')
+    tags = sorted({k[:-3] for k in g if k.endswith('_mi')})
+    for t in tags:
+        mi, pts, par = g[t + '_mi'], g[t + '_pts'], g[t + '_par']
+        m = BayesSardModel(pts.shape[0], par, multi_ind=mi, point_str='ut')
+        kx = m._exp_x_kxpx(par, mi, pts)
+        assert within(rel_err(kx, g[t + '_kxpx']), 1e-13, 'bs kxpx vs reference ' + t)
+        V = utils.vandermonde(mi, pts)
+        assert V.shape == g[t + '_V'].shape
+        assert within(rel_err(V, g[t + '_V']), 1e-15, 'vandermonde vs reference ' + t)
+    # Monte-Carlo verification, 2e6 standard normal samples (the reference draws 1e7; same 5e-3 bar)
+    rng = np.random.default_rng(12)
+    xs = rng.standard_normal((1, 2000000))
+    p = xs.T ** mi_1d[0][None, :]
+    k = np.exp(-0.5 * (xs.T - data) ** 2)                   # alpha = 1, ell = 1, unscaled kernel
+    px, xpx, pxpx = model._exp_x_px(mi_1d), model._exp_x_xpx(mi_1d), model._exp_x_pxpx(mi_1d)
+    assert np.abs(px - p.mean(axis=0)).max() < 5e-3
+    assert np.abs(xpx - (xs.T * p).mean(axis=0)[None, :]).max() < 5e-3
+    assert np.abs(pxpx - p.T.dot(p) / p.shape[0]).max() < 5e-3
+    assert np.abs(ke - k.T.dot(p) / p.shape[0]).max() < 5e-3
+
+
+@pytest.mark.parametrize('tag', ['d1', 'd3', 'd6'])
+def test_reference_metric_functions_per_item(amd, golden, tag):
+    """utils.neg_log_likelihood / log_cred_ratio / mse_matrix with the reference's per-item signatures
+    (ssmtoybox/tests/test_utils.py:16-33 calls them this way), through the device reductions, against the reference's
+    values - including covariances that are not positive definite."""
+    from ssmtoybox_amd import utils
+    g = golden('g7_metrics')
+    x, m, P = g[tag + '_x'], g[tag + '_m'], g[tag + '_P']
+    D, T, M = m.shape
+    for k in (0, T // 2, T - 1):
+        mse = utils.mse_matrix(x[:, k, :], m[:, k, :])
+        assert mse.shape == (D, D) and np.allclose(mse, g[tag + '_mse'][..., k], rtol=1e-12, atol=1e-14)
+        for i in (0, M - 1):
+            nll = utils.neg_log_likelihood(x[:, k, i], m[:, k, i], P[..., k, i])
+            assert abs(nll - g[tag + '_nll'][k, i]) < 1e-11 * max(1.0, abs(nll))
+            lcr = utils.log_cred_ratio(x[:, k, i], m[:, k, i], P[..., k, i], mse + 1e-6 * np.eye(D))
+            assert abs(lcr - g[tag + '_lcr'][k, i]) < 1e-9 * max(1.0, abs(lcr))
+    if tag + '_Pi' in g:
+        Pi, flip = g[tag + '_Pi'], g[tag + '_flip']
+        ks, is_ = np.nonzero(flip)
+        for k, i in list(zip(ks, is_))[:4]:
+            mse = g[tag + '_mse'][..., k] + 1e-6 * np.eye(D)
+            nll = utils.neg_log_likelihood(x[:, k, i], m[:, k, i], Pi[..., k, i])
+            assert abs(nll - g[tag + '_nlli'][k, i]) < 1e-9 * max(1.0, abs(nll))
+            lcr = utils.log_cred_ratio(x[:, k, i], m[:, k, i], Pi[..., k, i], mse)
+            assert abs(lcr - g[tag + '_lcri'][k, i]) < 1e-8 * max(1.0, abs(lcr))
+    with pytest.raises(np.linalg.LinAlgError):
+        utils.neg_log_likelihood(np.zeros(D), np.ones(D), np.zeros((D, D)))
+    # the reference's own smoke test: a random state, mean and covariance of dimension 5
+    rng = np.random.default_rng(3)
+    xx, mm, A = rng.standard_normal(5), rng.standard_normal(5), rng.standard_normal((5, 5))
+    cov = A.dot(A.T)
+    dx = xx - mm
+    want = 0.5 * (np.linalg.slogdet(cov)[1] + dx.dot(np.linalg.inv(cov)).dot(dx) + 5 * np.log(2 * np.pi))
+    assert abs(utils.neg_log_likelihood(xx, mm, cov) - want) < 1e-10 * abs(want)
+    assert utils.mse_matrix(rng.standard_normal((5, 100)), rng.standard_normal((5, 100))).shape == (5, 5)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the filter recursion around the path
 # ---------------------------------------------------------------------------------------------------------------

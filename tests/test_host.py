@@ -189,3 +189,36 @@ def test_c_abi_point_sets_match_reference(golden):
     # argument errors
     assert lib.ssmq_points_count(9, 2, None, 0) < 0 and lib.ssmq_points_count(UT, 0, None, 0) < 0
     assert lib.ssmq_points_count(GH, 10, np.array([7.0]).ctypes.data_as(_lib.c_double_p), 1) < 0     # 7^10 points
+
+
+def test_polynomial_expectations_reference_known_answers():
+    """ssmtoybox/tests/test_bqmod.py:262-314 of the reference (test_x_px, test_exp_x_xpx, test_exp_x_pxpx) on the
+    product's methods - integer arithmetic on the multi-indices, the host part of `ssmq_bs_moments` (no device)."""
+    from ssmtoybox_amd.bq.bqmod import BayesSardModel
+    model = BayesSardModel.__new__(BayesSardModel)           # the three methods use no state
+    mi_1d = np.array([[0, 1, 2]])
+    mi_2d = np.array([[0, 1, 0, 1, 0, 2], [0, 0, 1, 1, 2, 0]])
+    ke = model._exp_x_px(mi_1d)
+    assert ke.shape == (3,) and np.array_equal(ke, [1, 0, 1])
+    ke = model._exp_x_px(mi_2d)
+    assert ke.shape == (6,) and np.array_equal(ke, [1, 0, 0, 0, 1, 1])
+    ke = model._exp_x_xpx(mi_1d)
+    assert ke.shape == mi_1d.shape and np.array_equal(ke, [[0, 1, 0]])
+    ke = model._exp_x_xpx(mi_2d)
+    assert ke.shape == mi_2d.shape and np.array_equal(ke, [[0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0]])
+    ke = model._exp_x_pxpx(mi_1d)
+    assert np.array_equal(ke, [[1, 0, 1], [0, 1, 0], [1, 0, 3]])
+    ke = model._exp_x_pxpx(mi_2d)
+    assert np.array_equal(ke, [[1, 0, 0, 0, 1, 1], [0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0],
+                               [1, 0, 0, 0, 3, 1], [1, 0, 0, 0, 1, 3]])
+    # and the reference's own outputs for every Bayes-Sard golden case (incl. its alpha_e factor in E[x p(x)'])
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g2_bs_weights.npz'))
+    tags = sorted({k[:-3] for k in g.files if k.endswith('_mi')})
+    assert len(tags) >= 10
+    for t in tags:
+        mi = g[t + '_mi']
+        assert np.array_equal(model._exp_x_px(mi), g[t + '_px']), t
+        assert np.array_equal(model._exp_x_xpx(mi), g[t + '_xpx']), t
+        assert np.array_equal(model._exp_x_pxpx(mi), g[t + '_pxpx']), t
+    with pytest.raises(Exception):
+        model._exp_x_px(np.array([[0, -1]]))

@@ -11,20 +11,21 @@ from bench import FilterBench                    # noqa: E402
 B = int(os.environ.get('B', 10000))
 T = int(os.environ.get('T', 100))
 filt = os.environ.get('FILT', 'gpqkf')
-wl = FilterBench(amd, B, T, 1, 'ungm', filt)
-for _ in range(20):
+N = int(os.environ.get('N', 100))
+wl = FilterBench(amd, B, T, 1, os.environ.get('WL', 'ungm'), filt)
+for _ in range(5):
     wl.step()
 _lib.sync()
 ts = []
 for rep in range(5):
     e0, e1 = _lib.Event(), _lib.Event()
     e0.record()
-    for _ in range(100):
+    for _ in range(N):
         wl.step()
     e1.record()
     _lib.sync()
-    ts.append(e0.elapsed_ms(e1) * 10.0)          # us per launch
+    ts.append(e0.elapsed_ms(e1) * 1e3 / N)          # us per launch
 fm, fP, st = wl.results()
 print('%-40s B=%d T=%d  %s  us/launch: median %.2f min %.2f  checksum %.17g' %
       (os.path.basename(os.environ.get('SSMQ_LIBRARY', 'libssmq.so')), B, T,
-       wl.kernel[-22:], float(np.median(ts)), min(ts), float(np.nansum(fm) + np.nansum(fP))))
+       wl.kernel[-40:], float(np.median(ts)), min(ts), float(np.nansum(fm) + np.nansum(fP))))
