@@ -129,10 +129,10 @@ def test_apply_generic_kernel_matches(amd, golden, name):
     fid, p, sidx, din, dout = MODELS[name]
     mod, f = make_model(name)
     means, covs, times = g[name + '_mean'], g[name + '_cov'], g[name + '_time']
-    if din > 3:
-        pytest.skip('GH-5 grid too large')
-    tf = amd.GaussHermiteTransform(din, 5)       # N = 5^D: no register-resident specialisation for D >= 2
-    pts, wm = orc.points_gh(din, 5), orc.weights_gh(din, 5)
+    deg = 5 if din <= 3 else 3                   # N = 5^D (<= 125) or 3^D (81 ... 729): no register-resident
+    tf = amd.GaussHermiteTransform(din, deg)     # specialisation for D >= 2, the generic kernel's limit is N = 1024
+    pts, wm = orc.points_gh(din, deg), orc.weights_gh(din, deg)
+    assert din <= 3 or 'k_apply_wide' in tf.kernel_name(f)
     got = tf.apply_batch(f, means, covs, times.astype(float))
     for i in range(means.shape[0]):
         ref = orc.apply_sigma(fid, means[i], covs[i], times[i], pts, wm, wm, p, sidx)
