@@ -129,6 +129,8 @@ def test_apply_generic_kernel_matches(amd, golden, name):
     fid, p, sidx, din, dout = MODELS[name]
     mod, f = make_model(name)
     means, covs, times = g[name + '_mean'], g[name + '_cov'], g[name + '_time']
+    if 3 ** din > 1024:
+        pytest.skip('no Gauss-Hermite grid of this dimension fits the generic kernel (N <= 1024)')
     deg = 5 if din <= 3 else 3                   # N = 5^D (<= 125) or 3^D (81 ... 729): no register-resident
     tf = amd.GaussHermiteTransform(din, deg)     # specialisation for D >= 2, the generic kernel's limit is N = 1024
     pts, wm = orc.points_gh(din, deg), orc.weights_gh(din, deg)
