@@ -887,6 +887,7 @@ struct GraphDropGuard {
 
 namespace ssmq {
 void reset_wide_attributes();
+void drop_theta_arena();
 void reset_device_caches() {
     g_fc.drop_graph();
     g_fc.consts_ok = false;
@@ -894,6 +895,7 @@ void reset_device_caches() {
     g_fc.ws = nullptr;
     g_fc.ws_bytes = 0;
     drop_gemm_scratch();
+    drop_theta_arena();
     reset_wide_attributes();
 }
 }  // namespace ssmq
@@ -1402,10 +1404,50 @@ extern "C" int ssmq_lcr_sums_dev(int D, int64_t B, int64_t ld, int T, const doub
 }
 
 namespace ssmq {
+size_t gp_weights_wide_ws_bytes(int D, int N, int64_t P);
 int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double *d_par, int P, double jitter,
-                           double *d_consts, int32_t *d_status);
+                           double *d_consts, int32_t *d_status, void *ws, size_t ws_bytes);
 int launch_gauss_logpdf(int Y, int64_t B, int64_t ld, const double *y, const double *y_mean, const double *P_y,
                         double *out, hipStream_t s);
+}
+
+namespace {
+// Device arena + pinned staging blocks of ssmq_gp_theta_step, grow-only, dropped when the device changes.
+struct ThetaArena {
+    void *dev = nullptr, *hin = nullptr, *hout = nullptr;
+    size_t dev_bytes = 0, hin_bytes = 0, hout_bytes = 0;
+    static int grow(void **p, size_t *have, size_t need, bool host) {
+        if (*have >= need) return SSMQ_OK;
+        if (*p) {
+            SSMQ_HIP(hipStreamSynchronize(stream()));
+            if (host) hipHostFree(*p); else hipFree(*p);
+        }
+        *p = nullptr;
+        *have = 0;
+        const size_t want = need + need / 4;       // a little head room: consecutive calls differ by a few items
+        if (host) SSMQ_HIP(hipHostMalloc(p, want, hipHostMallocDefault)); else SSMQ_HIP(hipMalloc(p, want));
+        *have = want;
+        return SSMQ_OK;
+    }
+    int reserve(size_t d, size_t hi, size_t ho) {
+        int rc;
+        if ((rc = grow(&dev, &dev_bytes, d, false)) || (rc = grow(&hin, &hin_bytes, hi, true)) ||
+            (rc = grow(&hout, &hout_bytes, ho, true)))
+            return rc;
+        return SSMQ_OK;
+    }
+    void drop() {
+        if (dev) hipFree(dev);
+        if (hin) hipHostFree(hin);
+        if (hout) hipHostFree(hout);
+        dev = hin = hout = nullptr;
+        dev_bytes = hin_bytes = hout_bytes = 0;
+    }
+};
+ThetaArena g_theta;
+}  // namespace
+namespace ssmq {
+void drop_theta_arena() { g_theta.drop(); }
 }
 
 namespace {
@@ -1447,79 +1489,107 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     hipStream_t s = stream();
     const int64_t ld = (P + 63) / 64 * 64;
     const WideLayout cld = wide_layout(D, D, Nd, SSMQ_FORM_BQ), clo = wide_layout(D, Y, No, SSMQ_FORM_BQ);
-    const int64_t ns = shared_state ? 1 : P, ny = shared_y ? 1 : P;
-    DevBuf xid, xio, pard, paro, cd, co, min_, cin, yin, ysoa, gq, rr, st, tt, work, aos;
-    // SoA work planes: m_pr D | P_pr D*D | C_xx D*D | y_mean Y | P_y Y*Y | P_yx Y*D | m_fi D | P_fi D*D | loglik 1
-    const size_t n_pl = (size_t)D + 3 * (size_t)D * D + Y + (size_t)Y * Y + (size_t)Y * D + D + 1;
-    if ((rc = xid.alloc(sizeof(double) * D * Nd)) || (rc = xio.alloc(sizeof(double) * D * No)) ||
-        (rc = pard.alloc(sizeof(double) * P * (1 + D))) || (rc = paro.alloc(sizeof(double) * P * (1 + D))) ||
-        (rc = cd.alloc(sizeof(double) * P * cld.total)) || (rc = co.alloc(sizeof(double) * P * clo.total)) ||
-        (rc = min_.alloc(sizeof(double) * ns * D)) || (rc = cin.alloc(sizeof(double) * ns * D * D)) ||
-        (rc = yin.alloc(sizeof(double) * P * Y)) || (rc = ysoa.alloc(sizeof(double) * ld * Y)) ||
-        (rc = gq.alloc(sizeof(double) * D * D)) || (rc = rr.alloc(sizeof(double) * Y * Y)) ||
-        (rc = st.alloc(sizeof(int32_t) * 6 * ld)) || (rc = tt.alloc(sizeof(double))) ||
-        (rc = work.alloc(sizeof(double) * ld * n_pl)) || (rc = aos.alloc(sizeof(double) * P * ((size_t)D + D * D))))
-        return rc;
-    std::vector<double> zg((size_t)D * D, 0.0), zr((size_t)Y * Y, 0.0), ybuf;
-    SSMQ_HIP(hipMemcpyAsync(xid.p, h_dyn->xi.data(), sizeof(double) * D * Nd, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(xio.p, h_obs->xi.data(), sizeof(double) * D * No, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(pard.p, par_dyn, sizeof(double) * P * (1 + D), hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(paro.p, par_obs, sizeof(double) * P * (1 + D), hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(min_.p, mean, sizeof(double) * ns * D, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(cin.p, cov, sizeof(double) * ns * D * D, hipMemcpyHostToDevice, s));
-    if (shared_y) {   // replicate on the host: the update kernels read one measurement plane set per item
-        ybuf.resize((size_t)P * Y);
-        for (int64_t i = 0; i < P; ++i)
-            for (int k = 0; k < Y; ++k) ybuf[(size_t)i * Y + k] = y[k];
+    const int64_t ns = shared_state ? 1 : P;
+    // ---- one device arena and two pinned host blocks, kept between calls (the marginalised filter calls this once per
+    // BFGS iteration with a handful of items: forty allocations and three synchronisations per call were 310 us) -----------
+    // input block, same layout on host and device:  xi_dyn | xi_obs | par_dyn | par_obs | mean | cov | y (planes) | GQG | R | t
+    const size_t n_in = (size_t)D * Nd + (size_t)D * No + 2 * (size_t)P * (1 + D) + (size_t)ns * (D + D * D) + (size_t)ld * Y +
+                        (size_t)D * D + (size_t)Y * Y + 1;
+    // work planes: m_pr D | P_pr D*D | C_xx D*D | y_mean Y | P_y Y*Y | P_yx Y*D, then the output block m_fi D | P_fi D*D |
+    // loglik 1 | merged status (int32), then the five partial status vectors
+    const size_t n_mid = (size_t)D + 2 * (size_t)D * D + Y + (size_t)Y * Y + (size_t)Y * D;
+    const size_t n_out = (size_t)D + (size_t)D * D + 1;
+    const size_t out_bytes = sizeof(double) * n_out * ld + sizeof(int32_t) * ld;
+    const size_t ws_d = gp_weights_wide_ws_bytes(D, Nd, P), ws_o = gp_weights_wide_ws_bytes(D, No, P);
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t off_in = 0, off_cd = al(sizeof(double) * n_in), off_co = off_cd + al(sizeof(double) * P * cld.total),
+                 off_mid = off_co + al(sizeof(double) * P * clo.total), off_out = off_mid + al(sizeof(double) * n_mid * ld),
+                 off_st = off_out + al(out_bytes), off_ws = off_st + al(sizeof(int32_t) * 5 * ld),
+                 total = off_ws + std::max(ws_d, ws_o);
+    if ((rc = g_theta.reserve(total, sizeof(double) * n_in, out_bytes))) return rc;
+    char *dev = (char *)g_theta.dev;
+    double *hin = (double *)g_theta.hin;
+    {
+        double *h = hin;
+        auto put = [&](const double *src, size_t n) {
+            memcpy(h, src, sizeof(double) * n);
+            h += n;
+        };
+        put(h_dyn->xi.data(), (size_t)D * Nd);
+        put(h_obs->xi.data(), (size_t)D * No);
+        put(par_dyn, (size_t)P * (1 + D));
+        put(par_obs, (size_t)P * (1 + D));
+        put(mean, (size_t)ns * D);
+        put(cov, (size_t)ns * D * D);
+        for (int k = 0; k < Y; ++k) {                      // measurements straight into the plane layout
+            for (int64_t i = 0; i < P; ++i) h[(size_t)k * ld + i] = y[(shared_y ? 0 : (size_t)i * Y) + k];
+            for (int64_t i = P; i < ld; ++i) h[(size_t)k * ld + i] = 0.0;
+        }
+        h += (size_t)ld * Y;
+        if (GQG) put(GQG, (size_t)D * D); else { memset(h, 0, sizeof(double) * D * D); h += (size_t)D * D; }
+        if (R) put(R, (size_t)Y * Y); else { memset(h, 0, sizeof(double) * Y * Y); h += (size_t)Y * Y; }
+        *h++ = time;
     }
-    SSMQ_HIP(hipMemcpyAsync(yin.p, shared_y ? ybuf.data() : y, sizeof(double) * P * Y, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(gq.p, GQG ? GQG : zg.data(), sizeof(double) * D * D, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(rr.p, R ? R : zr.data(), sizeof(double) * Y * Y, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(tt.p, &time, sizeof(double), hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemsetAsync(st.p, 0, sizeof(int32_t) * 6 * ld, s));
-    int32_t *st_wd = (int32_t *)st.p, *st_wo = st_wd + ld, *st_td = st_wo + ld, *st_to = st_td + ld, *st_up = st_to + ld,
-            *st_all = st_up + ld;
-    if ((rc = ssmq_aos_to_soa(yin.d(), ysoa.d(), Y, P, ld))) return rc;
-    if ((rc = gp_weights_wide_consts(D, D, Nd, xid.d(), pard.d(), (int)P, jitter, cd.d(), st_wd))) return rc;
-    if ((rc = gp_weights_wide_consts(D, Y, No, xio.d(), paro.d(), (int)P, jitter, co.d(), st_wo))) return rc;
-    double *w = work.d();
+    SSMQ_HIP(hipMemcpyAsync(dev + off_in, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
+    double *in = (double *)(dev + off_in);
+    double *xid = in; in += (size_t)D * Nd;
+    double *xio = in; in += (size_t)D * No;
+    double *pard = in; in += (size_t)P * (1 + D);
+    double *paro = in; in += (size_t)P * (1 + D);
+    double *min_ = in; in += (size_t)ns * D;
+    double *cin = in; in += (size_t)ns * D * D;
+    double *ysoa = in; in += (size_t)ld * Y;
+    double *gq = in; in += (size_t)D * D;
+    double *rr = in; in += (size_t)Y * Y;
+    double *tt = in;
+    double *cd = (double *)(dev + off_cd), *co = (double *)(dev + off_co);
+    int32_t *st_wd = (int32_t *)(dev + off_st), *st_wo = st_wd + ld, *st_td = st_wo + ld, *st_to = st_td + ld, *st_up = st_to + ld;
+    SSMQ_HIP(hipMemsetAsync(st_wd, 0, sizeof(int32_t) * 5 * ld, s));
+    if ((rc = gp_weights_wide_consts(D, D, Nd, xid, pard, (int)P, jitter, cd, st_wd, dev + off_ws, ws_d))) return rc;
+    if ((rc = gp_weights_wide_consts(D, Y, No, xio, paro, (int)P, jitter, co, st_wo, dev + off_ws, ws_o))) return rc;
+    double *w = (double *)(dev + off_mid);
     double *m_pr = w; w += ld * D;
     double *P_pr = w; w += ld * D * D;
     double *C_xx = w; w += ld * D * D;
     double *y_mean = w; w += ld * Y;
     double *P_y = w; w += ld * Y * Y;
-    double *P_yx = w; w += ld * Y * D;
+    double *P_yx = w;
+    w = (double *)(dev + off_out);
     double *m_fi = w; w += ld * D;
     double *P_fi = w; w += ld * D * D;
-    double *ll = w;
+    double *ll = w; w += ld;
+    int32_t *st_all = (int32_t *)w;
     WideArgs a;
     memset(&a, 0, sizeof(a));
     a.D = D; a.E = D; a.N = Nd; a.form = SSMQ_FORM_BQ; a.mode = SSMQ_WIDE_FULL; a.fid = f_dyn->id; a.time_stride = 0;
     a.emv_mode = h_dyn->emv_mode; a.tp_nu = 0.0; a.cov_scale = a.ccov_scale = 1.0;
-    a.consts = cd.d(); a.consts_stride = cld.total; a.cov_add = gq.d();
-    a.mean = min_.d(); a.cov = cin.d(); a.time = tt.d(); a.es_in = 1; a.bs_mean = shared_state ? 0 : D;
+    a.consts = cd; a.consts_stride = cld.total; a.cov_add = gq;
+    a.mean = min_; a.cov = cin; a.time = tt; a.es_in = 1; a.bs_mean = shared_state ? 0 : D;
     a.bs_cov = shared_state ? 0 : (int64_t)D * D;
     a.mean_f = m_pr; a.cov_f = P_pr; a.cov_fx = C_xx; a.es_out = ld; a.bs_mf = a.bs_cf = a.bs_cfx = 1; a.status = st_td;
     fill_fpar(f_dyn, &a.fp);
     if ((rc = hip_fail(launch_apply_wide(a, P, s), "k_apply_wide(theta, dyn)"))) return rc;
-    a.E = Y; a.N = No; a.fid = f_obs->id; a.emv_mode = h_obs->emv_mode; a.consts = co.d(); a.consts_stride = clo.total;
-    a.cov_add = rr.d(); a.mean = m_pr; a.cov = P_pr; a.es_in = ld; a.bs_mean = a.bs_cov = 1;
+    a.E = Y; a.N = No; a.fid = f_obs->id; a.emv_mode = h_obs->emv_mode; a.consts = co; a.consts_stride = clo.total;
+    a.cov_add = rr; a.mean = m_pr; a.cov = P_pr; a.es_in = ld; a.bs_mean = a.bs_cov = 1;
     a.mean_f = y_mean; a.cov_f = P_y; a.cov_fx = P_yx; a.status = st_to;
     fill_fpar(f_obs, &a.fp);
     if ((rc = hip_fail(launch_apply_wide(a, P, s), "k_apply_wide(theta, obs)"))) return rc;
-    if ((rc = launch_kalman_update(D, Y, P, ld, m_pr, P_pr, y_mean, P_y, P_yx, ysoa.d(), m_fi, P_fi, st_up, s))) return rc;
-    if ((rc = launch_gauss_logpdf(Y, P, ld, ysoa.d(), y_mean, P_y, ll, s))) return rc;
+    if ((rc = launch_kalman_update(D, Y, P, ld, m_pr, P_pr, y_mean, P_y, P_yx, ysoa, m_fi, P_fi, st_up, s))) return rc;
+    if ((rc = launch_gauss_logpdf(Y, P, ld, ysoa, y_mean, P_y, ll, s))) return rc;
     hipLaunchKernelGGL(k_merge_theta_status, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, st_wd, st_wo, st_td, st_to,
                        st_up, st_all, P);
     if ((rc = hip_fail(hipGetLastError(), "k_merge_theta_status"))) return rc;
-    if ((rc = ssmq_soa_to_aos(m_fi, aos.d(), D, P, ld))) return rc;
-    if ((rc = ssmq_soa_to_aos(P_fi, aos.d() + P * D, D * D, P, ld))) return rc;
-    SSMQ_HIP(hipMemcpyAsync(post_mean, aos.d(), sizeof(double) * P * D, hipMemcpyDeviceToHost, s));
-    SSMQ_HIP(hipMemcpyAsync(post_cov, aos.d() + P * D, sizeof(double) * P * D * D, hipMemcpyDeviceToHost, s));
-    SSMQ_HIP(hipMemcpyAsync(loglik, ll, sizeof(double) * P, hipMemcpyDeviceToHost, s));
-    std::vector<int32_t> hst(P);
-    SSMQ_HIP(hipMemcpyAsync(hst.data(), st_all, sizeof(int32_t) * P, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(g_theta.hout, dev + off_out, out_bytes, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipStreamSynchronize(s));
+    // planes -> the caller's item-major arrays
+    const double *ho = (const double *)g_theta.hout;
+    const int32_t *hst = (const int32_t *)(ho + n_out * ld);
+    for (int e = 0; e < D; ++e)
+        for (int64_t i = 0; i < P; ++i) post_mean[(size_t)i * D + e] = ho[(size_t)e * ld + i];
+    const double *hp = ho + (size_t)D * ld;
+    for (int e = 0; e < D * D; ++e)
+        for (int64_t i = 0; i < P; ++i) post_cov[(size_t)i * D * D + e] = hp[(size_t)e * ld + i];
+    memcpy(loglik, hp + (size_t)D * D * ld, sizeof(double) * P);
     int first = 0;
     for (int64_t i = 0; i < P; ++i) {
         if (status) status[i] = hst[i];

@@ -896,36 +896,49 @@ __global__ void k_pack_wide_consts(int D, int E, int N, const double *xi, const 
 
 // d_xi [D][N], d_par [P][1+D] device; d_consts [P][wide_layout(D, E, N, BQ).total], d_status [P] device outputs.
 // Synchronous (the temporaries are released on return).
+// Workspace of gp_weights_wide_consts for P parameter rows (bytes; every part 256-byte aligned)
+static size_t wide_consts_part(size_t doubles) { return (sizeof(double) * doubles + 255) / 256 * 256; }
+size_t gp_weights_wide_ws_bytes(int D, int N, int64_t P) {
+    const size_t nn = (size_t)N * N, p = (size_t)P;
+    const size_t work_stride = 10 * nn + 4 * (size_t)N + (size_t)D * N + 2 * N + 64;
+    return 2 * wide_consts_part(p * N) + 3 * wide_consts_part(p * nn) + 2 * wide_consts_part(p * D * N) +
+           2 * wide_consts_part(p) + wide_consts_part(p * work_stride) + wide_consts_part(D + 2) +
+           (N > 64 ? wide_consts_part(p * N * (N + 1) / 2) : 0);
+}
+
+// GP weights of P parameter rows, packed as the per-item constant blocks of the generic transform kernel.  Everything is
+// enqueued on the library's stream, nothing is allocated and nothing waits: ws (gp_weights_wide_ws_bytes) is the caller's.
 int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double *d_par, int P, double jitter,
-                           double *d_consts, int32_t *d_status) {
+                           double *d_consts, int32_t *d_status, void *ws, size_t ws_bytes) {
     hipStream_t s = stream();
-    const size_t nn = (size_t)N * N;
+    const size_t nn = (size_t)N * N, p = (size_t)P;
     const int64_t work_stride = (int64_t)(10 * nn + 4 * (size_t)N + (size_t)D * N + 2 * N + 64);
-    DBuf dwm, dWc, dWcc, diK, dq, dQ, dR, dmv, div, dwork, dz;
+    if (!ws || ws_bytes < gp_weights_wide_ws_bytes(D, N, P)) {
+        set_error("gp_weights_wide_consts: workspace too small");
+        return SSMQ_E_ARG;
+    }
+    char *w = (char *)ws;
+    auto take = [&](size_t doubles) {
+        double *r = (double *)w;
+        w += wide_consts_part(doubles);
+        return r;
+    };
+    double *dwm = take(p * N), *dq = take(p * N), *dWc = take(p * nn), *diK = take(p * nn), *dQ = take(p * nn);
+    double *dWcc = take(p * D * N), *dR = take(p * D * N), *dmv = take(p), *div = take(p);
+    double *dwork = take(p * (size_t)work_stride), *dz = take(D + 2);
+    double *dlp = N > 64 ? take(p * N * (N + 1) / 2) : nullptr;   // packed Cholesky factors of the staged large-N path
     int rc;
-    if ((rc = dwm.alloc(sizeof(double) * P * N)) || (rc = dWc.alloc(sizeof(double) * P * nn)) ||
-        (rc = dWcc.alloc(sizeof(double) * P * D * N)) || (rc = diK.alloc(sizeof(double) * P * nn)) ||
-        (rc = dq.alloc(sizeof(double) * P * N)) || (rc = dQ.alloc(sizeof(double) * P * nn)) ||
-        (rc = dR.alloc(sizeof(double) * P * D * N)) || (rc = dmv.alloc(sizeof(double) * P)) ||
-        (rc = div.alloc(sizeof(double) * P)) || (rc = dwork.alloc(sizeof(double) * (size_t)P * work_stride)) ||
-        (rc = dz.alloc(sizeof(double) * (D + 2))))
-        return rc;
-    DBuf dlp;       // packed Cholesky factors of the staged large-N path (launch_weights)
-    if (N > 64 && (rc = dlp.alloc(sizeof(double) * (size_t)P * N * (N + 1) / 2))) return rc;
-    SSMQ_HIP(hipMemsetAsync(dQ.p, 0, sizeof(double) * P * nn, s));
+    SSMQ_HIP(hipMemsetAsync(dQ, 0, sizeof(double) * p * nn, s));
     WgtArgs a;
     memset(&a, 0, sizeof(a));
     a.D = D; a.N = N; a.P = P; a.NB = 0; a.jitter = jitter;
-    a.xi = d_xi; a.par = d_par; a.mulind = (const int32_t *)dz.p; a.px = dz.d(); a.xpx = dz.d(); a.pxpx = dz.d();
-    a.wm = dwm.d(); a.Wc = dWc.d(); a.Wcc = dWcc.d(); a.iK = diK.d(); a.q = dq.d(); a.Q = dQ.d(); a.R = dR.d();
-    a.mv = dmv.d(); a.iv = div.d(); a.status = d_status; a.work = dwork.d(); a.work_stride = work_stride;
-    a.lpack = N > 64 ? dlp.d() : nullptr;
+    a.xi = d_xi; a.par = d_par; a.mulind = (const int32_t *)dz; a.px = dz; a.xpx = dz; a.pxpx = dz;
+    a.wm = dwm; a.Wc = dWc; a.Wcc = dWcc; a.iK = diK; a.q = dq; a.Q = dQ; a.R = dR;
+    a.mv = dmv; a.iv = div; a.status = d_status; a.work = dwork; a.work_stride = work_stride;
+    a.lpack = dlp;
     if ((rc = launch_weights(a, s))) return rc;
-    hipLaunchKernelGGL(k_pack_wide_consts, dim3(P), dim3(64), 0, s, D, E, N, d_xi, dwm.d(), dWc.d(), dWcc.d(), diK.d(),
-                       dmv.d(), d_consts);
-    if ((rc = hip_fail(hipGetLastError(), "k_pack_wide_consts"))) return rc;
-    SSMQ_HIP(hipStreamSynchronize(s));
-    return SSMQ_OK;
+    hipLaunchKernelGGL(k_pack_wide_consts, dim3(P), dim3(64), 0, s, D, E, N, d_xi, dwm, dWc, dWcc, diK, dmv, d_consts);
+    return hip_fail(hipGetLastError(), "k_pack_wide_consts");
 }
 
 // ---- the kernel-level methods of the reference as entry points of their own ---------------------------------------------
