@@ -6,6 +6,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ssmq_host.h"
 #include "ssmq_apply_small.h"
@@ -403,6 +404,66 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
 
 using namespace ssmq;
 
+namespace {
+// Device arena + pinned staging blocks of the host-buffer entry points that are called in tight loops with small batches
+// (ssmq_apply_batch: the drop-in apply(); ssmq_gp_theta_step), grow-only, dropped when the device changes.  The calls are
+// synchronous on the library's one stream, so one arena serves them all.
+struct StagingArena {
+    void *dev = nullptr, *hin = nullptr, *hout = nullptr;
+    size_t dev_bytes = 0, hin_bytes = 0, hout_bytes = 0;
+    static int grow(void **p, size_t *have, size_t need, bool host) {
+        if (*have >= need) return SSMQ_OK;
+        if (*p) {
+            SSMQ_HIP(hipStreamSynchronize(stream()));
+            if (host) hipHostFree(*p); else hipFree(*p);
+        }
+        *p = nullptr;
+        *have = 0;
+        const size_t want = need + need / 4;       // a little head room: consecutive calls differ by a few items
+        if (host) SSMQ_HIP(hipHostMalloc(p, want, hipHostMallocDefault)); else SSMQ_HIP(hipMalloc(p, want));
+        *have = want;
+        return SSMQ_OK;
+    }
+    int reserve(size_t d, size_t hi, size_t ho) {
+        int rc;
+        if ((rc = grow(&dev, &dev_bytes, d, false)) || (rc = grow(&hin, &hin_bytes, hi, true)) ||
+            (rc = grow(&hout, &hout_bytes, ho, true)))
+            return rc;
+        return SSMQ_OK;
+    }
+    void drop() {
+        if (dev) hipFree(dev);
+        if (hin) hipHostFree(hin);
+        if (hout) hipHostFree(hout);
+        dev = hin = hout = nullptr;
+        dev_bytes = hin_bytes = hout_bytes = 0;
+    }
+};
+StagingArena g_stage;
+
+// memcpy between caller memory and the pinned blocks; large blocks on several threads (one core moves ~8 GB/s, which
+// would cost more than the PCIe transfer it feeds)
+void fast_copy(void *dst, const void *src, size_t bytes) {
+    constexpr size_t kChunk = size_t(2) << 20;
+    if (bytes < 2 * kChunk) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t nt = std::min<size_t>(8, bytes / kChunk);
+    const size_t per = (bytes / nt + 63) / 64 * 64;
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; ++t) {
+        const size_t lo = t * per, n = lo < bytes ? std::min(per, bytes - lo) : 0;
+        if (n) th.emplace_back([=] { memcpy((char *)dst + lo, (const char *)src + lo, n); });
+    }
+    memcpy(dst, src, std::min(per, bytes));
+    for (auto &t : th) t.join();
+}
+}  // namespace
+namespace ssmq {
+void drop_staging_arena() { g_stage.drop(); }
+}
+
 extern "C" {
 
 int ssmq_version(void) { return SSMQ_VERSION; }
@@ -657,39 +718,85 @@ int ssmq_apply_batch(ssmq_transform *h, const ssmq_integrand *f, int64_t B, cons
     if (B == 0) return SSMQ_OK;
     const int D = h->D, E = h->E;
     const int64_t ld = (B + 63) / 64 * 64;
-    const int n_in = D + D * D, n_out = E + E * E + E * D;
-    DevBuf aos_in, soa_in, aos_out, soa_out, d_time, d_st;
-    if ((rc = aos_in.alloc(sizeof(double) * B * n_in)) || (rc = soa_in.alloc(sizeof(double) * ld * n_in)) ||
-        (rc = aos_out.alloc(sizeof(double) * B * n_out)) || (rc = soa_out.alloc(sizeof(double) * ld * n_out)) ||
-        (rc = d_time.alloc(sizeof(double) * (time_stride ? B : 1))) || (rc = d_st.alloc(sizeof(int32_t) * ld)))
-        return rc;
+    const size_t n_in = (size_t)D + (size_t)D * D, n_out = (size_t)E + (size_t)E * E + (size_t)E * D;
+    const size_t n_time = time && time_stride ? (size_t)B : 1;
+    // Small batches - the drop-in apply() is B = 1 - convert the layout on the host and move one pinned block each way:
+    // one upload, one kernel, one download (the reference needs 60-120 us per apply(); six allocations, five layout
+    // kernels and seven copies per call took longer than that).  Large batches transpose on the device.
+    const bool host_layout = (size_t)B * (n_in + n_out) <= 65536;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    // device: [planes in | time] [planes out | status] and, for the device-side conversion, [AoS in | time] [AoS out | status]
+    const size_t pin_bytes = sizeof(double) * (n_in * ld + n_time), pout_bytes = sizeof(double) * n_out * ld + sizeof(int32_t) * ld;
+    const size_t ain_bytes = sizeof(double) * ((size_t)B * n_in + n_time), aout_bytes = sizeof(double) * B * n_out + sizeof(int32_t) * ld;
+    const size_t off_in = 0, off_out = al(pin_bytes), off_ai = off_out + al(pout_bytes),
+                 off_ao = off_ai + (host_layout ? 0 : al(ain_bytes)), total = off_ao + (host_layout ? 0 : al(aout_bytes));
+    // every transfer goes through the pinned blocks: copies from / to pageable caller memory stalled for 20-30 ms at some
+    // sizes (the runtime pins fresh pages on the fly)
+    if ((rc = g_stage.reserve(total, host_layout ? pin_bytes : ain_bytes, host_layout ? pout_bytes : aout_bytes))) return rc;
     hipStream_t s = stream();
-    // host AoS -> device AoS (mean block, then cov block) -> SoA planes
-    SSMQ_HIP(hipMemcpyAsync(aos_in.d(), mean, sizeof(double) * B * D, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(aos_in.d() + B * D, cov, sizeof(double) * B * D * D, hipMemcpyHostToDevice, s));
-    double tzero = 0.0;
-    SSMQ_HIP(hipMemcpyAsync(d_time.d(), time ? time : &tzero, sizeof(double) * (time && time_stride ? B : 1),
-                            hipMemcpyHostToDevice, s));
-    if ((rc = ssmq_aos_to_soa(aos_in.d(), soa_in.d(), D, B, ld))) return rc;
-    if ((rc = ssmq_aos_to_soa(aos_in.d() + B * D, soa_in.d() + ld * D, D * D, B, ld))) return rc;
-    double *o_mf = soa_out.d(), *o_cf = o_mf + ld * E, *o_cfx = o_cf + ld * E * E;
-    rc = apply_dev_impl(h, f, B, ld, soa_in.d(), soa_in.d() + ld * D, d_time.d(), time && time_stride ? 1 : 0, o_mf, o_cf,
-                        o_cfx, (int32_t *)d_st.p, nullptr, nullptr, false);
+    char *dev = (char *)g_stage.dev;
+    double *soa_in = (double *)(dev + off_in), *d_time = soa_in + n_in * ld;
+    double *o_mf = (double *)(dev + off_out), *o_cf = o_mf + ld * E, *o_cfx = o_cf + ld * E * E;
+    int32_t *d_st = (int32_t *)(o_cfx + ld * E * D);
+    const double tzero = 0.0;
+    double *hin = (double *)g_stage.hin;
+    if (host_layout) {
+        for (int e = 0; e < D; ++e) {
+            double *pl = hin + (size_t)e * ld;
+            for (int64_t i = 0; i < B; ++i) pl[i] = mean[(size_t)i * D + e];
+            for (int64_t i = B; i < ld; ++i) pl[i] = 0.0;
+        }
+        for (int e = 0; e < D * D; ++e) {
+            double *pl = hin + (size_t)(D + e) * ld;
+            for (int64_t i = 0; i < B; ++i) pl[i] = cov[(size_t)i * D * D + e];
+            for (int64_t i = B; i < ld; ++i) pl[i] = 0.0;
+        }
+        memcpy(hin + n_in * ld, time ? time : &tzero, sizeof(double) * n_time);
+        SSMQ_HIP(hipMemcpyAsync(soa_in, hin, pin_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        double *aos_in = (double *)(dev + off_ai);
+        fast_copy(hin, mean, sizeof(double) * B * D);
+        fast_copy(hin + (size_t)B * D, cov, sizeof(double) * B * D * D);
+        memcpy(hin + (size_t)B * n_in, time ? time : &tzero, sizeof(double) * n_time);
+        SSMQ_HIP(hipMemcpyAsync(aos_in, hin, ain_bytes, hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(d_time, aos_in + (size_t)B * n_in, sizeof(double) * n_time, hipMemcpyDeviceToDevice, s));
+        if ((rc = ssmq_aos_to_soa(aos_in, soa_in, D, B, ld))) return rc;
+        if ((rc = ssmq_aos_to_soa(aos_in + B * D, soa_in + ld * D, D * D, B, ld))) return rc;
+    }
+    rc = apply_dev_impl(h, f, B, ld, soa_in, soa_in + ld * D, d_time, time && time_stride ? 1 : 0, o_mf, o_cf, o_cfx, d_st,
+                        nullptr, nullptr, false);
     if (rc) return rc;
-    double *a_mf = aos_out.d(), *a_cf = a_mf + B * E, *a_cfx = a_cf + B * E * E;
-    if ((rc = ssmq_soa_to_aos(o_mf, a_mf, E, B, ld))) return rc;
-    if ((rc = ssmq_soa_to_aos(o_cf, a_cf, E * E, B, ld))) return rc;
-    if ((rc = ssmq_soa_to_aos(o_cfx, a_cfx, E * D, B, ld))) return rc;
-    SSMQ_HIP(hipMemcpyAsync(mean_f, a_mf, sizeof(double) * B * E, hipMemcpyDeviceToHost, s));
-    SSMQ_HIP(hipMemcpyAsync(cov_f, a_cf, sizeof(double) * B * E * E, hipMemcpyDeviceToHost, s));
-    SSMQ_HIP(hipMemcpyAsync(cov_fx, a_cfx, sizeof(double) * B * E * D, hipMemcpyDeviceToHost, s));
-    std::vector<int32_t> st(B);
-    SSMQ_HIP(hipMemcpyAsync(st.data(), d_st.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
-    SSMQ_HIP(hipStreamSynchronize(s));
+    const int32_t *hst;
+    const double *ho = (const double *)g_stage.hout;
+    if (host_layout) {
+        SSMQ_HIP(hipMemcpyAsync(g_stage.hout, o_mf, pout_bytes, hipMemcpyDeviceToHost, s));
+        SSMQ_HIP(hipStreamSynchronize(s));
+        for (int e = 0; e < E; ++e)
+            for (int64_t i = 0; i < B; ++i) mean_f[(size_t)i * E + e] = ho[(size_t)e * ld + i];
+        const double *hc = ho + (size_t)E * ld;
+        for (int e = 0; e < E * E; ++e)
+            for (int64_t i = 0; i < B; ++i) cov_f[(size_t)i * E * E + e] = hc[(size_t)e * ld + i];
+        const double *hx = hc + (size_t)E * E * ld;
+        for (int e = 0; e < E * D; ++e)
+            for (int64_t i = 0; i < B; ++i) cov_fx[(size_t)i * E * D + e] = hx[(size_t)e * ld + i];
+        hst = (const int32_t *)(hx + (size_t)E * D * ld);
+    } else {
+        double *a_mf = (double *)(dev + off_ao), *a_cf = a_mf + B * E, *a_cfx = a_cf + B * E * E;
+        if ((rc = ssmq_soa_to_aos(o_mf, a_mf, E, B, ld))) return rc;
+        if ((rc = ssmq_soa_to_aos(o_cf, a_cf, E * E, B, ld))) return rc;
+        if ((rc = ssmq_soa_to_aos(o_cfx, a_cfx, E * D, B, ld))) return rc;
+        SSMQ_HIP(hipMemcpyAsync(a_mf + (size_t)B * n_out, d_st, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, s));
+        SSMQ_HIP(hipMemcpyAsync(g_stage.hout, a_mf, aout_bytes, hipMemcpyDeviceToHost, s));
+        SSMQ_HIP(hipStreamSynchronize(s));
+        fast_copy(mean_f, ho, sizeof(double) * B * E);
+        fast_copy(cov_f, ho + (size_t)B * E, sizeof(double) * B * E * E);
+        fast_copy(cov_fx, ho + (size_t)B * (E + E * E), sizeof(double) * B * E * D);
+        hst = (const int32_t *)(ho + (size_t)B * n_out);
+    }
     int first = 0;
     for (int64_t i = 0; i < B; ++i) {
-        if (status) status[i] = st[i];
-        if (st[i] && !first) first = (int)std::min<int64_t>(i + 1, 0x7fffffff);
+        if (status) status[i] = hst[i];
+        if (hst[i] && !first) first = (int)std::min<int64_t>(i + 1, 0x7fffffff);
     }
     return first;
 }
@@ -887,7 +994,7 @@ struct GraphDropGuard {
 
 namespace ssmq {
 void reset_wide_attributes();
-void drop_theta_arena();
+void drop_staging_arena();
 void reset_device_caches() {
     g_fc.drop_graph();
     g_fc.consts_ok = false;
@@ -895,7 +1002,7 @@ void reset_device_caches() {
     g_fc.ws = nullptr;
     g_fc.ws_bytes = 0;
     drop_gemm_scratch();
-    drop_theta_arena();
+    drop_staging_arena();
     reset_wide_attributes();
 }
 }  // namespace ssmq
@@ -1411,44 +1518,6 @@ int launch_gauss_logpdf(int Y, int64_t B, int64_t ld, const double *y, const dou
                         double *out, hipStream_t s);
 }
 
-namespace {
-// Device arena + pinned staging blocks of ssmq_gp_theta_step, grow-only, dropped when the device changes.
-struct ThetaArena {
-    void *dev = nullptr, *hin = nullptr, *hout = nullptr;
-    size_t dev_bytes = 0, hin_bytes = 0, hout_bytes = 0;
-    static int grow(void **p, size_t *have, size_t need, bool host) {
-        if (*have >= need) return SSMQ_OK;
-        if (*p) {
-            SSMQ_HIP(hipStreamSynchronize(stream()));
-            if (host) hipHostFree(*p); else hipFree(*p);
-        }
-        *p = nullptr;
-        *have = 0;
-        const size_t want = need + need / 4;       // a little head room: consecutive calls differ by a few items
-        if (host) SSMQ_HIP(hipHostMalloc(p, want, hipHostMallocDefault)); else SSMQ_HIP(hipMalloc(p, want));
-        *have = want;
-        return SSMQ_OK;
-    }
-    int reserve(size_t d, size_t hi, size_t ho) {
-        int rc;
-        if ((rc = grow(&dev, &dev_bytes, d, false)) || (rc = grow(&hin, &hin_bytes, hi, true)) ||
-            (rc = grow(&hout, &hout_bytes, ho, true)))
-            return rc;
-        return SSMQ_OK;
-    }
-    void drop() {
-        if (dev) hipFree(dev);
-        if (hin) hipHostFree(hin);
-        if (hout) hipHostFree(hout);
-        dev = hin = hout = nullptr;
-        dev_bytes = hin_bytes = hout_bytes = 0;
-    }
-};
-ThetaArena g_theta;
-}  // namespace
-namespace ssmq {
-void drop_theta_arena() { g_theta.drop(); }
-}
 
 namespace {
 __global__ void k_merge_theta_status(const int32_t *w_dyn, const int32_t *w_obs, const int32_t *t_dyn, const int32_t *t_obs,
@@ -1506,9 +1575,9 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
                  off_mid = off_co + al(sizeof(double) * P * clo.total), off_out = off_mid + al(sizeof(double) * n_mid * ld),
                  off_st = off_out + al(out_bytes), off_ws = off_st + al(sizeof(int32_t) * 5 * ld),
                  total = off_ws + std::max(ws_d, ws_o);
-    if ((rc = g_theta.reserve(total, sizeof(double) * n_in, out_bytes))) return rc;
-    char *dev = (char *)g_theta.dev;
-    double *hin = (double *)g_theta.hin;
+    if ((rc = g_stage.reserve(total, sizeof(double) * n_in, out_bytes))) return rc;
+    char *dev = (char *)g_stage.dev;
+    double *hin = (double *)g_stage.hin;
     {
         double *h = hin;
         auto put = [&](const double *src, size_t n) {
@@ -1579,10 +1648,10 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     hipLaunchKernelGGL(k_merge_theta_status, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, st_wd, st_wo, st_td, st_to,
                        st_up, st_all, P);
     if ((rc = hip_fail(hipGetLastError(), "k_merge_theta_status"))) return rc;
-    SSMQ_HIP(hipMemcpyAsync(g_theta.hout, dev + off_out, out_bytes, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(g_stage.hout, dev + off_out, out_bytes, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipStreamSynchronize(s));
     // planes -> the caller's item-major arrays
-    const double *ho = (const double *)g_theta.hout;
+    const double *ho = (const double *)g_stage.hout;
     const int32_t *hst = (const int32_t *)(ho + n_out * ld);
     for (int e = 0; e < D; ++e)
         for (int64_t i = 0; i < P; ++i) post_mean[(size_t)i * D + e] = ho[(size_t)e * ld + i];
