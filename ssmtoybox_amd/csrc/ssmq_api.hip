@@ -809,26 +809,32 @@ int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, co
     if (B == 0) return SSMQ_OK;
     const int D = h->D, N = h->N;
     if (wide_lds_bytes(D, h->E, N) > 160 * 1024 - 64) return SSMQ_E_UNSUPPORTED;
-    DevBuf dm, dc, dx, dl, ds;
-    if ((rc = dm.alloc(sizeof(double) * B * D)) || (rc = dc.alloc(sizeof(double) * B * D * D)) ||
-        (rc = dx.alloc(sizeof(double) * B * D * N)) || (rc = dl.alloc(sizeof(double) * B * D * D)) ||
-        (rc = ds.alloc(sizeof(int32_t) * B)))
-        return rc;
+    // staging arena: [mean | cov] up, [x | chol | status] down, one transfer each way through the pinned blocks
+    const size_t nb = (size_t)B, n_in = nb * ((size_t)D + (size_t)D * D), n_x = nb * D * N, n_l = nb * D * D;
+    const size_t in_bytes = sizeof(double) * n_in, out_bytes = sizeof(double) * (n_x + n_l) + sizeof(int32_t) * nb;
+    const size_t off_out = (in_bytes + 255) / 256 * 256;
+    if ((rc = g_stage.reserve(off_out + out_bytes, in_bytes, out_bytes))) return rc;
     hipStream_t s = stream();
-    SSMQ_HIP(hipMemcpyAsync(dm.p, mean, sizeof(double) * B * D, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(dc.p, cov, sizeof(double) * B * D * D, hipMemcpyHostToDevice, s));
+    double *dm = (double *)g_stage.dev, *dc = dm + nb * D;
+    double *dx = (double *)((char *)g_stage.dev + off_out), *dl = dx + n_x;
+    int32_t *ds = (int32_t *)(dl + n_l);
+    double *hin = (double *)g_stage.hin;
+    fast_copy(hin, mean, sizeof(double) * nb * D);
+    fast_copy(hin + nb * D, cov, sizeof(double) * n_l);
+    SSMQ_HIP(hipMemcpyAsync(dm, hin, in_bytes, hipMemcpyHostToDevice, s));
     WideArgs a;
     memset(&a, 0, sizeof(a));
     a.D = D; a.E = h->E; a.N = N; a.form = h->form; a.mode = SSMQ_WIDE_POINTS; a.consts = h->d_wide;
     a.cov_scale = a.ccov_scale = 1.0;
-    a.mean = dm.d(); a.cov = dc.d(); a.es_in = 1; a.bs_mean = D; a.bs_cov = D * D; a.status = (int32_t *)ds.p;
-    a.x_out = dx.d(); a.chol_out = dl.d();
+    a.mean = dm; a.cov = dc; a.es_in = 1; a.bs_mean = D; a.bs_cov = D * D; a.status = ds;
+    a.x_out = dx; a.chol_out = dl;
     if ((rc = hip_fail(launch_apply_wide(a, B, s), "k_apply_wide(points)"))) return rc;
-    SSMQ_HIP(hipMemcpyAsync(x, dx.p, sizeof(double) * B * D * N, hipMemcpyDeviceToHost, s));
-    SSMQ_HIP(hipMemcpyAsync(chol, dl.p, sizeof(double) * B * D * D, hipMemcpyDeviceToHost, s));
-    std::vector<int32_t> st(B);
-    SSMQ_HIP(hipMemcpyAsync(st.data(), ds.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(g_stage.hout, dx, out_bytes, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipStreamSynchronize(s));
+    const double *ho = (const double *)g_stage.hout;
+    fast_copy(x, ho, sizeof(double) * n_x);
+    fast_copy(chol, ho + n_x, sizeof(double) * n_l);
+    const int32_t *st = (const int32_t *)(ho + n_x + n_l);
     int first = 0;
     for (int64_t i = 0; i < B; ++i) {
         if (status) status[i] = st[i];
@@ -849,55 +855,65 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
     if (B == 0) return SSMQ_OK;
     const int D = h->D, E = h->E, N = h->N;
     if (wide_lds_bytes(D, E, N) > 160 * 1024 - 64) return SSMQ_E_UNSUPPORTED;
-    DevBuf dl, dfx, dm, dx, omf, ocf, ocfx;
-    if ((rc = dl.alloc(sizeof(double) * B * D * D)) || (rc = dfx.alloc(sizeof(double) * B * E * N)) ||
-        (rc = dm.alloc(sizeof(double) * B * D)) || (rc = dx.alloc(sizeof(double) * B * D * N)) ||
-        (rc = omf.alloc(sizeof(double) * B * E)) || (rc = ocf.alloc(sizeof(double) * B * E * E)) ||
-        (rc = ocfx.alloc(sizeof(double) * B * E * D)))
-        return rc;
+    // staging arena: [chol | fx | mean | x] up, [mean_f | cov_f | cov_fx] down through the pinned blocks; the padded copies
+    // of the matrix-core route behind them
+    const bool centred = h->form == SSMQ_FORM_SIGMA;
+    const bool gemm = h->d_wc_pad && h->form == SSMQ_FORM_BQ && B * E >= kGemmMinRows;
+    const size_t nb = (size_t)B, n_l = nb * D * D, n_fx = nb * E * N, n_m = centred ? nb * D : 0, n_x = centred ? nb * D * N : 0;
+    const size_t n_out = nb * ((size_t)E + (size_t)E * E + (size_t)E * D);
+    const size_t in_bytes = sizeof(double) * (n_l + n_fx + n_m + n_x), out_bytes = sizeof(double) * n_out;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t pad_bytes = gemm ? sizeof(double) * nb * E * h->np_pad : 0;
+    const size_t off_out = al(in_bytes), off_fxp = off_out + al(out_bytes), off_tt = off_fxp + al(pad_bytes);
+    if ((rc = g_stage.reserve(off_tt + al(pad_bytes), in_bytes, out_bytes))) return rc;
     hipStream_t s = stream();
-    SSMQ_HIP(hipMemcpyAsync(dl.p, chol, sizeof(double) * B * D * D, hipMemcpyHostToDevice, s));
-    SSMQ_HIP(hipMemcpyAsync(dfx.p, fx, sizeof(double) * B * E * N, hipMemcpyHostToDevice, s));
-    if (h->form == SSMQ_FORM_SIGMA) {
-        SSMQ_HIP(hipMemcpyAsync(dm.p, mean, sizeof(double) * B * D, hipMemcpyHostToDevice, s));
-        SSMQ_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * B * D * N, hipMemcpyHostToDevice, s));
+    char *dev = (char *)g_stage.dev;
+    double *dl = (double *)dev, *dfx = dl + n_l, *dm = dfx + n_fx, *dx = dm + n_m;
+    double *omf = (double *)(dev + off_out), *ocf = omf + nb * E, *ocfx = ocf + nb * E * E;
+    double *hin = (double *)g_stage.hin;
+    fast_copy(hin, chol, sizeof(double) * n_l);
+    fast_copy(hin + n_l, fx, sizeof(double) * n_fx);
+    if (centred) {
+        fast_copy(hin + n_l + n_fx, mean, sizeof(double) * n_m);
+        fast_copy(hin + n_l + n_fx + n_m, x, sizeof(double) * n_x);
     }
+    SSMQ_HIP(hipMemcpyAsync(dl, hin, in_bytes, hipMemcpyHostToDevice, s));
     WideArgs a;
     memset(&a, 0, sizeof(a));
     a.D = D; a.E = E; a.N = N; a.form = h->form; a.mode = SSMQ_WIDE_FX; a.emv_mode = h->emv_mode; a.tp_nu = h->tp_nu;
     a.cov_scale = a.ccov_scale = 1.0;
-    a.consts = h->d_wide; a.mean = dm.d(); a.chol_in = dl.d(); a.fx_in = dfx.d(); a.x_in = dx.d();
-    a.mean_f = omf.d(); a.cov_f = ocf.d(); a.cov_fx = ocfx.d(); a.es_out = 1; a.bs_mf = E; a.bs_cf = E * E;
+    a.consts = h->d_wide; a.mean = dm; a.chol_in = dl; a.fx_in = dfx; a.x_in = dx;
+    a.mean_f = omf; a.cov_f = ocf; a.cov_fx = ocfx; a.es_out = 1; a.bs_mf = E; a.bs_cf = E * E;
     a.bs_cfx = E * D;
-    DevBuf fxp, ttp;
-    if (h->d_wc_pad && h->form == SSMQ_FORM_BQ && B * E >= kGemmMinRows) {
+    if (gemm) {
         // matrix-core route: rows re-pitched to the padded column count, T = FX Wc for the whole batch, then the rest
         const int NP = h->np_pad;
         const int64_t M = B * E;
-        if ((rc = fxp.alloc(sizeof(double) * M * NP))) return rc;
-        SSMQ_HIP(hipMemsetAsync(fxp.p, 0, sizeof(double) * M * NP, s));
-        SSMQ_HIP(hipMemcpy2DAsync(fxp.p, sizeof(double) * NP, dfx.p, sizeof(double) * N, sizeof(double) * N, M,
+        double *fxp = (double *)(dev + off_fxp), *ttp = (double *)(dev + off_tt);
+        SSMQ_HIP(hipMemsetAsync(fxp, 0, sizeof(double) * M * NP, s));
+        SSMQ_HIP(hipMemcpy2DAsync(fxp, sizeof(double) * NP, dfx, sizeof(double) * N, sizeof(double) * N, M,
                                   hipMemcpyDeviceToDevice, s));
         if (h->tp_nu <= 0.0 && h->d_wcx_pad && fxwc_cov_supported(E) && D <= 16 && !getenv("SSMQ_NO_FUSED_COV")) {
             // means of the supplied values, then the GEMM whose epilogue forms both covariances (no T in memory)
             const WideLayout wl = wide_layout(D, E, N, h->form);
-            if ((rc = launch_row_means(fxp.d(), h->d_wide + wl.wm, M, NP, N, omf.d(), s))) return rc;
-            if ((rc = launch_fxwc_cov_mfma(NP, fxp.d(), h->d_wcx_pad, M, NP, omf.d(), dl.d(), h->d_wide + wl.emv,
-                                           h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, nullptr, 1.0, 1.0, E, D, ocf.d(),
-                                           ocfx.d(), 1, (int64_t)E * E, (int64_t)E * D, s)))
+            if ((rc = launch_row_means(fxp, h->d_wide + wl.wm, M, NP, N, omf, s))) return rc;
+            if ((rc = launch_fxwc_cov_mfma(NP, fxp, h->d_wcx_pad, M, NP, omf, dl, h->d_wide + wl.emv,
+                                           h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, nullptr, 1.0, 1.0, E, D, ocf, ocfx, 1,
+                                           (int64_t)E * E, (int64_t)E * D, s)))
                 return rc;
             a.mode = -1;   // done
         } else {
-            if ((rc = ttp.alloc(sizeof(double) * M * NP))) return rc;
-            if ((rc = launch_fxwc_mfma(NP, fxp.d(), h->d_wc_pad, ttp.d(), M, NP, NP, s))) return rc;
-            a.fx_ld = NP; a.fx_in = fxp.d(); a.t_in = ttp.d();
+            if ((rc = launch_fxwc_mfma(NP, fxp, h->d_wc_pad, ttp, M, NP, NP, s))) return rc;
+            a.fx_ld = NP; a.fx_in = fxp; a.t_in = ttp;
         }
     }
     if (a.mode != -1 && (rc = hip_fail(launch_apply_wide(a, B, s), "k_apply_wide(fx)"))) return rc;
-    SSMQ_HIP(hipMemcpyAsync(mean_f, omf.p, sizeof(double) * B * E, hipMemcpyDeviceToHost, s));
-    SSMQ_HIP(hipMemcpyAsync(cov_f, ocf.p, sizeof(double) * B * E * E, hipMemcpyDeviceToHost, s));
-    SSMQ_HIP(hipMemcpyAsync(cov_fx, ocfx.p, sizeof(double) * B * E * D, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(g_stage.hout, omf, out_bytes, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipStreamSynchronize(s));
+    const double *ho = (const double *)g_stage.hout;
+    fast_copy(mean_f, ho, sizeof(double) * nb * E);
+    fast_copy(cov_f, ho + nb * E, sizeof(double) * nb * E * E);
+    fast_copy(cov_fx, ho + nb * (E + (size_t)E * E), sizeof(double) * nb * E * D);
     return SSMQ_OK;
 }
 

@@ -38,3 +38,23 @@ for name, tf, f, D in cases:
             tf.apply_batch(f, means, covs, 1.0)
         dt = (time.perf_counter() - t0) / n
         print('%-22s apply_batch B=%-6d %8.1f us per call  %.3e transforms/s' % (name, B, dt * 1e6, B / dt), flush=True)
+
+
+def polar2cartesian(x, pars):
+    return x[0] * np.array([np.cos(x[1]), np.sin(x[1])])
+
+
+mt = amd.BayesSardTransform(2, 2, np.array([[1.0, 1, 1]]), multi_ind=np.array([[0, 1, 0, 2, 0], [0, 0, 1, 0, 2]]), point_str='ut')
+mean, cov = np.array([1, np.pi / 2]), np.diag([0.05 ** 2, (np.pi / 10) ** 2])
+for _ in range(10):
+    mt.apply(polar2cartesian, mean, cov, np.atleast_1d(0))
+t0 = time.perf_counter()
+for _ in range(1000):
+    mt.apply(polar2cartesian, mean, cov, np.atleast_1d(0))
+dt = (time.perf_counter() - t0) / 1000
+t0 = time.perf_counter()
+for _ in range(1000):
+    np.apply_along_axis(polar2cartesian, 0, np.zeros((2, 5)), None)
+df = (time.perf_counter() - t0) / 1000
+print('python callable (polar -> cartesian, BSQ D=2 N=5) apply() %8.1f us per call, of which %.1f us evaluate f in Python'
+      % (dt * 1e6, df * 1e6), flush=True)
