@@ -16,8 +16,10 @@
  *   - return value: 0 ok; > 0 = 1 + index of the first batch item whose input covariance is not positive definite
  *     (the reference raises numpy.linalg.LinAlgError there: bq/bqmtran.py:98, mtran.py:139); < 0 error
  *     (SSMQ_E_*); ssmq_last_error() gives the text.  No exception crosses the ABI.
- *   - a transform handle is bound to the device that was current when it was created; one HIP stream per process
- *     (ssmq calls are not thread-safe on one handle; different handles are independent).
+ *   - a transform handle is bound to the device that was current when it was created.  The library keeps process-global
+ *     state - one HIP stream, grow-only workspaces and pinned staging blocks, a cached launch graph, the communicator -
+ *     so calls must come from ONE thread at a time (one process per GPU is the intended deployment); the caches are
+ *     dropped when ssmq_set_device() selects another device.
  *   - there is NO CPU fallback anywhere behind this ABI: without a usable gfx950 device every compute entry point
  *     returns SSMQ_E_HIP.
  */
