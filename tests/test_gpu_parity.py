@@ -1697,6 +1697,7 @@ def test_launch_loop_graph_follows_weight_updates(amd, golden, monkeypatch):
     factors zeroed when the new Wc fails the acceptance test): the next pass must re-capture, not replay the stale
     variant.  Checked against a freshly built filter holding the same weights."""
     from ssmtoybox_amd import ssinf, ssmod as sm
+    monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)      # the premise of this test is that a fast path is selected
     g = golden('g4_filters')
     y = np.tile(g['rer_y'], (1, 1, 16))[:, :30]
     dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, g['rer_m0'], g['rer_P0']), sm.GaussRV(3, cov=g['rer_Q']))
