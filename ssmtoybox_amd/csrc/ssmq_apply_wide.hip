@@ -288,6 +288,9 @@ __global__ __launch_bounds__(BLOCK) void k_apply_wide(const WideArgs a) {
 // CU keeps 8+ trajectories in flight instead of the 3 that the LDS image of k_apply_wide allows - that kernel spent
 // its time waiting (10 us per trajectory behind ~35 barriers and serial LDS / L2 round trips, 277 us for B = 1e4).
 constexpr int kEvalWaves = 4;
+// DM: compile-time bound on D and E (the unrolled per-point loops run to DM, predicated on the run-time sizes)
+// FC: integrand fixed at compile time (no switch, no select chain for a state index it does not take), or -1
+template <int DM, int FC = -1>
 __global__ __launch_bounds__(64 * kEvalWaves) void k_eval_wave(const WideArgs a, int64_t B) {
     __shared__ double s_all[kEvalWaves][SSMQ_MAX_DIM * SSMQ_MAX_DIM + SSMQ_MAX_DIM];
     const int D = a.D, E = a.E, N = a.N;
@@ -330,25 +333,25 @@ __global__ __launch_bounds__(64 * kEvalWaves) void k_eval_wave(const WideArgs a,
     const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
     const int64_t fl = a.fx_ld ? a.fx_ld : N;
     double *rows = a.fx_out + b * E * fl;
-    double macc[SSMQ_MAX_DIM];
+    double macc[DM];
 #pragma unroll
-    for (int e = 0; e < SSMQ_MAX_DIM; ++e) macc[e] = 0.0;
+    for (int e = 0; e < DM; ++e) macc[e] = 0.0;
     for (int n0 = 0; n0 < fl; n0 += 64) {
         const int n = n0 + lane;
-        double o[SSMQ_MAX_DIM];
+        double o[DM];
 #pragma unroll
-        for (int e = 0; e < SSMQ_MAX_DIM; ++e) o[e] = 0.0;
+        for (int e = 0; e < DM; ++e) o[e] = 0.0;
         if (n < N) {
-            double xin[SSMQ_MAX_DIM], x[SSMQ_MAX_DIM];
+            double xin[DM], x[DM];
 #pragma unroll
-            for (int k = 0; k < SSMQ_MAX_DIM; ++k) xin[k] = k < D ? c[cl.xiT + n * D + k] : 0.0;
+            for (int k = 0; k < DM; ++k) xin[k] = k < D ? c[cl.xiT + n * D + k] : 0.0;
 #pragma unroll
-            for (int d = 0; d < SSMQ_MAX_DIM; ++d) {
+            for (int d = 0; d < DM; ++d) {
                 double s = 0.0;
                 if (d < D) {
                     s = sm[d];
 #pragma unroll
-                    for (int k = 0; k < SSMQ_MAX_DIM; ++k)
+                    for (int k = 0; k < DM; ++k)
                         if (k <= d) s += sL[d * D + k] * xin[k];
                 }
                 x[d] = s;
@@ -356,28 +359,34 @@ __global__ __launch_bounds__(64 * kEvalWaves) void k_eval_wave(const WideArgs a,
             double xs[kMaxIntegrandIn];
 #pragma unroll
             for (int k = 0; k < kMaxIntegrandIn; ++k) {
-                double v = x[k < SSMQ_MAX_DIM ? k : 0];
-                if (a.fp.n_idx > 0) {              // state-index selection (MeasurementModel.state_index)
+                double v = k < DM ? x[k < DM ? k : 0] : 0.0;
+                if (FC < 0 && a.fp.n_idx > 0) {    // state-index selection (MeasurementModel.state_index)
                     const int src = k < a.fp.n_idx ? a.fp.idx[k] : 0;
                     v = x[0];
 #pragma unroll
-                    for (int q = 1; q < SSMQ_MAX_DIM; ++q) v = (src == q) ? x[q] : v;
+                    for (int q = 1; q < DM; ++q) v = (src == q) ? x[q] : v;
                 }
                 xs[k] = v;
             }
-            eval_integrand(a.fid, xs, t, a.fp, o);
+            if constexpr (FC >= 0) {
+                Fn<FC> fn;
+                fn.init(t, a.fp);
+                fn.template eval<SSMQ_MAX_FIDX>(xs, o);
+            } else {
+                eval_integrand(a.fid, xs, t, a.fp, o);
+            }
             const double w = c[cl.wm + n];
 #pragma unroll
-            for (int e = 0; e < SSMQ_MAX_DIM; ++e) macc[e] += o[e] * w;
+            for (int e = 0; e < DM; ++e) macc[e] += o[e] * w;
         }
         if (n < fl) {
 #pragma unroll
-            for (int e = 0; e < SSMQ_MAX_DIM; ++e)
+            for (int e = 0; e < DM; ++e)
                 if (e < E) rows[(int64_t)e * fl + n] = n < N ? (ok ? o[e] : nan) : 0.0;
         }
     }
 #pragma unroll
-    for (int e = 0; e < SSMQ_MAX_DIM; ++e) {
+    for (int e = 0; e < DM; ++e) {
         if (e < E) {
             const double s = wave_sum(macc[e]);
             if (lane == 0) {
@@ -390,7 +399,15 @@ __global__ __launch_bounds__(64 * kEvalWaves) void k_eval_wave(const WideArgs a,
 }
 
 hipError_t launch_eval_wave(const WideArgs &a, int64_t B, hipStream_t s) {
-    hipLaunchKernelGGL(k_eval_wave, dim3((unsigned)((B + kEvalWaves - 1) / kEvalWaves)), dim3(64 * kEvalWaves), 0, s, a, B);
+    const dim3 grid((unsigned)((B + kEvalWaves - 1) / kEvalWaves)), block(64 * kEvalWaves);
+    const int dm = a.D > a.E ? a.D : a.E;
+    if (a.fid == SSMQ_F_SMOOTH10D_DYN && a.fp.n_idx == 0 && dm <= 10)
+        hipLaunchKernelGGL((k_eval_wave<10, SSMQ_F_SMOOTH10D_DYN>), grid, block, 0, s, a, B);
+    else if (dm <= 4) hipLaunchKernelGGL(k_eval_wave<4>, grid, block, 0, s, a, B);
+    else if (dm <= 8) hipLaunchKernelGGL(k_eval_wave<8>, grid, block, 0, s, a, B);
+    else if (dm <= 10) hipLaunchKernelGGL(k_eval_wave<10>, grid, block, 0, s, a, B);
+    else if (dm <= 12) hipLaunchKernelGGL(k_eval_wave<12>, grid, block, 0, s, a, B);
+    else hipLaunchKernelGGL(k_eval_wave<SSMQ_MAX_DIM>, grid, block, 0, s, a, B);
     return hipGetLastError();
 }
 
