@@ -293,6 +293,13 @@ static const FusedEntry kFused[] = {
     SSMQ_FUSED_FAST(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
     SSMQ_FUSED_FAST(SSMQ_F_REENTRY2D_BIAS_DYN, SSMQ_F_RADAR2D_MEAS, 6, 2, 13, 0),
     SSMQ_FUSED_FAST(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 11, 1),
+    // spherical-radial point sets (2 D points: the cubature Kalman filter and every BQ transform built with 'sr')
+    SSMQ_FUSED(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 4, 0),
+    SSMQ_FUSED(SSMQ_F_REENTRY1D_DYN, SSMQ_F_RANGE_MEAS, 3, 1, 6, 0),
+    SSMQ_FUSED(SSMQ_F_CV_DYN, SSMQ_F_RADAR2D_MEAS, 4, 2, 8, 0),
+    SSMQ_FUSED(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 10, 0),
+    SSMQ_FUSED(SSMQ_F_REENTRY2D_BIAS_DYN, SSMQ_F_RADAR2D_MEAS, 6, 2, 12, 0),
+    SSMQ_FUSED(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 10, 1),
 #endif
 };
 

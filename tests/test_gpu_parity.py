@@ -571,6 +571,49 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
     assert within(cov_err(S1, S2), 2e-8, 'reentry ukf smoother fused vs loop sP (entry-scaled)')
 
 
+def test_spherical_radial_fused_filters_match_launch_loop(amd, golden, monkeypatch):
+    """Fused instantiations for spherical-radial point sets (2 D points: the cubature Kalman filter, BQ transforms built
+    with 'sr'): one-kernel time loop against the launch loop of stand-alone kernels, on the reentry, pendulum and
+    coordinated-turn models; the cubature filter on UNGM additionally has a reference golden (test_ungm_filter_golden)."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g4_filters')
+    dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, g['rer_m0'], g['rer_P0']), sm.GaussRV(3, cov=g['rer_Q']))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=g['rer_R']), 5)
+    rng = np.random.default_rng(21)
+    pend = sm.Pendulum2DTransition(sm.GaussRV(2, mean=np.array([1.5, 0.0]), cov=0.01 * np.eye(2)),
+                                   sm.GaussRV(2, cov=0.01 * np.eye(2)), 0.01)
+    pobs = sm.Pendulum2DMeasurement(sm.GaussRV(1, cov=np.array([[0.1]])), 2)
+    yp = np.sin(1.5 + 0.05 * rng.standard_normal((1, 40, 64))) + 0.3 * rng.standard_normal((1, 40, 64))
+    m0c = np.array([1000, 300, 1000, 0, np.deg2rad(-3.0)])
+    ct = sm.CoordinatedTurnTransition(sm.GaussRV(5, m0c, np.diag([100, 10, 100, 10, 0.1])),
+                                      sm.GaussRV(5, cov=np.diag([1e-3, 1e-2, 1e-3, 1e-2, 1e-5])), dt=0.1)
+    bear = sm.BearingMeasurement(sm.GaussRV(4, cov=10e-3 * np.eye(4)), 5, state_index=[0, 2], sensor_pos=SENSORS)
+    pos = m0c[[0, 2]][:, None, None] + np.array([30.0, 0.0])[:, None, None] * np.arange(1, 9)[None, :, None]
+    yc = np.arctan2(pos[1][None] - SENSORS[:, 1][:, None, None], pos[0][None] - SENSORS[:, 0][:, None, None]) + \
+        0.05 * rng.standard_normal((4, 8, 64))
+    cases = [('reentry ckf', ssinf.CubatureKalman(dyn, obs), np.tile(g['rer_y'], (1, 1, 8))[:, :40], 'D=5,Y=2,ND=10', 1e-11),
+             ('pendulum ckf', ssinf.CubatureKalman(pend, pobs), yp, 'D=2,Y=1,ND=4', 1e-11),
+             ('pendulum gpqkf sr', ssinf.GaussianProcessKalman(pend, pobs, np.array([[1.0, 3, 3]]), np.array([[1.0, 3, 3]]),
+                                                               'rbf', 'sr'), yp, 'D=2,Y=1,ND=4', 1e-10),
+             ('pendulum tpqkf sr', ssinf.StudentProcessKalman(pend, pobs, np.array([[1.0, 3, 3]]), np.array([[1.0, 3, 3]]),
+                                                              'rbf', 'sr'), yp, 'D=2,Y=1,ND=4', 1e-10),
+             ('ct ckf', ssinf.CubatureKalman(ct, bear), yc, 'D=5,Y=4,ND=10', 1e-10)]
+    for name, alg, y, tag, bar in cases:
+        monkeypatch.delenv('SSMQ_NO_FUSED', raising=False)
+        assert 'k_filter_fused<' + tag in alg.kernel_name(), alg.kernel_name()
+        fm, fP = alg.forward_pass_batch(y, raise_on_failure=False)
+        st = alg.status.copy()
+        monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+        assert 'hipGraph' in alg.kernel_name()
+        fm2, fP2 = alg.forward_pass_batch(y, raise_on_failure=False)
+        monkeypatch.delenv('SSMQ_NO_FUSED')
+        assert np.array_equal(st, alg.status), name
+        ok = st == 0
+        assert ok.any(), name
+        assert within(mean_err(fm[..., ok], fm2[..., ok]), bar, name + ' fused vs loop fm (row-scaled)')
+        assert within(cov_err(fP[..., ok], fP2[..., ok]), 10 * bar, name + ' fused vs loop fP (entry-scaled)')
+
+
 def test_student_filters_golden(amd, golden, monkeypatch):
     """Studentian recursion (ssinf.py:555-857) against the reference's trajectories: fully-symmetric Student filter on
     UNGM (fused kernel) and on CV + radar (launch loop, generic kernels), and the t-process quadrature Student filter
