@@ -82,8 +82,13 @@ __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const
             load_a(kb + 1, an);
         }
         const double *sb = lds + buf * 16 * LB;
+#ifndef SSMQ_GEMM_PARK_AT
+#define SSMQ_GEMM_PARK_AT 3      // the next slab goes to LDS before the last of the four k sub-steps: the writes and
+                                 // the waits for the global loads hide behind its MFMAs (2-4 % over parking after them)
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            if (s == SSMQ_GEMM_PARK_AT && kb + 1 < NT) park_b(buf ^ 1);
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const double b = sb[(4 * lg + s) * LB + ct * 16 + li];
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const
             }
         }
         if (kb + 1 < NT) {
-            park_b(buf ^ 1);
+            if (SSMQ_GEMM_PARK_AT >= 4) park_b(buf ^ 1);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -194,6 +199,7 @@ __global__ __launch_bounds__(kGemmBlock, 2) void k_fxwc_cov_mfma(const double *_
         const double *sb = lds + buf * 16 * LB;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            if (s == SSMQ_GEMM_PARK_AT && kb + 1 < NT) park_b(buf ^ 1);
 #pragma unroll
             for (int ct = 0; ct < NTX; ++ct) {
                 const double w = sb[(4 * lg + s) * LB + ct * 16 + lip];    // X[16 kb + 4 lg + s][16 ct + pi(li)]
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(kGemmBlock, 2) void k_fxwc_cov_mfma(const double *_
             }
         }
         if (kb + 1 < NT) {
-            park_b(buf ^ 1);
+            if (SSMQ_GEMM_PARK_AT >= 4) park_b(buf ^ 1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = an[q];
         }
