@@ -225,6 +225,44 @@ def test_reference_property_tests(amd):
     assert abs(mean_out[0]) < 1e-12 and 0.9 < mean_out[1] < 1.0      # E[r sin(th)] a little below 1
 
 
+def test_integration_md_binding_runs(amd):
+    """The reference-side binding printed in INTEGRATION.md (sections 1-2) is executed as written - only the import of
+    the reference's ABC and the library path are redirected, since the reference does not travel to the GPU box - and its
+    apply() is compared with the package's own transform on UNGM."""
+    import re
+    from ssmtoybox_amd import ssmod as sm, _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    stub = blocks[0]
+    assert 'class HipGaussianProcessTransform' in stub and "ctypes.CDLL('libssmq.so')" in stub
+    stub = stub.replace('from ssmtoybox.mtran import MomentTransform', 'from ssmtoybox_amd.mtran import MomentTransform')
+    stub = stub.replace("ctypes.CDLL('libssmq.so')", 'ctypes.CDLL({!r})'.format(_lib.library_path()))
+    ns = {}
+    exec(compile(stub, 'INTEGRATION.md#1', 'exec'), ns)
+    helper = re.search(r'def _integrand\(fid, par=\(\), idx=\(\)\):.*?return s\n', blocks[1], flags=re.S).group(0)
+    exec(compile(helper, 'INTEGRATION.md#2', 'exec'), ns)
+
+    class Model:                                   # what section 2 attaches to the reference's model classes
+        ssmq_integrand = ns['_integrand'](1)       # SSMQ_F_UNGM_DYN
+
+        def dyn_eval(self, x, t, dx=False):
+            raise AssertionError('the device evaluates the integrand')
+    par = np.array([[1.0, 3.0]])
+    pts = amd.UnscentedTransform.unit_sigma_points(1)
+    tf = ns['HipGaussianProcessTransform'](1, 1, par, pts)
+    ours = amd.GaussianProcessTransform(1, 1, par)
+    assert np.allclose(tf.wm, ours.wm, rtol=1e-13) and np.allclose(tf.Wc, ours.Wc, rtol=1e-12, atol=1e-15)
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    for mean, cov, t in ((0.3, 1.7, 4.0), (-2.0, 0.4, 11.0)):
+        got = tf.apply(Model().dyn_eval, np.array([mean]), np.array([[cov]]), np.atleast_1d(t))
+        ref = ours.apply(dyn.dyn_eval, np.array([mean]), np.array([[cov]]), np.atleast_1d(t))
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape and np.allclose(a, b, rtol=1e-13, atol=1e-15)
+    with pytest.raises(np.linalg.LinAlgError):
+        tf.apply(Model().dyn_eval, np.zeros(1), -np.eye(1), np.atleast_1d(0.0))
+
+
 def test_not_positive_definite(amd):
     from ssmtoybox_amd import ssmod as sm
     tf = amd.UnscentedTransform(2)
