@@ -411,6 +411,251 @@ hipError_t launch_eval_wave(const WideArgs &a, int64_t B, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- whole transform, ONE WAVE per trajectory, for point sets of up to 64 points ---------------------------------------
+// The shapes without a register-resident specialisation that are not large either: Gauss-Hermite grids, fully-symmetric
+// degree-5 sets in low dimension, BQ transforms at D = 7 ... 16 with 2 D (+ 1) points (the unisolvent Bayes-Sard case of
+// BASELINE configs[4]: D = 10, N = 21), the theta-batched step (per-trajectory weights).  Same arithmetic and summation
+// orders as k_apply_wide, but lane n owns sigma point n through Cholesky -> point -> integrand (registers), the products
+// run with lanes over output columns / entries out of a wave-private LDS slice, and nothing ever waits at a workgroup
+// barrier: four independent trajectories per block, as k_eval_wave.
+constexpr int kWaveWaves = 4;
+__host__ __device__ inline int wave_lds_doubles(int D, int E, int N) {
+    const int m = E > D ? E : D;
+    return SSMQ_MAX_DIM * SSMQ_MAX_DIM + 2 * SSMQ_MAX_DIM + 2 * SSMQ_MAX_DIM * SSMQ_MAX_DIM + (E + m) * N;
+}
+
+template <int DM, int FC = -1>
+__global__ __launch_bounds__(64 * kWaveWaves) void k_apply_wave(const WideArgs a, int64_t B) {
+    extern __shared__ __align__(16) double lds[];
+    const int D = a.D, E = a.E, N = a.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * kWaveWaves + wave;
+    if (b >= B) return;                         // whole waves leave; no workgroup barrier below
+    double *sL = lds + (size_t)wave * wave_lds_doubles(D, E, N);   // D*D factor (pitch D)
+    double *sm = sL + SSMQ_MAX_DIM * SSMQ_MAX_DIM;                 // D input mean
+    double *smf = sm + SSMQ_MAX_DIM;                               // E transformed mean
+    double *sg = smf + SSMQ_MAX_DIM;                               // E*D  fx Wcc'
+    double *sS = sg + SSMQ_MAX_DIM * SSMQ_MAX_DIM;                 // E*E  t-process quadratic form
+    double *sfx = sS + SSMQ_MAX_DIM * SSMQ_MAX_DIM;                // E*N  integrand values (centred in place: SIGMA)
+    double *sA = sfx + E * N;                                      // BQ: E*N fx Wc;  SIGMA: D*N points minus mean
+    const double *c = a.consts + b * a.consts_stride;
+    const WideLayout cl = wide_layout(D, E, N, a.form);
+    const double nan = __builtin_nan("");
+#define SSMQ_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define OUT_ADDR(ptr, e, bs) ptr[(int64_t)(e) * a.es_out + b * (bs)]
+    // ---- 1. inputs, Cholesky (as k_eval_wave) ----------------------------------------------------------------------------
+    for (int d = lane; d < D; d += 64) sm[d] = a.mean[d * a.es_in + b * a.bs_mean];
+    for (int i = lane; i < D * D; i += 64) {
+        const int r = i / D, cc = i % D;
+        sL[i] = (cc <= r) ? a.cov[(int64_t)i * a.es_in + b * a.bs_cov] : 0.0;
+    }
+    SSMQ_WAVE_SYNC();
+    bool ok = true;
+    for (int j = 0; j < D; ++j) {
+        const double ajj = sL[j * D + j];
+        ok = ok && (ajj > 0.0);
+        const double ljj = sqrt(ajj), r = 1.0 / ljj;
+        SSMQ_WAVE_SYNC();
+        if (lane == 0) sL[j * D + j] = ljj;
+        for (int i = j + 1 + lane; i < D; i += 64) sL[i * D + j] *= r;
+        SSMQ_WAVE_SYNC();
+        const int m = D - j - 1;
+        for (int idx = lane; idx < m * m; idx += 64) {
+            const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+            if (k <= i) sL[i * D + k] -= sL[i * D + j] * sL[k * D + j];
+        }
+        SSMQ_WAVE_SYNC();
+    }
+    if (lane == 0 && a.status) a.status[b] = ok ? 0 : 1;
+    // ---- 2. lane n: sigma point and integrand ----------------------------------------------------------------------------
+    const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
+    if (lane < N) {
+        const int n = lane;
+        double xin[DM], x[DM], o[DM];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) xin[k] = k < D ? c[cl.xiT + n * D + k] : 0.0;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            double sacc = 0.0;
+            if (d < D) {
+                sacc = sm[d];
+#pragma unroll
+                for (int k = 0; k < DM; ++k)
+                    if (k <= d) sacc += sL[d * D + k] * xin[k];
+            }
+            x[d] = sacc;
+            o[d] = 0.0;
+        }
+        double xs[kMaxIntegrandIn];
+#pragma unroll
+        for (int k = 0; k < kMaxIntegrandIn; ++k) {
+            double v = k < DM ? x[k < DM ? k : 0] : 0.0;
+            if (FC < 0 && a.fp.n_idx > 0) {        // state-index selection (MeasurementModel.state_index)
+                const int src = k < a.fp.n_idx ? a.fp.idx[k] : 0;
+                v = x[0];
+#pragma unroll
+                for (int q = 1; q < DM; ++q) v = (src == q) ? x[q] : v;
+            }
+            xs[k] = v;
+        }
+        if constexpr (FC >= 0) {
+            Fn<FC> fn;
+            fn.init(t, a.fp);
+            fn.template eval<SSMQ_MAX_FIDX>(xs, o);
+        } else {
+            eval_integrand(a.fid, xs, t, a.fp, o);
+        }
+#pragma unroll
+        for (int e = 0; e < DM; ++e)
+            if (e < E) sfx[e * N + n] = o[e];
+        if (a.form == SSMQ_FORM_SIGMA) {
+#pragma unroll
+            for (int d = 0; d < DM; ++d)
+                if (d < D) sA[d * N + n] = x[d] - sm[d];
+        }
+    }
+    SSMQ_WAVE_SYNC();
+    // ---- 3. mean: lane e ---------------------------------------------------------------------------------------------------
+    if (lane < E) {
+        double sacc = 0.0;
+        for (int n = 0; n < N; ++n) sacc += sfx[lane * N + n] * c[cl.wm + n];
+        smf[lane] = sacc;
+        OUT_ADDR(a.mean_f, lane, a.bs_mf) = ok ? sacc : nan;
+    }
+    SSMQ_WAVE_SYNC();
+    if (a.form == SSMQ_FORM_BQ) {
+        // ---- 4. T = fx Wc: lane j owns column j (rows of Wc read coalesced), then (fx Wc) fx' over the lower triangle ---------
+        auto times_matrix = [&](int off) {
+            double acc[DM];
+#pragma unroll
+            for (int e = 0; e < DM; ++e) acc[e] = 0.0;
+            if (lane < N) {
+                for (int i = 0; i < N; ++i) {
+                    const double w = c[off + (int64_t)i * N + lane];
+#pragma unroll
+                    for (int e = 0; e < DM; ++e)
+                        if (e < E) acc[e] += sfx[e * N + i] * w;
+                }
+#pragma unroll
+                for (int e = 0; e < DM; ++e)
+                    if (e < E) sA[e * N + lane] = acc[e];
+            }
+        };
+        times_matrix(cl.Wc);
+        SSMQ_WAVE_SYNC();
+        double cv[(DM * (DM + 1) / 2 + 63) / 64];      // this lane's lower-triangle entries of fx Wc fx'
+#pragma unroll
+        for (int q = 0; q < (DM * (DM + 1) / 2 + 63) / 64; ++q) {
+            const int idx = q * 64 + lane;
+            double sacc = 0.0;
+            if (idx < E * (E + 1) / 2) {
+                int e = 0;
+                while ((e + 1) * (e + 2) / 2 <= idx) ++e;
+                const int e2 = idx - e * (e + 1) / 2;
+                for (int j = 0; j < N; ++j) sacc += sA[e * N + j] * sfx[e2 * N + j];
+            }
+            cv[q] = sacc;
+        }
+        if (a.tp_nu > 0.0) {
+            SSMQ_WAVE_SYNC();
+            times_matrix(cl.iK);
+            SSMQ_WAVE_SYNC();
+            for (int idx = lane; idx < E * E; idx += 64) {
+                const int e = idx / E, e2 = idx % E;
+                double sacc = 0.0;
+                for (int j = 0; j < N; ++j) sacc += sA[e * N + j] * sfx[e2 * N + j];
+                sS[idx] = sacc;
+            }
+            SSMQ_WAVE_SYNC();
+        }
+#pragma unroll
+        for (int q = 0; q < (DM * (DM + 1) / 2 + 63) / 64; ++q) {
+            const int idx = q * 64 + lane;
+            if (idx < E * (E + 1) / 2) {
+                int e = 0;
+                while ((e + 1) * (e + 2) / 2 <= idx) ++e;
+                const int e2 = idx - e * (e + 1) / 2;
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int r = side ? e2 : e, cidx = side ? e : e2;      // (e, e2) and its mirror
+                    if (side && e == e2) continue;
+                    const int o2 = r * E + cidx;
+                    const bool use = (r == cidx) || (a.emv_mode == SSMQ_EMV_BROADCAST);
+                    double em = use ? c[cl.emv + o2] : 0.0;
+                    if (a.tp_nu > 0.0) em = (a.tp_nu - 2.0 + sS[o2]) * (1.0 / (a.tp_nu - 2.0 + (double)N)) * em;
+                    double v = (cv[q] - smf[r] * smf[cidx] + em) * a.cov_scale;
+                    if (a.cov_add) v += a.cov_add[o2];
+                    OUT_ADDR(a.cov_f, o2, a.bs_cf) = ok ? v : nan;
+                }
+            }
+        }
+        // ---- 5. cross-covariance (fx Wcc') L' ------------------------------------------------------------------------------
+        for (int idx = lane; idx < E * D; idx += 64) {
+            const int e = idx / D, d = idx % D;
+            double sacc = 0.0;
+            for (int n = 0; n < N; ++n) sacc += sfx[e * N + n] * c[cl.Wcc + d * N + n];
+            sg[idx] = sacc;
+        }
+        SSMQ_WAVE_SYNC();
+        for (int idx = lane; idx < E * D; idx += 64) {
+            const int e = idx / D, j = idx % D;
+            double sacc = 0.0;
+            for (int d = 0; d <= j; ++d) sacc += sg[e * D + d] * sL[j * D + d];
+            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? sacc * a.ccov_scale : nan;
+        }
+    } else {
+        // ---- classical centred form (mtran.py:141-149), Wc = diag(wc) ----------------------------------------------------------
+        for (int idx = lane; idx < E * N; idx += 64) sfx[idx] -= smf[idx / N];
+        SSMQ_WAVE_SYNC();
+        for (int idx = lane; idx < E * E; idx += 64) {
+            const int e = idx / E, e2 = idx % E;
+            double sacc = 0.0;
+            for (int n = 0; n < N; ++n) sacc += (sfx[e * N + n] * c[cl.Wc + n]) * sfx[e2 * N + n];
+            sacc *= a.cov_scale;
+            if (a.cov_add) sacc += a.cov_add[idx];
+            OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? sacc : nan;
+        }
+        for (int idx = lane; idx < E * D; idx += 64) {
+            const int e = idx / D, d = idx % D;
+            double sacc = 0.0;
+            for (int n = 0; n < N; ++n) sacc += (sfx[e * N + n] * c[cl.Wc + n]) * sA[d * N + n];
+            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? sacc * a.ccov_scale : nan;
+        }
+    }
+#undef OUT_ADDR
+#undef SSMQ_WAVE_SYNC
+}
+
+template <int DM, int FC>
+static hipError_t launch_wave_one(const WideArgs &a, int64_t B, hipStream_t s) {
+    const size_t lds = sizeof(double) * kWaveWaves * (size_t)wave_lds_doubles(a.D, a.E, a.N);
+    if (lds > 48 * 1024) {     // beyond the default limit: raise it (per device and instantiation; a cheap call, rare shapes)
+        hipError_t e = hipFuncSetAttribute((const void *)k_apply_wave<DM, FC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_apply_wave<DM, FC>), dim3((unsigned)((B + kWaveWaves - 1) / kWaveWaves)), dim3(64 * kWaveWaves), lds,
+                       s, a, B);
+    return hipGetLastError();
+}
+// whole transforms (built-in integrand) of this shape run one wave per trajectory (k_apply_wave) rather than one workgroup
+bool wide_full_uses_wave(int D, int E, int N) {
+    return N <= 64 && !getenv("SSMQ_NO_WAVE") &&
+           sizeof(double) * kWaveWaves * (size_t)wave_lds_doubles(D, E, N) <= 160 * 1024 - 64;
+}
+static bool wave_route(const WideArgs &a) { return a.mode == SSMQ_WIDE_FULL && wide_full_uses_wave(a.D, a.E, a.N); }
+static hipError_t launch_apply_wave(const WideArgs &a, int64_t B, hipStream_t s) {
+    const int dm = a.D > a.E ? a.D : a.E;
+    hipError_t e;
+    if (a.fid == SSMQ_F_SMOOTH10D_DYN && a.fp.n_idx == 0 && dm <= 10) e = launch_wave_one<10, SSMQ_F_SMOOTH10D_DYN>(a, B, s);
+    else if (dm <= 4) e = launch_wave_one<4, -1>(a, B, s);
+    else if (dm <= 8) e = launch_wave_one<8, -1>(a, B, s);
+    else if (dm <= 12) e = launch_wave_one<12, -1>(a, B, s);
+    else e = launch_wave_one<SSMQ_MAX_DIM, -1>(a, B, s);
+    return e;
+}
+
 size_t wide_lds_bytes(int D, int E, int N) {
     return sizeof(double) * (size_t)(D * D + D + D * N + 2 * E * N + E + 2 * E * E + E * D);
 }
@@ -430,6 +675,7 @@ static bool attr_set = false;
 void reset_wide_attributes() { attr_set = false; }
 
 hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s) {
+    if (wave_route(a)) return launch_apply_wave(a, B, s);
     const size_t lds = wide_lds_bytes_for(a);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_apply_wide<64>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -500,7 +500,7 @@ class MarginalInference(GaussianInference):
         raise NotImplementedError('no smoother for the marginalised filter on the device path')
 
     def kernel_name(self):
-        return 'per theta batch: k_weights x2 | k_pack_wide_consts x2 | k_apply_wide x2 | k_kalman_update | k_gauss_logpdf'
+        return 'per theta batch: k_weights x2 | k_pack_wide_consts x2 | k_apply_wave x2 | k_kalman_update | k_gauss_logpdf'
 
 
 class MarginalizedGaussianProcessKalman(MarginalInference):

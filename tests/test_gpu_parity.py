@@ -141,6 +141,42 @@ def test_apply_generic_kernel_matches(amd, golden, name):
         assert_moments_close([a[i] for a in got], ref, covs[i], what=(name, i, tf.kernel_name(f)))
 
 
+def test_wave_kernel_matches_workgroup_kernel(amd, golden, monkeypatch):
+    """Point sets of up to 64 points without a register-resident specialisation run on k_apply_wave (one wave per
+    trajectory); SSMQ_NO_WAVE=1 sends them to k_apply_wide (one workgroup per trajectory).  Same arithmetic: BQ, t-process
+    and centred forms, sub-state measurement models, not-positive-definite inputs."""
+    g = golden('g3_apply')
+    cases = [('reentry_dyn', lambda d, e: amd.GaussianProcessTransform(d, e, np.array([[1.0] + [3.0] * d]), 'rbf', 'gh',
+                                                                      {'degree': 2})),                     # N = 32
+             ('reentry_dyn', lambda d, e: amd.StudentTProcessTransform(d, e, np.array([[1.0] + [3.0] * d]), 'rbf', 'fs',
+                                                                       {'degree': 5})),                    # N = 51
+             ('radar_meas', lambda d, e: amd.GaussHermiteTransform(d, 2)),                                  # N = 32, sub-state
+             ('bearing_meas', lambda d, e: amd.BayesSardTransform(d, e, np.array([[1.0] + [3.0] * d]), 2, 'fs',
+                                                                  {'degree': 5})),                          # N = 51, E = 4
+             ('ct_dyn', lambda d, e: amd.FullySymmetricStudentTransform(d, 5)),                             # N = 51
+             ('pend_dyn', lambda d, e: amd.GaussHermiteTransform(d, 7))]                                # N = 49
+    for name, make in cases:
+        fid, p, sidx, din, dout = MODELS[name]
+        mod, f = make_model(name)
+        means, covs, times = g[name + '_mean'].copy(), g[name + '_cov'].copy(), g[name + '_time']
+        covs[3] = -covs[3]                                  # one input that is not positive definite
+        tf = make(din, dout)
+        monkeypatch.delenv('SSMQ_NO_WAVE', raising=False)
+        assert tf.kernel_name(f) == 'k_apply_wave', tf.kernel_name(f)
+        got = tf.apply_batch(f, means, covs, times.astype(float), return_status=True)
+        monkeypatch.setenv('SSMQ_NO_WAVE', '1')
+        assert tf.kernel_name(f) == 'k_apply_wide'
+        ref = tf.apply_batch(f, means, covs, times.astype(float), return_status=True)
+        monkeypatch.delenv('SSMQ_NO_WAVE')
+        assert np.array_equal(got[3], ref[3]) and got[3][3] != 0 and not got[3][:3].any()
+        ok = ref[3] == 0
+        assert np.isnan(got[0][3]).all() and np.isnan(got[1][3]).all()
+        for a_, b_, what in zip(got[:3], ref[:3], ('mean', 'cov', 'ccov')):
+            sc = np.abs(b_[ok]).max()
+            assert within(np.abs(a_[ok] - b_[ok]).max() / sc, 1e-13, '{} {} wave vs workgroup {}'.format(
+                name, type(tf).__name__, what))
+
+
 def test_apply_python_callable(amd, golden):
     """Arbitrary Python integrand: device sigma points, host f, device reductions (bq/bqmtran.py:97-107 split)."""
     g = golden('g3_apply')
@@ -1566,7 +1602,7 @@ def test_bsq_d10_device_integrand(amd, golden):
         tf = amd.BayesSardTransform(10, 10, gp_par(10, 3.0), g[t + '_mi'], pstr, ppar)
         w = dict(wm=g[t + '_wm'], Wc=g[t + '_Wc'], Wcc=g[t + '_Wcc'], model_var=float(g[t + '_mv']))
         tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
-        assert tf.kernel_name(model.dyn_eval) == 'k_apply_wide'
+        assert tf.kernel_name(model.dyn_eval) == ('k_apply_wave' if pstr == 'ut' else 'k_apply_wide')
         mf, cf, cfx = tf.apply_batch(model.dyn_eval, means, covs, 0.0)
         for i in range(0, B, 9):
             ref = orc.apply_bq(orc.F_SMOOTH10D_DYN, means[i], covs[i], 0.0, g[t + '_pts'], w)
