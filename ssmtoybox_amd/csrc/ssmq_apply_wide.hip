@@ -419,9 +419,12 @@ hipError_t launch_eval_wave(const WideArgs &a, int64_t B, hipStream_t s) {
 // run with lanes over output columns / entries out of a wave-private LDS slice, and nothing ever waits at a workgroup
 // barrier: four independent trajectories per block, as k_eval_wave.
 constexpr int kWaveWaves = 4;
-__host__ __device__ inline int wave_lds_doubles(int D, int E, int N) {
+// A point set of N <= 32 points leaves half of the wave idle, so a wave carries K <= 64 / N trajectories side by side:
+// "group" g = lane / G, G = 64 / K lanes, works on trajectory K (4 block + wave) + g with its own LDS slice; the group's
+// first N lanes own its sigma points / columns, all G lanes share its entry loops.
+__host__ __device__ inline int wave_lds_doubles(int D, int E, int N, bool tp) {      // per group
     const int m = E > D ? E : D;
-    return SSMQ_MAX_DIM * SSMQ_MAX_DIM + 2 * SSMQ_MAX_DIM + 2 * SSMQ_MAX_DIM * SSMQ_MAX_DIM + (E + m) * N;
+    return D * D + D + E + E * m + (tp ? E * E : 0) + (E + m) * N + 2;
 }
 
 template <int DM, int FC = -1>
@@ -429,49 +432,60 @@ __global__ __launch_bounds__(64 * kWaveWaves) void k_apply_wave(const WideArgs a
     extern __shared__ __align__(16) double lds[];
     const int D = a.D, E = a.E, N = a.N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t b = (int64_t)blockIdx.x * kWaveWaves + wave;
-    if (b >= B) return;                         // whole waves leave; no workgroup barrier below
-    double *sL = lds + (size_t)wave * wave_lds_doubles(D, E, N);   // D*D factor (pitch D)
-    double *sm = sL + SSMQ_MAX_DIM * SSMQ_MAX_DIM;                 // D input mean
-    double *smf = sm + SSMQ_MAX_DIM;                               // E transformed mean
-    double *sg = smf + SSMQ_MAX_DIM;                               // E*D  fx Wcc'
-    double *sS = sg + SSMQ_MAX_DIM * SSMQ_MAX_DIM;                 // E*E  t-process quadratic form
-    double *sfx = sS + SSMQ_MAX_DIM * SSMQ_MAX_DIM;                // E*N  integrand values (centred in place: SIGMA)
-    double *sA = sfx + E * N;                                      // BQ: E*N fx Wc;  SIGMA: D*N points minus mean
-    const double *c = a.consts + b * a.consts_stride;
+    const int K = a.wave_k, G = 64 / K, gi = lane / G, gl = lane - gi * G;   // G >= N lanes per trajectory
+    const int64_t b0 = ((int64_t)blockIdx.x * kWaveWaves + wave) * K;
+    if (b0 >= B) return;                        // whole waves leave; no workgroup barrier below
+    const int64_t b = b0 + gi;
+    const bool active = gi < K && b < B;        // idle lanes still take part in the wave-scope synchronisation
+    const int stride = (wave_lds_doubles(D, E, N, a.tp_nu > 0.0) + 1) & ~1;
+    double *sL = lds + ((size_t)wave * K + (gi < K ? gi : 0)) * stride;   // D*D factor (pitch D)
+    double *sm = sL + D * D;                    // D    input mean
+    double *smf = sm + D;                       // E    transformed mean
+    double *sC = smf + E;                       // E*E  fx Wc fx', then (same place) sg: E*D fx Wcc'
+    double *sg = sC;
+    double *sS = sC + E * (E > D ? E : D);      // E*E  t-process quadratic form (only then)
+    double *sfx = sS + (a.tp_nu > 0.0 ? E * E : 0);   // E*N  integrand values (centred in place: SIGMA)
+    double *sA = sfx + E * N;                   // BQ: E*N fx Wc;  SIGMA: D*N points minus mean
+    const double *c = a.consts + (active ? b : b0) * a.consts_stride;
     const WideLayout cl = wide_layout(D, E, N, a.form);
     const double nan = __builtin_nan("");
 #define SSMQ_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define OUT_ADDR(ptr, e, bs) ptr[(int64_t)(e) * a.es_out + b * (bs)]
-    // ---- 1. inputs, Cholesky (as k_eval_wave) ----------------------------------------------------------------------------
-    for (int d = lane; d < D; d += 64) sm[d] = a.mean[d * a.es_in + b * a.bs_mean];
-    for (int i = lane; i < D * D; i += 64) {
-        const int r = i / D, cc = i % D;
-        sL[i] = (cc <= r) ? a.cov[(int64_t)i * a.es_in + b * a.bs_cov] : 0.0;
+    // ---- 1. inputs, Cholesky (as k_eval_wave), the group's lanes over the entries ---------------------------------------------
+    if (active) {
+        for (int d = gl; d < D; d += G) sm[d] = a.mean[d * a.es_in + b * a.bs_mean];
+        for (int i = gl; i < D * D; i += G) {
+            const int r = i / D, cc = i % D;
+            sL[i] = (cc <= r) ? a.cov[(int64_t)i * a.es_in + b * a.bs_cov] : 0.0;
+        }
     }
     SSMQ_WAVE_SYNC();
     bool ok = true;
     for (int j = 0; j < D; ++j) {
-        const double ajj = sL[j * D + j];
+        const double ajj = active ? sL[j * D + j] : 1.0;
         ok = ok && (ajj > 0.0);
         const double ljj = sqrt(ajj), r = 1.0 / ljj;
         SSMQ_WAVE_SYNC();
-        if (lane == 0) sL[j * D + j] = ljj;
-        for (int i = j + 1 + lane; i < D; i += 64) sL[i * D + j] *= r;
+        if (active) {
+            if (gl == 0) sL[j * D + j] = ljj;
+            for (int i = j + 1 + gl; i < D; i += G) sL[i * D + j] *= r;
+        }
         SSMQ_WAVE_SYNC();
-        const int m = D - j - 1;
-        for (int idx = lane; idx < m * m; idx += 64) {
-            const int i = j + 1 + idx / m, k = j + 1 + idx % m;
-            if (k <= i) sL[i * D + k] -= sL[i * D + j] * sL[k * D + j];
+        if (active) {
+            const int m = D - j - 1;
+            for (int idx = gl; idx < m * m; idx += G) {
+                const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+                if (k <= i) sL[i * D + k] -= sL[i * D + j] * sL[k * D + j];
+            }
         }
         SSMQ_WAVE_SYNC();
     }
-    if (lane == 0 && a.status) a.status[b] = ok ? 0 : 1;
-    // ---- 2. lane n: sigma point and integrand ----------------------------------------------------------------------------
-    const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
-    if (lane < N) {
-        const int n = lane;
+    if (active && gl == 0 && a.status) a.status[b] = ok ? 0 : 1;
+    // ---- 2. lane n of the group: sigma point and integrand -----------------------------------------------------------------
+    if (active && gl < N) {
+        const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
+        const int n = gl;
         double xin[DM], x[DM], o[DM];
 #pragma unroll
         for (int k = 0; k < DM; ++k) xin[k] = k < D ? c[cl.xiT + n * D + k] : 0.0;
@@ -516,133 +530,147 @@ __global__ __launch_bounds__(64 * kWaveWaves) void k_apply_wave(const WideArgs a
         }
     }
     SSMQ_WAVE_SYNC();
-    // ---- 3. mean: lane e ---------------------------------------------------------------------------------------------------
-    if (lane < E) {
-        double sacc = 0.0;
-        for (int n = 0; n < N; ++n) sacc += sfx[lane * N + n] * c[cl.wm + n];
-        smf[lane] = sacc;
-        OUT_ADDR(a.mean_f, lane, a.bs_mf) = ok ? sacc : nan;
+    // ---- 3. mean: the group's lanes over the output rows -------------------------------------------------------------------
+    if (active) {
+        for (int e = gl; e < E; e += G) {
+            double sacc = 0.0;
+            for (int n = 0; n < N; ++n) sacc += sfx[e * N + n] * c[cl.wm + n];
+            smf[e] = sacc;
+            OUT_ADDR(a.mean_f, e, a.bs_mf) = ok ? sacc : nan;
+        }
     }
     SSMQ_WAVE_SYNC();
     if (a.form == SSMQ_FORM_BQ) {
         // ---- 4. T = fx Wc: lane j owns column j (rows of Wc read coalesced), then (fx Wc) fx' over the lower triangle ---------
         auto times_matrix = [&](int off) {
+            if (!active || gl >= N) return;
             double acc[DM];
 #pragma unroll
             for (int e = 0; e < DM; ++e) acc[e] = 0.0;
-            if (lane < N) {
-                for (int i = 0; i < N; ++i) {
-                    const double w = c[off + (int64_t)i * N + lane];
-#pragma unroll
-                    for (int e = 0; e < DM; ++e)
-                        if (e < E) acc[e] += sfx[e * N + i] * w;
-                }
+            for (int i = 0; i < N; ++i) {
+                const double w = c[off + (int64_t)i * N + gl];
 #pragma unroll
                 for (int e = 0; e < DM; ++e)
-                    if (e < E) sA[e * N + lane] = acc[e];
+                    if (e < E) acc[e] += sfx[e * N + i] * w;
+            }
+#pragma unroll
+            for (int e = 0; e < DM; ++e)
+                if (e < E) sA[e * N + gl] = acc[e];
+        };
+        auto lower_products = [&](double *dst) {       // dst[e][e2] = sum_j sA[e][j] sfx[e2][j], e2 <= e, mirrored
+            if (!active) return;
+            for (int idx = gl; idx < E * (E + 1) / 2; idx += G) {
+                int e = 0;
+                while ((e + 1) * (e + 2) / 2 <= idx) ++e;
+                const int e2 = idx - e * (e + 1) / 2;
+                double sacc = 0.0;
+                for (int j = 0; j < N; ++j) sacc += sA[e * N + j] * sfx[e2 * N + j];
+                dst[e * E + e2] = sacc;
+                dst[e2 * E + e] = sacc;
             }
         };
         times_matrix(cl.Wc);
         SSMQ_WAVE_SYNC();
-        double cv[(DM * (DM + 1) / 2 + 63) / 64];      // this lane's lower-triangle entries of fx Wc fx'
-#pragma unroll
-        for (int q = 0; q < (DM * (DM + 1) / 2 + 63) / 64; ++q) {
-            const int idx = q * 64 + lane;
-            double sacc = 0.0;
-            if (idx < E * (E + 1) / 2) {
-                int e = 0;
-                while ((e + 1) * (e + 2) / 2 <= idx) ++e;
-                const int e2 = idx - e * (e + 1) / 2;
-                for (int j = 0; j < N; ++j) sacc += sA[e * N + j] * sfx[e2 * N + j];
-            }
-            cv[q] = sacc;
-        }
+        lower_products(sC);
         if (a.tp_nu > 0.0) {
             SSMQ_WAVE_SYNC();
             times_matrix(cl.iK);
             SSMQ_WAVE_SYNC();
-            for (int idx = lane; idx < E * E; idx += 64) {
-                const int e = idx / E, e2 = idx % E;
-                double sacc = 0.0;
-                for (int j = 0; j < N; ++j) sacc += sA[e * N + j] * sfx[e2 * N + j];
-                sS[idx] = sacc;
-            }
-            SSMQ_WAVE_SYNC();
-        }
-#pragma unroll
-        for (int q = 0; q < (DM * (DM + 1) / 2 + 63) / 64; ++q) {
-            const int idx = q * 64 + lane;
-            if (idx < E * (E + 1) / 2) {
-                int e = 0;
-                while ((e + 1) * (e + 2) / 2 <= idx) ++e;
-                const int e2 = idx - e * (e + 1) / 2;
-#pragma unroll
-                for (int side = 0; side < 2; ++side) {
-                    const int r = side ? e2 : e, cidx = side ? e : e2;      // (e, e2) and its mirror
-                    if (side && e == e2) continue;
-                    const int o2 = r * E + cidx;
-                    const bool use = (r == cidx) || (a.emv_mode == SSMQ_EMV_BROADCAST);
-                    double em = use ? c[cl.emv + o2] : 0.0;
-                    if (a.tp_nu > 0.0) em = (a.tp_nu - 2.0 + sS[o2]) * (1.0 / (a.tp_nu - 2.0 + (double)N)) * em;
-                    double v = (cv[q] - smf[r] * smf[cidx] + em) * a.cov_scale;
-                    if (a.cov_add) v += a.cov_add[o2];
-                    OUT_ADDR(a.cov_f, o2, a.bs_cf) = ok ? v : nan;
+            if (active) {
+                for (int idx = gl; idx < E * E; idx += G) {
+                    const int e = idx / E, e2 = idx % E;
+                    double sacc = 0.0;
+                    for (int j = 0; j < N; ++j) sacc += sA[e * N + j] * sfx[e2 * N + j];
+                    sS[idx] = sacc;
                 }
             }
         }
-        // ---- 5. cross-covariance (fx Wcc') L' ------------------------------------------------------------------------------
-        for (int idx = lane; idx < E * D; idx += 64) {
-            const int e = idx / D, d = idx % D;
-            double sacc = 0.0;
-            for (int n = 0; n < N; ++n) sacc += sfx[e * N + n] * c[cl.Wcc + d * N + n];
-            sg[idx] = sacc;
+        SSMQ_WAVE_SYNC();
+        if (active) {
+            for (int idx = gl; idx < E * E; idx += G) {
+                const int e = idx / E, e2 = idx % E;
+                const bool use = (e == e2) || (a.emv_mode == SSMQ_EMV_BROADCAST);
+                double em = use ? c[cl.emv + idx] : 0.0;
+                if (a.tp_nu > 0.0) em = (a.tp_nu - 2.0 + sS[idx]) * (1.0 / (a.tp_nu - 2.0 + (double)N)) * em;
+                double v = (sC[idx] - smf[e] * smf[e2] + em) * a.cov_scale;
+                if (a.cov_add) v += a.cov_add[idx];
+                OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? v : nan;
+            }
+        }
+        SSMQ_WAVE_SYNC();                               // sg takes the place of sC
+        if (active) {
+            // ---- 5. cross-covariance (fx Wcc') L' --------------------------------------------------------------------------
+            for (int idx = gl; idx < E * D; idx += G) {
+                const int e = idx / D, d = idx % D;
+                double sacc = 0.0;
+                for (int n = 0; n < N; ++n) sacc += sfx[e * N + n] * c[cl.Wcc + d * N + n];
+                sg[idx] = sacc;
+            }
         }
         SSMQ_WAVE_SYNC();
-        for (int idx = lane; idx < E * D; idx += 64) {
-            const int e = idx / D, j = idx % D;
-            double sacc = 0.0;
-            for (int d = 0; d <= j; ++d) sacc += sg[e * D + d] * sL[j * D + d];
-            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? sacc * a.ccov_scale : nan;
+        if (active) {
+            for (int idx = gl; idx < E * D; idx += G) {
+                const int e = idx / D, j = idx % D;
+                double sacc = 0.0;
+                for (int d = 0; d <= j; ++d) sacc += sg[e * D + d] * sL[j * D + d];
+                OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? sacc * a.ccov_scale : nan;
+            }
         }
     } else {
         // ---- classical centred form (mtran.py:141-149), Wc = diag(wc) ----------------------------------------------------------
-        for (int idx = lane; idx < E * N; idx += 64) sfx[idx] -= smf[idx / N];
+        if (active)
+            for (int idx = gl; idx < E * N; idx += G) sfx[idx] -= smf[idx / N];
         SSMQ_WAVE_SYNC();
-        for (int idx = lane; idx < E * E; idx += 64) {
-            const int e = idx / E, e2 = idx % E;
-            double sacc = 0.0;
-            for (int n = 0; n < N; ++n) sacc += (sfx[e * N + n] * c[cl.Wc + n]) * sfx[e2 * N + n];
-            sacc *= a.cov_scale;
-            if (a.cov_add) sacc += a.cov_add[idx];
-            OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? sacc : nan;
-        }
-        for (int idx = lane; idx < E * D; idx += 64) {
-            const int e = idx / D, d = idx % D;
-            double sacc = 0.0;
-            for (int n = 0; n < N; ++n) sacc += (sfx[e * N + n] * c[cl.Wc + n]) * sA[d * N + n];
-            OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? sacc * a.ccov_scale : nan;
+        if (active) {
+            for (int idx = gl; idx < E * E; idx += G) {
+                const int e = idx / E, e2 = idx % E;
+                double sacc = 0.0;
+                for (int n = 0; n < N; ++n) sacc += (sfx[e * N + n] * c[cl.Wc + n]) * sfx[e2 * N + n];
+                sacc *= a.cov_scale;
+                if (a.cov_add) sacc += a.cov_add[idx];
+                OUT_ADDR(a.cov_f, idx, a.bs_cf) = ok ? sacc : nan;
+            }
+            for (int idx = gl; idx < E * D; idx += G) {
+                const int e = idx / D, d = idx % D;
+                double sacc = 0.0;
+                for (int n = 0; n < N; ++n) sacc += (sfx[e * N + n] * c[cl.Wc + n]) * sA[d * N + n];
+                OUT_ADDR(a.cov_fx, idx, a.bs_cfx) = ok ? sacc * a.ccov_scale : nan;
+            }
         }
     }
 #undef OUT_ADDR
 #undef SSMQ_WAVE_SYNC
 }
 
+// trajectories per wave: as many as there are N-lane groups, but not so many that the LDS slices leave the SIMDs with
+// fewer than ~3 waves each (the kernel waits on LDS / L2 round trips; measured at D = 10, N = 21: K = 1 / 2 / 3)
+static int wave_groups(int D, int E, int N, bool tp) {
+    if (const char *k = getenv("SSMQ_WAVE_K")) return std::max(1, std::min(64 / N, atoi(k)));
+    const size_t slice = sizeof(double) * (size_t)((wave_lds_doubles(D, E, N, tp) + 1) & ~1);
+    const size_t budget = (160 * 1024) / 12;                 // 12 waves per CU
+    return (int)std::max<size_t>(1, std::min<size_t>(64 / N, budget / std::max<size_t>(slice, 1)));
+}
+static size_t wave_lds_bytes(int D, int E, int N, bool tp, int K) {
+    return sizeof(double) * kWaveWaves * (size_t)K * (size_t)((wave_lds_doubles(D, E, N, tp) + 1) & ~1);
+}
 template <int DM, int FC>
 static hipError_t launch_wave_one(const WideArgs &a, int64_t B, hipStream_t s) {
-    const size_t lds = sizeof(double) * kWaveWaves * (size_t)wave_lds_doubles(a.D, a.E, a.N);
+    WideArgs aw = a;
+    aw.wave_k = wave_groups(a.D, a.E, a.N, a.tp_nu > 0.0);
+    const size_t lds = wave_lds_bytes(a.D, a.E, a.N, a.tp_nu > 0.0, aw.wave_k);
+    const int64_t per_block = (int64_t)kWaveWaves * aw.wave_k;
     if (lds > 48 * 1024) {     // beyond the default limit: raise it (per device and instantiation; a cheap call, rare shapes)
         hipError_t e = hipFuncSetAttribute((const void *)k_apply_wave<DM, FC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 64);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_apply_wave<DM, FC>), dim3((unsigned)((B + kWaveWaves - 1) / kWaveWaves)), dim3(64 * kWaveWaves), lds,
-                       s, a, B);
+    hipLaunchKernelGGL((k_apply_wave<DM, FC>), dim3((unsigned)((B + per_block - 1) / per_block)), dim3(64 * kWaveWaves), lds,
+                       s, aw, B);
     return hipGetLastError();
 }
 // whole transforms (built-in integrand) of this shape run one wave per trajectory (k_apply_wave) rather than one workgroup
 bool wide_full_uses_wave(int D, int E, int N) {
-    return N <= 64 && !getenv("SSMQ_NO_WAVE") &&
-           sizeof(double) * kWaveWaves * (size_t)wave_lds_doubles(D, E, N) <= 160 * 1024 - 64;
+    return N >= 1 && N <= 64 && !getenv("SSMQ_NO_WAVE") && wave_lds_bytes(D, E, N, true, 1) <= 160 * 1024 - 64;
 }
 static bool wave_route(const WideArgs &a) { return a.mode == SSMQ_WIDE_FULL && wide_full_uses_wave(a.D, a.E, a.N); }
 static hipError_t launch_apply_wave(const WideArgs &a, int64_t B, hipStream_t s) {

@@ -51,6 +51,7 @@ struct WideArgs {
     double *fx_out;
     const double *t_in;
     double *mrow_out;       // k_eval_wave: transformed means as rows b E + e, for the GEMM epilogue
+    int32_t wave_k;         // k_apply_wave: trajectories side by side in one wave (set by the launcher)
     FPar fp;
 };
 
