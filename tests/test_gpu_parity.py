@@ -1602,7 +1602,7 @@ def test_bsq_d10_device_integrand(amd, golden):
         tf = amd.BayesSardTransform(10, 10, gp_par(10, 3.0), g[t + '_mi'], pstr, ppar)
         w = dict(wm=g[t + '_wm'], Wc=g[t + '_Wc'], Wcc=g[t + '_Wcc'], model_var=float(g[t + '_mv']))
         tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
-        assert tf.kernel_name(model.dyn_eval) == ('k_apply_wave' if pstr == 'ut' else 'k_apply_wide')
+        assert tf.kernel_name(model.dyn_eval) in (('k_apply_wave', 'k_apply_wide') if pstr == 'ut' else ('k_apply_wide',))
         mf, cf, cfx = tf.apply_batch(model.dyn_eval, means, covs, 0.0)
         for i in range(0, B, 9):
             ref = orc.apply_bq(orc.F_SMOOTH10D_DYN, means[i], covs[i], 0.0, g[t + '_pts'], w)
