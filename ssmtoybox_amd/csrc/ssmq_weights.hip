@@ -755,7 +755,11 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
     a.stage = 0;
     if (N <= 64) {
         a.use_lds = 1;
-        hipLaunchKernelGGL(k_weights<256>, dim3(a.P), dim3(256), sizeof(double) * 2 * nn, s, a);
+        // up to 8 points every loop of the kernel has at most 64 iterations: one wave per parameter row does the same
+        // arithmetic (each thread still owns at most one element of every N x N step) with barriers that cost nothing,
+        // and four times as many rows are resident per CU - the theta-batched callers launch 1e4 ... 1e5 rows
+        const int threads = (N <= 8 && a.NB <= 8 && !getenv("SSMQ_WEIGHTS_WIDE_BLOCK")) ? 64 : 256;
+        hipLaunchKernelGGL(k_weights<256>, dim3(a.P), dim3(threads), sizeof(double) * 2 * nn, s, a);
         return hip_fail(hipGetLastError(), "k_weights");
     }
     static bool attr_set = false;
