@@ -315,6 +315,46 @@ class C5GemmBench:
         return ms, cb
 
 
+def measure_c5_unisolvent(amd, B=100000, iters=20):
+    """The other half of BASELINE configs[4] as SURVEY 8d restates it: Bayes-Sard transform at D = E = 10 with the
+    unscented point set, N = 21 = number of basis functions (unisolvent case), device-resident moments, device integrand
+    (k_apply_wave: generic shapes of up to 64 points, several trajectories per wave)."""
+    from ssmtoybox_amd import _lib, ssmod
+    D = 10
+    mi = np.hstack((np.zeros((D, 1), dtype=int), np.eye(D, dtype=int), 2 * np.eye(D, dtype=int)))
+    tf = amd.BayesSardTransform(D, D, np.array([[1.0] + [3.0] * D]), multi_ind=mi, point_str='ut')
+    f = ssmod.Smooth10DTransition().dyn_eval
+    rng = np.random.default_rng(6)
+    means = rng.standard_normal((B, D))
+    a = rng.standard_normal((B, D, D)) / np.sqrt(D)
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(D)
+    mean, cov = _lib.SoA.from_host(means), _lib.SoA.from_host(covs)
+    mf, cf, cfx = _lib.SoA(D, B), _lib.SoA(D * D, B), _lib.SoA(D * D, B)
+    st = _lib.DeviceBuffer(4 * mean.ld)
+    tbuf = _lib.DeviceBuffer(8)
+    tbuf.upload(np.zeros(1))
+    for _ in range(3):
+        tf.apply_batch_dev(f, mean, cov, tbuf, mf, cf, cfx, st, 0)
+    _lib.sync()
+    e0, e1 = _lib.Event(), _lib.Event()
+    e0.record()
+    for _ in range(iters):
+        tf.apply_batch_dev(f, mean, cov, tbuf, mf, cf, cfx, st, 0)
+    e1.record()
+    ms = e0.elapsed_ms(e1) / iters
+    name = tf.kernel_name(f)
+    for buf in (mean, cov, mf, cf, cfx):
+        buf.buf.free()
+    st.free()
+    tbuf.free()
+    alg = 8 * (D + D * D + D + D * D + D * D) * B          # SURVEY 8d: 2480 B per transform at D = E = 10
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {'kernel': name, 'ms_per_launch': ms, 'transforms_per_s': B / (ms * 1e-3), 'bound': 'hbm', 'achieved': gbs,
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'bytes_per_launch': alg,
+            'workload': 'Bayes-Sard transform, D=E=10, unscented points N=21 = basis functions (unisolvent), B=1e5',
+            'note': 'compute-bound shape (~25k lane-operations for 2480 algorithmic bytes): see DESIGN.md 3.2'}
+
+
 class Mt6Bench:
     """Batched GPQ moment transform, D = E = 6, N = 13, B = 1e5, rotating buffer sets (> 256 MB in total so that the
     Infinity Cache cannot hold the working set between launches)."""
@@ -732,6 +772,7 @@ def main():
                                           'v_mfma_f64_16x16x4_f64'}
         if cb5:
             out['roofline_c5']['cpu_baseline'] = cb5
+        out['roofline_c5']['unisolvent_n21'] = measure_c5_unisolvent(amd)
     if rank == 0:
         print(json.dumps(out))
     wl.free()
