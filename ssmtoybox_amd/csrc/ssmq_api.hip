@@ -1531,18 +1531,10 @@ size_t gp_weights_wide_ws_bytes(int D, int N, int64_t P);
 int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double *d_par, int P, double jitter,
                            double *d_consts, int32_t *d_status, void *ws, size_t ws_bytes);
 int launch_gauss_logpdf(int Y, int64_t B, int64_t ld, const double *y, const double *y_mean, const double *P_y,
-                        double *out, hipStream_t s);
+                        double *out, hipStream_t s, const int32_t *merge = nullptr, int32_t *merge_out = nullptr);
 }
 
 
-namespace {
-__global__ void k_merge_theta_status(const int32_t *w_dyn, const int32_t *w_obs, const int32_t *t_dyn, const int32_t *t_obs,
-                                     const int32_t *upd, int32_t *out, int64_t P) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    out[i] = (w_dyn[i] ? 1 : 0) | (w_obs[i] ? 2 : 0) | (t_dyn[i] ? 4 : 0) | (t_obs[i] ? 8 : 0) | (upd[i] ? 16 : 0);
-}
-}  // namespace
 
 // One filter step per parameter item: weights(theta_dyn) -> dyn transform -> + GQG -> weights(theta_obs) -> obs transform
 // -> + R -> measurement update and log N(y | y_mean, P_y).  Everything between the host arrays stays on the device.
@@ -1660,10 +1652,8 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     fill_fpar(f_obs, &a.fp);
     if ((rc = hip_fail(launch_apply_wide(a, P, s), "k_apply_wide(theta, obs)"))) return rc;
     if ((rc = launch_kalman_update(D, Y, P, ld, m_pr, P_pr, y_mean, P_y, P_yx, ysoa, m_fi, P_fi, st_up, s))) return rc;
-    if ((rc = launch_gauss_logpdf(Y, P, ld, ysoa, y_mean, P_y, ll, s))) return rc;
-    hipLaunchKernelGGL(k_merge_theta_status, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, st_wd, st_wo, st_td, st_to,
-                       st_up, st_all, P);
-    if ((rc = hip_fail(hipGetLastError(), "k_merge_theta_status"))) return rc;
+    // log-likelihood and the merged status flags in one launch (the five partial vectors are contiguous, pitch ld)
+    if ((rc = launch_gauss_logpdf(Y, P, ld, ysoa, y_mean, P_y, ll, s, st_wd, st_all))) return rc;
     SSMQ_HIP(hipMemcpyAsync(g_stage.hout, dev + off_out, out_bytes, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipStreamSynchronize(s));
     // planes -> the caller's item-major arrays

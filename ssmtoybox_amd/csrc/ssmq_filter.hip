@@ -250,10 +250,16 @@ int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr
 
 // ---- log N(y | y_mean, P_y) per trajectory (scipy multivariate_normal.logpdf as used at ssinf.py:1198) ----------------
 // Cholesky route: -(delta' P_y^-1 delta + log det P_y + Y log 2 pi) / 2; NaN where P_y is not positive definite.
+// merge: five status vectors of the theta-batched step [w_dyn | w_obs | t_dyn | t_obs | upd], pitch ld, folded into
+// bit flags at merge_out (ssmq_gp_theta_step) in the same launch - or null
 __global__ __launch_bounds__(kUpdBlock) void k_gauss_logpdf(const double *y, const double *y_mean, const double *P_y,
-                                                            double *out, int Y, int64_t B, int64_t ld) {
+                                                            double *out, int Y, int64_t B, int64_t ld,
+                                                            const int32_t *merge, int32_t *merge_out) {
     const uint32_t b = blockIdx.x * kUpdBlock + threadIdx.x;
     if ((int64_t)b >= B) return;
+    if (merge)
+        merge_out[b] = (merge[b] ? 1 : 0) | (merge[ld + b] ? 2 : 0) | (merge[2 * ld + b] ? 4 : 0) |
+                       (merge[3 * ld + b] ? 8 : 0) | (merge[4 * ld + b] ? 16 : 0);
     double S[SSMQ_MAX_DIM * SSMQ_MAX_DIM], v[SSMQ_MAX_DIM];
     for (int i = 0; i < Y; ++i)
         for (int j = 0; j <= i; ++j) S[i * Y + j] = P_y[((int64_t)i * Y + j) * ld + b];
@@ -283,13 +289,13 @@ __global__ __launch_bounds__(kUpdBlock) void k_gauss_logpdf(const double *y, con
 }
 
 int launch_gauss_logpdf(int Y, int64_t B, int64_t ld, const double *y, const double *y_mean, const double *P_y,
-                        double *out, hipStream_t s) {
+                        double *out, hipStream_t s, const int32_t *merge, int32_t *merge_out) {
     if (Y < 1 || Y > SSMQ_MAX_DIM) {
         set_error("logpdf: Y out of range");
         return SSMQ_E_ARG;
     }
     const unsigned grid = (unsigned)((B + kUpdBlock - 1) / kUpdBlock);
-    hipLaunchKernelGGL(k_gauss_logpdf, dim3(grid), dim3(kUpdBlock), 0, s, y, y_mean, P_y, out, Y, B, ld);
+    hipLaunchKernelGGL(k_gauss_logpdf, dim3(grid), dim3(kUpdBlock), 0, s, y, y_mean, P_y, out, Y, B, ld, merge, merge_out);
     return hip_fail(hipGetLastError(), "k_gauss_logpdf");
 }
 

@@ -932,8 +932,7 @@ int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double
     double *dwork = take(p * (size_t)work_stride), *dz = take(D + 2);
     double *dlp = N > 64 ? take(p * N * (N + 1) / 2) : nullptr;   // packed Cholesky factors of the staged large-N path
     int rc;
-    SSMQ_HIP(hipMemsetAsync(dQ, 0, sizeof(double) * p * nn, s));
-    WgtArgs a;
+    WgtArgs a;          // (the GP branch of k_weights writes every element of Q, NaN on failure: nothing to clear)
     memset(&a, 0, sizeof(a));
     a.D = D; a.N = N; a.P = P; a.NB = 0; a.jitter = jitter;
     a.xi = d_xi; a.par = d_par; a.mulind = (const int32_t *)dz; a.px = dz; a.xpx = dz; a.pxpx = dz;
