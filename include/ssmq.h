@@ -332,7 +332,7 @@ int ssmq_filter_smooth_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
  * shared_state = 1, else [P][D] / [P][D*D]; y [Y] when shared_y = 1, else [P][Y].  GQG [D*D], R [Y*Y] host or NULL.
  * status[i] (may be NULL): bit 0 K_dyn not positive definite, bit 1 K_obs, bit 2 cov (Cholesky in the dyn transform),
  * bit 3 predictive cov, bit 4 P_y.  Returns 0, or 1 + index of the first item with a nonzero status.  Synchronous;
- * the weights never leave the device (k_weights writes per-item constant blocks that k_apply_wide reads in place).
+ * the weights never leave the device (k_weights writes per-item constant blocks that the generic transform kernel reads in place).
  */
 int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
                        const ssmq_integrand *f_obs, int64_t P, const double *par_dyn, const double *par_obs,
