@@ -60,6 +60,7 @@ def make_transform(form, D, E, pts, wm, Wc, Wcc=None, emv=None, emv_broadcast=0,
     t.pts, t.wm, t.Wc, t.Wcc, t.emv, t.iK = [_p(a) for a in arrs]
     if integrand is not None:
         t.f = integrand
+    t._keep = arrs          # the struct holds raw pointers into these arrays: they live as long as it does
     return t, arrs
 
 

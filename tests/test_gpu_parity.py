@@ -1076,6 +1076,13 @@ def test_simulate_statistics_match_numpy_streams(amd):
 # ---------------------------------------------------------------------------------------------------------------
 # error statistics reduced on the device (utils.py:18-148 aggregated as research/tpq/tpq_base.py:154-172)
 # ---------------------------------------------------------------------------------------------------------------
+def _lib_buffer(host):
+    from ssmtoybox_amd import _lib
+    d = _lib.DeviceBuffer(host.nbytes)
+    d.upload(host)
+    return d
+
+
 def _planes(a, ld):
     """(D, T, B) or (D, D, T, B) -> DeviceBuffer of planes [T][D..][ld]."""
     from ssmtoybox_amd import _lib
@@ -1914,6 +1921,57 @@ def test_config2_ungm_gpqkf_1e4(amd):
     cfm, cfP, cst = co.filter_forward(td, to, np.ascontiguousarray(y.T[:, :, None]), np.zeros(1), one, 10 * one, one,
                                       threads=8)
     _compare_filter(fm, fP, alg.status, cfm.transpose(2, 1, 0), cfP.transpose(2, 3, 1, 0), cst)
+
+
+def test_lengthscale_filter_sweep(amd):
+    """research/bsq/bsq_ungm.py:190-240 (`lengthscale_filter_demo`): GPQ-Kalman on UNGM re-built for every length-scale of
+    a grid and run over the same 20 measurement sequences of 500 steps, then RMSE / NLL / credibility ratio per grid
+    point.  Every filter run is compared with the C oracle on the device's own weights; the error statistics come from
+    the device reductions and are compared with the oracle's restatement of utils.py on the downloaded moments."""
+    from oracle import c_oracle as co
+    from bench import simulate_ungm
+    from ssmtoybox_amd import ssinf, ssmod as sm, mcshard
+    steps, mc = 500, 20
+    x, y = simulate_ungm(mc, steps, 23)
+    dyn = sm.UNGMTransition(sm.GaussRV(1, cov=np.array([[5.0]])), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    one = np.eye(1)
+    rmse = []
+    for el in (1e-1, 3e-1, 1.0, 3.0, 1e1, 3e1):
+        par = np.array([[1.0, el]])
+        alg = ssinf.GaussianProcessKalman(dyn, obs, par, par, kernel='rbf', points='ut')
+        fm, fP = alg.forward_pass_batch(y[None], raise_on_failure=False)
+        td, keep1 = _c_bq_transform(alg.tf_dyn, 1, co.Integrand.make(orc.F_UNGM_DYN))     # keep*: the structs point into them
+        to, keep2 = _c_bq_transform(alg.tf_obs, 1, co.Integrand.make(orc.F_UNGM_MEAS))
+        cfm, cfP, cst = co.filter_forward(td, to, np.ascontiguousarray(y.T[:, :, None]), np.zeros(1), 5.0 * one,
+                                          10 * one, one, threads=4)
+        cfm, cfP = cfm.transpose(2, 1, 0), cfP.transpose(2, 3, 1, 0)
+        st = alg.status
+        assert np.array_equal(st == 0, cst == 0), el
+        ok = st == 0
+        assert ok.sum() >= mc // 2, (el, int(ok.sum()))
+        # 500 steps of a recursion that amplifies rounding differences: tight at the start, percentiles over the run
+        rel = np.abs(fm - cfm)[0][:, ok] / np.abs(cfm[0][:, ok]).max()
+        assert within(float(rel[:10].max()), 1e-10, 'lengthscale sweep l={} first steps'.format(el))
+        assert within(float(np.median(rel)), 1e-11, 'lengthscale sweep l={} median'.format(el))
+        # error statistics of this grid point, device reductions vs the oracle on the same moments
+        ld = 64
+        d_x, d_m, d_P = _planes(x[None, :, :], ld), _planes(fm, ld), _planes(fP, ld)
+        stl = np.zeros(ld, dtype=np.int32)
+        stl[:mc] = st
+        d_st = _lib_buffer(stl)
+        s1 = mcshard.device_error_sums(1, mc, ld, steps, d_x, d_m, d_P, d_st)
+        o1 = orc.error_sums(x[None, :, :], fm, fP, ok)
+        for k in ('se', 'rmse', 'nll', 'mse', 'n_ok', 'n_pd'):
+            assert np.allclose(s1[k], o1[k], rtol=1e-10, atol=1e-12), (el, k)
+        tot = mcshard.finalize(s1)
+        s2 = mcshard.device_lcr_sums(1, mc, ld, steps, d_x, d_m, d_P, tot['mse'], d_st)
+        o2 = orc.lcr_sums(x[None, :, :], fm, fP, tot['mse'] + 1e-6 * np.eye(1), ok)
+        assert np.allclose(s2['lcr'], o2['lcr'], rtol=1e-8, atol=1e-8) and np.array_equal(s2['n'], o2['n'])
+        rmse.append(tot['rmse_total'])
+        for buf in (d_x, d_m, d_P, d_st):
+            buf.free()
+    assert np.all(np.isfinite(rmse)) and max(rmse) / min(rmse) > 1.01      # the length-scale matters
 
 
 def _compare_filter_prefix(fm, fP, st, cfm, cfP, cst, T, what, tol_m=1e-9, tol_P=1e-9):
