@@ -740,6 +740,14 @@ def main():
             out['roofline_mt6']['cpu_baseline'] = cpu_baseline_apply(
                 mt.tf, mt.model._fid, (0.1,), 6, 6, means[:50000], covs[:50000], 3.0, 'the D=E=6 GPQ transform')
         mt.free()
+        # the same kernel with ten generations of waves instead of one (B = 1e6): how close it gets to HBM when the
+        # load / compute / store phases of different waves overlap
+        mt = Mt6Bench(amd, 1000000, seed=12, nsets=2)
+        ms, b_alg, _ = mt.measure(warmup=3, iters=30)
+        out['roofline_mt6']['at_1e6_trajectories'] = {'ms_per_launch': ms, 'achieved': b_alg / (ms * 1e-3) / 1e9,
+                                                      'unit': 'GB/s', 'frac': b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                      'bytes_per_launch': b_alg}
+        mt.free()
     if rank == 0 and single and not args.no_mt6:
         # BASELINE configs[2]: the filters that are stable on the reentry model (the GPQ-Kalman recursion itself fails
         # within three steps on every trajectory, in the reference as here: tests/test_gpu_parity.py::test_config3_gpqkf_*)
