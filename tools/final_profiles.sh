@@ -11,6 +11,20 @@ bash profiles/collect_pmc.sh $out/pmc > $out/pmc.log 2>&1
 bash tools/pmc_fused.sh $out/pmc_fused > $out/pmc_fused.log 2>&1
 python profiles/pmc_summary.py $out/pmc > $out/pmc_traffic.json
 cp $(find $out/prof -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
+# the same trace split by grid size: bench.py launches some kernels at two batch sizes (the D = 6 transform at 1e5 and 1e6)
+python3 - $out <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(list)
+for path in glob.glob(out + '/prof/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(path)):
+        g = r.get('Grid_Size_X') or r.get('Grid_Size')
+        acc[(r['Kernel_Name'], int(g))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+with open(out + '/kernel_stats_by_grid.csv', 'w') as f:
+    f.write('"Name","GridSize","Calls","AverageNs","MinNs","MaxNs"\n')
+    for (name, grid), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        f.write('"%s",%d,%d,%.1f,%d,%d\n' % (name, grid, len(v), sum(v) / len(v), min(v), max(v)))
+PY
 cat $out/bench.json
 head -8 $out/kernel_stats.csv | cut -c1-160
 cat $out/pmc_traffic.json
