@@ -785,6 +785,9 @@ def main():
         print(json.dumps(out))
     wl.free()
     comm.close()
+    if getattr(comm, 'abandoned_rccl_thread', False):
+        sys.stdout.flush()
+        os._exit(0)          # a helper thread is still inside ncclCommInitRank: no atexit handler may wait for it
 
 
 if __name__ == '__main__':

@@ -101,6 +101,10 @@ int ssmq_version(void);
 const char *ssmq_last_error(void);
 int ssmq_device_count(int *n);
 int ssmq_set_device(int device);
+/* The device the library's stream and caches live on (the calling thread's current device on first use), -1 on error.
+ * The HIP current device is PER THREAD: a caller that enters the library from a second thread selects this device there
+ * first (ssmq_set_device), otherwise the library would move to that thread's default device. */
+int ssmq_current_device(void);
 int ssmq_device_name(char *buf, int len);
 
 /* ---- device memory, layout conversion, timing (plumbing) ---------------------------------------------------- */

@@ -157,6 +157,7 @@ _PROTOTYPES = {
                                          c_double_p]),
     'ssmq_bs_moments': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_int32_p, ctypes.c_int,
                                        c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    'ssmq_current_device': (ctypes.c_int, []),
     'ssmq_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'ssmq_comm_init': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     'ssmq_comm_rank': (ctypes.c_int, []),

@@ -483,6 +483,10 @@ int ssmq_set_device(int device) {
     SSMQ_HIP(hipSetDevice(device));
     return ensure_device();
 }
+int ssmq_current_device(void) {
+    if (ensure_device()) return -1;
+    return g_stream_dev;
+}
 int ssmq_device_name(char *buf, int len) {
     if (!buf || len <= 0) return SSMQ_E_ARG;
     int rc = ensure_device();

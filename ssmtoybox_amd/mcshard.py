@@ -66,7 +66,7 @@ def _id_file(rank_env=None):
 class RcclComm:
     """RCCL communicator behind the C ABI (ssmq_comm_*).  One per process; the device must be selected first."""
 
-    def __init__(self, rank, world, id_file=None, timeout_s=300.0, force=False):
+    def __init__(self, rank, world, id_file=None, timeout_s=300.0, force=False, init_timeout_s=240.0):
         """force: create an RCCL communicator even for world = 1 (rehearsal of the RCCL path on one GPU)."""
         lib = _lib.load()
         self.rank, self.world = int(rank), int(world)
@@ -99,7 +99,33 @@ class RcclComm:
                         raise _lib.SsmqError('RCCL rendezvous: no id file {} after {} s'.format(self._file, timeout_s))
                     time.sleep(0.01)
                 buf = ctypes.create_string_buffer(raw, 128)
-        _lib.check(lib.ssmq_comm_init(self.rank, self.world, buf if self._rccl else None, 128), 'ssmq_comm_init')
+        # ncclCommInitRank is collective: if a peer never arrives it blocks for good.  It runs on a helper thread (ctypes
+        # releases the GIL) so that this rank can give up after init_timeout_s and report the failure (open_comm then
+        # moves every rank to the gloo fallback); a thread left behind in RCCL is abandoned (hung_init).
+        self.hung_init = False
+        if self._rccl and (self.world > 1 or os.environ.get('SSMQ_RCCL_INIT_THREAD') == '1'):   # (env: one-rank rehearsal)
+            import threading
+            box = {}
+            dev = lib.ssmq_current_device()              # HIP's current device is per thread: select it over there too
+
+            def _init():
+                try:
+                    if dev >= 0:
+                        _lib.check(lib.ssmq_set_device(dev), 'ssmq_set_device')
+                    box['rc'] = lib.ssmq_comm_init(self.rank, self.world, buf, 128)
+                    box['err'] = _lib.last_error() if box['rc'] else ''
+                except Exception as e:                   # noqa: BLE001
+                    box['rc'], box['err'] = -1, str(e)
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(init_timeout_s)
+            if th.is_alive():
+                self.hung_init = True
+                raise _lib.SsmqError('RCCL communicator: ncclCommInitRank did not return within {} s'.format(init_timeout_s))
+            if box.get('rc'):
+                raise _lib.SsmqError('ssmq_comm_init failed (code {}): {}'.format(box['rc'], box.get('err', '')))
+        else:
+            _lib.check(lib.ssmq_comm_init(self.rank, self.world, buf if self._rccl else None, 128), 'ssmq_comm_init')
 
     def _reduce(self, fn, flat):
         flat = np.ascontiguousarray(flat, dtype=np.float64).copy()
@@ -187,6 +213,7 @@ def open_comm(rank, world, force_rccl=False, consensus_timeout_s=120.0, log=None
         comm = RcclComm(rank, world, force=force_rccl)
     except Exception as e:                                   # noqa: BLE001 - any failure means "no RCCL on this rank"
         err = '{}: {}'.format(type(e).__name__, e)
+    hung = 'did not return' in err
     if world <= 1:
         if comm is None:
             raise _lib.SsmqError('RCCL communicator: ' + err)
@@ -218,6 +245,7 @@ def open_comm(rank, world, force_rccl=False, consensus_timeout_s=120.0, log=None
         pass
     fb = TorchComm(dist)
     fb.fallback_reason = why
+    fb.abandoned_rccl_thread = hung      # the caller should leave with os._exit once its output is written
     return fb
 
 
