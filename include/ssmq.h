@@ -118,6 +118,12 @@ int ssmq_sync(void);
 /* AoS [B][n] (reference layout) <-> SoA planes [n][ld] (HBM layout), both on the device. */
 int ssmq_aos_to_soa(const double *d_aos, double *d_soa, int n, int64_t B, int64_t ld);
 int ssmq_soa_to_aos(const double *d_soa, double *d_aos, int n, int64_t B, int64_t ld);
+/* Host arrays in the reference's study layout (n_elem..., n_outer, B) - dim_y x T x B measurements, D x T x B means,
+ * D x D x T x B covariances of forward_pass / the Monte-Carlo loops (ssinf.py:66-118, research/tpq/tpq_base.py:175-192) -
+ * to / from the filters' time-major planes [n_outer][n_elem][ld] in HBM.  Transfers go through the library's pinned
+ * staging block in chunks; padding lanes (B .. ld) are zero-filled on upload.  Synchronous. */
+int ssmq_upload_planes(const double *host, int n_outer, int n_elem, int64_t B, int64_t ld, double *d_planes);
+int ssmq_download_planes(const double *d_planes, int n_outer, int n_elem, int64_t B, int64_t ld, double *host);
 /* HIP events on the library's stream (bench.py times kernels with these). */
 int ssmq_event_create(void **ev);
 int ssmq_event_destroy(void *ev);

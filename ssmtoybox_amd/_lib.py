@@ -158,6 +158,10 @@ _PROTOTYPES = {
     'ssmq_bs_moments': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_int32_p, ctypes.c_int,
                                        c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     'ssmq_current_device': (ctypes.c_int, []),
+    'ssmq_upload_planes': (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_void_p]),
+    'ssmq_download_planes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                            c_double_p]),
     'ssmq_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'ssmq_comm_init': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     'ssmq_comm_rank': (ctypes.c_int, []),
@@ -273,6 +277,23 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def upload_study(arr, n_elem, ld, dst):
+    """arr (n_elem..., T, B) host array (reference layout) -> planes [T][n_elem][ld] at DeviceBuffer dst."""
+    arr = np.ascontiguousarray(arr, dtype=np.float64)
+    T, B = arr.shape[-2], arr.shape[-1]
+    check(load().ssmq_upload_planes(arr.ctypes.data_as(c_double_p), T, int(n_elem), B, int(ld), ctypes.c_void_p(dst.ptr)),
+          'ssmq_upload_planes')
+
+
+def download_study(src, shape_elem, T, B, ld):
+    """planes [T][prod(shape_elem)][ld] at DeviceBuffer src -> host array shape_elem + (T, B) (reference layout)."""
+    out = np.empty(tuple(shape_elem) + (int(T), int(B)))
+    n = int(np.prod(shape_elem)) if len(shape_elem) else 1
+    check(load().ssmq_download_planes(ctypes.c_void_p(src.ptr), int(T), n, int(B), int(ld), out.ctypes.data_as(c_double_p)),
+          'ssmq_download_planes')
+    return out
 
 
 class SoA:

@@ -710,6 +710,81 @@ struct DevBuf {
 };
 }  // namespace
 
+// ---- host arrays in the reference's study layout <-> time-major planes in HBM, through the pinned staging blocks --------
+// The filters' device buffers are [n_outer][n_elem][ld] (time step, element, trajectory); the reference's arrays are
+// (n_elem..., n_outer, B): dim_y x T x B measurements in, D x T x B means and D x D x T x B covariances out
+// (ssinf.py:66-118).  Rows of B doubles are contiguous on both sides, so the permutation is a row copy: done on the host
+// between the caller's array and the pinned block (several threads), one contiguous transfer per chunk.
+namespace {
+void copy_rows(bool to_planes, double *host, double *pinned, int64_t t0, int64_t t1, int n_outer, int n_elem, int64_t B,
+               int64_t ld) {
+    // planes row (t - t0, e) of the chunk <-> host row (e, t)
+    const int64_t rows = (t1 - t0) * n_elem;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, (rows * B) / (256 * 1024)));
+    auto work = [=](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            const int64_t t = t0 + r / n_elem, e = r % n_elem;
+            double *pl = pinned + r * ld, *hs = host + (e * n_outer + t) * B;
+            if (to_planes) {
+                memcpy(pl, hs, sizeof(double) * B);
+                if (ld > B) memset(pl + B, 0, sizeof(double) * (ld - B));
+            } else {
+                memcpy(hs, pl, sizeof(double) * B);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    const int64_t per = (rows + nt - 1) / nt;
+    for (int k = 1; k < nt; ++k)
+        if (k * per < rows) th.emplace_back(work, k * per, std::min(rows, (k + 1) * per));
+    work(0, std::min(rows, per));
+    for (auto &t : th) t.join();
+}
+constexpr size_t kPlaneChunkBytes = size_t(128) << 20;
+}  // namespace
+
+int ssmq_upload_planes(const double *host, int n_outer, int n_elem, int64_t B, int64_t ld, double *d_planes) {
+    if (!host || !d_planes || n_outer < 0 || n_elem < 1 || B < 0 || ld < B) {
+        set_error("upload_planes: bad argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_outer == 0 || B == 0) return SSMQ_OK;
+    hipStream_t s = stream();
+    const size_t step_bytes = sizeof(double) * (size_t)n_elem * ld;
+    const int64_t tc = std::max<int64_t>(1, std::min<int64_t>(n_outer, (int64_t)(kPlaneChunkBytes / step_bytes)));
+    if ((rc = g_stage.reserve(0, step_bytes * tc, 0))) return rc;
+    for (int64_t t0 = 0; t0 < n_outer; t0 += tc) {
+        const int64_t t1 = std::min<int64_t>(n_outer, t0 + tc);
+        copy_rows(true, const_cast<double *>(host), (double *)g_stage.hin, t0, t1, n_outer, n_elem, B, ld);
+        SSMQ_HIP(hipMemcpyAsync(d_planes + (size_t)t0 * n_elem * ld, g_stage.hin, step_bytes * (t1 - t0), hipMemcpyHostToDevice, s));
+        SSMQ_HIP(hipStreamSynchronize(s));       // the pinned block is refilled for the next chunk
+    }
+    return SSMQ_OK;
+}
+
+int ssmq_download_planes(const double *d_planes, int n_outer, int n_elem, int64_t B, int64_t ld, double *host) {
+    if (!host || !d_planes || n_outer < 0 || n_elem < 1 || B < 0 || ld < B) {
+        set_error("download_planes: bad argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_outer == 0 || B == 0) return SSMQ_OK;
+    hipStream_t s = stream();
+    const size_t step_bytes = sizeof(double) * (size_t)n_elem * ld;
+    const int64_t tc = std::max<int64_t>(1, std::min<int64_t>(n_outer, (int64_t)(kPlaneChunkBytes / step_bytes)));
+    if ((rc = g_stage.reserve(0, 0, step_bytes * tc))) return rc;
+    for (int64_t t0 = 0; t0 < n_outer; t0 += tc) {
+        const int64_t t1 = std::min<int64_t>(n_outer, t0 + tc);
+        SSMQ_HIP(hipMemcpyAsync(g_stage.hout, d_planes + (size_t)t0 * n_elem * ld, step_bytes * (t1 - t0), hipMemcpyDeviceToHost, s));
+        SSMQ_HIP(hipStreamSynchronize(s));
+        copy_rows(false, host, (double *)g_stage.hout, t0, t1, n_outer, n_elem, B, ld);
+    }
+    return SSMQ_OK;
+}
+
 int ssmq_apply_batch(ssmq_transform *h, const ssmq_integrand *f, int64_t B, const double *mean, const double *cov,
                      const double *time, int time_stride, double *mean_f, double *cov_f, double *cov_fx,
                      int32_t *status) {

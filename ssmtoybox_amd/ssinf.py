@@ -169,11 +169,10 @@ class GaussianInference:
         Y, T, B = data.shape
         D = self.mod_dyn.dim_state
         ld = (B + 63) // 64 * 64
-        # measurements are already plane-shaped: [T][Y][ld]
-        ybuf = np.zeros((T, Y, ld))
-        ybuf[:, :, :B] = data.transpose(1, 0, 2)
-        d_y = _lib.DeviceBuffer(ybuf.nbytes)
-        d_y.upload(ybuf)
+        # (dim_y, T, B) -> planes [T][Y][ld]: a row permutation, done between the caller's array and the library's pinned
+        # staging block (`ssmq_upload_planes`)
+        d_y = _lib.DeviceBuffer(8 * T * Y * ld)
+        _lib.upload_study(data, Y, ld, d_y)
         m0 = np.broadcast_to(self.x0_mean, (B, D)) if x0_mean is None else np.asarray(x0_mean, dtype=np.float64)
         P0 = np.broadcast_to(self._initial_cov(), (B, D, D)) if x0_cov is None else np.asarray(x0_cov, dtype=np.float64)
         mbuf = np.zeros((D, ld))
@@ -203,14 +202,14 @@ class GaussianInference:
                                                       ctypes.c_void_p(d_fm.ptr), ctypes.c_void_p(d_fP.ptr),
                                                       ctypes.c_void_p(d_sm.ptr), ctypes.c_void_p(d_sP.ptr),
                                                       ctypes.c_void_p(d_st.ptr)), 'ssmq_filter_smooth_dev')
-            self.sm_mean = np.ascontiguousarray(d_sm.download((T, D, ld))[:, :, :B].transpose(1, 0, 2))
-            self.sm_cov = np.ascontiguousarray(d_sP.download((T, D, D, ld))[:, :, :, :B].transpose(1, 2, 0, 3))
+            self.sm_mean = _lib.download_study(d_sm, (D,), T, B, ld)
+            self.sm_cov = _lib.download_study(d_sP, (D, D), T, B, ld)
             d_sm.free()
             d_sP.free()
         else:
             self._launch(lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st)
-        fm = d_fm.download((T, D, ld))[:, :, :B].transpose(1, 0, 2)
-        fP = d_fP.download((T, D, D, ld))[:, :, :, :B].transpose(1, 2, 0, 3)
+        fm = _lib.download_study(d_fm, (D,), T, B, ld)       # planes [T][D][ld] -> (D, T, B), via pinned staging
+        fP = _lib.download_study(d_fP, (D, D), T, B, ld)
         self.status = d_st.download((ld,), dtype=np.int32)[:B]
         for buf in (d_y, d_m0, d_P0, d_fm, d_fP, d_st):
             buf.free()
@@ -218,7 +217,7 @@ class GaussianInference:
             b = int(np.flatnonzero(self.status)[0])
             raise np.linalg.LinAlgError('Matrix is not positive definite (trajectory {}, step {})'.format(
                 b, int(self.status[b]) - 1))
-        self.fi_mean, self.fi_cov = np.ascontiguousarray(fm), np.ascontiguousarray(fP)
+        self.fi_mean, self.fi_cov = fm, fP
         return self.fi_mean, self.fi_cov
 
 
