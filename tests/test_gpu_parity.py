@@ -85,6 +85,26 @@ def make_transform(amd, tname, din, dout, g=None, key=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def test_study_layout_transfers(amd):
+    """ssmq_upload_planes / ssmq_download_planes: (n_elem..., T, B) host arrays <-> time-major planes [T][n_elem][ld],
+    ragged B (zero-filled padding lanes), and a transfer that spans several staging chunks."""
+    from ssmtoybox_amd import _lib
+    rng = np.random.default_rng(5)
+    for shape_elem, T, B in (((3,), 7, 100), ((2, 2), 5, 64), ((), 4, 1), ((6, 6), 6, 100000)):
+        n = int(np.prod(shape_elem)) if shape_elem else 1
+        ld = (B + 63) // 64 * 64
+        arr = rng.standard_normal(tuple(shape_elem) + (T, B))
+        d = _lib.DeviceBuffer(8 * T * n * ld)
+        _lib.upload_study(arr, n, ld, d)
+        planes = d.download((T, n, ld)) if T * n * ld < 5_000_000 else None
+        if planes is not None:
+            want = np.moveaxis(arr.reshape(n, T, B), 0, 1)                      # (T, n, B)
+            assert np.array_equal(planes[:, :, :B], want) and not planes[:, :, B:].any()
+        back = _lib.download_study(d, shape_elem, T, B, ld)
+        assert back.shape == arr.shape and np.array_equal(back, arr)
+        d.free()
+
+
 def test_layout_roundtrip(amd):
     from ssmtoybox_amd import _lib
     rng = np.random.default_rng(0)
