@@ -17,7 +17,7 @@ import numpy as np
 from numpy.polynomial.hermite_e import hermegauss, hermeval
 
 from . import _lib
-from ._lib import Integrand, FORM_BQ, FORM_SIGMA, EMV_DIAG, EMV_BROADCAST
+from ._lib import FORM_SIGMA, EMV_DIAG
 
 
 class MomentTransform(metaclass=ABCMeta):

@@ -9,7 +9,6 @@ convenience: a Monte-Carlo study should reduce its filter outputs where they lie
 research/tpq/tpq_base.py:154-172 does on the CPU.  `squared_error` is not restated: its aggregate over the Monte-Carlo
 axis is the `se` entry of `mcshard.device_error_sums`.
 """
-import ctypes
 
 import numpy as np
 
