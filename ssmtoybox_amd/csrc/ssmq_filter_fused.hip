@@ -504,6 +504,10 @@ static const AugEntry kAug[] = {
     SSMQ_KEEP(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 5, 0),
     SSMQ_KEEP(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 5, 0),
     SSMQ_KEEP(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
+    SSMQ_KEEP(SSMQ_F_REENTRY2D_BIAS_DYN, SSMQ_F_RADAR2D_MEAS, 6, 2, 13, 0),
+    // spherical-radial point sets (cubature smoother)
+    SSMQ_KEEP(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 4, 0),
+    SSMQ_KEEP(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 10, 0),
 #endif
 };
 

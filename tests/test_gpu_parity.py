@@ -706,6 +706,15 @@ def test_spherical_radial_fused_filters_match_launch_loop(amd, golden, monkeypat
         assert ok.any(), name
         assert within(mean_err(fm[..., ok], fm2[..., ok]), bar, name + ' fused vs loop fm (row-scaled)')
         assert within(cov_err(fP[..., ok], fP2[..., ok]), 10 * bar, name + ' fused vs loop fP (entry-scaled)')
+        if name in ('reentry ckf', 'pendulum ckf') and ok.all():
+            # cubature smoother: forward pass that keeps the predictive moments as one kernel, then the RTS pass
+            alg.forward_pass_batch(y)
+            s1, S1 = alg.backward_pass_batch()
+            monkeypatch.setenv('SSMQ_NO_FUSED', '1')
+            s2, S2 = alg.backward_pass_batch()
+            monkeypatch.delenv('SSMQ_NO_FUSED')
+            assert within(mean_err(s1, s2), 1e-8, name + ' smoother fused vs loop sm (row-scaled)')
+            assert within(cov_err(S1, S2), 2e-8, name + ' smoother fused vs loop sP (entry-scaled)')
 
 
 def test_student_filters_golden(amd, golden, monkeypatch):
