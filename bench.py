@@ -37,10 +37,12 @@ CLOCK_HZ = 2.4e9          # MI355X peak engine clock
 F64_MFMA_PEAK_TF = 78.6  # MI355X fp64 matrix peak = 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (equals the fp64 vector peak)
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed PMC summary (profiles/pmc_traffic.json, produced by
-    profiles/collect_pmc.sh + profiles/pmc_summary.py from separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the
-    gfx950 note in MI355X_MICROARCH.md prescribes).  None if the kernel is not in the summary."""
+def pmc_traffic(kernel_name, grid=None):
+    """HBM bytes per launch of `kernel_name` at grid size `grid` (threads) from the committed PMC summary
+    (profiles/pmc_traffic.json, produced by profiles/collect_pmc.sh + profiles/pmc_summary.py from separate rocprofv3
+    --pmc passes, FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes).  Entries are keyed on
+    (kernel, grid): the same kernel launched at two batch sizes has two entries.  None if there is no entry for this
+    pair - never the figure of another grid."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         table = json.load(open(path))
@@ -50,13 +52,16 @@ def pmc_traffic(kernel_name):
     base = kernel_name.split('<')[0]
     want = [int(v) for v in re.findall(r'=(\d+)', kernel_name)]
     nshape = 4 if 'fused' in base else 3           # (D, Y, ND, NO) or (D, E, N) identify the shape
+    hits = []
     for key, rec in table.items():
         if key.startswith('_') or key.split('<')[0] != base:
             continue
-        have = [int(v) for v in re.findall(r'(\d+)', key.split('<', 1)[1])]
+        have = [int(v) for v in re.findall(r'(\d+)', key.split('<', 1)[1].split('>')[0])]
         if have[:nshape] == want[:nshape]:
-            return rec.get('hbm_bytes_per_launch')
-    return None
+            hits.append(rec)
+    if grid is not None:
+        hits = [r for r in hits if int(r.get('grid', -1)) == int(grid)]
+    return hits[0].get('hbm_bytes_per_launch') if len(hits) == 1 else None
 
 
 def simulate_ungm(B, T, seed):
@@ -119,18 +124,23 @@ class FilterBench:
     workload: 'ungm' (BASELINE configs[1]: GPQ-Kalman, D = 1, N = 3) | 'reentry5' (configs[2] with the reference's 5-D
     model, N = 11) | 'reentry6' (the synthetic 6-D variant, N = 13); filt: 'gpqkf' | 'ukf'."""
 
-    def __init__(self, amd, B, T, seed, workload='ungm', filt='gpqkf'):
+    def __init__(self, amd, B, T, seed, workload='ungm', filt='gpqkf', device_data=False):
         from ssmtoybox_amd import _lib, ssmod, ssinf
         from ssmtoybox_amd.mtran import resolve_integrand
         self._lib = _lib
         self.B, self.T = B, T
         self.ld = ld = (B + 63) // 64 * 64
+        d_xy = None
         if workload == 'ungm':
-            self.x_true, y = simulate_ungm(B, T, seed)
-            self.x_true, y = self.x_true[None], y[None]
             m0, P0 = np.zeros(1), np.eye(1)
             dyn = ssmod.UNGMTransition(ssmod.GaussRV(1), ssmod.GaussRV(1, cov=np.array([[10.0]])))
             obs = ssmod.UNGMMeasurement(ssmod.GaussRV(1), 1)
+            if device_data:          # large batches: trajectories and measurements from the device simulator, never on the host
+                d_xy = ssmod.simulate_dev(dyn, obs, T, B, seed=seed)[:2]
+                self.x_true = y = None
+            else:
+                self.x_true, y = simulate_ungm(B, T, seed)
+                self.x_true, y = self.x_true[None], y[None]
             ell = 3.0
         elif workload == 'ct':
             # BASELINE configs[3]: coordinated-turn dynamics (5 states), four bearing sensors (tests/test_ssinf.py:66-82
@@ -177,14 +187,17 @@ class FilterBench:
         else:
             par = np.array([[1.0] + [ell] * D])
             self.alg = ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut')
-        ybuf = np.zeros((T, Y, ld))
-        ybuf[:, :, :B] = y.transpose(1, 0, 2)
-        self.d_y = _lib.DeviceBuffer(ybuf.nbytes)
-        self.d_y.upload(ybuf)
-        xbuf = np.zeros((T, D, ld))                 # true states, same planes as the filter output (error sums)
-        xbuf[:, :, :B] = self.x_true.transpose(1, 0, 2)
-        self.d_x = _lib.DeviceBuffer(xbuf.nbytes)
-        self.d_x.upload(xbuf)
+        if d_xy is not None:
+            self.d_x, self.d_y = d_xy
+        else:
+            ybuf = np.zeros((T, Y, ld))
+            ybuf[:, :, :B] = y.transpose(1, 0, 2)
+            self.d_y = _lib.DeviceBuffer(ybuf.nbytes)
+            self.d_y.upload(ybuf)
+            xbuf = np.zeros((T, D, ld))                 # true states, same planes as the filter output (error sums)
+            xbuf[:, :, :B] = self.x_true.transpose(1, 0, 2)
+            self.d_x = _lib.DeviceBuffer(xbuf.nbytes)
+            self.d_x.upload(xbuf)
         mb = np.zeros((D, ld))
         mb[:] = m0[:, None]
         Pb = np.zeros((D * D, ld))
@@ -363,6 +376,7 @@ class Mt6Bench:
         from ssmtoybox_amd import _lib, ssmod
         self._lib = _lib
         self.B = B
+        self.ld = (B + 63) // 64 * 64
         par = np.array([[1.0] + [3.0] * 6])
         self.tf = amd.GaussianProcessTransform(6, 6, par, 'rbf', 'ut')
         self.model = ssmod.ReentryVehicle2DBiasTransition(dt=0.1)
@@ -581,7 +595,7 @@ def filter_leg(amd, workload, filt, B, T, seed, cpu_sample, cpu_budget, what, wi
     fm, fP, st = wl.results()
     ach = wl.bytes_per_pass() / (ms * 1e-3) / 1e9
     rec = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-           'traffic': pmc_traffic(wl.kernel), 'kernel': wl.kernel, 'bytes_per_launch': wl.bytes_per_pass(),
+           'traffic': pmc_traffic(wl.kernel, wl.ld), 'kernel': wl.kernel, 'bytes_per_launch': wl.bytes_per_pass(),
            'ms_per_launch': ms, 'filter_steps_per_s': B * T / (ms * 1e-3), 'failed_trajectories': int((st != 0).sum()),
            'workload': what}
     ib = issue_block(wl.kernel, T, ms)
@@ -619,13 +633,130 @@ def make_comm():
     launched = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
     if not launched:
         return mcshard.SingleComm(), 0, 1, local_rank
+    why = ''
+    if backend != 'gloo' and world > ndev:
+        # RCCL refuses two ranks on one device; every rank sees the same device count, so all of them take this branch
+        backend, why = 'gloo', '{} ranks on {} device(s)'.format(world, ndev)
+        if rank == 0:
+            sys.stderr.write('bench.py: {} - RCCL needs one device per rank, all-reduce over gloo\n'.format(why))
     if backend == 'gloo':
         import torch.distributed as dist
         dist.init_process_group('gloo')
-        return mcshard.TorchComm(dist), rank, world, local_rank
+        comm = mcshard.TorchComm(dist)
+        comm.fallback_reason = why
+        return comm, rank, world, local_rank
     comm = mcshard.open_comm(rank, world, force_rccl=os.environ.get('SSMQ_BENCH_FORCE_RCCL') == '1',
                              log=lambda m: sys.stderr.write(m + '\n'))
     return comm, rank, world, local_rank
+
+
+def saturated_sweep(amd, T, batches, base_kernel, base_ms, base_B):
+    """The headline filter pass (UNGM GPQ-Kalman) at growing batch sizes: BASELINE's B = 1e4 is 157 waves on 1024 SIMDs;
+    this shows what the same kernel does on a full chip.  Trajectories and measurements come from the device simulator.
+    Per entry: HBM fraction (24 algorithmic bytes per filter step) and the chip-wide fp64 issue fraction (VALU
+    instructions per wave and step from the committed SQ counters x 4 cycles, over all SIMDs)."""
+    pm = pmc_issue(base_kernel)
+    valu_ws = pm['SQ_INSTS_VALU'] / pm['SQ_WAVES'] / 100.0 if pm else None      # counters were taken at T = 100
+    rows = []
+    for B in batches:
+        if B == base_B:
+            ms, kernel, failed = base_ms, base_kernel, None
+        else:
+            wl = FilterBench(amd, B, T, seed=41, workload='ungm', filt='gpqkf', device_data=True)
+            ms = timed_passes(wl, 2, 10)
+            st = wl.d_st.download((wl.ld,), dtype=np.int32)[:B]
+            failed, kernel = int((st != 0).sum()), wl.kernel
+            wl.free()
+        ach = 24.0 * B * T / (ms * 1e-3) / 1e9
+        row = {'mc': B, 'ms_per_launch': ms, 'filter_steps_per_s': B * T / (ms * 1e-3), 'achieved': ach, 'unit': 'GB/s',
+               'frac': ach / HBM_PEAK_GBS, 'waves_per_simd': (B + 63) // 64 / 1024.0}
+        if failed is not None:
+            row['failed_trajectories'] = failed
+        if valu_ws:
+            row['issue_frac_chip'] = (B + 63) // 64 * T * valu_ws * 4.0 / CLOCK_HZ / (1024.0 * ms * 1e-3)
+        rows.append(row)
+    return rows
+
+
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def child_env(rank, world, port, id_file, base=None):
+    """Environment of rank `rank` of a self-spawned launch: what torch.distributed.run would export (RANK, LOCAL_RANK,
+    WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR, MASTER_PORT) plus the explicit rendezvous file of the RCCL id, so the
+    ranks do not depend on sharing a parent pid."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SSMQ_RCCL_ID_FILE=id_file, SSMQ_BENCH_CHILD='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this pool (RCCL across processes)
+    return env
+
+
+def needs_launcher(gpus, env=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: this process starts the N ranks itself."""
+    env = os.environ if env is None else env
+    return gpus > 1 and 'WORLD_SIZE' not in env and 'RANK' not in env
+
+
+def launch_ranks(gpus, argv, timeout_s=1500.0, script=None):
+    """Start `gpus` fresh processes of this file (one rank per GPU), relay rank 0's JSON line, return the exit code.
+    This process never touches the GPU (children are started with subprocess, not exec)."""
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='ssmq_bench_')
+    id_file = os.path.join(tmp, 'rccl.id')
+    port = free_port()
+    me = os.path.abspath(script or __file__)
+    procs = []
+    for r in range(gpus):
+        procs.append(subprocess.Popen([sys.executable, me] + list(argv), env=child_env(r, gpus, port, id_file),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc, line = 0, None
+    t_end = time.time() + timeout_s
+    try:
+        text, _ = procs[0].communicate(timeout=max(1.0, t_end - time.time()))
+        for ln in text.decode('utf-8', 'replace').splitlines():
+            if ln.startswith('{'):
+                line = ln
+            elif ln.strip():
+                sys.stderr.write(ln + '\n')
+        for pr in procs:
+            pr.wait(timeout=max(1.0, t_end - time.time()))
+    except subprocess.TimeoutExpired:
+        sys.stderr.write('bench.py: ranks did not finish within {:.0f} s\n'.format(timeout_s))
+        rc = 124
+    for r, pr in enumerate(procs):
+        if pr.poll() is None:
+            pr.kill()
+            pr.wait()
+        if pr.returncode and not rc:
+            sys.stderr.write('bench.py: rank {} exited with code {}\n'.format(r, pr.returncode))
+            rc = pr.returncode if pr.returncode > 0 else 1
+    for name in os.listdir(tmp):
+        try:
+            os.unlink(os.path.join(tmp, name))
+        except OSError:
+            pass
+    try:
+        os.rmdir(tmp)
+    except OSError:
+        pass
+    if line is None:
+        sys.stderr.write('bench.py: rank 0 printed no result line\n')
+        return rc or 1
+    out = json.loads(line)
+    out.setdefault('config', {})['launcher'] = 'bench.py --gpus {}: {} child processes, one rank per GPU'.format(gpus, gpus)
+    print(json.dumps(out))
+    if out.get('n_gpus') != gpus:
+        sys.stderr.write('bench.py: result line reports n_gpus = {} for --gpus {}\n'.format(out.get('n_gpus'), gpus))
+        return rc or 1
+    return rc
 
 
 def main():
@@ -633,7 +764,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=10000, help='MC trajectories per GPU')
+    ap.add_argument('--batch', type=int, default=10000, help='MC trajectories per GPU (weak scaling, the default)')
+    ap.add_argument('--total-batch', type=int, default=0,
+                    help='strong scaling: this many MC trajectories in total, split over the ranks in contiguous slices '
+                         '(mcshard.shard_bounds); e.g. BASELINE configs[2]: --workload reentry6 --filter ukf '
+                         '--total-batch 100000 --time-steps 50')
     ap.add_argument('--time-steps', type=int, default=100)
     ap.add_argument('--workload', default='ungm', choices=['ungm', 'reentry5', 'reentry6', 'ct'],
                     help="'ungm' is the headline (BASELINE configs[1]); the others are extra measurements")
@@ -642,13 +777,29 @@ def main():
     ap.add_argument('--no-mt6', action='store_true', help='skip the single-kernel / other-config legs of the N = 1 run')
     args = ap.parse_args()
 
+    if needs_launcher(args.gpus):
+        # one rank per GPU, started from here; nothing above or in this branch initialises the GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    # the result line goes to the descriptor stdout had at start-up, whatever a library does to fd 1 later
+    result_out = os.fdopen(os.dup(1), 'w')
     import ssmtoybox_amd as amd
     if amd.device_count() < 1:
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     from ssmtoybox_amd import _lib, mcshard
     comm, rank, world, local_rank = make_comm()
+    if world != args.gpus and rank == 0:
+        sys.stderr.write('bench.py: --gpus {} but the launcher started {} rank(s); reporting n_gpus = {}\n'.format(
+            args.gpus, world, world))
 
     B, T = args.batch, args.time_steps
+    strong = args.total_batch > 0
+    if strong:
+        lo, hi = mcshard.shard_bounds(args.total_batch, rank, world)
+        B = hi - lo
+        if B < 1:
+            raise SystemExit('bench.py: --total-batch {} leaves rank {} of {} without trajectories'.format(
+                args.total_batch, rank, world))
     wl = FilterBench(amd, B, T, seed=1 + rank, workload=args.workload, filt=args.filter)
     for _ in range(args.warmup):
         wl.step()
@@ -674,10 +825,25 @@ def main():
         mcshard.device_lcr_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, agg['mse'], wl.d_st), comm))
     rmse, nll = agg['rmse_total'], float(agg['nll_avg'].mean())
 
+    # per-rank launch times (one slot per rank, summed), trajectories per rank, and what the final collective costs: the
+    # packed phase-1 buffer all-reduced 20 times after a common start (every rank takes part: collective calls)
+    slot = np.zeros(2 * world)
+    slot[rank], slot[world + rank] = pass_ms_dev, B
+    slot = comm.allreduce_sum(slot)
+    n_packed = sum(int(np.asarray(v).size) for v in loc.values())
+    lat = []
+    comm.barrier()
+    for _ in range(20):
+        t1 = time.perf_counter()
+        comm.allreduce_sum(np.zeros(n_packed))
+        lat.append(time.perf_counter() - t1)
+    allreduce_us = float(np.median(lat)) * 1e6
+
     out = None
     headline = args.workload == 'ungm' and args.filter == 'gpqkf'
     if rank == 0:
-        steps_total = world * B * T * args.steps
+        b_total = int(round(slot[world:].sum()))          # trajectories of all ranks (world x B when weak)
+        steps_total = b_total * T * args.steps
         value = steps_total / elapsed
         bytes_pass = wl.bytes_per_pass()
         ach = bytes_pass / (pass_ms_dev * 1e-3) / 1e9
@@ -686,17 +852,20 @@ def main():
             'filter steps/sec (batched MC), {} {}'.format(args.filter, args.workload),
             'value': value, 'unit': 'filter steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': ('GaussianProcessTransform (RBF, UT points) GPQ-Kalman on UNGM, D=1, N=3, '
                                     '{} MC trajectories per GPU x T={} time steps per pass (BASELINE configs[1])'.format(B, T))
                        if headline else
                        '{} on {} (D={}, Y={}), {} MC trajectories per GPU x T={}'.format(args.filter, args.workload, wl.D,
                                                                                        wl.Y, B, T),
-                       'mc_per_gpu': B, 'time_steps': T, 'parallelism': 'mc-shard x{}'.format(world),
+                       'mc_per_gpu': B, 'mc_total': b_total, 'time_steps': T, 'parallelism': 'mc-shard x{}'.format(world),
+                       'per_rank_kernel_ms': [float(v) for v in slot[:world]],
+                       'per_rank_trajectories': [int(round(v)) for v in slot[world:]],
+                       'allreduce_us': allreduce_us, 'allreduce_bytes': 8 * n_packed,
                        'collective': type(comm).__name__ + (
                            ' (gloo fallback: ' + comm.fallback_reason + ')' if getattr(comm, 'fallback_reason', '') else '')},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(wl.kernel),
+                         'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(wl.kernel, wl.ld),
                          'kernel': wl.kernel,
                          'bytes_per_launch': bytes_pass, 'ms_per_launch': pass_ms_dev,
                          'note': 'the contract\'s HBM figure; this kernel is a serial recursion per trajectory and is '
@@ -730,11 +899,15 @@ def main():
         ms, b_alg, b_mov = mt.measure()
         ach = b_alg / (ms * 1e-3) / 1e9
         out['roofline_mt6'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(mt.kernel), 'kernel': mt.kernel,
+                               'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(mt.kernel, mt.ld), 'kernel': mt.kernel,
                                'bytes_per_launch': b_alg, 'bytes_moved_per_launch': b_mov, 'ms_per_launch': ms,
                                'transforms_per_s': mt.B / (ms * 1e-3), 'max_scaled_err_vs_oracle': err,
                                'workload': 'batched GPQ moment transform, D=E=6, N=13, B=1e5, 4 rotating buffer sets '
                                            '(north_star target; BASELINE configs[2] transform shape)'}
+        # the same figures inside `roofline`, the block the driver's record keeps (north_star: >= 0.40 on this kernel)
+        out['roofline']['target'] = {k: out['roofline_mt6'][k] for k in (
+            'kernel', 'frac', 'achieved', 'unit', 'ms_per_launch', 'bytes_per_launch', 'traffic', 'max_scaled_err_vs_oracle')}
+        out['roofline']['target']['workload'] = 'north_star: batched GPQ moment transform D=E=6, N=13, B=1e5 (>= 0.40 asked)'
         if with_cpu:
             means, covs = mt.host
             out['roofline_mt6']['cpu_baseline'] = cpu_baseline_apply(
@@ -748,6 +921,9 @@ def main():
                                                       'unit': 'GB/s', 'frac': b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                       'bytes_per_launch': b_alg}
         mt.free()
+        out['roofline']['target']['frac_at_1e6'] = out['roofline_mt6']['at_1e6_trajectories']['frac']
+        if headline:
+            out['roofline']['saturated'] = saturated_sweep(amd, T, (10000, 100000, 1000000), wl.kernel, pass_ms_dev, B)
     if rank == 0 and single and not args.no_mt6:
         # BASELINE configs[2]: the filters that are stable on the reentry model (the GPQ-Kalman recursion itself fails
         # within three steps on every trajectory, in the reference as here: tests/test_gpu_parity.py::test_config3_gpqkf_*)
@@ -782,7 +958,8 @@ def main():
             out['roofline_c5']['cpu_baseline'] = cb5
         out['roofline_c5']['unisolvent_n21'] = measure_c5_unisolvent(amd)
     if rank == 0:
-        print(json.dumps(out))
+        result_out.write(json.dumps(out) + '\n')
+        result_out.flush()
     wl.free()
     comm.close()
     if getattr(comm, 'abandoned_rccl_thread', False):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SSMQ_VERSION 100
+#define SSMQ_VERSION 101
 
 #define SSMQ_OK 0
 #define SSMQ_E_ARG (-1)          /* bad argument (null pointer, size out of range, unknown id) */
@@ -432,12 +432,16 @@ int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f
  * time; nothing else in this library depends on it.
  *   ssmq_comm_unique_id  rank 0: 128-byte id (ncclGetUniqueId) to be handed to every rank out of band
  *   ssmq_comm_init       every rank, after ssmq_set_device: joins the communicator (world = 1 with id = NULL: no RCCL)
+ *   ssmq_comm_abandon_init   for a caller that ran ssmq_comm_init on a helper thread and stopped waiting for it (a peer
+ *                        never arrived): puts the process's stdout back (ssmq_comm_init parks it on stderr while RCCL
+ *                        prints its banner); harmless at any other time
  *   ssmq_allreduce_sum / _max   host buffer of n doubles, reduced in place over all ranks (synchronous)
  *   ssmq_comm_barrier    drains this rank's stream, then a one-element all-reduce
  * One communicator per process; calls are collective and must be issued in the same order on every rank.
  */
 int ssmq_comm_unique_id(char *id, int len);
 int ssmq_comm_init(int rank, int world, const char *id, int len);
+int ssmq_comm_abandon_init(void);
 int ssmq_comm_rank(void);
 int ssmq_comm_world(void);
 int ssmq_allreduce_sum(double *buf, int64_t n);

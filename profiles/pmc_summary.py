@@ -53,6 +53,7 @@ def main():
             rd = sum(v) / len(v) * 1024 * (fr or 2.0)
             wr = sum(w) / len(w) * 1024 * (fw or 1.0)
             key = name.replace('(anonymous namespace)::', '').split('(')[0].replace('void ssmq::', '').replace('ssmq::', '').replace(' ', '')
+            key = '{}@{}'.format(key, grid)          # the same kernel at two batch sizes: two entries
             out[key] = {'launches': len(v), 'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr,
                         'hbm_bytes_per_launch': rd + wr, 'grid': grid}
     print(json.dumps(out, indent=1))

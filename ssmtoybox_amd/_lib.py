@@ -12,6 +12,7 @@ import numpy as np
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
+ABI_VERSION = 101          # include/ssmq.h SSMQ_VERSION this binding's struct layouts and prototypes were written for
 SSMQ_MAX_FPAR = 16
 SSMQ_MAX_FIDX = 16
 FORM_BQ, FORM_SIGMA = 0, 1
@@ -164,6 +165,7 @@ _PROTOTYPES = {
                                             c_double_p]),
     'ssmq_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'ssmq_comm_init': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
+    'ssmq_comm_abandon_init': (ctypes.c_int, []),
     'ssmq_comm_rank': (ctypes.c_int, []),
     'ssmq_comm_world': (ctypes.c_int, []),
     'ssmq_allreduce_sum': (ctypes.c_int, [c_double_p, ctypes.c_int64]),
@@ -191,6 +193,12 @@ def load():
         raise SsmqError('libssmq.so not found at {} - build it with __graft_entry__.build() / '
                         'make -C ssmtoybox_amd/csrc; this package has no CPU fallback'.format(path))
     lib = ctypes.CDLL(path)
+    lib.ssmq_version.restype = ctypes.c_int
+    have = lib.ssmq_version()
+    if have != ABI_VERSION:
+        # struct ssmq_integrand changed size between 100 and 101 (idx[8] -> idx[16]): a stale library would read past it
+        raise SsmqError('{} reports ABI version {}, this binding needs {} - rebuild it (make -C ssmtoybox_amd/csrc)'.format(
+            path, have, ABI_VERSION))
     for name, (res, args) in _PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -1090,7 +1090,10 @@ struct GraphDropGuard {
 namespace ssmq {
 void reset_wide_attributes();
 void drop_staging_arena();
+static unsigned g_device_epoch = 1;
+unsigned device_epoch() { return g_device_epoch; }
 void reset_device_caches() {
+    ++g_device_epoch;
     g_fc.drop_graph();
     g_fc.consts_ok = false;
     if (g_fc.ws) hipFree(g_fc.ws);

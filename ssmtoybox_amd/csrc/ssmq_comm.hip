@@ -5,6 +5,7 @@
 // librccl is opened at run time (dlopen) by the first ssmq_comm_* call: the compute entry points of libssmq carry no
 // dependency on it, and single-process users never load it.
 #include <dlfcn.h>
+#include <atomic>
 #include <unistd.h>
 #include <cstdio>
 #include <cstring>
@@ -31,6 +32,17 @@ comm_t g_comm = nullptr;
 int g_rank = 0, g_world = 1;
 double *g_dbuf = nullptr;
 size_t g_dbuf_n = 0;
+// stdout is parked on this descriptor while ncclCommInitRank runs (see ssmq_comm_init); -1 when stdout is in place
+std::atomic<int> g_saved_stdout{-1};
+
+void restore_stdout() {
+    const int saved = g_saved_stdout.exchange(-1);
+    if (saved >= 0) {
+        fflush(stdout);
+        dup2(saved, STDOUT_FILENO);
+        close(saved);
+    }
+}
 
 int load_rccl() {
     if (g_rccl.lib) return SSMQ_OK;
@@ -126,17 +138,23 @@ int ssmq_comm_init(int rank, int world, const char *id, int len) {
     UniqueId u;
     memcpy(u.internal, id, kIdBytes);
     // RCCL prints a version banner on stdout while the communicator is created; callers own stdout (bench.py prints one
-    // JSON line there), so it is sent to stderr for the duration of the call
+    // JSON line there), so it is sent to stderr for the duration of the call.  The saved descriptor is global: a caller
+    // that runs this function on a helper thread and gives up on it (a peer never arrived) gets its stdout back with
+    // ssmq_comm_abandon_init().
     fflush(stdout);
     const int saved = dup(STDOUT_FILENO);
-    if (saved >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
-    const int nrc = g_rccl.CommInitRank(&g_comm, world, u, rank);
-    fflush(stdout);
     if (saved >= 0) {
-        dup2(saved, STDOUT_FILENO);
-        close(saved);
+        dup2(STDERR_FILENO, STDOUT_FILENO);
+        g_saved_stdout.store(saved);
     }
+    const int nrc = g_rccl.CommInitRank(&g_comm, world, u, rank);
+    restore_stdout();
     return nccl_fail(nrc, "ncclCommInitRank");
+}
+
+int ssmq_comm_abandon_init(void) {
+    restore_stdout();
+    return SSMQ_OK;
 }
 
 int ssmq_comm_rank(void) { return g_rank; }

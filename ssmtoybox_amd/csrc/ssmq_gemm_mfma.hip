@@ -287,12 +287,12 @@ __global__ __launch_bounds__(kGemmBlock, 2) void k_fxwc_cov_mfma(const double *_
 template <int NT>
 hipError_t launch_cov(const double *A, const double *X, int64_t M, int lda, const CovEpilogue &ep, hipStream_t s) {
     constexpr size_t lds = sizeof(double) * 2 * 16 * (NT * 16 + 16 + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
+    if (attr_epoch != device_epoch()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_fxwc_cov_mfma<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_epoch = device_epoch();
     }
     hipLaunchKernelGGL((k_fxwc_cov_mfma<NT>), dim3((unsigned)((M + 63) / 64)), dim3(kGemmBlock), lds, s, A, X, M, lda, ep);
     return hipGetLastError();
@@ -301,12 +301,12 @@ hipError_t launch_cov(const double *A, const double *X, int64_t M, int lda, cons
 template <int NT, int RT>
 hipError_t launch_rt(const double *A, const double *Bm, double *T, int64_t M, int lda, int ldt, hipStream_t s) {
     constexpr size_t lds = sizeof(double) * 2 * 16 * (NT * 16 + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
+    if (attr_epoch != device_epoch()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_fxwc_mfma<NT, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_epoch = device_epoch();
     }
     constexpr int rows = 64 * RT;
     hipLaunchKernelGGL((k_fxwc_mfma<NT, RT>), dim3((unsigned)((M + rows - 1) / rows)), dim3(kGemmBlock), lds, s, A, Bm, T, M,

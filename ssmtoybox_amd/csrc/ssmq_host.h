@@ -28,6 +28,9 @@ void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what);
 hipStream_t stream();
 int ensure_device();
+// Bumped whenever the library moves to another device (reset_device_caches): per-function attributes
+// (hipFuncAttributeMaxDynamicSharedMemorySize) are per device and must be set again after a change.
+unsigned device_epoch();
 
 #define SSMQ_HIP(call)                                        \
     do {                                                      \

@@ -762,11 +762,11 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(k_weights<256>, dim3(a.P), dim3(threads), sizeof(double) * 2 * nn, s, a);
         return hip_fail(hipGetLastError(), "k_weights");
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
+    if (attr_epoch != ssmq::device_epoch()) {
         SSMQ_HIP(hipFuncSetAttribute((const void *)k_weights<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         SSMQ_HIP(hipFuncSetAttribute((const void *)k_weights_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-        attr_set = true;
+        attr_epoch = ssmq::device_epoch();
     }
     const bool staged = packed <= lds_cap && N <= kInvLanes * kInvSlots && !getenv("SSMQ_WEIGHTS_NO_LDS");
     if (!staged) {

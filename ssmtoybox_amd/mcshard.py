@@ -59,8 +59,10 @@ def _id_file(rank_env=None):
     if explicit:
         return explicit
     tmp = os.environ.get('TMPDIR', '/tmp')
-    return os.path.join(tmp, 'ssmq_rccl_{}_{}_{}.id'.format(os.getppid(), os.environ.get('MASTER_PORT', '0'),
-                                                         os.environ.get('TORCHELASTIC_RUN_ID', 'none')))
+    # an elastic restart keeps (ppid, port, run id): the restart count tells the attempts apart
+    return os.path.join(tmp, 'ssmq_rccl_{}_{}_{}_{}.id'.format(
+        os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
+        os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')))
 
 
 class RcclComm:
@@ -75,6 +77,13 @@ class RcclComm:
         buf = ctypes.create_string_buffer(128)
         if self._rccl:
             if self.rank == 0:
+                # nothing of an earlier attempt under the same name may be taken for this one's
+                import glob
+                for stale in [self._file] + glob.glob(self._file + '.st*'):
+                    try:
+                        os.unlink(stale)
+                    except OSError:
+                        pass
                 _lib.check(lib.ssmq_comm_unique_id(buf, 128), 'ssmq_comm_unique_id')
                 tmp = self._file + '.tmp{}'.format(os.getpid())
                 with open(tmp, 'wb') as f:
@@ -121,6 +130,7 @@ class RcclComm:
             th.join(init_timeout_s)
             if th.is_alive():
                 self.hung_init = True
+                lib.ssmq_comm_abandon_init()             # the thread still holds stdout on stderr: take it back
                 raise _lib.SsmqError('RCCL communicator: ncclCommInitRank did not return within {} s'.format(init_timeout_s))
             if box.get('rc'):
                 raise _lib.SsmqError('ssmq_comm_init failed (code {}): {}'.format(box['rc'], box.get('err', '')))

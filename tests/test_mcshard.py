@@ -121,3 +121,53 @@ def test_launched_ranks_agree_on_gloo_when_rccl_is_unavailable(tmp_path):
         assert p_.exitcode == 0
     assert name == 'TorchComm' and why and notes
     assert np.array_equal(out, [3.0, 20.0]) and np.array_equal(mx, [1.0])
+
+
+# ---- bench.py --gpus N: the self-spawned launch (no GPU needed: the ranks here are a stand-in script) ----------------
+_RANK_STUB = '''
+import json, os, sys
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+assert os.environ['LOCAL_RANK'] == os.environ['RANK'] and os.environ['MASTER_ADDR'] == '127.0.0.1'
+assert os.environ['SSMQ_RCCL_ID_FILE'].endswith('rccl.id') and int(os.environ['MASTER_PORT']) > 0
+# every rank leaves a mark next to the id file: the ranks share ONE rendezvous directory
+open(os.environ['SSMQ_RCCL_ID_FILE'] + '.seen%d' % rank, 'w').close()
+mode = sys.argv[1]
+if mode == 'fail' and rank == world - 1:
+    sys.exit(3)
+if rank == 0:
+    import time
+    d = os.path.dirname(os.environ['SSMQ_RCCL_ID_FILE'])
+    t0 = time.time()
+    while len([n for n in os.listdir(d) if '.seen' in n]) < world and time.time() - t0 < 30:
+        time.sleep(0.01)
+    print('a banner line some library printed')
+    print(json.dumps({'n_gpus': 1 if mode == 'one' else world, 'argv': sys.argv[1:],
+                      'seen': len([n for n in os.listdir(d) if '.seen' in n]), 'config': {}}))
+else:
+    print('rank', rank, 'says hello')          # must not reach the launcher's stdout
+'''
+
+
+def test_bench_gpus_flag_starts_that_many_ranks(tmp_path, capfd):
+    import json
+    import bench
+    assert bench.needs_launcher(8, {}) and not bench.needs_launcher(1, {})
+    assert not bench.needs_launcher(8, {'WORLD_SIZE': '8', 'RANK': '3'})          # under torch.distributed.run: a rank
+    env = bench.child_env(2, 4, 29511, '/x/rccl.id', {'PATH': '/bin'})
+    assert (env['RANK'], env['LOCAL_RANK'], env['WORLD_SIZE'], env['MASTER_PORT']) == ('2', '2', '4', '29511')
+    assert env['SSMQ_RCCL_ID_FILE'] == '/x/rccl.id' and env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and env['PATH'] == '/bin'
+    stub = tmp_path / 'rank.py'
+    stub.write_text(_RANK_STUB)
+    capfd.readouterr()
+    assert bench.launch_ranks(3, ['ok', '--steps', '5'], timeout_s=60, script=str(stub)) == 0
+    out, err = capfd.readouterr()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out                                     # ONE JSON line on stdout, banners and peers on stderr
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 3 and rec['seen'] == 3 and rec['argv'] == ['ok', '--steps', '5']
+    assert '3 child processes' in rec['config']['launcher']
+    assert 'banner line' in err and 'says hello' in err
+    assert bench.launch_ranks(2, ['fail'], timeout_s=60, script=str(stub)) == 3        # a rank that dies fails the launch
+    capfd.readouterr()
+    assert bench.launch_ranks(2, ['one'], timeout_s=60, script=str(stub)) == 1         # one GPU measured N times: refused
+    assert 'n_gpus = 1 for --gpus 2' in capfd.readouterr()[1]
