@@ -337,7 +337,7 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         const int want[4] = {h->opt_mask & (tp ? SSMQ_OPT_UT : 3), h->opt_mask & SSMQ_OPT_UT, h->opt_mask & SSMQ_OPT_LDL & (tp ? 0 : 1), 0};
         for (int k = 0; k < 4 && !se; ++k) se = find_small(f->id, h->D, h->E, h->N, h->form, tp, sel, want[k]);
     }
-    if (kernel_name) *kernel_name = se ? se->name : (wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
+    if (kernel_name) *kernel_name = se ? se->name : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
     if (dry_run) return SSMQ_OK;
     if (B <= 0) return SSMQ_OK;
     if (!d_mean || !d_cov || !d_mean_f || !d_cov_f || !d_cov_fx || !d_status || (fi.uses_time && !d_time) ||

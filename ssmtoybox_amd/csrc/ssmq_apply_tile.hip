@@ -1,0 +1,371 @@
+// Whole moment transform for point sets of up to 64 points with every product on the matrix cores
+// (v_mfma_f64_16x16x4_f64): the generic shapes between the register-resident kernels (ssmq_apply_small.h) and the
+// batch GEMM of large point sets (ssmq_gemm_mfma.hip) - Gauss-Hermite grids, fully-symmetric degree-5 sets in low
+// dimension, BQ transforms at D = 7 ... 16 with 2 D (+ 1) points (BASELINE configs[4], unisolvent half: Bayes-Sard,
+// D = E = 10, N = 21).  k_apply_wave ran these with lanes over output entries out of LDS: 2 200 wave instructions per
+// trajectory, 5 % of either roofline.  Here (bq/bqmtran.py:158-223, mtran.py:141-149):
+//
+//   a wave takes G = min(4, 64 / N) trajectories at a time.  Lanes in G groups: inputs -> LDS slice, Cholesky, then
+//   lane (g, n) owns sigma point n of trajectory g: x_n = m + L xi_n, f(x_n) in registers, written to the
+//   trajectory's FX tile in LDS in the order the matrix instruction wants its B operand: lane (c, q) of a 16 x 4
+//   fragment reads FX[c][4 s + q], s = 0 .. KS - 1, as consecutive doubles.
+//   Per trajectory, with f[s] those fragments (the SAME registers serve every product below as the B operand):
+//     T' = Wc FX'        NB x KS instructions, A = fragments of Wc (LDS, shared by the workgroup).  The accumulator
+//                        of row block blk, register r, lane (c, q) is T[c][16 blk + 4 r + q] - exactly the A operand
+//                        (row c, k = q) of the step that sums over n = 4 (4 blk + r) .. + 3, so
+//     cov = T FX'        KS instructions straight from the accumulators, no transposition, no LDS round trip
+//     P'  = Wcc FX'      KS instructions;  ccov' = L P'  ceil(D / 4) instructions (A = fragments of the factor)
+//     mean               KS multiply-adds per lane + two cross-lane adds
+//   t-process: S = fx iK fx' the same way (NB KS + KS more).  Centred form (classical rules): Wc = diag(wc),
+//   Wcc = xi diag(wc), the mean subtracted from the fragments first.
+// 27 matrix instructions per trajectory at D = E = 10, N = 21 instead of ~9 000 multiply-adds spread over lanes that
+// were mostly idle.  The fp64 matrix rate equals the vector rate on CDNA4: what is gained is issue slots and
+// lane utilisation, not peak.  Results differ from k_apply_wave / k_apply_wide at rounding level (other summation
+// order inside the products); the covariance is formed for e2 <= e1 and mirrored, as every other kernel does.
+#include "ssmq_device.h"
+#include "ssmq_wide.h"
+
+namespace ssmq {
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kTileWaves = 4;
+
+struct TileGeom {
+    int KS, KSP, NB, G, GL;
+    int frag_doubles;     // workgroup-shared operand fragments
+    int wave_doubles;     // per-wave slice
+};
+// k-steps a point set is padded to (the kernel is instantiated for these; padding = zero fragments, no loop guards)
+__host__ __device__ constexpr inline int tile_ksm(int N) {
+    return N <= 16 ? 4 : N <= 24 ? 6 : N <= 32 ? 8 : N <= 52 ? 13 : 16;
+}
+__host__ __device__ inline TileGeom tile_geom(int D, int E, int N, bool tp) {
+    TileGeom g;
+    g.KS = tile_ksm(N);
+    g.KSP = g.KS | 1;                       // odd pitch: the 64 lanes of a fragment read fall on distinct banks
+    g.NB = (g.KS + 3) / 4;
+    g.G = 64 / N < 4 ? 64 / N : 4;
+    g.GL = 64 / g.G;
+    g.frag_doubles = 64 * ((tp ? 2 : 1) * g.NB * g.KS + 2 * g.KS) + N * (D | 1);     // + unit points [N][D | 1]
+    g.frag_doubles = (g.frag_doubles + 1) & ~1;
+    g.wave_doubles = g.G * (D * D + D + E * 4 * g.KSP) + 2 + 64 + 16;   // factor + mean + FX tile per trajectory, status words, column slots
+    g.wave_doubles = (g.wave_doubles + 1) & ~1;
+    return g;
+}
+
+#define SSMQ_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// DM: compile-time bound on D and E; KS: k-steps of 4 points the point set is padded to (tile_ksm(N));
+// FC: integrand fixed at compile time, or -1
+#ifndef SSMQ_TILE_OCC
+#define SSMQ_TILE_OCC 2      // waves per SIMD the register allocation is held to
+#endif
+#ifndef SSMQ_TILE_WGS_PER_CU
+#define SSMQ_TILE_WGS_PER_CU 6
+#endif
+template <int DM, int KS, int FC = -1>
+__global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(const WideArgs a, int64_t B) {
+    extern __shared__ __align__(16) double lds[];
+    constexpr int KSM = KS, NBM = (KS + 3) / 4, NB = NBM, KSP = KS | 1;
+    const int D = a.D, E = a.E, N = a.N;
+    const bool tp = a.tp_nu > 0.0, sigma = a.form == SSMQ_FORM_SIGMA;
+    const TileGeom tg = tile_geom(D, E, N, tp);
+    const int G = tg.G, GL = tg.GL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const WideLayout cl = wide_layout(D, E, N, a.form);
+    const double *cs = a.consts;
+    const double nan = __builtin_nan("");
+
+    // ---- operand fragments of the constants, once per workgroup ---------------------------------------------------------
+    double *fWc = lds;                              // [NB][KS][64]  lane (c, q): Wc[16 blk + c][4 s + q]
+    double *fIK = fWc + NB * KS * 64;               // the same of iK (t-process only)
+    double *fWcc = fIK + (tp ? NB * KS * 64 : 0);   // [KS][64]      lane (c, q): Wcc[c][4 s + q]
+    double *fWm = fWcc + KS * 64;                   // [KS][64]      lane (c, q): wm[4 s + q]
+    double *sXi = fWm + KS * 64;                    // [N][D | 1]    unit sigma points
+    for (int i = threadIdx.x; i < N * D; i += 64 * kTileWaves) sXi[(i / D) * (D | 1) + i % D] = cs[cl.xiT + i];
+    for (int i = threadIdx.x; i < NB * KS * 64; i += 64 * kTileWaves) {
+        const int l = i & 63, s = (i >> 6) % KS, blk = (i >> 6) / KS;
+        const int row = 16 * blk + (l & 15), col = 4 * s + (l >> 4);
+        const bool in = row < N && col < N;
+        double w = 0.0;
+        if (in) w = sigma ? (row == col ? cs[cl.Wc + row] : 0.0) : cs[cl.Wc + row * N + col];
+        fWc[i] = w;
+        if (tp) fIK[i] = in ? cs[cl.iK + row * N + col] : 0.0;
+    }
+    for (int i = threadIdx.x; i < KS * 64; i += 64 * kTileWaves) {
+        const int l = i & 63, s = i >> 6;
+        const int d = l & 15, n = 4 * s + (l >> 4);
+        double w = 0.0;
+        if (d < D && n < N) w = sigma ? cs[cl.xiT + n * D + d] * cs[cl.Wc + n] : cs[cl.Wcc + d * N + n];
+        fWcc[i] = w;
+        fWm[i] = n < N ? cs[cl.wm + n] : 0.0;
+    }
+    // ---- the wave's slice: factor + mean and FX tile per trajectory --------------------------------------------------------
+    double *wbase = lds + tg.frag_doubles + (size_t)wave * tg.wave_doubles;
+    const int per_traj = D * D + D + E * 4 * KSP;
+    int *s_ok = (int *)(wbase + G * per_traj);
+    for (int i = lane; i < tg.wave_doubles; i += 64) wbase[i] = 0.0;     // the tile's padding (n >= N) stays zero for good
+    __syncthreads();
+
+    // entries of the model variance / additive term this lane finishes: rows e1 = q + 4 r, column e2 = c
+    double emv_r[4], add_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e1 = q + 4 * r, e2 = c;
+        const bool in = e1 < E && e2 < E;
+        const bool use = !sigma && in && ((e1 == e2) || a.emv_mode == SSMQ_EMV_BROADCAST);
+        emv_r[r] = use ? cs[cl.emv + e1 * E + e2] : 0.0;
+        add_r[r] = (in && a.cov_add) ? a.cov_add[e1 * E + e2] : 0.0;
+    }
+    const double tp_den = tp ? 1.0 / (a.tp_nu - 2.0 + (double)N) : 0.0;
+
+    const int gi = lane / GL, gl = lane - gi * GL;
+    const int64_t n_groups = (B + G - 1) / G;
+    const int64_t grp0 = (int64_t)blockIdx.x * kTileWaves + wave, grp_step = (int64_t)gridDim.x * kTileWaves;
+    // Inputs: lane (g, i), i < D, owns row i of trajectory g's covariance (lower triangle) and entry i of its mean.  The
+    // rows of the NEXT group are requested before this group's matrix work starts, so the HBM round trip is never waited for.
+    const uint32_t es8 = (uint32_t)(a.es_in * 8), eo8 = (uint32_t)(a.es_out * 8);   // plane pitches in bytes (< 2^32: launcher)
+    // Every lane loads from a valid address (trajectory and row clamped, entries beyond the diagonal re-read the diagonal
+    // one: same cache line): no divergent branches around the loads; what a lane does not own is never used.
+    double in_row[DM], in_m = 0.0;
+    const int gl_row = gl < D ? gl : D - 1;
+    auto fetch = [&](int64_t grp) {
+        int64_t bq = grp * G + (gi < G ? gi : G - 1);
+        bq = bq < B ? bq : B - 1;
+        const char *pm = (const char *)(a.mean + bq) + (uint64_t)(uint32_t)gl_row * es8;
+        const char *pc = (const char *)(a.cov + bq) + (uint64_t)((uint32_t)gl_row * (uint32_t)D) * es8;
+        in_m = *(const double *)pm;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) in_row[k] = *(const double *)(pc + (uint64_t)(uint32_t)(k < gl_row ? k : gl_row) * es8);
+    };
+    double *scol = wbase + G * per_traj + 2;        // [64] one slot per lane: the current elimination column
+    fetch(grp0);
+    for (int64_t grp = grp0; grp < n_groups; grp += grp_step) {
+        const int64_t b0 = grp * G;
+        // ---- 1. Cholesky, one row per lane in registers; column j travels through the slice (right-looking, the subtractions
+        //         in the order k = 0, 1, ... of the left-looking dot products: the factor of the other generic kernels) --------
+        const int64_t b = b0 + gi;
+        const bool active = gi < G && b < B;
+        double *sL = wbase + (gi < G ? gi : 0) * per_traj;      // D*D factor (pitch D), zeros above the diagonal
+        double *sm = sL + D * D;
+        double *sfx = sm + D;                                   // [E][4][KSP]
+        const double *gcol = scol + gi * GL;                    // the group's column: entry k at gcol[k]
+        double rowv[DM];
+#pragma unroll
+        for (int k = 0; k < DM; ++k) rowv[k] = in_row[k];
+        const double my_m = in_m;
+        fetch(grp + grp_step < n_groups ? grp + grp_step : grp);
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < DM; ++j) {
+            if (j < D) {                                        // wave-uniform
+                scol[lane] = rowv[j];                           // column j before scaling, every lane its own slot
+                SSMQ_WAVE_SYNC();
+                const double ajj = active ? gcol[j] : 1.0;
+                ok = ok && (ajj > 0.0);
+                double ljj, rinv;
+                sqrt_rsqrt(ajj, ljj, rinv);
+                const double lij = (gl == j) ? ljj : rowv[j] * rinv;
+                rowv[j] = lij;
+#pragma unroll
+                for (int k = j + 1; k < DM; ++k)                // l_kj formed here as lane k forms it for itself
+                    rowv[k] = fma(-lij, gcol[k] * rinv, rowv[k]);    // entries k > gl (and k >= D) are never used
+                SSMQ_WAVE_SYNC();
+            }
+        }
+        if (active && gl < D) {
+#pragma unroll
+            for (int k = 0; k < DM; ++k)
+                if (k < D) sL[gl * D + k] = k <= gl ? rowv[k] : 0.0;
+            sm[gl] = my_m;
+        }
+        if (active && gl == 0) {
+            if (a.status) a.status[b] = ok ? 0 : 1;
+            s_ok[gi] = ok ? 1 : 0;
+        }
+        SSMQ_WAVE_SYNC();
+        // ---- 2. lane (g, n): sigma point and integrand, values into the trajectory's tile -------------------------------------
+        if (active && gl < N) {
+            const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
+            const int n = gl;
+            double xin[DM], x[DM], o[DM];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) xin[k] = k < D ? sXi[n * (D | 1) + k] : 0.0;
+#pragma unroll
+            for (int d = 0; d < DM; ++d) {
+                double sacc = 0.0;
+                if (d < D) {
+                    sacc = sm[d];
+#pragma unroll
+                    for (int k = 0; k < DM; ++k)
+                        if (k <= d) sacc += sL[d * D + k] * xin[k];
+                }
+                x[d] = sacc;
+                o[d] = 0.0;
+            }
+            double xs[kMaxIntegrandIn];
+#pragma unroll
+            for (int k = 0; k < kMaxIntegrandIn; ++k) {
+                double v = k < DM ? x[k < DM ? k : 0] : 0.0;
+                if (FC < 0 && a.fp.n_idx > 0) {        // state-index selection (MeasurementModel.state_index)
+                    const int src = k < a.fp.n_idx ? a.fp.idx[k] : 0;
+                    v = x[0];
+#pragma unroll
+                    for (int qq = 1; qq < DM; ++qq) v = (src == qq) ? x[qq] : v;
+                }
+                xs[k] = v;
+            }
+            if constexpr (FC >= 0) {
+                Fn<FC> fn;
+                fn.init(t, a.fp);
+                fn.template eval<SSMQ_MAX_FIDX>(xs, o);
+            } else {
+                eval_integrand(a.fid, xs, t, a.fp, o);
+            }
+            const int pos = (n & 3) * KSP + (n >> 2);
+#pragma unroll
+            for (int e = 0; e < DM; ++e)
+                if (e < E) sfx[e * 4 * KSP + pos] = o[e];
+        }
+        SSMQ_WAVE_SYNC();
+        // ---- 3. one trajectory at a time on the matrix cores; lane (c, q) = column c, k sub-index q ------------------------------
+        for (int g = 0; g < G; ++g) {
+            const int64_t bb = b0 + g;
+            if (bb >= B) break;                                  // wave-uniform
+            const double *tL = wbase + g * per_traj, *tfx = tL + D * D + D;
+            const bool okg = s_ok[g] != 0;
+            double f[KSM];
+#pragma unroll
+            for (int s = 0; s < KSM; ++s) f[s] = c < E ? tfx[(c * 4 + q) * KSP + s] : 0.0;
+            // mean: column c, the four k sub-indices summed across the lane groups
+            double mpart = 0.0;
+#pragma unroll
+            for (int s = 0; s < KSM; ++s) mpart = fma(fWm[s * 64 + lane], f[s], mpart);
+            mpart += __shfl_xor(mpart, 16, 64);
+            mpart += __shfl_xor(mpart, 32, 64);
+            const double mc = mpart;
+            if (sigma) {
+#pragma unroll
+                for (int s = 0; s < KSM; ++s)
+                    if (4 * s + q < N) f[s] -= mc;
+            }
+            v4d acc[NBM], cov = {0.0, 0.0, 0.0, 0.0}, sq = {0.0, 0.0, 0.0, 0.0};
+            auto quadratic = [&](const double *fA, v4d &out) {     // out = FX A FX' (A symmetric N x N, as fragments)
+#pragma unroll
+                for (int blk = 0; blk < NBM; ++blk) {
+                    acc[blk] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s = 0; s < KSM; ++s)
+                        acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(fA[(blk * KS + s) * 64 + lane], f[s], acc[blk], 0, 0, 0);
+                }
+#pragma unroll
+                for (int blk = 0; blk < NBM; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * blk + r < KS) out = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[blk][r], f[4 * blk + r], out, 0, 0, 0);
+            };
+            quadratic(fWc, cov);
+            if (tp) quadratic(fIK, sq);
+            // cross-covariance: P' = Wcc FX' (rows d), then ccov' = L P'
+            v4d pacc = {0.0, 0.0, 0.0, 0.0}, cc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KSM; ++s) pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(fWcc[s * 64 + lane], f[s], pacc, 0, 0, 0);
+#pragma unroll
+            for (int t4 = 0; t4 < (DM + 3) / 4; ++t4) {
+                if (4 * t4 < D) {
+                    const int d = 4 * t4 + q;
+                    const double lf = (c < D && d < D) ? tL[c * D + d] : 0.0;
+                    cc = __builtin_amdgcn_mfma_f64_16x16x4f64(lf, pacc[t4], cc, 0, 0, 0);
+                }
+            }
+            // ---- stores: mean (q = 0 lanes), covariance for e2 <= e1 mirrored, cross-covariance ---------------------------------
+            // plane index (32 bits) x plane pitch in bytes (32 bits) on top of the trajectory's wave-uniform base address
+            auto at = [&](double *base, int idx) { return (double *)((char *)(base + bb) + (uint64_t)(uint32_t)idx * eo8); };
+            if (q == 0 && c < E) *at(a.mean_f, c) = okg ? mc : nan;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e1 = q + 4 * r, e2 = c;
+                const double m1 = __shfl(mc, e1 & 15, 64);       // lane e1 (q = 0) holds the mean of row e1
+                if (e1 < E && e2 <= e1) {
+                    double v;
+                    if (sigma) {
+                        v = cov[r] * a.cov_scale + add_r[r];
+                    } else {
+                        double em = emv_r[r];
+                        if (tp) em = (a.tp_nu - 2.0 + sq[r]) * tp_den * em;
+                        v = (cov[r] - m1 * mc + em) * a.cov_scale + add_r[r];
+                    }
+                    v = okg ? v : nan;
+                    *at(a.cov_f, e1 * E + e2) = v;
+                    if (e2 != e1) *at(a.cov_f, e2 * E + e1) = v;
+                }
+                const int dd = q + 4 * r;                         // ccov[e = c][d' = dd]
+                if (c < E && dd < D) *at(a.cov_fx, c * D + dd) = okg ? cc[r] * a.ccov_scale : nan;
+            }
+        }
+        SSMQ_WAVE_SYNC();        // the next group's inputs overwrite the slice
+    }
+}
+
+template <int DM, int KS, int FC>
+hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
+    const TileGeom tg = tile_geom(a.D, a.E, a.N, a.tp_nu > 0.0);
+    const size_t lds = sizeof(double) * ((size_t)tg.frag_doubles + (size_t)kTileWaves * tg.wave_doubles);
+    if (lds > 48 * 1024) {     // per device and instantiation; a cheap call, rare shapes
+        hipError_t e = hipFuncSetAttribute((const void *)k_apply_tile<DM, KS, FC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t groups = (B + tg.G - 1) / tg.G, blocks = (groups + kTileWaves - 1) / kTileWaves;
+    // a few workgroups per CU, each walking its share of the batch: the constants' fragments are built once per workgroup
+    const int64_t cap = 256 * SSMQ_TILE_WGS_PER_CU;
+    hipLaunchKernelGGL((k_apply_tile<DM, KS, FC>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(64 * kTileWaves), lds, s,
+                       a, B);
+    return hipGetLastError();
+}
+
+template <int KS>
+hipError_t launch_tile_ks(const WideArgs &a, int64_t B, hipStream_t s) {
+    const int dm = a.D > a.E ? a.D : a.E;
+    if constexpr (KS == 6)
+        if (a.fid == SSMQ_F_SMOOTH10D_DYN && a.fp.n_idx == 0 && dm <= 10) return launch_tile_one<10, KS, SSMQ_F_SMOOTH10D_DYN>(a, B, s);
+    if (dm <= 4) return launch_tile_one<4, KS, -1>(a, B, s);
+    if (dm <= 8) return launch_tile_one<8, KS, -1>(a, B, s);
+    if (dm <= 12) return launch_tile_one<12, KS, -1>(a, B, s);
+    return launch_tile_one<SSMQ_MAX_DIM, KS, -1>(a, B, s);
+}
+
+}  // namespace
+
+size_t tile_lds_bytes(int D, int E, int N, bool tp) {
+    const TileGeom tg = tile_geom(D, E, N, tp);
+    return sizeof(double) * ((size_t)tg.frag_doubles + (size_t)kTileWaves * tg.wave_doubles);
+}
+
+// whole transforms (built-in integrand, one constant block for the batch) of this shape run on the matrix cores
+bool wide_full_uses_tile(int D, int E, int N) {
+    return N > 8 && N <= 64 && D <= 16 && E <= 16 && !getenv("SSMQ_NO_TILE") && !getenv("SSMQ_NO_WAVE") &&
+           tile_lds_bytes(D, E, N, true) <= 160 * 1024 - 64;
+}
+
+// plane pitches must fit 32 bits in bytes (the kernel forms addresses as 32 x 32 -> 64-bit products)
+// ... and consecutive trajectories must be consecutive doubles of a plane (the library's batch layout)
+bool tile_pitch_ok(const WideArgs &a) {
+    return a.es_in < ((int64_t)1 << 29) && a.es_out < ((int64_t)1 << 29) && a.bs_mean == 1 && a.bs_cov == 1 && a.bs_mf == 1 &&
+           a.bs_cf == 1 && a.bs_cfx == 1;
+}
+
+hipError_t launch_apply_tile(const WideArgs &a, int64_t B, hipStream_t s) {
+    switch (tile_ksm(a.N)) {
+        case 4: return launch_tile_ks<4>(a, B, s);
+        case 6: return launch_tile_ks<6>(a, B, s);
+        case 8: return launch_tile_ks<8>(a, B, s);
+        case 13: return launch_tile_ks<13>(a, B, s);
+        default: return launch_tile_ks<16>(a, B, s);
+    }
+}
+
+}  // namespace ssmq

@@ -703,6 +703,7 @@ static bool attr_set = false;
 void reset_wide_attributes() { attr_set = false; }
 
 hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s) {
+    if (a.mode == SSMQ_WIDE_FULL && a.consts_stride == 0 && wide_full_uses_tile(a.D, a.E, a.N) && tile_pitch_ok(a)) return launch_apply_tile(a, B, s);
     if (wave_route(a)) return launch_apply_wave(a, B, s);
     const size_t lds = wide_lds_bytes_for(a);
     if (!attr_set) {

@@ -58,6 +58,10 @@ struct WideArgs {
 size_t wide_lds_bytes(int D, int E, int N);
 hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s);   // FULL mode, N <= 64: k_apply_wave inside
 bool wide_full_uses_wave(int D, int E, int N);
+// ... or, with one constant block for the whole batch and 8 < N <= 64, on the matrix cores (ssmq_apply_tile.hip)
+bool wide_full_uses_tile(int D, int E, int N);
+hipError_t launch_apply_tile(const WideArgs &a, int64_t B, hipStream_t s);
+bool tile_pitch_ok(const WideArgs &a);
 // evaluation pass of the two-pass matrix-core route, one wave per trajectory (fx_out, chol_out, mean_f, mrow_out, status)
 hipError_t launch_eval_wave(const WideArgs &a, int64_t B, hipStream_t s);
 

@@ -162,9 +162,10 @@ def test_apply_generic_kernel_matches(amd, golden, name):
 
 
 def test_wave_kernel_matches_workgroup_kernel(amd, golden, monkeypatch):
-    """Point sets of up to 64 points without a register-resident specialisation run on k_apply_wave (one wave per
-    trajectory); SSMQ_NO_WAVE=1 sends them to k_apply_wide (one workgroup per trajectory).  Same arithmetic: BQ, t-process
-    and centred forms, sub-state measurement models, not-positive-definite inputs."""
+    """Point sets of 9 ... 64 points without a register-resident specialisation run on k_apply_tile (every product on the
+    matrix cores); SSMQ_NO_TILE=1 sends them to k_apply_wave (one wave per trajectory, lanes over output entries),
+    SSMQ_NO_WAVE=1 to k_apply_wide (one workgroup per trajectory).  Same arithmetic up to the summation order inside the
+    products: BQ, t-process and centred forms, sub-state measurement models, not-positive-definite inputs."""
     g = golden('g3_apply')
     cases = [('reentry_dyn', lambda d, e: amd.GaussianProcessTransform(d, e, np.array([[1.0] + [3.0] * d]), 'rbf', 'gh',
                                                                       {'degree': 2})),                     # N = 32
@@ -174,7 +175,10 @@ def test_wave_kernel_matches_workgroup_kernel(amd, golden, monkeypatch):
              ('bearing_meas', lambda d, e: amd.BayesSardTransform(d, e, np.array([[1.0] + [3.0] * d]), 2, 'fs',
                                                                   {'degree': 5})),                          # N = 51, E = 4
              ('ct_dyn', lambda d, e: amd.FullySymmetricStudentTransform(d, 5)),                             # N = 51
-             ('pend_dyn', lambda d, e: amd.GaussHermiteTransform(d, 7))]                                # N = 49
+             ('pend_dyn', lambda d, e: amd.GaussHermiteTransform(d, 7)),                                    # N = 49
+             ('pend_dyn', lambda d, e: amd.GaussHermiteTransform(d, 4)),                                    # N = 16
+             ('ungm_dyn', lambda d, e: amd.GaussianProcessTransform(d, e, np.array([[1.0, 3.0]]), 'rbf', 'gh',
+                                                                    {'degree': 15}))]                       # D = 1, N = 15
     for name, make in cases:
         fid, p, sidx, din, dout = MODELS[name]
         mod, f = make_model(name)
@@ -182,19 +186,31 @@ def test_wave_kernel_matches_workgroup_kernel(amd, golden, monkeypatch):
         covs[3] = -covs[3]                                  # one input that is not positive definite
         tf = make(din, dout)
         monkeypatch.delenv('SSMQ_NO_WAVE', raising=False)
+        monkeypatch.delenv('SSMQ_NO_TILE', raising=False)
+        assert tf.kernel_name(f) == 'k_apply_tile', tf.kernel_name(f)
+        tile = tf.apply_batch(f, means, covs, times.astype(float), return_status=True)
+        monkeypatch.setenv('SSMQ_NO_TILE', '1')
         assert tf.kernel_name(f) == 'k_apply_wave', tf.kernel_name(f)
         got = tf.apply_batch(f, means, covs, times.astype(float), return_status=True)
         monkeypatch.setenv('SSMQ_NO_WAVE', '1')
         assert tf.kernel_name(f) == 'k_apply_wide'
         ref = tf.apply_batch(f, means, covs, times.astype(float), return_status=True)
         monkeypatch.delenv('SSMQ_NO_WAVE')
-        assert np.array_equal(got[3], ref[3]) and got[3][3] != 0 and not got[3][:3].any()
-        ok = ref[3] == 0
-        assert np.isnan(got[0][3]).all() and np.isnan(got[1][3]).all()
-        for a_, b_, what in zip(got[:3], ref[:3], ('mean', 'cov', 'ccov')):
-            sc = np.abs(b_[ok]).max()
-            assert within(np.abs(a_[ok] - b_[ok]).max() / sc, 1e-13, '{} {} wave vs workgroup {}'.format(
-                name, type(tf).__name__, what))
+        monkeypatch.delenv('SSMQ_NO_TILE')
+        for res, kern, bar in ((got, 'wave', 1e-13), (tile, 'tile', 1e-12)):
+            assert np.array_equal(res[3], ref[3]) and res[3][3] != 0 and not res[3][:3].any()
+            ok = ref[3] == 0
+            assert np.isnan(res[0][3]).all() and np.isnan(res[1][3]).all() and np.isnan(res[2][3]).all()
+            for a_, b_, what in zip(res[:3], ref[:3], ('mean', 'cov', 'ccov')):
+                sc = np.abs(b_[ok]).max()
+                if kern == 'tile' and what == 'ccov' and isinstance(tf, amd.SigmaPointTransform):
+                    # the centred rules form x_n - m from x_n = m + L xi_n (mtran.py:145-148), rounded at eps |m| (the radar
+                    # model: m = 6500, L xi = 1e-3); the tile kernel multiplies by L xi_n itself - closer to the exact value
+                    bar = 1e-10
+                assert within(np.abs(a_[ok] - b_[ok]).max() / sc, bar, '{} {} {} vs workgroup {}'.format(
+                    name, type(tf).__name__, kern, what))
+            if kern == 'tile':          # formed for e2 <= e1 and mirrored: exactly symmetric
+                assert np.array_equal(res[1][ok], res[1][ok].transpose(0, 2, 1))
 
 
 def test_apply_python_callable(amd, golden):
@@ -1638,7 +1654,7 @@ def test_bsq_d10_device_integrand(amd, golden):
         tf = amd.BayesSardTransform(10, 10, gp_par(10, 3.0), g[t + '_mi'], pstr, ppar)
         w = dict(wm=g[t + '_wm'], Wc=g[t + '_Wc'], Wcc=g[t + '_Wcc'], model_var=float(g[t + '_mv']))
         tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
-        assert tf.kernel_name(model.dyn_eval) in (('k_apply_wave', 'k_apply_wide') if pstr == 'ut' else ('k_apply_wide',))
+        assert tf.kernel_name(model.dyn_eval) in (('k_apply_tile', 'k_apply_wave', 'k_apply_wide') if pstr == 'ut' else ('k_apply_wide',))
         mf, cf, cfx = tf.apply_batch(model.dyn_eval, means, covs, 0.0)
         for i in range(0, B, 9):
             ref = orc.apply_bq(orc.F_SMOOTH10D_DYN, means[i], covs[i], 0.0, g[t + '_pts'], w)
