@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "../../include/ssmq.h"
+#include "ssmq_math.h"
 
 namespace ssmq {
 
@@ -217,7 +218,7 @@ struct Fn<SSMQ_F_PENDULUM_DYN> {
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {
         o[0] = x[0] + x[1] * dt;
-        o[1] = x[1] - 9.81 * dt * sin(x[0]);
+        o[1] = x[1] - 9.81 * dt * sin_nr(x[0]);
     }
 };
 template <>
@@ -226,7 +227,7 @@ struct Fn<SSMQ_F_PENDULUM_MEAS> {
     __device__ __forceinline__ void init(double, const FPar &) {}
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {
-        o[0] = sin(x[0]);
+        o[0] = sin_nr(x[0]);
     }
 };
 template <>
@@ -238,7 +239,7 @@ struct Fn<SSMQ_F_REENTRY1D_DYN> {
     __device__ __forceinline__ void eval(const double *x, double *o) const {
         const double gam = 1.0 / 6.096;
         o[0] = x[0] - dt * x[1];
-        o[1] = x[1] - dt * exp(-gam * x[0]) * (x[1] * x[1]) * x[2];
+        o[1] = x[1] - dt * exp_nr(-gam * x[0]) * (x[1] * x[1]) * x[2];
         o[2] = x[2];
     }
 };
@@ -249,7 +250,9 @@ struct Fn<SSMQ_F_RANGE_MEAS> {
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {
         const double sx = 30.0, sy = 30.0;
-        o[0] = sqrt(sx * sx + (x[0] - sy) * (x[0] - sy));
+        double rg, irg;
+        sqrt_rsqrt(sx * sx + (x[0] - sy) * (x[0] - sy), rg, irg);      // >= 900: normal range
+        o[0] = rg;
     }
 };
 struct ReentryCore {
@@ -300,7 +303,7 @@ struct Fn<SSMQ_F_SMOOTH10D_DYN> {
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             double sn, cs;
-            sincos(x[i], &sn, &cs);
+            sincos_nr(x[i], &sn, &cs);
             o[i] = sn + x[5 + i] * x[5 + i];
             o[5 + i] = x[5 + i] * cs;
         }
@@ -317,8 +320,11 @@ struct Fn<SSMQ_F_RADAR2D_MEAS> {
     template <int E>
     __device__ __forceinline__ void eval(const double *x, double *o) const {
         const double dx = x[0] - lx, dy = x[1] - ly;
-        o[0] = sqrt(dx * dx + dy * dy);
-        o[1] = atan2(dy, dx);
+        const double r2 = dx * dx + dy * dy;
+        double rg, irg;
+        sqrt_rsqrt(r2, rg, irg);                   // normal-range helper ...
+        o[0] = r2 > 0.0 ? rg : r2;                  // ... and a target exactly at the radar
+        o[1] = atan2_nr(dy, dx);
     }
 };
 template <>
@@ -330,7 +336,7 @@ struct Fn<SSMQ_F_CT_DYN> {
     __device__ __forceinline__ void eval(const double *x, double *o) const {
         const double om = x[4];
         double a, b;
-        sincos(om * dt, &a, &b);
+        sincos_nr(om * dt, &a, &b);
         const double c = a / om, d = (1.0 - b) / om;
         o[0] = x[0] + c * x[1] - d * x[3];
         o[1] = b * x[1] - a * x[3];
@@ -348,7 +354,7 @@ struct Fn<SSMQ_F_BEARING_MEAS> {
     __device__ __forceinline__ void eval(const double *x, double *o) const {
 #pragma unroll
         for (int s = 0; s < E; ++s) {
-            if (s < SSMQ_MAX_FPAR / 2) o[s] = atan2(x[1] - fp->p[2 * s + 1], x[0] - fp->p[2 * s]);
+            if (s < SSMQ_MAX_FPAR / 2) o[s] = atan2_nr(x[1] - fp->p[2 * s + 1], x[0] - fp->p[2 * s]);
         }
     }
 };
@@ -361,7 +367,7 @@ struct Fn<SSMQ_F_CTRS_DYN> {
     __device__ __forceinline__ void eval(const double *x, double *o) const {
         const double q0 = x[5], q1 = x[6];
         double s3, c3;
-        sincos(x[3], &s3, &c3);
+        sincos_nr(x[3], &s3, &c3);
         double f0, f1;
         if (x[4] == 0.0) {
             f0 = dt * x[2] * c3;
@@ -369,7 +375,7 @@ struct Fn<SSMQ_F_CTRS_DYN> {
         } else {
             const double c = x[2] / x[4];
             double s34, c34;
-            sincos(x[3] + x[4] * dt, &s34, &c34);
+            sincos_nr(x[3] + x[4] * dt, &s34, &c34);
             f0 = c * (s34 - s3) + 0.5 * dt * dt * c3 * q0;
             f1 = c * (-c34 + c3) + 0.5 * dt * dt * s3 * q0;
         }
