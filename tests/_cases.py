@@ -84,6 +84,33 @@ def within(value, tol, what):
     return bool(value < tol)
 
 
+def _recorded():
+    """(what -> largest value measured) from the parity statistics committed under profiles/ by earlier rounds."""
+    import glob
+    import json
+    import os
+    out = {}
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+    for path in sorted(glob.glob(os.path.join(root, 'r0*_parity_stats.json'))):
+        try:
+            for r in json.load(open(path)):
+                out[r['what']] = max(out.get(r['what'], 0.0), float(r['measured']))
+        except (OSError, ValueError, KeyError):
+            pass
+    return out
+
+
+RECORDED = _recorded()
+
+
+def capped(bar, what, factor=1e3, floor=1e-13):
+    """A condition-number bar (64 cond eps, 8 cond^2 eps) is a worst case and can sit many orders above what the
+    kernels deliver; where an earlier round RECORDED the measured value of this very comparison, the bar is at most
+    1e3 x that (never below `floor`), so a regression of a few digits fails instead of hiding under the worst case."""
+    rec = RECORDED.get(str(what))
+    return bar if rec is None else min(bar, max(factor * rec, floor))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # tolerance of one moment transform against the NumPy reference (north star: 1e-10 relative, fp64)
 # ---------------------------------------------------------------------------------------------------------------

@@ -603,8 +603,90 @@ def g9_sweeps():
     save('g9_sweeps', **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G10: the two recursions that are compared at the reference's own noise level, on more trajectories and with the
+# reference's weights stored, so that an extended-precision referee (oracle/ssmq_referee.py) can say how far the reference
+# itself is from the exact result of its algorithm: Bayes-Sard Kalman filter on the reentry model (BASELINE configs[2]),
+# t-process Kalman filter on the coordinated-turn model with bearing sensors (configs[3])
+# ---------------------------------------------------------------------------------------------------------------
+def _weights_of(tf, tag, out):
+    out[tag + '_wm'], out[tag + '_Wc'], out[tag + '_Wcc'] = tf.wm.copy(), tf.Wc.copy(), tf.Wcc.copy()
+    out[tag + '_pts'] = tf.model.points.copy()
+    out[tag + '_mv'] = np.atleast_2d(np.asarray(tf.model.model_var, dtype=float)).copy()
+    if getattr(tf.model, 'iK', None) is not None:
+        out[tag + '_iK'] = np.asarray(tf.model.iK, dtype=float).copy()
+
+
+def g10_referee():
+    out = {}
+    # --- reentry 5-D + radar, Bayes-Sard Kalman filter as in g4 (research/bsq/bsq_tracking.py:263-281) ---
+    steps, sims = 30, 24
+    m0 = np.array([6500.4, 349.14, -1.8093, -6.7967, 0.6932])
+    P0 = np.diag([1e-6, 1e-6, 1e-6, 1e-6, 1])
+    Qn = np.diag([2.4064e-5, 2.4064e-5, 1e-6])
+    Rn = np.diag([1e-6, 0.17e-6])
+    dyn = ssmod.ReentryVehicle2DTransition(GaussRV(5, m0, P0), GaussRV(3, cov=Qn))
+    obs = ssmod.Radar2DMeasurement(GaussRV(2, cov=Rn), 5)
+    np.random.seed(20261)
+    x = dyn.simulate_discrete(steps, sims)
+    y = obs.simulate_measurements(x)
+    par_dyn = np.array([[1.0, 1, 1, 1, 1, 1]])
+    par_obs = np.array([[1.0, 0.9, 0.9, 1e4, 1e4, 1e4]])
+    mi = np.hstack((np.zeros((5, 1)), np.eye(5), 2 * np.eye(5))).astype(int)
+    bsq = ssinf.BayesSardKalman(dyn, obs, par_dyn, par_obs, mi, mi, 'ut')
+    bsq.tf_dyn.model.model_var = 2e-6 * np.eye(5)
+    bsq.tf_obs.model.model_var = 0 * np.eye(2)
+    _weights_of(bsq.tf_dyn, 'rer_dyn', out)
+    _weights_of(bsq.tf_obs, 'rer_obs', out)
+    fm, fc = np.full((5, steps, sims), np.nan), np.full((5, 5, steps, sims), np.nan)
+    for s in range(sims):
+        try:
+            fm[..., s], fc[..., s] = bsq.forward_pass(y[..., s])
+        except np.linalg.LinAlgError:
+            pass
+        bsq.reset()
+    out['rer_y'], out['rer_fm'], out['rer_fc'] = y, fm, fc
+    out['rer_m0'], out['rer_P0'], out['rer_Q'], out['rer_R'], out['rer_G'] = m0, P0, Qn, Rn, dyn.noise_gain
+
+    # --- coordinated turn 5-D + four bearing sensors, t-process Kalman filter (tests/test_ssinf.py:66-82 model set-up;
+    #     heavy-tailed measurement noise as tests/test_gpu_parity.py::test_config4_tpq_ct_bearing_1e4 generates it) ---
+    steps, sims = 6, 48
+    rng = np.random.default_rng(20262)
+    m0 = np.array([1000, 300, 1000, 0, np.deg2rad(-3.0)])
+    P0 = np.diag([100, 10, 100, 10, 0.1])
+    dt, r1, r2 = 0.1, 0.1, 1.75e-4
+    A = np.array([[dt ** 3 / 3, dt ** 2 / 2], [dt ** 2 / 2, dt]])
+    Q = np.zeros((5, 5))
+    Q[:2, :2], Q[2:4, 2:4], Q[4, 4] = r1 * A, r1 * A, r2 * dt
+    Rn = 10e-3 * np.eye(4)
+    sensors = np.vstack((1000 * np.eye(2), -1000 * np.eye(2))).astype(float)
+    dyn = ssmod.CoordinatedTurnTransition(GaussRV(5, m0, P0), GaussRV(5, cov=Q), dt=dt)
+    obs = ssmod.BearingMeasurement(GaussRV(4, cov=Rn), 5, state_index=[0, 2], sensor_pos=sensors)
+    x = m0[:, None] + np.linalg.cholesky(P0).dot(rng.standard_normal((5, sims)))
+    y = np.zeros((4, steps, sims))
+    Lq = np.linalg.cholesky(Q + 1e-12 * np.eye(5))
+    for k in range(steps):
+        x = np.stack([dyn.dyn_fcn(x[:, i], np.zeros(5), k) for i in range(sims)], axis=1) + Lq.dot(rng.standard_normal((5, sims)))
+        y[:, k] = np.arctan2(x[2][None] - sensors[:, 1:2], x[0][None] - sensors[:, 0:1]) + 0.1 * rng.standard_t(3, size=(4, sims))
+    par = np.array([[1.0, 100, 100, 100, 100, 1]])
+    tpq = ssinf.StudentProcessKalman(dyn, obs, par, par)
+    _weights_of(tpq.tf_dyn, 'ct_dyn', out)
+    _weights_of(tpq.tf_obs, 'ct_obs', out)
+    out['ct_nu'] = np.array([float(tpq.tf_dyn.model.nu)])
+    fm, fc = np.full((5, steps, sims), np.nan), np.full((5, 5, steps, sims), np.nan)
+    for s in range(sims):
+        try:
+            fm[..., s], fc[..., s] = tpq.forward_pass(y[..., s])
+        except np.linalg.LinAlgError:
+            pass
+        tpq.reset()
+    out['ct_y'], out['ct_fm'], out['ct_fc'] = y, fm, fc
+    out['ct_m0'], out['ct_P0'], out['ct_Q'], out['ct_R'], out['ct_sensors'], out['ct_dt'] = m0, P0, Q, Rn, sensors, np.array([dt])
+    save('g10_referee', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
     if 'g1' in which:
         g1_points()
     if 'g2' in which:
@@ -623,3 +705,5 @@ if __name__ == '__main__':
         g8_marginal()
     if 'g9' in which:
         g9_sweeps()
+    if 'g10' in which:
+        g10_referee()

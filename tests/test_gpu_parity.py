@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from oracle import ssmq_oracle as orc
-from tests._cases import MODELS, SIGMA_TF, BQ_TF, SENSORS, assert_moments_close, rel_err, RTOL, cov_err, mean_err, mean_err_sigma, within
+from tests._cases import MODELS, SIGMA_TF, BQ_TF, SENSORS, assert_moments_close, rel_err, RTOL, cov_err, mean_err, mean_err_sigma, within, capped
 from tests.golden.make_golden_cases import GP_CASES, BS_CASES, gp_par
 
 pytestmark = pytest.mark.gpu
@@ -374,13 +374,16 @@ def test_gp_weights_golden(amd, golden, case):
         assert rel_err(tf.model.q, g[t + '_q']) < 1e-13
         assert rel_err(tf.model.Q, g[t + '_Q']) < 1e-13
         assert rel_err(tf.model.R, g[t + '_R']) < 1e-13
-        assert rel_err(tf.model.iK, g[t + '_iK']) < tol1
-        assert rel_err(tf.wm, g[t + '_wm']) < tol1
-        assert rel_err(tf.Wcc, g[t + '_Wcc']) < tol1
-        assert rel_err(tf.Wc, g[t + '_Wc']) < tol2
+        def chk(value, bar, what):          # worst-case conditioning bar, capped by what earlier rounds measured
+            what = t + ' ' + what
+            return within(value, capped(bar, what), what)
+        assert chk(rel_err(tf.model.iK, g[t + '_iK']), tol1, 'iK')
+        assert chk(rel_err(tf.wm, g[t + '_wm']), tol1, 'wm')
+        assert chk(rel_err(tf.Wcc, g[t + '_Wcc']), tol1, 'Wcc')
+        assert chk(rel_err(tf.Wc, g[t + '_Wc']), tol2, 'Wc')
         assert np.array_equal(tf.Wc, tf.Wc.T)
-        assert abs(tf.model.model_var - g[t + '_mv']) < tol2 * max(1.0, abs(float(g[t + '_mv'])))
-        assert abs(tf.model.integral_var - g[t + '_iv']) < tol2
+        assert chk(abs(tf.model.model_var - g[t + '_mv']) / max(1.0, abs(float(g[t + '_mv']))), tol2, 'model_var')
+        assert chk(abs(tf.model.integral_var - g[t + '_iv']), tol2, 'integral_var')
         # theta-batched: every row of a (P, 1 + D) parameter matrix gets its own workgroup
         pars = np.vstack([par, gp_par(dim, ell * 1.5, 1.0, aniso), par])
         w = device_gp_weights(tf.model.points, pars)
@@ -409,15 +412,15 @@ def test_rbf_kernel_methods_golden(amd, golden, case):
         assert np.array_equal(K, K.T) and np.all(np.diag(K) == 1.0)
         assert rel_err(k.eval(par, x, g[t + '_x2']), g[t + '_K12']) < 1e-14
         assert rel_err(k.eval(par, x, 0.5 * x + 0.2, diag=True), g[t + '_Kdiag']) < 1e-14
-        assert within(rel_err(k.eval_chol(par, x, scaling=False), g[t + '_L']), max(1e-13, 64 * cond * 2.2e-16), t + ' eval_chol')
-        assert within(rel_err(k.eval_chol(par, x), g[t + '_Ls']), max(1e-13, 64 * conds * 2.2e-16), t + ' eval_chol scaled')
+        assert within(rel_err(k.eval_chol(par, x, scaling=False), g[t + '_L']), capped(max(1e-13, 64 * cond * 2.2e-16), t + ' eval_chol'), t + ' eval_chol')
+        assert within(rel_err(k.eval_chol(par, x), g[t + '_Ls']), capped(max(1e-13, 64 * conds * 2.2e-16), t + ' eval_chol scaled'), t + ' eval_chol scaled')
         L = k.eval_chol(par, x)
         assert np.array_equal(L, np.tril(L))
-        assert within(rel_err(k.eval_inv_dot(par, x), g[t + '_iKs']), max(1e-13, 64 * conds * 2.2e-16), t + ' eval_inv_dot scaled')
-        assert within(rel_err(k.eval_inv_dot(par, x, scaling=False), g[t + '_iK']), max(1e-13, 64 * cond * 2.2e-16), t + ' eval_inv_dot')
+        assert within(rel_err(k.eval_inv_dot(par, x), g[t + '_iKs']), capped(max(1e-13, 64 * conds * 2.2e-16), t + ' eval_inv_dot scaled'), t + ' eval_inv_dot scaled')
+        assert within(rel_err(k.eval_inv_dot(par, x, scaling=False), g[t + '_iK']), capped(max(1e-13, 64 * cond * 2.2e-16), t + ' eval_inv_dot'), t + ' eval_inv_dot')
         assert np.array_equal(k.eval_inv_dot(par, x, scaling=False), tf.model.iK)      # the inverse the weights were made with
         assert within(rel_err(k.eval_inv_dot(par, x, g[t + '_b'], scaling=False), g[t + '_iKb']),
-                      max(1e-13, 64 * cond * 2.2e-16), t + ' eval_inv_dot rhs')
+                      capped(max(1e-13, 64 * cond * 2.2e-16), t + ' eval_inv_dot rhs'), t + ' eval_inv_dot rhs')
         with pytest.raises(ValueError):
             k.eval_inv_dot(par, x, np.ones((x.shape[1], 2)))
         par2 = g[t + '_par2']
@@ -428,8 +431,10 @@ def test_rbf_kernel_methods_golden(amd, golden, case):
         assert rel_err(k.exp_x_kx(par, x, scaling=True), g[t + '_qs']) < 1e-13
         tol2 = max(1e-10, 8 * conds ** 2 * 2.2e-16)
         emv = float(g[t + '_emv_call'])
-        assert within(abs(tf.model.exp_model_variance(par) - emv) / max(1.0, abs(emv)), tol2, t + ' exp_model_variance(par)')
-        assert abs(tf.model.integral_variance(par) - float(g[t + '_ivar_call'])) < max(1e-10, 8 * cond ** 2 * 2.2e-16)
+        assert within(abs(tf.model.exp_model_variance(par) - emv) / max(1.0, abs(emv)),
+                      capped(tol2, t + ' exp_model_variance(par)'), t + ' exp_model_variance(par)')
+        assert within(abs(tf.model.integral_variance(par) - float(g[t + '_ivar_call'])),
+                      capped(max(1e-10, 8 * cond ** 2 * 2.2e-16), t + ' integral_variance(par)'), t + ' integral_variance(par)')
 
 
 def test_gp_weights_scaling_invariance(amd):
@@ -1397,6 +1402,38 @@ def test_bsq_d10(amd, golden):
             assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=(tag, i))
 
 
+@pytest.mark.parametrize('tag,pstr,ppar,B', [('d10_fs5_td2', 'fs', {'degree': 5}, 10000), ('d10_ut', 'ut', None, 100000)])
+def test_bsq_d10_full_batch(amd, golden, tag, pstr, ppar, B):
+    """BASELINE configs[4] at the sizes bench.py times (SURVEY 8d's restatement: Bayes-Sard, D = E = 10, fully-symmetric
+    degree-5 rule N = 201 at B = 1e4 - evaluation pass + matrix-core GEMM with the covariance epilogue - and the unisolvent
+    unscented set N = 21 at B = 1e5 on k_apply_tile), device integrand, the reference's weights injected: 200 sampled
+    trajectories against the oracle, exact symmetry, batch-permutation invariance bit for bit, status all zero."""
+    from ssmtoybox_amd import ssmod as sm
+    g = golden('g2_bs_weights')
+    t = 'bs_' + tag
+    rng = np.random.default_rng(77)
+    means = rng.standard_normal((B, 10))
+    a = rng.standard_normal((B, 10, 10)) / np.sqrt(10)
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(10)
+    tf = amd.BayesSardTransform(10, 10, gp_par(10, 3.0), g[t + '_mi'], pstr, ppar)
+    w = dict(wm=g[t + '_wm'], Wc=g[t + '_Wc'], Wcc=g[t + '_Wcc'], model_var=float(g[t + '_mv']))
+    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
+    f = sm.Smooth10DTransition().dyn_eval
+    assert tf.kernel_name(f) == ('k_apply_tile' if pstr == 'ut' else 'k_apply_wide')       # (wide = the matrix-core route's name)
+    mf, cf, cfx, st = tf.apply_batch(f, means, covs, 0.0, return_status=True)
+    assert not st.any() and np.all(np.isfinite(mf)) and np.all(np.isfinite(cf)) and np.all(np.isfinite(cfx))
+    assert np.array_equal(cf, cf.transpose(0, 2, 1))
+    pts = g[t + '_pts']
+    worst = 0.0
+    for i in np.random.default_rng(78).choice(B, 200, replace=False):
+        ref = orc.apply_bq(orc.F_SMOOTH10D_DYN, means[i], covs[i], 0.0, pts, w)
+        worst = max(worst, assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=(tag, i)))
+    assert within(worst, 1e-10, 'configs[4] {} B={} device transform vs oracle (200 samples, scaled)'.format(tag, B))
+    perm = np.random.default_rng(79).permutation(B)[:2048]
+    mf2, cf2, cfx2 = tf.apply_batch(f, means[perm], covs[perm], 0.0)
+    assert np.array_equal(mf2, mf[perm]) and np.array_equal(cf2, cf[perm]) and np.array_equal(cfx2, cfx[perm])
+
+
 @pytest.mark.parametrize('N,E,B', [(201, 10, 64), (201, 7, 37), (120, 5, 60), (250, 3, 100), (201, 10, 2500)])
 def test_matrix_core_route_exact_on_integers(amd, monkeypatch, N, E, B):
     """fx Wc through v_mfma_f64_16x16x4_f64 (ssmq_gemm_mfma.hip): with small-integer operands every product and sum
@@ -1856,8 +1893,9 @@ def test_theta_batched_weights_large(amd):
     for i in (0, 100, 511):
         ref = orc.gp_weights(pars[i], pts)
         cond = np.linalg.cond(orc.rbf_eval(pars[i], pts, scaling=False) + 1e-8 * np.eye(7))
-        assert rel_err(w['wm'][i], ref['wm']) < max(1e-10, 64 * cond * 2.2e-16)
-        assert rel_err(w['Wc'][i], ref['Wc']) < max(1e-10, 8 * cond ** 2 * 2.2e-16)
+        for key, bar in (('wm', max(1e-10, 64 * cond * 2.2e-16)), ('Wc', max(1e-10, 8 * cond ** 2 * 2.2e-16))):
+            what = 'theta-batched weights row {} {} vs oracle'.format(i, key)
+            assert within(rel_err(w[key][i], ref[key]), capped(bar, what), what)
 
 
 def test_launch_loop_graph_follows_weight_updates(amd, golden, monkeypatch):
@@ -2179,8 +2217,78 @@ def test_config3_reentry_filters_1e5(amd):
     assert within(mean_err(fm[:, :, :2000][:, :, good], cfm.transpose(2, 1, 0)[:, :, good]), 1e-2,
                   'configs[2] BSQKF 5-D fm vs oracle (row-scaled)')
     _compare_filter_prefix(fm[:, :, :2000], fP[:, :, :, :2000], bsq.status[:2000], cfm.transpose(2, 1, 0),
-                           cfP.transpose(2, 3, 1, 0), cst, T, 'configs[2] BSQKF 5-D', tol_m=0.2, tol_P=0.2)   # measured 4e-2 / 5e-2: the
-    # uncentred form's own noise level on this model (NumPy oracle vs the reference: 2.4e-2, tests/test_oracle_golden.py)
+                           cfP.transpose(2, 3, 1, 0), cst, T, 'configs[2] BSQKF 5-D', tol_m=0.1, tol_P=0.1)   # measured 4e-2 / 5e-2: the
+    # uncentred form's own noise level on this model - two fp64 evaluations cannot be closer.  What pins the device here is
+    # test_referee_reentry_bsqkf_device: against the EXACT recursion it is as close as the reference's own NumPy run.
+
+
+def _referee_no_worse(got, ref, what, factor=2.0, floor=1e-12):
+    """Per time step, pooled over the trajectories: the device's distance from the EXACT result against the reference's.
+    The root mean square over trajectories and entries is held to `factor`; the maximum over a few dozen trajectories
+    is itself a noisy statistic of two independent rounding-error samples and gets 1.5 x that."""
+    for key, f in (('m_rms', factor), ('P_rms', factor), ('m_max', 1.5 * factor), ('P_max', 1.5 * factor)):
+        ratio = float(np.max(got[key] / (ref[key] + floor)))
+        assert within(ratio, f, '{}: max over steps of |device - exact| / |reference - exact| ({})'.format(what, key))
+    # and over the whole run the two are equally good: mean ratio of the per-step rms errors
+    for key in ('m_rms', 'P_rms'):
+        assert within(float(np.mean(got[key] / (ref[key] + floor))), 1.25, '{}: mean over steps of the {} ratio'.format(what, key))
+
+
+def test_referee_reentry_bsqkf_device(amd, monkeypatch):
+    """BASELINE configs[2] with the filter that is stable on the reentry model, refereed in extended precision: the
+    reference's NumPy evaluation of this recursion is itself 1e-2 (covariance, entry-scaled) / 0.9 standard deviations
+    (mean) away from the exact result of its algorithm at step 1 (uncentred covariance, bq/bqmtran.py:199;
+    tests/test_referee.py) - so device-vs-reference differences of a few per cent say nothing.  What is asserted here:
+    at every step the device is no further from the EXACT moments (oracle/ssmq_referee.py, 40 digits, same fp64 weights
+    and measurements) than twice the reference's own distance - for the dense kernels and for the LDL' fast path."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    from tests import _referee as rf
+    g = rf.load()
+    xm, xP = rf.reentry_exact()
+    ref = rf.step_errors(g['rer_fm'], g['rer_fc'], xm, xP)
+    dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, g['rer_m0'], g['rer_P0']), sm.GaussRV(3, cov=g['rer_Q']))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=g['rer_R']), 5)
+    mi = np.hstack((np.zeros((5, 1)), np.eye(5), 2 * np.eye(5))).astype(int)
+    for fast in (True, False):
+        if fast:
+            monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)
+        else:
+            monkeypatch.setenv('SSMQ_NO_FASTPATH', '1')
+        alg = ssinf.BayesSardKalman(dyn, obs, np.array([[1.0, 1, 1, 1, 1, 1]]), np.array([[1.0, 0.9, 0.9, 1e4, 1e4, 1e4]]),
+                                    mi, mi, 'ut')
+        for tf, tag in ((alg.tf_dyn, 'rer_dyn'), (alg.tf_obs, 'rer_obs')):
+            tf.wm, tf.Wc, tf.Wcc = g[tag + '_wm'], g[tag + '_Wc'], g[tag + '_Wcc']       # the reference's weights
+            tf.model.model_var = g[tag + '_mv']
+        assert 'k_filter_fused<D=5,Y=2' in alg.kernel_name() and ('OPT=3' in alg.kernel_name()) == fast
+        fm, fP = alg.forward_pass_batch(g['rer_y'])
+        assert not alg.status.any()
+        got = rf.step_errors(fm, fP, xm, xP)
+        _referee_no_worse(got, ref, 'reentry BSQKF ' + ('LDL fast path' if fast else 'dense kernels'))
+    monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)
+
+
+def test_referee_ct_tpqkf_device(amd):
+    """BASELINE configs[3] refereed the same way: t-process Kalman filter, coordinated turn + four bearing sensors, heavy-tailed
+    measurement noise; all six steps (the verdict asked for steps 4-6, where the per-step bars against the C oracle are
+    widest)."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    from tests import _referee as rf
+    g = rf.load()
+    xm, xP = rf.ct_exact()
+    ref = rf.step_errors(g['ct_fm'], g['ct_fc'], xm, xP)
+    dyn = sm.CoordinatedTurnTransition(sm.GaussRV(5, g['ct_m0'], g['ct_P0']), sm.GaussRV(5, cov=g['ct_Q']), dt=float(g['ct_dt'][0]))
+    obs = sm.BearingMeasurement(sm.GaussRV(4, cov=g['ct_R']), 5, state_index=[0, 2], sensor_pos=g['ct_sensors'])
+    par = np.array([[1.0, 100, 100, 100, 100, 1]])
+    alg = ssinf.StudentProcessKalman(dyn, obs, par, par)
+    for tf, tag in ((alg.tf_dyn, 'ct_dyn'), (alg.tf_obs, 'ct_obs')):
+        tf.wm, tf.Wc, tf.Wcc = g[tag + '_wm'], g[tag + '_Wc'], g[tag + '_Wcc']
+        tf.model.iK = g[tag + '_iK']
+        tf.model.model_var = float(g[tag + '_mv'][0, 0])
+    assert 'k_filter_fused<D=5,Y=4' in alg.kernel_name()
+    fm, fP = alg.forward_pass_batch(g['ct_y'], raise_on_failure=False)
+    assert (alg.status == 0).mean() > 0.9
+    got = rf.step_errors(np.where(alg.status[None, None] == 0, fm, np.nan), fP, xm, xP)
+    _referee_no_worse(got, ref, 'coordinated-turn TPQKF', factor=3.0)
 
 
 def test_config4_tpq_ct_bearing_1e4(amd):
