@@ -144,7 +144,8 @@ class FilterBench:
             ell = 3.0
         elif workload == 'ct':
             # BASELINE configs[3]: coordinated-turn dynamics (5 states), four bearing sensors (tests/test_ssinf.py:66-82
-            # of the reference); data from the device simulator (Gaussian noise; the filter under test is the t-process one)
+            # of the reference); data from the device simulator with HEAVY-TAILED measurement noise: Student-t, 3 degrees
+            # of freedom, the covariance the filter is told (scale = (nu - 2) / nu R, research/tpq/tpq_ungm.py:60-63)
             m0 = np.array([1000, 300, 1000, 0, np.deg2rad(-3.0)])
             P0 = np.diag([100, 10, 100, 10, 0.1])
             dt, r1, r2 = 0.1, 0.1, 1.75e-4
@@ -155,7 +156,9 @@ class FilterBench:
             dyn = ssmod.CoordinatedTurnTransition(ssmod.GaussRV(5, m0, P0), ssmod.GaussRV(5, cov=Q), dt=dt)
             obs = ssmod.BearingMeasurement(ssmod.GaussRV(4, cov=10e-3 * np.eye(4)), 5, state_index=[0, 2],
                                            sensor_pos=sensors)
-            d_x, d_y, _ = ssmod.simulate_dev(dyn, obs, T, B, seed=seed)
+            sim_obs = ssmod.BearingMeasurement(ssmod.StudentRV(4, scale=(1.0 / 3.0) * 10e-3 * np.eye(4), dof=3.0), 5,
+                                               state_index=[0, 2], sensor_pos=sensors)
+            d_x, d_y, _ = ssmod.simulate_dev(dyn, sim_obs, T, B, seed=seed)
             self.x_true = d_x.download((T, 5, ld))[:, :, :B].transpose(1, 0, 2)
             y = d_y.download((T, 4, ld))[:, :, :B].transpose(1, 0, 2)
             d_x.free()

@@ -382,6 +382,34 @@ int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, 
                       double *d_y);
 
 /*
+ * The same with any of the reference's random variables for the initial state, the process noise and the measurement
+ * noise, and optionally the continuous-time dynamics:
+ *   SSMQ_RV_GAUSS    mean + chol z                                  GaussRV     utils.py:580-625
+ *   SSMQ_RV_STUDENT  mean + chol z / sqrt(u), u ~ Gamma(dof/2, 2/dof) StudentRV   utils.py:349-382, 628-674 (chol = factor
+ *                    of the SCALE matrix)
+ *   SSMQ_RV_MIXTURE  component k with probability alpha[k], then Gaussian (mean[k], chol[k])   utils.py:254-299,
+ *                    research/tpq/tpq_base.py:13-32; n_comp <= 8
+ * mean [n_comp][dim] (NULL = 0), chol [n_comp][dim*dim] lower factors, alpha [n_comp]: host arrays.
+ * continuous != 0: Euler-Maruyama of TransitionModel.simulate_continuous (ssmod.py:201-244) -
+ *   x[k] = x[k-1] + dt dyn_fcn_cont(x[k-1], (sqrt(dt)/dt) q[k-1], k-1), T = floor(duration / dt) columns, the initial
+ *   state not among them - for the models that define dyn_fcn_cont: SSMQ_F_REENTRY1D_DYN (ssmod.py:429-432),
+ *   SSMQ_F_REENTRY2D_DYN (:569-585), SSMQ_F_CTRS_DYN (:779-780); SSMQ_E_UNSUPPORTED otherwise (the reference's other models
+ *   return None there).  Measurements (f_obs) are taken of the returned columns, column k at time k + 1.
+ * Gamma variates: Marsaglia-Tsang on the same counter-based stream (attempt t of (trajectory, step, purpose) has its own
+ * counter), so every draw is a pure function of (seed, global trajectory index, step).
+ */
+enum ssmq_rv_kind { SSMQ_RV_GAUSS = 0, SSMQ_RV_STUDENT = 1, SSMQ_RV_MIXTURE = 2 };
+typedef struct ssmq_rv {
+    int32_t kind, dim, n_comp, reserved;
+    double dof;
+    const double *mean, *chol, *alpha;
+} ssmq_rv;
+int ssmq_simulate_rv_dev(const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, int D, int Y, const ssmq_rv *x0,
+                         const ssmq_rv *q, const ssmq_rv *r, const double *G, int dyn_additive, int obs_additive,
+                         int64_t B, int64_t ld, int T, int continuous, double dt, uint64_t seed, uint64_t traj_offset,
+                         double *d_x, double *d_y);
+
+/*
  * Error statistics of B filtered trajectories against the true states, summed over the Monte-Carlo axis on the device
  * (utils.py:18-38 squared_error, :41-64 mse_matrix, :123-148 neg_log_likelihood; aggregated per time step as
  * research/tpq/tpq_base.py:154-160 does).  d_x, d_fm [T][D][ld], d_fP [T][D*D][ld] (the filter's output buffers),

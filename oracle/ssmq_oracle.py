@@ -915,3 +915,126 @@ def simulate(fid_dyn, fid_obs, steps, B, x0_mean, x0_cov, q_mean, q_cov, r_mean,
         f = np.stack([integrand(fid_dyn, xa[:, b], k, p_dyn) for b in range(B)], axis=1)
         x = f + G.dot(q) if dyn_additive else f
     return np.stack(xs, axis=1), np.stack(ys, axis=1)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the simulators' other random variables and the continuous-time dynamics (restatement of ssmq_simulate.hip's generator;
+# the DISTRIBUTIONS are the reference's: utils.py:254-299 gauss_mixture, :349-382 multivariate_t; ssmod.py:201-244)
+# --------------------------------------------------------------------------------------------------------------
+RV_GAUSS, RV_STUDENT, RV_MIXTURE = 0, 1, 2
+
+
+def uniform_one(seed, traj, step, tag):
+    """One 53-bit uniform in (0, 1) per (global trajectory index, time step, tag): words 0 and 1 of the Philox block."""
+    traj = np.asarray(traj, dtype=np.uint64)
+    c = philox4x32_10([traj, traj >> np.uint64(32), np.full(traj.shape, step, dtype=np.uint64),
+                       np.full(traj.shape, tag, dtype=np.uint64)], [seed & 0xffffffff, (seed >> 32) & 0xffffffff])
+    return ((((c[0] >> np.uint64(5)) << np.uint64(26)) | (c[1] >> np.uint64(6))).astype(np.float64) + 0.5) / 2.0 ** 53
+
+
+def gamma_mt(seed, traj, step, base, shape):
+    """Gamma(shape, 1), shape >= 1, by Marsaglia-Tsang: attempt t takes its normal from tag base | (0x100 + t), its uniform
+    from base | (0x180 + t); at most 16 attempts."""
+    traj = np.asarray(traj, dtype=np.uint64)
+    d = shape - 1.0 / 3.0
+    c = 1.0 / np.sqrt(9.0 * d)
+    v = np.ones(traj.shape)
+    done = np.zeros(traj.shape, dtype=bool)
+    for t in range(16):
+        x, _ = normal_pair(seed, traj, step, base | (0x100 + t))
+        u = uniform_one(seed, traj, step, base | (0x180 + t))
+        w = 1.0 + c * x
+        cand = w * w * w
+        with np.errstate(invalid='ignore', divide='ignore'):
+            acc = (cand > 0.0) & (np.log(u) < 0.5 * x * x + d - d * cand + d * np.log(np.where(cand > 0, cand, 1.0)))
+        fall = np.where(np.abs(cand) > 0.0, np.abs(cand), 1.0)
+        v = np.where(done, v, np.where(acc, cand, fall))
+        done = done | acc
+        if done.all():
+            break
+    return d * v
+
+
+def sample_rv(rv, seed, traj, step, purpose):
+    """(dim, B) draws of a random variable given as dict(kind, mean (K, n), chol (K, n, n), alpha (K,), dof)."""
+    traj = np.asarray(traj, dtype=np.uint64)
+    mean, chol = np.atleast_2d(rv['mean']), np.asarray(rv['chol']).reshape(-1, rv['mean'].shape[-1], rv['mean'].shape[-1])
+    n, B = mean.shape[1], traj.size
+    comp = np.zeros(B, dtype=int)
+    if rv['kind'] == RV_MIXTURE:
+        u = uniform_one(seed, traj, step, (purpose << 16) | 0x200)
+        cum = np.cumsum(rv['alpha'])
+        comp = np.minimum((u[:, None] >= cum[None, :]).sum(axis=1), len(cum) - 1)
+    z = np.zeros((n, B))
+    for j in range(0, n, 2):
+        z0, z1 = normal_pair(seed, traj, step, (purpose << 16) | (j >> 1))
+        z[j] = z0
+        if j + 1 < n:
+            z[j + 1] = z1
+    scale = np.ones(B)
+    if rv['kind'] == RV_STUDENT:
+        g = gamma_mt(seed, traj, step, purpose << 16, 0.5 * rv['dof']) * (2.0 / rv['dof'])
+        scale = 1.0 / np.sqrt(g)
+    return mean[comp].T + np.einsum('bij,jb->ib', chol[comp], z) * scale
+
+
+def gauss_rv(mean, cov):
+    return dict(kind=RV_GAUSS, mean=np.atleast_2d(np.asarray(mean, dtype=float)), chol=np.linalg.cholesky(np.atleast_2d(cov))[None])
+
+
+def student_rv(mean, scale, dof):
+    return dict(kind=RV_STUDENT, mean=np.atleast_2d(np.asarray(mean, dtype=float)), chol=np.linalg.cholesky(np.atleast_2d(scale))[None],
+                dof=float(dof))
+
+
+def mixture_rv(means, covs, alphas):
+    a = np.asarray(alphas, dtype=float)
+    return dict(kind=RV_MIXTURE, mean=np.stack([np.atleast_1d(m) for m in means]).astype(float),
+                chol=np.stack([np.linalg.cholesky(np.atleast_2d(c)) for c in covs]), alpha=a / a.sum())
+
+
+def integrand_cont(fid, x, q):
+    """dx/dt of the models that define dyn_fcn_cont: reentry-1D ssmod.py:429-432, reentry-2D :569-585, CTRS :779-780."""
+    if fid == F_REENTRY1D_DYN:
+        gam = 1 / 6.096
+        return np.array([-x[1] + q[0], -np.exp(-gam * x[0]) * x[1] ** 2 * x[2] + q[1], q[2]])
+    if fid == F_REENTRY2D_DYN:
+        r0, h0, gm0, b0 = 6374.0, 13.406, 3.9860e5, -0.59783
+        b = b0 * np.exp(x[4])
+        rr, vv = np.sqrt(x[0] ** 2 + x[1] ** 2), np.sqrt(x[2] ** 2 + x[3] ** 2)
+        dr = b * np.exp((r0 - rr) / h0) * vv
+        gr = -gm0 / rr ** 3
+        return np.array([x[2], x[3], dr * x[2] + gr * x[0] + q[0], dr * x[3] + gr * x[1] + q[1], q[2]])
+    if fid == F_CTRS_DYN:
+        return np.array([x[2] * np.cos(x[3]), x[2] * np.sin(x[3]), 0 * x[0], x[4], 0 * x[0]])
+    raise ValueError(fid)
+
+
+def simulate_rv(fid_dyn, fid_obs, steps, B, x0, q, r, G=None, p_dyn=(), p_obs=(), dyn_additive=True, obs_additive=True,
+                state_index=None, seed=0, traj_offset=0, continuous_dt=None):
+    """`simulate` with arbitrary random variables (dicts as sample_rv takes them) and, with continuous_dt, the
+    Euler-Maruyama recursion of simulate_continuous (ssmod.py:201-244: the initial state is not among the columns)."""
+    D, dq = x0['mean'].shape[1], q['mean'].shape[1]
+    G = np.eye(D, dq) if G is None else G
+    traj = np.arange(B, dtype=np.uint64) + np.uint64(traj_offset)
+    x = sample_rv(x0, seed, traj, 0, 0)
+    xs, ys = [], []
+    for k in range(steps):
+        if continuous_dt is not None:
+            dt = continuous_dt
+            qk = (np.sqrt(dt) / dt) * sample_rv(q, seed, traj, k, 1)
+            x = x + dt * integrand_cont(fid_dyn, x, qk)
+        xs.append(x)
+        if fid_obs is not None:
+            rk = sample_rv(r, seed, traj, k, 2)
+            xa = x if obs_additive else np.vstack((x, rk))
+            sel = xa if state_index is None else xa[np.asarray(state_index)]
+            h = np.stack([integrand(fid_obs, sel[:, b], k + 1, p_obs) for b in range(B)], axis=1)
+            ys.append(h + rk if obs_additive else h)
+        if k + 1 == steps or continuous_dt is not None:
+            continue
+        qk = sample_rv(q, seed, traj, k, 1)
+        xa = x if dyn_additive else np.vstack((x, qk))
+        f = np.stack([integrand(fid_dyn, xa[:, b], k, p_dyn) for b in range(B)], axis=1)
+        x = f + G.dot(qk) if dyn_additive else f
+    return np.stack(xs, axis=1), (np.stack(ys, axis=1) if ys else None)

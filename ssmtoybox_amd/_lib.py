@@ -50,6 +50,14 @@ class Integrand(ctypes.Structure):
         return s
 
 
+class Rv(ctypes.Structure):
+    """struct ssmq_rv: a Gaussian / Student-t / Gaussian-mixture random variable for the device simulator."""
+    _fields_ = [('kind', ctypes.c_int32), ('dim', ctypes.c_int32), ('n_comp', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('dof', ctypes.c_double), ('mean', c_double_p), ('chol', c_double_p), ('alpha', c_double_p)]
+
+
+RV_GAUSS, RV_STUDENT, RV_MIXTURE = 0, 1, 2
+
 _PROTOTYPES = {
     # name: (restype, argtypes)
     'ssmq_version': (ctypes.c_int, []),
@@ -143,6 +151,11 @@ _PROTOTYPES = {
                                          ctypes.c_int64, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
                                          c_double_p, c_double_p, c_double_p, ctypes.c_uint64, ctypes.c_uint64,
                                          ctypes.c_void_p, ctypes.c_void_p]),
+    'ssmq_simulate_rv_dev': (ctypes.c_int, [ctypes.POINTER(Integrand), ctypes.POINTER(Integrand), ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(Rv), ctypes.POINTER(Rv), ctypes.POINTER(Rv), c_double_p,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64,
+                                            ctypes.c_void_p, ctypes.c_void_p]),
     'ssmq_error_sums_width': (ctypes.c_int, [ctypes.c_int]),
     'ssmq_error_sums_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p]),

@@ -1755,31 +1755,40 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     return first;
 }
 
-namespace ssmq {
-int launch_simulate(int mode, int D, int Y, int dq, int dr, int dyn_additive, int obs_additive, int T, int64_t B,
-                    int64_t ld, uint64_t seed, uint64_t traj_offset, const ssmq_integrand *f_dyn,
-                    const ssmq_integrand *f_obs, const double *d_consts, double *d_x, double *d_y, hipStream_t s);
-}
-
-extern "C" int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, int D, int Y, int dq, int dr,
-                                 int dyn_additive, int obs_additive, int64_t B, int64_t ld, int T,
-                                 const double *x0_mean, const double *x0_chol, const double *q_mean,
-                                 const double *q_chol, const double *G, const double *r_mean, const double *r_chol,
-                                 uint64_t seed, uint64_t traj_offset, double *d_x, double *d_y) {
+extern "C" int ssmq_simulate_rv_dev(const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, int D, int Y, const ssmq_rv *x0,
+                                    const ssmq_rv *q, const ssmq_rv *r, const double *G, int dyn_additive, int obs_additive,
+                                    int64_t B, int64_t ld, int T, int continuous, double dt, uint64_t seed,
+                                    uint64_t traj_offset, double *d_x, double *d_y) {
     const int mode = (f_dyn ? 1 : 0) | (f_obs ? 2 : 0);
-    if (!mode || D < 1 || D > SSMQ_MAX_DIM || B < 0 || ld < B || T < 0 || !d_x || (f_dyn && (!x0_mean || !x0_chol || !q_chol ||
-        dq < 1 || dq > SSMQ_MAX_DIM)) || (f_obs && (!r_chol || !d_y || Y < 1 || Y > SSMQ_MAX_DIM || dr < 1 || dr > SSMQ_MAX_DIM))) {
+    auto rv_ok = [](const ssmq_rv *v, int dim) {
+        return v && v->dim == dim && v->chol && v->kind >= SSMQ_RV_GAUSS && v->kind <= SSMQ_RV_MIXTURE &&
+               (v->kind != SSMQ_RV_STUDENT || v->dof > 2.0) &&
+               (v->kind == SSMQ_RV_MIXTURE ? (v->n_comp >= 1 && v->n_comp <= 8 && v->alpha) : v->n_comp <= 1);
+    };
+    int dq = (f_dyn && q) ? q->dim : 0, dr = (f_obs && r) ? r->dim : 0;
+    if (!mode || D < 1 || D > SSMQ_MAX_DIM || B < 0 || ld < B || T < 0 || !d_x ||
+        (f_dyn && (!rv_ok(x0, D) || dq < 1 || dq > SSMQ_MAX_DIM || !rv_ok(q, dq))) ||
+        (f_obs && (!d_y || Y < 1 || Y > SSMQ_MAX_DIM || dr < 1 || dr > SSMQ_MAX_DIM || !rv_ok(r, dr))) ||
+        (continuous && (!f_dyn || !(dt > 0.0)))) {
         set_error("simulate: bad argument");
         return SSMQ_E_ARG;
     }
-    if (!f_dyn) dq = 0;
-    if (!f_obs) { dr = 0; Y = 0; }
+    if (!f_obs) Y = 0;
     FInfo fid, fio;
     if (f_dyn) {
         const int in_dyn = D + (dyn_additive ? 0 : dq);
-        if (!integrand_info(f_dyn->id, &fid) || fid.din > in_dyn || fid.dout != D || in_dyn > kMaxIntegrandIn ||
-            f_dyn->n_idx != 0) {
+        if (!integrand_info(f_dyn->id, &fid) || fid.dout != D || f_dyn->n_idx != 0 ||
+            (!continuous && (fid.din > in_dyn || in_dyn > kMaxIntegrandIn))) {
             set_error("simulate: transition integrand / dimension mismatch (state + noise inputs: at most 16)");
+            return SSMQ_E_ARG;
+        }
+        if (continuous && !has_continuous_dynamics(f_dyn->id)) {
+            set_error("simulate: this model has no continuous-time dynamics (dyn_fcn_cont is defined for the reentry-1D, "
+                      "reentry-2D and constant-turn-rate-and-speed models only, ssmod.py:429-432, 569-585, 779-780)");
+            return SSMQ_E_UNSUPPORTED;
+        }
+        if (continuous && dq < (f_dyn->id == SSMQ_F_CTRS_DYN ? 1 : 3)) {
+            set_error("simulate: the continuous-time dynamics read three noise components");
             return SSMQ_E_ARG;
         }
     }
@@ -1799,28 +1808,57 @@ extern "C" int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integra
     int rc = ensure_device();
     if (rc) return rc;
     if (B == 0 || T == 0) return SSMQ_OK;
+    SimLaunch h;
+    memset(&h, 0, sizeof(h));
     std::vector<double> hc;
-    auto put = [&](const double *p, size_t n, int eye_cols = 0) {
-        for (size_t i = 0; i < n; ++i)
-            hc.push_back(p ? p[i] : (eye_cols && (int)(i / eye_cols) == (int)(i % eye_cols) ? 1.0 : 0.0));
+    auto put_rv = [&](const ssmq_rv *v, SimRv *out) {
+        out->off = (int)hc.size();
+        if (!v) {
+            out->kind = SSMQ_RV_GAUSS; out->dim = 0; out->ncomp = 1; out->dof = 0.0;
+            hc.push_back(1.0);
+            return;
+        }
+        const int nc = v->kind == SSMQ_RV_MIXTURE ? v->n_comp : 1, n = v->dim;
+        out->kind = v->kind; out->dim = n; out->ncomp = nc; out->dof = v->dof;
+        for (int k = 0; k < nc; ++k) hc.push_back(v->kind == SSMQ_RV_MIXTURE ? v->alpha[k] : 1.0);
+        for (int i = 0; i < nc * n; ++i) hc.push_back(v->mean ? v->mean[i] : 0.0);
+        for (int i = 0; i < nc * n * n; ++i) hc.push_back(v->chol[i]);
     };
-    put(f_dyn ? x0_mean : nullptr, D);
-    put(f_dyn ? x0_chol : nullptr, (size_t)D * D);
-    put(q_mean, dq);
-    put(q_chol, (size_t)dq * dq);
-    put(G, (size_t)D * dq, dq);     // default noise gain eye(D, dq)  (ssmod.py:52)
-    put(r_mean, dr);
-    put(r_chol, (size_t)dr * dr);
+    put_rv(f_dyn ? x0 : nullptr, &h.rv[0]);
+    put_rv(f_dyn ? q : nullptr, &h.rv[1]);
+    put_rv(f_obs ? r : nullptr, &h.rv[2]);
+    h.g_off = (int)hc.size();
+    for (int i = 0; i < D * dq; ++i)        // default noise gain eye(D, dq)  (ssmod.py:52)
+        hc.push_back(G ? G[i] : ((i / dq) == (i % dq) ? 1.0 : 0.0));
     DevBuf dc;
-    if ((rc = dc.alloc(sizeof(double) * hc.size()))) return rc;
+    if ((rc = dc.alloc(sizeof(double) * std::max<size_t>(hc.size(), 1)))) return rc;
     hipStream_t s = stream();
     SSMQ_HIP(hipMemcpyAsync(dc.p, hc.data(), sizeof(double) * hc.size(), hipMemcpyHostToDevice, s));
-    rc = launch_simulate(mode, D, Y, dq, dr, dyn_additive, obs_additive, T, B, ld, seed, traj_offset, f_dyn, f_obs, dc.d(),
-                         d_x, d_y, s);
+    h.mode = mode; h.D = D; h.Y = Y; h.dq = dq; h.dr = dr; h.dyn_additive = dyn_additive; h.obs_additive = obs_additive; h.T = T;
+    h.continuous = continuous ? 1 : 0; h.dt = dt; h.B = B; h.ld = ld; h.seed = seed; h.traj_offset = traj_offset;
+    h.f_dyn = f_dyn; h.f_obs = f_obs; h.d_consts = dc.d(); h.d_x = d_x; h.d_y = d_y;
+    rc = launch_simulate(h, s);
     hipError_t e = hipStreamSynchronize(s);
     if (rc) return rc;
     SSMQ_HIP(e);
     return SSMQ_OK;
+}
+
+// the Gaussian case with plain arrays (the round-1 entry point)
+extern "C" int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, int D, int Y, int dq, int dr,
+                                 int dyn_additive, int obs_additive, int64_t B, int64_t ld, int T,
+                                 const double *x0_mean, const double *x0_chol, const double *q_mean,
+                                 const double *q_chol, const double *G, const double *r_mean, const double *r_chol,
+                                 uint64_t seed, uint64_t traj_offset, double *d_x, double *d_y) {
+    ssmq_rv x0{SSMQ_RV_GAUSS, D, 1, 0, 0.0, x0_mean, x0_chol, nullptr};
+    ssmq_rv q{SSMQ_RV_GAUSS, dq, 1, 0, 0.0, q_mean, q_chol, nullptr};
+    ssmq_rv r{SSMQ_RV_GAUSS, dr, 1, 0, 0.0, r_mean, r_chol, nullptr};
+    if (f_dyn && (!x0_mean || !x0_chol || !q_chol)) {
+        set_error("simulate: bad argument");
+        return SSMQ_E_ARG;
+    }
+    return ssmq_simulate_rv_dev(f_dyn, f_obs, D, Y, &x0, &q, &r, G, dyn_additive, obs_additive, B, ld, T, 0, 0.0, seed,
+                                traj_offset, d_x, d_y);
 }
 
 extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,

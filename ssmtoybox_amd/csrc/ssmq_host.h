@@ -60,6 +60,24 @@ int launch_fxwc_cov_mfma(int NP, const double *A, const double *X, int64_t M, in
                          int64_t bs, int64_t bs_fx, hipStream_t s);
 int launch_row_means(const double *A, const double *wm, int64_t M, int lda, int N, double *mean_rows, hipStream_t s);
 
+// trajectory / measurement simulator (ssmq_simulate.hip)
+struct SimRv {
+    int kind, dim, ncomp, off;      // off: doubles into the constants block (alpha | mean | chol)
+    double dof;
+};
+struct SimLaunch {
+    int mode, D, Y, dq, dr, dyn_additive, obs_additive, T, continuous, g_off;
+    double dt;
+    int64_t B, ld;
+    uint64_t seed, traj_offset;
+    SimRv rv[3];                    // initial state, process noise, measurement noise
+    const ssmq_integrand *f_dyn, *f_obs;
+    const double *d_consts;
+    double *d_x, *d_y;
+};
+int launch_simulate(const SimLaunch &h, hipStream_t s);
+bool has_continuous_dynamics(int fid);
+
 // measurement update (ssmq_filter.hip)
 int launch_kalman_update(int D, int Y, int64_t B, int64_t ld, const double *m_pr, const double *P_pr,
                          const double *y_mean, const double *P_y, const double *P_yx, const double *y, double *m_fi,

@@ -5,9 +5,9 @@ to its device integrand (include/ssmq.h `enum ssmq_integrand_id`) so that a mome
 
 Only what the moment-transform path needs is here: dimensions, noise additivity, noise gain, the integrand descriptor and
 a NumPy evaluation of the same formula for callers that want function values on the host (it is never used by
-`apply()`).  `simulate_discrete` / `simulate_measurements` (ssmod.py:168-199, 1011-1039) run on the device
-(`ssmq_simulate_dev`: counter-based Philox generator, so results match the reference's np.random streams only
-statistically); Jacobians and the Student / mixture random variables' samplers stay in the reference.
+`apply()`).  `simulate_discrete` / `simulate_continuous` / `simulate_measurements` (ssmod.py:168-244, 1011-1039) run on
+the device (`ssmq_simulate_rv_dev`: counter-based Philox generator, so results match the reference's np.random streams
+only statistically) for Gaussian, Student-t and Gaussian-mixture random variables; Jacobians stay in the reference.
 """
 import ctypes
 
@@ -18,7 +18,8 @@ from ._lib import Integrand
 
 
 class GaussRV:
-    """Mean / covariance carrier with the reference's `get_stats()` protocol (utils.py:580-625); no sampling."""
+    """Mean / covariance carrier with the reference's `get_stats()` protocol (utils.py:580-625); sampling happens on the
+    device inside the simulators."""
 
     def __init__(self, dim, mean=None, cov=None):
         self.dim = dim
@@ -42,11 +43,27 @@ class StudentRV:
         return self.mean, self.scale, self.dof
 
 
-def _gauss_stats(rv, what):
-    """Mean and lower Cholesky factor of a Gaussian random variable (the device simulator draws mean + L z)."""
-    if not isinstance(rv, GaussRV):
-        raise NotImplementedError('device simulation needs a GaussRV for ' + what)
-    cov = np.atleast_2d(np.asarray(rv.cov, dtype=np.float64))
+class GaussianMixtureRV:
+    """Gaussian mixture (research/tpq/tpq_base.py:13-32, sampled by utils.gauss_mixture utils.py:254-299): tuples of
+    means and covariances, mixing proportions `alphas`."""
+
+    def __init__(self, dim, means=None, covs=None, alphas=None):
+        if covs is None or alphas is None or len(covs) != len(alphas):
+            raise ValueError('Same number of means, covariances and mixture weights needs to be supplied!')
+        self.dim = dim
+        self.covs = tuple(np.atleast_2d(np.asarray(c, dtype=float)) for c in covs)
+        self.means = tuple(np.zeros(dim) for _ in covs) if means is None else tuple(
+            np.atleast_1d(np.asarray(m, dtype=float)) for m in means)
+        if len(self.means) != len(self.covs):
+            raise ValueError('Same number of means, covariances and mixture weights needs to be supplied!')
+        self.alphas = np.asarray(alphas, dtype=float)
+
+    def get_stats(self):
+        return self.means, self.covs, self.alphas
+
+
+def _lower_factor(cov):
+    cov = np.atleast_2d(np.asarray(cov, dtype=np.float64))
     try:
         L = np.linalg.cholesky(cov)
     except np.linalg.LinAlgError:
@@ -56,29 +73,65 @@ def _gauss_stats(rv, what):
             raise
         A = V * np.sqrt(np.clip(lam, 0.0, None))
         L = np.linalg.qr(A.T)[1].T
-    return np.ascontiguousarray(rv.mean, dtype=np.float64), np.ascontiguousarray(L)
+    return np.ascontiguousarray(L)
 
 
-def simulate_dev(dyn, obs, steps, mc_sims, seed=0, traj_offset=0):
+def _gauss_stats(rv, what):
+    """Mean and lower Cholesky factor of a Gaussian random variable (the device simulator draws mean + L z)."""
+    if not isinstance(rv, GaussRV):
+        raise NotImplementedError('a GaussRV is needed for ' + what)
+    return np.ascontiguousarray(rv.mean, dtype=np.float64), _lower_factor(rv.cov)
+
+
+def _rv_desc(rv, what):
+    """struct ssmq_rv for one of the reference's random variables (+ the arrays it points to, to be kept alive)."""
+    p = lambda a: a.ctypes.data_as(_lib.c_double_p)
+    d = _lib.Rv()
+    if isinstance(rv, GaussRV):
+        mean, chol = np.ascontiguousarray(rv.mean, dtype=np.float64), _lower_factor(rv.cov)
+        d.kind, d.dim, d.n_comp, d.dof, alpha = _lib.RV_GAUSS, mean.size, 1, 0.0, None
+    elif isinstance(rv, StudentRV):
+        mean, chol = np.ascontiguousarray(rv.mean, dtype=np.float64), _lower_factor(rv.scale)
+        d.kind, d.dim, d.n_comp, d.dof, alpha = _lib.RV_STUDENT, mean.size, 1, float(rv.dof), None
+    elif isinstance(rv, GaussianMixtureRV):
+        mean = np.ascontiguousarray(np.stack(rv.means), dtype=np.float64)
+        chol = np.ascontiguousarray(np.stack([_lower_factor(c) for c in rv.covs]))
+        alpha = np.ascontiguousarray(rv.alphas / rv.alphas.sum(), dtype=np.float64)
+        d.kind, d.dim, d.n_comp, d.dof = _lib.RV_MIXTURE, rv.dim, len(rv.covs), 0.0
+    else:
+        raise NotImplementedError('{}: GaussRV, StudentRV or GaussianMixtureRV expected'.format(what))
+    d.mean, d.chol = p(mean), p(chol)
+    d.alpha = p(alpha) if alpha is not None else None
+    return d, (mean, chol, alpha)
+
+
+def simulate_dev(dyn, obs, steps, mc_sims, seed=0, traj_offset=0, continuous_dt=None):
     """States and measurements of `mc_sims` trajectories generated on the device, left there in the filter's layout:
     returns (d_x, d_y, ld) with d_x planes [steps][D][ld], d_y [steps][Y][ld] (DeviceBuffers; caller frees).
-    x[0] ~ init_rv, x[k] = dyn_fcn(x[k-1], q[k-1], k-1), y[k] = meas_fcn(x[k], r[k], k+1) (ssmod.py:168-199, 1011-1039).
-    Trajectory b uses the random stream of global index traj_offset + b."""
+    x[0] ~ init_rv, x[k] = dyn_fcn(x[k-1], q[k-1], k-1), y[k] = meas_fcn(x[k], r[k], k+1) (ssmod.py:168-199, 1011-1039);
+    with `continuous_dt` the states are the Euler-Maruyama steps of dyn_fcn_cont instead (ssmod.py:201-244).
+    Trajectory b uses the random stream of global index traj_offset + b.  obs = None: states only (d_y is None)."""
     lib = _lib.load()
-    D, Y = dyn.dim_state, obs.dim_out
+    D = dyn.dim_state
+    Y = obs.dim_out if obs is not None else 0
     ld = (mc_sims + 63) // 64 * 64
-    m0, L0 = _gauss_stats(dyn.init_rv, 'the initial state')
-    qm, Lq = _gauss_stats(dyn.noise_rv, 'the process noise')
-    rm, Lr = _gauss_stats(obs.noise_rv, 'the measurement noise')
+    x0, k0 = _rv_desc(dyn.init_rv, 'the initial state')
+    q, k1 = _rv_desc(dyn.noise_rv, 'the process noise')
     G = np.ascontiguousarray(dyn.noise_gain, dtype=np.float64)
     f_dyn, _ = dyn.device_integrand()
-    f_obs, _ = obs.device_integrand()
-    d_x, d_y = _lib.DeviceBuffer(8 * steps * D * ld), _lib.DeviceBuffer(8 * steps * Y * ld)
-    p = lambda a: a.ctypes.data_as(_lib.c_double_p)
-    _lib.check(lib.ssmq_simulate_dev(ctypes.byref(f_dyn), ctypes.byref(f_obs), D, Y, qm.size, rm.size,
-                                     1 if dyn.noise_additive else 0, 1 if obs.noise_additive else 0, mc_sims, ld, steps,
-                                     p(m0), p(L0), p(qm), p(Lq), p(G), p(rm), p(Lr), seed, traj_offset,
-                                     ctypes.c_void_p(d_x.ptr), ctypes.c_void_p(d_y.ptr)), 'ssmq_simulate_dev')
+    d_x = _lib.DeviceBuffer(8 * steps * D * ld)
+    d_y = f_obs = r = None
+    if obs is not None:
+        r, k2 = _rv_desc(obs.noise_rv, 'the measurement noise')
+        f_obs, _ = obs.device_integrand()
+        d_y = _lib.DeviceBuffer(8 * steps * Y * ld)
+    _lib.check(lib.ssmq_simulate_rv_dev(ctypes.byref(f_dyn), ctypes.byref(f_obs) if obs is not None else None, D, Y,
+                                        ctypes.byref(x0), ctypes.byref(q), ctypes.byref(r) if obs is not None else None,
+                                        G.ctypes.data_as(_lib.c_double_p), 1 if dyn.noise_additive else 0,
+                                        1 if (obs is None or obs.noise_additive) else 0, mc_sims, ld, steps,
+                                        0 if continuous_dt is None else 1, 0.0 if continuous_dt is None else float(continuous_dt),
+                                        seed, traj_offset, ctypes.c_void_p(d_x.ptr),
+                                        ctypes.c_void_p(d_y.ptr) if d_y is not None else None), 'ssmq_simulate_rv_dev')
     return d_x, d_y, ld
 
 
@@ -108,19 +161,22 @@ class TransitionModel:
     def simulate_discrete(self, steps, mc_sims=1, seed=0, traj_offset=0):
         """(dim_state, steps, mc_sims) state trajectories (ssmod.py:168-199), generated on the device.  The reference
         draws from the global np.random state; here the stream is named by `seed` (and the trajectory's global index)."""
-        lib = _lib.load()
-        D = self.dim_state
-        ld = (mc_sims + 63) // 64 * 64
-        m0, L0 = _gauss_stats(self.init_rv, 'the initial state')
-        qm, Lq = _gauss_stats(self.noise_rv, 'the process noise')
-        G = np.ascontiguousarray(self.noise_gain, dtype=np.float64)
-        f_dyn, _ = self.device_integrand()
-        d_x = _lib.DeviceBuffer(8 * steps * D * ld)
-        p = lambda a: a.ctypes.data_as(_lib.c_double_p)
-        _lib.check(lib.ssmq_simulate_dev(ctypes.byref(f_dyn), None, D, 0, qm.size, 0, 1 if self.noise_additive else 0, 1,
-                                         mc_sims, ld, steps, p(m0), p(L0), p(qm), p(Lq), p(G), None, None, seed,
-                                         traj_offset, ctypes.c_void_p(d_x.ptr), None), 'ssmq_simulate_dev')
-        x = d_x.download((steps, D, ld))[:, :, :mc_sims].transpose(1, 0, 2)
+        d_x, _, ld = simulate_dev(self, None, steps, mc_sims, seed, traj_offset)
+        x = d_x.download((steps, self.dim_state, ld))[:, :, :mc_sims].transpose(1, 0, 2)
+        d_x.free()
+        return np.ascontiguousarray(x)
+
+    def dyn_fcn_cont(self, x, q, time):
+        """Continuous-time dynamics dx/dt (ssmod.py:81-104): defined by the reentry and constant-turn-rate models only."""
+        return None
+
+    def simulate_continuous(self, duration, dt=0.1, mc_sims=1, seed=0, traj_offset=0):
+        """(dim_state, floor(duration / dt), mc_sims) Euler-Maruyama trajectories of the continuous-time dynamics
+        (ssmod.py:201-244: x[k] = x[k-1] + dt dyn_fcn_cont(x[k-1], (sqrt(dt) / dt) q[k-1], k-1), the initial state is
+        not returned), generated on the device."""
+        steps = int(np.floor(duration / dt))
+        d_x, _, ld = simulate_dev(self, None, steps, mc_sims, seed, traj_offset, continuous_dt=dt)
+        x = d_x.download((steps, self.dim_state, ld))[:, :, :mc_sims].transpose(1, 0, 2)
         d_x.free()
         return np.ascontiguousarray(x)
 
@@ -181,6 +237,10 @@ class ReentryVehicle1DTransition(TransitionModel):
         return np.array([x[0] - self.dt * x[1] + q[0],
                          x[1] - self.dt * np.exp(-self.Gamma * x[0]) * x[1] ** 2 * x[2] + q[1], x[2] + q[2]])
 
+    def dyn_fcn_cont(self, x, q, time):
+        """ssmod.py:429-432."""
+        return np.array([-x[1] + q[0], -np.exp(-self.Gamma * x[0]) * x[1] ** 2 * x[2] + q[1], q[2]])
+
 
 class ReentryVehicle2DTransition(TransitionModel):
     """ssmod.py:438-584 (5-D state [x, y, vx, vy, omega]; noise enters the last three states)."""
@@ -205,6 +265,15 @@ class ReentryVehicle2DTransition(TransitionModel):
 
     def dyn_fcn(self, x, q, time):
         return np.array(self._core(x)) + self.noise_gain.dot(q)
+
+    def dyn_fcn_cont(self, x, q, time):
+        """ssmod.py:569-585."""
+        b = self.b0 * np.exp(x[4])
+        R = np.sqrt(x[0] ** 2 + x[1] ** 2)
+        V = np.sqrt(x[2] ** 2 + x[3] ** 2)
+        D = b * np.exp((self.R0 - R) / self.H0) * V
+        G = -self.Gm0 / R ** 3
+        return np.array([x[2], x[3], D * x[2] + G * x[0] + q[0], D * x[3] + G * x[1] + q[1], q[2]])
 
 
 class ReentryVehicle2DBiasTransition(ReentryVehicle2DTransition):
@@ -273,6 +342,10 @@ class ConstantTurnRateSpeed(TransitionModel):
                           dt * q[0], dt * x[3] + 0.5 * dt ** 2 * q[1], dt * q[1]])
         return x + f
 
+    def dyn_fcn_cont(self, x, q, time):
+        """ssmod.py:779-780."""
+        return np.array([x[2] * np.cos(x[3]), x[2] * np.sin(x[3]), 0, x[4], 0])
+
 
 class ConstantVelocity(TransitionModel):
     """ssmod.py:783-855."""
@@ -328,17 +401,15 @@ class MeasurementModel:
         D, steps, mc_sims = x.shape
         Y = self.dim_out
         ld = (mc_sims + 63) // 64 * 64
-        rm, Lr = _gauss_stats(self.noise_rv, 'the measurement noise')
+        r, keep = _rv_desc(self.noise_rv, 'the measurement noise')
         f_obs, _ = self.device_integrand()
         xb = np.zeros((steps, D, ld))
         xb[:, :, :mc_sims] = x.transpose(1, 0, 2)
         d_x, d_y = _lib.DeviceBuffer(xb.nbytes), _lib.DeviceBuffer(8 * steps * Y * ld)
         d_x.upload(xb)
-        p = lambda a: a.ctypes.data_as(_lib.c_double_p)
-        _lib.check(lib.ssmq_simulate_dev(None, ctypes.byref(f_obs), D, Y, 0, rm.size, 1, 1 if self.noise_additive else 0,
-                                         mc_sims, ld, steps, None, None, None, None, None, p(rm), p(Lr), seed,
-                                         traj_offset, ctypes.c_void_p(d_x.ptr), ctypes.c_void_p(d_y.ptr)),
-                   'ssmq_simulate_dev')
+        _lib.check(lib.ssmq_simulate_rv_dev(None, ctypes.byref(f_obs), D, Y, None, None, ctypes.byref(r), None, 1,
+                                            1 if self.noise_additive else 0, mc_sims, ld, steps, 0, 0.0, seed, traj_offset,
+                                            ctypes.c_void_p(d_x.ptr), ctypes.c_void_p(d_y.ptr)), 'ssmq_simulate_rv_dev')
         y = d_y.download((steps, Y, ld))[:, :, :mc_sims].transpose(1, 0, 2)
         d_x.free()
         d_y.free()

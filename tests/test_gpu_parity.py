@@ -1123,6 +1123,116 @@ def test_simulate_statistics_match_numpy_streams(amd):
     assert abs(e_dev - e_ref) < 0.1 * e_ref
 
 
+def _oracle_rv(rv):
+    from ssmtoybox_amd import ssmod as sm
+    if isinstance(rv, sm.StudentRV):
+        return orc.student_rv(rv.mean, rv.scale, rv.dof)
+    if isinstance(rv, sm.GaussianMixtureRV):
+        return orc.mixture_rv(rv.means, rv.covs, rv.alphas)
+    return orc.gauss_rv(rv.mean, rv.cov)
+
+
+def test_simulate_student_and_mixture_noise_match_restatement(amd):
+    """Student-t and Gaussian-mixture random variables in the simulators (utils.py:254-299, 349-382; StudentRV :628-674,
+    GaussianMixtureRV research/tpq/tpq_base.py:13-32) - the reference's heavy-tailed studies (research/tpq/tpq_ungm.py:40-66):
+    device draws against the oracle's restatement of the generator, shard invariance, and the two-call interface."""
+    from ssmtoybox_amd import ssmod as sm
+    nu = 4.0
+    cases = {
+        'student': (sm.UNGMTransition(sm.StudentRV(1, scale=(nu - 2) / nu * np.eye(1), dof=nu),
+                                      sm.StudentRV(1, scale=(nu - 2) / nu * 10 * np.eye(1), dof=nu)),
+                    sm.UNGMMeasurement(sm.StudentRV(1, scale=(nu - 2) / nu * np.eye(1), dof=nu), 1)),
+        'mixture': (sm.UNGMTransition(sm.GaussRV(1), sm.GaussianMixtureRV(1, covs=(10 * np.eye(1), 100 * np.eye(1)), alphas=(0.8, 0.2))),
+                    sm.UNGMMeasurement(sm.GaussianMixtureRV(1, means=(np.zeros(1), 0.5 * np.ones(1)),
+                                                            covs=(0.01 * np.eye(1), np.eye(1)), alphas=(0.9, 0.1)), 1)),
+    }
+    T, B, seed, off = 6, 200, 77, 4000000000
+    for name, (dyn, obs) in cases.items():
+        x, y = _download_sim(*sm.simulate_dev(dyn, obs, T, B, seed=seed, traj_offset=off), 1, 1, T, B)
+        ox, oy = orc.simulate_rv(orc.F_UNGM_DYN, orc.F_UNGM_MEAS, T, B, _oracle_rv(dyn.init_rv), _oracle_rv(dyn.noise_rv),
+                                 _oracle_rv(obs.noise_rv), seed=seed, traj_offset=off)
+        assert within(rel_err(x[:, 0], ox[:, 0]), 1e-12, 'simulate ' + name + ': initial draw vs generator restatement')
+        assert within(max(rel_err(x, ox), rel_err(y, oy)), 1e-8, 'simulate ' + name + ': 6 steps vs generator restatement')
+        h = 70
+        xa, ya = _download_sim(*sm.simulate_dev(dyn, obs, T, h, seed=seed, traj_offset=off), 1, 1, T, h)
+        xb, yb = _download_sim(*sm.simulate_dev(dyn, obs, T, B - h, seed=seed, traj_offset=off + h), 1, 1, T, B - h)
+        assert np.array_equal(np.concatenate((xa, xb), axis=2), x) and np.array_equal(np.concatenate((ya, yb), axis=2), y)
+        x2 = dyn.simulate_discrete(T, B, seed=seed, traj_offset=off)
+        assert np.array_equal(x2, x) and np.array_equal(obs.simulate_measurements(x2, seed=seed, traj_offset=off), y)
+
+
+def test_simulate_student_and_mixture_statistics(amd):
+    """Statistical parity with the reference's samplers (np.random.gamma / multivariate_normal / choice streams):
+    Student-t draws against the t distribution (Kolmogorov-Smirnov) and NumPy's multivariate_t recipe, mixture draws
+    against the component proportions and the mixture's moments, 2e5 draws each."""
+    from scipy import stats
+    from ssmtoybox_amd import ssmod as sm
+    B = 200000
+    nu, scale = 5.0, np.array([[2.0, 0.6], [0.6, 1.0]])
+    obs = sm.Radar2DMeasurement(sm.StudentRV(2, mean=np.array([1.0, -2.0]), scale=scale, dof=nu), 5)     # additive: y = h(x) + r
+    x = np.tile(np.array([6500.0, 350.0, -1.8, -6.8, 0.7])[:, None, None], (1, 1, B))
+    r = obs.simulate_measurements(x, seed=11)[:, 0] - np.array([np.hypot(6500.0, 350.0), np.arctan2(350.0, 6500.0)])[:, None]
+    L = np.linalg.cholesky(scale)
+    w = np.linalg.solve(L, r - np.array([[1.0], [-2.0]]))           # whitened: independent-looking t marginals
+    for i in range(2):
+        assert stats.kstest(w[i], 't', args=(nu,)).pvalue > 1e-3
+    rng = np.random.default_rng(5)
+    ref = (rng.multivariate_normal(np.zeros(2), scale, B) / np.sqrt(rng.gamma(nu / 2, 2 / nu, B))[:, None]).T   # utils.py:379-382
+    assert np.allclose(np.cov(r), np.cov(ref), rtol=0.1) and np.allclose(np.cov(r), scale * nu / (nu - 2), rtol=0.1)
+    assert abs(stats.kurtosis(w[0]) - stats.kurtosis(np.linalg.solve(L, ref)[0])) < 3.0          # heavy tails, both
+    assert stats.kurtosis(w[0]) > 2.0
+    # mixture: glint noise as in research/tpq/tpq_constant_velocity.py:33
+    alphas, covs = np.array([0.85, 0.15]), (0.01 * np.eye(1), 4.0 * np.eye(1))
+    obs = sm.UNGMMeasurement(sm.GaussianMixtureRV(1, covs=covs, alphas=alphas), 1)
+    r = obs.simulate_measurements(np.zeros((1, 1, B)), seed=12)[0, 0]
+    var = alphas[0] * 0.01 + alphas[1] * 4.0
+    assert abs(r.mean()) < 5 * np.sqrt(var / B) and abs(r.var() - var) < 0.03 * var
+    inner = np.mean(np.abs(r) < 0.3)            # within 3 sigma of the narrow component: ~ alpha_0 + alpha_1 P(|N(0,4)| < 0.3)
+    assert abs(inner - (alphas[0] * stats.norm.cdf(3) * 1 + alphas[0] * (stats.norm.cdf(3) - 1) +
+                        alphas[1] * (2 * stats.norm.cdf(0.15) - 1))) < 5e-3
+
+
+@pytest.mark.parametrize('name', ['reentry2d', 'reentry1d', 'ctrs'])
+def test_simulate_continuous(amd, name):
+    """TransitionModel.simulate_continuous (ssmod.py:201-244): Euler-Maruyama over dyn_fcn_cont for the three models that
+    define it, against the oracle's restatement with the same generator, against the model's own host dyn_fcn_cont driven by
+    the generator's noise (one-step residuals), and refused for the models whose dyn_fcn_cont is `pass` in the reference."""
+    from ssmtoybox_amd import ssmod as sm
+    if name == 'reentry2d':
+        m0 = np.array([6500.4, 349.14, -1.8093, -6.7967, 0.6932])
+        dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, m0, np.diag([1e-6, 1e-6, 1e-6, 1e-6, 1e-3])),
+                                            sm.GaussRV(3, cov=np.diag([2.4064e-5, 2.4064e-5, 1e-6])))
+        fid = orc.F_REENTRY2D_DYN
+    elif name == 'reentry1d':
+        dyn = sm.ReentryVehicle1DTransition(sm.GaussRV(3, np.array([90.0, 6.0, 1.5]), np.diag([0.0929, 1.4865, 1e-4])),
+                                            sm.GaussRV(3, cov=np.diag([1e-4, 1e-4, 1e-6])))
+        fid = orc.F_REENTRY1D_DYN
+    else:
+        dyn = sm.ConstantTurnRateSpeed(sm.GaussRV(5, np.array([0.0, 0.0, 10.0, 0.3, 0.05]), 0.01 * np.eye(5)),
+                                       sm.StudentRV(2, scale=0.1 * np.eye(2), dof=4.0))
+        fid = orc.F_CTRS_DYN
+    dt, duration, B, seed, off = 0.05, 2.0, 150, 5, 12345678901
+    x = dyn.simulate_continuous(duration, dt, B, seed=seed, traj_offset=off)
+    T = int(np.floor(duration / dt))
+    assert x.shape == (dyn.dim_state, T, B)
+    ox, _ = orc.simulate_rv(fid, None, T, B, _oracle_rv(dyn.init_rv), _oracle_rv(dyn.noise_rv), None, seed=seed, traj_offset=off,
+                            continuous_dt=dt)
+    assert within(rel_err(x, ox), 1e-9, 'simulate_continuous ' + name + ' vs generator restatement')
+    # one-step residuals with the model's own dyn_fcn_cont (host NumPy) and the generator's noise
+    traj = np.arange(B, dtype=np.uint64) + np.uint64(off)
+    for k in (1, 7, T - 1):
+        q = (np.sqrt(dt) / dt) * orc.sample_rv(_oracle_rv(dyn.noise_rv), seed, traj, k, 1)
+        step = np.stack([x[:, k - 1, b] + dt * dyn.dyn_fcn_cont(x[:, k - 1, b], q[:, b], k - 1) for b in range(B)], axis=1)
+        assert np.allclose(x[:, k], step, rtol=1e-12, atol=1e-12)
+    # measurements of a continuous trajectory, as research/gpq/gpq_tracking.py:144-146 takes them
+    if name == 'reentry2d':
+        obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=np.diag([1e-6, 0.17e-6])), 5)
+        y = obs.simulate_measurements(x, seed=seed, traj_offset=off)
+        assert y.shape == (2, T, B) and np.allclose(y[0], np.hypot(x[0], x[1]), atol=1e-2)
+    with pytest.raises(amd.SsmqError):
+        sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1)).simulate_continuous(1.0, 0.1, 4)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # error statistics reduced on the device (utils.py:18-148 aggregated as research/tpq/tpq_base.py:154-172)
 # ---------------------------------------------------------------------------------------------------------------
@@ -2291,6 +2401,11 @@ def test_referee_ct_tpqkf_device(amd):
     _referee_no_worse(got, ref, 'coordinated-turn TPQKF', factor=3.0)
 
 
+def stats_kurtosis(v):
+    v = np.asarray(v, dtype=float) - np.mean(v)
+    return float(np.mean(v ** 4) / np.mean(v ** 2) ** 2 - 3.0)
+
+
 def test_config4_tpq_ct_bearing_1e4(amd):
     """BASELINE configs[3]: Student-t process quadrature Kalman filter, 5-D coordinated-turn state, bearing sensors,
     1e4 MC runs (StudentProcessKalman builds its transforms with dim_out = 1: broadcast model variance)."""
@@ -2307,17 +2422,14 @@ def test_config4_tpq_ct_bearing_1e4(amd):
     Rn = 10e-3 * np.eye(4)
     dyn = sm.CoordinatedTurnTransition(sm.GaussRV(5, m0, P0), sm.GaussRV(5, cov=Q), dt=dt)
     obs = sm.BearingMeasurement(sm.GaussRV(4, cov=Rn), 5, state_index=[0, 2], sensor_pos=SENSORS)
-    # heavy-tailed synthetic measurements: true bearings of a noisy turn + Student-t (nu = 3) noise
-    x = m0[:, None] + np.linalg.cholesky(P0).dot(rng.standard_normal((5, B)))
-    y = np.zeros((4, T, B))
-    for k in range(T):
-        x = np.stack([dyn.dyn_fcn(x[:, i], np.zeros(5)) for i in range(0)] or [x[0]]) if False else x
-        om = x[4]
-        a, b_, c, d = np.sin(om * dt), np.cos(om * dt), np.sin(om * dt) / om, (1 - np.cos(om * dt)) / om
-        x = np.stack((x[0] + c * x[1] - d * x[3], b_ * x[1] - a * x[3], d * x[1] + x[2] + c * x[3], a * x[1] + b_ * x[3],
-                      x[4])) + np.linalg.cholesky(Q + 1e-12 * np.eye(5)).dot(rng.standard_normal((5, B)))
-        y[:, k] = np.arctan2(x[2][None] - SENSORS[:, 1:2], x[0][None] - SENSORS[:, 0:1]) + \
-            0.1 * rng.standard_t(3, size=(4, B))
+    # heavy-tailed synthetic measurements from the PRODUCT's simulator: true bearings of a noisy turn + Student-t (nu = 3)
+    # noise of scale 0.1 (the filter itself is told the Gaussian R above, as a mismatched-noise study would)
+    sim_obs = sm.BearingMeasurement(sm.StudentRV(4, scale=0.01 * np.eye(4), dof=3.0), 5, state_index=[0, 2], sensor_pos=SENSORS)
+    d_x, d_y, ld = sm.simulate_dev(dyn, sim_obs, T, B, seed=14)
+    y = d_y.download((T, 4, ld))[:, :, :B].transpose(1, 0, 2)
+    d_x.free()
+    d_y.free()
+    assert stats_kurtosis(y[0, 0] - np.median(y[0, 0])) > 3.0        # heavy tails are there
     par = np.array([[1.0, 100, 100, 100, 100, 1]])
     alg = ssinf.StudentProcessKalman(dyn, obs, par, par)
     assert 'k_filter_fused<D=5,Y=4' in alg.kernel_name()
