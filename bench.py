@@ -371,6 +371,65 @@ def measure_c5_unisolvent(amd, B=100000, iters=20):
             'note': 'compute-bound shape (~25k lane-operations for 2480 algorithmic bytes): see DESIGN.md 3.2'}
 
 
+def measure_c5_degree7(amd, B=10000, iters=5, with_cpu=True):
+    """BASELINE configs[4] AS WORDED: Bayes-Sard transform at D = E = 10 with a fully-symmetric rule of degree 7.  The
+    reference has degree 3 and 5 only (mtran.py:392); the rule is this build's own (1181 points, exact to degree 7:
+    tests/test_host.py) and therefore parity-unpinned - the ARITHMETIC on it is checked against the oracle with the
+    device's weights.  Route: evaluation pass, T = FX [Wc | Wcc'] by column blocks on the matrix cores, per-trajectory
+    rest (k_apply_big)."""
+    from ssmtoybox_amd import _lib, ssmod
+    from ssmtoybox_amd.bq.bqmod import n_sum_k
+    from oracle import ssmq_oracle as orc
+    D = 10
+    mi = np.hstack([n_sum_k(D, k) for k in range(3)])
+    t0 = time.perf_counter()
+    tf = amd.BayesSardTransform(D, D, np.array([[1.0] + [3.0] * D]), mi, 'fs', {'degree': 7})
+    t_weights = time.perf_counter() - t0
+    N = tf.wm.shape[0]
+    f = ssmod.Smooth10DTransition().dyn_eval
+    rng = np.random.default_rng(6)
+    means = rng.standard_normal((B, D))
+    a = rng.standard_normal((B, D, D)) / np.sqrt(D)
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(D)
+    mean, cov = _lib.SoA.from_host(means), _lib.SoA.from_host(covs)
+    mf, cf, cfx = _lib.SoA(D, B), _lib.SoA(D * D, B), _lib.SoA(D * D, B)
+    st = _lib.DeviceBuffer(4 * mean.ld)
+    tbuf = _lib.DeviceBuffer(8)
+    tbuf.upload(np.zeros(1))
+    for _ in range(2):
+        tf.apply_batch_dev(f, mean, cov, tbuf, mf, cf, cfx, st, 0)
+    _lib.sync()
+    e0, e1 = _lib.Event(), _lib.Event()
+    e0.record()
+    for _ in range(iters):
+        tf.apply_batch_dev(f, mean, cov, tbuf, mf, cf, cfx, st, 0)
+    e1.record()
+    ms = e0.elapsed_ms(e1) / iters
+    g_mf, g_cf = mf.to_host(), cf.to_host((D, D))
+    w = dict(wm=tf.wm, Wc=tf.Wc, Wcc=tf.Wcc, model_var=tf.model.model_var)
+    err = 0.0
+    for i in (0, B // 2, B - 1):
+        r = orc.apply_bq(orc.F_SMOOTH10D_DYN, means[i], covs[i], 0.0, tf.model.points, w)
+        sc = float(np.max(np.abs(r[0])))
+        err = max(err, float(np.max(np.abs(g_mf[i] - r[0])) / sc), float(np.max(np.abs(g_cf[i] - r[1])) / max(sc ** 2, np.abs(r[1]).max())))
+    name = tf.kernel_name(f)
+    for buf in (mean, cov, mf, cf, cfx):
+        buf.buf.free()
+    st.free()
+    tbuf.free()
+    flop = 2.0 * B * D * float(N) * N
+    tfs = flop / (ms * 1e-3) / 1e12
+    rec = {'kernel': name, 'points': int(N), 'ms_per_launch': ms, 'transforms_per_s': B / (ms * 1e-3), 'bound': 'mfma',
+           'achieved': tfs, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tfs / F64_MFMA_PEAK_TF, 'flop_per_launch': flop,
+           'weights_s': t_weights, 'max_scaled_err_vs_oracle': err,
+           'workload': 'BASELINE configs[4] as worded: Bayes-Sard, D=E=10, fully-symmetric DEGREE-7 rule (this build\'s own: '
+                       '1181 points, parity-unpinned), 66 basis functions, B=1e4; flop = 2 B E N^2 (the product fx Wc alone)'}
+    if with_cpu:
+        rec['cpu_baseline'] = cpu_baseline_apply(tf, _lib.F_SMOOTH10D_DYN, (), D, D, means[:64], covs[:64], 4.0,
+                                                 'the D=E=10, N=1181 degree-7 Bayes-Sard transform')
+    return rec
+
+
 class Mt6Bench:
     """Batched GPQ moment transform, D = E = 6, N = 13, B = 1e5, rotating buffer sets (> 256 MB in total so that the
     Infinity Cache cannot hold the working set between launches)."""
@@ -960,6 +1019,7 @@ def main():
         if cb5:
             out['roofline_c5']['cpu_baseline'] = cb5
         out['roofline_c5']['unisolvent_n21'] = measure_c5_unisolvent(amd)
+        out['roofline_c5']['degree7_as_worded'] = measure_c5_degree7(amd, with_cpu=with_cpu)
     if rank == 0:
         result_out.write(json.dumps(out) + '\n')
         result_out.flush()

@@ -44,7 +44,7 @@ extern "C" {
 #define SSMQ_MAX_FPAR 16 /* doubles of integrand constants */
 #define SSMQ_MAX_FIDX 16 /* state-index entries (= SSMQ_MAX_DIM: any sub-state of any state) */
 #define SSMQ_MAX_DIM 16  /* D, E (input / output dimension of a transform) */
-#define SSMQ_MAX_PTS 1024 /* N (sigma points) */
+#define SSMQ_MAX_PTS 4096 /* N (sigma points) */
 
 /* Integrands: closed-form dynamics / measurement functions of ssmtoybox/ssmod.py evaluated on the device so sigma
  * points never leave the GPU (bq/bqmtran.py:132-156 evaluates a Python callable column by column). */
@@ -355,7 +355,10 @@ int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_
  *   SSMQ_PTS_UT  unscented, 2D+1 points    mtran.py:234-293   par = [kappa, alpha, beta]   (NaN / missing: max(3-D,0), 1, 2)
  *   SSMQ_PTS_SR  spherical-radial, 2D      mtran.py:171-204   par = []
  *   SSMQ_PTS_GH  Gauss-Hermite, degree^D   mtran.py:315-360   par = [degree]               (default 3)
- *   SSMQ_PTS_FS  fully symmetric Student   mtran.py:405-578   par = [degree 3|5, kappa, dof] (defaults 3, max(3-D,0), 4)
+ *   SSMQ_PTS_FS  fully symmetric Student   mtran.py:405-578   par = [degree 3|5, kappa, dof] (defaults 3, max(3-D,0), 4);
+ *                degree 7: NOT in the reference (mtran.py:392 stops at 5) - this build's rule for BASELINE configs[4],
+ *                generators [0], [v1], [v2], [u,u], [u,u,u], 1 + 4D + 2D(D-1) + 4D(D-1)(D-2)/3 points (1181 at D = 10), exact
+ *                for all monomials of total degree <= 7 under St(0, I, max(dof, 7)); parity-unpinned, property-tested
  * BQ models use the points only (bq/bqmod.py:340-382).  ssmq_points_count returns N (or < 0); ssmq_points fills
  * xi [D*N] (row-major (D, N), the reference's column order), wm [N] mean weights, wc [N] covariance weights (any may be
  * NULL) and returns N.

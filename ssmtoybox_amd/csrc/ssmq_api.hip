@@ -145,6 +145,10 @@ static int upload_consts(ssmq_transform *h) {
     for (int n = 0; n < N; ++n) s[cs.wm + n] = w[cw.wm + n] = h->wm[n];
     if (sigma) {
         for (int n = 0; n < N; ++n) s[cs.Wc + n] = w[cw.Wc + n] = h->Wc[n];
+        // the centred form's cross-covariance sum_n wc_n (fx_n - m)(x_n - m_x)' with x_n - m_x = L xi_n is (fx_c W') L' for
+        // W[d][n] = xi[d][n] wc_n: kept in the natural-layout block's Wcc slot for the kernels that form it that way
+        for (int d = 0; d < D; ++d)
+            for (int n = 0; n < N; ++n) w[cw.Wcc + d * N + n] = h->xi[d * N + n] * h->Wc[n];
     } else {
         for (int i = 0; i < N; ++i)
             for (int j = 0; j < N; ++j) {
@@ -236,6 +240,34 @@ static int upload_consts(ssmq_transform *h) {
         SSMQ_HIP(hipMemcpyAsync(h->d_wcx_pad, xpad.data(), sizeof(double) * np * nx, hipMemcpyHostToDevice, stream()));
         SSMQ_HIP(hipStreamSynchronize(stream()));   // xpad goes out of scope
     }
+    if (!sigma && N > 64 && !np && !getenv("SSMQ_NO_MFMA")) {
+        // any other point count beyond the wave kernels: Wc (and iK for the t-process) as column blocks of kBigCols
+        // columns, block c = [kb 16][kBigCols] zero-padded, for the blocked GEMM (launch_fxwc_blocks)
+        // the Wc blocks carry D extra columns from column 16 kb on: Wcc', so that fx Wcc' comes out of the same GEMM
+        const int kb = (N + 15) / 16, ncols = 16 * kb + D, ncb = (ncols + kBigCols - 1) / kBigCols;
+        const size_t per = (size_t)kb * 16 * kBigCols, total = per * ncb;
+        auto pack = [&](const std::vector<double> &src, double **dst, bool with_wcc) -> int {
+            std::vector<double> blk(total, 0.0);
+            auto at = [&](int i, int j) -> double & { return blk[(size_t)(j / kBigCols) * per + (size_t)i * kBigCols + j % kBigCols]; };
+            for (int i = 0; i < N; ++i) {
+                for (int j = 0; j < N; ++j) at(i, j) = src[(size_t)i * N + j];
+                if (with_wcc)
+                    for (int d = 0; d < D; ++d) at(i, 16 * kb + d) = h->Wcc[(size_t)d * N + i];
+            }
+            if (*dst && (h->big_kb != kb || h->big_ncb != ncb)) {
+                hipFree(*dst);
+                *dst = nullptr;
+            }
+            if (!*dst) SSMQ_HIP(hipMalloc(dst, sizeof(double) * total));
+            SSMQ_HIP(hipMemcpy(*dst, blk.data(), sizeof(double) * total, hipMemcpyHostToDevice));
+            return SSMQ_OK;
+        };
+        int rcp = pack(h->Wc, &h->d_wc_blk, true);
+        if (rcp) return rcp;
+        if (h->tp_nu > 0.0 && (int)h->iK.size() == N * N && (rcp = pack(h->iK, &h->d_ik_blk, false))) return rcp;
+        h->big_kb = kb;
+        h->big_ncb = ncb;
+    }
     SSMQ_HIP(hipMemcpyAsync(h->d_small, s.data(), sizeof(double) * cs.total, hipMemcpyHostToDevice, stream()));
     SSMQ_HIP(hipMemcpyAsync(h->d_wide, w.data(), sizeof(double) * cw.total, hipMemcpyHostToDevice, stream()));
     SSMQ_HIP(hipStreamSynchronize(stream()));
@@ -315,6 +347,27 @@ static int gemm_scratch(int64_t M, int NP, int64_t B, int D, double **fx, double
     *chol = *tt + n_t;
     return SSMQ_OK;
 }
+// scratch of the blocked route: FX [M][lda] | T [M][ldt] x n_t | means [M] | factors [B][D][D]
+static int big_scratch(int64_t M, int lda, int ldt, int n_t, int64_t B, int D, double **fx, double **tt, double **mrow,
+                       double **chol) {
+    const size_t n_fx = (size_t)M * lda, n_tt = (size_t)M * ldt * n_t;
+    const size_t need = sizeof(double) * (n_fx + n_tt + (size_t)M + (size_t)B * D * D);
+    if (g_gemm_ws_bytes < need) {
+        if (g_gemm_ws) {
+            SSMQ_HIP(hipStreamSynchronize(stream()));
+            hipFree(g_gemm_ws);
+        }
+        g_gemm_ws = nullptr;
+        g_gemm_ws_bytes = 0;
+        SSMQ_HIP(hipMalloc(&g_gemm_ws, need));
+        g_gemm_ws_bytes = need;
+    }
+    *fx = (double *)g_gemm_ws;
+    *tt = *fx + n_fx;
+    *mrow = *tt + n_tt;
+    *chol = *mrow + M;
+    return SSMQ_OK;
+}
 static void drop_gemm_scratch() {
     if (g_gemm_ws) hipFree(g_gemm_ws);
     g_gemm_ws = nullptr;
@@ -337,7 +390,12 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         const int want[4] = {h->opt_mask & (tp ? SSMQ_OPT_UT : 3), h->opt_mask & SSMQ_OPT_UT, h->opt_mask & SSMQ_OPT_LDL & (tp ? 0 : 1), 0};
         for (int k = 0; k < 4 && !se; ++k) se = find_small(f->id, h->D, h->E, h->N, h->form, tp, sel, want[k]);
     }
-    if (kernel_name) *kernel_name = se ? se->name : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
+    const bool wide_fits = wide_lds_bytes(h->D, h->E, h->N) <= 160 * 1024 - 64;
+    // point sets beyond the wave kernels without a fused matrix-core instantiation: evaluation pass, blocked GEMM, rest
+    const bool big = !se && h->N > 64 && ((h->form == SSMQ_FORM_BQ && h->d_wc_blk && (B * h->E >= kGemmMinRows || !wide_fits) &&
+                                           (h->tp_nu <= 0.0 || h->d_ik_blk)) ||
+                                          (h->form == SSMQ_FORM_SIGMA && !wide_fits));
+    if (kernel_name) *kernel_name = se ? se->name : big ? "k_apply_big" : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
     if (dry_run) return SSMQ_OK;
     if (B <= 0) return SSMQ_OK;
     if (!d_mean || !d_cov || !d_mean_f || !d_cov_f || !d_cov_fx || !d_status || (fi.uses_time && !d_time) ||
@@ -357,7 +415,7 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         a.fp.ttab = ttab;
         return hip_fail(se->fn(a, stream()), se->name);
     }
-    if (wide_lds_bytes(h->D, h->E, h->N) > 160 * 1024 - 64) {
+    if (!big && !wide_fits) {
         set_error("apply: shape too large for the LDS-resident generic kernel");
         return SSMQ_E_UNSUPPORTED;
     }
@@ -371,6 +429,25 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     a.status = d_status;
     fill_fpar(f, &a.fp);
     a.fp.ttab = ttab;
+    if (big) {
+        const bool bq = h->form == SSMQ_FORM_BQ, tpb = bq && h->tp_nu > 0.0;
+        const int kb = (h->N + 15) / 16, lda = kb * 16, ldt = bq ? h->big_ncb * kBigCols : 0;
+        const int64_t M = B * h->E;
+        double *fx, *tt, *mrow, *chol;
+        if ((rc = big_scratch(M, lda, ldt, bq ? (tpb ? 2 : 1) : 0, B, h->D, &fx, &tt, &mrow, &chol))) return rc;
+        WideArgs e = a;
+        e.fx_ld = lda; e.fx_out = fx; e.mrow_out = mrow; e.chol_out = chol;
+        if ((rc = hip_fail(launch_eval_wave(e, B, stream()), "k_eval_wave"))) return rc;
+        if (bq && (rc = launch_fxwc_blocks(fx, h->d_wc_blk, tt, M, lda, ldt, kb, h->big_ncb, stream()))) return rc;
+        if (tpb && (rc = launch_fxwc_blocks(fx, h->d_ik_blk, tt + (size_t)M * ldt, M, lda, ldt, kb, h->big_ncb, stream()))) return rc;
+        BigRest r;
+        memset(&r, 0, sizeof(r));
+        r.D = h->D; r.E = h->E; r.N = h->N; r.form = h->form; r.emv_mode = h->emv_mode; r.tp_nu = h->tp_nu;
+        r.cov_scale = cov_scale; r.ccov_scale = ccov_scale; r.consts = h->d_wide; r.fx = fx; r.t = bq ? tt : nullptr;
+        r.t2 = tpb ? tt + (size_t)M * ldt : nullptr; r.lda = lda; r.ldt = ldt; r.p_col = 16 * kb; r.mean_rows = mrow; r.chol = chol;
+        r.cov_add = d_cov_add; r.cov_f = d_cov_f; r.cov_fx = d_cov_fx; r.es = ld; r.bs_cf = 1; r.bs_cfx = 1; r.status = d_status;
+        return launch_big_rest(r, B, stream());
+    }
     if (h->d_wc_pad && h->form == SSMQ_FORM_BQ && B * h->E >= kGemmMinRows) {
         // large point set: integrand values of the whole batch -> one GEMM on the matrix cores -> per-trajectory rest
         const int NP = h->np_pad;
@@ -669,6 +746,8 @@ void ssmq_transform_destroy(ssmq_transform *h) {
     if (h->d_wide) hipFree(h->d_wide);
     if (h->d_wc_pad) hipFree(h->d_wc_pad);
     if (h->d_wcx_pad) hipFree(h->d_wcx_pad);
+    if (h->d_wc_blk) hipFree(h->d_wc_blk);
+    if (h->d_ik_blk) hipFree(h->d_ik_blk);
     delete h;
 }
 
@@ -933,18 +1012,28 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
     if (rc) return rc;
     if (B == 0) return SSMQ_OK;
     const int D = h->D, E = h->E, N = h->N;
-    if (wide_lds_bytes(D, E, N) > 160 * 1024 - 64) return SSMQ_E_UNSUPPORTED;
+    const bool wide_fits = wide_lds_bytes(D, E, N) <= 160 * 1024 - 64;
+    const bool centred = h->form == SSMQ_FORM_SIGMA;
+    // point sets beyond the wave kernels without a fused matrix-core instantiation (as apply_dev_impl): blocked GEMM + rest
+    const bool big = N > 64 && ((!centred && h->d_wc_blk && (B * E >= kGemmMinRows || !wide_fits) && (h->tp_nu <= 0.0 || h->d_ik_blk)) ||
+                                (centred && !wide_fits));
+    if (!big && !wide_fits) {
+        set_error("apply_fx_batch: shape too large for the LDS-resident generic kernel");
+        return SSMQ_E_UNSUPPORTED;
+    }
     // staging arena: [chol | fx | mean | x] up, [mean_f | cov_f | cov_fx] down through the pinned blocks; the padded copies
     // of the matrix-core route behind them
-    const bool centred = h->form == SSMQ_FORM_SIGMA;
-    const bool gemm = h->d_wc_pad && h->form == SSMQ_FORM_BQ && B * E >= kGemmMinRows;
+    const bool gemm = !big && h->d_wc_pad && h->form == SSMQ_FORM_BQ && B * E >= kGemmMinRows;
     const size_t nb = (size_t)B, n_l = nb * D * D, n_fx = nb * E * N, n_m = centred ? nb * D : 0, n_x = centred ? nb * D * N : 0;
     const size_t n_out = nb * ((size_t)E + (size_t)E * E + (size_t)E * D);
     const size_t in_bytes = sizeof(double) * (n_l + n_fx + n_m + n_x), out_bytes = sizeof(double) * n_out;
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t pad_bytes = gemm ? sizeof(double) * nb * E * h->np_pad : 0;
+    const int big_kb = (N + 15) / 16, big_lda = big_kb * 16, big_ldt = (big && !centred) ? h->big_ncb * kBigCols : 0;
+    const int big_nt = (big && !centred) ? (h->tp_nu > 0.0 ? 2 : 1) : 0;
+    const size_t pad_bytes = gemm ? sizeof(double) * nb * E * h->np_pad : big ? sizeof(double) * nb * E * big_lda : 0;
+    const size_t t_bytes = gemm ? pad_bytes : sizeof(double) * nb * E * (size_t)big_ldt * big_nt;
     const size_t off_out = al(in_bytes), off_fxp = off_out + al(out_bytes), off_tt = off_fxp + al(pad_bytes);
-    if ((rc = g_stage.reserve(off_tt + al(pad_bytes), in_bytes, out_bytes))) return rc;
+    if ((rc = g_stage.reserve(off_tt + al(t_bytes), in_bytes, out_bytes))) return rc;
     hipStream_t s = stream();
     char *dev = (char *)g_stage.dev;
     double *dl = (double *)dev, *dfx = dl + n_l, *dm = dfx + n_fx, *dx = dm + n_m;
@@ -964,7 +1053,27 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
     a.consts = h->d_wide; a.mean = dm; a.chol_in = dl; a.fx_in = dfx; a.x_in = dx;
     a.mean_f = omf; a.cov_f = ocf; a.cov_fx = ocfx; a.es_out = 1; a.bs_mf = E; a.bs_cf = E * E;
     a.bs_cfx = E * D;
-    if (gemm) {
+    if (big) {
+        const int64_t M = B * E;
+        double *fxp = (double *)(dev + off_fxp), *ttp = (double *)(dev + off_tt);
+        SSMQ_HIP(hipMemsetAsync(fxp, 0, sizeof(double) * M * big_lda, s));
+        SSMQ_HIP(hipMemcpy2DAsync(fxp, sizeof(double) * big_lda, dfx, sizeof(double) * N, sizeof(double) * N, M,
+                                  hipMemcpyDeviceToDevice, s));
+        const WideLayout wl = wide_layout(D, E, N, h->form);
+        if ((rc = launch_row_means(fxp, h->d_wide + wl.wm, M, big_lda, N, omf, s))) return rc;
+        if (!centred && (rc = launch_fxwc_blocks(fxp, h->d_wc_blk, ttp, M, big_lda, big_ldt, big_kb, h->big_ncb, s))) return rc;
+        if (big_nt == 2 && (rc = launch_fxwc_blocks(fxp, h->d_ik_blk, ttp + (size_t)M * big_ldt, M, big_lda, big_ldt, big_kb,
+                                                    h->big_ncb, s)))
+            return rc;
+        BigRest r;
+        memset(&r, 0, sizeof(r));
+        r.D = D; r.E = E; r.N = N; r.form = h->form; r.emv_mode = h->emv_mode; r.tp_nu = h->tp_nu; r.cov_scale = r.ccov_scale = 1.0;
+        r.consts = h->d_wide; r.fx = fxp; r.t = centred ? nullptr : ttp; r.t2 = big_nt == 2 ? ttp + (size_t)M * big_ldt : nullptr;
+        r.lda = big_lda; r.ldt = big_ldt; r.p_col = 16 * big_kb; r.mean_rows = omf; r.chol = dl;
+        r.cov_f = ocf; r.cov_fx = ocfx; r.es = 1; r.bs_cf = (int64_t)E * E; r.bs_cfx = (int64_t)E * D;
+        if ((rc = launch_big_rest(r, B, s))) return rc;
+        a.mode = -1;   // done
+    } else if (gemm) {
         // matrix-core route: rows re-pitched to the padded column count, T = FX Wc for the whole batch, then the rest
         const int NP = h->np_pad;
         const int64_t M = B * E;

@@ -27,8 +27,12 @@ constexpr int kGemmBlock = 256;
 
 template <int NT, int RT>   // RT row tiles of 16 per wave: a workgroup owns 64 RT rows
 __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const double *__restrict__ A, const double *__restrict__ Bm,
-                                                          double *__restrict__ T, int64_t M, int lda, int ldt) {
-    constexpr int NP = NT * 16;          // padded N = padded K
+                                                          double *__restrict__ T, int64_t M, int lda, int ldt, int KB) {
+    // KB: k blocks of 16 (= NT for the square case).  Large point sets run one launch over column blocks of NP columns:
+    // blockIdx.y selects the block, stored contiguously as [KB 16][NP] (host-made, zero-padded), and the NP output columns
+    constexpr int NP = NT * 16;          // columns of this block (the square case: padded N = padded K)
+    Bm += (int64_t)blockIdx.y * KB * 16 * NP;
+    T += (int64_t)blockIdx.y * NP;
     constexpr int LB = NP + 4;           // LDS row pitch (doubles)
     extern __shared__ __align__(16) double lds[];      // [2][16][LB]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -75,9 +79,9 @@ __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const
     load_a(0, a);
     park_b(0);
     __syncthreads();
-    for (int kb = 0; kb < NT; ++kb) {
+    for (int kb = 0; kb < KB; ++kb) {
         const int buf = kb & 1;
-        if (kb + 1 < NT) {
+        if (kb + 1 < KB) {
             load_b(kb + 1);
             load_a(kb + 1, an);
         }
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const
 #endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if (s == SSMQ_GEMM_PARK_AT && kb + 1 < NT) park_b(buf ^ 1);
+            if (s == SSMQ_GEMM_PARK_AT && kb + 1 < KB) park_b(buf ^ 1);
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const double b = sb[(4 * lg + s) * LB + ct * 16 + li];
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const
                     acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt][s], b, acc[rt][ct], 0, 0, 0);
             }
         }
-        if (kb + 1 < NT) {
+        if (kb + 1 < KB) {
             if (SSMQ_GEMM_PARK_AT >= 4) park_b(buf ^ 1);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
@@ -299,7 +303,8 @@ hipError_t launch_cov(const double *A, const double *X, int64_t M, int lda, cons
 }
 
 template <int NT, int RT>
-hipError_t launch_rt(const double *A, const double *Bm, double *T, int64_t M, int lda, int ldt, hipStream_t s) {
+hipError_t launch_rt(const double *A, const double *Bm, double *T, int64_t M, int lda, int ldt, hipStream_t s, int KB = NT,
+                     int ncb = 1) {
     constexpr size_t lds = sizeof(double) * 2 * 16 * (NT * 16 + 4);
     static unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
     if (attr_epoch != device_epoch()) {
@@ -309,8 +314,8 @@ hipError_t launch_rt(const double *A, const double *Bm, double *T, int64_t M, in
         attr_epoch = device_epoch();
     }
     constexpr int rows = 64 * RT;
-    hipLaunchKernelGGL((k_fxwc_mfma<NT, RT>), dim3((unsigned)((M + rows - 1) / rows)), dim3(kGemmBlock), lds, s, A, Bm, T, M,
-                       lda, ldt);
+    hipLaunchKernelGGL((k_fxwc_mfma<NT, RT>), dim3((unsigned)((M + rows - 1) / rows), (unsigned)ncb), dim3(kGemmBlock), lds, s,
+                       A, Bm, T, M, lda, ldt, KB);
     return hipGetLastError();
 }
 
@@ -341,6 +346,15 @@ int launch_fxwc_mfma(int NP, const double *A, const double *Bm, double *T, int64
         default: set_error("fxwc_mfma: no instantiation for this point count"); return SSMQ_E_UNSUPPORTED;
     }
     return hip_fail(e, "k_fxwc_mfma");
+}
+
+// Any point count: T [M][ldt] = A [M][lda] * W, W given as `ncb` column blocks of kBigCols columns, block c stored
+// contiguously as [KB 16][kBigCols] (zero-padded); lda >= 16 KB, ldt >= ncb kBigCols.  One launch, blockIdx.y = block: the
+// workgroups of consecutive row blocks share a block of W (2.4 MB at N = 1161: L2-resident), A is streamed once per block.
+int launch_fxwc_blocks(const double *A, const double *Wblk, double *T, int64_t M, int lda, int ldt, int KB, int ncb,
+                       hipStream_t s) {
+    if (M <= 0) return SSMQ_OK;
+    return hip_fail(launch_rt<kBigCols / 16, 1>(A, Wblk, T, M, lda, ldt, s, KB, ncb), "k_fxwc_mfma(blocks)");
 }
 
 // mean_rows[i] = FX[i][:] . wm for caller-supplied integrand values (the evaluation pass computes it itself): one wave per

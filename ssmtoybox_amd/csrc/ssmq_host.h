@@ -19,6 +19,10 @@ struct ssmq_transform {
     int np_pad = 0;
     // ... and [Wc | Wcc'] as np_pad x (np_pad + 16) for the route whose GEMM epilogue forms both covariances, or null
     double *d_wcx_pad = nullptr;
+    // point sets without an instantiation of that route (N > 64): Wc (and iK for the t-process) as column blocks of
+    // kBigCols columns, each [big_kb 16][kBigCols] zero-padded (ssmq_apply_big.hip); null = not built
+    double *d_wc_blk = nullptr, *d_ik_blk = nullptr;
+    int big_kb = 0, big_ncb = 0;   // k blocks of 16 points; column blocks of [Wc | pad to 16 big_kb | Wcc'] (big_ncb)
     uint32_t generation = 0;   // bumped by every upload of constants (create / update)
 };
 
@@ -59,6 +63,25 @@ int launch_fxwc_cov_mfma(int NP, const double *A, const double *X, int64_t M, in
                          double cov_scale, double ccov_scale, int E, int D, double *cov_f, double *cov_fx, int64_t es,
                          int64_t bs, int64_t bs_fx, hipStream_t s);
 int launch_row_means(const double *A, const double *wm, int64_t M, int lda, int N, double *mean_rows, hipStream_t s);
+// ... and for any point count, by column blocks (ssmq_gemm_mfma.hip); the per-trajectory rest (ssmq_apply_big.hip)
+constexpr int kBigCols = 256;
+int launch_fxwc_blocks(const double *A, const double *Wblk, double *T, int64_t M, int lda, int ldt, int KB, int ncb,
+                       hipStream_t s);
+struct BigRest {
+    int D, E, N, form, emv_mode;
+    double tp_nu, cov_scale, ccov_scale;
+    const double *consts;          // WideLayout block (wm, Wc diagonal for the centred form, Wcc, xiT, emv)
+    const double *fx, *t, *t2;     // rows b E + e: integrand values [lda], fx Wc [ldt] (null: centred form), fx iK [ldt] or null
+    int64_t lda, ldt;
+    int p_col;                     // BQ: column of T where the D columns fx Wcc' start (the GEMM's extra columns)
+    const double *mean_rows;       // [B E]
+    const double *chol;            // [B][D][D]
+    const double *cov_add;         // [E*E] or null
+    double *cov_f, *cov_fx;        // element e of trajectory b at ptr[e * es + b * bs_*]
+    int64_t es, bs_cf, bs_cfx;
+    const int32_t *status;         // [B] or null: nonzero -> NaN outputs
+};
+int launch_big_rest(const BigRest &r, int64_t B, hipStream_t s);
 
 // trajectory / measurement simulator (ssmq_simulate.hip)
 struct SimRv {

@@ -161,7 +161,7 @@ int build(int kind, int D, const double *par, int n_par, Rule &r) {
         }
         case SSMQ_PTS_FS: {
             int deg = (int)par_or(par, n_par, 0, 3.0);
-            if (deg != 3 && deg != 5) deg = 3;                        // the reference prints a note and defaults to 3
+            if (deg != 3 && deg != 5 && deg != 7) deg = 3;            // the reference prints a note and defaults to 3
             const double kappa = par_or(par, n_par, 1, std::fmax(3.0 - D, 0.0));
             const double dof = std::fmax(par_or(par, n_par, 2, 4.0), (double)deg);
             const double i2 = dof / (dof - 2.0);
@@ -172,6 +172,37 @@ int build(int kind, int D, const double *par, int n_par, Rule &r) {
                 for (int i = 0; i < D; ++i) r.cols.push_back(axis(i, -u));
                 r.wm.assign(2 * D + 1, 1.0 / (2.0 * (D + kappa)));
                 r.wm[0] = kappa / (D + kappa);
+            } else if (deg == 7) {
+                // NOT in the reference (its rules stop at degree 5, mtran.py:392): this build's degree-7 rule for BASELINE
+                // configs[4], generators [0], [v1], [v2], [u, u], [u, u, u]; derivation in ssmtoybox_amd/mtran.py
+                // (FullySymmetricStudentTransform.degree7_rule), exactness for all monomials of degree <= 7 is tested
+                const int n = D;
+                const double nu = dof, m2 = i2, m22 = nu * nu / ((nu - 2.0) * (nu - 4.0)), m4 = 3.0 * m22;
+                const double m222 = nu * nu * nu / ((nu - 2.0) * (nu - 4.0) * (nu - 6.0)), m42 = 3.0 * m222, m6 = 15.0 * m222;
+                const double sq = m42 / m22;
+                const double d3 = n >= 3 ? m222 / (8.0 * sq * sq * sq) : 0.0;
+                const double c2 = n >= 2 ? (m22 / (sq * sq) - 8.0 * (n - 2) * d3) / 4.0 : 0.0;
+                const double t = 4.0 * (n - 1) * c2 + 4.0 * (n - 1) * (n - 2) * d3;
+                const double r1 = m2 - t * sq, r2 = m4 - t * sq * sq, r3 = m6 - t * sq * sq * sq;
+                const double e2 = r2 / r1, e1 = (r3 + e2 * r1) / r2, disc = e1 * e1 - 4.0 * e2;
+                if (!(disc > 0.0 && e1 > 0.0 && e2 > 0.0)) {
+                    set_error("points: degree-7 rule has no real axis generators for this dimension / dof");
+                    return SSMQ_E_ARG;
+                }
+                const double p = 0.5 * (e1 + std::sqrt(disc)), q = 0.5 * (e1 - std::sqrt(disc));
+                const double a = 0.5 * (r2 - r1 * q) / (p * (p - q)), b = 0.5 * (r1 * p - r2) / (q * (p - q));
+                const int n_pair = 2 * n * (n - 1), n_trip = 4 * n * (n - 1) * (n - 2) / 3;
+                const double u = std::sqrt(sq);
+                symmetric_set(D, {}, r.cols);
+                symmetric_set(D, {std::sqrt(p)}, r.cols);
+                symmetric_set(D, {std::sqrt(q)}, r.cols);
+                if (D > 1) symmetric_set(D, {u, u}, r.cols);
+                if (D > 2) symmetric_set(D, {u, u, u}, r.cols);
+                r.wm.push_back(1.0 - (2.0 * n * a + 2.0 * n * b + n_pair * c2 + n_trip * d3));
+                for (int i = 0; i < 2 * n; ++i) r.wm.push_back(a);
+                for (int i = 0; i < 2 * n; ++i) r.wm.push_back(b);
+                for (int i = 0; i < n_pair; ++i) r.wm.push_back(c2);
+                for (int i = 0; i < n_trip; ++i) r.wm.push_back(d3);
             } else {
                 const double i22 = dof * dof / ((dof - 2.0) * (dof - 4.0)), i4 = 3.0 * i22, u = std::sqrt(i4 / i2);
                 symmetric_set(D, {}, r.cols);

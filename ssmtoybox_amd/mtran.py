@@ -278,9 +278,14 @@ class GaussHermiteTransform(SigmaPointTransform):
 
 
 class FullySymmetricStudentTransform(SigmaPointTransform):
-    """Fully symmetric rule for Student-t densities, degree 3 or 5 (mtran.py:363-578)."""
+    """Fully symmetric rule for Student-t densities, degree 3 or 5 (mtran.py:363-578), and - NOT in the reference, whose
+    rules stop at degree 5 (mtran.py:392) - a degree-7 rule of this build for BASELINE configs[4] ("fully-symmetric
+    7th-degree rule, state-dim 10"): generators [0], [v1], [v2], [u, u], [u, u, u], N = 1 + 4 D + 2 D (D - 1) +
+    4 D (D - 1)(D - 2) / 3 points (1181 at D = 10), exact for every monomial of total degree <= 7 under the same
+    multivariate-t moments the reference's degree-5 rule matches (`degree7_rule`; parity-unpinned by construction, its
+    defining property is tested instead)."""
 
-    _supported_degrees_ = [3, 5]
+    _supported_degrees_ = [3, 5, 7]
 
     def __init__(self, dim, degree=3, kappa=None, dof=4):
         self.degree, self.kappa, self.dof = degree, kappa, dof
@@ -304,6 +309,8 @@ class FullySymmetricStudentTransform(SigmaPointTransform):
             w = np.full(2 * dim + 1, 1 / (2 * (dim + kappa)))
             w[0] = kappa / (dim + kappa)
             return w
+        if degree == 7:
+            return FullySymmetricStudentTransform.degree7_rule(dim, dof)[1]
         i2 = dof / (dof - 2)
         i22 = dof ** 2 / ((dof - 2) * (dof - 4))
         i4 = 3 * i22
@@ -319,10 +326,51 @@ class FullySymmetricStudentTransform(SigmaPointTransform):
         if degree == 3:
             u = np.sqrt(i2 * (dim + kappa))
             return u * np.hstack((np.zeros((dim, 1)), np.eye(dim), -np.eye(dim)))
+        if degree == 7:
+            return FullySymmetricStudentTransform.degree7_rule(dim, dof)[0]
         i4 = 3 * dof ** 2 / ((dof - 2) * (dof - 4))
         u = np.sqrt(i4 / i2)
         sym = FullySymmetricStudentTransform.symmetric_set
         return np.hstack((sym(dim, []), sym(dim, [u]), sym(dim, [u, u])))
+
+    @staticmethod
+    def degree7_rule(dim, dof=7.0):
+        """(points (dim, N), weights (N,)) of this build's degree-7 fully symmetric rule for St(0, I, dof), dof > 6.
+        Moment equations of the seven even monomial types 1, x^2, x^4, x^2 y^2, x^6, x^4 y^2, x^2 y^2 z^2: the last three
+        fix the generator of the pair / triple sets (u^2 = M42 / M22) and their weights, the axis sets [v1], [v2] then
+        match the second, fourth and sixth moments that remain (a two-point moment problem with one free parameter,
+        fixed as e2 = m2 / m1)."""
+        n, nu = int(dim), float(max(dof, 7.0))
+        g = nu / (nu - 2.0)
+        m2_, m22 = g, nu ** 2 / ((nu - 2) * (nu - 4))
+        m4_ = 3 * m22
+        m222 = nu ** 3 / ((nu - 2) * (nu - 4) * (nu - 6))
+        m42, m6_ = 3 * m222, 15 * m222
+        s = m42 / m22                                   # u^2
+        d3 = m222 / (8 * s ** 3) if n >= 3 else 0.0
+        c2 = (m22 / s ** 2 - 8 * (n - 2) * d3) / 4 if n >= 2 else 0.0
+        t = 4 * (n - 1) * c2 + 4 * (n - 1) * (n - 2) * d3
+        r1, r2, r3 = m2_ - t * s, m4_ - t * s ** 2, m6_ - t * s ** 3
+        e2 = r2 / r1
+        e1 = (r3 + e2 * r1) / r2
+        disc = e1 * e1 - 4 * e2
+        if not (disc > 0 and e1 > 0 and e2 > 0):
+            raise ValueError('degree-7 rule: no real axis generators for dim = {}, dof = {}'.format(dim, dof))
+        p, r = (e1 + np.sqrt(disc)) / 2, (e1 - np.sqrt(disc)) / 2
+        alpha = (r2 - r1 * r) / (p * (p - r))
+        beta = (r1 * p - r2) / (r * (p - r))
+        a, b = alpha / 2, beta / 2
+        n_pair, n_trip = 2 * n * (n - 1), 4 * n * (n - 1) * (n - 2) // 3
+        w0 = 1 - (2 * n * a + 2 * n * b + n_pair * c2 + n_trip * d3)
+        sym = FullySymmetricStudentTransform.symmetric_set
+        u = np.sqrt(s)
+        sets = [sym(n, []), sym(n, [np.sqrt(p)]), sym(n, [np.sqrt(r)])]
+        if n >= 2:
+            sets.append(sym(n, [u, u]))
+        if n >= 3:
+            sets.append(sym(n, [u, u, u]))
+        w = np.hstack((w0, a * np.ones(2 * n), b * np.ones(2 * n), c2 * np.ones(n_pair), d3 * np.ones(n_trip)))
+        return np.hstack(sets), w
 
     @staticmethod
     def symmetric_set(dim, gen):

@@ -149,16 +149,63 @@ def test_apply_generic_kernel_matches(amd, golden, name):
     fid, p, sidx, din, dout = MODELS[name]
     mod, f = make_model(name)
     means, covs, times = g[name + '_mean'], g[name + '_cov'], g[name + '_time']
-    if 3 ** din > 1024:
-        pytest.skip('no Gauss-Hermite grid of this dimension fits the generic kernel (N <= 1024)')
-    deg = 5 if din <= 3 else 3                   # N = 5^D (<= 125) or 3^D (81 ... 729): no register-resident
-    tf = amd.GaussHermiteTransform(din, deg)     # specialisation for D >= 2, the generic kernel's limit is N = 1024
-    pts, wm = orc.points_gh(din, deg), orc.weights_gh(din, deg)
-    assert din <= 3 or 'k_apply_wide' in tf.kernel_name(f)
+    deg = 5 if din <= 3 else 3                   # N = 5^D (<= 125) or 3^D (81 ... 2187): no register-resident
+    tf = amd.GaussHermiteTransform(din, deg)     # specialisation for D >= 2; 3^7 = 2187 points (the 7-input CTRS model) are
+    pts, wm = orc.points_gh(din, deg), orc.weights_gh(din, deg)      # beyond the LDS-resident kernel: k_apply_big
+    assert din <= 3 or tf.kernel_name(f) == ('k_apply_big' if din == 7 else 'k_apply_wide')
     got = tf.apply_batch(f, means, covs, times.astype(float))
     for i in range(means.shape[0]):
         ref = orc.apply_sigma(fid, means[i], covs[i], times[i], pts, wm, wm, p, sidx)
         assert_moments_close([a[i] for a in got], ref, covs[i], what=(name, i, tf.kernel_name(f)))
+
+
+@pytest.mark.parametrize('kind,deg,name', [('gp', 3, 'reentry_dyn'), ('tp', 3, 'reentry_dyn'), ('bs', 3, 'ct_dyn'), ('gp', 3, 'ctrs_dyn')])
+def test_blocked_matrix_core_route(amd, golden, monkeypatch, kind, deg, name):
+    """BQ transforms on point sets beyond the wave kernels that have no instantiation of the fused matrix-core route
+    (Gauss-Hermite degree 3 at D = 5: N = 243, at D = 7: N = 2187): evaluation pass, T = FX Wc by column blocks of 256 on the
+    matrix cores (and fx iK for the t-process), per-trajectory rest (k_apply_big) - against the oracle with the device's own
+    weights, and against the LDS-resident workgroup kernel where the shape fits it."""
+    g = golden('g3_apply')
+    fid, p, sidx, din, dout = MODELS[name]
+    mod, f = make_model(name)
+    means, covs, times = g[name + '_mean'], g[name + '_cov'], g[name + '_time']
+    reps = 32                                             # 16 x 32 = 512 trajectories: beyond the route's minimum row count
+    means, covs, times = np.tile(means, (reps, 1)), np.tile(covs, (reps, 1, 1)), np.tile(times, reps)
+    par = np.array([[1.0] + [3.0] * din])
+    mi = np.hstack((np.zeros((din, 1)), np.eye(din), 2 * np.eye(din))).astype(int)
+    tf = {'gp': lambda: amd.GaussianProcessTransform(din, dout, par, 'rbf', 'gh', {'degree': deg}),
+          'tp': lambda: amd.StudentTProcessTransform(din, dout, par, 'rbf', 'gh', {'degree': deg}),
+          'bs': lambda: amd.BayesSardTransform(din, dout, par, mi, 'gh', {'degree': deg})}[kind]()
+    N = tf.model.points.shape[1]
+    assert N == deg ** din and tf.kernel_name(f) in ('k_apply_big', 'k_apply_wide')
+    got = tf.apply_batch(f, means, covs, times.astype(float), return_status=True)
+    assert not got[3].any()
+    w = dict(wm=tf.wm, Wc=tf.Wc, Wcc=tf.Wcc, model_var=tf.model.model_var, iK=getattr(tf.model, 'iK', None))
+    worst = 0.0
+    for i in range(0, 16, 3):
+        ref = orc.apply_bq(fid, means[i], covs[i], times[i], tf.model.points, w, p, sidx, tp_nu=4.0 if kind == 'tp' else None)
+        worst = max(worst, assert_moments_close([a[i] for a in got[:3]], ref, covs[i], what=(kind, name, i)))
+    assert within(worst, 1e-10, 'blocked matrix-core route {} {} N={} vs oracle (scaled)'.format(kind, name, N))
+    assert np.array_equal(got[1], got[1].transpose(0, 2, 1))
+    assert np.array_equal(got[0][:16], got[0][16:32]) and np.array_equal(got[1][:16], got[1][-16:])     # tiled inputs, same outputs
+    # the same transform with the integrand as an arbitrary Python callable (device sigma points -> host f -> device
+    # reductions through the same blocked route)
+    nb = 16 if N <= 1024 else 4
+    host = tf.apply_batch(lambda x, par: orc.integrand(fid, x if sidx is None else x[list(sidx)], par[0], p), means[:nb], covs[:nb],
+                          times[:nb].astype(float), fcn_pars=None)
+    for a_, b_, what in zip(host, got[:3], ('mean', 'cov', 'ccov')):
+        assert within(np.abs(a_ - b_[:nb]).max() / np.abs(b_[:nb]).max(), 1e-11, 'blocked route, host callable vs device integrand {} {} {}'.format(kind, name, what))
+    if N <= 1024:
+        monkeypatch.setenv('SSMQ_NO_MFMA', '1')
+        tf2 = {'gp': lambda: amd.GaussianProcessTransform(din, dout, par, 'rbf', 'gh', {'degree': deg}),
+               'tp': lambda: amd.StudentTProcessTransform(din, dout, par, 'rbf', 'gh', {'degree': deg}),
+               'bs': lambda: amd.BayesSardTransform(din, dout, par, mi, 'gh', {'degree': deg})}[kind]()
+        tf2.wm, tf2.Wc, tf2.Wcc = tf.wm, tf.Wc, tf.Wcc
+        assert tf2.kernel_name(f) == 'k_apply_wide'
+        ref = tf2.apply_batch(f, means[:16], covs[:16], times[:16].astype(float))
+        monkeypatch.delenv('SSMQ_NO_MFMA')
+        for a_, b_, what in zip(got[:3], ref, ('mean', 'cov', 'ccov')):
+            assert within(np.abs(a_[:16] - b_).max() / np.abs(b_).max(), 1e-11, 'blocked route vs workgroup kernel {} {} {}'.format(kind, name, what))
 
 
 def test_wave_kernel_matches_workgroup_kernel(amd, golden, monkeypatch):
