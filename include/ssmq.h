@@ -316,6 +316,13 @@ int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_d
  * The forward pass that keeps the predictive moments is one kernel for the UNGM / pendulum / reentry (5, 2, 11) shapes,
  * else the launch loop (hipGraph).
  */
+/* The backward pass alone (ssinf.py:120-147, 325-344) over moments the caller kept from its own forward pass (the
+ * marginalised filter drives its forward pass from the host): filtered d_fm [T][D][ld], d_fP [T][D*D][ld], predictive
+ * d_pm, d_pP (element k = the prediction INTO step k), dynamics cross-covariance d_pC [T][D*D][ld]; outputs d_sm, d_sP;
+ * d_status [ld] gets bit 30 set where a predictive covariance is not positive definite.  D <= 7.  Synchronous. */
+int ssmq_rts_backward_dev(int D, int64_t B, int64_t ld, int T, const double *d_fm, const double *d_fP, const double *d_pm,
+                          const double *d_pP, const double *d_pC, double *d_sm, double *d_sP, int32_t *d_status);
+
 int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
                            const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                            const double *d_m0, const double *d_P0, const double *GQG, const double *R, double *d_fm,
@@ -337,9 +344,13 @@ int ssmq_filter_smooth_aug_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
  * re-weighting bq/bqmtran.py:93-95).  For item i = 0..P-1:
  *   weights(par_dyn[i]) -> dyn transform at `time` (+ GQG) -> weights(par_obs[i]) -> obs transform at `time` (+ R)
  *   -> Kalman update with y -> post_mean[i][D], post_cov[i][D*D], loglik[i] = log N(y | y_mean, P_y).
- * h_dyn / h_obs supply shapes, sigma points and the emv mode (their own weights are not used; GP models only, additive
- * noise).  par_dyn, par_obs: host [P][1+D] = [alpha, ell_1..ell_D] (already exponentiated).  mean [D] / cov [D*D] when
- * shared_state = 1, else [P][D] / [P][D*D]; y [Y] when shared_y = 1, else [P][Y].  GQG [D*D], R [Y*Y] host or NULL.
+ * h_dyn / h_obs supply shapes, sigma points and the emv mode (their own weights are not used; GP models only).
+ * par_dyn: host [P][1+Din], par_obs [P][1+D] = [alpha, ell_1..] (already exponentiated), Din = input dimension of h_dyn.
+ * Additive dynamics: Din = D.  Dynamics that take their noise as an argument: h_dyn is a (D + dq) -> D transform and the
+ * caller passes the augmented moments [mean; q_mean], blockdiag(cov, Q) (ssinf.py:1174-1176) with GQG = NULL; the
+ * measurement model is additive in either case (the reference builds that transform on dim_state inputs, ssinf.py:1288).
+ * mean [Din] / cov [Din*Din] when shared_state = 1, else [P][Din] / [P][Din*Din]; y [Y] when shared_y = 1, else [P][Y].
+ * GQG [D*D], R [Y*Y] host or NULL.
  * status[i] (may be NULL): bit 0 K_dyn not positive definite, bit 1 K_obs, bit 2 cov (Cholesky in the dyn transform),
  * bit 3 predictive cov, bit 4 P_y.  Returns 0, or 1 + index of the first item with a nonzero status.  Synchronous;
  * the weights never leave the device (k_weights writes per-item constant blocks that the generic transform kernel reads in place).

@@ -133,6 +133,7 @@ _PROTOTYPES = {
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_void_p]),
+    'ssmq_rts_backward_dev': (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 8),
     'ssmq_student_filter_forward_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
                                                        ctypes.POINTER(Integrand), ctypes.c_int64, ctypes.c_int64,
                                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

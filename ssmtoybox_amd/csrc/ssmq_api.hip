@@ -1592,6 +1592,25 @@ extern "C" int ssmq_filter_smooth_aug_dev(ssmq_transform *h_dyn, const ssmq_inte
     return SSMQ_OK;
 }
 
+// backward_pass alone (ssinf.py:120-147, 325-344) over moments a caller kept from its own forward pass - the marginalised
+// filter, whose forward pass is driven from the host (BFGS per step)
+extern "C" int ssmq_rts_backward_dev(int D, int64_t B, int64_t ld, int T, const double *d_fm, const double *d_fP,
+                                     const double *d_pm, const double *d_pP, const double *d_pC, double *d_sm, double *d_sP,
+                                     int32_t *d_status) {
+    if (D < 1 || B < 0 || T < 0 || ld < B || !d_fm || !d_fP || !d_pm || !d_pP || !d_pC || !d_sm || !d_sP || !d_status) {
+        set_error("rts_backward: bad argument");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0 || T == 0) return SSMQ_OK;
+    rc = launch_rts_backward(D, B, ld, T, d_fm, d_fP, d_pm, d_pP, d_pC, d_sm, d_sP, d_status, stream(), D);
+    hipError_t e = hipStreamSynchronize(stream());
+    if (rc) return rc;
+    SSMQ_HIP(e);
+    return SSMQ_OK;
+}
+
 extern "C" int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
                                       const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                                       const double *d_m0, const double *d_P0, const double *GQG, const double *R,
@@ -1739,16 +1758,19 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
         set_error("gp_theta_step: bad argument");
         return SSMQ_E_ARG;
     }
-    const int D = h_dyn->D, Y = h_obs->E, Nd = h_dyn->N, No = h_obs->N;
-    if (h_dyn->E != D || h_obs->D != D || h_dyn->form != SSMQ_FORM_BQ || h_obs->form != SSMQ_FORM_BQ ||
+    // Din > D: dynamics that take their noise as an argument - the caller passes the AUGMENTED moments [m; q_mean],
+    // blockdiag(P, Q) (ssinf.py:1174-1176) and GQG = NULL; the measurement model is additive (the reference builds its
+    // measurement transform on dim_state inputs, ssinf.py:1288, so it cannot run a non-additive one either)
+    const int Din = h_dyn->D, D = h_dyn->E, Y = h_obs->E, Nd = h_dyn->N, No = h_obs->N;
+    if (Din < D || h_obs->D != D || h_dyn->form != SSMQ_FORM_BQ || h_obs->form != SSMQ_FORM_BQ ||
         h_dyn->tp_nu > 0.0 || h_obs->tp_nu > 0.0) {
-        set_error("gp_theta_step: needs GP-quadrature transforms D -> D and D -> Y (additive-noise models)");
+        set_error("gp_theta_step: needs GP-quadrature transforms (D + dq) -> D and D -> Y");
         return SSMQ_E_ARG;
     }
     FInfo fid, fio;
     int rc = check_integrand(h_dyn, f_dyn, &fid);
     if (rc || (rc = check_integrand(h_obs, f_obs, &fio))) return rc;
-    if (wide_lds_bytes(D, D, Nd) > 160 * 1024 - 64 || wide_lds_bytes(D, Y, No) > 160 * 1024 - 64) {
+    if (wide_lds_bytes(Din, D, Nd) > 160 * 1024 - 64 || wide_lds_bytes(D, Y, No) > 160 * 1024 - 64) {
         set_error("gp_theta_step: shape too large for the LDS-resident generic kernel");
         return SSMQ_E_UNSUPPORTED;
     }
@@ -1756,19 +1778,19 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     if (P == 0) return SSMQ_OK;
     hipStream_t s = stream();
     const int64_t ld = (P + 63) / 64 * 64;
-    const WideLayout cld = wide_layout(D, D, Nd, SSMQ_FORM_BQ), clo = wide_layout(D, Y, No, SSMQ_FORM_BQ);
+    const WideLayout cld = wide_layout(Din, D, Nd, SSMQ_FORM_BQ), clo = wide_layout(D, Y, No, SSMQ_FORM_BQ);
     const int64_t ns = shared_state ? 1 : P;
     // ---- one device arena and two pinned host blocks, kept between calls (the marginalised filter calls this once per
     // BFGS iteration with a handful of items: forty allocations and three synchronisations per call were 310 us) -----------
     // input block, same layout on host and device:  xi_dyn | xi_obs | par_dyn | par_obs | mean | cov | y (planes) | GQG | R | t
-    const size_t n_in = (size_t)D * Nd + (size_t)D * No + 2 * (size_t)P * (1 + D) + (size_t)ns * (D + D * D) + (size_t)ld * Y +
-                        (size_t)D * D + (size_t)Y * Y + 1;
+    const size_t n_in = (size_t)Din * Nd + (size_t)D * No + (size_t)P * (1 + Din) + (size_t)P * (1 + D) +
+                        (size_t)ns * (Din + Din * Din) + (size_t)ld * Y + (size_t)D * D + (size_t)Y * Y + 1;
     // work planes: m_pr D | P_pr D*D | C_xx D*D | y_mean Y | P_y Y*Y | P_yx Y*D, then the output block m_fi D | P_fi D*D |
     // loglik 1 | merged status (int32), then the five partial status vectors
-    const size_t n_mid = (size_t)D + 2 * (size_t)D * D + Y + (size_t)Y * Y + (size_t)Y * D;
+    const size_t n_mid = (size_t)D + (size_t)D * D + (size_t)D * Din + Y + (size_t)Y * Y + (size_t)Y * D;
     const size_t n_out = (size_t)D + (size_t)D * D + 1;
     const size_t out_bytes = sizeof(double) * n_out * ld + sizeof(int32_t) * ld;
-    const size_t ws_d = gp_weights_wide_ws_bytes(D, Nd, P), ws_o = gp_weights_wide_ws_bytes(D, No, P);
+    const size_t ws_d = gp_weights_wide_ws_bytes(Din, Nd, P), ws_o = gp_weights_wide_ws_bytes(D, No, P);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t off_in = 0, off_cd = al(sizeof(double) * n_in), off_co = off_cd + al(sizeof(double) * P * cld.total),
                  off_mid = off_co + al(sizeof(double) * P * clo.total), off_out = off_mid + al(sizeof(double) * n_mid * ld),
@@ -1783,12 +1805,12 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
             memcpy(h, src, sizeof(double) * n);
             h += n;
         };
-        put(h_dyn->xi.data(), (size_t)D * Nd);
+        put(h_dyn->xi.data(), (size_t)Din * Nd);
         put(h_obs->xi.data(), (size_t)D * No);
-        put(par_dyn, (size_t)P * (1 + D));
+        put(par_dyn, (size_t)P * (1 + Din));
         put(par_obs, (size_t)P * (1 + D));
-        put(mean, (size_t)ns * D);
-        put(cov, (size_t)ns * D * D);
+        put(mean, (size_t)ns * Din);
+        put(cov, (size_t)ns * Din * Din);
         for (int k = 0; k < Y; ++k) {                      // measurements straight into the plane layout
             for (int64_t i = 0; i < P; ++i) h[(size_t)k * ld + i] = y[(shared_y ? 0 : (size_t)i * Y) + k];
             for (int64_t i = P; i < ld; ++i) h[(size_t)k * ld + i] = 0.0;
@@ -1800,12 +1822,12 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     }
     SSMQ_HIP(hipMemcpyAsync(dev + off_in, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
     double *in = (double *)(dev + off_in);
-    double *xid = in; in += (size_t)D * Nd;
+    double *xid = in; in += (size_t)Din * Nd;
     double *xio = in; in += (size_t)D * No;
-    double *pard = in; in += (size_t)P * (1 + D);
+    double *pard = in; in += (size_t)P * (1 + Din);
     double *paro = in; in += (size_t)P * (1 + D);
-    double *min_ = in; in += (size_t)ns * D;
-    double *cin = in; in += (size_t)ns * D * D;
+    double *min_ = in; in += (size_t)ns * Din;
+    double *cin = in; in += (size_t)ns * Din * Din;
     double *ysoa = in; in += (size_t)ld * Y;
     double *gq = in; in += (size_t)D * D;
     double *rr = in; in += (size_t)Y * Y;
@@ -1813,12 +1835,12 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     double *cd = (double *)(dev + off_cd), *co = (double *)(dev + off_co);
     int32_t *st_wd = (int32_t *)(dev + off_st), *st_wo = st_wd + ld, *st_td = st_wo + ld, *st_to = st_td + ld, *st_up = st_to + ld;
     SSMQ_HIP(hipMemsetAsync(st_wd, 0, sizeof(int32_t) * 5 * ld, s));
-    if ((rc = gp_weights_wide_consts(D, D, Nd, xid, pard, (int)P, jitter, cd, st_wd, dev + off_ws, ws_d))) return rc;
+    if ((rc = gp_weights_wide_consts(Din, D, Nd, xid, pard, (int)P, jitter, cd, st_wd, dev + off_ws, ws_d))) return rc;
     if ((rc = gp_weights_wide_consts(D, Y, No, xio, paro, (int)P, jitter, co, st_wo, dev + off_ws, ws_o))) return rc;
     double *w = (double *)(dev + off_mid);
     double *m_pr = w; w += ld * D;
     double *P_pr = w; w += ld * D * D;
-    double *C_xx = w; w += ld * D * D;
+    double *C_xx = w; w += ld * D * Din;
     double *y_mean = w; w += ld * Y;
     double *P_y = w; w += ld * Y * Y;
     double *P_yx = w;
@@ -1829,15 +1851,15 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     int32_t *st_all = (int32_t *)w;
     WideArgs a;
     memset(&a, 0, sizeof(a));
-    a.D = D; a.E = D; a.N = Nd; a.form = SSMQ_FORM_BQ; a.mode = SSMQ_WIDE_FULL; a.fid = f_dyn->id; a.time_stride = 0;
+    a.D = Din; a.E = D; a.N = Nd; a.form = SSMQ_FORM_BQ; a.mode = SSMQ_WIDE_FULL; a.fid = f_dyn->id; a.time_stride = 0;
     a.emv_mode = h_dyn->emv_mode; a.tp_nu = 0.0; a.cov_scale = a.ccov_scale = 1.0;
     a.consts = cd; a.consts_stride = cld.total; a.cov_add = gq;
-    a.mean = min_; a.cov = cin; a.time = tt; a.es_in = 1; a.bs_mean = shared_state ? 0 : D;
-    a.bs_cov = shared_state ? 0 : (int64_t)D * D;
+    a.mean = min_; a.cov = cin; a.time = tt; a.es_in = 1; a.bs_mean = shared_state ? 0 : Din;
+    a.bs_cov = shared_state ? 0 : (int64_t)Din * Din;
     a.mean_f = m_pr; a.cov_f = P_pr; a.cov_fx = C_xx; a.es_out = ld; a.bs_mf = a.bs_cf = a.bs_cfx = 1; a.status = st_td;
     fill_fpar(f_dyn, &a.fp);
     if ((rc = hip_fail(launch_apply_wide(a, P, s), "k_apply_wide(theta, dyn)"))) return rc;
-    a.E = Y; a.N = No; a.fid = f_obs->id; a.emv_mode = h_obs->emv_mode; a.consts = co; a.consts_stride = clo.total;
+    a.D = D; a.E = Y; a.N = No; a.fid = f_obs->id; a.emv_mode = h_obs->emv_mode; a.consts = co; a.consts_stride = clo.total;
     a.cov_add = rr; a.mean = m_pr; a.cov = P_pr; a.es_in = ld; a.bs_mean = a.bs_cov = 1;
     a.mean_f = y_mean; a.cov_f = P_y; a.cov_fx = P_yx; a.status = st_to;
     fill_fpar(f_obs, &a.fp);

@@ -363,16 +363,23 @@ class MarginalInference(GaussianInference):
     the theta-conditioned state posteriors.  Every evaluation "weights(theta) -> two transforms -> update" runs on the
     device through `ssmq_gp_theta_step`, batched over theta: one call per finite-difference gradient
     (param_dim + 1 items) and one per marginalisation (2 param_dim items).  The optimiser itself is SciPy on the host, as
-    in the reference.  Additive-noise models and GP-quadrature transforms only.
+    in the reference.  GP-quadrature transforms; dynamics with additive noise or with the noise as an argument (the
+    augmented moments of ssinf.py:1174-1176); additive measurement models - the reference builds the measurement transform
+    on `dim_state` inputs (ssinf.py:1288) and cannot run a non-additive one either.
 
     Reference quirks kept: the measurement update evaluates both transforms at time index k, not k - 1
     (ssinf.py:112 passes k); the mixture covariance is the weighted sum of the conditional covariances, without the
-    spread-of-the-means term (ssinf.py:1114-1115)."""
+    spread-of-the-means term (ssinf.py:1114-1115); the predictive moments the smoother uses come from the generic time
+    update at index k - 1 (ssinf.py:104-107) with whatever weights the dynamics transform was LAST given - the dummy unit
+    parameters at the first step, afterwards those of the last parameter point of the previous step's marginalisation
+    (BQTransform.apply keeps the weights of its last `kern_par`, bq/bqmtran.py:93-95)."""
 
     def __init__(self, dyn, obs, tf_dyn, tf_obs, par_mean=None, par_cov=None):
         super().__init__(dyn, obs, tf_dyn, tf_obs)
-        if not self._additive:
-            raise NotImplementedError('the device theta-step covers additive-noise models')
+        if not self.mod_obs.noise_additive:
+            raise NotImplementedError('marginalised filter: the measurement transform is built on dim_state inputs '
+                                      '(ssinf.py:1288); a measurement model that takes its noise as an argument does not '
+                                      'run in the reference either')
         self.param_dyn_dim = self.mod_dyn.dim_in + 1
         self.param_obs_dim = self.mod_obs.dim_state + 1
         self.param_dim = self.param_dyn_dim + self.param_obs_dim
@@ -385,11 +392,29 @@ class MarginalInference(GaussianInference):
         self.param_pts_num = self.param_upts.shape[1]
         self.x_mean_fi, self.x_cov_fi = self.x0_mean, self.x0_cov
         self.fd_step = 1.4901161193847656e-08      # SciPy's default forward-difference step for BFGS
+        self._last_theta = None                    # parameters the reference's transforms would hold by now
+        self.pr_mean = self.pr_cov = self.pr_xx_cov = None
 
     def reset(self):
         super().reset()
         self.param_mean, self.param_cov = self.param_prior_mean, self.param_prior_cov
         self.x_mean_fi, self.x_cov_fi = self.x0_mean, self.x0_cov
+        self.pr_mean = self.pr_cov = self.pr_xx_cov = None
+        # _last_theta stays: the reference's reset() does not touch the weights its transforms were last given either
+
+    def _augment(self, mean, cov):
+        """ssinf.py:271-272 / 1174-1176: [mean; q_mean], blockdiag(cov, Q) for dynamics that take their noise as an argument;
+        mean (D,) / cov (D, D) or per-item (P, D) / (P, D, D)."""
+        if self.mod_dyn.noise_additive:
+            return mean, cov
+        mean, cov = np.asarray(mean, dtype=np.float64), np.asarray(cov, dtype=np.float64)
+        qm, qc = np.atleast_1d(self.q_mean), np.atleast_2d(self.q_cov)
+        D, dq = self.mod_dyn.dim_state, qm.shape[0]
+        m = np.concatenate((mean, np.broadcast_to(qm, mean.shape[:-1] + (dq,))), axis=-1)
+        c = np.zeros(cov.shape[:-2] + (D + dq, D + dq))
+        c[..., :D, :D] = cov
+        c[..., D:, D:] = qc
+        return m, c
 
     def theta_step(self, theta, mean, cov, y, time):
         """theta (P, param_dim) log-parameters; mean (D,) / cov (D, D) shared by all items or (P, D) / (P, D, D);
@@ -401,13 +426,14 @@ class MarginalInference(GaussianInference):
         D = self.mod_dyn.dim_state
         pd, ppd = _lib.as_c(np.exp(theta[:, :self.param_dyn_dim]))
         po, ppo = _lib.as_c(np.exp(theta[:, self.param_dyn_dim:]))
+        mean, cov = self._augment(mean, cov)
         mean, pm = _lib.as_c(mean)
         cov, pc = _lib.as_c(cov)
         y, py = _lib.as_c(y)
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
         f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
         h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
-        gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
+        gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T)) if self.mod_dyn.noise_additive else (None, None)
         rr, pr = _lib.as_c(self.r_cov)
         om, pom = _lib.out_c((P, D))
         oc, poc = _lib.out_c((P, D, D))
@@ -470,19 +496,68 @@ class MarginalInference(GaussianInference):
         mean, cov = self._state_posterior_moments(param_pts.T, y, time)
         self.x_mean_fi = np.einsum('ji,j->i', mean, self.param_wts)
         self.x_cov_fi = np.einsum('kij,k->ij', cov, self.param_wts)
+        self._last_theta = param_pts[:, -1].copy()       # the parameters the reference's transforms are left with
 
-    def forward_pass(self, data):
-        """data (dim_y, T) -> (D, T), (D, D, T).  ssinf.py:66-118: the generic time update of step k is overwritten by
-        the theta-conditioned ones inside the measurement update, so only the latter is run."""
+    def _predictive_moments(self, time):
+        """The generic time update of forward_pass (ssinf.py:104-107 -> :254-295), dynamics half: what the smoother later
+        reads as pr_mean / pr_cov / pr_xx_cov.  One device transform with the weights the reference's dynamics transform
+        holds at this point (see the class docstring)."""
+        par = None if self._last_theta is None else np.exp(self._last_theta[:self.param_dyn_dim])[None, :]
+        m_in, P_in = self._augment(np.asarray(self.x_mean_fi, dtype=float), np.asarray(self.x_cov_fi, dtype=float))
+        m_pr, P_pr, C = self.tf_dyn.apply(self.mod_dyn.dyn_eval, m_in, P_in, np.atleast_1d(float(time)), par)
+        if self.mod_dyn.noise_additive:
+            P_pr = P_pr + self.G.dot(self.q_cov).dot(self.G.T)
+        return m_pr, P_pr, C[:, :self.mod_dyn.dim_state]
+
+    def forward_pass(self, data, keep_predictive=True):
+        """data (dim_y, T) -> (D, T), (D, D, T).  ssinf.py:66-118.  The generic time update of step k only feeds the
+        smoother (its moments are overwritten by the theta-conditioned ones inside the measurement update):
+        keep_predictive=False skips it."""
         data = np.asarray(data, dtype=np.float64)
         T = data.shape[1]
         D = self.mod_dyn.dim_state
         fm, fP = np.zeros((D, T)), np.zeros((D, D, T))
+        pm, pP, pC = np.zeros((D, T)), np.zeros((D, D, T)), np.zeros((D, D, T))
         for k in range(1, T + 1):
+            if keep_predictive:
+                pm[:, k - 1], pP[..., k - 1], pC[..., k - 1] = self._predictive_moments(k - 1)
             self._measurement_update(data[:, k - 1], k)
             fm[:, k - 1], fP[..., k - 1] = self.x_mean_fi, self.x_cov_fi
         self.fi_mean, self.fi_cov = fm, fP
+        self.pr_mean, self.pr_cov, self.pr_xx_cov = (pm, pP, pC) if keep_predictive else (None, None, None)
         return fm, fP
+
+    def backward_pass(self):
+        """RTS smoothing of the last forward_pass (ssinf.py:120-147, inherited by the reference's MarginalInference): the
+        recursion on the device (`ssmq_rts_backward_dev`) over the moments the forward pass kept."""
+        assert self.fi_mean is not None and self.pr_mean is not None, 'run forward_pass (keep_predictive=True) first'
+        lib = _lib.load()
+        D, T = self.fi_mean.shape
+        ld = 64
+
+        def planes(a, n):             # (n..., T) -> [T][n][ld], trajectory 0
+            buf = np.zeros((T, n, ld))
+            buf[:, :, 0] = np.asarray(a, dtype=np.float64).reshape(n, T).T
+            if n == D * D:
+                buf[:, :, 1:] = np.eye(D).reshape(1, -1, 1)          # padding lanes are never read; keep them PD anyway
+            d = _lib.DeviceBuffer(buf.nbytes)
+            d.upload(buf)
+            return d
+        d_fm, d_fP = planes(self.fi_mean, D), planes(self.fi_cov, D * D)
+        d_pm, d_pP, d_pC = planes(self.pr_mean, D), planes(self.pr_cov, D * D), planes(self.pr_xx_cov, D * D)
+        d_sm, d_sP, d_st = _lib.DeviceBuffer(8 * T * D * ld), _lib.DeviceBuffer(8 * T * D * D * ld), _lib.DeviceBuffer(4 * ld)
+        d_st.zero()
+        _lib.check(lib.ssmq_rts_backward_dev(D, 1, ld, T, *(ctypes.c_void_p(b.ptr) for b in (d_fm, d_fP, d_pm, d_pP, d_pC, d_sm,
+                                                                                             d_sP, d_st))), 'ssmq_rts_backward_dev')
+        sm = d_sm.download((T, D, ld))[:, :, 0].T
+        sP = d_sP.download((T, D, D, ld))[..., 0].transpose(1, 2, 0)
+        st = int(d_st.download((ld,), dtype=np.int32)[0])
+        for b in (d_fm, d_fP, d_pm, d_pP, d_pC, d_sm, d_sP, d_st):
+            b.free()
+        if st:
+            raise np.linalg.LinAlgError('Matrix is not positive definite (a predictive covariance of the smoother)')
+        self.sm_mean, self.sm_cov = np.ascontiguousarray(sm), np.ascontiguousarray(sP)
+        return self.sm_mean, self.sm_cov
 
     def forward_pass_batch(self, data, **kwargs):
         """One trajectory after another: the Laplace step is a sequential host optimiser per trajectory."""
@@ -490,13 +565,13 @@ class MarginalInference(GaussianInference):
         out = []
         for b in range(data.shape[2]):
             self.reset()
-            out.append(self.forward_pass(data[..., b]))
+            out.append(self.forward_pass(data[..., b], keep_predictive=False))
         self.fi_mean = np.stack([o[0] for o in out], axis=-1)
         self.fi_cov = np.stack([o[1] for o in out], axis=-1)
         return self.fi_mean, self.fi_cov
 
     def backward_pass_batch(self):
-        raise NotImplementedError('no smoother for the marginalised filter on the device path')
+        raise NotImplementedError('the marginalised filter smooths one trajectory at a time: forward_pass + backward_pass')
 
     def kernel_name(self):
         return 'per theta batch: k_weights x2 | k_pack_wide_consts x2 | k_apply_wave x2 | k_kalman_update | k_gauss_logpdf'

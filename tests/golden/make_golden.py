@@ -685,8 +685,65 @@ def g10_referee():
     save('g10_referee', **out)
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# G11: marginalised GPQ filter - the smoother the reference inherits (ssinf.py:120-147 over the moments forward_pass keeps),
+# and dynamics that take their noise as an argument (augmented moments, ssinf.py:1174-1176)
+# ---------------------------------------------------------------------------------------------------------------
+class _RecordingMarginal(ssinf.MarginalizedGaussianProcessKalman):
+    """Records the Laplace moments of every step so that a comparison can take the optimiser out of the picture."""
+
+    def _param_posterior_moments(self, y, k):
+        super()._param_posterior_moments(y, k)
+        self.rec.append((self.param_mean.copy(), self.param_cov.copy()))
+
+
+def g11_marginal_smoother():
+    out = {}
+    rng = np.random.default_rng(11)
+    cases = {
+        'ungm': (ssmod.UNGMTransition(GaussRV(1, cov=np.atleast_2d(1.0)), GaussRV(1, cov=np.atleast_2d(10.0))),
+                 ssmod.UNGMMeasurement(GaussRV(1, cov=np.atleast_2d(1.0)), 1)),
+        'ungmna': (ssmod.UNGMNATransition(GaussRV(1, mean=np.array([1.0]), cov=np.atleast_2d(1.0)), GaussRV(1, cov=np.atleast_2d(10.0))),
+                   ssmod.UNGMMeasurement(GaussRV(1, cov=np.atleast_2d(1.0)), 1)),
+    }
+    steps = 10
+    # (the filter itself only for the additive model: with the noise as an argument the reference's _measurement_update
+    # allocates dim_in rows for the state mean, ssinf.py:1101, and forward_pass then fails to store it)
+    for name, (dyn, obs) in list(cases.items())[:1]:
+        np.random.seed(111)
+        x = dyn.simulate_discrete(steps, 1)
+        y = obs.simulate_measurements(x)[..., 0]
+        alg = _RecordingMarginal(dyn, obs, 'rbf', 'sr')
+        alg.rec = []
+        fm, fc = alg.forward_pass(y)
+        sm, sc = alg.backward_pass()
+        tag = name + '_'
+        out[tag + 'y'], out[tag + 'fm'], out[tag + 'fc'], out[tag + 'sm'], out[tag + 'sc'] = y, fm, fc, sm, sc
+        out[tag + 'pm'], out[tag + 'pc'], out[tag + 'pxx'] = alg.pr_mean[:, 1:], alg.pr_cov[..., 1:], alg.pr_xx_cov[..., 1:]
+        out[tag + 'tm'] = np.stack([r[0] for r in alg.rec], axis=-1)
+        out[tag + 'tc'] = np.stack([r[1] for r in alg.rec], axis=-1)
+    # theta-conditioned evaluations with the noise as an argument of the dynamics
+    dyn, obs = cases['ungmna']
+    alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'ut')
+    n = 10
+    theta = 0.6 * rng.standard_normal((n, alg.param_dim))
+    m = 1.0 + rng.standard_normal((n, 1)) * 2
+    P = 0.5 + rng.random((n, 1, 1)) * 3
+    yv = rng.standard_normal((n, 1)) * 3
+    k = rng.integers(0, 40, n)
+    pm, pc, ll = np.zeros((n, 1)), np.zeros((n, 1, 1)), np.zeros(n)
+    for i in range(n):
+        alg.x_mean_fi, alg.x_cov_fi = m[i].copy(), P[i].copy()
+        ll[i] = alg._param_log_likelihood(theta[i], yv[i], int(k[i]))
+        pm[i], pc[i] = alg._state_posterior_moments(theta[i], yv[i], int(k[i]))
+    for key, val in (('theta', theta), ('m', m), ('P', P), ('y', yv), ('k', k), ('pm', pm), ('pc', pc), ('ll', ll)):
+        out['na_' + key] = val
+    save('g11_marginal_smoother', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
     if 'g1' in which:
         g1_points()
     if 'g2' in which:
@@ -707,3 +764,5 @@ if __name__ == '__main__':
         g9_sweeps()
     if 'g10' in which:
         g10_referee()
+    if 'g11' in which:
+        g11_marginal_smoother()

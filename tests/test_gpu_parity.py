@@ -1059,6 +1059,64 @@ def test_marginal_filter_forward_pass(amd, golden):
     assert within(e_P.max(), 1e-11, 'marginal filter, reference Laplace moments injected: covariances over 12 steps')
 
 
+def test_marginal_filter_smoother_and_nonadditive_dynamics(amd, golden):
+    """(1) The smoother the reference's MarginalInference inherits (ssinf.py:120-147): with the reference's per-step Laplace
+    moments injected, the predictive moments forward_pass keeps (generic time update at index k - 1 with the weights of the
+    LAST parameter point of the previous step - bq/bqmtran.py:93-95 - the dummy unit parameters at step 1), the filtered
+    and the smoothed moments against the reference's.  (2) theta-conditioned steps for dynamics that take their noise as an
+    argument (UNGMNA; augmented moments, ssinf.py:1174-1176) against the reference's _param_log_likelihood /
+    _state_posterior_moments."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g11_marginal_smoother')
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'sr')
+    y = g['ungm_y']
+    T = y.shape[1]
+    pm, pP, pC = np.zeros((1, T)), np.zeros((1, 1, T)), np.zeros((1, 1, T))
+    fm, fP = np.zeros((1, T)), np.zeros((1, 1, T))
+    for k in range(1, T + 1):
+        pm[:, k - 1], pP[..., k - 1], pC[..., k - 1] = alg._predictive_moments(k - 1)
+        alg._measurement_update(y[:, k - 1], k, laplace=(g['ungm_tm'][:, k - 1], g['ungm_tc'][..., k - 1]))
+        fm[:, k - 1], fP[..., k - 1] = alg.x_mean_fi, alg.x_cov_fi
+    alg.fi_mean, alg.fi_cov, alg.pr_mean, alg.pr_cov, alg.pr_xx_cov = fm, fP, pm, pP, pC
+    smm, smP = alg.backward_pass()
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+    assert within(max(rel(fm, g['ungm_fm']), rel(fP, g['ungm_fc'])), 1e-10, 'marginal smoother: filtered moments, Laplace moments injected')
+    assert within(max(rel(pm, g['ungm_pm']), rel(pP, g['ungm_pc']), rel(pC, g['ungm_pxx'])), 1e-10,
+                  'marginal smoother: predictive moments kept by forward_pass')
+    assert within(max(rel(smm, g['ungm_sm']), rel(smP, g['ungm_sc'])), 1e-10, 'marginal smoother: smoothed moments vs reference')
+    assert np.array_equal(smm[:, -2:], fm[:, -2:])                      # the reference's indexing quirk (SURVEY app. B-9)
+    # the whole thing through the public calls (own BFGS runs: optimiser paths differ, loose)
+    alg2 = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'sr')
+    f2, _ = alg2.forward_pass(y)
+    s2, sP2 = alg2.backward_pass()
+    assert s2.shape == (1, T) and np.all(np.isfinite(s2)) and np.all(sP2 > 0) and np.median(np.abs(s2 - g['ungm_sm'])) < 0.05
+    # (2) noise as an argument of the dynamics
+    dyn = sm.UNGMNATransition(sm.GaussRV(1, mean=np.array([1.0])), sm.GaussRV(1, cov=np.array([[10.0]])))
+    alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'ut')
+    assert alg.param_dim == 3 + 2
+    worst = 0.0
+    for i in range(g['na_theta'].shape[0]):
+        alg.x_mean_fi, alg.x_cov_fi = g['na_m'][i], g['na_P'][i]
+        ll = alg._param_log_likelihood(g['na_theta'][i], g['na_y'][i], int(g['na_k'][i]))
+        m, c = alg._state_posterior_moments(g['na_theta'][i], g['na_y'][i], int(g['na_k'][i]))
+        worst = max(worst, abs(ll - g['na_ll'][i]) / max(1.0, abs(g['na_ll'][i])), rel(m, g['na_pm'][i]), rel(c, g['na_pc'][i]))
+    assert within(worst, 1e-9, 'marginal filter, noise as an argument of the dynamics: theta-conditioned steps vs reference')
+    # all items in one call = one at a time
+    alg.x_mean_fi, alg.x_cov_fi = g['na_m'][0], g['na_P'][0]
+    mb, cb, llb, st = alg.theta_step(g['na_theta'], g['na_m'][0], g['na_P'][0], g['na_y'][0], int(g['na_k'][0]))
+    m0, c0 = alg._state_posterior_moments(g['na_theta'][3], g['na_y'][0], int(g['na_k'][0]))
+    assert not st.any() and np.array_equal(mb[3], m0) and np.array_equal(cb[3], c0)
+    # the filter runs on such a model (the reference's own forward_pass fails to store its dim_in-sized state mean)
+    np.random.seed(0)
+    ys = 0.05 * np.cumsum(np.ones((1, 6)), axis=1)
+    fm3, fP3 = alg.forward_pass(ys)
+    assert fm3.shape == (1, 6) and np.all(np.isfinite(fm3)) and np.all(fP3 > 0)
+    with pytest.raises(NotImplementedError):
+        ssinf.MarginalizedGaussianProcessKalman(dyn, sm.UNGMNAMeasurement(sm.GaussRV(1), 1), 'rbf', 'ut')
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # simulators on the device (ssmod.py:168-199, 1011-1039), counter-based generator
 # ---------------------------------------------------------------------------------------------------------------
