@@ -63,7 +63,7 @@ __host__ __device__ inline TileGeom tile_geom(int D, int E, int N, bool tp) {
 #define SSMQ_TILE_OCC 2      // waves per SIMD the register allocation is held to
 #endif
 #ifndef SSMQ_TILE_WGS_PER_CU
-#define SSMQ_TILE_WGS_PER_CU 6
+#define SSMQ_TILE_WGS_PER_CU 2      // the resident number at this register count: every wave walks ~16 groups
 #endif
 template <int DM, int KS, int FC = -1>
 __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(const WideArgs a, int64_t B) {
@@ -78,6 +78,10 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
     const WideLayout cl = wide_layout(D, E, N, a.form);
     const double *cs = a.consts;
     const double nan = __builtin_nan("");
+    // BQ form, D <= 15: row 15 of the Wcc operand is free and carries wm, so the transformed mean comes out of the
+    // cross-covariance product (accumulator register 3 of the lanes q = 3) instead of a separate sum + cross-lane adds
+    const bool mrow = !sigma && D <= 15;
+    const int kq = mrow ? 3 : 0;                      // the k sub-index whose lanes hold the mean for the m m' product
 
     // ---- operand fragments of the constants, once per workgroup ---------------------------------------------------------
     double *fWc = lds;                              // [NB][KS][64]  lane (c, q): Wc[16 blk + c][4 s + q]
@@ -100,13 +104,13 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
         const int d = l & 15, n = 4 * s + (l >> 4);
         double w = 0.0;
         if (d < D && n < N) w = sigma ? cs[cl.xiT + n * D + d] * cs[cl.Wc + n] : cs[cl.Wcc + d * N + n];
+        if (mrow && d == 15 && n < N) w = cs[cl.wm + n];      // BQ form: the mean rides along as row 15 of P' = Wcc FX'
         fWcc[i] = w;
         fWm[i] = n < N ? cs[cl.wm + n] : 0.0;
     }
     // ---- the wave's slice: factor + mean and FX tile per trajectory --------------------------------------------------------
     double *wbase = lds + tg.frag_doubles + (size_t)wave * tg.wave_doubles;
     const int per_traj = D * D + D + E * 4 * KSP;
-    int *s_ok = (int *)(wbase + G * per_traj);
     for (int i = lane; i < tg.wave_doubles; i += 64) wbase[i] = 0.0;     // the tile's padding (n >= N) stays zero for good
     __syncthreads();
 
@@ -121,6 +125,19 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
         add_r[r] = (in && a.cov_add) ? a.cov_add[e1 * E + e2] : 0.0;
     }
     const double tp_den = tp ? 1.0 / (a.tp_nu - 2.0 + (double)N) : 0.0;
+    // what this lane stores per trajectory: plane indices and a mask (bit r: covariance entry (e1, e2) with e2 <= e1,
+    // bit 4 + r: its mirror image, bit 8 + r: cross-covariance entry (c, q + 4 r))
+    int pl_cov[4], pl_cvt[4], pl_cc[4], smask = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e1 = q + 4 * r, e2 = c;
+        pl_cov[r] = e1 * E + e2;
+        pl_cvt[r] = e2 * E + e1;
+        pl_cc[r] = c * D + e1;
+        if (e1 < E && e2 <= e1) smask |= 1 << r;
+        if (e1 < E && e2 < e1) smask |= 16 << r;
+        if (c < E && e1 < D) smask |= 256 << r;
+    }
 
     const int gi = lane / GL, gl = lane - gi * GL;
     const int64_t n_groups = (B + G - 1) / G;
@@ -182,10 +199,7 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
                 if (k < D) sL[gl * D + k] = k <= gl ? rowv[k] : 0.0;
             sm[gl] = my_m;
         }
-        if (active && gl == 0) {
-            if (a.status) a.status[b] = ok ? 0 : 1;
-            s_ok[gi] = ok ? 1 : 0;
-        }
+        if (active && gl == 0 && a.status) a.status[b] = ok ? 0 : 1;
         SSMQ_WAVE_SYNC();
         // ---- 2. lane (g, n): sigma point and integrand, values into the trajectory's tile -------------------------------------
         if (active && gl < N) {
@@ -227,30 +241,38 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
             }
             const int pos = (n & 3) * KSP + (n >> 2);
 #pragma unroll
-            for (int e = 0; e < DM; ++e)
-                if (e < E) sfx[e * 4 * KSP + pos] = o[e];
+            for (int e = 0; e < DM; ++e)                 // a covariance that is not positive definite poisons every output
+                if (e < E) sfx[e * 4 * KSP + pos] = ok ? o[e] : nan;
         }
         SSMQ_WAVE_SYNC();
+        // The next group's inputs (requested at the top of this iteration) are taken into registers NOW, while nothing else is
+        // outstanding: the compiler would otherwise wait for them at their first use, after this iteration's stores have been
+        // issued - and the in-order memory counter then makes that wait cover every store acknowledgement as well.
+#pragma unroll
+        for (int k = 0; k < DM; ++k) asm volatile("" : "+v"(in_row[k]));
+        asm volatile("" : "+v"(in_m));
         // ---- 3. one trajectory at a time on the matrix cores; lane (c, q) = column c, k sub-index q ------------------------------
         for (int g = 0; g < G; ++g) {
             const int64_t bb = b0 + g;
             if (bb >= B) break;                                  // wave-uniform
             const double *tL = wbase + g * per_traj, *tfx = tL + D * D + D;
-            const bool okg = s_ok[g] != 0;
             double f[KSM];
 #pragma unroll
             for (int s = 0; s < KSM; ++s) f[s] = c < E ? tfx[(c * 4 + q) * KSP + s] : 0.0;
-            // mean: column c, the four k sub-indices summed across the lane groups
-            double mpart = 0.0;
+            double mc = 0.0;
+            if (!mrow) {
+                // mean: column c, the four k sub-indices summed across the lane groups
+                double mpart = 0.0;
 #pragma unroll
-            for (int s = 0; s < KSM; ++s) mpart = fma(fWm[s * 64 + lane], f[s], mpart);
-            mpart += __shfl_xor(mpart, 16, 64);
-            mpart += __shfl_xor(mpart, 32, 64);
-            const double mc = mpart;
-            if (sigma) {
+                for (int s = 0; s < KSM; ++s) mpart = fma(fWm[s * 64 + lane], f[s], mpart);
+                mpart += __shfl_xor(mpart, 16, 64);
+                mpart += __shfl_xor(mpart, 32, 64);
+                mc = mpart;
+                if (sigma) {
 #pragma unroll
-                for (int s = 0; s < KSM; ++s)
-                    if (4 * s + q < N) f[s] -= mc;
+                    for (int s = 0; s < KSM; ++s)
+                        if (4 * s + q < N) f[s] -= mc;
+                }
             }
             v4d acc[NBM], cov = {0.0, 0.0, 0.0, 0.0}, sq = {0.0, 0.0, 0.0, 0.0};
             auto quadratic = [&](const double *fA, v4d &out) {     // out = FX A FX' (A symmetric N x N, as fragments)
@@ -269,10 +291,11 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
             };
             quadratic(fWc, cov);
             if (tp) quadratic(fIK, sq);
-            // cross-covariance: P' = Wcc FX' (rows d), then ccov' = L P'
+            // cross-covariance: P' = Wcc FX' (rows d; row 15 = the mean), then ccov' = L P'
             v4d pacc = {0.0, 0.0, 0.0, 0.0}, cc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < KSM; ++s) pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(fWcc[s * 64 + lane], f[s], pacc, 0, 0, 0);
+            if (mrow) mc = pacc[3];                               // lanes q = 3: row 15 of P', column c
 #pragma unroll
             for (int t4 = 0; t4 < (DM + 3) / 4; ++t4) {
                 if (4 * t4 < D) {
@@ -281,29 +304,28 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
                     cc = __builtin_amdgcn_mfma_f64_16x16x4f64(lf, pacc[t4], cc, 0, 0, 0);
                 }
             }
-            // ---- stores: mean (q = 0 lanes), covariance for e2 <= e1 mirrored, cross-covariance ---------------------------------
+            // cov - m m': one more step of the same accumulation (A = -m, B = m in the lanes of one k sub-index)
+            const double am = (q == kq) ? mc : 0.0;
+            if (!sigma) cov = __builtin_amdgcn_mfma_f64_16x16x4f64(-am, am, cov, 0, 0, 0);
+            // ---- stores: mean, covariance for e2 <= e1 mirrored, cross-covariance ------------------------------------------------
             // plane index (32 bits) x plane pitch in bytes (32 bits) on top of the trajectory's wave-uniform base address
             auto at = [&](double *base, int idx) { return (double *)((char *)(base + bb) + (uint64_t)(uint32_t)idx * eo8); };
-            if (q == 0 && c < E) *at(a.mean_f, c) = okg ? mc : nan;
+            if (q == kq && c < E) *at(a.mean_f, c) = mc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int e1 = q + 4 * r, e2 = c;
-                const double m1 = __shfl(mc, e1 & 15, 64);       // lane e1 (q = 0) holds the mean of row e1
-                if (e1 < E && e2 <= e1) {
+                if (smask & (1 << r)) {
                     double v;
                     if (sigma) {
                         v = cov[r] * a.cov_scale + add_r[r];
                     } else {
                         double em = emv_r[r];
                         if (tp) em = (a.tp_nu - 2.0 + sq[r]) * tp_den * em;
-                        v = (cov[r] - m1 * mc + em) * a.cov_scale + add_r[r];
+                        v = (cov[r] + em) * a.cov_scale + add_r[r];
                     }
-                    v = okg ? v : nan;
-                    *at(a.cov_f, e1 * E + e2) = v;
-                    if (e2 != e1) *at(a.cov_f, e2 * E + e1) = v;
+                    *at(a.cov_f, pl_cov[r]) = v;
+                    if (smask & (16 << r)) *at(a.cov_f, pl_cvt[r]) = v;
                 }
-                const int dd = q + 4 * r;                         // ccov[e = c][d' = dd]
-                if (c < E && dd < D) *at(a.cov_fx, c * D + dd) = okg ? cc[r] * a.ccov_scale : nan;
+                if (smask & (256 << r)) *at(a.cov_fx, pl_cc[r]) = cc[r] * a.ccov_scale;
             }
         }
         SSMQ_WAVE_SYNC();        // the next group's inputs overwrite the slice

@@ -203,6 +203,29 @@ class SigmaPointTransform(_DeviceApply, MomentTransform):
         return dt.get(D, E, N, FORM_SIGMA, self.unit_sp, self.wm, wc, None, None, EMV_DIAG, 0.0, None)
 
 
+class MonteCarloTransform(SigmaPointTransform):
+    """Monte Carlo transform, the reference's baseline (mtran.py:62-94): n standard-normal unit points drawn once at
+    construction (np.random, as there), mean weights 1 / n, covariance weights 1 / (n - 1) - on the device it is a centred
+    sigma-point rule like the others (n <= 4096 = SSMQ_MAX_PTS; beyond 64 points the streaming route of k_apply_big).
+    The reference keeps the two weights as scalars; `wm` / `Wc` here are the expanded vector / diagonal matrix."""
+
+    def __init__(self, dim, n=100):
+        n = int(n)
+        if n < 2 or n > 4096:
+            raise ValueError('MonteCarloTransform: 2 <= n <= 4096 points on the device path')
+        wm, wc = self.weights(n)
+        self.wm, self.Wc = np.full(n, wm), np.diag(np.full(n, wc))
+        self.unit_sp = self.unit_sigma_points(dim, n)
+
+    @staticmethod
+    def weights(n):
+        return 1.0 / n, 1.0 / (n - 1)
+
+    @staticmethod
+    def unit_sigma_points(dim, n):
+        return np.random.multivariate_normal(np.zeros(dim), np.eye(dim), size=n).T
+
+
 class SphericalRadialTransform(SigmaPointTransform):
     """Spherical-radial rule, 2*dim points (mtran.py:152-204)."""
 

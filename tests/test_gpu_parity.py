@@ -208,6 +208,30 @@ def test_blocked_matrix_core_route(amd, golden, monkeypatch, kind, deg, name):
             assert within(np.abs(a_[:16] - b_).max() / np.abs(b_).max(), 1e-11, 'blocked route vs workgroup kernel {} {} {}'.format(kind, name, what))
 
 
+@pytest.mark.parametrize('n', [40, 1000])
+def test_monte_carlo_transform(amd, golden, n):
+    """MonteCarloTransform (mtran.py:62-94, the reference's baseline): unit points from np.random at construction, weights
+    1 / n and 1 / (n - 1); on the device a centred rule (k_apply_tile for n <= 64, the streaming route beyond).  Against the
+    oracle's centred moments on the transform's own points, and against a plain NumPy evaluation of the reference's lines."""
+    g = golden('g3_apply')
+    name = 'reentry_dyn'
+    fid, p, sidx, din, dout = MODELS[name]
+    mod, f = make_model(name)
+    means, covs, times = g[name + '_mean'], g[name + '_cov'], g[name + '_time']
+    np.random.seed(5)
+    tf = amd.MonteCarloTransform(din, n)
+    assert tf.unit_sp.shape == (din, n) and tf.kernel_name(f) in ('k_apply_tile', 'k_apply_wide', 'k_apply_big')
+    got = tf.apply_batch(f, means, covs, times.astype(float))
+    for i in range(0, means.shape[0], 5):
+        ref = orc.apply_sigma(fid, means[i], covs[i], times[i], tf.unit_sp, tf.wm, np.diag(tf.Wc), p, sidx)
+        assert_moments_close([a[i] for a in got], ref, covs[i], what=('mc', n, i))
+        x = means[i][:, None] + np.linalg.cholesky(covs[i]).dot(tf.unit_sp)                      # mtran.py:79-91 as written
+        fx = np.apply_along_axis(lambda c: orc.integrand(fid, c, times[i], p), 0, x)
+        mf = (1.0 / n * fx).sum(axis=1)
+        dfx = fx - mf[:, None]
+        assert np.allclose(got[0][i], mf, rtol=1e-12) and np.allclose(got[1][i], 1.0 / (n - 1) * dfx.dot(dfx.T), rtol=1e-9, atol=1e-12)
+
+
 def test_wave_kernel_matches_workgroup_kernel(amd, golden, monkeypatch):
     """Point sets of 9 ... 64 points without a register-resident specialisation run on k_apply_tile (every product on the
     matrix cores); SSMQ_NO_TILE=1 sends them to k_apply_wave (one wave per trajectory, lanes over output entries),
