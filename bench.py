@@ -334,7 +334,7 @@ class C5GemmBench:
 def measure_c5_unisolvent(amd, B=100000, iters=20):
     """The other half of BASELINE configs[4] as SURVEY 8d restates it: Bayes-Sard transform at D = E = 10 with the
     unscented point set, N = 21 = number of basis functions (unisolvent case), device-resident moments, device integrand
-    (k_apply_wave: generic shapes of up to 64 points, several trajectories per wave)."""
+    (k_apply_tile: generic shapes of 9-64 points, every product on the matrix cores)."""
     from ssmtoybox_amd import _lib, ssmod
     D = 10
     mi = np.hstack((np.zeros((D, 1), dtype=int), np.eye(D, dtype=int), 2 * np.eye(D, dtype=int)))
@@ -368,7 +368,7 @@ def measure_c5_unisolvent(amd, B=100000, iters=20):
     return {'kernel': name, 'ms_per_launch': ms, 'transforms_per_s': B / (ms * 1e-3), 'bound': 'hbm', 'achieved': gbs,
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'bytes_per_launch': alg,
             'workload': 'Bayes-Sard transform, D=E=10, unscented points N=21 = basis functions (unisolvent), B=1e5',
-            'note': 'compute-bound shape (~25k lane-operations for 2480 algorithmic bytes): see DESIGN.md 3.2'}
+            'note': 'latency / issue-bound shape (Cholesky chain, 28 dependent matrix steps per trajectory): DESIGN.md 3.7'}
 
 
 def measure_c5_degree7(amd, B=10000, iters=5, with_cpu=True):
@@ -589,7 +589,9 @@ def pmc_issue(kernel):
     OPT=..>); matched against the template arguments <D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, STU> of the profile."""
     import csv
     import re
-    path = os.path.join(ROOT, 'profiles', 'r02_fused_sq.csv')
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_fused_sq.csv')))      # the latest round's summary
+    path = found[-1] if found else os.path.join(ROOT, 'profiles', 'r02_fused_sq.csv')
     if not kernel.startswith('k_filter_fused<'):
         return None
     nums = [int(v) for v in re.findall(r'=(\d+)', kernel)]
@@ -625,7 +627,7 @@ def issue_block(kernel, T, ms_per_launch):
             'frac': achieved / peak, 'kernel': kernel,
             'valu_instructions_per_wave_per_step': valu_wave / T,
             'salu_instructions_per_wave_per_step': pm['SQ_INSTS_SALU'] / waves / T,
-            'pmc': {'source': 'profiles/r02_fused_sq.csv (rocprofv3 --pmc, tools/pmc_fused.sh)',
+            'pmc': {'source': 'profiles/r0*_fused_sq.csv, latest (rocprofv3 --pmc, tools/pmc_fused.sh)',
                     'frac_valu_x4_over_wave_cycles': pm['SQ_INSTS_VALU'] / pm['SQ_WAVE_CYCLES'],
                     'active_inst_valu_over_wave_cycles': pm['SQ_ACTIVE_INST_VALU'] / pm['SQ_WAVE_CYCLES'],
                     'wait_any_over_wave_cycles': pm['SQ_WAIT_ANY'] / pm['SQ_WAVE_CYCLES'],

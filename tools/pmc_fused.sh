@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of the bench kernels (k_filter_fused on UNGM - the headline - and on the reentry / coordinated-turn models,
 # the D = 6 transform, the D = 10 passes): two PMC passes over bench.py, no tracing domains.
-# Output: gpurun_out/pmc_fused/summary.csv (copied to profiles/r02_fused_sq.csv).
+# Output: gpurun_out/pmc_fused/summary.csv (copied to profiles/rNN_fused_sq.csv).
 set -e
 out=${1:-gpurun_out/pmc_fused}
 export TMPDIR=/tmp
@@ -12,7 +12,7 @@ python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-want = ('k_filter_fused', 'k_apply_small<6', 'k_fxwc', 'k_eval_wave')
+want = ('k_filter_fused', 'k_apply_small<6', 'k_fxwc', 'k_eval_wave', 'k_apply_tile', 'k_apply_wave', 'k_big_rest')
 for sub in ('a', 'b'):
     for path in glob.glob(root + '/' + sub + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(path)):
