@@ -50,14 +50,20 @@ def pmc_traffic(kernel_name, grid=None):
         return None
     import re
     base = kernel_name.split('<')[0]
-    want = [int(v) for v in re.findall(r'=(\d+)', kernel_name)]
-    nshape = 4 if 'fused' in base else 3           # (D, Y, ND, NO) or (D, E, N) identify the shape
+    nums = [int(v) for v in re.findall(r'=(\d+)', kernel_name)]
+    if 'fused' in base:
+        # reported name: <D=,Y=,ND=,NO=,F_DYN,F_OBS,FORM,TP=,SELO=,OPT=>; profile: <D,Y,ND,NO,FD,FO,FORM,TP,SELO,OPT,STU>
+        want = nums[:4] + [1 if 'SSMQ_FORM_SIGMA' in kernel_name else 0] + nums[4:7]
+        pick = lambda t: t[:4] + t[6:10]
+    else:
+        want = nums[:3]                                # (D, E, N) identify the shape
+        pick = lambda t: t[:3]
     hits = []
     for key, rec in table.items():
         if key.startswith('_') or key.split('<')[0] != base:
             continue
-        have = [int(v) for v in re.findall(r'(\d+)', key.split('<', 1)[1].split('>')[0])]
-        if have[:nshape] == want[:nshape]:
+        have = [int(v) for v in re.findall(r'-?\d+', key.split('<', 1)[1].split('>')[0])]
+        if pick(have) == want:
             hits.append(rec)
     if grid is not None:
         hits = [r for r in hits if int(r.get('grid', -1)) == int(grid)]
