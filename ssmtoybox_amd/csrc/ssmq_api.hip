@@ -392,7 +392,9 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     }
     const bool wide_fits = wide_lds_bytes(h->D, h->E, h->N) <= 160 * 1024 - 64;
     // point sets beyond the wave kernels without a fused matrix-core instantiation: evaluation pass, blocked GEMM, rest
-    const bool big = !se && h->N > 64 && ((h->form == SSMQ_FORM_BQ && h->d_wc_blk && (B * h->E >= kGemmMinRows || !wide_fits) &&
+    // (the kernel-name query runs with B = 0: it reports the route of a large batch)
+    const int64_t b_route = dry_run ? ((int64_t)1 << 20) : B;
+    const bool big = !se && h->N > 64 && ((h->form == SSMQ_FORM_BQ && h->d_wc_blk && (b_route * h->E >= kGemmMinRows || !wide_fits) &&
                                            (h->tp_nu <= 0.0 || h->d_ik_blk)) ||
                                           (h->form == SSMQ_FORM_SIGMA && !wide_fits));
     if (kernel_name) *kernel_name = se ? se->name : big ? "k_apply_big" : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");

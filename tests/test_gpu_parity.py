@@ -159,12 +159,14 @@ def test_apply_generic_kernel_matches(amd, golden, name):
         assert_moments_close([a[i] for a in got], ref, covs[i], what=(name, i, tf.kernel_name(f)))
 
 
-@pytest.mark.parametrize('kind,deg,name', [('gp', 3, 'reentry_dyn'), ('tp', 3, 'reentry_dyn'), ('bs', 3, 'ct_dyn'), ('gp', 3, 'ctrs_dyn')])
-def test_blocked_matrix_core_route(amd, golden, monkeypatch, kind, deg, name):
+@pytest.mark.parametrize('kind,pstr,deg,name', [('gp', 'gh', 3, 'cv_dyn'), ('tp', 'fs', 5, 'ctrs_dyn'), ('bs', 'gh', 3, 'cv_dyn'),
+                                                ('gp', 'gh', 3, 'ctrs_dyn')])
+def test_blocked_matrix_core_route(amd, golden, monkeypatch, kind, pstr, deg, name):
     """BQ transforms on point sets beyond the wave kernels that have no instantiation of the fused matrix-core route
-    (Gauss-Hermite degree 3 at D = 5: N = 243, at D = 7: N = 2187): evaluation pass, T = FX Wc by column blocks of 256 on the
-    matrix cores (and fx iK for the t-process), per-trajectory rest (k_apply_big) - against the oracle with the device's own
-    weights, and against the LDS-resident workgroup kernel where the shape fits it."""
+    (Gauss-Hermite degree 3 at D = 4: N = 81, at D = 7: N = 2187; fully-symmetric degree 5 at D = 7: N = 99): evaluation pass,
+    T = FX [Wc | Wcc'] by column blocks of 256 on the matrix cores (and fx iK for the t-process), per-trajectory rest
+    (k_apply_big) - against the oracle with the device's own weights, and against the LDS-resident workgroup kernel where the
+    shape fits it."""
     g = golden('g3_apply')
     fid, p, sidx, din, dout = MODELS[name]
     mod, f = make_model(name)
@@ -173,11 +175,12 @@ def test_blocked_matrix_core_route(amd, golden, monkeypatch, kind, deg, name):
     means, covs, times = np.tile(means, (reps, 1)), np.tile(covs, (reps, 1, 1)), np.tile(times, reps)
     par = np.array([[1.0] + [3.0] * din])
     mi = np.hstack((np.zeros((din, 1)), np.eye(din), 2 * np.eye(din))).astype(int)
-    tf = {'gp': lambda: amd.GaussianProcessTransform(din, dout, par, 'rbf', 'gh', {'degree': deg}),
-          'tp': lambda: amd.StudentTProcessTransform(din, dout, par, 'rbf', 'gh', {'degree': deg}),
-          'bs': lambda: amd.BayesSardTransform(din, dout, par, mi, 'gh', {'degree': deg})}[kind]()
+    make = {'gp': lambda: amd.GaussianProcessTransform(din, dout, par, 'rbf', pstr, {'degree': deg}),
+            'tp': lambda: amd.StudentTProcessTransform(din, dout, par, 'rbf', pstr, {'degree': deg}),
+            'bs': lambda: amd.BayesSardTransform(din, dout, par, mi, pstr, {'degree': deg})}[kind]
+    tf = make()
     N = tf.model.points.shape[1]
-    assert N == deg ** din and tf.kernel_name(f) in ('k_apply_big', 'k_apply_wide')
+    assert N == (deg ** din if pstr == 'gh' else 2 * din * din + 1) and tf.kernel_name(f) == 'k_apply_big'
     got = tf.apply_batch(f, means, covs, times.astype(float), return_status=True)
     assert not got[3].any()
     w = dict(wm=tf.wm, Wc=tf.Wc, Wcc=tf.Wcc, model_var=tf.model.model_var, iK=getattr(tf.model, 'iK', None))
@@ -197,11 +200,9 @@ def test_blocked_matrix_core_route(amd, golden, monkeypatch, kind, deg, name):
         assert within(np.abs(a_ - b_[:nb]).max() / np.abs(b_[:nb]).max(), 1e-11, 'blocked route, host callable vs device integrand {} {} {}'.format(kind, name, what))
     if N <= 1024:
         monkeypatch.setenv('SSMQ_NO_MFMA', '1')
-        tf2 = {'gp': lambda: amd.GaussianProcessTransform(din, dout, par, 'rbf', 'gh', {'degree': deg}),
-               'tp': lambda: amd.StudentTProcessTransform(din, dout, par, 'rbf', 'gh', {'degree': deg}),
-               'bs': lambda: amd.BayesSardTransform(din, dout, par, mi, 'gh', {'degree': deg})}[kind]()
+        tf2 = make()
         tf2.wm, tf2.Wc, tf2.Wcc = tf.wm, tf.Wc, tf.Wcc
-        assert tf2.kernel_name(f) == 'k_apply_wide'
+        assert tf2.kernel_name(f) == 'k_apply_wide'        # SSMQ_NO_MFMA: no column blocks are built
         ref = tf2.apply_batch(f, means[:16], covs[:16], times[:16].astype(float))
         monkeypatch.delenv('SSMQ_NO_MFMA')
         for a_, b_, what in zip(got[:3], ref, ('mean', 'cov', 'ccov')):
@@ -1911,6 +1912,74 @@ def test_random_shapes_against_oracle(amd):
                 ref = orc.moments_bq(fx[b], chol[b], wm, Wc, Wcc, ed)
             for got, want in zip((mf[b], cf[b], cfx[b]), ref):
                 assert np.allclose(got, want, rtol=1e-11, atol=1e-11 * max(1.0, np.abs(want).max())), (trial, D, E, N, form, tp)
+
+
+def test_generic_routes_random_point_sets(amd):
+    """The run-time-shape routes on RANDOM rules (points, weights, model variances drawn at random - no structure a
+    kernel could lean on) with the reference's models as device integrands: k_apply_tile (9 ... 64 points), the blocked
+    matrix-core route (65 ... 700 points, batches above its minimum row count) and the workgroup kernel (small batches),
+    BQ / t-process / centred forms, sub-state measurement models - against the oracle's moments of the same rule."""
+    from ssmtoybox_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(303)
+    names = ('reentry_dyn', 'radar_meas', 'ct_dyn', 'bearing_meas', 'pend_dyn', 'cv_dyn', 'reentry1d_dyn', 'ctrs_dyn', 'ungm_dyn')
+    seen = set()
+    for trial in range(36):
+        name = names[trial % len(names)]
+        fid, p, sidx, D, E = MODELS[name]
+        N = int(rng.integers(9, 65)) if trial % 2 == 0 else int(rng.integers(65, 700))
+        form = int(rng.integers(0, 2))
+        tp = (form == 0) and bool(rng.integers(0, 2))
+        B = int(rng.integers(1, 40)) if trial % 3 == 0 else int(rng.integers(260, 400))
+        xi = rng.standard_normal((D, N))
+        wm = rng.random(N)
+        wm /= wm.sum()
+        Wc = rng.standard_normal((N, N)) / N
+        Wc = Wc + Wc.T
+        wcd = rng.random(N) / N
+        Wcc = rng.standard_normal((D, N)) / N
+        emv = np.diag(rng.random(E))
+        iK = rng.standard_normal((N, N))
+        iK = iK.dot(iK.T) / N
+        h = lib.ssmq_transform_create(D, E, N, form, _lib.as_c(xi)[1], _lib.as_c(wm)[1], _lib.as_c(wcd if form else Wc)[1],
+                                      None if form else _lib.as_c(Wcc)[1], _lib.as_c(emv)[1], 0, 4.0 if tp else 0.0,
+                                      _lib.as_c(iK)[1] if tp else None)
+        assert h, (name, N, form)
+        integ = _lib.Integrand.make(fid, p, sidx)
+        buf = ctypes.create_string_buffer(256)
+        lib.ssmq_apply_kernel_name(ctypes.c_void_p(h), ctypes.byref(integ), buf, 256)
+        if name == 'ungm_dyn':
+            means = rng.standard_normal((B, D))
+        else:
+            g0 = {'reentry_dyn': [6500.4, 349.14, -1.8093, -6.7967, 0.6932], 'radar_meas': [6500.4, 349.14, -1.8, -6.8, 0.7],
+                  'ct_dyn': [1000, 300, 1000, 0, -0.05], 'bearing_meas': [100, 3, 200, 0, -0.05], 'pend_dyn': [1.5, 0.0],
+                  'cv_dyn': [10.0, 1.0, -5.0, 0.5], 'reentry1d_dyn': [90.0, 6.0, 1.5], 'ctrs_dyn': [0, 0, 10, 0.3, 0.05, 0, 0]}[name]
+            means = np.array(g0, dtype=float) + 0.01 * rng.standard_normal((B, D))
+        a_ = rng.standard_normal((B, D, D)) / np.sqrt(D)
+        covs = 1e-3 * (np.einsum('bij,bkj->bik', a_, a_) + 0.2 * np.eye(D))
+        times = np.full(B, 3.0)
+        mf, cf, cfx = np.empty((B, E)), np.empty((B, E, E)), np.empty((B, E, D))
+        st = np.zeros(B, dtype=np.int32)
+        rc = lib.ssmq_apply_batch(ctypes.c_void_p(h), ctypes.byref(integ), B, _lib.as_c(means)[1], _lib.as_c(covs)[1],
+                                  _lib.as_c(times)[1], 1, _lib.as_c(mf)[1], _lib.as_c(cf)[1], _lib.as_c(cfx)[1],
+                                  st.ctypes.data_as(_lib.c_int32_p))
+        assert rc == 0 and not st.any(), (name, N, form, tp, B, buf.value)
+        lib.ssmq_transform_destroy(ctypes.c_void_p(h))
+        seen.add(buf.value.decode())
+        for b in range(0, B, max(1, B // 4)):
+            L = np.linalg.cholesky(covs[b])
+            x = means[b][:, None] + L.dot(xi)
+            fx = orc.eval_columns(fid, x, 3.0, p, sidx)
+            if form:
+                ref = orc.moments_sigma(fx, x, means[b], wm, wcd)
+            else:
+                ed = orc.tp_emv_diag(fx, iK, np.diag(emv), 4.0) if tp else np.diag(emv)
+                ref = orc.moments_bq(fx, L, wm, Wc, Wcc, ed)
+            # random weights of either sign: terms of size max|fx|^2 sum(|W|) cancel, that is the scale of the rounding
+            sc = max(1.0, float(np.abs(fx).max())) ** 2 * max(1.0, float(np.abs(wcd if form else Wc).sum()))
+            for got, want, s_ in zip((mf[b], cf[b], cfx[b]), ref, (np.sqrt(sc), sc, np.sqrt(sc))):
+                assert np.max(np.abs(got - want)) <= 1e-11 * s_, (trial, name, N, form, tp, B, buf.value, np.max(np.abs(got - want)) / s_)
+    assert {'k_apply_tile', 'k_apply_big'} <= seen, seen          # (small batches of the large rules run on k_apply_wide)
 
 
 def test_bsq_d10_device_integrand(amd, golden):
