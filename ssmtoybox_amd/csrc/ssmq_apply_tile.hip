@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
     const double nan = __builtin_nan("");
     // BQ form, D <= 15: row 15 of the Wcc operand is free and carries wm, so the transformed mean comes out of the
     // cross-covariance product (accumulator register 3 of the lanes q = 3) instead of a separate sum + cross-lane adds
-    const bool mrow = !sigma && D <= 15;
+    const bool mrow = !sigma && D <= 15 && a.wave_k == 0;     // (wave_k = 1: SSMQ_TILE_NO_MROW, to test the D = 16 path on smaller models)
     const int kq = mrow ? 3 : 0;                      // the k sub-index whose lanes hold the mean for the m m' product
 
     // ---- operand fragments of the constants, once per workgroup ---------------------------------------------------------
@@ -344,8 +344,10 @@ hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
     const int64_t groups = (B + tg.G - 1) / tg.G, blocks = (groups + kTileWaves - 1) / kTileWaves;
     // a few workgroups per CU, each walking its share of the batch: the constants' fragments are built once per workgroup
     const int64_t cap = 256 * SSMQ_TILE_WGS_PER_CU;
+    WideArgs aw = a;
+    aw.wave_k = getenv("SSMQ_TILE_NO_MROW") ? 1 : 0;
     hipLaunchKernelGGL((k_apply_tile<DM, KS, FC>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(64 * kTileWaves), lds, s,
-                       a, B);
+                       aw, B);
     return hipGetLastError();
 }
 
