@@ -9,6 +9,7 @@
 #include <thread>
 #include <vector>
 #include "ssmq_host.h"
+#include "ssmq_update.h"
 #include "ssmq_apply_small.h"
 
 namespace ssmq {
@@ -1203,9 +1204,11 @@ void reset_wide_attributes();
 void drop_staging_arena();
 static unsigned g_device_epoch = 1;
 unsigned device_epoch() { return g_device_epoch; }
+void drop_theta_step_graphs();
 void reset_device_caches() {
     ++g_device_epoch;
     g_fc.drop_graph();
+    drop_theta_step_graphs();
     g_fc.consts_ok = false;
     if (g_fc.ws) hipFree(g_fc.ws);
     g_fc.ws = nullptr;
@@ -1744,9 +1747,36 @@ int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double
                            double *d_consts, int32_t *d_status, void *ws, size_t ws_bytes);
 int launch_gauss_logpdf(int Y, int64_t B, int64_t ld, const double *y, const double *y_mean, const double *P_y,
                         double *out, hipStream_t s, const int32_t *merge = nullptr, int32_t *merge_out = nullptr);
+// the two-launch route of the theta-batched step (ssmq_weights.hip: k_theta_weights, ssmq_apply_wide.hip: k_theta_chain)
+bool gp_theta_weights_fits(int D0, int N0, int D1, int N1);
+int gp_theta_weights_pair(const int D[2], const int E[2], const int N[2], const double *const d_xi[2],
+                          const double *const d_par[2], int P, double jitter, double *const d_consts[2],
+                          int32_t *const d_status[2]);
+bool theta_chain_supported(int Din, int D, int Y, int Nd, int No);
+hipError_t launch_theta_chain(const WideArgs &dyn, const WideArgs &obs, const UpdArgs &upd, const double *y, double *loglik,
+                              const int32_t *merge, int32_t *merge_out, int64_t B, hipStream_t s);
 }
 
 
+
+namespace {
+struct ThetaGraph {
+    std::vector<uint64_t> key;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+std::vector<ThetaGraph> g_theta_graphs;
+void drop_theta_graphs() {
+    for (auto &g : g_theta_graphs) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+    }
+    g_theta_graphs.clear();
+}
+}  // namespace
+namespace ssmq {
+void drop_theta_step_graphs() { drop_theta_graphs(); }
+}
 
 // One filter step per parameter item: weights(theta_dyn) -> dyn transform -> + GQG -> weights(theta_obs) -> obs transform
 // -> + R -> measurement update and log N(y | y_mean, P_y).  Everything between the host arrays stays on the device.
@@ -1822,7 +1852,6 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
         if (R) put(R, (size_t)Y * Y); else { memset(h, 0, sizeof(double) * Y * Y); h += (size_t)Y * Y; }
         *h++ = time;
     }
-    SSMQ_HIP(hipMemcpyAsync(dev + off_in, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
     double *in = (double *)(dev + off_in);
     double *xid = in; in += (size_t)Din * Nd;
     double *xio = in; in += (size_t)D * No;
@@ -1836,9 +1865,28 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     double *tt = in;
     double *cd = (double *)(dev + off_cd), *co = (double *)(dev + off_co);
     int32_t *st_wd = (int32_t *)(dev + off_st), *st_wo = st_wd + ld, *st_td = st_wo + ld, *st_to = st_td + ld, *st_up = st_to + ld;
-    SSMQ_HIP(hipMemsetAsync(st_wd, 0, sizeof(int32_t) * 5 * ld, s));
-    if ((rc = gp_weights_wide_consts(Din, D, Nd, xid, pard, (int)P, jitter, cd, st_wd, dev + off_ws, ws_d))) return rc;
-    if ((rc = gp_weights_wide_consts(D, Y, No, xio, paro, (int)P, jitter, co, st_wo, dev + off_ws, ws_o))) return rc;
+    // everything between the two pinned blocks as ONE unit.  The launch-per-stage route (ten launches + two copies) runs
+    // eagerly the first time a (shape, item count) is seen, is captured into a hipGraph the second time and replayed from
+    // then on: the marginalised filter calls this hundreds of times with two item counts (gradient: param_dim + 1,
+    // marginalisation: 2 param_dim); 89 -> 76 us per call at P = 7
+    // two launches - k_theta_weights (both transforms' weights, LDS-resident) and k_theta_chain (transform -> transform ->
+    // update -> log-likelihood by the wave that owns the item) - where the point sets fit; else the launch per stage
+    const bool two_launch = theta_chain_supported(Din, D, Y, Nd, No) && gp_theta_weights_fits(Din, Nd, D, No);
+    auto enqueue = [&]() -> int {
+    int rc;
+    SSMQ_HIP(hipMemcpyAsync(dev + off_in, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
+    if (!two_launch) {
+        SSMQ_HIP(hipMemsetAsync(st_wd, 0, sizeof(int32_t) * 5 * ld, s));
+        if ((rc = gp_weights_wide_consts(Din, D, Nd, xid, pard, (int)P, jitter, cd, st_wd, dev + off_ws, ws_d))) return rc;
+        if ((rc = gp_weights_wide_consts(D, Y, No, xio, paro, (int)P, jitter, co, st_wo, dev + off_ws, ws_o))) return rc;
+    } else {
+        // every flag vector is written by the two kernels themselves (padding items beyond P are never read back)
+        const int dd[2] = {Din, D}, ee[2] = {D, Y}, nn[2] = {Nd, No};
+        const double *const xx[2] = {xid, xio}, *const pp[2] = {pard, paro};
+        double *const cc[2] = {cd, co};
+        int32_t *const ss[2] = {st_wd, st_wo};
+        if ((rc = gp_theta_weights_pair(dd, ee, nn, xx, pp, (int)P, jitter, cc, ss))) return rc;
+    }
     double *w = (double *)(dev + off_mid);
     double *m_pr = w; w += ld * D;
     double *P_pr = w; w += ld * D * D;
@@ -1860,16 +1908,62 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     a.bs_cov = shared_state ? 0 : (int64_t)Din * Din;
     a.mean_f = m_pr; a.cov_f = P_pr; a.cov_fx = C_xx; a.es_out = ld; a.bs_mf = a.bs_cf = a.bs_cfx = 1; a.status = st_td;
     fill_fpar(f_dyn, &a.fp);
-    if ((rc = hip_fail(launch_apply_wide(a, P, s), "k_apply_wide(theta, dyn)"))) return rc;
+    const WideArgs a_dyn = a;
+    if (!two_launch && (rc = hip_fail(launch_apply_wide(a, P, s), "k_apply_wide(theta, dyn)"))) return rc;
     a.D = D; a.E = Y; a.N = No; a.fid = f_obs->id; a.emv_mode = h_obs->emv_mode; a.consts = co; a.consts_stride = clo.total;
     a.cov_add = rr; a.mean = m_pr; a.cov = P_pr; a.es_in = ld; a.bs_mean = a.bs_cov = 1;
     a.mean_f = y_mean; a.cov_f = P_y; a.cov_fx = P_yx; a.status = st_to;
     fill_fpar(f_obs, &a.fp);
+    if (two_launch) {
+        const UpdArgs u{m_pr, P_pr, y_mean, P_y, P_yx, ysoa, m_fi, P_fi, st_up, nullptr, nullptr, P, ld, 0, D, Y, 0.0, nullptr, D};
+        if ((rc = hip_fail(launch_theta_chain(a_dyn, a, u, ysoa, ll, st_wd, st_all, P, s), "k_theta_chain"))) return rc;
+    } else {
     if ((rc = hip_fail(launch_apply_wide(a, P, s), "k_apply_wide(theta, obs)"))) return rc;
     if ((rc = launch_kalman_update(D, Y, P, ld, m_pr, P_pr, y_mean, P_y, P_yx, ysoa, m_fi, P_fi, st_up, s))) return rc;
     // log-likelihood and the merged status flags in one launch (the five partial vectors are contiguous, pitch ld)
     if ((rc = launch_gauss_logpdf(Y, P, ld, ysoa, y_mean, P_y, ll, s, st_wd, st_all))) return rc;
+    }
     SSMQ_HIP(hipMemcpyAsync(g_stage.hout, dev + off_out, out_bytes, hipMemcpyDeviceToHost, s));
+    return SSMQ_OK;
+    };
+    {
+        std::vector<uint64_t> key = {(uint64_t)(uintptr_t)dev, (uint64_t)(uintptr_t)hin, (uint64_t)(uintptr_t)g_stage.hout, (uint64_t)P,
+                                     (uint64_t)Din, (uint64_t)D, (uint64_t)Y, (uint64_t)Nd, (uint64_t)No, (uint64_t)shared_state,
+                                     (uint64_t)h_dyn->emv_mode, (uint64_t)h_obs->emv_mode, (uint64_t)total, (uint64_t)two_launch};
+        uint64_t jb;
+        memcpy(&jb, &jitter, sizeof(jb));
+        key.push_back(jb);
+        for (const ssmq_integrand *f : {f_dyn, f_obs}) {
+            const unsigned char *pb = (const unsigned char *)f;
+            uint64_t hsh = 1469598103934665603ull;
+            for (size_t i = 0; i < sizeof(ssmq_integrand); ++i) hsh = (hsh ^ pb[i]) * 1099511628211ull;
+            key.push_back(hsh);
+        }
+        ThetaGraph *tg = nullptr;
+        for (auto &g : g_theta_graphs)
+            if (g.key == key) tg = &g;
+        if (two_launch || getenv("SSMQ_NO_THETA_GRAPH")) {   // two launches + two copies: replay measured no faster (52 us either way)
+            if ((rc = enqueue())) return rc;
+        } else if (!tg) {
+            if (g_theta_graphs.size() >= 6) drop_theta_graphs();
+            g_theta_graphs.push_back(ThetaGraph{key, nullptr, nullptr});
+            if ((rc = enqueue())) return rc;
+        } else {
+            if (!tg->exec) {
+                SSMQ_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                rc = enqueue();
+                hipGraph_t g = nullptr;
+                hipError_t ce = hipStreamEndCapture(s, &g);
+                if (rc || ce != hipSuccess) {
+                    if (g) hipGraphDestroy(g);
+                    return rc ? rc : hip_fail(ce, "hipStreamEndCapture(theta step)");
+                }
+                tg->graph = g;
+                SSMQ_HIP(hipGraphInstantiate(&tg->exec, tg->graph, nullptr, nullptr, 0));
+            }
+            SSMQ_HIP(hipGraphLaunch(tg->exec, s));
+        }
+    }
     SSMQ_HIP(hipStreamSynchronize(s));
     // planes -> the caller's item-major arrays
     const double *ho = (const double *)g_stage.hout;

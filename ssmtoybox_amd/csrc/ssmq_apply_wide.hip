@@ -7,6 +7,7 @@
 // entries (e, j) for T = fx Wc (Wc rows streamed from L2, coalesced over j) and for every (E x E) / (E x D) result.
 #include "ssmq_device.h"
 #include "ssmq_wide.h"
+#include "ssmq_update.h"
 
 namespace ssmq {
 
@@ -427,18 +428,20 @@ __host__ __device__ inline int wave_lds_doubles(int D, int E, int N, bool tp) { 
     return D * D + D + E + E * m + (tp ? E * E : 0) + (E + m) * N + 2;
 }
 
-template <int DM, int FC = -1>
-__global__ __launch_bounds__(64 * kWaveWaves) void k_apply_wave(const WideArgs a, int64_t B) {
-    extern __shared__ __align__(16) double lds[];
+// The body, for the wave with global index `wid` (trajectories wid K ... wid K + K - 1) and its LDS slice `lw` (K
+// groups of wave_lds_doubles): k_apply_wave below runs it once, k_theta_chain twice in a row.  False when the wave has no
+// trajectory (nothing done, nothing synchronised).
+template <int DM, int FC>
+__device__ __forceinline__ bool apply_wave_body(const WideArgs &a, int64_t B, int64_t wid, double *lw) {
     const int D = a.D, E = a.E, N = a.N;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int K = a.wave_k, G = 64 / K, gi = lane / G, gl = lane - gi * G;   // G >= N lanes per trajectory
-    const int64_t b0 = ((int64_t)blockIdx.x * kWaveWaves + wave) * K;
-    if (b0 >= B) return;                        // whole waves leave; no workgroup barrier below
+    const int64_t b0 = wid * K;
+    if (b0 >= B) return false;                  // whole waves leave; no workgroup barrier below
     const int64_t b = b0 + gi;
     const bool active = gi < K && b < B;        // idle lanes still take part in the wave-scope synchronisation
     const int stride = (wave_lds_doubles(D, E, N, a.tp_nu > 0.0) + 1) & ~1;
-    double *sL = lds + ((size_t)wave * K + (gi < K ? gi : 0)) * stride;   // D*D factor (pitch D)
+    double *sL = lw + (size_t)(gi < K ? gi : 0) * stride;   // D*D factor (pitch D)
     double *sm = sL + D * D;                    // D    input mean
     double *smf = sm + D;                       // E    transformed mean
     double *sC = smf + E;                       // E*E  fx Wc fx', then (same place) sg: E*D fx Wcc'
@@ -640,6 +643,15 @@ __global__ __launch_bounds__(64 * kWaveWaves) void k_apply_wave(const WideArgs a
     }
 #undef OUT_ADDR
 #undef SSMQ_WAVE_SYNC
+    return true;
+}
+
+template <int DM, int FC = -1>
+__global__ __launch_bounds__(64 * kWaveWaves) void k_apply_wave(const WideArgs a, int64_t B) {
+    extern __shared__ __align__(16) double lds[];
+    const int wave = threadIdx.x >> 6;
+    const int stride = (wave_lds_doubles(a.D, a.E, a.N, a.tp_nu > 0.0) + 1) & ~1;
+    apply_wave_body<DM, FC>(a, B, (int64_t)blockIdx.x * kWaveWaves + wave, lds + (size_t)wave * a.wave_k * stride);
 }
 
 // trajectories per wave: as many as there are N-lane groups, but not so many that the LDS slices leave the SIMDs with
@@ -682,6 +694,97 @@ static hipError_t launch_apply_wave(const WideArgs &a, int64_t B, hipStream_t s)
     else if (dm <= 12) e = launch_wave_one<12, -1>(a, B, s);
     else e = launch_wave_one<SSMQ_MAX_DIM, -1>(a, B, s);
     return e;
+}
+
+// ---- the theta-batched step after its weights, ONE launch (ssmq_gp_theta_step) ------------------------------
+// time update -> measurement transform -> Kalman update -> log-likelihood of item b were four launches of a few
+// microseconds each, every one waiting for the previous; here the wave that owns the item runs the two transforms back to
+// back (apply_wave_body, handing m_pr / P_pr over through their global planes: release + acquire at agent scope around a
+// wave barrier, the second transform's lanes read what other lanes of the same wave wrote) and the first lane of the
+// item's group goes on with the update and the log-density (ssmq_update.h: the bodies of k_kalman_update /
+// k_gauss_logpdf, so the results are the same bits as the launch-per-stage route's).
+struct ThetaChainArgs {
+    WideArgs dyn, obs;          // same wave_k
+    UpdArgs upd;                // status = the update's own flag vector (set here, not accumulated)
+    const double *y;
+    double *loglik;
+    const int32_t *merge;       // five flag vectors, pitch upd.ld
+    int32_t *merge_out;
+    int32_t lds_per_wave;       // doubles
+};
+
+template <int DM, bool GEN>
+__global__ __launch_bounds__(64 * kWaveWaves) void k_theta_chain(const ThetaChainArgs c, int64_t B) {
+    extern __shared__ __align__(16) double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wid = (int64_t)blockIdx.x * kWaveWaves + wave;
+    double *lw = lds + (size_t)wave * c.lds_per_wave;
+#define SSMQ_AGENT_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_wave_barrier(); \
+                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+    const int K = c.dyn.wave_k, G = 64 / K, gi = lane / G, gl = lane - gi * G;
+    const int64_t b = wid * K + gi;
+    if (wid * K >= B) return;
+    apply_wave_body<DM, -1>(c.dyn, B, wid, lw);
+    SSMQ_AGENT_SYNC();
+    apply_wave_body<DM, -1>(c.obs, B, wid, lw);
+    SSMQ_AGENT_SYNC();
+#undef SSMQ_AGENT_SYNC
+    if (gi >= K || gl != 0 || b >= B) return;
+    const uint32_t ub = (uint32_t)b;
+    c.upd.status[ub] = 0;
+    const int D = c.upd.D, Y = c.upd.Y;
+    bool done = false;
+    if constexpr (!GEN) {
+#define SSMQ_UPD(d, y_) if (!done && d <= DM && D == d && Y == y_) { kalman_update_item<d, y_>(c.upd, ub); done = true; }
+        SSMQ_UPD(1, 1) SSMQ_UPD(2, 1) SSMQ_UPD(2, 2) SSMQ_UPD(3, 1) SSMQ_UPD(4, 2) SSMQ_UPD(5, 2) SSMQ_UPD(5, 4) SSMQ_UPD(6, 2)
+#undef SSMQ_UPD
+    } else {
+        kalman_update_item_generic(c.upd, ub);
+    }
+    gauss_logpdf_item(c.y, c.upd.y_mean, c.upd.P_y, c.loglik, Y, c.upd.ld, c.merge, c.merge_out, ub);
+}
+
+// the (D, Y) pairs with a register-resident update (launch_kalman_update_ex's table)
+static bool update_is_specialised(int D, int Y) {
+    return (D == 1 && Y == 1) || (D == 2 && (Y == 1 || Y == 2)) || (D == 3 && Y == 1) || (D == 4 && Y == 2) ||
+           (D == 5 && (Y == 2 || Y == 4)) || (D == 6 && Y == 2);
+}
+
+bool theta_chain_supported(int Din, int D, int Y, int Nd, int No) {
+    return !getenv("SSMQ_NO_THETA_FUSED") && wide_full_uses_wave(Din, D, Nd) && wide_full_uses_wave(D, Y, No) && Nd <= 64 && No <= 64;
+}
+
+template <int DM, bool GEN>
+static hipError_t launch_chain_one(const ThetaChainArgs &c, int64_t B, size_t lds, hipStream_t s) {
+    static unsigned attr_epoch = 0;
+    if (lds > 48 * 1024 && attr_epoch != device_epoch()) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_theta_chain<DM, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+        attr_epoch = device_epoch();
+    }
+    const int64_t per_block = (int64_t)kWaveWaves * c.dyn.wave_k;
+    hipLaunchKernelGGL((k_theta_chain<DM, GEN>), dim3((unsigned)((B + per_block - 1) / per_block)), dim3(64 * kWaveWaves), lds, s,
+                       c, B);
+    return hipGetLastError();
+}
+
+// dyn / obs: WideArgs of the two transforms as for launch_apply_wide (mode FULL, form BQ); upd: the update's arguments
+hipError_t launch_theta_chain(const WideArgs &dyn, const WideArgs &obs, const UpdArgs &upd, const double *y, double *loglik,
+                              const int32_t *merge, int32_t *merge_out, int64_t B, hipStream_t s) {
+    ThetaChainArgs c;
+    c.dyn = dyn; c.obs = obs; c.upd = upd; c.y = y; c.loglik = loglik; c.merge = merge; c.merge_out = merge_out;
+    const int K = std::min(wave_groups(dyn.D, dyn.E, dyn.N, false), wave_groups(obs.D, obs.E, obs.N, false));
+    c.dyn.wave_k = c.obs.wave_k = K;
+    const int per_item = std::max((wave_lds_doubles(dyn.D, dyn.E, dyn.N, false) + 1) & ~1, (wave_lds_doubles(obs.D, obs.E, obs.N, false) + 1) & ~1);
+    c.lds_per_wave = K * per_item;
+    const size_t lds = sizeof(double) * kWaveWaves * (size_t)c.lds_per_wave;
+    const int dm = std::max(std::max(dyn.D, dyn.E), std::max(obs.D, obs.E));
+    const bool gen = !update_is_specialised(upd.D, upd.Y);
+    if (dm <= 4) return gen ? launch_chain_one<4, true>(c, B, lds, s) : launch_chain_one<4, false>(c, B, lds, s);
+    if (dm <= 8) return gen ? launch_chain_one<8, true>(c, B, lds, s) : launch_chain_one<8, false>(c, B, lds, s);
+    if (dm <= 12) return gen ? launch_chain_one<12, true>(c, B, lds, s) : launch_chain_one<12, false>(c, B, lds, s);
+    return gen ? launch_chain_one<SSMQ_MAX_DIM, true>(c, B, lds, s) : launch_chain_one<SSMQ_MAX_DIM, false>(c, B, lds, s);
 }
 
 size_t wide_lds_bytes(int D, int E, int N) {

@@ -402,15 +402,20 @@ __device__ void bs_basis_entry(int D, int N, int NB, int n, int qb, const double
     kxpx = kprod;
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
-    extern __shared__ __align__(16) double lds[];
+// where one parameter row's workspace and results live: the global arrays of WgtArgs at row p (k_weights), or the
+// workgroup's LDS (k_theta_weights, which only keeps the packed constants of the transform kernel)
+struct WgtOut {
+    double *work, *q, *Q, *R, *iK, *wm, *Wc, *Wcc, *mv, *iv;
+    int32_t *status;
+};
+
+__device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *lds) {
     __shared__ double s_sil[SSMQ_MAX_DIM], s_red[16];
     __shared__ int s_flag, s_piv;
-    const int D = a.D, N = a.N, NB = a.NB, p = blockIdx.x, tid = threadIdx.x;
+    const int D = a.D, N = a.N, NB = a.NB, tid = threadIdx.x;
     const double *par = a.par + (int64_t)p * (1 + D);
     const double alpha = par[0];
-    double *w = a.work + (int64_t)p * a.work_stride;
+    double *w = o.work;
     // workspace carve-up (global); A and X move to LDS when they fit
     double *gA = w; w += N * N;
     double *gX = w; w += N * N;
@@ -423,9 +428,7 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     double *X = a.use_lds == 1 ? lds + N * N : gX;
     // products: the LDS-tiled routine for large point sets (LDS is free again once the inverse exists), else the plain one
 #define GEMM(...) do { if (large) gemm_tiled(lds, __VA_ARGS__); else gemm(__VA_ARGS__); } while (0)
-    double *oq = a.q + (int64_t)p * N, *oQ = a.Q + (int64_t)p * N * N, *oR = a.R + (int64_t)p * D * N;
-    double *oiK = a.iK + (int64_t)p * N * N, *owm = a.wm + (int64_t)p * N, *oWc = a.Wc + (int64_t)p * N * N;
-    double *oWcc = a.Wcc + (int64_t)p * D * N;
+    double *oq = o.q, *oQ = o.Q, *oR = o.R, *oiK = o.iK, *owm = o.wm, *oWc = o.Wc, *oWcc = o.Wcc;
 
     if (tid < D) s_sil[tid] = 1.0 / par[1 + tid];   // par[1:] ** -1   (bq/bqkern.py:454)
     bsync();
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     bsync();
     // ---- (K + jitter I)^-1 ----------------------------------------------------------------------------------------
     pd = large ? chol_packed_lds(lds, N, &s_flag) : chol_block(A, N, &s_flag);
-    if (tid == 0) a.status[p] = pd ? 0 : 1;
+    if (tid == 0) *o.status = pd ? 0 : 1;
     if (a.stage == 1) {      // large point sets: the factor goes to the workspace, the inverse is a launch of its own
         if (pd) {
             double *dst = a.lpack + (int64_t)p * (N * (N + 1) / 2);
@@ -462,14 +465,14 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
         return;
     }
     } else {
-        pd = a.status[p] == 0;
+        pd = *o.status == 0;
     }
     if (!pd) {
         const double nan = __builtin_nan("");
         for (int idx = tid; idx < N * N; idx += kWgtBlock) { oiK[idx] = nan; oWc[idx] = nan; oQ[idx] = nan; }
         for (int idx = tid; idx < D * N; idx += kWgtBlock) { oWcc[idx] = nan; oR[idx] = nan; }
         for (int n = tid; n < N; n += kWgtBlock) { owm[n] = nan; oq[n] = nan; }
-        if (tid == 0) { a.mv[p] = nan; a.iv[p] = nan; }
+        if (tid == 0) { *o.mv = nan; *o.iv = nan; }
         return;
     }
     if (a.stage == 0) chol_inverse(A, X, N);     // stage 2: k_weights_inverse has filled X
@@ -543,8 +546,8 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
         tr = block_sum(tr, s_red);
         qq = block_sum(qq, s_red);
         if (tid == 0) {
-            a.mv[p] = (alpha * alpha) * (1.0 - tr);
-            a.iv[p] = kbar - qq;
+            *o.mv = (alpha * alpha) * (1.0 - tr);
+            *o.iv = kbar - qq;
         }
             return;
     }
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     bsync();
     const bool pd2 = chol_block(G, NB, &s_flag);
     if (!pd2) {
-        if (tid == 0) a.status[p] = 2;
+        if (tid == 0) *o.status = 2;
         return;
     }
     chol_inverse(G, iG, NB);                                 // cho_solve(cho_factor(.), I): not symmetrised
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
         for (int idx = tid; idx < N * N; idx += kWgtBlock) Vc[idx] = V[idx];
         bsync();
         if (!lu_inverse(Vc, iV, N, &s_piv, &s_flag)) {
-            if (tid == 0) a.status[p] = 3;
+            if (tid == 0) *o.status = 3;
             return;
         }
         GEMM(owm, N, a.px, NB, false, iV, N, false, 1, N, NB);              // wm = iV' px  == px' iV
@@ -607,8 +610,8 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
         t1 = block_sum(t1, s_red);
         t3 = block_sum(t3, s_red);
         if (tid == 0) {
-            a.mv[p] = ks2 * (1.0 - tr);
-            a.iv[p] = kbar - t1 - t1 + t3;
+            *o.mv = ks2 * (1.0 - tr);
+            *o.iv = kbar - t1 - t1 + t3;
         }
         return;
     }
@@ -684,10 +687,19 @@ __global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
     qq = block_sum(qq, s_red);
     bb = block_sum(bb, s_red);
     if (tid == 0) {
-        a.mv[p] = ks2 * (1.0 - tr1 + tr2);
-        a.iv[p] = kbar - qq + bb;
+        *o.mv = ks2 * (1.0 - tr1 + tr2);
+        *o.iv = kbar - qq + bb;
     }
 #undef GEMM
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_weights(const WgtArgs a) {
+    extern __shared__ __align__(16) double lds[];
+    const int64_t p = blockIdx.x, N = a.N, D = a.D;
+    const WgtOut o{a.work + p * a.work_stride, a.q + p * N, a.Q + p * N * N, a.R + p * D * N, a.iK + p * N * N, a.wm + p * N,
+                   a.Wc + p * N * N, a.Wcc + p * D * N, a.mv + p, a.iv + p, a.status + p};
+    weights_body(a, o, (int)p, lds);
 }
 
 // ---- host side: polynomial moments under N(0, I) (integer tables; bq/bqmod.py:635-731) -----------------------------
@@ -942,6 +954,94 @@ int gp_weights_wide_consts(int D, int E, int N, const double *d_xi, const double
     if ((rc = launch_weights(a, s))) return rc;
     hipLaunchKernelGGL(k_pack_wide_consts, dim3(P), dim3(64), 0, s, D, E, N, d_xi, dwm, dWc, dWcc, diK, dmv, d_consts);
     return hip_fail(hipGetLastError(), "k_pack_wide_consts");
+}
+
+// ---- both transforms' weights of the theta-batched step in ONE launch, workspace and results in LDS ----------------------
+// gp_weights_wide_consts twice was four launches (k_weights, k_pack_wide_consts for the dynamics and for the measurement
+// model), each k_weights a chain of ~25 barrier-separated steps over a GLOBAL workspace - at N = 4 ... 21 points that is
+// 13 us of write -> barrier -> read round trips for a few thousand flops.  Here blockIdx.y picks the transform, the
+// workspace and every intermediate result of weights_body (q, Q, R, iK, wm, Wc, Wcc) live in the workgroup's LDS, and
+// the only global writes are the transform kernel's constant block (what k_pack_wide_consts copied) and the status flag.
+// Same body, same summation orders: the constants are the same bits as the two-launch route's.
+struct ThetaWgtArgs {
+    WgtArgs w[2];
+    double *consts[2];
+    int32_t E[2];
+};
+
+static size_t theta_weights_lds_doubles(int D, int N) {
+    const size_t nn = (size_t)N * N;
+    return 2 * nn + (4 * nn + (size_t)D * N + N) + (3 * nn + 2 * (size_t)N + 2 * (size_t)D * N + 2);
+}
+
+__global__ __launch_bounds__(256) void k_theta_weights(const ThetaWgtArgs t) {
+    extern __shared__ __align__(16) double lds[];
+    const bool second = blockIdx.y != 0;
+    const WgtArgs a = second ? t.w[1] : t.w[0];
+    double *consts = second ? t.consts[1] : t.consts[0];
+    const int E = second ? t.E[1] : t.E[0];
+    const int p = blockIdx.x, N = a.N, D = a.D, nn = N * N;
+    double *w = lds + 2 * nn;           // [0, 2 nn): the kernel matrix and its inverse (weights_body, use_lds == 1)
+    WgtOut o;
+    o.work = w; w += 4 * nn + D * N + N;
+    o.q = w; w += N;
+    o.Q = w; w += nn;
+    o.R = w; w += D * N;
+    o.iK = w; w += nn;
+    o.wm = w; w += N;
+    o.Wc = w; w += nn;
+    o.Wcc = w; w += D * N;
+    o.mv = w;
+    o.iv = w + 1;
+    o.status = a.status + p;
+    weights_body(a, o, p, lds);
+    bsync();
+    const WideLayout cl = wide_layout(D, E, N, SSMQ_FORM_BQ);
+    double *c = consts + (int64_t)p * cl.total;
+    for (int i = threadIdx.x; i < D * N; i += blockDim.x) c[cl.xiT + i] = a.xi[(i % D) * N + i / D];   // [N][D]
+    for (int i = threadIdx.x; i < N; i += blockDim.x) c[cl.wm + i] = o.wm[i];
+    for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+        c[cl.Wc + i] = o.Wc[i];
+        c[cl.iK + i] = o.iK[i];
+    }
+    for (int i = threadIdx.x; i < D * N; i += blockDim.x) c[cl.Wcc + i] = o.Wcc[i];
+    const double mv = *o.mv;
+    for (int i = threadIdx.x; i < E * E; i += blockDim.x) c[cl.emv + i] = mv;
+}
+
+bool gp_theta_weights_fits(int D0, int N0, int D1, int N1) {
+    const size_t cap = 160 * 1024 - 1024;
+    return N0 <= 64 && N1 <= 64 && sizeof(double) * theta_weights_lds_doubles(D0, N0) <= cap &&
+           sizeof(double) * theta_weights_lds_doubles(D1, N1) <= cap;
+}
+
+// transform i (0: dynamics, 1: measurement): D[i] -> E[i] on N[i] points d_xi[i], parameter rows d_par[i] [P][1 + D[i]],
+// constant blocks d_consts[i] [P][wide_layout(D, E, N, BQ).total], flags d_status[i] [P].  Enqueued, nothing allocated.
+int gp_theta_weights_pair(const int D[2], const int E[2], const int N[2], const double *const d_xi[2],
+                          const double *const d_par[2], int P, double jitter, double *const d_consts[2],
+                          int32_t *const d_status[2]) {
+    hipStream_t s = stream();
+    ThetaWgtArgs t;
+    memset(&t, 0, sizeof(t));
+    size_t lds = 0;
+    int threads = 64;
+    for (int i = 0; i < 2; ++i) {
+        WgtArgs &a = t.w[i];
+        a.D = D[i]; a.N = N[i]; a.P = P; a.NB = 0; a.use_lds = 1; a.stage = 0; a.jitter = jitter;
+        a.xi = d_xi[i]; a.par = d_par[i]; a.mulind = (const int32_t *)d_xi[i]; a.px = a.xpx = a.pxpx = d_xi[i];   // unused: NB = 0
+        a.status = d_status[i];
+        t.consts[i] = d_consts[i];
+        t.E[i] = E[i];
+        lds = std::max(lds, sizeof(double) * theta_weights_lds_doubles(D[i], N[i]));
+        if (N[i] > 8 || getenv("SSMQ_WEIGHTS_WIDE_BLOCK")) threads = 256;     // as launch_weights
+    }
+    static unsigned attr_epoch = 0;
+    if (lds > 48 * 1024 && attr_epoch != ssmq::device_epoch()) {
+        SSMQ_HIP(hipFuncSetAttribute((const void *)k_theta_weights, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr_epoch = ssmq::device_epoch();
+    }
+    hipLaunchKernelGGL(k_theta_weights, dim3(P, 2), dim3(threads), lds, s, t);
+    return hip_fail(hipGetLastError(), "k_theta_weights");
 }
 
 // ---- the kernel-level methods of the reference as entry points of their own ---------------------------------------------

@@ -416,33 +416,53 @@ class MarginalInference(GaussianInference):
         c[..., D:, D:] = qc
         return m, c
 
+    def _theta_static(self):
+        """What does not change between calls of `theta_step` (the marginalised filter makes hundreds per time step and the
+        ctypes conversions were a third of a call): integrand descriptors, transform handles, the noise terms, and a
+        prototype of the entry point that takes the array addresses as plain integers."""
+        st = getattr(self, '_theta_cache', None)
+        if st is None:
+            lib = _lib.load()
+            f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
+            f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
+            vp = ctypes.c_void_p
+            proto = ctypes.CFUNCTYPE(ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, vp, vp, ctypes.c_double, vp, vp, ctypes.c_int,
+                                     vp, ctypes.c_int, ctypes.c_double, vp, vp, vp, vp, vp, vp)
+            st = dict(fn=proto(('ssmq_gp_theta_step', lib)), f_dyn=f_dyn, f_obs=f_obs,
+                      pf_dyn=ctypes.addressof(f_dyn), pf_obs=ctypes.addressof(f_obs),
+                      h_dyn=self.tf_dyn._handle_for(e_dyn), h_obs=self.tf_obs._handle_for(e_obs),
+                      gqg=(np.ascontiguousarray(self.G.dot(self.q_cov).dot(self.G.T), dtype=np.float64)
+                           if self.mod_dyn.noise_additive else None),
+                      rr=np.ascontiguousarray(self.r_cov, dtype=np.float64),
+                      jitter=float(self.tf_dyn.model.kernel.jitter))
+            self._theta_cache = st
+        return st
+
     def theta_step(self, theta, mean, cov, y, time):
         """theta (P, param_dim) log-parameters; mean (D,) / cov (D, D) shared by all items or (P, D) / (P, D, D);
         y (Y,) or (P, Y).  Returns conditional posterior means (P, D), covariances (P, D, D), log-likelihoods (P,) and
         the status flags (P,) of `ssmq_gp_theta_step`."""
-        lib = _lib.load()
-        theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+        c = self._theta_static()
+        theta = np.asarray(theta, dtype=np.float64)
+        if theta.ndim < 2:
+            theta = theta.reshape(1, -1)
         P = theta.shape[0]
         D = self.mod_dyn.dim_state
-        pd, ppd = _lib.as_c(np.exp(theta[:, :self.param_dyn_dim]))
-        po, ppo = _lib.as_c(np.exp(theta[:, self.param_dyn_dim:]))
+        par = np.exp(theta)
+        pd = np.ascontiguousarray(par[:, :self.param_dyn_dim])
+        po = np.ascontiguousarray(par[:, self.param_dyn_dim:])
         mean, cov = self._augment(mean, cov)
-        mean, pm = _lib.as_c(mean)
-        cov, pc = _lib.as_c(cov)
-        y, py = _lib.as_c(y)
-        f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
-        f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
-        h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
-        gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T)) if self.mod_dyn.noise_additive else (None, None)
-        rr, pr = _lib.as_c(self.r_cov)
-        om, pom = _lib.out_c((P, D))
-        oc, poc = _lib.out_c((P, D, D))
-        ll, pll = _lib.out_c((P,))
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        cov = np.ascontiguousarray(cov, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        om, oc, ll = np.empty((P, D)), np.empty((P, D, D)), np.empty(P)
         st = np.zeros(P, dtype=np.int32)
-        _lib.check(lib.ssmq_gp_theta_step(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs),
-                                          ctypes.byref(f_obs), P, ppd, ppo, float(self.tf_dyn.model.kernel.jitter), pm,
-                                          pc, 1 if mean.ndim == 1 else 0, py, 1 if y.ndim == 1 else 0, float(time), pg,
-                                          pr, pom, poc, pll, st.ctypes.data_as(_lib.c_int32_p)), 'ssmq_gp_theta_step')
+        gqg = c['gqg']
+        _lib.check(c['fn'](c['h_dyn'], c['pf_dyn'], c['h_obs'], c['pf_obs'], P, pd.ctypes.data, po.ctypes.data, c['jitter'],
+                           mean.ctypes.data, cov.ctypes.data, 1 if mean.ndim == 1 else 0, y.ctypes.data,
+                           1 if y.ndim == 1 else 0, float(time), None if gqg is None else gqg.ctypes.data,
+                           c['rr'].ctypes.data, om.ctypes.data, oc.ctypes.data, ll.ctypes.data, st.ctypes.data),
+                   'ssmq_gp_theta_step')
         return om, oc, ll, st
 
     def _param_log_prior(self, theta):

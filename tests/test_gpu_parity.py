@@ -1052,6 +1052,66 @@ def test_marginal_theta_step_batch_vs_oracle(amd):
     assert st2[17] & 4 and not np.delete(st2, 17).any()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('model', ['ungm', 'pendulum_ut', 'pendulum_gh', 'nonadditive'])
+def test_theta_step_two_launch_route_is_bitwise_the_stage_route(amd, model, monkeypatch):
+    """`ssmq_gp_theta_step` as two launches (k_theta_weights: both transforms' weights in LDS; k_theta_chain: transform ->
+    transform -> update -> log-likelihood in the wave that owns the item) against the launch-per-stage route
+    (SSMQ_NO_THETA_FUSED) on the same items: same bodies, same summation orders, so EQUAL BITS - including items whose
+    covariance or kernel matrix is not positive definite (NaN results, same flags) and item counts that leave waves and
+    lane groups ragged.  The stage route runs eagerly the first time a shape is seen, is captured the second time and
+    replayed from then on."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    if os.environ.get('SSMQ_NO_WAVE'):
+        pytest.skip('the chained kernel is built on the wave kernel')
+    rng = np.random.default_rng(11)
+    if model == 'ungm':
+        dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+        obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+        alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'sr')
+    elif model.startswith('pendulum'):
+        dt = 0.01
+        Q = np.array([[dt ** 3 / 3, dt ** 2 / 2], [dt ** 2 / 2, dt]])
+        dyn = sm.Pendulum2DTransition(sm.GaussRV(2, np.array([1.5, 0]), 0.01 * np.eye(2)), sm.GaussRV(2, cov=Q), dt)
+        obs = sm.Pendulum2DMeasurement(sm.GaussRV(1, cov=np.array([[0.1]])), 2)
+        alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'ut' if model.endswith('ut') else 'gh',
+                                                      point_hyp=None if model.endswith('ut') else {'degree': 3})
+    else:
+        dyn = sm.UNGMNATransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[1.0]])))
+        obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+        alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'ut')
+    D = dyn.dim_state
+    for n in (1, alg.param_dim + 1, 2 * alg.param_dim, 333):
+        th = 0.4 * rng.standard_normal((n, alg.param_dim))
+        m = 0.5 * rng.standard_normal((n, D))
+        a = rng.standard_normal((n, D, D)) * 0.3
+        P = np.einsum('nij,nkj->nik', a, a) + 0.05 * np.eye(D)
+        if n > 20:
+            P[5] = -np.eye(D)                       # input covariance not positive definite
+            th[9, 1:] = np.nan                      # no kernel matrix: both weight sets fail
+        y = rng.standard_normal((n, obs.dim_out))
+        res = {}
+        for route in ('two', 'two_again', 'stage', 'stage_captured', 'stage_replayed'):
+            if route == 'stage':
+                monkeypatch.setenv('SSMQ_NO_THETA_FUSED', '1')
+            res[route] = alg.theta_step(th, m, P, y, 4)
+        monkeypatch.delenv('SSMQ_NO_THETA_FUSED')
+        for route in ('two_again', 'stage', 'stage_captured', 'stage_replayed'):
+            for got, want in zip(res[route], res['two']):
+                assert np.array_equal(got, want, equal_nan=got.dtype.kind == 'f'), (model, n, route)
+        if n > 20:
+            st = res['two'][3]
+            assert st[5] & 4 and st[9] and not np.delete(st, [5, 9]).any()
+            assert np.isnan(res['two'][0][5]).all() and np.isfinite(np.delete(res['two'][2], [5, 9])).all()
+        # the same arguments shared by all items (the marginalisation call pattern)
+        r1 = alg.theta_step(th, m[0], P[0], y[0], 4)
+        monkeypatch.setenv('SSMQ_NO_THETA_FUSED', '1')
+        r2 = alg.theta_step(th, m[0], P[0], y[0], 4)
+        monkeypatch.delenv('SSMQ_NO_THETA_FUSED')
+        for got, want in zip(r1, r2):
+            assert np.array_equal(got, want, equal_nan=got.dtype.kind == 'f'), (model, n, 'shared')
+
+
 def test_marginal_filter_forward_pass(amd, golden):
     """Whole marginalised filter on a short UNGM sequence.  BFGS on finite differences of a 1e-13-accurate objective:
     the optimiser path, not the device arithmetic, limits how closely two implementations agree."""
