@@ -236,6 +236,9 @@ static int upload_consts(ssmq_transform *h) {
         for (int k = 0; k < N; ++k) {
             for (int j = 0; j < N; ++j) xpad[(size_t)k * nx + j] = h->Wc[k * N + j];
             for (int d = 0; d < D && d < 16; ++d) xpad[(size_t)k * nx + np + d] = h->Wcc[d * N + k];
+            // the tile's last column is free up to D = 15: wm there makes FX wm a by-product of the same GEMM
+            // (k_bq_fused reads it; k_fxwc_cov_mfma only looks at columns < D)
+            if (D <= 15) xpad[(size_t)k * nx + np + 15] = h->wm[k];
         }
         if (!h->d_wcx_pad) SSMQ_HIP(hipMalloc(&h->d_wcx_pad, sizeof(double) * np * nx));
         SSMQ_HIP(hipMemcpyAsync(h->d_wcx_pad, xpad.data(), sizeof(double) * np * nx, hipMemcpyHostToDevice, stream()));
@@ -398,7 +401,9 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     const bool big = !se && h->N > 64 && ((h->form == SSMQ_FORM_BQ && h->d_wc_blk && (b_route * h->E >= kGemmMinRows || !wide_fits) &&
                                            (h->tp_nu <= 0.0 || h->d_ik_blk)) ||
                                           (h->form == SSMQ_FORM_SIGMA && !wide_fits));
-    if (kernel_name) *kernel_name = se ? se->name : big ? "k_apply_big" : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
+    const bool one_launch = !se && !big && h->form == SSMQ_FORM_BQ && h->d_wc_pad && h->d_wcx_pad && h->tp_nu <= 0.0 &&
+                            b_route * h->E >= kGemmMinRows && bq_fused_supported(h->D, h->E, h->N);
+    if (kernel_name) *kernel_name = se ? se->name : big ? "k_apply_big" : one_launch ? "k_bq_fused" : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
     if (dry_run) return SSMQ_OK;
     if (B <= 0) return SSMQ_OK;
     if (!d_mean || !d_cov || !d_mean_f || !d_cov_f || !d_cov_fx || !d_status || (fi.uses_time && !d_time) ||
@@ -456,6 +461,11 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         const int NP = h->np_pad;
         const int64_t M = B * h->E;
         double *fx, *tt, *chol;
+        if (h->tp_nu <= 0.0 && h->d_wcx_pad && bq_fused_supported(h->D, h->E, h->N)) {
+            // one launch: the workgroup that owns a block of the GEMM's rows evaluates the integrand into LDS itself
+            const WideLayout wl = wide_layout(h->D, h->E, h->N, h->form);
+            return launch_bq_fused(a, h->d_wcx_pad, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, stream());
+        }
         if (h->tp_nu <= 0.0 && h->d_wcx_pad && fxwc_cov_supported(h->E) && h->D <= 16 && !getenv("SSMQ_NO_FUSED_COV")) {
             // two passes: (1) one wave per trajectory: factor, points, integrand values, mean; (2) the GEMM whose
             // epilogue forms the covariance and the cross-covariance from its accumulators
@@ -1204,6 +1214,19 @@ void reset_wide_attributes();
 void drop_staging_arena();
 static unsigned g_device_epoch = 1;
 unsigned device_epoch() { return g_device_epoch; }
+// CUs of the current device (persistent kernels launch one workgroup per CU); 256 if the query fails
+int compute_units() {
+    static unsigned epoch = 0;
+    static int cus = 256;
+    if (epoch != g_device_epoch) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        epoch = g_device_epoch;
+    }
+    return cus;
+}
 void drop_theta_step_graphs();
 void reset_device_caches() {
     ++g_device_epoch;

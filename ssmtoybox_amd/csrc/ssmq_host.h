@@ -35,6 +35,7 @@ int ensure_device();
 // Bumped whenever the library moves to another device (reset_device_caches): per-function attributes
 // (hipFuncAttributeMaxDynamicSharedMemorySize) are per device and must be set again after a change.
 unsigned device_epoch();
+int compute_units();
 
 #define SSMQ_HIP(call)                                        \
     do {                                                      \
@@ -58,6 +59,10 @@ int gemm_mfma_padded(int N);
 int launch_fxwc_mfma(int NP, const double *A, const double *Bm, double *T, int64_t M, int lda, int ldt, hipStream_t s);
 // ... with the covariance of every trajectory formed in the epilogue (no T in memory)
 bool fxwc_cov_supported(int E);
+// whole BQ transform in one launch, integrand values LDS-resident (ssmq_bq_fused.hip); WideArgs: ssmq_wide.h
+struct WideArgs;
+bool bq_fused_supported(int D, int E, int N);
+int launch_bq_fused(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, hipStream_t s);
 int launch_fxwc_cov_mfma(int NP, const double *A, const double *X, int64_t M, int lda, const double *mean_rows,
                          const double *chol, const double *emv, int emv_broadcast, const double *cov_add,
                          double cov_scale, double ccov_scale, int E, int D, double *cov_f, double *cov_fx, int64_t es,

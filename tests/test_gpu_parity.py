@@ -1721,7 +1721,7 @@ def test_bsq_d10_full_batch(amd, golden, tag, pstr, ppar, B):
     w = dict(wm=g[t + '_wm'], Wc=g[t + '_Wc'], Wcc=g[t + '_Wcc'], model_var=float(g[t + '_mv']))
     tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
     f = sm.Smooth10DTransition().dyn_eval
-    assert tf.kernel_name(f) == ('k_apply_tile' if pstr == 'ut' else 'k_apply_wide')       # (wide = the matrix-core route's name)
+    assert tf.kernel_name(f) in (('k_apply_tile',) if pstr == 'ut' else ('k_bq_fused', 'k_apply_wide'))   # (wide = the two-pass matrix-core route's name)
     mf, cf, cfx, st = tf.apply_batch(f, means, covs, 0.0, return_status=True)
     assert not st.any() and np.all(np.isfinite(mf)) and np.all(np.isfinite(cf)) and np.all(np.isfinite(cfx))
     assert np.array_equal(cf, cf.transpose(0, 2, 1))
@@ -1830,7 +1830,7 @@ def test_two_pass_matrix_core_route(amd, monkeypatch, case):
         covs[B // 2] = -np.eye(D)
         monkeypatch.delenv('SSMQ_NO_FUSED_COV', raising=False)
         monkeypatch.delenv('SSMQ_NO_MFMA', raising=False)
-        assert tf.kernel_name(fn) == 'k_apply_wide'
+        assert tf.kernel_name(fn) in ('k_apply_wide', 'k_bq_fused')
         mf, cf, cfx, st = tf.apply_batch(fn, means, covs, 2.0, return_status=True)
         monkeypatch.setenv('SSMQ_NO_FUSED_COV', '1')
         mf3, cf3, cfx3, st3 = tf.apply_batch(fn, means, covs, 2.0, return_status=True)
@@ -2067,7 +2067,7 @@ def test_bsq_d10_device_integrand(amd, golden):
         tf = amd.BayesSardTransform(10, 10, gp_par(10, 3.0), g[t + '_mi'], pstr, ppar)
         w = dict(wm=g[t + '_wm'], Wc=g[t + '_Wc'], Wcc=g[t + '_Wcc'], model_var=float(g[t + '_mv']))
         tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
-        assert tf.kernel_name(model.dyn_eval) in (('k_apply_tile', 'k_apply_wave', 'k_apply_wide') if pstr == 'ut' else ('k_apply_wide',))
+        assert tf.kernel_name(model.dyn_eval) in (('k_apply_tile', 'k_apply_wave', 'k_apply_wide') if pstr == 'ut' else ('k_apply_wide', 'k_bq_fused'))
         mf, cf, cfx = tf.apply_batch(model.dyn_eval, means, covs, 0.0)
         for i in range(0, B, 9):
             ref = orc.apply_bq(orc.F_SMOOTH10D_DYN, means[i], covs[i], 0.0, g[t + '_pts'], w)
