@@ -70,6 +70,16 @@ def pmc_traffic(kernel_name, grid=None):
     return hits[0].get('hbm_bytes_per_launch') if len(hits) == 1 else None
 
 
+def pmc_traffic_named(prefix):
+    """HBM bytes per launch of the ONE entry of profiles/pmc_traffic.json whose kernel name starts with `prefix`."""
+    try:
+        table = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+    except (OSError, ValueError):
+        return None
+    hits = [rec for key, rec in table.items() if key.startswith(prefix)]
+    return hits[0].get('hbm_bytes_per_launch') if len(hits) == 1 else None
+
+
 def simulate_ungm(B, T, seed):
     """Synthetic UNGM trajectories + measurements (x0 ~ N(0,1), q ~ N(0,10), r ~ N(0,1): tests/test_ssinf.py:23-30 of the
     reference), vectorised over the batch.  Returns x (T, B), y (T, B)."""
@@ -1024,6 +1034,20 @@ def main():
                                           'standing in for BASELINE configs[4]\'s 7th-degree rule - the reference has '
                                           'degree 3 and 5 only (mtran.py:392) - B=1e4: (1e5 x 208) x (208 x 208) on '
                                           'v_mfma_f64_16x16x4_f64'}
+        # the whole transform is ONE launch since round 3 (k_bq_fused: factor, points, integrand values into an LDS tile,
+        # both matrix-core products and the covariance epilogue; FX never reaches HBM): its matrix-core arithmetic is the
+        # main product on 16-row tiles of 224 columns plus the second product of the covariance epilogue
+        name_full = c5.tf.kernel_name(__import__('ssmtoybox_amd').ssmod.Smooth10DTransition().dyn_eval)
+        flop_full = 2.0 * c5.M * c5.NP * (c5.NP + 16) + 2.0 * c5.M * c5.NP * 32
+        alg_bytes = 10000 * 8.0 * (10 + 100 + 10 + 100 + 100) + 4.0 * 10000
+        tr = pmc_traffic_named('k_bq_fused') if name_full == 'k_bq_fused' else None
+        out['roofline_c5']['full_transform'] = {
+            'kernel': name_full, 'ms_per_launch': ms_full, 'bound': 'mfma', 'flop_per_launch': flop_full,
+            'achieved': flop_full / (ms_full * 1e-3) / 1e12, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+            'frac': flop_full / (ms_full * 1e-3) / 1e12 / F64_MFMA_PEAK_TF, 'algorithmic_bytes': alg_bytes, 'traffic': tr,
+            'traffic_over_algorithmic': (tr / alg_bytes) if tr else None,
+            'note': 'two-pass route (k_eval_wave + k_fxwc_cov_mfma, SSMQ_NO_BQ_FUSED=1): 0.332-0.337 ms, 618 MB of HBM '
+                    'traffic (profiles/r03_a_bench.json, pmc_traffic.json at bd95560)'}
         if cb5:
             out['roofline_c5']['cpu_baseline'] = cb5
         out['roofline_c5']['unisolvent_n21'] = measure_c5_unisolvent(amd)

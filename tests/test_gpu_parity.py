@@ -1859,6 +1859,63 @@ def test_two_pass_matrix_core_route(amd, monkeypatch, case):
                   'matrix-core route vs workgroup kernel, ' + case)     # (1.5e-13 seen at N = 125 with a non-symmetric Wc)
 
 
+@pytest.mark.parametrize('D, pstr, ppar, N, E', [(10, 'fs', {'degree': 5}, 201, 6), (10, 'fs', {'degree': 5}, 201, 7),
+                                                 (10, 'fs', {'degree': 5}, 201, 8), (10, 'fs', {'degree': 5}, 201, 12),
+                                                 (10, 'fs', {'degree': 5}, 201, 16), (7, 'gh', {'degree': 2}, 128, 6),
+                                                 (7, 'gh', {'degree': 2}, 128, 9), (7, 'gh', {'degree': 2}, 128, 15),
+                                                 (3, 'gh', {'degree': 5}, 125, 8)])
+def test_one_launch_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
+    """k_bq_fused (ssmq_bq_fused.hip: factor, integrand values into an LDS tile, both matrix-core products and the covariance
+    epilogue in one launch) over its shape space: output dimensions 6 ... 16 (a workgroup owns floor(64 / E) or fewer whole
+    trajectories - 10, 9, 8, 5, 4 - with the compile-time bounds 8 and 16 and the 128- and 208-column instantiations),
+    an integrand behind a state index (bearings to E sensors from two entries of the state: ssmod.py:1155-1198), batches
+    that end in a partial tile, a covariance that is not positive definite.  Against the two-pass route (SSMQ_NO_BQ_FUSED)
+    at the rounding level and against the oracle."""
+    from ssmtoybox_amd import ssmod as sm
+    if os.environ.get('SSMQ_NO_MFMA') or os.environ.get('SSMQ_NO_BQ_FUSED'):
+        pytest.skip('the matrix-core routes are switched off')
+    rng = np.random.default_rng(100 * D + E)
+    sens = 30.0 * rng.standard_normal((E, 2))
+    sidx = [0, 2] if D > 3 else [0, 1]
+    obs = sm.BearingMeasurement(sm.GaussRV(E), D, state_index=sidx, sensor_pos=sens)
+    fn = obs.meas_eval
+    tf = amd.GaussianProcessTransform(D, E, gp_par(D, 2.0), 'rbf', pstr, ppar)
+    pts = tf.model.points
+    assert pts.shape == (D, N)
+    wm = rng.standard_normal(N) / N
+    Wc = rng.standard_normal((N, N)) / N
+    Wc = 0.5 * (Wc + Wc.T) + 1e-3 * rng.standard_normal((N, N)) / N
+    Wcc = rng.standard_normal((D, N)) / N
+    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = wm, Wc, Wcc, 0.21
+    w = dict(wm=wm, Wc=Wc, Wcc=Wcc, model_var=0.21)
+    assert tf.kernel_name(fn) == 'k_bq_fused'
+    for B in (257, 1000):
+        means = 3.0 * rng.standard_normal((B, D))
+        a = rng.standard_normal((B, D, D)) / np.sqrt(D)
+        covs = 0.5 * (np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(D))
+        bad = B - 2                                            # in the last, partial tile
+        covs[bad] = -np.eye(D)
+        mf, cf, cfx, st = tf.apply_batch(fn, means, covs, 0.0, return_status=True)
+        monkeypatch.setenv('SSMQ_NO_BQ_FUSED', '1')
+        assert tf.kernel_name(fn) == 'k_apply_wide'
+        mf2, cf2, cfx2, st2 = tf.apply_batch(fn, means, covs, 0.0, return_status=True)
+        monkeypatch.delenv('SSMQ_NO_BQ_FUSED')
+        assert st[bad] != 0 and not np.delete(st, bad).any() and np.array_equal(st, st2)
+        assert np.all(np.isnan(mf[bad])) and np.all(np.isnan(cf[bad])) and np.all(np.isnan(cfx[bad]))
+        ok = np.arange(B) != bad
+        assert np.all(np.isfinite(mf[ok])) and np.all(np.isfinite(cf[ok])) and np.all(np.isfinite(cfx[ok]))
+        assert np.array_equal(cf[ok], cf[ok].transpose(0, 2, 1))
+        sc = np.abs(cf2[ok]).max()
+        what = 'one launch vs two passes, D=%d E=%d N=%d B=%d ' % (D, E, N, B)
+        assert within(np.abs(mf[ok] - mf2[ok]).max() / np.abs(mf2[ok]).max(), 1e-13, what + 'mean')
+        assert within(np.abs(cf[ok] - cf2[ok]).max() / sc, 1e-13, what + 'cov')
+        assert within(np.abs(cfx[ok] - cfx2[ok]).max() / np.abs(cfx2[ok]).max(), 1e-13, what + 'ccov')
+        for i in (0, 1, B // 2, B - 1):
+            ref = orc.apply_bq(orc.F_BEARING_MEAS, means[i], covs[i], 0.0, pts, w, tuple(sens.reshape(-1)), sidx)
+            rc = np.tril(ref[1]) + np.tril(ref[1], -1).T
+            assert_moments_close((mf[i], cf[i], cfx[i]), (ref[0], rc, ref[2]), covs[i], what=(D, E, N, B, i))
+
+
 def test_state_index_with_more_than_eight_entries(amd):
     """A measurement-type integrand that reads 10 selected entries of a 13-dimensional state (state_index of 10 entries):
     the device integrand evaluates on the selected sub-state (generic kernel), as the oracle's restatement of
