@@ -449,7 +449,9 @@ bool bq_fused_supported(int D, int E, int N) {
     const int np = gemm_mfma_padded(N);
     if (np != 128 && np != 208) return false;
     // D <= 15: column 15 of the Wcc' tile of X carries wm (ssmq_api.hip: upload of d_wcx_pad)
-    if (D < 1 || D > 15 || E < 6 || E > 16 || !fxwc_cov_supported(E)) return false;
+    // E <= 10: no built-in integrand has more outputs (10-D model: 10; bearings: SSMQ_MAX_FPAR / 2 = 8 sensors), so nothing
+    // beyond that could be tested
+    if (D < 1 || D > 15 || E < 6 || E > 10 || !fxwc_cov_supported(E)) return false;
     return fused_geom_ok(fused_geom(np / 16, D, E, fused_dm(nullptr, D, E)), np / 16, D, E);   // (the generic bound: the larger footprint)
 }
 
