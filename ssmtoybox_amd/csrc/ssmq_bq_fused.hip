@@ -306,16 +306,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
             smr[lr] = gt[3];
             if (valid) a.mean_f[(int64_t)e * a.es_out + b * a.bs_mf] = gt[3];
         }
-        for (int j = 0; j < D; ++j) {
-            double p = 0.0;
+        // (fx Wcc') L' for row li: the G tile goes through LDS (the slab region is free: the loop's last barrier has been
+        // passed) and lane group lg takes the columns j = lg, lg + 4, ... - the sum over d with two cross-lane exchanges per j
+        // instead was 3 us per tile of dependent ds_bpermute round trips
+        double *sG = slab + RT * 64 * 8 + 512 + rt * 256;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = 4 * lg + r;
-                if (d <= j) p += gt[r] * Lb[SSMQ_PK(j, d)];
-            }
-            p += __shfl_xor(p, 16, 64);
-            p += __shfl_xor(p, 32, 64);
-            if (lg == 0 && valid) a.cov_fx[(int64_t)(e * D + j) * a.es_out + b * a.bs_cfx] = p * a.ccov_scale;
+        for (int r = 0; r < 4; ++r) sG[li * 16 + 4 * lg + r] = gt[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = lg; j < D; j += 4) {
+            double p = 0.0;
+            for (int d = 0; d <= j; ++d) p += sG[li * 16 + d] * Lb[SSMQ_PK(j, d)];
+            if (valid) a.cov_fx[(int64_t)(e * D + j) * a.es_out + b * a.bs_cfx] = p * a.ccov_scale;
         }
     }
     // ---- 4b. S = T FX2', this wave's column tiles ----------------------------------------------------------------------------------
@@ -326,7 +329,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
         const double *f0p = sFX + r0 * FP + 4 * lg, *f1p = sFX + r1 * FP + 4 * lg;
 #pragma unroll
         for (int ct = 0; ct < C0; ++ct) {
+#ifdef BQF_SKIP_4B
+            if (0) {
+#else
             if ((EVEN || ct < cnt) && cbase + ct < NT) {
+#endif
                 const int col = 16 * (cbase + ct);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -352,6 +359,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
     }
     __syncthreads();
     if (ch == 1) return;
+#ifdef BQF_SKIP_4C
+    if (acc2[0][0] != 12345.678) return;
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -405,7 +415,7 @@ FusedGeom fused_geom_for(int waves, int NT, int D, int E, int DM) {
 bool fused_geom_ok(const FusedGeom &q, int NT, int D, int E) {
     const int RT = q.waves / 2, KS = 2 * q.waves;
     const size_t slab = (size_t)2 * KS * (NT * 16 + 20);
-    return q.tpw >= 1 && 4 * q.tpw * E >= 3 * 16 * RT && (size_t)q.tpw * D * D <= slab && (size_t)RT * 64 * 8 + 512 <= slab;
+    return q.tpw >= 1 && 4 * q.tpw * E >= 3 * 16 * RT && (size_t)q.tpw * D * D <= slab && (size_t)RT * 64 * 8 + 512 + RT * 256 <= slab;
 }
 // one 512-thread workgroup per CU.  (Two of 256 threads - 32-row tiles, 8-row slabs, 80 KB each - were measured at D = E =
 // 10, N = 201, B = 1e4: 339 us against 322 us; the two workgroups of a CU run in phase, so their producer and store steps
