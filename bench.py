@@ -70,6 +70,33 @@ def pmc_traffic(kernel_name, grid=None):
     return hits[0].get('hbm_bytes_per_launch') if len(hits) == 1 else None
 
 
+def measure_theta_step(calls=500):
+    """Latency of the theta-batched step of the marginalised GPQ filter (`ssmq_gp_theta_step`, one call =
+    weights of both transforms, time update, measurement transform, Kalman update and log-likelihood for every parameter
+    item) at the item counts the filter sends: param_dim + 1 (gradient) on the pendulum model.  Wall clock through the
+    Python wrapper, inputs and outputs on the host."""
+    from ssmtoybox_amd import ssinf, ssmod
+    dyn = ssmod.Pendulum2DTransition(ssmod.GaussRV(2, mean=np.array([1.5, 0.0]), cov=0.01 * np.eye(2)),
+                                     ssmod.GaussRV(2, cov=0.01 * np.eye(2)), 0.01)
+    obs = ssmod.Pendulum2DMeasurement(ssmod.GaussRV(1, cov=np.array([[0.1]])), 2)
+    alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'sr')
+    rng = np.random.default_rng(0)
+    P = alg.param_dim + 1
+    theta = 0.1 * rng.standard_normal((P, alg.param_dim))
+    y = rng.standard_normal(1)
+    m0, P0 = np.zeros(2), np.eye(2)
+    for _ in range(10):
+        alg.theta_step(theta, m0, P0, y, 1)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        alg.theta_step(theta, m0, P0, y, 1)
+    us = (time.perf_counter() - t0) / calls * 1e6
+    return {'us_per_call': us, 'items': P, 'theta_steps_per_s': P / (us * 1e-6), 'launches_per_call': 2,
+            'kernels': ['k_theta_weights', 'k_theta_chain'],
+            'workload': 'MarginalizedGaussianProcessKalman.theta_step, pendulum 2-D + 1-D measurement, spherical-radial points, '
+                        '%d parameter items (param_dim + 1), host arrays in and out' % P}
+
+
 def pmc_traffic_named(prefix):
     """HBM bytes per launch of the ONE entry of profiles/pmc_traffic.json whose kernel name starts with `prefix`."""
     try:
@@ -1052,6 +1079,8 @@ def main():
             out['roofline_c5']['cpu_baseline'] = cb5
         out['roofline_c5']['unisolvent_n21'] = measure_c5_unisolvent(amd)
         out['roofline_c5']['degree7_as_worded'] = measure_c5_degree7(amd, with_cpu=with_cpu)
+    if rank == 0 and single and not args.no_mt6:
+        out['theta_step'] = measure_theta_step()
     if rank == 0:
         result_out.write(json.dumps(out) + '\n')
         result_out.flush()

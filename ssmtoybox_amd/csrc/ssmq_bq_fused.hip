@@ -13,7 +13,7 @@
 //   2. TT = 512 / TPW lanes per trajectory over its points, factor and mean in registers: sigma point, integrand, E values
 //      into the tile; zero padding;
 //   3. the transposed product [T G]' = [Wc | Wcc' | wm]' FX' as in k_fxwc_cov_mfma - slabs of 16 rows of X double-buffered
-//      in LDS, fetched TWO slabs ahead into registers - with wave w on row tile w & 3 and on ONE HALF of the column tiles
+//      in LDS, staged through ONE register set (written right after a barrier, re-requested at once) - with wave w on row tile w & 3 and on ONE HALF of the column tiles
 //      (w >> 2): two waves per SIMD, 56 accumulator registers each.  The FX fragments come from the LDS tile: lane group lg
 //      feeds column 16 kb + lg + 4 s in MFMA step s (stride 4, so that with the row pitch NP + 2 = 18 mod 32 the 32 lanes of
 //      a ds_read_b64 half fall on 32 different bank pairs); the slab rows are stored permuted to match.  Column 15 of the
@@ -78,10 +78,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
     // ---- 0. what does not depend on the factors goes out first: the first slab of X, this lane's first sigma point --------
     constexpr int PER = (KS * NX + TB - 1) / TB;
     constexpr bool EXACT = PER * TB == KS * NX;
-    // two slabs ahead in registers (bra / brb alternate): an L2 round trip under load is longer than one slab's matrix
-    // instructions, with one slab ahead the waves stood at the vmcnt wait of park_b (matrix pipe 43 % busy)
-    double bra[PER], brb[PER];
-    auto load_b = [&](int kb, double (&breg)[PER]) {
+    // ONE register set for the slabs: at the start of step kb - right after the barrier that ended step kb - 1 - slab kb + 1
+    // (requested a whole step ago) is written to the buffer that step kb - 1 has just released and slab kb + 2 is
+    // requested into the same registers, so the LDS writes have the whole step to complete before the next barrier.
+    // Measured alternatives (D = E = 10, N = 201, B = 1e4; this form 313-316 us): one slab ahead, parked before the last
+    // k sub-step 338; two register sets, two slabs ahead, parked there 313-316 (no gain for 14 registers); LDS-DMA
+    // (global_load_lds_dwordx4, two pieces per row, issued after the barrier, drained by the next one) 325-332 - the
+    // compiler then waits for ALL outstanding LDS reads (lgkmcnt(0)) before each group of matrix instructions.
+    double breg[PER];
+    auto load_b = [&](int kb) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int i = tid + q * TB;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
     // row k of a slab lives at a permuted position, so that the lanes of a ds_read_b64 half (lane groups lg = 0, 1 or 2, 3,
     // reading k = lg + 4 s) are 16 bank pairs apart with the pitch LB = 4 mod 32
     auto phys = [](int k) { return KS == 16 ? 4 * (k & 3) + (k >> 2) : 4 * (k & 1) + ((k & 3) >> 1) + 2 * (k >> 2); };
-    auto park_b = [&](int buf, const double (&breg)[PER]) {
+    auto park_b = [&](int buf) {
         double *dst = slab + buf * KS * LB;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
         const int gq = tid / E;
         srow[tid] = (gq << 8) | (tid - gq * E);
     }
-    load_b(0, bra);
+    load_b(0);
     // the lanes of a trajectory: TT consecutive threads, point n = tl, tl + TT, ...
     const int TT = TB / TPW, pgi = tid / TT, tl = tid - pgi * TT;
     const bool pact = pgi < nb;
@@ -239,9 +244,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
         const int r = idx / N;
         sFX[(vrows + r) * FP + (idx - r * N)] = 0.0;
     }
-    park_b(0, bra);            // (the covariances in the slab region were last read before the barrier that ended step 1)
-    load_b(1, bra);
-    load_b(2, brb);
+    park_b(0);                 // (the covariances in the slab region were last read before the barrier that ended step 1)
+    load_b(1);
     __syncthreads();
     // ---- 3. [T G]' = X' FX'; the G tile's last column is wm: the transformed mean comes out of the same product -----------------
     const int rt = wave % RT, ch = wave / RT;
@@ -251,20 +255,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
     v4d acc[C0];
 #pragma unroll
     for (int ct = 0; ct < C0; ++ct) acc[ct] = v4d{0.0, 0.0, 0.0, 0.0};
-    // one slab: buffer kb & 1 holds slab kb, `older` slab kb + 1 (parked into the other buffer before the last k sub-step),
-    // `newer` slab kb + 2; `older` is then reloaded with slab kb + 3
-    auto slab_step = [&](int kb, double (&older)[PER], double (&newer)[PER]) {
+#ifdef BQF_SKIP_MAIN
+    for (int kb = 0; kb < 0; ++kb) {
+#else
+    for (int kb = 0; kb < NKB; ++kb) {
+#endif
         const int buf = kb & 1;
+        if (kb + 1 < NKB) {
+            park_b(buf ^ 1);
+            load_b(kb + 2);
+        }
         double af[SPB];
 #pragma unroll
         for (int s = 0; s < SPB; ++s) af[s] = frow[KS * kb + lg + 4 * s];
         const double *sb = slab + buf * KS * LB;
 #pragma unroll
         for (int s = 0; s < SPB; ++s) {
-            if (s == SPB - 1 && kb + 1 < NKB) {
-                park_b(buf ^ 1, older);
-                load_b(kb + 3, older);
-            }
 #pragma unroll
             for (int ct = 0; ct < C0; ++ct) {
                 if (EVEN || ct < cnt) {
@@ -274,14 +280,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
             }
         }
         __syncthreads();
-    };
-#ifdef BQF_SKIP_MAIN
-    for (int kb = 0; kb < 0; kb += 2) {
-#else
-    for (int kb = 0; kb < NKB; kb += 2) {
-#endif
-        slab_step(kb, bra, brb);
-        if (kb + 1 < NKB) slab_step(kb + 1, brb, bra);
     }
 #ifdef BQF_SKIP_EPI
     {

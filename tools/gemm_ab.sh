@@ -1,13 +1,5 @@
 #!/bin/bash
-# A/B of the row-block size of the matrix-core GEMM at a few batch sizes (kernel time from rocprofv3)
+# timing experiments on k_fxwc_mfma: library variants with the barrier and / or the slab traffic compiled out (results wrong)
 export TMPDIR=/tmp
-for rt in 1 2; do for B in 1024 4096; do
-  rm -rf gpurun_out/prof_wide
-  SSMQ_GEMM_RT=$rt rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_wide -o w -- python3 tools/wide_time.py $B > gpurun_out/wide_time.log 2>&1 || { tail -5 gpurun_out/wide_time.log; exit 1; }
-  python3 - $rt $B <<'PY'
-import csv, sys
-for r in csv.DictReader(open('gpurun_out/prof_wide/w_kernel_trace.csv')):
-    if 'fxwc' in r['Kernel_Name']:
-        print('RT', sys.argv[1], 'B', sys.argv[2], 'us', (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-PY
-done; done
+echo base; timeout -k 10 120 python tools/c5_ab.py
+for lib in variants/libssmq_*.so; do echo $lib; SSMQ_LIBRARY=$lib timeout -k 10 120 python tools/c5_ab.py 2>&1 | grep -v Assert | tail -3; done
