@@ -32,7 +32,11 @@ __device__ __forceinline__ void load4(const double *p, bool on, double (&v)[4]) 
     }
 }
 
-__global__ __launch_bounds__(64 * kRestWaves) void k_big_rest(const BigRest r, int64_t B) {
+// (launch bounds: two workgroups per CU.  Allowed 512 registers the compiler keeps the MFMA accumulators in AGPRs, and on
+// gfx950 a v_mfma_f64_16x16x4_f64 with AGPR accumulators issues every 103-140 cycles instead of every 64:
+// tools/micro/mfma_f64_peak.hip - 48 against 77 TFLOP/s chip-wide.  Every other matrix-core kernel of the library already
+// had its accumulators in architectural VGPRs.)
+__global__ __launch_bounds__(64 * kRestWaves, 2) void k_big_rest(const BigRest r, int64_t B) {
     const int lane = threadIdx.x & 63;
     const int c = lane & 15, q = lane >> 4;
     const int64_t b = (int64_t)blockIdx.x * kRestWaves + (threadIdx.x >> 6);

@@ -80,16 +80,11 @@ __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const
     park_b(0);
     __syncthreads();
     for (int kb = 0; kb < KB; ++kb) {
-#ifdef GEMM_NO_SLAB
-        const int buf = 0;
-        if (kb + 1 < KB) load_a(kb + 1, an);
-#else
         const int buf = kb & 1;
         if (kb + 1 < KB) {
             load_b(kb + 1);
             load_a(kb + 1, an);
         }
-#endif
         const double *sb = lds + buf * 16 * LB;
 #ifndef SSMQ_GEMM_PARK_AT
 #define SSMQ_GEMM_PARK_AT 3      // the next slab goes to LDS before the last of the four k sub-steps: the writes and
@@ -97,9 +92,7 @@ __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const
 #endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-#ifndef GEMM_NO_SLAB
             if (s == SSMQ_GEMM_PARK_AT && kb + 1 < KB) park_b(buf ^ 1);
-#endif
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const double b = sb[(4 * lg + s) * LB + ct * 16 + li];
@@ -115,9 +108,7 @@ __global__ __launch_bounds__(kGemmBlock, RT == 1 ? 2 : 1) void k_fxwc_mfma(const
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a[rt][q] = an[rt][q];
         }
-#ifndef GEMM_NO_BARRIER
         __syncthreads();
-#endif
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
