@@ -8,10 +8,11 @@
 //   workgroup = 8 waves, TPW whole trajectories = TPW E <= 64 rows of FX, kept in LDS ([row][NP + 2]; N = 201, E = 10: 6
 //   trajectories, 60 rows - what fits 160 KB beside the slabs);
 //   0. the first slab of X, this lane's first sigma point and the covariance's additive terms are requested;
-//   1. one wave per trajectory: mean / covariance in, Cholesky factor in ONE lane's registers (D <= 10; else the wave's
-//      lanes over LDS as k_eval_wave), kept packed in LDS for steps 2 and 4;
-//   2. TT = 512 / TPW lanes per trajectory over its points, factor and mean in registers: sigma point, integrand, E values
-//      into the tile; zero padding;
+//   1. one wave per trajectory: mean / covariance in; the Cholesky factorisations of all the tile's trajectories in the lanes
+//      of ONE wave, in registers (D <= 10; else one wave per trajectory over LDS as k_eval_wave); factors packed in LDS for
+//      steps 2 and 4;
+//   2. the (trajectory, point) pairs over the workgroup's lanes (ten wave-iterations for 6 x 201 pairs): sigma point from
+//      the LDS-resident factor, integrand, E values into the tile; zero padding;
 //   3. the transposed product [T G]' = [Wc | Wcc' | wm]' FX' as in k_fxwc_cov_mfma - slabs of 16 rows of X double-buffered
 //      in LDS, staged through ONE register set (written right after a barrier, re-requested at once) - with wave w on row tile w & 3 and on ONE HALF of the column tiles
 //      (w >> 2): two waves per SIMD, 56 accumulator registers each.  The FX fragments come from the LDS tile: lane group lg
@@ -110,15 +111,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
         srow[tid] = (gq << 8) | (tid - gq * E);
     }
     load_b(0);
-    // the lanes of a trajectory: TT consecutive threads, point n = tl, tl + TT, ...
-    const int TT = TB / TPW, pgi = tid / TT, tl = tid - pgi * TT;
-    const bool pact = pgi < nb;
+    // the (trajectory, point) pairs of the tile in ONE index space over the workgroup's lanes, idx = tid, tid + TB, ...: ten
+    // wave-iterations for 6 x 201 pairs.  (Vector instructions cost their four cycles whatever the number of active lanes,
+    // and - tools/micro/mfma_valu_overlap.hip - they do not hide under matrix instructions: TB / TPW lanes per trajectory
+    // with the factor in registers was 24 wave-iterations, and one factorisation per WAVE six times the instructions of
+    // six factorisations in the lanes of one wave.)
+    const float rN = 1.0f / (float)N;
+    auto split = [&](int idx, int &gi, int &n) {           // idx -> (trajectory, point); exact for idx < 2^20
+        gi = (int)(((float)idx + 0.5f) * rN);
+        n = idx - gi * N;
+    };
     double xin[DM];
     auto load_xi = [&](int n, double (&dst)[DM]) {
 #pragma unroll
         for (int k = 0; k < DM; ++k) dst[k] = (k < D && n < N) ? c[cl.xiT + n * D + k] : 0.0;
     };
-    load_xi(pact ? tl : N, xin);
+    {
+        int gi0, n0;
+        split(tid, gi0, n0);
+        load_xi(tid < nb * N ? n0 : N, xin);
+    }
     // the additive terms of the covariance (4c): in the store loop every one would be a dependent L2 round trip
     double ev = 0.0, ca = 0.0;
     if (tid < E * E) {
@@ -141,22 +153,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
             const int r = i / D, cc = i - r * D;
             A[i] = (cc <= r) ? a.cov[(int64_t)i * a.es_in + b * a.bs_cov] : 0.0;
         }
-        SSMQ_WAVE_SYNC();
-        bool ok = true;
-        if constexpr (REGCHOL) {
-            // lower triangle into lane registers (every lane: LDS broadcasts), identity beyond D; left-looking, the
-            // subtraction order of the other kernels' factorisations
-            double S[PK];
-#pragma unroll
-            for (int i = 0; i < DM; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j) S[SSMQ_PK(i, j)] = (i < D) ? A[i * D + j] : (i == j ? 1.0 : 0.0);
-            ok = chol_packed<DM>(S);
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < PK; ++q) sLp[gi * PK + q] = S[q];
-            }
-        } else {
+        if constexpr (!REGCHOL) {
+            SSMQ_WAVE_SYNC();
+            bool ok = true;
             for (int j = 0; j < D; ++j) {
                 const double ajj = A[j * D + j];
                 ok = ok && (ajj > 0.0);
@@ -178,39 +177,63 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
                 const int j = q - i * (i + 1) / 2;
                 sLp[gi * PK + q] = (i < D) ? A[i * D + j] : (i == j ? 1.0 : 0.0);
             }
-        }
-        if (lane == 0) {
-            sok[gi] = ok ? 1 : 0;
-            if (a.status) a.status[b] = ok ? 0 : 1;
+            if (lane == 0) {
+                sok[gi] = ok ? 1 : 0;
+                if (a.status) a.status[b] = ok ? 0 : 1;
+            }
         }
     }
 #undef SSMQ_WAVE_SYNC
-    __syncthreads();
-    // ---- 2. integrand values: TT lanes per trajectory over its points, factor and mean in registers -----------------------------
-    if (pact) {
-        const int64_t b = bw0 + pgi;
-        const double t = a.time ? a.time[a.time_stride ? b : 0] : 0.0;
-        const bool ok = sok[pgi] != 0;
-        double Lr[PK], mr[DM];
+    if constexpr (REGCHOL) {
+        // D <= 10: the factorisations in registers, lane j of wave 0 = trajectory j (left-looking, the subtraction order of
+        // the other kernels' factorisations; identity beyond D)
+        __syncthreads();
+#ifndef BQF_SKIP_CHOL
+        if (wave == 0) {
+            const int gi = lane < nb ? lane : 0;
+            const double *A = sA + gi * D * D;
+            double S[PK];
 #pragma unroll
-        for (int q = 0; q < PK; ++q) Lr[q] = sLp[pgi * PK + q];
+            for (int i = 0; i < DM; ++i)
 #pragma unroll
-        for (int d = 0; d < DM; ++d) mr[d] = d < D ? sm[pgi * DM + d] : 0.0;
-#ifdef BQF_SKIP_POINTS
-        for (int n = tl; n < 0; n += TT) {
-#else
-        for (int n = tl; n < N; n += TT) {
+                for (int j = 0; j <= i; ++j) S[SSMQ_PK(i, j)] = (i < D) ? A[i * D + j] : (i == j ? 1.0 : 0.0);
+            const bool ok = chol_packed<DM>(S);
+            if (lane < nb) {
+#pragma unroll
+                for (int q = 0; q < PK; ++q) sLp[gi * PK + q] = S[q];
+                sok[gi] = ok ? 1 : 0;
+                if (a.status) a.status[bw0 + gi] = ok ? 0 : 1;
+            }
+        }
 #endif
+    }
+    __syncthreads();
+    // ---- 2. integrand values ---------------------------------------------------------------------------------------------------
+    {
+        const double t0 = (a.time && !a.time_stride) ? a.time[0] : 0.0;
+#ifdef BQF_SKIP_POINTS
+        for (int idx = tid; idx < 0; idx += TB) {
+#else
+        for (int idx = tid; idx < nb * N; idx += TB) {
+#endif
+            int gi, n;
+            split(idx, gi, n);
+            const double t = (a.time && a.time_stride) ? a.time[bw0 + gi] : t0;
+            const double *Lp = sLp + gi * PK, *mp = sm + gi * DM;
             double x[DM], o[DM];
 #pragma unroll
             for (int d = 0; d < DM; ++d) {
-                double s = mr[d];
+                double s = d < D ? mp[d] : 0.0;
 #pragma unroll
-                for (int k = 0; k <= d; ++k) s += Lr[SSMQ_PK(d, k)] * xin[k];      // (rows beyond D: identity x 0)
+                for (int k = 0; k <= d; ++k) s += Lp[SSMQ_PK(d, k)] * xin[k];          // (rows beyond D: identity x 0)
                 x[d] = s;
                 o[d] = 0.0;
             }
-            load_xi(n + TT, xin);                  // the next point's coordinates while this one is evaluated (same registers)
+            {                                      // the next pair's coordinates while this one is evaluated (same registers)
+                int g2, n2;
+                split(idx + TB, g2, n2);
+                load_xi(idx + TB < nb * N ? n2 : N, xin);
+            }
             double xs[kMaxIntegrandIn];
 #pragma unroll
             for (int k = 0; k < kMaxIntegrandIn; ++k) {
@@ -230,9 +253,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
             } else {
                 eval_integrand(a.fid, xs, t, a.fp, o);
             }
+            const bool ok = sok[gi] != 0;
 #pragma unroll
             for (int e = 0; e < DM; ++e)
-                if (e < E) sFX[(pgi * E + e) * FP + n] = ok ? o[e] : nan;
+                if (e < E) sFX[(gi * E + e) * FP + n] = ok ? o[e] : nan;
         }
     }
     // the GEMM's padding columns, and whole rows of a last workgroup with fewer trajectories
