@@ -1,11 +1,18 @@
 // What the fp64 matrix pipe sustains with operands in registers only: every wave issues `iters` x 14 independent
-// v_mfma_f64_16x16x4_f64 (14 accumulators, as the GEMM kernels hold), W waves per SIMD.  Prints TFLOP/s for W = 1, 2, 4 -
-// the ceiling the LDS-fed loops of ssmq_gemm_mfma.hip / ssmq_bq_fused.hip are measured against.
-// hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_f64_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
+// v_mfma_f64_16x16x4_f64 (14 accumulators, as the GEMM kernels hold), on 8 / 64 / 256 workgroup slots x 1, 2, 4 waves per
+// SIMD.  Prints TFLOP/s, the shader clock (s_memtime against the 100 MHz s_memrealtime) and cycles per instruction and
+// SIMD - the ceiling the LDS-fed loops of ssmq_gemm_mfma.hip / ssmq_bq_fused.hip are measured against.  With -DAGPR_FORM the
+// launch bounds leave room for 512 registers and hipcc puts the accumulators into AGPRs: 103-140 cycles per instruction
+// instead of 64 (measured on MI355X, ROCm 7.2).  tools/micro/run_mfma_micro.sh builds and runs both.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256, 2) void k(double *out, int iters, double a0, double b0, unsigned long long *clk) {
+#ifdef AGPR_FORM
+#define MFMA_BOUNDS __launch_bounds__(256)        // room for 512 registers: hipcc keeps the accumulators in AGPRs
+#else
+#define MFMA_BOUNDS __launch_bounds__(256, 2)     // 256 registers: accumulators in architectural VGPRs
+#endif
+__global__ MFMA_BOUNDS void k(double *out, int iters, double a0, double b0, unsigned long long *clk) {
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     v4d acc[14];
 #pragma unroll
@@ -17,9 +24,6 @@ __global__ __launch_bounds__(256, 2) void k(double *out, int iters, double a0, d
 #pragma unroll
         for (int i = 0; i < 14; ++i) {
             asm volatile("" : "+v"(a[i]));           // a different A operand per instruction, as in the GEMM kernels
-#ifdef ACC_IN_VGPR
-            asm volatile("" : "+v"(acc[i]));         // accumulators in architectural VGPRs (the GEMM kernels' are), not AGPRs
-#endif
             acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b, acc[i], 0, 0, 0);
         }
     }
