@@ -417,25 +417,31 @@ class MarginalInference(GaussianInference):
         return m, c
 
     def _theta_static(self):
-        """What does not change between calls of `theta_step` (the marginalised filter makes hundreds per time step and the
+        """What rarely changes between calls of `theta_step` (the marginalised filter makes hundreds per time step and the
         ctypes conversions were a third of a call): integrand descriptors, transform handles, the noise terms, and a
-        prototype of the entry point that takes the array addresses as plain integers."""
+        prototype of the entry point that takes the array addresses as plain integers.  Rebuilt when a model constant, a
+        state index or a noise covariance has been changed since (compared by value: research code assigns them after
+        construction)."""
+        state_index = getattr(self.mod_obs, 'state_index', None)
+        key = (self.mod_dyn._par(), self.mod_obs._par(), None if state_index is None else tuple(state_index))
         st = getattr(self, '_theta_cache', None)
-        if st is None:
-            lib = _lib.load()
-            f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
-            f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
-            vp = ctypes.c_void_p
-            proto = ctypes.CFUNCTYPE(ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, vp, vp, ctypes.c_double, vp, vp, ctypes.c_int,
-                                     vp, ctypes.c_int, ctypes.c_double, vp, vp, vp, vp, vp, vp)
-            st = dict(fn=proto(('ssmq_gp_theta_step', lib)), f_dyn=f_dyn, f_obs=f_obs,
-                      pf_dyn=ctypes.addressof(f_dyn), pf_obs=ctypes.addressof(f_obs),
-                      h_dyn=self.tf_dyn._handle_for(e_dyn), h_obs=self.tf_obs._handle_for(e_obs),
-                      gqg=(np.ascontiguousarray(self.G.dot(self.q_cov).dot(self.G.T), dtype=np.float64)
-                           if self.mod_dyn.noise_additive else None),
-                      rr=np.ascontiguousarray(self.r_cov, dtype=np.float64),
-                      jitter=float(self.tf_dyn.model.kernel.jitter))
-            self._theta_cache = st
+        if st is not None and st['key'] == key and np.array_equal(st['q_cov'], self.q_cov) and \
+                np.array_equal(st['rr'], self.r_cov) and np.array_equal(st['G'], self.G):
+            return st
+        lib = _lib.load()
+        f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
+        f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
+        vp = ctypes.c_void_p
+        proto = ctypes.CFUNCTYPE(ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, vp, vp, ctypes.c_double, vp, vp, ctypes.c_int,
+                                 vp, ctypes.c_int, ctypes.c_double, vp, vp, vp, vp, vp, vp)
+        st = dict(key=key, fn=proto(('ssmq_gp_theta_step', lib)), f_dyn=f_dyn, f_obs=f_obs,
+                  pf_dyn=ctypes.addressof(f_dyn), pf_obs=ctypes.addressof(f_obs),
+                  h_dyn=self.tf_dyn._handle_for(e_dyn), h_obs=self.tf_obs._handle_for(e_obs),
+                  q_cov=np.array(self.q_cov, dtype=np.float64), G=np.array(self.G, dtype=np.float64),
+                  gqg=(np.ascontiguousarray(self.G.dot(self.q_cov).dot(self.G.T), dtype=np.float64)
+                       if self.mod_dyn.noise_additive else None),
+                  rr=np.array(self.r_cov, dtype=np.float64, order='C'))
+        self._theta_cache = st
         return st
 
     def theta_step(self, theta, mean, cov, y, time):
@@ -458,7 +464,8 @@ class MarginalInference(GaussianInference):
         om, oc, ll = np.empty((P, D)), np.empty((P, D, D)), np.empty(P)
         st = np.zeros(P, dtype=np.int32)
         gqg = c['gqg']
-        _lib.check(c['fn'](c['h_dyn'], c['pf_dyn'], c['h_obs'], c['pf_obs'], P, pd.ctypes.data, po.ctypes.data, c['jitter'],
+        _lib.check(c['fn'](c['h_dyn'], c['pf_dyn'], c['h_obs'], c['pf_obs'], P, pd.ctypes.data, po.ctypes.data,
+                           float(self.tf_dyn.model.kernel.jitter),
                            mean.ctypes.data, cov.ctypes.data, 1 if mean.ndim == 1 else 0, y.ctypes.data,
                            1 if y.ndim == 1 else 0, float(time), None if gqg is None else gqg.ctypes.data,
                            c['rr'].ctypes.data, om.ctypes.data, oc.ctypes.data, ll.ctypes.data, st.ctypes.data),

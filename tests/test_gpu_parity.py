@@ -1110,6 +1110,15 @@ def test_theta_step_two_launch_route_is_bitwise_the_stage_route(amd, model, monk
         monkeypatch.delenv('SSMQ_NO_THETA_FUSED')
         for got, want in zip(r1, r2):
             assert np.array_equal(got, want, equal_nan=got.dtype.kind == 'f'), (model, n, 'shared')
+    # the per-filter cache of the wrapper (descriptors, handles, noise terms) follows a noise covariance assigned afterwards
+    before = alg.theta_step(th, m[0], P[0], y[0], 4)
+    alg.r_cov = 2.0 * alg.r_cov
+    after = alg.theta_step(th, m[0], P[0], y[0], 4)
+    ok = ~np.isnan(before[2])
+    assert ok.any() and not np.any(before[2][ok] == after[2][ok])
+    alg.r_cov = 0.5 * alg.r_cov
+    again = alg.theta_step(th, m[0], P[0], y[0], 4)
+    assert np.array_equal(again[2], before[2], equal_nan=True)
 
 
 def test_marginal_filter_forward_pass(amd, golden):
