@@ -1214,19 +1214,6 @@ void reset_wide_attributes();
 void drop_staging_arena();
 static unsigned g_device_epoch = 1;
 unsigned device_epoch() { return g_device_epoch; }
-// CUs of the current device (persistent kernels launch one workgroup per CU); 256 if the query fails
-int compute_units() {
-    static unsigned epoch = 0;
-    static int cus = 256;
-    if (epoch != g_device_epoch) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        epoch = g_device_epoch;
-    }
-    return cus;
-}
 void drop_theta_step_graphs();
 void reset_device_caches() {
     ++g_device_epoch;
@@ -1981,8 +1968,13 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
                     if (g) hipGraphDestroy(g);
                     return rc ? rc : hip_fail(ce, "hipStreamEndCapture(theta step)");
                 }
+                const hipError_t ie = hipGraphInstantiate(&tg->exec, g, nullptr, nullptr, 0);
+                if (ie != hipSuccess) {
+                    hipGraphDestroy(g);
+                    tg->exec = nullptr;
+                    return hip_fail(ie, "hipGraphInstantiate(theta step)");
+                }
                 tg->graph = g;
-                SSMQ_HIP(hipGraphInstantiate(&tg->exec, tg->graph, nullptr, nullptr, 0));
             }
             SSMQ_HIP(hipGraphLaunch(tg->exec, s));
         }

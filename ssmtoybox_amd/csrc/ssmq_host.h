@@ -35,7 +35,6 @@ int ensure_device();
 // Bumped whenever the library moves to another device (reset_device_caches): per-function attributes
 // (hipFuncAttributeMaxDynamicSharedMemorySize) are per device and must be set again after a change.
 unsigned device_epoch();
-int compute_units();
 
 #define SSMQ_HIP(call)                                        \
     do {                                                      \
