@@ -34,6 +34,7 @@ namespace ssmq {
 struct WgtArgs {
     int32_t D, N, P, NB, bs, use_lds;
     int32_t stage;      // 0: everything in one launch; 1: K + factor only (large point sets); 2: from the inverse onwards
+    int32_t tiled;      // 1: the products go through LDS tiles (gemm_tiled) although K and its inverse live in global memory
     int32_t var_mode;   // 1: BayesSardModel.exp_model_variance / integral_variance semantics (bq/bqmod.py:995-1050): always
                         // the general formulas, no jitter on V' iK V; weights are still written but are not the reference's
     double jitter;
@@ -427,7 +428,8 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
     double *A = a.use_lds == 1 ? lds : gA;
     double *X = a.use_lds == 1 ? lds + N * N : gX;
     // products: the LDS-tiled routine for large point sets (LDS is free again once the inverse exists), else the plain one
-#define GEMM(...) do { if (large) gemm_tiled(lds, __VA_ARGS__); else gemm(__VA_ARGS__); } while (0)
+    const bool tiled = large || a.tiled != 0;
+#define GEMM(...) do { if (tiled) gemm_tiled(lds, __VA_ARGS__); else gemm(__VA_ARGS__); } while (0)
     double *oq = o.q, *oQ = o.Q, *oR = o.R, *oiK = o.iK, *owm = o.wm, *oWc = o.Wc, *oWcc = o.Wcc;
 
     if (tid < D) s_sil[tid] = 1.0 / par[1 + tid];   // par[1:] ** -1   (bq/bqkern.py:454)
@@ -782,8 +784,11 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
     }
     const bool staged = packed <= lds_cap && N <= kInvLanes * kInvSlots && !getenv("SSMQ_WEIGHTS_NO_LDS");
     if (!staged) {
+        // K, its factor and its inverse in the (L2-resident) workspace; the products still run through LDS tiles - the same
+        // sums in the same order as gemm(), which streamed both operands of every dot product from L2 (N = 1 181: 2.5 s)
         a.use_lds = 0;
-        hipLaunchKernelGGL(k_weights<1024>, dim3(a.P), dim3(1024), 0, s, a);
+        a.tiled = 1;
+        hipLaunchKernelGGL(k_weights<1024>, dim3(a.P), dim3(1024), tiles, s, a);
         return hip_fail(hipGetLastError(), "k_weights");
     }
     if (!a.lpack) {
