@@ -60,9 +60,12 @@ template <> struct HasTimeTable<SSMQ_F_UNGMNA_DYN> { static constexpr bool value
 #ifndef SSMQ_FUSED_FORCE_OCC
 #define SSMQ_FUSED_FORCE_OCC 0   // A/B builds (tools/build_variant.sh): waves per SIMD requested for every instantiation
 #endif
+#ifndef SSMQ_FUSED_OCC_D5_SIGMA
+#define SSMQ_FUSED_OCC_D5_SIGMA 1   // waves per SIMD for the centred D = 5 kernels (276 registers unconstrained; A/B: tools/build_variant.sh)
+#endif
 template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT, int STU = -1>
 __global__ __launch_bounds__(kSmallBlock, (SSMQ_FUSED_FORCE_OCC ? SSMQ_FUSED_FORCE_OCC
-                                           : ((D >= 6 || (D >= 5 && FORM == SSMQ_FORM_SIGMA)) ? 1 : 2))) void k_filter_fused(const FusedArgs a) {
+                                           : (D >= 6 ? 1 : ((D >= 5 && FORM == SSMQ_FORM_SIGMA) ? SSMQ_FUSED_OCC_D5_SIGMA : 2)))) void k_filter_fused(const FusedArgs a) {
     if ((int)threadIdx.x >= a.lpw) return;
     const uint32_t b = blockIdx.x * a.lpw + threadIdx.x;
     if ((int64_t)b >= a.B) return;
