@@ -61,7 +61,8 @@ template <> struct HasTimeTable<SSMQ_F_UNGMNA_DYN> { static constexpr bool value
 #define SSMQ_FUSED_FORCE_OCC 0   // A/B builds (tools/build_variant.sh): waves per SIMD requested for every instantiation
 #endif
 #ifndef SSMQ_FUSED_OCC_D5_SIGMA
-#define SSMQ_FUSED_OCC_D5_SIGMA 1   // waves per SIMD for the centred D = 5 kernels (276 registers unconstrained; A/B: tools/build_variant.sh)
+#define SSMQ_FUSED_OCC_D5_SIGMA 1   // waves per SIMD for the centred D = 5 kernels: 276 registers unconstrained; held to 256
+                                    // (2 waves) 20 of them spill and the UKF pass is 2-3 % slower (round 3, tools/build_variant.sh)
 #endif
 template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT, int STU = -1>
 __global__ __launch_bounds__(kSmallBlock, (SSMQ_FUSED_FORCE_OCC ? SSMQ_FUSED_FORCE_OCC
