@@ -1,8 +1,8 @@
+"""How long the device needs to bring its clocks back up after idle: the UKF pass on the reentry model (B = 1e5, T = 50) in
+consecutive groups of ten launches from idle, after 3 s of other work, after 2 s of idle (profiles/r03_clock_rampup.txt)."""
 import os, sys, time
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ssmtoybox_amd as amd
-from ssmtoybox_amd import _lib
 from bench import FilterBench, Mt6Bench, timed_passes
 amd.set_device(0)
 wl = FilterBench(amd, 100000, 50, 31, 'reentry5', 'ukf')
