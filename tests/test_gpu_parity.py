@@ -1081,7 +1081,8 @@ def test_theta_step_two_launch_route_is_bitwise_the_stage_route(amd, model, monk
         obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
         alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'ut')
     D = dyn.dim_state
-    for n in (1, alg.param_dim + 1, 2 * alg.param_dim, 333):
+    # (20 001 items on one model: many workgroups per CU in flight, the hand-over through global planes under load)
+    for n in (1, alg.param_dim + 1, 2 * alg.param_dim, 333) + ((20001,) if model == 'pendulum_ut' else ()):
         th = 0.4 * rng.standard_normal((n, alg.param_dim))
         m = 0.5 * rng.standard_normal((n, D))
         a = rng.standard_normal((n, D, D)) * 0.3
