@@ -33,15 +33,47 @@ class Transform(ctypes.Structure):
                 ('Wcc', DP), ('emv', DP), ('iK', DP), ('f', Integrand)]
 
 
+FLAGS = 'gcc -O2 -fopenmp (portable build, oracle/Makefile: all)'
+
+
 def load():
+    """The portable build (oracle/Makefile `all`), or the file SSMQ_ORACLE_LIB names (the sanitizer build of
+    tools/oracle_asan.sh)."""
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, 'libssmq_oracle.so')
+        path = os.environ.get('SSMQ_ORACLE_LIB') or os.path.join(_HERE, 'libssmq_oracle.so')
         if not os.path.exists(path):
             subprocess.check_call(['make', '-C', _HERE])
         _lib = ctypes.CDLL(path)
         _lib.orc_max_threads.restype = ctypes.c_int
     return _lib
+
+
+def use_native():
+    """For bench.py's cpu_baseline leg: (re)build the port with -O3 -march=native ON THIS HOST (`make -B native`; a file
+    built on another machine may use instructions this one lacks) and switch to it.  Returns the compiler line, or the
+    portable build's when the native build is not possible (no compiler on the box)."""
+    global _lib, FLAGS
+    try:
+        subprocess.check_call(['make', '-B', '-C', _HERE, 'native'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = ctypes.CDLL(os.path.join(_HERE, 'libssmq_oracle_native.so'))
+        lib.orc_max_threads.restype = ctypes.c_int
+        _lib = lib
+        FLAGS = open(os.path.join(_HERE, 'libssmq_oracle_native.flags')).read().strip() + ' (built on this host)'
+    except (OSError, subprocess.CalledProcessError):
+        load()
+    return FLAGS
+
+
+def cpu_model():
+    """First `model name` of /proc/cpuinfo (the host the baseline is timed on)."""
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def _p(a):

@@ -742,8 +742,124 @@ def g11_marginal_smoother():
     save('g11_marginal_smoother', **out)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G12: quadrature weights on LARGE point sets (N > 201), made by the reference on INJECTED point sets
+# ---------------------------------------------------------------------------------------------------------------
+def _inject_points(model, pts):
+    """the reference has no rule with more than 2 D^2 + 1 points besides Gauss-Hermite grids; any other
+    set is handed to its models by overwriting the three attributes Model.__init__ derives from the points
+    (bq/bqmod.py:91-100)."""
+    model.points = np.ascontiguousarray(pts)
+    model.dim_in, model.num_pts = pts.shape
+    model.eye_n = np.eye(pts.shape[1])
+
+
+G12_ROWS, G12_PROBES = 24, 6
+
+
+def _smooth_map(dim):
+    """The build's synthetic smooth D -> D map (ssmtoybox_amd.ssmod.Smooth10DTransition at D = 10) as a plain callable of
+    the shape BQTransform._fcn_eval expects (bq/bqmtran.py:132-156): f(x, fcn_par)."""
+    h = dim // 2
+
+    def f(x, *args):
+        return np.concatenate((np.sin(x[:h]) + x[h:2 * h] ** 2, x[h:2 * h] * np.cos(x[:h])))
+    return f
+
+
+def _big_matrix_digest(out, key, a, rng):
+    """An (N, N) symmetric matrix of a large set is committed as: its diagonal, G12_ROWS full rows (seeded choice) and
+    its products with G12_PROBES seeded probe vectors - every entry enters the probes, the rows pin entries singly."""
+    n = a.shape[0]
+    rows = np.sort(rng.choice(n, size=min(G12_ROWS, n), replace=False))
+    probes = rng.standard_normal((n, G12_PROBES))
+    out[key + '_rows_idx'], out[key + '_rows'] = rows, a[rows]
+    out[key + '_diag'] = np.diag(a).copy()
+    out[key + '_probes'], out[key + '_probed'] = probes, a.dot(probes)
+    out[key + '_absmax'] = np.float64(np.max(np.abs(a)))
+    out[key + '_fro'] = np.float64(np.linalg.norm(a))
+
+
+def g12_large_weights():
+    """GP and Bayes-Sard (total degree <= 2) weights on (i) the reference's own Gauss-Hermite degree-3 grid at D = 6
+    (N = 729) and (ii) this build's fully-symmetric degree-7 rule at D = 10 (N = 1181, BASELINE configs[4] as worded; the
+    rule is not in the reference, mtran.py:392, so the POINTS are this build's and stored as inputs; the WEIGHTS are the
+    reference's).  The full N = 1181 Bayes-Sard Wc is stored too (lower triangle) so that a GPU test can inject the
+    reference's own weights into apply()."""
+    import time as _time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from ssmtoybox_amd.mtran import FullySymmetricStudentTransform as BuildFS     # host C++ (libssmq.so ssmq_points), no GPU
+    out = {}
+    rng = np.random.default_rng(20261004)
+    fs7 = np.ascontiguousarray(BuildFS.unit_sigma_points(10, degree=7))
+    # length scales: cond(K + 1e-8 I) is 3.5e4 / 2.4e3 / 8.3e5 - at ell = 3 the GH grid has cond 2e10 and no two evaluations
+    # of iK Q iK agree to any digit, so that grid is pinned at ell = 1.5; the degree-7 set at the bench's ell = 3 and at 1
+    cases = [('d6_gh3_l15', 6, 1.5, GaussHermiteTransform.unit_sigma_points(6, 3)),
+             ('d10_fs7_l1', 10, 1.0, fs7), ('d10_fs7_l3', 10, 3.0, fs7)]
+    for tag, dim, ell, pts in cases:
+        N = pts.shape[1]
+        par = gp_par(dim, ell)
+        mi = np.hstack([n_sum_k(dim, td) for td in range(3)])
+        out[tag + '_pts'], out[tag + '_par'], out[tag + '_mi'] = pts, par, mi
+        # GP (bq/bqmod.py:495-523)
+        t0 = _time.time()
+        tf = GaussianProcessTransform(dim, dim, par, 'rbf', 'ut')
+        _inject_points(tf.model, pts)
+        wm, Wc, Wcc = tf.weights(par)
+        tf.wm, tf.Wc, tf.Wcc = wm, Wc, Wcc           # as research/tpq/tpq_ungm.py:114-124 does
+        m, k = tf.model, tf.model.kernel
+        K = k.eval(par, pts, scaling=False)
+        out['gp_' + tag + '_cond'] = np.float64(np.linalg.cond(K + 1e-8 * np.eye(N)))
+        out['gp_' + tag + '_wm'], out['gp_' + tag + '_Wcc'] = wm, Wcc
+        out['gp_' + tag + '_q'], out['gp_' + tag + '_R'] = m.q, k.exp_x_xkx(par, pts)
+        out['gp_' + tag + '_mv'], out['gp_' + tag + '_iv'] = np.float64(m.model_var), np.float64(m.integral_var)
+        _big_matrix_digest(out, 'gp_' + tag + '_Wc', Wc, rng)
+        _big_matrix_digest(out, 'gp_' + tag + '_iK', m.iK, rng)
+        _big_matrix_digest(out, 'gp_' + tag + '_Q', m.Q, rng)
+        _big_matrix_digest(out, 'gp_' + tag + '_K', K, rng)
+        print(tag, 'gp', N, 'points', round(_time.time() - t0, 1), 's  cond', out['gp_' + tag + '_cond'])
+        # Bayes-Sard, general case Q < N (bq/bqmod.py:963-988)
+        t0 = _time.time()
+        tb = BayesSardTransform(dim, dim, par, mi, 'fs', {'degree': 5})
+        _inject_points(tb.model, pts)
+        wm, Wc, Wcc = tb.weights(par, mi)
+        tb.wm, tb.Wc, tb.Wcc = wm, Wc, Wcc
+        mb = tb.model
+        V = vandermonde(mi, pts)
+        iK = mb.kernel.eval_inv_dot(par, pts, scaling=False)
+        out['bs_' + tag + '_condK'] = out['gp_' + tag + '_cond']
+        out['bs_' + tag + '_condV'] = np.float64(np.linalg.cond(V))
+        out['bs_' + tag + '_condVKV'] = np.float64(np.linalg.cond(V.T.dot(iK).dot(V) + 1e-8 * np.eye(V.shape[1])))
+        out['bs_' + tag + '_wm'], out['bs_' + tag + '_Wcc'] = wm, Wcc
+        out['bs_' + tag + '_mv'], out['bs_' + tag + '_iv'] = np.float64(mb.model_var), np.float64(mb.integral_var)
+        out['bs_' + tag + '_kxpx'] = mb._exp_x_kxpx(par, mi, pts)
+        _big_matrix_digest(out, 'bs_' + tag + '_Wc', Wc, rng)
+        if tag == 'd10_fs7_l3':
+            out['bs_' + tag + '_Wc_tril'] = Wc[np.tril_indices(N)]
+        print(tag, 'bs', N, 'points', round(_time.time() - t0, 1), 's  condVKV', out['bs_' + tag + '_condVKV'])
+        # apply() of the reference with these weights (bq/bqmtran.py:60-109) on a smooth D -> D map the build also has as a
+        # device integrand (F_SMOOTH10D_DYN restated here as a plain callable; its first `dim` components are used)
+        n_in = 6
+        means = rng.standard_normal((n_in, dim))
+        covs = np.zeros((n_in, dim, dim))
+        for i in range(n_in):
+            a = rng.standard_normal((dim, dim)) / np.sqrt(dim)
+            covs[i] = a.dot(a.T) + 0.1 * np.eye(dim)
+        out[tag + '_apply_mean'], out[tag + '_apply_cov'] = means, covs
+        f = _smooth_map(dim)
+        mf, cf, cfx = np.zeros((n_in, dim)), np.zeros((n_in, dim, dim)), np.zeros((n_in, dim, dim))
+        for i in range(n_in):
+            mf[i], cf[i], cfx[i] = tb.apply(f, means[i], covs[i], np.atleast_1d(0))
+        out['bs_' + tag + '_apply_mf'], out['bs_' + tag + '_apply_cf'], out['bs_' + tag + '_apply_cfx'] = mf.copy(), cf.copy(), cfx.copy()
+        for i in range(n_in):
+            mf[i], cf[i], cfx[i] = tf.apply(f, means[i], covs[i], np.atleast_1d(0))
+        out['gp_' + tag + '_apply_mf'], out['gp_' + tag + '_apply_cf'], out['gp_' + tag + '_apply_cfx'] = mf, cf, cfx
+    save('g12_large_weights', **out)
+
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
     if 'g1' in which:
         g1_points()
     if 'g2' in which:
@@ -766,3 +882,5 @@ if __name__ == '__main__':
         g10_referee()
     if 'g11' in which:
         g11_marginal_smoother()
+    if 'g12' in which:
+        g12_large_weights()

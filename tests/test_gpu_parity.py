@@ -511,6 +511,130 @@ def test_rbf_kernel_methods_golden(amd, golden, case):
                       capped(max(1e-10, 8 * cond ** 2 * 2.2e-16), t + ' integral_variance(par)'), t + ' integral_variance(par)')
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# weights and transforms on LARGE point sets (202 <= N): the reference's values on injected sets (golden g12)
+# ---------------------------------------------------------------------------------------------------------------
+G12_CASES = [('d6_gh3_l15', 'gh', {'degree': 3}), ('d10_fs7_l1', 'fs', {'degree': 7}), ('d10_fs7_l3', 'fs', {'degree': 7})]
+
+
+def _digest_err(g, key, a):
+    from tests.test_oracle_golden import digest_err
+    return digest_err(g, key, a)
+
+
+def _full_from_tril(v, n):
+    full = np.zeros((n, n))
+    full[np.tril_indices(n)] = v
+    return full + np.tril(full, -1).T
+
+
+@pytest.mark.parametrize('case', G12_CASES, ids=[c[0] for c in G12_CASES])
+def test_large_set_weights_golden(amd, golden, case):
+    """Quadrature weights above N = 201 (the tiled stage-2 route of k_weights<1024>): GP and Bayes-Sard (total degree <=
+    2) on the Gauss-Hermite degree-3 grid at D = 6 (N = 729) and on this build's degree-7 rule at D = 10 (N = 1181, BASELINE
+    configs[4] as worded), against the REFERENCE's weights on the same (injected) point sets - full vectors, and for the
+    (N, N) matrices the committed digest (diagonal, 24 rows, 6 probe products, Frobenius norm).  Bars: cond-scaled with the
+    stored condition numbers, as for the small sets."""
+    g = golden('g12_large_weights')
+    tag, pstr, ppar = case
+    pts, par, mi = g[tag + '_pts'], g[tag + '_par'], g[tag + '_mi']
+    dim, N = pts.shape
+    eps = 2.2e-16
+    tf = amd.GaussianProcessTransform(dim, dim, par, 'rbf', pstr, ppar)
+    assert np.array_equal(tf.model.points, pts)          # the rule the fixture was made on IS the one the build generates
+    cond = float(g['gp_' + tag + '_cond'])
+    tol1, tol2 = max(RTOL, 64 * cond * eps), max(RTOL, 8 * cond ** 2 * eps)
+    t = 'g12 gp ' + tag + ' '
+    assert rel_err(tf.model.q, g['gp_' + tag + '_q']) < 1e-13
+    assert within(_digest_err(g, 'gp_' + tag + '_Q', tf.model.Q), 1e-13, t + 'Q')
+    assert within(_digest_err(g, 'gp_' + tag + '_K', tf.model.kernel.eval(par, pts, scaling=False)), 1e-13, t + 'K')
+    assert within(_digest_err(g, 'gp_' + tag + '_iK', tf.model.iK), tol1, t + 'iK')
+    assert within(rel_err(tf.wm, g['gp_' + tag + '_wm']), tol1, t + 'wm')
+    assert within(rel_err(tf.Wcc, g['gp_' + tag + '_Wcc']), tol1, t + 'Wcc')
+    assert within(_digest_err(g, 'gp_' + tag + '_Wc', tf.Wc), tol2, t + 'Wc')
+    assert np.array_equal(tf.Wc, tf.Wc.T)
+    assert within(abs(tf.model.model_var - float(g['gp_' + tag + '_mv'])), tol2, t + 'model_var')
+    assert within(abs(tf.model.integral_var - float(g['gp_' + tag + '_iv'])), tol2, t + 'integral_var')
+    # Bayes-Sard, general case (66 / 28 basis functions < N)
+    tb = amd.BayesSardTransform(dim, dim, par, mi, pstr, ppar)
+    cK, cVKV = float(g['bs_' + tag + '_condK']), float(g['bs_' + tag + '_condVKV'])
+    tolb = max(1e-12, 64 * max(cK, cVKV) * eps)
+    tolb2 = max(1e-12, 8 * max(cK, cVKV) ** 2 * eps)      # Wc = iK (Q - A B A') iK: K^-1 twice (bq/bqmod.py:976)
+    t = 'g12 bs ' + tag + ' '
+    assert within(rel_err(tb.model._exp_x_kxpx(par, mi, pts), g['bs_' + tag + '_kxpx']), 1e-13, t + 'kxpx')
+    assert within(rel_err(tb.wm, g['bs_' + tag + '_wm']), tolb, t + 'wm')
+    assert within(rel_err(tb.Wcc, g['bs_' + tag + '_Wcc']), tolb, t + 'Wcc')
+    assert within(_digest_err(g, 'bs_' + tag + '_Wc', tb.Wc), capped(tolb2, t + 'Wc'), t + 'Wc')
+    assert np.array_equal(tb.Wc, tb.Wc.T)
+    if 'bs_' + tag + '_Wc_tril' in g:
+        assert within(rel_err(tb.Wc, _full_from_tril(g['bs_' + tag + '_Wc_tril'], N)), capped(tolb2, t + 'Wc (every entry)'), t + 'Wc (every entry)')
+    assert within(abs(tb.model.model_var - float(g['bs_' + tag + '_mv'])), tolb, t + 'model_var')
+    assert within(abs(tb.model.integral_var - float(g['bs_' + tag + '_iv'])), tolb, t + 'integral_var')
+    # apply() with the build's OWN large-set weights against the reference's apply() with ITS weights (6 inputs each)
+    h = dim // 2
+
+    def f(x, par_):
+        return np.concatenate((np.sin(x[:h]) + x[h:2 * h] ** 2, x[h:2 * h] * np.cos(x[:h])))
+    for kind, tr, bar in (('gp', tf, max(RTOL, tol2)), ('bs', tb, max(RTOL, tolb2))):
+        worst = 0.0
+        for i in range(g[tag + '_apply_mean'].shape[0]):
+            mean, cov = g[tag + '_apply_mean'][i], g[tag + '_apply_cov'][i]
+            got = tr.apply(f, mean, cov, np.atleast_1d(0))
+            ref = (g[kind + '_' + tag + '_apply_mf'][i], g[kind + '_' + tag + '_apply_cf'][i], g[kind + '_' + tag + '_apply_cfx'][i])
+            worst = max(worst, assert_moments_close(got, ref, cov, rtol=bar, what=(kind, tag, i)))
+        assert within(worst, bar, 'g12 {} {} apply() with own weights vs the reference (scaled)'.format(kind, tag))
+
+
+def test_config4_as_worded_degree7_full_batch(amd, golden):
+    """BASELINE configs[4] AS WORDED: Bayes-Sard transform, D = E = 10, fully-symmetric degree-7 rule (N = 1181), B = 1e4
+    on the device integrand, with the REFERENCE's weights injected (golden g12: the reference's bq_weights on this point
+    set, every entry of Wc).  128 sampled trajectories against the oracle with the same weights, the reference's own
+    apply() outputs for the 6 committed inputs, exact symmetry, batch-permutation invariance bit for bit."""
+    from ssmtoybox_amd import ssmod as sm
+    g = golden('g12_large_weights')
+    tag = 'd10_fs7_l3'
+    pts, par, mi = g[tag + '_pts'], g[tag + '_par'], g[tag + '_mi']
+    N = pts.shape[1]
+    B = 10000
+    rng = np.random.default_rng(177)
+    means = rng.standard_normal((B, 10))
+    a = rng.standard_normal((B, 10, 10)) / np.sqrt(10)
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(10)
+    n_ref = g[tag + '_apply_mean'].shape[0]
+    means[:n_ref], covs[:n_ref] = g[tag + '_apply_mean'], g[tag + '_apply_cov']
+    tf = amd.BayesSardTransform(10, 10, par, mi, 'fs', {'degree': 7})
+    assert np.array_equal(tf.model.points, pts)
+    w = dict(wm=g['bs_' + tag + '_wm'], Wc=_full_from_tril(g['bs_' + tag + '_Wc_tril'], N), Wcc=g['bs_' + tag + '_Wcc'],
+             model_var=float(g['bs_' + tag + '_mv']))
+    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
+    f = sm.Smooth10DTransition().dyn_eval
+    mf, cf, cfx, st = tf.apply_batch(f, means, covs, 0.0, return_status=True)
+    assert not st.any() and np.all(np.isfinite(mf)) and np.all(np.isfinite(cf)) and np.all(np.isfinite(cfx))
+    assert np.array_equal(cf, cf.transpose(0, 2, 1))
+    worst = 0.0
+    for i in range(n_ref):
+        ref = (g['bs_' + tag + '_apply_mf'][i], g['bs_' + tag + '_apply_cf'][i], g['bs_' + tag + '_apply_cfx'][i])
+        worst = max(worst, assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=('reference apply', i)))
+    assert within(worst, 1e-10, 'configs[4] as worded: device transform vs the REFERENCE apply() (6 inputs, scaled)')
+    worst = 0.0
+    for i in np.random.default_rng(178).choice(B, 128, replace=False):
+        ref = orc.apply_bq(orc.F_SMOOTH10D_DYN, means[i], covs[i], 0.0, pts, w)
+        worst = max(worst, assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=(tag, i)))
+    assert within(worst, 1e-10, 'configs[4] as worded (degree 7, N=1181, B=1e4) device transform vs oracle (128 samples, scaled)')
+    perm = np.random.default_rng(179).permutation(B)[:1024]
+    mf2, cf2, cfx2 = tf.apply_batch(f, means[perm], covs[perm], 0.0)
+    assert np.array_equal(mf2, mf[perm]) and np.array_equal(cf2, cf[perm]) and np.array_equal(cfx2, cfx[perm])
+    # the same batch with the build's OWN weights: differs by what the weights' conditioning allows
+    tf2 = amd.BayesSardTransform(10, 10, par, mi, 'fs', {'degree': 7})
+    mf3, cf3, cfx3 = tf2.apply_batch(f, means[:256], covs[:256], 0.0)
+    eps = 2.2e-16
+    bar = max(1e-10, 64 * max(float(g['bs_' + tag + '_condK']), float(g['bs_' + tag + '_condVKV'])) * eps)
+    worst = 0.0
+    for i in range(256):
+        worst = max(worst, assert_moments_close((mf3[i], cf3[i], cfx3[i]), (mf[i], cf[i], cfx[i]), covs[i], rtol=bar, what=('own weights', i)))
+    assert within(worst, bar, 'configs[4] as worded: own weights vs reference weights, 256 transforms (scaled)')
+
+
 def test_gp_weights_scaling_invariance(amd):
     # tests/test_bqmtran.py:40-46 of the reference: exact equality
     tf = amd.GaussianProcessTransform(3, 3, np.array([[1.0, 3.0, 3.0, 3.0]]))
