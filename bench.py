@@ -426,8 +426,8 @@ def measure_c5_unisolvent(amd, B=100000, iters=20):
 def measure_c5_degree7(amd, B=10000, iters=5, with_cpu=True):
     """BASELINE configs[4] AS WORDED: Bayes-Sard transform at D = E = 10 with a fully-symmetric rule of degree 7.  The
     reference has degree 3 and 5 only (mtran.py:392); the rule is this build's own (1181 points, exact to degree 7:
-    tests/test_host.py) and therefore parity-unpinned - the ARITHMETIC on it is checked against the oracle with the
-    device's weights.  Route: evaluation pass, T = FX [Wc | Wcc'] by column blocks on the matrix cores, per-trajectory
+    tests/test_host.py), so the POINTS are parity-unpinned; weights and transform on them are pinned to the reference run on
+    the injected set (tests/golden/g12_large_weights.npz, tests/test_gpu_parity.py::test_config4_as_worded_degree7_full_batch).  Route: evaluation pass, T = FX [Wc | Wcc'] by column blocks on the matrix cores, per-trajectory
     rest (k_apply_big)."""
     from ssmtoybox_amd import _lib, ssmod
     from ssmtoybox_amd.bq.bqmod import n_sum_k
@@ -459,9 +459,15 @@ def measure_c5_degree7(amd, B=10000, iters=5, with_cpu=True):
     e1.record()
     ms = e0.elapsed_ms(e1) / iters
     g_mf, g_cf = mf.to_host(), cf.to_host((D, D))
-    w = dict(wm=tf.wm, Wc=tf.Wc, Wcc=tf.Wcc, model_var=tf.model.model_var)
+    # the check: the ORACLE's weights on this point set (oracle/ssmq_oracle.py: bs_weights, pinned to the reference's
+    # weights on the same 1181 points by tests/golden/g12_large_weights.npz) and the oracle's transform with them, against
+    # the device's transform with the DEVICE's weights - both halves of the route are compared, not the apply alone
+    w = orc.bs_weights(np.array([[1.0] + [3.0] * D]), tf.model.points, mi)
+    w_err = max(float(np.max(np.abs(tf.wm - w['wm'])) / np.max(np.abs(w['wm']))),
+                float(np.max(np.abs(tf.Wc - w['Wc'])) / np.max(np.abs(w['Wc']))),
+                float(np.max(np.abs(tf.Wcc - w['Wcc'])) / np.max(np.abs(w['Wcc']))))
     err = 0.0
-    for i in (0, B // 2, B - 1):
+    for i in (0, B // 3, B // 2, B - 1):
         r = orc.apply_bq(orc.F_SMOOTH10D_DYN, means[i], covs[i], 0.0, tf.model.points, w)
         sc = float(np.max(np.abs(r[0])))
         err = max(err, float(np.max(np.abs(g_mf[i] - r[0])) / sc), float(np.max(np.abs(g_cf[i] - r[1])) / max(sc ** 2, np.abs(r[1]).max())))
@@ -474,9 +480,11 @@ def measure_c5_degree7(amd, B=10000, iters=5, with_cpu=True):
     tfs = flop / (ms * 1e-3) / 1e12
     rec = {'kernel': name, 'points': int(N), 'ms_per_launch': ms, 'transforms_per_s': B / (ms * 1e-3), 'bound': 'mfma',
            'achieved': tfs, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tfs / F64_MFMA_PEAK_TF, 'flop_per_launch': flop,
-           'weights_s': t_weights, 'max_scaled_err_vs_oracle': err,
+           'weights_s': t_weights, 'max_scaled_err_vs_oracle': err, 'weights_rel_err_vs_oracle': w_err,
+           'check': 'device weights + device transform against ORACLE weights + oracle transform (the oracle weights are pinned to '
+                    'the reference on this point set: tests/golden/g12_large_weights.npz); cond(K) = 8.3e5, so 64 cond eps = 1.2e-8',
            'workload': 'BASELINE configs[4] as worded: Bayes-Sard, D=E=10, fully-symmetric DEGREE-7 rule (this build\'s own: '
-                       '1181 points, parity-unpinned), 66 basis functions, B=1e4; flop = 2 B E N^2 (the product fx Wc alone)'}
+                       '1181 points; the rule is not in the reference, weights and transform on it are pinned by golden g12), 66 basis functions, B=1e4; flop = 2 B E N^2 (the product fx Wc alone)'}
     if with_cpu:
         rec['cpu_baseline'] = cpu_baseline_apply(tf, _lib.F_SMOOTH10D_DYN, (), D, D, means[:64], covs[:64], 4.0,
                                                  'the D=E=10, N=1181 degree-7 Bayes-Sard transform')
@@ -516,17 +524,23 @@ class Mt6Bench:
         self.i += 1
         self.tf.apply_batch_dev(self.f, mean, cov, self.time, mf, cf, cfx, st, 0)
 
-    def measure(self, warmup=10, iters=100):
+    def measure(self, warmup=10, iters=100, blocks=5):
+        """Median over `blocks` blocks of iters / blocks launches each (HIP events around a block; SURVEY 8d protocol)."""
         settle(self.launch, self._lib.sync)
         for _ in range(warmup):
             self.launch()
         self._lib.sync()
-        e0, e1 = self._lib.Event(), self._lib.Event()
-        e0.record()
-        for _ in range(iters):
-            self.launch()
-        e1.record()
-        ms = e0.elapsed_ms(e1) / iters
+        per = max(1, iters // blocks)
+        times = []
+        for _ in range(blocks):
+            e0, e1 = self._lib.Event(), self._lib.Event()
+            e0.record()
+            for _ in range(per):
+                self.launch()
+            e1.record()
+            times.append(e0.elapsed_ms(e1) / per)
+        ms = float(np.median(times))
+        self.block_ms = [float(t) for t in times]
         bytes_alg = 8 * (6 + 36 + 6 + 36 + 36) * self.B          # SURVEY.md 8d: 960 B per transform at D = E = 6
         bytes_moved = 8 * (6 + 21 + 6 + 36 + 36) * self.B        # what the kernel actually reads + writes (lower tri. in)
         return ms, bytes_alg, bytes_moved
@@ -557,9 +571,23 @@ class Mt6Bench:
         return float(worst)
 
 
+_CPU_PORT = {}
+
+
+def cpu_port_info():
+    """Switch the C port to its -O3 -march=native build, compiled on THIS host when the first baseline leg runs
+    (oracle/Makefile: native), and name the host: every cpu_baseline record carries `cpu_model` and `flags`."""
+    if not _CPU_PORT:
+        from oracle import c_oracle as co
+        _CPU_PORT['flags'] = co.use_native()
+        _CPU_PORT['cpu_model'] = co.cpu_model()
+    return dict(_CPU_PORT)
+
+
 def host_cores(max_threads=16):
     """Host threads the CPU baseline may use: this process's CPU share, at most 16 (a 1-GPU box's share)."""
     from oracle import c_oracle as co
+    cpu_port_info()
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -608,7 +636,7 @@ def cpu_baseline_filter(wl, B_sample, budget_s, what):
         co.filter_forward(td, to, yb, wl.m0, wl.P0, GQG, wl.alg.r_cov, threads=cores)
         total += time.perf_counter() - t0
         passes += 1
-    rec = {'value': passes * B_sample * T / total, 'unit': 'filter steps/s', 'cores': cores, 'kind': 'port',
+    rec = {'value': passes * B_sample * T / total, 'unit': 'filter steps/s', 'cores': cores, 'kind': 'port', **cpu_port_info(),
            'sample': '{} passes of the first {} trajectories x T={} of {}, oracle/ssmq_oracle.c, OpenMP over '
                      'trajectories, {:.1f} s'.format(passes, B_sample, T, what, total)}
     return rec, fm.transpose(2, 1, 0), fP.transpose(2, 3, 1, 0), st
@@ -631,7 +659,7 @@ def cpu_baseline_apply(tf, integ_id, integ_par, D, E, means, covs, budget_s, wha
         co.apply_batch(t, means, covs, 0.0, threads=cores)
         total += time.perf_counter() - t0
         passes += 1
-    return {'value': passes * means.shape[0] / total, 'unit': 'transforms/s', 'cores': cores, 'kind': 'port',
+    return {'value': passes * means.shape[0] / total, 'unit': 'transforms/s', 'cores': cores, 'kind': 'port', **cpu_port_info(),
             'sample': '{} passes of {} transforms of {}, oracle/ssmq_oracle.c, OpenMP over trajectories, {:.1f} s'.format(
                 passes, means.shape[0], what, total)}
 
@@ -1041,6 +1069,16 @@ def main():
         out['roofline']['target'] = {k: out['roofline_mt6'][k] for k in (
             'kernel', 'frac', 'achieved', 'unit', 'ms_per_launch', 'bytes_per_launch', 'traffic', 'max_scaled_err_vs_oracle')}
         out['roofline']['target']['workload'] = 'north_star: batched GPQ moment transform D=E=6, N=13, B=1e5 (>= 0.40 asked)'
+        # ... and once more as SCALARS of `roofline`: the driver's record keeps scalar fields only
+        r6 = out['roofline_mt6']
+        out['roofline'].update({
+            'target_kernel': r6['kernel'], 'target_frac': r6['frac'], 'target_achieved_gbs': r6['achieved'],
+            'target_ms_per_launch': r6['ms_per_launch'], 'target_bytes_per_launch': r6['bytes_per_launch'],
+            'target_bytes_moved_per_launch': r6['bytes_moved_per_launch'], 'target_traffic': r6['traffic'],
+            'target_max_scaled_err_vs_oracle': r6['max_scaled_err_vs_oracle'],
+            'target_timing': 'median of {} blocks of {} launches, HIP events'.format(len(mt.block_ms), max(1, 100 // len(mt.block_ms))),
+            'target_ms_min_block': min(mt.block_ms), 'target_ms_max_block': max(mt.block_ms)})
+        out['roofline_mt6']['block_ms'] = mt.block_ms
         if with_cpu:
             means, covs = mt.host
             out['roofline_mt6']['cpu_baseline'] = cpu_baseline_apply(
@@ -1055,8 +1093,14 @@ def main():
                                                       'bytes_per_launch': b_alg}
         mt.free()
         out['roofline']['target']['frac_at_1e6'] = out['roofline_mt6']['at_1e6_trajectories']['frac']
+        out['roofline']['target_frac_at_1e6'] = out['roofline_mt6']['at_1e6_trajectories']['frac']
         if headline:
             out['roofline']['saturated'] = saturated_sweep(amd, T, (10000, 100000, 1000000), wl.kernel, pass_ms_dev, B)
+            for row in out['roofline']['saturated']:
+                tag = {10000: '1e4', 100000: '1e5', 1000000: '1e6'}.get(row['mc'], str(row['mc']))
+                out['roofline']['saturated_frac_' + tag] = row['frac']
+                if 'issue_frac_chip' in row:
+                    out['roofline']['saturated_issue_frac_chip_' + tag] = row['issue_frac_chip']
     if rank == 0 and single and not args.no_mt6:
         # BASELINE configs[2]: the filters that are stable on the reentry model (the GPQ-Kalman recursion itself fails
         # within three steps on every trajectory, in the reference as here: tests/test_gpu_parity.py::test_config3_gpqkf_*)
