@@ -242,6 +242,30 @@ static int upload_consts(ssmq_transform *h) {
         }
         if (!h->d_wcx_pad) SSMQ_HIP(hipMalloc(&h->d_wcx_pad, sizeof(double) * np * nx));
         SSMQ_HIP(hipMemcpyAsync(h->d_wcx_pad, xpad.data(), sizeof(double) * np * nx, hipMemcpyHostToDevice, stream()));
+        // the same with S in place of Wc: S = lower triangle of Wc with half its diagonal, so that Wc = S + S' and
+        // fx Wc fx' = C + C', C = (fx S) fx' (k_bq_fused / k_bq_stream: half the matrix instructions of the main product).
+        // Only for a Wc that is symmetric to the last bit - every Wc the weight kernels (and the reference, bq/bqmod.py:520-521)
+        // produce; an injected non-symmetric one keeps the routes that form (fx Wc) fx' as written.
+        bool symmetric = true;
+        for (int k = 0; k < N && symmetric; ++k)
+            for (int j = 0; j < k; ++j)
+                if (h->Wc[k * N + j] != h->Wc[j * N + k]) {
+                    symmetric = false;
+                    break;
+                }
+        if (symmetric) {
+            std::vector<double> spad(xpad);
+            for (int k = 0; k < N; ++k)
+                for (int j = 0; j < N; ++j)
+                    spad[(size_t)k * nx + j] = j < k ? h->Wc[k * N + j] : (j == k ? 0.5 * h->Wc[k * N + k] : 0.0);
+            if (!h->d_sx_pad) SSMQ_HIP(hipMalloc(&h->d_sx_pad, sizeof(double) * np * nx));
+            SSMQ_HIP(hipMemcpyAsync(h->d_sx_pad, spad.data(), sizeof(double) * np * nx, hipMemcpyHostToDevice, stream()));
+            SSMQ_HIP(hipStreamSynchronize(stream()));   // spad goes out of scope
+        } else if (h->d_sx_pad) {
+            SSMQ_HIP(hipStreamSynchronize(stream()));
+            hipFree(h->d_sx_pad);
+            h->d_sx_pad = nullptr;
+        }
         SSMQ_HIP(hipStreamSynchronize(stream()));   // xpad goes out of scope
     }
     if (!sigma && N > 64 && !np && !getenv("SSMQ_NO_MFMA")) {
@@ -401,7 +425,7 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     const bool big = !se && h->N > 64 && ((h->form == SSMQ_FORM_BQ && h->d_wc_blk && (b_route * h->E >= kGemmMinRows || !wide_fits) &&
                                            (h->tp_nu <= 0.0 || h->d_ik_blk)) ||
                                           (h->form == SSMQ_FORM_SIGMA && !wide_fits));
-    const bool one_launch = !se && !big && h->form == SSMQ_FORM_BQ && h->d_wc_pad && h->d_wcx_pad && h->tp_nu <= 0.0 &&
+    const bool one_launch = !se && !big && h->form == SSMQ_FORM_BQ && h->d_wc_pad && h->d_sx_pad && h->tp_nu <= 0.0 &&
                             b_route * h->E >= kGemmMinRows && bq_fused_supported(h->D, h->E, h->N);
     if (kernel_name) *kernel_name = se ? se->name : big ? "k_apply_big" : one_launch ? "k_bq_fused" : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
     if (dry_run) return SSMQ_OK;
@@ -461,10 +485,10 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         const int NP = h->np_pad;
         const int64_t M = B * h->E;
         double *fx, *tt, *chol;
-        if (h->tp_nu <= 0.0 && h->d_wcx_pad && bq_fused_supported(h->D, h->E, h->N)) {
+        if (h->tp_nu <= 0.0 && h->d_sx_pad && bq_fused_supported(h->D, h->E, h->N)) {
             // one launch: the workgroup that owns a block of the GEMM's rows evaluates the integrand into LDS itself
             const WideLayout wl = wide_layout(h->D, h->E, h->N, h->form);
-            return launch_bq_fused(a, h->d_wcx_pad, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, stream());
+            return launch_bq_fused(a, h->d_sx_pad, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, stream());
         }
         if (h->tp_nu <= 0.0 && h->d_wcx_pad && fxwc_cov_supported(h->E) && h->D <= 16 && !getenv("SSMQ_NO_FUSED_COV")) {
             // two passes: (1) one wave per trajectory: factor, points, integrand values, mean; (2) the GEMM whose
@@ -759,6 +783,7 @@ void ssmq_transform_destroy(ssmq_transform *h) {
     if (h->d_wide) hipFree(h->d_wide);
     if (h->d_wc_pad) hipFree(h->d_wc_pad);
     if (h->d_wcx_pad) hipFree(h->d_wcx_pad);
+    if (h->d_sx_pad) hipFree(h->d_sx_pad);
     if (h->d_wc_blk) hipFree(h->d_wc_blk);
     if (h->d_ik_blk) hipFree(h->d_ik_blk);
     delete h;

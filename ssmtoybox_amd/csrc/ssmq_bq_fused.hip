@@ -30,6 +30,7 @@
 // addresses cost 66-117 spilled registers), dropped.
 #include "ssmq_host.h"
 #include "ssmq_wide.h"
+#include <type_traits>
 
 namespace ssmq {
 namespace {
@@ -38,7 +39,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct BqFusedArgs {
     WideArgs w;             // shape, integrand, constants (points, wm), inputs, outputs, scales - as for k_eval_wave
-    const double *X;        // [NP][NP + 16] = [Wc | Wcc' | wm] zero-padded
+    const double *X;        // [NP][NP + 16] = [S | Wcc' | wm] zero-padded, S = tril(Wc) with half the diagonal (Wc = S + S')
     const double *emv;      // [E * E]
     int32_t emv_broadcast, tpw, fx_doubles;
     int64_t B;
@@ -51,14 +52,19 @@ template <int NT, int DM, int FC, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(const BqFusedArgs g) {
     constexpr int TB = 64 * WAVES, RT = WAVES / 2, KS = 2 * WAVES, NKB = NT * 16 / KS, SPB = KS / 4;
     constexpr int NP = NT * 16, NX = NP + 16, NTX = NT + 1, LB = NX + 4, FP = NP + 2;
-    constexpr int C0 = (NTX + 1) / 2;              // column tiles of the first RT waves; the others take the other NTX - C0 <= C0
-    constexpr bool EVEN = (NTX % 2) == 0;
+    // Column tiles of X = [S | Wcc' | wm] by PARITY: wave half ch owns the tiles ct = 2 t + ch (t = 0 .. C0 - 1, ct <= NT; tile NT
+    // is the G tile [Wcc' | wm]).  S is the lower triangle of Wc with half its diagonal (Wc = S + S', so fx Wc fx' = C + C' with
+    // C = (fx S) fx'): the k-block kb contributes to tile ct < NT only for 16 ct < KS (kb + 1) - NT (NT + 1) / 2 + NT tile steps
+    // instead of NT (NT + 1), with both halves busy in every step.
+    constexpr int C0 = (NTX + 1) / 2;
+    constexpr int GCH = NT & 1, GT = NT >> 1;      // the G tile's half and local index
     constexpr int PK = DM * (DM + 1) / 2;          // packed lower triangle
     constexpr bool REGCHOL = DM <= 10;             // the factorisation in one lane's registers (else: the wave's lanes over LDS)
     extern __shared__ __align__(16) double lds[];
     const WideArgs &a = g.w;
     const int D = a.D, E = a.E, N = a.N;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: everything per wave below branches, never masks
     const int li = lane & 15, lg = lane >> 4;
     const int lip = 4 * (li & 3) + (li >> 2);
     const int TPW = g.tpw, rows = TPW * E;
@@ -77,34 +83,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
     const double *c = a.consts;
     const WideLayout cl = wide_layout(D, E, N, a.form);
     // ---- 0. what does not depend on the factors goes out first: the first slab of X, this lane's first sigma point --------
-    constexpr int PER = (KS * NX + TB - 1) / TB;
-    constexpr bool EXACT = PER * TB == KS * NX;
+    static_assert(WAVES == 8, "slab staging and tile schedule below are written for 16-row slabs (KS = 16)");
     // ONE register set for the slabs: at the start of step kb - right after the barrier that ended step kb - 1 - slab kb + 1
     // (requested a whole step ago) is written to the buffer that step kb - 1 has just released and slab kb + 2 is
     // requested into the same registers, so the LDS writes have the whole step to complete before the next barrier.
-    // Measured alternatives (D = E = 10, N = 201, B = 1e4; this form 313-316 us): one slab ahead, parked before the last
-    // k sub-step 338; two register sets, two slabs ahead, parked there 313-316 (no gain for 14 registers); LDS-DMA
-    // (global_load_lds_dwordx4, two pieces per row, issued after the barrier, drained by the next one) 325-332 - the
-    // compiler then waits for ALL outstanding LDS reads (lgkmcnt(0)) before each group of matrix instructions.
-    double breg[PER];
-    auto load_b = [&](int kb) {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int i = tid + q * TB;
-            breg[q] = ((EXACT || i < KS * NX) && kb < NKB) ? g.X[(int64_t)kb * KS * NX + i] : 0.0;
-        }
-    };
+    // (Measured alternatives, round 3: one slab ahead parked before the last k sub-step, two register sets, LDS-DMA - none faster.)
+    // Thread (r, hf, c16) moves the columns 16 (2 j + hf) + c16 of slab row r, j = 0 .. C0 - 1: pairs of column tiles.  S is lower
+    // triangular, so slab kb holds nothing right of column 16 (kb + 1): pair j is moved only for 2 j <= kb, and the last pair (the
+    // G tile) always - conditions on the loop counter alone, i.e. scalar branches around whole instructions.
+    const int sr = tid >> 5, shf = (tid >> 4) & 1, sc16 = tid & 15;
+    double breg[C0];
+    auto phys = [](int k) { return 4 * (k & 3) + (k >> 2); };
     // row k of a slab lives at a permuted position, so that the lanes of a ds_read_b64 half (lane groups lg = 0, 1 or 2, 3,
     // reading k = lg + 4 s) are 16 bank pairs apart with the pitch LB = 4 mod 32
-    auto phys = [](int k) { return KS == 16 ? 4 * (k & 3) + (k >> 2) : 4 * (k & 1) + ((k & 3) >> 1) + 2 * (k >> 2); };
-    auto park_b = [&](int buf) {
-        double *dst = slab + buf * KS * LB;
+    auto load_b = [&](int kb) {
+        if (kb < NKB) {
+            const double *src = g.X + ((int64_t)kb * KS + sr) * NX + 16 * shf + sc16;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int i = tid + q * TB;
-            const int k = i / NX;
-            if (EXACT || i < KS * NX) dst[phys(k) * LB + (i - k * NX)] = breg[q];
+            for (int j = 0; j < C0; ++j)
+                if (2 * j <= kb || j == C0 - 1) breg[j] = (2 * j + 1 < NTX || shf == 0) ? src[32 * j] : 0.0;
         }
+    };
+    auto park_b = [&](int buf, int kb) {
+        double *dst = slab + buf * KS * LB + phys(sr) * LB + 16 * shf + sc16;
+#pragma unroll
+        for (int j = 0; j < C0; ++j)
+            if ((2 * j <= kb || j == C0 - 1) && (2 * j + 1 < NTX || shf == 0)) dst[32 * j] = breg[j];
     };
     if (tid < 16 * RT) {
         const int gq = tid / E;
@@ -268,17 +272,30 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
         const int r = idx / N;
         sFX[(vrows + r) * FP + (idx - r * N)] = 0.0;
     }
-    park_b(0);                 // (the covariances in the slab region were last read before the barrier that ended step 1)
+    park_b(0, 0);              // (the covariances in the slab region were last read before the barrier that ended step 1)
     load_b(1);
     __syncthreads();
     // ---- 3. [T G]' = X' FX'; the G tile's last column is wm: the transformed mean comes out of the same product -----------------
     const int rt = wave % RT, ch = wave / RT;
-    const int cbase = ch ? C0 : 0, cnt = ch ? NTX - C0 : C0;
     const int lrow = (16 * rt + li) < rows ? (16 * rt + li) : rows - 1;   // rows beyond the tile: any row, never stored
     const double *frow = sFX + lrow * FP;
     v4d acc[C0];
 #pragma unroll
-    for (int ct = 0; ct < C0; ++ct) acc[ct] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < C0; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+    // this lane's corner of a slab: row 4 lg + s of the permuted order is k = lg + 4 s; tile t of this half starts 32 t columns on
+    const int woff = 4 * lg * LB + 16 * ch + lip, goff = 4 * lg * LB + 16 * NT + lip;
+    // NA tiles of S in one k-block: the four k sub-steps, each with its NA reads issued ahead of its NA matrix instructions
+    auto mma = [&](auto na_c, const double *sb, const double (&af)[4]) {
+        constexpr int NA = decltype(na_c)::value;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            double w[NA > 0 ? NA : 1];
+#pragma unroll
+            for (int t = 0; t < NA; ++t) w[t] = sb[woff + s * LB + 32 * t];              // X[16 kb + lg + 4 s][16 (2 t + ch) + pi(li)]
+#pragma unroll
+            for (int t = 0; t < NA; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[t], af[s], acc[t], 0, 0, 0);
+        }
+    };
 #ifdef BQF_SKIP_MAIN
     for (int kb = 0; kb < 0; ++kb) {
 #else
@@ -286,23 +303,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
 #endif
         const int buf = kb & 1;
         if (kb + 1 < NKB) {
-            park_b(buf ^ 1);
+            park_b(buf ^ 1, kb + 1);
             load_b(kb + 2);
         }
-        double af[SPB];
+        double af[4];
 #pragma unroll
-        for (int s = 0; s < SPB; ++s) af[s] = frow[KS * kb + lg + 4 * s];
+        for (int s = 0; s < 4; ++s) af[s] = frow[KS * kb + lg + 4 * s];
         const double *sb = slab + buf * KS * LB;
+        // tiles of S this k-block reaches: ct = 2 t + ch <= kb (the rest of the column is zero)
+        const int na = (kb - ch + 2) >> 1;
+        if (ch == GCH) {                      // the G tile [Wcc' | wm]: every k-block
 #pragma unroll
-        for (int s = 0; s < SPB; ++s) {
-#pragma unroll
-            for (int ct = 0; ct < C0; ++ct) {
-                if (EVEN || ct < cnt) {
-                    const double w = sb[phys(lg + 4 * s) * LB + (cbase + ct) * 16 + lip];   // X[KS kb + lg + 4 s][16 (cbase + ct) + pi(li)]
-                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, af[s], acc[ct], 0, 0, 0);
-                }
-            }
+            for (int s = 0; s < 4; ++s)
+                acc[GT] = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[goff + s * LB], af[s], acc[GT], 0, 0, 0);
         }
+        if constexpr (C0 >= 7) { if (na == 7) mma(std::integral_constant<int, 7>{}, sb, af); }
+        if constexpr (C0 >= 6) { if (na == 6) mma(std::integral_constant<int, 6>{}, sb, af); }
+        if constexpr (C0 >= 5) { if (na == 5) mma(std::integral_constant<int, 5>{}, sb, af); }
+        if (na == 4) mma(std::integral_constant<int, 4>{}, sb, af);
+        if (na == 3) mma(std::integral_constant<int, 3>{}, sb, af);
+        if (na == 2) mma(std::integral_constant<int, 2>{}, sb, af);
+        if (na == 1) mma(std::integral_constant<int, 1>{}, sb, af);
         __syncthreads();
     }
 #ifdef BQF_SKIP_EPI
@@ -316,14 +337,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
         return;
     }
 #endif
-    // ---- 4a. the waves that hold the G tile (global tile NT = local tile NT - C0 of the second half): mean, cross-covariance ----
-    if (ch == 1) {
+    // ---- 4a. the waves that hold the G tile (global tile NT = local tile GT of half GCH): mean, cross-covariance ---------------
+    double *sP = slab;                             // [2][RT][64][8]: the epilogue's exchange (the slabs are free: last barrier passed)
+    if (ch == GCH) {
         const int lr = 16 * rt + li;
         const bool valid = lr < vrows;
         const int gi = srow[lr] >> 8, e = srow[lr] & 255;
         const int64_t b = bw0 + gi;
         const double *Lb = sLp + (valid ? gi : 0) * PK;
-        const v4d gt = acc[NT - C0];
+        const v4d gt = acc[GT];
         if (lg == 3) {                               // column 15 of the tile: FX wm (NaN where the factorisation failed)
             smr[lr] = gt[3];
             if (valid) a.mean_f[(int64_t)e * a.es_out + b * a.bs_mf] = gt[3];
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
         // (fx Wcc') L' for row li: the G tile goes through LDS (the slab region is free: the loop's last barrier has been
         // passed) and lane group lg takes the columns j = lg, lg + 4, ... - the sum over d with two cross-lane exchanges per j
         // instead was 3 us per tile of dependent ds_bpermute round trips
-        double *sG = slab + RT * 64 * 8 + 512 + rt * 256;
+        double *sG = sP + ((GCH * RT + rt) * 64) * 8;     // this wave's own exchange slot, before it is written below
 #pragma unroll
         for (int r = 0; r < 4; ++r) sG[li * 16 + 4 * lg + r] = gt[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -343,76 +365,73 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
             if (valid) a.cov_fx[(int64_t)(e * D + j) * a.es_out + b * a.bs_cfx] = p * a.ccov_scale;
         }
     }
-    // ---- 4b. S = T FX2', this wave's column tiles ----------------------------------------------------------------------------------
+    // ---- 4b. C = T FX2' with T = fx S, this wave's column tiles -------------------------------------------------------------------
     const int s0 = (16 * rt / E) * E;             // first row of the first trajectory that intersects the row tile
     v4d acc2[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
     {
         const int r0 = (s0 + li) < rows ? (s0 + li) : rows - 1, r1 = (s0 + 16 + li) < rows ? (s0 + 16 + li) : rows - 1;
         const double *f0p = sFX + r0 * FP + 4 * lg, *f1p = sFX + r1 * FP + 4 * lg;
 #pragma unroll
-        for (int ct = 0; ct < C0; ++ct) {
+        for (int t = 0; t < C0; ++t) {
+            const int ct = 2 * t + ch;
 #ifdef BQF_SKIP_4B
             if (0) {
 #else
-            if ((EVEN || ct < cnt) && cbase + ct < NT) {
+            if (ct < NT) {
 #endif
-                const int col = 16 * (cbase + ct);
+                const int col = 16 * ct;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    acc2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[ct][r], f0p[col + r], acc2[0], 0, 0, 0);
-                    acc2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[ct][r], f1p[col + r], acc2[1], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[t][r], f0p[col + r], acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[t][r], f1p[col + r], acc2[1], 0, 0, 0);
                 }
             }
         }
     }
-    // the two halves of the column range meet in LDS (the slab is free again: the loop's last barrier has been passed),
-    // the additive terms beside them
-    double *sx = slab + (rt * 64 + lane) * 8;
-    double *sev = slab + RT * 64 * 8, *sca = sev + 256;
+    // Every wave's part of C goes to LDS (lane (lg, li) of wave (rt, ch): C[16 rt + lg + 4 r][s0 + 16 h + li] in slot 4 h + r;
+    // the slabs are free, the loop's last barrier has been passed), the additive terms and the (e, e2) table beside it
+    double *sev = sP + 2 * RT * 64 * 8, *sca = sev + 256;
+    int *spair = (int *)(sca + 256);
+    const int npair = E * (E + 1) / 2;
     if (tid < E * E) {
         sev[tid] = ev;
         sca[tid] = ca;
     }
-    if (ch == 1) {
+    if (tid < npair) {
+        int e = 0;
+        while ((e + 1) * (e + 2) / 2 <= tid) ++e;
+        spair[tid] = (e << 4) | (tid - e * (e + 1) / 2);
+    }
+    {
+        double *sx = sP + ((ch * RT + rt) * 64 + lane) * 8;
+        __builtin_amdgcn_wave_barrier();          // (the G waves read their slot as sG above)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sx[4 * h + r] = acc2[h][r];
     }
     __syncthreads();
-    if (ch == 1) return;
 #ifdef BQF_SKIP_4C
     if (acc2[0][0] != 12345.678) return;
 #endif
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc2[h][r] += sx[4 * h + r];
-    // ---- 4c. covariance entries (lane (lg, li): S[16 rt + lg + 4 r][s0 + 16 h + li]) ----------------------------------------------
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int l2 = s0 + 16 * h + li;
-        const bool v2 = l2 < vrows;
-        const int l2c = v2 ? l2 : 0;
-        const int g2 = srow[l2c] >> 8, e2 = srow[l2c] & 255;
-        const double m2 = smr[l2c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int l1 = 16 * rt + lg + 4 * r;
-            const bool v1 = l1 < vrows;
-            const int l1c = v1 ? l1 : 0;
-            const int g1 = srow[l1c] >> 8, e = srow[l1c] & 255;
-            if (v1 && v2 && g1 == g2 && e2 <= e) {
-                const int64_t b = bw0 + g1;
-                const int idx = e * E + e2, idt = e2 * E + e;
-                const bool use = (e == e2) || g.emv_broadcast;
-                const double em = use ? sev[idx] : 0.0;
-                double v = (acc2[h][r] - smr[l1c] * m2 + em) * a.cov_scale;
-                if (a.cov_add) v += sca[idx];
-                a.cov_f[(int64_t)idx * a.es_out + b * a.bs_cf] = v;
-                if (e2 != e) a.cov_f[(int64_t)idt * a.es_out + b * a.bs_cf] = v;     // mirrored entry, same value
-            }
-        }
+    // ---- 4c. covariance entries: fx Wc fx' = C + C'; one (trajectory, e >= e2) pair per thread, trajectory fastest --------------
+    for (int idx = tid; idx < nb * npair; idx += TB) {
+        const int p = idx / nb, gi = idx - p * nb;
+        const int e = spair[p] >> 4, e2 = spair[p] & 15;
+        const int l1 = gi * E + e, l2 = gi * E + e2;
+        auto cval = [&](int la, int lb) {          // C[la][lb]: both halves of the column range, half 0 first
+            const int rta = la >> 4, i = la & 15, j = lb - (16 * rta / E) * E;
+            const int at = ((rta * 64) + (j & 15) + 16 * (i & 3)) * 8 + 4 * (j >> 4) + (i >> 2);
+            return sP[at] + sP[RT * 64 * 8 + at];
+        };
+        const int64_t b = bw0 + gi;
+        const int ie = e * E + e2, it = e2 * E + e;
+        const bool use = (e == e2) || g.emv_broadcast;
+        const double em = use ? sev[ie] : 0.0;
+        double v = (cval(l1, l2) + cval(l2, l1) - smr[l1] * smr[l2] + em) * a.cov_scale;
+        if (a.cov_add) v += sca[ie];
+        a.cov_f[(int64_t)ie * a.es_out + b * a.bs_cf] = v;
+        if (e2 != e) a.cov_f[(int64_t)it * a.es_out + b * a.bs_cf] = v;     // mirrored entry, same value
     }
 }
 
@@ -437,7 +456,7 @@ FusedGeom fused_geom_for(int waves, int NT, int D, int E, int DM) {
 bool fused_geom_ok(const FusedGeom &q, int NT, int D, int E) {
     const int RT = q.waves / 2, KS = 2 * q.waves;
     const size_t slab = (size_t)2 * KS * (NT * 16 + 20);
-    return q.tpw >= 1 && 4 * q.tpw * E >= 3 * 16 * RT && (size_t)q.tpw * D * D <= slab && (size_t)RT * 64 * 8 + 512 + RT * 256 <= slab;
+    return q.tpw >= 1 && 4 * q.tpw * E >= 3 * 16 * RT && (size_t)q.tpw * D * D <= slab && (size_t)2 * RT * 64 * 8 + 512 + 32 <= slab;
 }
 // one 512-thread workgroup per CU.  (Two of 256 threads - 32-row tiles, 8-row slabs, 80 KB each - were measured at D = E =
 // 10, N = 201, B = 1e4: 339 us against 322 us; the two workgroups of a CU run in phase, so their producer and store steps

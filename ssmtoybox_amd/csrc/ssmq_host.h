@@ -19,6 +19,8 @@ struct ssmq_transform {
     int np_pad = 0;
     // ... and [Wc | Wcc'] as np_pad x (np_pad + 16) for the route whose GEMM epilogue forms both covariances, or null
     double *d_wcx_pad = nullptr;
+    // ... and [S | Wcc' | wm] with S = tril(sym(Wc)), half the diagonal (Wc = S + S'): the one-launch routes skip the zero blocks
+    double *d_sx_pad = nullptr;
     // point sets without an instantiation of that route (N > 64): Wc (and iK for the t-process) as column blocks of
     // kBigCols columns, each [big_kb 16][kBigCols] zero-padded (ssmq_apply_big.hip); null = not built
     double *d_wc_blk = nullptr, *d_ik_blk = nullptr;

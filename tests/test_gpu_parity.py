@@ -2018,9 +2018,13 @@ def test_one_launch_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
     assert pts.shape == (D, N)
     wm = rng.standard_normal(N) / N
     Wc = rng.standard_normal((N, N)) / N
-    Wc = 0.5 * (Wc + Wc.T) + 1e-3 * rng.standard_normal((N, N)) / N
+    Wc = 0.5 * (Wc + Wc.T)
     Wcc = rng.standard_normal((D, N)) / N
-    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = wm, Wc, Wcc, 0.21
+    # the one-launch route forms fx Wc fx' as C + C' with C = (fx S) fx', Wc = S + S' (half the matrix instructions): it is
+    # offered for a Wc that is symmetric to the last bit only; any other keeps the two passes, which form (fx Wc) fx' as written
+    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = wm, Wc + 1e-3 * np.triu(rng.standard_normal((N, N)), 1) / N, Wcc, 0.21
+    assert tf.kernel_name(fn) == 'k_apply_wide'
+    tf.Wc = Wc
     w = dict(wm=wm, Wc=Wc, Wcc=Wcc, model_var=0.21)
     assert tf.kernel_name(fn) == 'k_bq_fused'
     for B in (257, 1000):
