@@ -13,14 +13,16 @@
 //      steps 2 and 4;
 //   2. the (trajectory, point) pairs over the workgroup's lanes (ten wave-iterations for 6 x 201 pairs): sigma point from
 //      the LDS-resident factor, integrand, E values into the tile; zero padding;
-//   3. the transposed product [T G]' = [Wc | Wcc' | wm]' FX' as in k_fxwc_cov_mfma - slabs of 16 rows of X double-buffered
-//      in LDS, staged through ONE register set (written right after a barrier, re-requested at once) - with wave w on row tile w & 3 and on ONE HALF of the column tiles
+//   3. the transposed product [T G]' = [S | Wcc' | wm]' FX' - S the lower triangle of Wc with half its diagonal, Wc = S + S', so
+//      that fx Wc fx' = C + C' with C = (fx S) fx' and the zero k-blocks above the diagonal are neither loaded nor multiplied
+//      (round 4: 104 tile steps instead of 182) - slabs of 16 rows of X double-buffered in LDS, requested two steps ahead, the
+//      k-blocks walked long-short-long (12, 0, 11, 1, ...); wave w on row tile w & 3 and on the column tiles of ONE PARITY
 //      (w >> 2): two waves per SIMD, 56 accumulator registers each.  The FX fragments come from the LDS tile: lane group lg
 //      feeds column 16 kb + lg + 4 s in MFMA step s (stride 4, so that with the row pitch NP + 2 = 18 mod 32 the 32 lanes of
 //      a ds_read_b64 half fall on 32 different bank pairs); the slab rows are stored permuted to match.  Column 15 of the
 //      Wcc' tile of X is wm (D <= 15): the transformed mean is a by-product of the product;
-//   4. cross-covariance from the G tile and the packed factors; S = T FX2' on the accumulators as in k_fxwc_cov_mfma, each
-//      wave over its own column tiles, the two halves summed through LDS; covariance entries stored from the registers.
+//   4. cross-covariance from the G tile and the packed factors; C = T FX2' on the accumulators as in k_fxwc_cov_mfma, each
+//      wave over its own column tiles; all parts meet in LDS, one thread per (trajectory, e >= e2) forms C + C' and stores.
 // Grid: ceil(B / TPW) workgroups, one per CU: 1 667 at B = 1e4, E = 10 = 6.5 rounds of 256 (7 taken), against 3.05 rounds
 // of 512 (4 taken) of the two-pass route.  Measured (tools/c5_full.py, tools/bqf_ab.sh with one step compiled out at a
 // time; D = E = 10, N = 201, B = 1e4): 322 us against 337 us for the two passes; per tile ~27 us in the product (the matrix
@@ -84,31 +86,36 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
     const WideLayout cl = wide_layout(D, E, N, a.form);
     // ---- 0. what does not depend on the factors goes out first: the first slab of X, this lane's first sigma point --------
     static_assert(WAVES == 8, "slab staging and tile schedule below are written for 16-row slabs (KS = 16)");
-    // ONE register set for the slabs: at the start of step kb - right after the barrier that ended step kb - 1 - slab kb + 1
-    // (requested a whole step ago) is written to the buffer that step kb - 1 has just released and slab kb + 2 is
-    // requested into the same registers, so the LDS writes have the whole step to complete before the next barrier.
-    // (Measured alternatives, round 3: one slab ahead parked before the last k sub-step, two register sets, LDS-DMA - none faster.)
+    // Slabs of 16 rows of X are double-buffered in LDS and staged through registers: written right after the barrier that
+    // released their buffer, so the LDS writes have a whole step to complete before the next barrier.
     // Thread (r, hf, c16) moves the columns 16 (2 j + hf) + c16 of slab row r, j = 0 .. C0 - 1: pairs of column tiles.  S is lower
     // triangular, so slab kb holds nothing right of column 16 (kb + 1): pair j is moved only for 2 j <= kb, and the last pair (the
     // G tile) always - conditions on the loop counter alone, i.e. scalar branches around whole instructions.
     const int sr = tid >> 5, shf = (tid >> 4) & 1, sc16 = tid & 15;
-    double breg[C0];
+    // The k-blocks are walked in the order 12, 0, 11, 1, 10, 2, ... (kseq): a long step (many tiles of S reach it) next to a
+    // short one, so that any two consecutive steps carry about the same number of matrix instructions, and the slabs are
+    // requested TWO steps ahead into two register sets - a slab has a long + a short step (~1.8 us) to arrive, where one set and
+    // the natural order left the loads of the short early steps (8 matrix instructions per SIMD at kb = 0) exposed.
+    double breg[2][C0];
     auto phys = [](int k) { return 4 * (k & 3) + (k >> 2); };
     // row k of a slab lives at a permuted position, so that the lanes of a ds_read_b64 half (lane groups lg = 0, 1 or 2, 3,
     // reading k = lg + 4 s) are 16 bank pairs apart with the pitch LB = 4 mod 32
-    auto load_b = [&](int kb) {
-        if (kb < NKB) {
+    auto kseq = [](int p) { return (p & 1) ? (p >> 1) : (NKB - 1 - (p >> 1)); };
+    auto load_b = [&](int p) {                 // slab of position p into register set p & 1
+        if (p < NKB) {
+            const int kb = kseq(p);
             const double *src = g.X + ((int64_t)kb * KS + sr) * NX + 16 * shf + sc16;
 #pragma unroll
             for (int j = 0; j < C0; ++j)
-                if (2 * j <= kb || j == C0 - 1) breg[j] = (2 * j + 1 < NTX || shf == 0) ? src[32 * j] : 0.0;
+                if (2 * j <= kb || j == C0 - 1) breg[p & 1][j] = (2 * j + 1 < NTX || shf == 0) ? src[32 * j] : 0.0;
         }
     };
-    auto park_b = [&](int buf, int kb) {
-        double *dst = slab + buf * KS * LB + phys(sr) * LB + 16 * shf + sc16;
+    auto park_b = [&](int p) {                 // ... and from there into LDS buffer p & 1
+        const int kb = kseq(p);
+        double *dst = slab + (p & 1) * KS * LB + phys(sr) * LB + 16 * shf + sc16;
 #pragma unroll
         for (int j = 0; j < C0; ++j)
-            if ((2 * j <= kb || j == C0 - 1) && (2 * j + 1 < NTX || shf == 0)) dst[32 * j] = breg[j];
+            if ((2 * j <= kb || j == C0 - 1) && (2 * j + 1 < NTX || shf == 0)) dst[32 * j] = breg[p & 1][j];
     };
     if (tid < 16 * RT) {
         const int gq = tid / E;
@@ -272,8 +279,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
         const int r = idx / N;
         sFX[(vrows + r) * FP + (idx - r * N)] = 0.0;
     }
-    park_b(0, 0);              // (the covariances in the slab region were last read before the barrier that ended step 1)
+    park_b(0);                 // (the covariances in the slab region were last read before the barrier that ended step 1)
     load_b(1);
+    load_b(2);
     __syncthreads();
     // ---- 3. [T G]' = X' FX'; the G tile's last column is wm: the transformed mean comes out of the same product -----------------
     const int rt = wave % RT, ch = wave / RT;
@@ -297,19 +305,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_bq_fused(con
         }
     };
 #ifdef BQF_SKIP_MAIN
-    for (int kb = 0; kb < 0; ++kb) {
+    for (int p = 0; p < 0; ++p) {
 #else
-    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int p = 0; p < NKB; ++p) {
 #endif
-        const int buf = kb & 1;
-        if (kb + 1 < NKB) {
-            park_b(buf ^ 1, kb + 1);
-            load_b(kb + 2);
+        const int kb = kseq(p);
+        if (p + 1 < NKB) {
+            park_b(p + 1);
+            load_b(p + 3);
         }
         double af[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) af[s] = frow[KS * kb + lg + 4 * s];
-        const double *sb = slab + buf * KS * LB;
+        const double *sb = slab + (p & 1) * KS * LB;
         // tiles of S this k-block reaches: ct = 2 t + ch <= kb (the rest of the column is zero)
         const int na = (kb - ch + 2) >> 1;
         if (ch == GCH) {                      // the G tile [Wcc' | wm]: every k-block
