@@ -268,6 +268,29 @@ static int upload_consts(ssmq_transform *h) {
         }
         SSMQ_HIP(hipStreamSynchronize(stream()));   // xpad goes out of scope
     }
+    if (!sigma && N > 208 && !getenv("SSMQ_NO_MFMA")) {
+        // one-launch route for these sizes (k_bq_stream): S = tril(Wc), half the diagonal, by panels - a Wc symmetric to the last
+        // bit only (see d_sx_pad above)
+        bool symmetric = bq_stream_supported(D, E, N) && h->tp_nu <= 0.0;
+        for (int k = 0; k < N && symmetric; ++k)
+            for (int j = 0; j < k; ++j)
+                if (h->Wc[(size_t)k * N + j] != h->Wc[(size_t)j * N + k]) {
+                    symmetric = false;
+                    break;
+                }
+        if (h->d_sx_pan) {
+            SSMQ_HIP(hipStreamSynchronize(stream()));
+            hipFree(h->d_sx_pan);
+            h->d_sx_pan = nullptr;
+        }
+        if (symmetric) {
+            std::vector<double> xs(bq_stream_x_doubles(N));
+            bq_stream_pack(D, N, h->Wc.data(), h->Wcc.data(), h->wm.data(), xs.data());
+            SSMQ_HIP(hipMalloc(&h->d_sx_pan, sizeof(double) * xs.size()));
+            SSMQ_HIP(hipMemcpyAsync(h->d_sx_pan, xs.data(), sizeof(double) * xs.size(), hipMemcpyHostToDevice, stream()));
+            SSMQ_HIP(hipStreamSynchronize(stream()));
+        }
+    }
     if (!sigma && N > 64 && !np && !getenv("SSMQ_NO_MFMA")) {
         // any other point count beyond the wave kernels: Wc (and iK for the t-process) as column blocks of kBigCols
         // columns, block c = [kb 16][kBigCols] zero-padded, for the blocked GEMM (launch_fxwc_blocks)
@@ -425,9 +448,11 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     const bool big = !se && h->N > 64 && ((h->form == SSMQ_FORM_BQ && h->d_wc_blk && (b_route * h->E >= kGemmMinRows || !wide_fits) &&
                                            (h->tp_nu <= 0.0 || h->d_ik_blk)) ||
                                           (h->form == SSMQ_FORM_SIGMA && !wide_fits));
+    const bool streamed = !se && h->form == SSMQ_FORM_BQ && h->tp_nu <= 0.0 && h->d_sx_pan && b_route * h->E >= kGemmMinRows &&
+                          bq_stream_supported(h->D, h->E, h->N);
     const bool one_launch = !se && !big && h->form == SSMQ_FORM_BQ && h->d_wc_pad && h->d_sx_pad && h->tp_nu <= 0.0 &&
                             b_route * h->E >= kGemmMinRows && bq_fused_supported(h->D, h->E, h->N);
-    if (kernel_name) *kernel_name = se ? se->name : big ? "k_apply_big" : one_launch ? "k_bq_fused" : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
+    if (kernel_name) *kernel_name = se ? se->name : streamed ? "k_bq_stream" : big ? "k_apply_big" : one_launch ? "k_bq_fused" : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
     if (dry_run) return SSMQ_OK;
     if (B <= 0) return SSMQ_OK;
     if (!d_mean || !d_cov || !d_mean_f || !d_cov_f || !d_cov_fx || !d_status || (fi.uses_time && !d_time) ||
@@ -461,6 +486,23 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     a.status = d_status;
     fill_fpar(f, &a.fp);
     a.fp.ttab = ttab;
+    if (streamed) {
+        // one launch, persistent workgroups (one per CU), each with its own block of FX scratch
+        hipDeviceProp_t prop;
+        int dev = 0;
+        SSMQ_HIP(hipGetDevice(&dev));
+        static int cus_dev = -1, cus = 0;
+        if (cus_dev != dev) {
+            SSMQ_HIP(hipGetDeviceProperties(&prop, dev));
+            cus = prop.multiProcessorCount;
+            cus_dev = dev;
+        }
+        double *fx, *tt, *chol;
+        const size_t n_sc = bq_stream_scratch_doubles(h->N, cus);
+        if ((rc = gemm_scratch((int64_t)n_sc, 1, 0, 0, &fx, &tt, &chol, true))) return rc;
+        const WideLayout wl = wide_layout(h->D, h->E, h->N, h->form);
+        return launch_bq_stream(a, h->d_sx_pan, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, fx, cus, stream());
+    }
     if (big) {
         const bool bq = h->form == SSMQ_FORM_BQ, tpb = bq && h->tp_nu > 0.0;
         const int kb = (h->N + 15) / 16, lda = kb * 16, ldt = bq ? h->big_ncb * kBigCols : 0;
@@ -784,6 +826,7 @@ void ssmq_transform_destroy(ssmq_transform *h) {
     if (h->d_wc_pad) hipFree(h->d_wc_pad);
     if (h->d_wcx_pad) hipFree(h->d_wcx_pad);
     if (h->d_sx_pad) hipFree(h->d_sx_pad);
+    if (h->d_sx_pan) hipFree(h->d_sx_pan);
     if (h->d_wc_blk) hipFree(h->d_wc_blk);
     if (h->d_ik_blk) hipFree(h->d_ik_blk);
     delete h;

@@ -21,6 +21,9 @@ struct ssmq_transform {
     double *d_wcx_pad = nullptr;
     // ... and [S | Wcc' | wm] with S = tril(sym(Wc)), half the diagonal (Wc = S + S'): the one-launch routes skip the zero blocks
     double *d_sx_pad = nullptr;
+    // ... and for point sets beyond that route's instantiations (208 < N): S by panels of 208 columns, G tile in panel 0
+    // (ssmq_bq_stream.hip: bq_stream_pack), or null
+    double *d_sx_pan = nullptr;
     // point sets without an instantiation of that route (N > 64): Wc (and iK for the t-process) as column blocks of
     // kBigCols columns, each [big_kb 16][kBigCols] zero-padded (ssmq_apply_big.hip); null = not built
     double *d_wc_blk = nullptr, *d_ik_blk = nullptr;
@@ -64,6 +67,13 @@ bool fxwc_cov_supported(int E);
 struct WideArgs;
 bool bq_fused_supported(int D, int E, int N);
 int launch_bq_fused(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, hipStream_t s);
+// ... the same for any larger point set, the point axis tiled (ssmq_bq_stream.hip)
+bool bq_stream_supported(int D, int E, int N);
+size_t bq_stream_x_doubles(int N);
+size_t bq_stream_scratch_doubles(int N, int grid);
+void bq_stream_pack(int D, int N, const double *Wc, const double *Wcc, const double *wm, double *X);
+int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, double *scratch,
+                     int grid, hipStream_t s);
 int launch_fxwc_cov_mfma(int NP, const double *A, const double *X, int64_t M, int lda, const double *mean_rows,
                          const double *chol, const double *emv, int emv_broadcast, const double *cov_add,
                          double cov_scale, double ccov_scale, int E, int D, double *cov_f, double *cov_fx, int64_t es,

@@ -608,6 +608,8 @@ def test_config4_as_worded_degree7_full_batch(amd, golden):
              model_var=float(g['bs_' + tag + '_mv']))
     tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = w['wm'], w['Wc'], w['Wcc'], w['model_var']
     f = sm.Smooth10DTransition().dyn_eval
+    if not (os.environ.get('SSMQ_NO_MFMA') or os.environ.get('SSMQ_NO_BQ_STREAM')):
+        assert tf.kernel_name(f) == 'k_bq_stream'           # one launch, the point axis tiled (ssmq_bq_stream.hip)
     mf, cf, cfx, st = tf.apply_batch(f, means, covs, 0.0, return_status=True)
     assert not st.any() and np.all(np.isfinite(mf)) and np.all(np.isfinite(cf)) and np.all(np.isfinite(cfx))
     assert np.array_equal(cf, cf.transpose(0, 2, 1))
@@ -2052,6 +2054,68 @@ def test_one_launch_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
             ref = orc.apply_bq(orc.F_BEARING_MEAS, means[i], covs[i], 0.0, pts, w, tuple(sens.reshape(-1)), sidx)
             rc = np.tril(ref[1]) + np.tril(ref[1], -1).T
             assert_moments_close((mf[i], cf[i], cfx[i]), (ref[0], rc, ref[2]), covs[i], what=(D, E, N, B, i))
+
+
+@pytest.mark.parametrize('D, pstr, ppar, N, E', [(6, 'gh', {'degree': 3}, 729, 6), (6, 'gh', {'degree': 3}, 729, 7),
+                                                 (3, 'gh', {'degree': 7}, 343, 8), (10, 'fs', {'degree': 7}, 1181, 8),
+                                                 (4, 'gh', {'degree': 4}, 256, 6), (2, 'gh', {'degree': 15}, 225, 7)])
+def test_streamed_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
+    """k_bq_stream (ssmq_bq_stream.hip: the one-launch route for 209 ... 4096 points - persistent workgroups, integrand values
+    through a per-workgroup scratch block in fragment order, S = tril(Wc) by panels of 13 column tiles, C + C' epilogue) over
+    its shape space beside configs[4]: output dimensions 6, 7, 8 (10, 9, 8 trajectories per 64-row tile), point counts with a
+    partial last panel / a single k-block past a panel boundary / exactly 16 k-blocks, the register (D <= 8) and the LDS
+    factorisation (D = 10 with a state index), batches that end in a partial tile, more tiles than workgroups, a covariance
+    that is not positive definite.  Against the blocked route (SSMQ_NO_BQ_STREAM) at rounding level and against the oracle."""
+    from ssmtoybox_amd import ssmod as sm
+    if os.environ.get('SSMQ_NO_MFMA') or os.environ.get('SSMQ_NO_BQ_STREAM'):
+        pytest.skip('the matrix-core routes are switched off')
+    rng = np.random.default_rng(1000 * D + E)
+    sens = 30.0 * rng.standard_normal((E, 2))
+    sidx = [0, 2] if D > 3 else [0, 1]
+    obs = sm.BearingMeasurement(sm.GaussRV(E), D, state_index=sidx, sensor_pos=sens)
+    fn = obs.meas_eval
+    tf = amd.GaussianProcessTransform(D, E, gp_par(D, 2.0), 'rbf', pstr, ppar)
+    pts = tf.model.points
+    assert pts.shape == (D, N)
+    wm = rng.standard_normal(N) / N
+    Wc = rng.standard_normal((N, N)) / N
+    Wc = 0.5 * (Wc + Wc.T)
+    Wcc = rng.standard_normal((D, N)) / N
+    # offered for a Wc that is symmetric to the last bit only (Wc = S + S'); any other keeps the blocked route
+    tf.wm, tf.Wc, tf.Wcc, tf.model.model_var = wm, Wc + 1e-3 * np.triu(rng.standard_normal((N, N)), 1) / N, Wcc, 0.21
+    other = 'k_apply_wide' if N > 240 and N <= 256 else 'k_apply_big'     # (256 points: the two-pass route's third instantiation)
+    assert tf.kernel_name(fn) == other
+    tf.Wc = Wc
+    w = dict(wm=wm, Wc=Wc, Wcc=Wcc, model_var=0.21)
+    assert tf.kernel_name(fn) == 'k_bq_stream'
+    for B in (257, 3001):
+        means = 3.0 * rng.standard_normal((B, D))
+        a = rng.standard_normal((B, D, D)) / np.sqrt(D)
+        covs = 0.5 * (np.einsum('bij,bkj->bik', a, a) + 0.1 * np.eye(D))
+        bad = B - 2                                            # in the last, partial tile
+        covs[bad] = -np.eye(D)
+        mf, cf, cfx, st = tf.apply_batch(fn, means, covs, 0.0, return_status=True)
+        monkeypatch.setenv('SSMQ_NO_BQ_STREAM', '1')
+        assert tf.kernel_name(fn) == other
+        mf2, cf2, cfx2, st2 = tf.apply_batch(fn, means, covs, 0.0, return_status=True)
+        monkeypatch.delenv('SSMQ_NO_BQ_STREAM')
+        assert st[bad] != 0 and not np.delete(st, bad).any() and np.array_equal(st, st2)
+        assert np.all(np.isnan(mf[bad])) and np.all(np.isnan(cf[bad])) and np.all(np.isnan(cfx[bad]))
+        ok = np.arange(B) != bad
+        assert np.all(np.isfinite(mf[ok])) and np.all(np.isfinite(cf[ok])) and np.all(np.isfinite(cfx[ok]))
+        assert np.array_equal(cf[ok], cf[ok].transpose(0, 2, 1))
+        sc = np.abs(cf2[ok]).max()
+        what = 'streamed vs blocked route, D=%d E=%d N=%d B=%d ' % (D, E, N, B)
+        assert within(np.abs(mf[ok] - mf2[ok]).max() / np.abs(mf2[ok]).max(), 1e-13, what + 'mean')
+        assert within(np.abs(cf[ok] - cf2[ok]).max() / sc, 1e-13, what + 'cov')
+        assert within(np.abs(cfx[ok] - cfx2[ok]).max() / np.abs(cfx2[ok]).max(), 1e-13, what + 'ccov')
+        for i in (0, 1, B // 2, B - 1):
+            ref = orc.apply_bq(orc.F_BEARING_MEAS, means[i], covs[i], 0.0, pts, w, tuple(sens.reshape(-1)), sidx)
+            assert_moments_close((mf[i], cf[i], cfx[i]), ref, covs[i], what=(D, E, N, B, i))
+        perm = rng.permutation(B)
+        perm = perm[perm != bad][:300]
+        mf3, cf3, cfx3 = tf.apply_batch(fn, means[perm], covs[perm], 0.0)
+        assert np.array_equal(mf3, mf[perm]) and np.array_equal(cf3, cf[perm]) and np.array_equal(cfx3, cfx[perm])
 
 
 def test_state_index_with_more_than_eight_entries(amd):
