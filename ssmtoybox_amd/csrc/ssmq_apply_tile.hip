@@ -34,6 +34,8 @@ constexpr int kTileWaves = 4;
 struct TileGeom {
     int KS, KSP, NB, G, GL;
     int frag_doubles;     // workgroup-shared operand fragments
+    int per_traj;         // a trajectory's part of the wave slice: factor + mean + FX tile (in_doubles), then its outputs [mean | cov | ccov]
+    int in_doubles;
     int wave_doubles;     // per-wave slice
 };
 // k-steps a point set is padded to (the kernel is instantiated for these; padding = zero fragments, no loop guards)
@@ -49,7 +51,9 @@ __host__ __device__ inline TileGeom tile_geom(int D, int E, int N, bool tp) {
     g.GL = 64 / g.G;
     g.frag_doubles = 64 * ((tp ? 2 : 1) * g.NB * g.KS + 2 * g.KS) + N * (D | 1);     // + unit points [N][D | 1]
     g.frag_doubles = (g.frag_doubles + 1) & ~1;
-    g.wave_doubles = g.G * (D * D + D + E * 4 * g.KSP) + 2 + 64 + 16;   // factor + mean + FX tile per trajectory, status words, column slots
+    g.in_doubles = D * D + D + E * 4 * g.KSP;
+    g.per_traj = g.in_doubles + E + E * E + E * D;
+    g.wave_doubles = g.G * g.per_traj + 2 + 64 + 16;   // per trajectory: factor + mean + FX tile; status words, column slots
     g.wave_doubles = (g.wave_doubles + 1) & ~1;
     return g;
 }
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
     }
     // ---- the wave's slice: factor + mean and FX tile per trajectory --------------------------------------------------------
     double *wbase = lds + tg.frag_doubles + (size_t)wave * tg.wave_doubles;
-    const int per_traj = D * D + D + E * 4 * KSP;
+    const int per_traj = tg.per_traj;
     for (int i = lane; i < tg.wave_doubles; i += 64) wbase[i] = 0.0;     // the tile's padding (n >= N) stays zero for good
     __syncthreads();
 
@@ -141,7 +145,10 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
 
     const int gi = lane / GL, gl = lane - gi * GL;
     const int64_t n_groups = (B + G - 1) / G;
+    // Every wave of the workgroup runs the same number of iterations (the stores below are a workgroup affair); a wave whose
+    // group lies beyond the batch walks through the barriers only.
     const int64_t grp0 = (int64_t)blockIdx.x * kTileWaves + wave, grp_step = (int64_t)gridDim.x * kTileWaves;
+    const int64_t base_end = n_groups;      // (loop bound on the workgroup's FIRST group of an iteration)
     // Inputs: lane (g, i), i < D, owns row i of trajectory g's covariance (lower triangle) and entry i of its mean.  The
     // rows of the NEXT group are requested before this group's matrix work starts, so the HBM round trip is never waited for.
     const uint32_t es8 = (uint32_t)(a.es_in * 8), eo8 = (uint32_t)(a.es_out * 8);   // plane pitches in bytes (< 2^32: launcher)
@@ -159,8 +166,11 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
         for (int k = 0; k < DM; ++k) in_row[k] = *(const double *)(pc + (uint64_t)(uint32_t)(k < gl_row ? k : gl_row) * es8);
     };
     double *scol = wbase + G * per_traj + 2;        // [64] one slot per lane: the current elimination column
-    fetch(grp0);
-    for (int64_t grp = grp0; grp < n_groups; grp += grp_step) {
+    fetch(grp0 < n_groups ? grp0 : n_groups - 1);
+    // outputs: planes [mean (E) | cov (E E) | ccov (E D)] of the workgroup's 4 G consecutive trajectories, see step 4
+    const int n_planes = E + E * E + E * D;
+    const bool out16 = ((((uintptr_t)a.mean_f) | ((uintptr_t)a.cov_f) | ((uintptr_t)a.cov_fx)) & 15) == 0 && (a.es_out & 1) == 0;
+    for (int64_t grp = grp0; grp - wave < base_end; grp += grp_step) {
         const int64_t b0 = grp * G;
         // ---- 1. Cholesky, one row per lane in registers; column j travels through the slice (right-looking, the subtractions
         //         in the order k = 0, 1, ... of the left-looking dot products: the factor of the other generic kernels) --------
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
 #pragma unroll
         for (int k = 0; k < DM; ++k) rowv[k] = in_row[k];
         const double my_m = in_m;
-        fetch(grp + grp_step < n_groups ? grp + grp_step : grp);
+        fetch(grp + grp_step < n_groups ? grp + grp_step : (grp < n_groups ? grp : n_groups - 1));
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < DM; ++j) {
@@ -307,10 +317,9 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
             // cov - m m': one more step of the same accumulation (A = -m, B = m in the lanes of one k sub-index)
             const double am = (q == kq) ? mc : 0.0;
             if (!sigma) cov = __builtin_amdgcn_mfma_f64_16x16x4f64(-am, am, cov, 0, 0, 0);
-            // ---- stores: mean, covariance for e2 <= e1 mirrored, cross-covariance ------------------------------------------------
-            // plane index (32 bits) x plane pitch in bytes (32 bits) on top of the trajectory's wave-uniform base address
-            auto at = [&](double *base, int idx) { return (double *)((char *)(base + bb) + (uint64_t)(uint32_t)idx * eo8); };
-            if (q == kq && c < E) *at(a.mean_f, c) = mc;
+            // ---- outputs of this trajectory into its part of the slice: [mean | cov (e2 <= e1 mirrored) | ccov] ------------------------
+            double *so = wbase + g * per_traj + tg.in_doubles;
+            if (q == kq && c < E) so[c] = mc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (smask & (1 << r)) {
@@ -322,13 +331,43 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
                         if (tp) em = (a.tp_nu - 2.0 + sq[r]) * tp_den * em;
                         v = (cov[r] + em) * a.cov_scale + add_r[r];
                     }
-                    *at(a.cov_f, pl_cov[r]) = v;
-                    if (smask & (16 << r)) *at(a.cov_f, pl_cvt[r]) = v;
+                    so[E + pl_cov[r]] = v;
+                    if (smask & (16 << r)) so[E + pl_cvt[r]] = v;
                 }
-                if (smask & (256 << r)) *at(a.cov_fx, pl_cc[r]) = cc[r] * a.ccov_scale;
+                if (smask & (256 << r)) so[E + E * E + pl_cc[r]] = cc[r] * a.ccov_scale;
             }
         }
-        SSMQ_WAVE_SYNC();        // the next group's inputs overwrite the slice
+        // ---- 4. stores, by the whole workgroup: its four waves hold the outputs of 4 G CONSECUTIVE trajectories; per plane these are
+        //         4 G consecutive doubles (96 bytes at G = 3), written as 16-byte pieces by neighbouring lanes.  (Round 3 stored
+        //         from the accumulators: every lane 8 bytes to a plane of its own, 24-byte fragments per plane and wave - 1.03 M
+        //         store instructions and 426 MB of partial-sector writes for a 168 MB payload at D = E = 10, N = 21, B = 1e5.) -----
+        __syncthreads();
+        {
+            const int64_t bc = (grp - wave) * G;                        // first trajectory of the workgroup's chunk
+            const int64_t left = B - bc;
+            const int nt = (int)(left < (int64_t)(kTileWaves * G) ? left : (int64_t)(kTileWaves * G));
+            const int pp = (nt + 1) >> 1;                               // pieces of two trajectories per plane
+            const double *sall = lds + tg.frag_doubles + tg.in_doubles;
+            for (int id = threadIdx.x; id < n_planes * pp; id += 64 * kTileWaves) {
+                const int p = id / pp, k = id - p * pp;
+                const int t0 = 2 * k, t1 = t0 + 1;
+                const int w0 = t0 / G, w1 = t1 / G;
+                const double v0 = sall[(size_t)w0 * tg.wave_doubles + (t0 - w0 * G) * per_traj + p];
+                const double v1 = t1 < nt ? sall[(size_t)w1 * tg.wave_doubles + (t1 - w1 * G) * per_traj + p] : 0.0;
+                double *dst;
+                if (p < E) dst = (double *)((char *)(a.mean_f + bc + t0) + (uint64_t)(uint32_t)p * eo8);
+                else if (p < E + E * E) dst = (double *)((char *)(a.cov_f + bc + t0) + (uint64_t)(uint32_t)(p - E) * eo8);
+                else dst = (double *)((char *)(a.cov_fx + bc + t0) + (uint64_t)(uint32_t)(p - E - E * E) * eo8);
+                if (t1 < nt && out16) {
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    *(v2d *)dst = v2d{v0, v1};
+                } else {
+                    dst[0] = v0;
+                    if (t1 < nt) dst[1] = v1;
+                }
+            }
+        }
+        __syncthreads();         // the next group's inputs and outputs overwrite the slices
     }
 }
 
