@@ -362,6 +362,35 @@ int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_
                        double *post_cov, double *loglik, int32_t *status);
 
 /*
+ * Batched Laplace step of the marginalised filter (ssinf.py:1243-1273 _param_posterior_moments: one scipy BFGS run per
+ * trajectory and time step in the reference; research/tpq/tpq_base.py:175-192 loops over trajectories): B independent
+ * minimisations of  -log N(y_b | theta-conditioned step)  -  log N(theta | prior_mean_b, prior_cov_b)  in lock step - every
+ * round ONE ssmq_gp_theta_step of (unfinished trajectories) x (param_dim + 1) items (objective + forward-difference gradient,
+ * step fd_step as scipy's default 1.4901161193847656e-08).  The optimiser restates SciPy 1.15's BFGS with its first line
+ * search (MINPACK-2 DCSRCH, c1 = 1e-4, c2 = 0.9, gtol 1e-5 on the max-norm, maxiter 200 param_dim).
+ * mean [B][Din], cov [B][Din*Din] (augmented as for ssmq_gp_theta_step), y [B][Y], prior_mean [B][P], prior_cov [B][P*P],
+ * theta [B][P]: start points in (normally the prior means), minimisers out; hess_inv [B][P*P] the BFGS inverse Hessian.
+ * status[b]: 0 converged, SSMQ_BFGS_MAXITER / _PRECISION_LOSS / _NAN = scipy's warnflag 1 / 2 / 3 (theta / hess_inv as scipy
+ * leaves them), SSMQ_BFGS_FALLBACK: the line search ended where scipy switches to its second one - the caller finishes this
+ * trajectory itself (scipy.optimize.minimize from the start point), SSMQ_BFGS_PRIOR_NOT_PD.  iters[b] (may be NULL): BFGS
+ * iterations; *rounds (may be NULL): device calls made.  Host arrays; synchronous.
+ */
+enum { SSMQ_BFGS_MAXITER = 1, SSMQ_BFGS_PRECISION_LOSS = 2, SSMQ_BFGS_NAN = 3, SSMQ_BFGS_FALLBACK = 100, SSMQ_BFGS_PRIOR_NOT_PD = 101 };
+/*
+ * The same optimiser on a host objective (no device): fn(ctx, n, P, traj, rows, vals) fills vals[i] with the objective of
+ * trajectory traj[i] at the parameter row rows[i][P] and returns 0 (< 0: abort with that code).  What the tests pin against
+ * scipy.optimize.minimize(method='BFGS') on the CPU.
+ */
+typedef int (*ssmq_objective_fn)(void *ctx, int64_t n, int P, const int64_t *traj, const double *rows, double *vals);
+int ssmq_bfgs_lockstep_host(ssmq_objective_fn fn, void *ctx, int64_t B, int P, double fd_step, double *theta, double *hess_inv,
+                            int32_t *status, int32_t *iters, int64_t *rounds);
+int ssmq_gp_marginal_laplace_batch(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                   const ssmq_integrand *f_obs, int64_t B, double jitter, const double *mean,
+                                   const double *cov, const double *y, double time, const double *GQG, const double *R,
+                                   const double *prior_mean, const double *prior_cov, double fd_step, double *theta,
+                                   double *hess_inv, int32_t *status, int32_t *iters, int64_t *rounds);
+
+/*
  * Unit sigma-point sets and classical quadrature weights, host code (no device needed):
  *   SSMQ_PTS_UT  unscented, 2D+1 points    mtran.py:234-293   par = [kappa, alpha, beta]   (NaN / missing: max(3-D,0), 1, 2)
  *   SSMQ_PTS_SR  spherical-radial, 2D      mtran.py:171-204   par = []

@@ -144,6 +144,13 @@ _PROTOTYPES = {
                                           ctypes.c_double, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int,
                                           ctypes.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                           c_int32_p]),
+    'ssmq_gp_marginal_laplace_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
+                                                      ctypes.POINTER(Integrand), ctypes.c_int64, ctypes.c_double, c_double_p,
+                                                      c_double_p, c_double_p, ctypes.c_double, c_double_p, c_double_p,
+                                                      c_double_p, c_double_p, ctypes.c_double, c_double_p, c_double_p,
+                                                      c_int32_p, c_int32_p, ctypes.POINTER(ctypes.c_int64)]),
+    'ssmq_bfgs_lockstep_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                               c_double_p, c_double_p, c_int32_p, c_int32_p, ctypes.POINTER(ctypes.c_int64)]),
     'ssmq_points_count': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int]),
     'ssmq_points': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, c_double_p,
                                    c_double_p]),
@@ -187,6 +194,8 @@ _PROTOTYPES = {
     'ssmq_comm_barrier': (ctypes.c_int, []),
     'ssmq_comm_destroy': (ctypes.c_int, []),
 }
+
+BFGS_MAXITER, BFGS_PRECISION_LOSS, BFGS_NAN, BFGS_FALLBACK, BFGS_PRIOR_NOT_PD = 1, 2, 3, 100, 101     # include/ssmq.h
 
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOTYPES))
 

@@ -1,0 +1,592 @@
+// Batched Laplace step of the marginalised GP-quadrature filter: B independent BFGS runs in lock step (host code).
+//
+// Reference: MarginalInference._param_posterior_moments (ssinf.py:1243-1273) runs scipy.optimize.minimize(method='BFGS')
+// on the negative log posterior of the kernel parameters, ONE trajectory at a time, once per time step; its callers loop
+// over Monte-Carlo trajectories in Python (research/tpq/tpq_base.py:175-192).  The objective of trajectory b at theta is
+//   - log N(y_b | moments of the theta-conditioned filter step)  -  log N(theta | prior mean_b, prior cov_b)
+// (ssinf.py:1153-1241) and costs one theta step on the device (ssmq_gp_theta_step); a forward-difference gradient costs
+// param_dim more.  Here every trajectory keeps its own optimiser state and each ROUND sends the points all unfinished
+// trajectories are waiting for - (param_dim + 1) per trajectory - to the device in ONE ssmq_gp_theta_step call.
+//
+// The optimiser is a restatement of what SciPy 1.15.3 (the pinned version of this image; not part of the reference tree) runs
+// for method='BFGS' with jac=True and default options: _minimize_bfgs (gtol 1e-5 on the max-norm, maxiter 200 n, initial
+// inverse Hessian I, "old_old_fval = f0 + |g0| / 2"), line_search_wolfe1 -> scalar_search_wolfe1 (c1 1e-4, c2 0.9, amin 1e-100,
+// amax 1e100, xtol 1e-14, at most 100 trial steps) -> MINPACK-2's DCSRCH / DCSTEP (More' & Thuente; SciPy's _dcsrch.py), written
+// as a per-trajectory state machine because the function values arrive a round later.  Where SciPy would fall back to its
+// second line search (line_search_wolfe2: DCSRCH ended in an ERROR or WARNING task) the trajectory is handed back with
+// status SSMQ_BFGS_FALLBACK and the caller finishes it with SciPy itself, from the start point - results as the serial path.
+#include "ssmq_host.h"
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+using namespace ssmq;
+
+namespace {
+
+constexpr int kMaxPar = 2 * (SSMQ_MAX_DIM + 1);
+
+struct Dcsrch {            // scipy/optimize/_dcsrch.py: class DCSRCH (state), _iterate
+    int stage = 0;
+    bool brackt = false;
+    double ginit = 0, gtest = 0, gx = 0, gy = 0, finit = 0, fx = 0, fy = 0, stx = 0, sty = 0, stmin = 0, stmax = 0, width = 0, width1 = 0;
+    double ftol = 1e-4, gtol = 0.9, xtol = 1e-14, stpmin = 1e-100, stpmax = 1e100;
+};
+enum Task { T_START, T_FG, T_CONV, T_WARN, T_ERROR };
+
+double sgn(double v) { return (v > 0) - (v < 0); }
+double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// _dcsrch.py: dcstep
+void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp, double fp, double dp, bool &brackt,
+            double stpmin, double stpmax) {
+    const double sgnd = sgn(dp) * sgn(dx);
+    double stpf, stpc, stpq;
+    if (fp > fx) {
+        const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+        const double s = std::fmax(std::fabs(theta), std::fmax(std::fabs(dx), std::fabs(dp)));
+        double gamma = s * std::sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp < stx) gamma *= -1;
+        const double p = (gamma - dx) + theta, q = ((gamma - dx) + gamma) + dp, r = p / q;
+        stpc = stx + r * (stp - stx);
+        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+        stpf = std::fabs(stpc - stx) <= std::fabs(stpq - stx) ? stpc : stpc + (stpq - stpc) / 2.0;
+        brackt = true;
+    } else if (sgnd < 0.0) {
+        const double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+        const double s = std::fmax(std::fabs(theta), std::fmax(std::fabs(dx), std::fabs(dp)));
+        double gamma = s * std::sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp > stx) gamma *= -1;
+        const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dx, r = p / q;
+        stpc = stp + r * (stx - stp);
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        stpf = std::fabs(stpc - stp) > std::fabs(stpq - stp) ? stpc : stpq;
+        brackt = true;
+    } else if (std::fabs(dp) < std::fabs(dx)) {
+        const double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+        const double s = std::fmax(std::fabs(theta), std::fmax(std::fabs(dx), std::fabs(dp)));
+        double gamma = s * std::sqrt(std::fmax(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+        if (stp > stx) gamma = -gamma;
+        const double p = (gamma - dp) + theta, q = (gamma + (dx - dp)) + gamma, r = p / q;
+        if (r < 0 && gamma != 0) stpc = stp + r * (stx - stp);
+        else if (stp > stx) stpc = stpmax;
+        else stpc = stpmin;
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        if (brackt) {
+            stpf = std::fabs(stpc - stp) < std::fabs(stpq - stp) ? stpc : stpq;
+            if (stp > stx) stpf = std::fmin(stp + 0.66 * (sty - stp), stpf);
+            else stpf = std::fmax(stp + 0.66 * (sty - stp), stpf);
+        } else {
+            stpf = std::fabs(stpc - stp) > std::fabs(stpq - stp) ? stpc : stpq;
+            stpf = clipd(stpf, stpmin, stpmax);
+        }
+    } else {
+        if (brackt) {
+            const double theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+            const double s = std::fmax(std::fabs(theta), std::fmax(std::fabs(dy), std::fabs(dp)));
+            double gamma = s * std::sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+            if (stp > sty) gamma = -gamma;
+            const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dy, r = p / q;
+            stpc = stp + r * (sty - stp);
+            stpf = stpc;
+        } else if (stp > stx) {
+            stpf = stpmax;
+        } else {
+            stpf = stpmin;
+        }
+    }
+    if (fp > fx) {
+        sty = stp; fy = fp; dy = dp;
+    } else {
+        if (sgnd < 0) {
+            sty = stx; fy = fx; dy = dx;
+        }
+        stx = stp; fx = fp; dx = dp;
+    }
+    stp = stpf;
+}
+
+// _dcsrch.py: DCSRCH._iterate.  Returns the next task; stp is updated in place.
+Task dcsrch_iterate(Dcsrch &d, double &stp, double f, double g, Task task) {
+    const double p5 = 0.5, p66 = 0.66, xtrapl = 1.1, xtrapu = 4.0;
+    if (task == T_START) {
+        if (stp < d.stpmin || stp > d.stpmax || g >= 0) return T_ERROR;
+        d.brackt = false;
+        d.stage = 1;
+        d.finit = f; d.ginit = g; d.gtest = d.ftol * d.ginit;
+        d.width = d.stpmax - d.stpmin; d.width1 = d.width / p5;
+        d.stx = 0.0; d.fx = d.finit; d.gx = d.ginit;
+        d.sty = 0.0; d.fy = d.finit; d.gy = d.ginit;
+        d.stmin = 0; d.stmax = stp + xtrapu * stp;
+        return T_FG;
+    }
+    const double ftest = d.finit + stp * d.gtest;
+    if (d.stage == 1 && f <= ftest && g >= 0) d.stage = 2;
+    Task out = T_FG;
+    if (d.brackt && (stp <= d.stmin || stp >= d.stmax)) out = T_WARN;
+    if (d.brackt && d.stmax - d.stmin <= d.xtol * d.stmax) out = T_WARN;
+    if (stp == d.stpmax && f <= ftest && g <= d.gtest) out = T_WARN;
+    if (stp == d.stpmin && (f > ftest || g >= d.gtest)) out = T_WARN;
+    if (f <= ftest && std::fabs(g) <= d.gtol * -d.ginit) out = T_CONV;
+    if (out == T_WARN || out == T_CONV) return out;
+    if (d.stage == 1 && f <= d.fx && f > ftest) {
+        const double fm = f - stp * d.gtest;
+        double fxm = d.fx - d.stx * d.gtest, fym = d.fy - d.sty * d.gtest;
+        const double gm = g - d.gtest;
+        double gxm = d.gx - d.gtest, gym = d.gy - d.gtest;
+        dcstep(d.stx, fxm, gxm, d.sty, fym, gym, stp, fm, gm, d.brackt, d.stmin, d.stmax);
+        d.fx = fxm + d.stx * d.gtest; d.fy = fym + d.sty * d.gtest;
+        d.gx = gxm + d.gtest; d.gy = gym + d.gtest;
+    } else {
+        dcstep(d.stx, d.fx, d.gx, d.sty, d.fy, d.gy, stp, f, g, d.brackt, d.stmin, d.stmax);
+    }
+    if (d.brackt) {
+        if (std::fabs(d.sty - d.stx) >= p66 * d.width1) stp = d.stx + p5 * (d.sty - d.stx);
+        d.width1 = d.width;
+        d.width = std::fabs(d.sty - d.stx);
+    }
+    if (d.brackt) {
+        d.stmin = std::fmin(d.stx, d.sty);
+        d.stmax = std::fmax(d.stx, d.sty);
+    } else {
+        d.stmin = stp + xtrapl * (stp - d.stx);
+        d.stmax = stp + xtrapu * (stp - d.stx);
+    }
+    stp = clipd(stp, d.stpmin, d.stpmax);
+    if ((d.brackt && (stp <= d.stmin || stp >= d.stmax)) || (d.brackt && d.stmax - d.stmin <= d.xtol * d.stmax)) stp = d.stx;
+    return T_FG;
+}
+
+// _linesearch.py: _cubicmin / _quadmin (None = false: an arithmetic error or a non-finite result)
+bool cubicmin(double a, double fa, double fpa, double b, double fb, double c, double fc, double *xmin) {
+    const double C = fpa, db = b - a, dc = c - a;
+    const double denom = (db * dc) * (db * dc) * (db - dc);
+    const double r0 = fb - fa - C * db, r1 = fc - fa - C * dc;
+    double A = dc * dc * r0 + -(db * db) * r1, Bq = -(dc * dc * dc) * r0 + db * db * db * r1;
+    if (denom == 0.0 || !std::isfinite(denom) || !std::isfinite(A) || !std::isfinite(Bq)) return false;
+    A /= denom;
+    Bq /= denom;
+    const double radical = Bq * Bq - 3 * A * C;
+    if (!(radical >= 0.0) || A == 0.0 || !std::isfinite(radical)) return false;
+    const double x = a + (-Bq + std::sqrt(radical)) / (3 * A);
+    if (!std::isfinite(x)) return false;
+    *xmin = x;
+    return true;
+}
+bool quadmin(double a, double fa, double fpa, double b, double fb, double *xmin) {
+    const double D = fa, C = fpa, db = b - a * 1.0;
+    if (db * db == 0.0) return false;
+    const double Bq = (fb - D - C * db) / (db * db);
+    if (Bq == 0.0 || !std::isfinite(Bq)) return false;
+    const double x = a - C / (2.0 * Bq);
+    if (!std::isfinite(x)) return false;
+    *xmin = x;
+    return true;
+}
+
+enum Phase { PH_INIT, PH_LINE, PH_LINE2, PH_DONE };
+
+struct Run {               // _minimize_bfgs' locals of one trajectory
+    Phase phase = PH_INIT;
+    int k = 0, ls_iter = 0, status = 0;
+    double x[kMaxPar], g[kMaxPar], pk[kMaxPar], xt[kMaxPar], H[kMaxPar * kMaxPar];
+    double old_fval = 0, old_old_fval = 0, derphi0 = 0, stp = 0;
+    Dcsrch ls;
+    Task task = T_START;
+    // second line search (scipy _linesearch.py: scalar_search_wolfe2 / _zoom), entered where the first one gives up
+    int w2_i = 0, z_i = 0;
+    bool zoom = false;
+    double w2_alpha0 = 0, w2_phi_a0 = 0, w2_derphi_a0 = 0;
+    double a_lo = 0, a_hi = 0, phi_lo = 0, phi_hi = 0, derphi_lo = 0, phi_rec = 0, a_rec = 0;
+};
+
+
+// values of the objective at n rows of parameters: rows [n][P], `traj[i]` = the trajectory row i belongs to; vals [n]
+struct Evaluator {
+    virtual int eval(int64_t n, const int64_t *traj, const double *rows, double *vals) = 0;
+    virtual ~Evaluator() {}
+};
+
+// B BFGS runs in lock step.  theta [B][P] start points in / minimisers out; skip[b] != 0: trajectory b is not run (status kept).
+int bfgs_lockstep(int64_t B, int P, double fd_step, Evaluator &ev, double *theta, double *hess_inv, int32_t *status, int32_t *iters,
+                  int64_t *rounds_out) {
+    const double gtol = 1e-5, inf = std::numeric_limits<double>::infinity();
+    const int maxiter = 200 * P;
+    std::vector<Run> run((size_t)B);
+    for (int64_t b = 0; b < B; ++b) {
+        Run &r = run[b];
+        for (int i = 0; i < P; ++i) r.x[i] = r.xt[i] = theta[(size_t)b * P + i];
+        for (int i = 0; i < P * P; ++i) r.H[i] = 0.0;
+        for (int i = 0; i < P; ++i) r.H[i * P + i] = 1.0;
+        if (status[b] != 0) {
+            r.phase = PH_DONE;
+            r.status = status[b];
+        }
+    }
+    std::vector<int64_t> want, traj;
+    std::vector<double> rows, vals;
+    int64_t rounds = 0;
+    const int per = P + 1;
+    for (;;) {
+        want.clear();
+        for (int64_t b = 0; b < B; ++b)
+            if (run[b].phase != PH_DONE) want.push_back(b);
+        if (want.empty()) break;
+        const int64_t nw = (int64_t)want.size(), items = nw * per;
+        rows.resize((size_t)items * P); vals.resize((size_t)items); traj.resize((size_t)items);
+        // objective and forward-difference gradient at xt: rows [xt; xt + h e_i]
+        for (int64_t w = 0; w < nw; ++w) {
+            const Run &r = run[want[w]];
+            for (int j = 0; j < per; ++j) {
+                traj[(size_t)(w * per + j)] = want[w];
+                for (int i = 0; i < P; ++i) rows[(size_t)(w * per + j) * P + i] = r.xt[i] + ((j == i + 1) ? fd_step : 0.0);
+            }
+        }
+        const int rc = ev.eval(items, traj.data(), rows.data(), vals.data());
+        if (rc < 0) return rc;
+        ++rounds;
+        for (int64_t w = 0; w < nw; ++w) {
+            Run &r = run[want[w]];
+            // value and gradient at xt (non-finite -> +inf as the Python objective, ssmtoybox_amd/ssinf.py)
+            double val[kMaxPar + 1], gt[kMaxPar];
+            for (int j = 0; j < per; ++j) {
+                const double v = vals[(size_t)(w * per + j)];
+                val[j] = std::isfinite(v) ? v : inf;
+            }
+            for (int i = 0; i < P; ++i) gt[i] = (val[i + 1] - val[0]) / ((r.xt[i] + fd_step) - r.xt[i]);
+            const double ft = val[0];
+            bool start_iteration = false;
+            if (r.phase == PH_INIT) {
+                r.old_fval = ft;
+                double n2 = 0.0, gmax = 0.0;
+                for (int i = 0; i < P; ++i) {
+                    r.g[i] = gt[i];
+                    n2 += gt[i] * gt[i];
+                    gmax = (std::isnan(gt[i]) || std::isnan(gmax)) ? NAN : std::fmax(gmax, std::fabs(gt[i]));   // numpy's max keeps NaN
+                }
+                r.old_old_fval = r.old_fval + std::sqrt(n2) / 2;
+                if (!(gmax > gtol)) {            // (a NaN gradient ends the loop as in SciPy: `while gnorm > gtol`)
+                    r.phase = PH_DONE;
+                    r.status = (std::isnan(gmax) || std::isnan(ft)) ? SSMQ_BFGS_NAN : 0;
+                    continue;
+                }
+                start_iteration = true;
+            } else {                             // PH_LINE / PH_LINE2: a trial step has been evaluated
+                double dphi = 0.0;
+                for (int i = 0; i < P; ++i) dphi += gt[i] * r.pk[i];
+                const double c1 = 1e-4, c2 = 0.9, amax = 1e100;
+                const double phi0 = r.old_fval, derphi0 = r.derphi0;
+                bool accepted = false, to_second = false, failed = false;
+                double next = 0.0;                 // the next trial step, if neither
+                if (r.phase == PH_LINE) {
+                    double stp = r.stp;
+                    const Task t = dcsrch_iterate(r.ls, stp, ft, dphi, T_FG);
+                    if (t == T_FG) {
+                        ++r.ls_iter;
+                        if (!std::isfinite(stp) || r.ls_iter >= 100) to_second = true;
+                        else next = stp;
+                    } else if (t == T_CONV) {
+                        accepted = true;
+                    } else {                       // WARNING / ERROR: SciPy goes on with line_search_wolfe2
+                        to_second = true;
+                    }
+                } else if (!r.zoom) {              // scalar_search_wolfe2, iteration w2_i, alpha1 = r.stp evaluated
+                    const double alpha1 = r.stp, phi_a1 = ft, derphi_a1 = dphi;
+                    auto start_zoom = [&](double a_lo, double a_hi, double phi_lo, double phi_hi, double derphi_lo) {
+                        r.zoom = true; r.z_i = 0;
+                        r.a_lo = a_lo; r.a_hi = a_hi; r.phi_lo = phi_lo; r.phi_hi = phi_hi; r.derphi_lo = derphi_lo;
+                        r.phi_rec = phi0; r.a_rec = 0.0;
+                    };
+                    if (r.w2_i >= 10) {            // for ... else: maxiter reached; the last evaluated step is returned
+                        accepted = true;
+                    } else if (alpha1 == 0.0) {
+                        failed = true;
+                    } else if ((phi_a1 > phi0 + c1 * alpha1 * derphi0) || ((phi_a1 >= r.w2_phi_a0) && r.w2_i > 0)) {
+                        start_zoom(r.w2_alpha0, alpha1, r.w2_phi_a0, phi_a1, r.w2_derphi_a0);
+                    } else if (std::fabs(derphi_a1) <= -c2 * derphi0) {
+                        accepted = true;
+                    } else if (derphi_a1 >= 0) {
+                        start_zoom(alpha1, r.w2_alpha0, phi_a1, r.w2_phi_a0, derphi_a1);
+                    } else {
+                        const double alpha2 = std::fmin(2 * alpha1, amax);
+                        r.w2_alpha0 = alpha1; r.w2_phi_a0 = phi_a1; r.w2_derphi_a0 = derphi_a1;
+                        ++r.w2_i;
+                        next = alpha2;
+                    }
+                } else {                           // _zoom: a_j = r.stp evaluated
+                    const double a_j = r.stp, phi_aj = ft, derphi_aj = dphi;
+                    if ((phi_aj > phi0 + c1 * a_j * derphi0) || (phi_aj >= r.phi_lo)) {
+                        r.phi_rec = r.phi_hi; r.a_rec = r.a_hi; r.a_hi = a_j; r.phi_hi = phi_aj;
+                    } else {
+                        if (std::fabs(derphi_aj) <= -c2 * derphi0) {
+                            accepted = true;
+                        } else {
+                            if (derphi_aj * (r.a_hi - r.a_lo) >= 0) {
+                                r.phi_rec = r.phi_hi; r.a_rec = r.a_hi; r.a_hi = r.a_lo; r.phi_hi = r.phi_lo;
+                            } else {
+                                r.phi_rec = r.phi_lo; r.a_rec = r.a_lo;
+                            }
+                            r.a_lo = a_j; r.phi_lo = phi_aj; r.derphi_lo = derphi_aj;
+                        }
+                    }
+                    if (!accepted) {
+                        ++r.z_i;
+                        if (r.z_i > 10) failed = true;
+                    }
+                }
+                if (to_second) {
+                    // scalar_search_wolfe2 from the same point and direction: first trial step as for the first search
+                    double alpha1 = 1.0;
+                    if (derphi0 != 0) alpha1 = std::fmin(1.0, 1.01 * 2 * (phi0 - r.old_old_fval) / derphi0);
+                    if (alpha1 < 0) alpha1 = 1.0;
+                    alpha1 = std::fmin(alpha1, amax);
+                    r.phase = PH_LINE2;
+                    r.zoom = false; r.w2_i = 0;
+                    r.w2_alpha0 = 0.0; r.w2_phi_a0 = phi0; r.w2_derphi_a0 = derphi0;
+                    next = alpha1;
+                }
+                if (failed) {                      // _LineSearchError: "Desired error not necessarily achieved due to precision loss"
+                    r.phase = PH_DONE;
+                    r.status = SSMQ_BFGS_PRECISION_LOSS;
+                    continue;
+                }
+                if (!accepted) {
+                    if (r.phase == PH_LINE2 && r.zoom) {
+                        // the next trial step of _zoom: cubic, else quadratic interpolation, else bisection
+                        const double dalpha = r.a_hi - r.a_lo;
+                        const double a = dalpha < 0 ? r.a_hi : r.a_lo, b = dalpha < 0 ? r.a_lo : r.a_hi;
+                        double a_j = 0.0;
+                        bool have = false;
+                        const double cchk = 0.2 * dalpha;
+                        if (r.z_i > 0) have = cubicmin(r.a_lo, r.phi_lo, r.derphi_lo, r.a_hi, r.phi_hi, r.a_rec, r.phi_rec, &a_j);
+                        if (r.z_i == 0 || !have || a_j > b - cchk || a_j < a + cchk) {
+                            const double qchk = 0.1 * dalpha;
+                            have = quadmin(r.a_lo, r.phi_lo, r.derphi_lo, r.a_hi, r.phi_hi, &a_j);
+                            if (!have || a_j > b - qchk || a_j < a + qchk) a_j = r.a_lo + 0.5 * dalpha;
+                        }
+                        next = a_j;
+                    }
+                    r.stp = next;
+                    for (int i = 0; i < P; ++i) r.xt[i] = r.x[i] + next * r.pk[i];
+                    continue;
+                }
+                // accepted: alpha_k = stp, the last evaluated step
+                const double alpha = r.stp;
+                double sk[kMaxPar], yk[kMaxPar], pn = 0.0, xn = 0.0, gmax = 0.0;
+                for (int i = 0; i < P; ++i) {
+                    sk[i] = alpha * r.pk[i];
+                    r.x[i] = r.x[i] + sk[i];
+                    yk[i] = gt[i] - r.g[i];
+                    r.g[i] = gt[i];
+                    pn += r.pk[i] * r.pk[i];
+                    xn += r.x[i] * r.x[i];
+                    gmax = (std::isnan(gt[i]) || std::isnan(gmax)) ? NAN : std::fmax(gmax, std::fabs(gt[i]));
+                }
+                r.old_old_fval = r.old_fval;
+                r.old_fval = ft;
+                ++r.k;
+                if (!(gmax > gtol) && !std::isnan(gmax)) {
+                    r.phase = PH_DONE;
+                    r.status = 0;
+                    continue;
+                }
+                if (alpha * std::sqrt(pn) <= 0.0) {      // xrtol = 0
+                    r.phase = PH_DONE;
+                    r.status = std::isnan(gmax) ? SSMQ_BFGS_NAN : 0;
+                    continue;
+                }
+                if (!std::isfinite(r.old_fval)) {
+                    r.phase = PH_DONE;
+                    r.status = SSMQ_BFGS_PRECISION_LOSS;
+                    continue;
+                }
+                double rho_inv = 0.0;
+                for (int i = 0; i < P; ++i) rho_inv += yk[i] * sk[i];
+                const double rho = rho_inv == 0.0 ? 1000.0 : 1.0 / rho_inv;
+                // Hk = (I - sk yk' rho) Hk (I - yk sk' rho) + rho sk sk'
+                double A2[kMaxPar * kMaxPar], HA[kMaxPar * kMaxPar], Hn[kMaxPar * kMaxPar];
+                for (int i = 0; i < P; ++i)
+                    for (int j = 0; j < P; ++j) A2[i * P + j] = (i == j ? 1.0 : 0.0) - yk[i] * sk[j] * rho;
+                for (int i = 0; i < P; ++i)
+                    for (int j = 0; j < P; ++j) {
+                        double s = 0.0;
+                        for (int k = 0; k < P; ++k) s += r.H[i * P + k] * A2[k * P + j];
+                        HA[i * P + j] = s;
+                    }
+                for (int i = 0; i < P; ++i)
+                    for (int j = 0; j < P; ++j) {
+                        double s = 0.0;
+                        for (int k = 0; k < P; ++k) s += ((i == k ? 1.0 : 0.0) - sk[i] * yk[k] * rho) * HA[k * P + j];
+                        Hn[i * P + j] = s + rho * sk[i] * sk[j];
+                    }
+                std::memcpy(r.H, Hn, sizeof(double) * P * P);
+                if (std::isnan(gmax)) {                  // `while gnorm > gtol` ends on NaN
+                    r.phase = PH_DONE;
+                    r.status = SSMQ_BFGS_NAN;
+                    continue;
+                }
+                if (r.k >= maxiter) {
+                    r.phase = PH_DONE;
+                    r.status = SSMQ_BFGS_MAXITER;
+                    continue;
+                }
+                start_iteration = true;
+            }
+            if (start_iteration) {
+                // pk = -Hk gfk; scalar_search_wolfe1's first trial step; DCSRCH "START"
+                double dphi0 = 0.0;
+                for (int i = 0; i < P; ++i) {
+                    double s = 0.0;
+                    for (int j = 0; j < P; ++j) s += r.H[i * P + j] * r.g[j];
+                    r.pk[i] = -s;
+                }
+                for (int i = 0; i < P; ++i) dphi0 += r.g[i] * r.pk[i];
+                r.derphi0 = dphi0;
+                double alpha1 = 1.0;
+                if (dphi0 != 0) {
+                    alpha1 = std::fmin(1.0, 1.01 * 2 * (r.old_fval - r.old_old_fval) / dphi0);
+                    if (alpha1 < 0) alpha1 = 1.0;
+                }
+                r.ls = Dcsrch();
+                double stp = alpha1;
+                const Task t = dcsrch_iterate(r.ls, stp, r.old_fval, dphi0, T_START);
+                if (t != T_FG || !std::isfinite(stp)) {
+                    // the first search refuses to start (e.g. not a descent direction): scalar_search_wolfe2 from its first step
+                    r.phase = PH_LINE2;
+                    r.zoom = false; r.w2_i = 0;
+                    r.w2_alpha0 = 0.0; r.w2_phi_a0 = r.old_fval; r.w2_derphi_a0 = dphi0;
+                    stp = std::fmin(alpha1, 1e100);
+                } else {
+                    r.ls_iter = 1;
+                    r.phase = PH_LINE;
+                }
+                r.stp = stp;
+                for (int i = 0; i < P; ++i) r.xt[i] = r.x[i] + stp * r.pk[i];
+            }
+        }
+    }
+    for (int64_t b = 0; b < B; ++b) {
+        const Run &r = run[b];
+        for (int i = 0; i < P; ++i) theta[(size_t)b * P + i] = r.x[i];
+        std::memcpy(hess_inv + (size_t)b * P * P, r.H, sizeof(double) * P * P);
+        status[b] = r.status;
+        if (iters) iters[b] = r.k;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    return SSMQ_OK;
+}
+
+// objective of the marginalised filter: -log N(y_b | theta-conditioned step) - log N(theta | prior_b)   (ssinf.py:1153-1241)
+struct MarginalObjective : Evaluator {
+    ssmq_transform *h_dyn, *h_obs;
+    const ssmq_integrand *f_dyn, *f_obs;
+    int Din, D, Y, Pd, Po, P;
+    double jitter, time;
+    const double *mean, *cov, *y, *GQG, *R, *prior_mean;
+    std::vector<double> Lp, logdet2;                 // per trajectory: Cholesky factor of the prior covariance, 2 sum log diag
+    std::vector<double> pd, po, mm, cc, yy, ll, om, oc;
+    std::vector<int32_t> st;
+    // log N(theta | m, C) = -(v'v + 2 sum log diag L + P log 2 pi) / 2, v = L^-1 (theta - m)   (ssinf.py:1200-1218)
+    double log_prior(int64_t b, const double *th) const {
+        const double *L = &Lp[(size_t)b * P * P], *m = prior_mean + (size_t)b * P;
+        double v[kMaxPar], q = 0.0;
+        for (int i = 0; i < P; ++i) {
+            double s = th[i] - m[i];
+            for (int k = 0; k < i; ++k) s -= L[i * P + k] * v[k];
+            v[i] = s / L[i * P + i];
+            q += v[i] * v[i];
+        }
+        return -0.5 * (q + logdet2[(size_t)b] + P * std::log(2.0 * M_PI));
+    }
+    int eval(int64_t items, const int64_t *traj, const double *rows, double *vals) override {
+        pd.resize((size_t)items * Pd); po.resize((size_t)items * Po);
+        mm.resize((size_t)items * Din); cc.resize((size_t)items * Din * Din); yy.resize((size_t)items * Y);
+        ll.resize((size_t)items); om.resize((size_t)items * D); oc.resize((size_t)items * D * D); st.assign((size_t)items, 0);
+        for (int64_t it = 0; it < items; ++it) {
+            const int64_t b = traj[it];
+            for (int i = 0; i < P; ++i) {
+                const double e = std::exp(rows[(size_t)it * P + i]);        // the kernel parameters are exp(theta)
+                if (i < Pd) pd[(size_t)it * Pd + i] = e;
+                else po[(size_t)it * Po + (i - Pd)] = e;
+            }
+            std::memcpy(&mm[(size_t)it * Din], mean + (size_t)b * Din, sizeof(double) * Din);
+            std::memcpy(&cc[(size_t)it * Din * Din], cov + (size_t)b * Din * Din, sizeof(double) * Din * Din);
+            std::memcpy(&yy[(size_t)it * Y], y + (size_t)b * Y, sizeof(double) * Y);
+        }
+        const int rc = ssmq_gp_theta_step(h_dyn, f_dyn, h_obs, f_obs, items, pd.data(), po.data(), jitter, mm.data(), cc.data(), 0,
+                                          yy.data(), 0, time, GQG, R, om.data(), oc.data(), ll.data(), st.data());
+        if (rc < 0) return rc;          // argument / device error; rc > 0 only reports items that are not positive definite
+        for (int64_t it = 0; it < items; ++it) vals[it] = -ll[(size_t)it] - log_prior(traj[it], rows + (size_t)it * P);
+        return 0;
+    }
+};
+
+// a host function as the objective: the optimiser's restatement is pinned against scipy.optimize.minimize on the CPU with it
+struct CallbackObjective : Evaluator {
+    ssmq_objective_fn fn;
+    void *ctx;
+    int P;
+    int eval(int64_t items, const int64_t *traj, const double *rows, double *vals) override { return fn(ctx, items, P, traj, rows, vals); }
+};
+
+}  // namespace
+
+extern "C" int ssmq_bfgs_lockstep_host(ssmq_objective_fn fn, void *ctx, int64_t B, int P, double fd_step, double *theta,
+                                       double *hess_inv, int32_t *status, int32_t *iters, int64_t *rounds) {
+    if (!fn || B < 0 || P < 1 || P > kMaxPar || (B > 0 && (!theta || !hess_inv || !status))) {
+        set_error("bfgs_lockstep_host: bad argument");
+        return SSMQ_E_ARG;
+    }
+    for (int64_t b = 0; b < B; ++b) status[b] = 0;
+    CallbackObjective ev;
+    ev.fn = fn; ev.ctx = ctx; ev.P = P;
+    return bfgs_lockstep(B, P, fd_step, ev, theta, hess_inv, status, iters, rounds);
+}
+
+extern "C" int ssmq_gp_marginal_laplace_batch(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                              const ssmq_integrand *f_obs, int64_t B, double jitter, const double *mean,
+                                              const double *cov, const double *y, double time, const double *GQG, const double *R,
+                                              const double *prior_mean, const double *prior_cov, double fd_step, double *theta,
+                                              double *hess_inv, int32_t *status, int32_t *iters, int64_t *rounds_out) {
+    if (!h_dyn || !h_obs || !f_dyn || !f_obs || B < 0 || (B > 0 && (!mean || !cov || !y || !prior_mean || !prior_cov || !theta ||
+                                                                     !hess_inv || !status))) {
+        set_error("marginal_laplace_batch: null argument");
+        return SSMQ_E_ARG;
+    }
+    MarginalObjective ev;
+    ev.h_dyn = h_dyn; ev.h_obs = h_obs; ev.f_dyn = f_dyn; ev.f_obs = f_obs;
+    ev.Din = h_dyn->D; ev.D = h_dyn->E; ev.Y = h_obs->E; ev.Pd = ev.Din + 1; ev.Po = h_obs->D + 1; ev.P = ev.Pd + ev.Po;
+    ev.jitter = jitter; ev.time = time; ev.mean = mean; ev.cov = cov; ev.y = y; ev.GQG = GQG; ev.R = R; ev.prior_mean = prior_mean;
+    const int P = ev.P;
+    if (P > kMaxPar) {
+        set_error("marginal_laplace_batch: too many kernel parameters");
+        return SSMQ_E_UNSUPPORTED;
+    }
+    if (rounds_out) *rounds_out = 0;
+    if (B == 0) return SSMQ_OK;
+    ev.Lp.assign((size_t)B * P * P, 0.0);
+    ev.logdet2.assign((size_t)B, 0.0);
+    for (int64_t b = 0; b < B; ++b) {
+        const double *C = prior_cov + (size_t)b * P * P;
+        double *L = &ev.Lp[(size_t)b * P * P];
+        status[b] = 0;
+        for (int j = 0; j < P && status[b] == 0; ++j) {
+            double s = C[j * P + j];
+            for (int k = 0; k < j; ++k) s -= L[j * P + k] * L[j * P + k];
+            if (!(s > 0.0)) {           // numpy.linalg.cholesky would raise in _param_log_prior
+                status[b] = SSMQ_BFGS_PRIOR_NOT_PD;
+                break;
+            }
+            const double ljj = std::sqrt(s);
+            L[j * P + j] = ljj;
+            ev.logdet2[(size_t)b] += 2.0 * std::log(ljj);
+            for (int i = j + 1; i < P; ++i) {
+                double t = C[i * P + j];
+                for (int k = 0; k < j; ++k) t -= L[i * P + k] * L[j * P + k];
+                L[i * P + j] = t / ljj;
+            }
+        }
+    }
+    return bfgs_lockstep(B, P, fd_step, ev, theta, hess_inv, status, iters, rounds_out);
+}

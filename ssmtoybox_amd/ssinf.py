@@ -427,6 +427,10 @@ class MarginalInference(GaussianInference):
         st = getattr(self, '_theta_cache', None)
         if st is not None and st['key'] == key and np.array_equal(st['q_cov'], self.q_cov) and \
                 np.array_equal(st['rr'], self.r_cov) and np.array_equal(st['G'], self.G):
+            # the handles are asked for on every call: _handle_for returns early when nothing changed, re-uploads replaced
+            # points / I_out and follows a transform object that was re-assigned (research code assigns alg.tf_dyn / tf_obs and
+            # their attributes after construction - a cached pointer would go stale or dangle)
+            st['h_dyn'], st['h_obs'] = self.tf_dyn._handle_for(st['e_dyn']), self.tf_obs._handle_for(st['e_obs'])
             return st
         lib = _lib.load()
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
@@ -434,7 +438,7 @@ class MarginalInference(GaussianInference):
         vp = ctypes.c_void_p
         proto = ctypes.CFUNCTYPE(ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, vp, vp, ctypes.c_double, vp, vp, ctypes.c_int,
                                  vp, ctypes.c_int, ctypes.c_double, vp, vp, vp, vp, vp, vp)
-        st = dict(key=key, fn=proto(('ssmq_gp_theta_step', lib)), f_dyn=f_dyn, f_obs=f_obs,
+        st = dict(key=key, fn=proto(('ssmq_gp_theta_step', lib)), f_dyn=f_dyn, f_obs=f_obs, e_dyn=e_dyn, e_obs=e_obs,
                   pf_dyn=ctypes.addressof(f_dyn), pf_obs=ctypes.addressof(f_obs),
                   h_dyn=self.tf_dyn._handle_for(e_dyn), h_obs=self.tf_obs._handle_for(e_obs),
                   q_cov=np.array(self.q_cov, dtype=np.float64), G=np.array(self.G, dtype=np.float64),
@@ -586,8 +590,96 @@ class MarginalInference(GaussianInference):
         self.sm_mean, self.sm_cov = np.ascontiguousarray(sm), np.ascontiguousarray(sP)
         return self.sm_mean, self.sm_cov
 
+    def laplace_batch(self, mean, cov, y, time, prior_mean, prior_cov):
+        """The Laplace step (ssinf.py:1243-1273) of B trajectories at once: B BFGS runs in lock step, every round one
+        theta-batched device call (`ssmq_gp_marginal_laplace_batch`, csrc/ssmq_marginal.hip).  mean (B, D) / cov (B, D, D)
+        filtered moments, y (B, Y), prior_mean (B, P) / prior_cov (B, P, P).  Returns the posterior modes (B, P), the BFGS
+        inverse Hessians (B, P, P), status (B,), iterations (B,) and the number of device calls."""
+        c = self._theta_static()
+        lib = _lib.load()
+        mean, cov = self._augment(np.asarray(mean, dtype=np.float64), np.asarray(cov, dtype=np.float64))
+        mean, cov = np.ascontiguousarray(mean), np.ascontiguousarray(cov)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        B, P = mean.shape[0], self.param_dim
+        pm, pc = np.ascontiguousarray(prior_mean, dtype=np.float64), np.ascontiguousarray(prior_cov, dtype=np.float64)
+        theta = pm.copy()
+        hinv = np.empty((B, P, P))
+        st, it = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        rounds = ctypes.c_int64(0)
+        dp = lambda a: None if a is None else a.ctypes.data_as(_lib.c_double_p)       # noqa: E731
+        ip = lambda a: a.ctypes.data_as(_lib.c_int32_p)       # noqa: E731
+        _lib.check(lib.ssmq_gp_marginal_laplace_batch(c['h_dyn'], ctypes.byref(c['f_dyn']), c['h_obs'], ctypes.byref(c['f_obs']), B,
+                                                      float(self.tf_dyn.model.kernel.jitter), dp(mean), dp(cov), dp(y), float(time),
+                                                      dp(c['gqg']), dp(c['rr']), dp(pm), dp(pc), float(self.fd_step), dp(theta),
+                                                      dp(hinv), ip(st), ip(it), ctypes.byref(rounds)),
+                   'ssmq_gp_marginal_laplace_batch')
+        return theta, hinv, st, it, int(rounds.value)
+
     def forward_pass_batch(self, data, **kwargs):
-        """One trajectory after another: the Laplace step is a sequential host optimiser per trajectory."""
+        """data (dim_y, T, B) -> (D, T, B), (D, D, T, B): the Monte-Carlo loop around forward_pass (research/tpq/tpq_base.py:175-192;
+        every trajectory from the prior, as `reset()` leaves the filter) with ALL trajectories advanced together.  Per time step:
+        the Laplace step of every trajectory in lock step (`laplace_batch`: B x (param_dim + 1) theta items per device call), then the
+        marginalisation over the 2 param_dim parameter sigma points of every trajectory in ONE call (B x 2 param_dim items).
+        `batch_failed[b]` = the step at which trajectory b failed (where forward_pass raises LinAlgError), 0 otherwise; its
+        moments are NaN from that step on.  `batch_stats`: device rounds, BFGS iterations."""
+        data = np.asarray(data, dtype=np.float64)
+        Y, T, B = data.shape
+        D, P = self.mod_dyn.dim_state, self.param_dim
+        self.reset()
+        xm = np.tile(np.asarray(self.x0_mean, dtype=float), (B, 1))
+        xP = np.tile(np.asarray(self.x0_cov, dtype=float), (B, 1, 1))
+        pm = np.tile(self.param_prior_mean, (B, 1))
+        pc = np.tile(self.param_prior_cov, (B, 1, 1))
+        fm, fP = np.zeros((D, T, B)), np.zeros((D, D, T, B))
+        npts = self.param_pts_num
+        self.batch_stats = dict(rounds=0, fallbacks=0, iterations=0)
+        # failed[b] = step at which trajectory b left the batch (0: still in it).  Where the serial loop raises LinAlgError for a
+        # trajectory (a kernel matrix / covariance that is not positive definite at one of its parameter points), the batch keeps
+        # going: NaN moments from that step on, the trajectory parked on the prior so that it costs nothing further.
+        failed = np.zeros(B, dtype=np.int64)
+        pts = None
+        for k in range(1, T + 1):
+            y = np.ascontiguousarray(data[:, k - 1, :].T)
+            theta, hinv, st, it, rounds = self.laplace_batch(xm, xP, y, k, pm, pc)
+            self.batch_stats['rounds'] += rounds
+            self.batch_stats['iterations'] += int(it.sum())
+            for b in np.flatnonzero(st == _lib.BFGS_FALLBACK):
+                self.x_mean_fi, self.x_cov_fi, self.param_mean, self.param_cov = xm[b], xP[b], pm[b], pc[b]
+                self._param_posterior_moments(y[b], k)
+                theta[b], hinv[b] = self.param_mean, self.param_cov - self.param_jitter
+                self.batch_stats['fallbacks'] += 1
+            pm_new, pc_new = theta, hinv + self.param_jitter
+            bad = (st == _lib.BFGS_PRIOR_NOT_PD) | ~np.all(np.isfinite(pm_new), axis=1) | ~np.all(np.isfinite(pc_new), axis=(1, 2))
+            # a Laplace covariance that is not positive definite: numpy.linalg.cholesky would raise in _measurement_update
+            ok_c = np.all(np.linalg.eigvalsh(np.where(bad[:, None, None], np.eye(P), 0.5 * (pc_new + pc_new.transpose(0, 2, 1)))) > 0, axis=1)
+            bad |= ~ok_c
+            pm_new[bad], pc_new[bad] = self.param_prior_mean, self.param_prior_cov
+            pm, pc = pm_new, pc_new
+            chol = np.linalg.cholesky(pc)
+            pts = pm[:, :, None] + chol @ self.param_upts                      # (B, P, 2 P)
+            items = np.ascontiguousarray(pts.transpose(0, 2, 1)).reshape(B * npts, P)
+            m, c, _, sts = self.theta_step(items, np.repeat(xm, npts, axis=0), np.repeat(xP, npts, axis=0),
+                                           np.repeat(y, npts, axis=0), k)
+            bad |= sts.reshape(B, npts).any(axis=1)
+            xm = np.einsum('bjd,j->bd', m.reshape(B, npts, D), self.param_wts)
+            xP = np.einsum('bjde,j->bde', c.reshape(B, npts, D, D), self.param_wts)
+            bad |= ~np.all(np.isfinite(xm), axis=1) | ~np.all(np.isfinite(xP), axis=(1, 2))
+            newly = bad & (failed == 0)
+            failed[newly] = k
+            out = failed > 0
+            xm[out], xP[out] = self.x0_mean, self.x0_cov
+            pm[out], pc[out] = self.param_prior_mean, self.param_prior_cov
+            fm[:, k - 1, :], fP[:, :, k - 1, :] = xm.T, xP.transpose(1, 2, 0)
+            fm[:, k - 1, out], fP[:, :, k - 1, out] = np.nan, np.nan
+        self.batch_failed = failed
+        self.x_mean_fi, self.x_cov_fi, self.param_mean, self.param_cov = xm[-1], xP[-1], pm[-1], pc[-1]
+        self._last_theta = pts[-1, :, -1].copy() if pts is not None else None
+        self.fi_mean, self.fi_cov = fm, fP
+        return fm, fP
+
+    def forward_pass_serial(self, data, **kwargs):
+        """One trajectory after another, one SciPy BFGS run per trajectory and step: the reference's own loop
+        (research/tpq/tpq_base.py:175-192 around ssinf.py:66-118); kept as the yardstick of forward_pass_batch."""
         data = np.asarray(data, dtype=np.float64)
         out = []
         for b in range(data.shape[2]):
