@@ -787,14 +787,16 @@ def make_comm():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     backend = os.environ.get('SSMQ_BENCH_BACKEND', 'rccl')
     from ssmtoybox_amd import mcshard, _lib
-    ndev = max(_lib.device_count(), 1)
+    have = _lib.device_count()
+    ndev = max(have, 1)
     local_rank %= ndev
-    _lib.set_device(local_rank)
+    if have > 0:                                 # (none: the stand-in ranks of tests/test_rccl_stub.py on a machine without a GPU)
+        _lib.set_device(local_rank)
     launched = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
     if not launched:
         return mcshard.SingleComm(), 0, 1, local_rank
     why = ''
-    if backend != 'gloo' and world > ndev:
+    if backend != 'gloo' and world > ndev and os.environ.get('SSMQ_BENCH_FORCE_RCCL') != '1':
         # RCCL refuses two ranks on one device; every rank sees the same device count, so all of them take this branch
         backend, why = 'gloo', '{} ranks on {} device(s)'.format(world, ndev)
         if rank == 0:
@@ -808,6 +810,29 @@ def make_comm():
     comm = mcshard.open_comm(rank, world, force_rccl=os.environ.get('SSMQ_BENCH_FORCE_RCCL') == '1',
                              log=lambda m: sys.stderr.write(m + '\n'))
     return comm, rank, world, local_rank
+
+
+def final_aggregation(comm, rank, world, loc, lcr_sums_of, pass_ms_dev, B):
+    """What every rank does after its timed passes - the path's only collectives:
+    phase 1: this rank's per-time-step error sums `loc` (mcshard.device_error_sums: reduced on the device from the filter's
+    output buffers), ONE all-reduce of the packed buffer; phase 2: log credibility ratio against the GLOBAL per-step MSE matrix
+    (`lcr_sums_of(mse)` -> this rank's sums), a second all-reduce; then the per-rank launch times and trajectory counts (one
+    slot per rank, summed) and what the final collective costs: the packed phase-1 buffer all-reduced 20 times after a common
+    start (every rank takes part: collective calls).  Shared by main() and the stand-in ranks of tests/test_rccl_stub.py."""
+    from ssmtoybox_amd import mcshard
+    agg = mcshard.finalize(mcshard.allreduce_sums(loc, comm))
+    lcr = mcshard.finalize_lcr(mcshard.allreduce_sums(lcr_sums_of(agg['mse']), comm))
+    slot = np.zeros(2 * world)
+    slot[rank], slot[world + rank] = pass_ms_dev, B
+    slot = comm.allreduce_sum(slot)
+    n_packed = sum(int(np.asarray(v).size) for v in loc.values())
+    lat = []
+    comm.barrier()
+    for _ in range(20):
+        t1 = time.perf_counter()
+        comm.allreduce_sum(np.zeros(n_packed))
+        lat.append(time.perf_counter() - t1)
+    return dict(agg=agg, lcr=lcr, slot=slot, allreduce_us=float(np.median(lat)) * 1e6, n_packed=n_packed)
 
 
 def saturated_sweep(amd, T, batches, base_kernel, base_ms, base_B):
@@ -978,27 +1003,11 @@ def main():
     elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
 
     # final aggregation: per-time-step error sums -> RMSE / NLL (the path's only collective)
-    # phase 1: sums reduced on the device from the filter's output buffers, one all-reduce; phase 2: log credibility
-    # ratio against the GLOBAL per-step MSE matrix, a second all-reduce
-    loc = mcshard.device_error_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, wl.d_st)
-    agg = mcshard.finalize(mcshard.allreduce_sums(loc, comm))
-    lcr = mcshard.finalize_lcr(mcshard.allreduce_sums(
-        mcshard.device_lcr_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, agg['mse'], wl.d_st), comm))
+    fa = final_aggregation(
+        comm, rank, world, mcshard.device_error_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, wl.d_st),
+        lambda mse: mcshard.device_lcr_sums(wl.D, B, wl.ld, T, wl.d_x, wl.d_fm, wl.d_fP, mse, wl.d_st), pass_ms_dev, B)
+    agg, lcr, slot, allreduce_us, n_packed = fa['agg'], fa['lcr'], fa['slot'], fa['allreduce_us'], fa['n_packed']
     rmse, nll = agg['rmse_total'], float(agg['nll_avg'].mean())
-
-    # per-rank launch times (one slot per rank, summed), trajectories per rank, and what the final collective costs: the
-    # packed phase-1 buffer all-reduced 20 times after a common start (every rank takes part: collective calls)
-    slot = np.zeros(2 * world)
-    slot[rank], slot[world + rank] = pass_ms_dev, B
-    slot = comm.allreduce_sum(slot)
-    n_packed = sum(int(np.asarray(v).size) for v in loc.values())
-    lat = []
-    comm.barrier()
-    for _ in range(20):
-        t1 = time.perf_counter()
-        comm.allreduce_sum(np.zeros(n_packed))
-        lat.append(time.perf_counter() - t1)
-    allreduce_us = float(np.median(lat)) * 1e6
 
     out = None
     headline = args.workload == 'ungm' and args.filter == 'gpqkf'

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <unistd.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include "ssmq_host.h"
@@ -74,6 +75,15 @@ int nccl_fail(int rc, const char *what) {
     return SSMQ_E_HIP;
 }
 
+// SSMQ_COMM_HOST_STAGING=1: the buffers handed to ncclAllReduce are the caller's HOST arrays and no HIP call is made - for
+// the stand-in librccl of tests/test_rccl_stub.py (which reduces through files), so that everything around the collective -
+// id publication, ncclCommInitRank on every rank, op codes, barrier, destroy - runs on a machine without a GPU.  Never set it
+// with the real RCCL.
+bool host_staging() {
+    static const bool on = getenv("SSMQ_COMM_HOST_STAGING") && getenv("SSMQ_COMM_HOST_STAGING")[0] == '1';
+    return on;
+}
+
 int allreduce(double *buf, int64_t n, int op) {
     if (!buf || n < 0) {
         ssmq::set_error("ssmq_allreduce: bad argument");
@@ -85,6 +95,7 @@ int allreduce(double *buf, int64_t n, int op) {
         ssmq::set_error("ssmq_allreduce: ssmq_comm_init has not been called");
         return SSMQ_E_ARG;
     }
+    if (host_staging()) return nccl_fail(g_rccl.AllReduce(buf, buf, (size_t)n, kFloat64, op, g_comm, nullptr), "ncclAllReduce");
     int rc = ssmq::ensure_device();
     if (rc) return rc;
     hipStream_t s = ssmq::stream();
@@ -132,7 +143,7 @@ int ssmq_comm_init(int rank, int world, const char *id, int len) {
     g_rank = rank;
     g_world = world;
     if (world == 1 && !id) return SSMQ_OK;   // single process: every reduction is the identity, RCCL is not loaded
-    int rc = ssmq::ensure_device();           // the communicator binds to the calling thread's current device
+    int rc = host_staging() ? SSMQ_OK : ssmq::ensure_device();   // the communicator binds to the calling thread's current device
     if (rc) return rc;
     if ((rc = load_rccl())) return rc;
     UniqueId u;
@@ -165,16 +176,18 @@ int ssmq_allreduce_max(double *buf, int64_t n) { return allreduce(buf, n, kMax);
 
 int ssmq_comm_barrier(void) {
     double one = 1.0;
-    int rc = ssmq::ensure_device();
-    if (rc) return rc;
-    SSMQ_HIP(hipStreamSynchronize(ssmq::stream()));
+    if (!host_staging()) {
+        int rc = ssmq::ensure_device();
+        if (rc) return rc;
+        SSMQ_HIP(hipStreamSynchronize(ssmq::stream()));
+    }
     return allreduce(&one, 1, kSum);
 }
 
 int ssmq_comm_destroy(void) {
     int rc = SSMQ_OK;
     if (g_comm) {
-        hipStreamSynchronize(ssmq::stream());
+        if (!host_staging()) hipStreamSynchronize(ssmq::stream());
         rc = nccl_fail(g_rccl.CommDestroy(g_comm), "ncclCommDestroy");
         g_comm = nullptr;
     }
