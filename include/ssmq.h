@@ -17,9 +17,13 @@
  *     (the reference raises numpy.linalg.LinAlgError there: bq/bqmtran.py:98, mtran.py:139); < 0 error
  *     (SSMQ_E_*); ssmq_last_error() gives the text.  No exception crosses the ABI.
  *   - a transform handle is bound to the device that was current when it was created.  The library keeps process-global
- *     state - one HIP stream, grow-only workspaces and pinned staging blocks, a cached launch graph, the communicator -
- *     so calls must come from ONE thread at a time (one process per GPU is the intended deployment); the caches are
- *     dropped when ssmq_set_device() selects another device.
+ *     state - one HIP stream, grow-only workspaces and pinned staging blocks, cached launch graphs, the communicator.
+ *     Threads: every compute entry point takes one process-wide (recursive) lock for its duration, so calls from several
+ *     threads - on the same handle or on different ones - are safe and run one after the other; the *_dev entry points stay
+ *     asynchronous with respect to the device (they queue on the library's stream and return).  The ssmq_comm_* entry points
+ *     are outside that lock and belong to one thread.  One process per GPU is the intended deployment; a
+ *     process that drives several devices does so one call at a time through ssmq_set_device(), which drops the caches of the
+ *     device it leaves.
  *   - there is NO CPU fallback anywhere behind this ABI: without a usable gfx950 device every compute entry point
  *     returns SSMQ_E_HIP.
  */

@@ -20,6 +20,11 @@ static int g_stream_dev = -1;
 
 void set_error(const std::string &msg) { g_err = msg; }
 
+std::recursive_mutex &api_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
 int hip_fail(hipError_t e, const char *what) {
     if (e == hipSuccess) return SSMQ_OK;
     set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -305,12 +310,16 @@ static int upload_consts(ssmq_transform *h) {
                 if (with_wcc)
                     for (int d = 0; d < D; ++d) at(i, 16 * kb + d) = h->Wcc[(size_t)d * N + i];
             }
+            // on the library's stream, as every other upload of this function: a transform queued there (the entry points ending
+            // in _dev are asynchronous) may still be reading the old blocks
             if (*dst && (h->big_kb != kb || h->big_ncb != ncb)) {
+                SSMQ_HIP(hipStreamSynchronize(stream()));
                 hipFree(*dst);
                 *dst = nullptr;
             }
             if (!*dst) SSMQ_HIP(hipMalloc(dst, sizeof(double) * total));
-            SSMQ_HIP(hipMemcpy(*dst, blk.data(), sizeof(double) * total, hipMemcpyHostToDevice));
+            SSMQ_HIP(hipMemcpyAsync(*dst, blk.data(), sizeof(double) * total, hipMemcpyHostToDevice, stream()));
+            SSMQ_HIP(hipStreamSynchronize(stream()));   // blk goes out of scope
             return SSMQ_OK;
         };
         int rcp = pack(h->Wc, &h->d_wc_blk, true);
@@ -452,7 +461,9 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
                           bq_stream_supported(h->D, h->E, h->N);
     const bool one_launch = !se && !big && h->form == SSMQ_FORM_BQ && h->d_wc_pad && h->d_sx_pad && h->tp_nu <= 0.0 &&
                             b_route * h->E >= kGemmMinRows && bq_fused_supported(h->D, h->E, h->N);
-    if (kernel_name) *kernel_name = se ? se->name : streamed ? "k_bq_stream" : big ? "k_apply_big" : one_launch ? "k_bq_fused" : (wide_full_uses_tile(h->D, h->E, h->N) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
+    if (kernel_name) *kernel_name = se ? se->name : streamed ? "k_bq_stream" : big ? "k_apply_big" : one_launch ? "k_bq_fused" : ((wide_full_uses_tile(h->D, h->E, h->N) && tile_ld_ok(dry_run ? 0 : ld)) ? "k_apply_tile" : wide_full_uses_wave(h->D, h->E, h->N) ? "k_apply_wave" : "k_apply_wide");
+    // (the same two conditions launch_apply_wide tests - tile_pitch_ok there, with unit batch strides as set below; the name
+    // query has no batch and reports the route of planes shorter than 2^29 doubles)
     if (dry_run) return SSMQ_OK;
     if (B <= 0) return SSMQ_OK;
     if (!d_mean || !d_cov || !d_mean_f || !d_cov_f || !d_cov_fx || !d_status || (fi.uses_time && !d_time) ||
@@ -626,6 +637,7 @@ int ssmq_version(void) { return SSMQ_VERSION; }
 const char *ssmq_last_error(void) { return g_err.c_str(); }
 
 int ssmq_device_count(int *n) {
+    SSMQ_API_LOCK();
     if (!n) return SSMQ_E_ARG;
     *n = 0;
     hipError_t e = hipGetDeviceCount(n);
@@ -636,14 +648,17 @@ int ssmq_device_count(int *n) {
     return SSMQ_OK;
 }
 int ssmq_set_device(int device) {
+    SSMQ_API_LOCK();
     SSMQ_HIP(hipSetDevice(device));
     return ensure_device();
 }
 int ssmq_current_device(void) {
+    SSMQ_API_LOCK();
     if (ensure_device()) return -1;
     return g_stream_dev;
 }
 int ssmq_device_name(char *buf, int len) {
+    SSMQ_API_LOCK();
     if (!buf || len <= 0) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -656,6 +671,7 @@ int ssmq_device_name(char *buf, int len) {
 }
 
 int ssmq_malloc(void **dptr, size_t bytes) {
+    SSMQ_API_LOCK();
     if (!dptr) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -663,11 +679,13 @@ int ssmq_malloc(void **dptr, size_t bytes) {
     return SSMQ_OK;
 }
 int ssmq_free(void *dptr) {
+    SSMQ_API_LOCK();
     if (!dptr) return SSMQ_OK;
     SSMQ_HIP(hipFree(dptr));
     return SSMQ_OK;
 }
 int ssmq_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream()));
@@ -675,6 +693,7 @@ int ssmq_memcpy_h2d(void *dst, const void *src, size_t bytes) {
     return SSMQ_OK;
 }
 int ssmq_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream()));
@@ -682,18 +701,21 @@ int ssmq_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     return SSMQ_OK;
 }
 int ssmq_memcpy_d2d(void *dst, const void *src, size_t bytes) {
+    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream()));
     return SSMQ_OK;
 }
 int ssmq_memset(void *dptr, int value, size_t bytes) {
+    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipMemsetAsync(dptr, value, bytes, stream()));
     return SSMQ_OK;
 }
 int ssmq_sync(void) {
+    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipStreamSynchronize(stream()));
@@ -701,6 +723,7 @@ int ssmq_sync(void) {
 }
 
 int ssmq_aos_to_soa(const double *d_aos, double *d_soa, int n, int64_t B, int64_t ld) {
+    SSMQ_API_LOCK();
     if (!d_aos || !d_soa || n <= 0 || B < 0 || ld < B) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -710,6 +733,7 @@ int ssmq_aos_to_soa(const double *d_aos, double *d_soa, int n, int64_t B, int64_
     return hip_fail(hipGetLastError(), "k_aos_to_soa");
 }
 int ssmq_soa_to_aos(const double *d_soa, double *d_aos, int n, int64_t B, int64_t ld) {
+    SSMQ_API_LOCK();
     if (!d_aos || !d_soa || n <= 0 || B < 0 || ld < B) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -720,6 +744,7 @@ int ssmq_soa_to_aos(const double *d_soa, double *d_aos, int n, int64_t B, int64_
 }
 
 int ssmq_event_create(void **ev) {
+    SSMQ_API_LOCK();
     if (!ev) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -729,16 +754,19 @@ int ssmq_event_create(void **ev) {
     return SSMQ_OK;
 }
 int ssmq_event_destroy(void *ev) {
+    SSMQ_API_LOCK();
     if (!ev) return SSMQ_OK;
     SSMQ_HIP(hipEventDestroy((hipEvent_t)ev));
     return SSMQ_OK;
 }
 int ssmq_event_record(void *ev) {
+    SSMQ_API_LOCK();
     if (!ev) return SSMQ_E_ARG;
     SSMQ_HIP(hipEventRecord((hipEvent_t)ev, stream()));
     return SSMQ_OK;
 }
 int ssmq_event_elapsed_ms(void *start, void *stop, float *ms) {
+    SSMQ_API_LOCK();
     if (!start || !stop || !ms) return SSMQ_E_ARG;
     SSMQ_HIP(hipEventSynchronize((hipEvent_t)stop));
     SSMQ_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
@@ -746,6 +774,7 @@ int ssmq_event_elapsed_ms(void *start, void *stop, float *ms) {
 }
 
 int ssmq_status_first(const int32_t *d_status, int64_t B, int64_t *first) {
+    SSMQ_API_LOCK();
     if (!d_status || !first || B < 0) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -800,6 +829,7 @@ ssmq_transform *ssmq_transform_create(int D, int E, int N, int form, const doubl
 
 int ssmq_transform_update(ssmq_transform *h, const double *xi, const double *wm, const double *Wc, const double *Wcc,
                           const double *emv, int emv_mode, double tp_nu, const double *tp_iK) {
+    SSMQ_API_LOCK();
     if (!h) return SSMQ_E_ARG;
     const int D = h->D, E = h->E, N = h->N;
     if (xi) h->xi.assign(xi, xi + D * N);
@@ -820,6 +850,7 @@ int ssmq_transform_update(ssmq_transform *h, const double *xi, const double *wm,
 }
 
 void ssmq_transform_destroy(ssmq_transform *h) {
+    SSMQ_API_LOCK();
     if (!h) return;
     if (h->d_small) hipFree(h->d_small);
     if (h->d_wide) hipFree(h->d_wide);
@@ -833,6 +864,7 @@ void ssmq_transform_destroy(ssmq_transform *h) {
 }
 
 int ssmq_transform_dims(const ssmq_transform *h, int *D, int *E, int *N) {
+    SSMQ_API_LOCK();
     if (!h) return SSMQ_E_ARG;
     if (D) *D = h->D;
     if (E) *E = h->E;
@@ -844,6 +876,7 @@ int ssmq_transform_dims(const ssmq_transform *h, int *D, int *E, int *N) {
 int ssmq_apply_batch_dev(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
                          const double *d_cov, const double *d_time, int time_stride, double *d_mean_f,
                          double *d_cov_f, double *d_cov_fx, int32_t *d_status) {
+    SSMQ_API_LOCK();
     if (!h || !f) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -852,6 +885,7 @@ int ssmq_apply_batch_dev(ssmq_transform *h, const ssmq_integrand *f, int64_t B, 
 }
 
 int ssmq_apply_kernel_name(const ssmq_transform *h, const ssmq_integrand *f, char *buf, int len) {
+    SSMQ_API_LOCK();
     if (!h || !f || !buf || len <= 0) return SSMQ_E_ARG;
     const char *name = nullptr;
     int rc = apply_dev_impl(const_cast<ssmq_transform *>(h), f, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
@@ -904,6 +938,7 @@ constexpr size_t kPlaneChunkBytes = size_t(128) << 20;
 }  // namespace
 
 int ssmq_upload_planes(const double *host, int n_outer, int n_elem, int64_t B, int64_t ld, double *d_planes) {
+    SSMQ_API_LOCK();
     if (!host || !d_planes || n_outer < 0 || n_elem < 1 || B < 0 || ld < B) {
         set_error("upload_planes: bad argument");
         return SSMQ_E_ARG;
@@ -925,6 +960,7 @@ int ssmq_upload_planes(const double *host, int n_outer, int n_elem, int64_t B, i
 }
 
 int ssmq_download_planes(const double *d_planes, int n_outer, int n_elem, int64_t B, int64_t ld, double *host) {
+    SSMQ_API_LOCK();
     if (!host || !d_planes || n_outer < 0 || n_elem < 1 || B < 0 || ld < B) {
         set_error("download_planes: bad argument");
         return SSMQ_E_ARG;
@@ -948,6 +984,7 @@ int ssmq_download_planes(const double *d_planes, int n_outer, int n_elem, int64_
 int ssmq_apply_batch(ssmq_transform *h, const ssmq_integrand *f, int64_t B, const double *mean, const double *cov,
                      const double *time, int time_stride, double *mean_f, double *cov_f, double *cov_fx,
                      int32_t *status) {
+    SSMQ_API_LOCK();
     if (!h || !f || B < 0 || !mean || !cov || !mean_f || !cov_f || !cov_fx) {
         set_error("apply_batch: null argument");
         return SSMQ_E_ARG;
@@ -1042,6 +1079,7 @@ int ssmq_apply_batch(ssmq_transform *h, const ssmq_integrand *f, int64_t B, cons
 
 int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, const double *cov, double *x,
                             double *chol, int32_t *status) {
+    SSMQ_API_LOCK();
     if (!h || B < 0 || !mean || !cov || !x || !chol) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -1084,6 +1122,7 @@ int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, co
 
 int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const double *mean, const double *x,
                         const double *fx, double *mean_f, double *cov_f, double *cov_fx) {
+    SSMQ_API_LOCK();
     if (!h || B < 0 || !chol || !fx || !mean_f || !cov_f || !cov_fx) return SSMQ_E_ARG;
     if (h->form == SSMQ_FORM_SIGMA && (!mean || !x)) {
         set_error("apply_fx_batch: the centred form needs mean and x");
@@ -1189,6 +1228,7 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
 // T = FX Wc on the matrix cores for device-resident integrand values (the GEMM-shaped stage of a large-N BQ transform)
 int ssmq_fxwc_batch_dev(ssmq_transform *h, int64_t M, const double *d_fx, int64_t ld_fx, double *d_t, int64_t ld_t,
                         int *n_padded) {
+    SSMQ_API_LOCK();
     if (!h || M < 0 || (M > 0 && (!d_fx || !d_t))) {
         set_error("fxwc_batch: bad argument");
         return SSMQ_E_ARG;
@@ -1212,6 +1252,7 @@ int ssmq_fxwc_batch_dev(ssmq_transform *h, int64_t M, const double *d_fx, int64_
 int ssmq_kalman_update_dev(int D, int Y, int64_t B, int64_t ld, const double *d_m_pr, const double *d_P_pr,
                            const double *d_y_mean, const double *d_P_y, const double *d_P_yx, const double *d_y,
                            double *d_m_fi, double *d_P_fi, int32_t *d_status) {
+    SSMQ_API_LOCK();
     if (D < 1 || Y < 1 || B < 0 || ld < B || !d_m_pr || !d_P_pr || !d_y_mean || !d_P_y || !d_P_yx || !d_y || !d_m_fi ||
         !d_P_fi || !d_status)
         return SSMQ_E_ARG;
@@ -1471,6 +1512,7 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
                                        const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                                        const double *d_m0, const double *d_P0, const double *GQG, const double *R,
                                        double *d_fm, double *d_fP, int32_t *d_status) {
+    SSMQ_API_LOCK();
     return filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, GQG, R, d_fm, d_fP, d_status,
                                nullptr, 0.0);
 }
@@ -1630,6 +1672,7 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
                                            const double *q_mean, const double *q_cov, int dq, const double *r_mean,
                                            const double *r_cov, int dr, double *d_fm, double *d_fP,
                                            int32_t *d_status) {
+    SSMQ_API_LOCK();
     return filter_forward_aug_impl(h_dyn, f_dyn, h_obs, f_obs, dim_state, B, ld, T, d_y, d_m0, d_P0, q_mean, q_cov, dq,
                                    r_mean, r_cov, dr, d_fm, d_fP, d_status, nullptr, nullptr, nullptr, nullptr);
 }
@@ -1649,6 +1692,7 @@ extern "C" int ssmq_filter_smooth_aug_dev(ssmq_transform *h_dyn, const ssmq_inte
                                           const double *q_mean, const double *q_cov, int dq, const double *r_mean,
                                           const double *r_cov, int dr, double *d_fm, double *d_fP, double *d_sm,
                                           double *d_sP, int32_t *d_status) {
+    SSMQ_API_LOCK();
     if (!h_dyn || !d_sm || !d_sP || dim_state <= 0 || dq < 0 || B < 0 || T < 0 || ld < B) {
         set_error("filter_smooth_aug: bad argument");
         return SSMQ_E_ARG;
@@ -1680,6 +1724,7 @@ extern "C" int ssmq_filter_smooth_aug_dev(ssmq_transform *h_dyn, const ssmq_inte
 extern "C" int ssmq_rts_backward_dev(int D, int64_t B, int64_t ld, int T, const double *d_fm, const double *d_fP,
                                      const double *d_pm, const double *d_pP, const double *d_pC, double *d_sm, double *d_sP,
                                      int32_t *d_status) {
+    SSMQ_API_LOCK();
     if (D < 1 || B < 0 || T < 0 || ld < B || !d_fm || !d_fP || !d_pm || !d_pP || !d_pC || !d_sm || !d_sP || !d_status) {
         set_error("rts_backward: bad argument");
         return SSMQ_E_ARG;
@@ -1698,6 +1743,7 @@ extern "C" int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integran
                                       const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                                       const double *d_m0, const double *d_P0, const double *GQG, const double *R,
                                       double *d_fm, double *d_fP, double *d_sm, double *d_sP, int32_t *d_status) {
+    SSMQ_API_LOCK();
     if (!h_dyn || !d_sm || !d_sP || B < 0 || T < 0 || ld < B) {
         set_error("filter_smooth: bad argument");
         return SSMQ_E_ARG;
@@ -1735,6 +1781,7 @@ extern "C" int ssmq_student_filter_forward_dev(ssmq_transform *h_dyn, const ssmq
                                                const double *d_S0, const double *GqG, const double *r_smat,
                                                const double *scale, double dof, double *d_fm, double *d_fP,
                                                int32_t *d_status) {
+    SSMQ_API_LOCK();
     if (!scale || !(dof > 0.0)) {
         set_error("student_filter_forward: scale[T] and dof > 0 are required");
         return SSMQ_E_ARG;
@@ -1811,11 +1858,13 @@ extern "C" int ssmq_error_sums_width(int D) { return D >= 1 && D <= SSMQ_MAX_DIM
 
 extern "C" int ssmq_error_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm,
                                    const double *d_fP, const int32_t *d_status, double *sums) {
+    SSMQ_API_LOCK();
     return metrics_impl(1, D, B, ld, T, d_x, d_fm, d_fP, d_status, nullptr, sums);
 }
 
 extern "C" int ssmq_lcr_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm,
                                  const double *d_fP, const int32_t *d_status, const double *mse, double *sums) {
+    SSMQ_API_LOCK();
     return metrics_impl(2, D, B, ld, T, d_x, d_fm, d_fP, d_status, mse, sums);
 }
 
@@ -1863,6 +1912,7 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
                                   double jitter, const double *mean, const double *cov, int shared_state,
                                   const double *y, int shared_y, double time, const double *GQG, const double *R,
                                   double *post_mean, double *post_cov, double *loglik, int32_t *status) {
+    SSMQ_API_LOCK();
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || P < 0 || P > 0x7fffffff || !par_dyn || !par_obs || !mean || !cov || !y ||
         !post_mean || !post_cov || !loglik) {
         set_error("gp_theta_step: bad argument");
@@ -2012,9 +2062,17 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
         memcpy(&jb, &jitter, sizeof(jb));
         key.push_back(jb);
         for (const ssmq_integrand *f : {f_dyn, f_obs}) {
-            const unsigned char *pb = (const unsigned char *)f;
+            // what the kernels read of the descriptor: id, counts and the USED parameter / index slots (not the padding or the
+            // unused tail, which a caller may leave uninitialised: every call would then look like a new graph)
             uint64_t hsh = 1469598103934665603ull;
-            for (size_t i = 0; i < sizeof(ssmq_integrand); ++i) hsh = (hsh ^ pb[i]) * 1099511628211ull;
+            auto mix = [&](const void *p, size_t n) {
+                const unsigned char *pb = (const unsigned char *)p;
+                for (size_t i = 0; i < n; ++i) hsh = (hsh ^ pb[i]) * 1099511628211ull;
+            };
+            const int np_ = f->n_par < 0 ? 0 : (f->n_par > SSMQ_MAX_FPAR ? SSMQ_MAX_FPAR : f->n_par);
+            const int ni_ = f->n_idx < 0 ? 0 : (f->n_idx > SSMQ_MAX_FIDX ? SSMQ_MAX_FIDX : f->n_idx);
+            mix(&f->id, sizeof(f->id)); mix(&f->n_par, sizeof(f->n_par)); mix(&f->n_idx, sizeof(f->n_idx));
+            mix(f->par, sizeof(f->par[0]) * np_); mix(f->idx, sizeof(f->idx[0]) * ni_);
             key.push_back(hsh);
         }
         ThetaGraph *tg = nullptr;
@@ -2023,7 +2081,11 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
         if (two_launch || getenv("SSMQ_NO_THETA_GRAPH")) {   // two launches + two copies: replay measured no faster (52 us either way)
             if ((rc = enqueue())) return rc;
         } else if (!tg) {
-            if (g_theta_graphs.size() >= 6) drop_theta_graphs();
+            if (g_theta_graphs.size() >= 6) {       // the oldest entry goes, not all of them (a filter alternates between two item counts)
+                if (g_theta_graphs.front().exec) hipGraphExecDestroy(g_theta_graphs.front().exec);
+                if (g_theta_graphs.front().graph) hipGraphDestroy(g_theta_graphs.front().graph);
+                g_theta_graphs.erase(g_theta_graphs.begin());
+            }
             g_theta_graphs.push_back(ThetaGraph{key, nullptr, nullptr});
             if ((rc = enqueue())) return rc;
         } else {
@@ -2069,6 +2131,7 @@ extern "C" int ssmq_simulate_rv_dev(const ssmq_integrand *f_dyn, const ssmq_inte
                                     const ssmq_rv *q, const ssmq_rv *r, const double *G, int dyn_additive, int obs_additive,
                                     int64_t B, int64_t ld, int T, int continuous, double dt, uint64_t seed,
                                     uint64_t traj_offset, double *d_x, double *d_y) {
+    SSMQ_API_LOCK();
     const int mode = (f_dyn ? 1 : 0) | (f_obs ? 2 : 0);
     auto rv_ok = [](const ssmq_rv *v, int dim) {
         return v && v->dim == dim && v->chol && v->kind >= SSMQ_RV_GAUSS && v->kind <= SSMQ_RV_MIXTURE &&
@@ -2160,6 +2223,7 @@ extern "C" int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integra
                                  const double *x0_mean, const double *x0_chol, const double *q_mean,
                                  const double *q_chol, const double *G, const double *r_mean, const double *r_chol,
                                  uint64_t seed, uint64_t traj_offset, double *d_x, double *d_y) {
+    SSMQ_API_LOCK();
     ssmq_rv x0{SSMQ_RV_GAUSS, D, 1, 0, 0.0, x0_mean, x0_chol, nullptr};
     ssmq_rv q{SSMQ_RV_GAUSS, dq, 1, 0, 0.0, q_mean, q_chol, nullptr};
     ssmq_rv r{SSMQ_RV_GAUSS, dr, 1, 0, 0.0, r_mean, r_chol, nullptr};
@@ -2173,6 +2237,7 @@ extern "C" int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integra
 
 extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,
                                        const ssmq_transform *h_obs, const ssmq_integrand *f_obs, char *buf, int len) {
+    SSMQ_API_LOCK();
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || !buf || len <= 0) return SSMQ_E_ARG;
     FInfo fio;
     if (!integrand_info(f_obs->id, &fio)) return SSMQ_E_ARG;

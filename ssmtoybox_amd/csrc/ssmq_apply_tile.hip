@@ -417,7 +417,7 @@ bool wide_full_uses_tile(int D, int E, int N) {
 // plane pitches must fit 32 bits in bytes (the kernel forms addresses as 32 x 32 -> 64-bit products)
 // ... and consecutive trajectories must be consecutive doubles of a plane (the library's batch layout)
 bool tile_pitch_ok(const WideArgs &a) {
-    return a.es_in < ((int64_t)1 << 29) && a.es_out < ((int64_t)1 << 29) && a.bs_mean == 1 && a.bs_cov == 1 && a.bs_mf == 1 &&
+    return tile_ld_ok(a.es_in) && tile_ld_ok(a.es_out) && a.bs_mean == 1 && a.bs_cov == 1 && a.bs_mf == 1 &&
            a.bs_cf == 1 && a.bs_cfx == 1;
 }
 

@@ -1,6 +1,7 @@
 // Host-side internals of libssmq shared between translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "ssmq_device.h"
@@ -34,6 +35,13 @@ struct ssmq_transform {
 namespace ssmq {
 
 void set_error(const std::string &msg);
+// The library's state is process-global (one stream, grow-only workspaces, staging blocks, graph caches): every compute entry
+// point of the C ABI holds this lock for its duration, so calls from several threads - on the same or on different handles -
+// are safe and run one after the other.  Recursive: entry points call each other (ssmq_gp_marginal_laplace_batch ->
+// ssmq_gp_theta_step).  The communicator entry points (ssmq_comm_*) do not take it: ncclCommInitRank may block for good on a
+// helper thread (mcshard.RcclComm) and must not take the rest of the library with it.
+std::recursive_mutex &api_mutex();
+#define SSMQ_API_LOCK() std::lock_guard<std::recursive_mutex> ssmq_api_lock_guard_(ssmq::api_mutex())
 int hip_fail(hipError_t e, const char *what);
 hipStream_t stream();
 int ensure_device();

@@ -549,6 +549,7 @@ extern "C" int ssmq_gp_marginal_laplace_batch(ssmq_transform *h_dyn, const ssmq_
                                               const double *cov, const double *y, double time, const double *GQG, const double *R,
                                               const double *prior_mean, const double *prior_cov, double fd_step, double *theta,
                                               double *hess_inv, int32_t *status, int32_t *iters, int64_t *rounds_out) {
+    SSMQ_API_LOCK();
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || B < 0 || (B > 0 && (!mean || !cov || !y || !prior_mean || !prior_cov || !theta ||
                                                                      !hess_inv || !status))) {
         set_error("marginal_laplace_batch: null argument");

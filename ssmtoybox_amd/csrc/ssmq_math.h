@@ -7,7 +7,8 @@
 //
 //   sincos_nr   three-term Cody-Waite reduction by pi/2 (FMA), fdlibm kernel polynomials (degree 13 / 14).  Within 2.5 ulp
 //               of libm for |x| <= 1e5; absolute error below 1e-12 up to |x| = 1e9 (tests/test_math_sequences.py); angles
-//               beyond 2^31 pi/2 (a state no filter recovers from) come out as garbage.  NaN / inf -> NaN as libm.
+//               beyond 2^30 (a state no filter recovers from) give NaN - and with it a status flag at the next
+//               factorisation - where libm returns a value.  NaN / inf -> NaN as libm.
 //   atan2_nr    ONE division - (mn - mx) / (mn + mx) beyond tan(pi/8) - and fdlibm's 11-coefficient polynomial on
 //               |t| <= 0.4375.  Within 2 ulp of libm for |x| + |y| in [1e-290, 1e290]; atan2(+-0, +-0) as libm (0 or pi);
 //               NaN -> NaN; an INFINITE operand gives NaN where libm returns a multiple of pi/4.
@@ -39,6 +40,9 @@ SSMQ_HD double div_seeded(double a, double b) {
 }
 
 SSMQ_HD void sincos_nr(double x, double *sn, double *cs) {
+    // beyond 2^30 (and for NaN / inf) the result is NaN, not the garbage of an overflowed quadrant count: a diverged state then
+    // shows up as a failed factorisation at the next step (status flag) instead of as a plausible-looking number
+    x = fabs(x) <= 1073741824.0 ? x : NAN;
     // n = nearest integer to x 2 / pi; r = x - n pi/2 in three pieces of pi/2 (33 + 33 + 53 bits: fdlibm's pio2_1, pio2_2, pio2_2t)
     const double n = rint(x * 6.36619772367581382433e-01);
     double r = fma(-n, 1.57079632673412561417e+00, x);
@@ -60,7 +64,7 @@ SSMQ_HD void sincos_nr(double x, double *sn, double *cs) {
     pc = fma(pc, z, -1.38888888888741095749e-03);
     pc = fma(pc, z, 4.16666666666666019037e-02);
     const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
-    const int q = (int)n;
+    const int q = (int)(n == n ? n : 0.0);       // (the conversion of a NaN is undefined in C)
     const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
     *sn = (q & 2) ? -s1 : s1;
     *cs = ((q + 1) & 2) ? -c1 : c1;

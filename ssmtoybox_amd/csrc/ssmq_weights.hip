@@ -1182,6 +1182,7 @@ static bool rbf_args_ok(int D, int N, const double *x, const double *par, int P)
 
 extern "C" int ssmq_rbf_eval(int D, int N1, const double *x1, int N2, const double *x2, const double *par, int P,
                              int scaling, int diag, double *K) {
+    SSMQ_API_LOCK();
     using namespace ssmq;
     if (!x2) { x2 = x1; N2 = N1; }
     if (!rbf_args_ok(D, N1, x1, par, P) || N2 < 1 || N2 > SSMQ_MAX_PTS || !K || (diag && N1 != N2)) {
@@ -1210,6 +1211,7 @@ extern "C" int ssmq_rbf_eval(int D, int N1, const double *x1, int N2, const doub
 
 extern "C" int ssmq_rbf_factor(int D, int N, const double *x, const double *par, int P, int scaling, double jitter,
                                const double *rhs, double *chol, double *iK, int32_t *status) {
+    SSMQ_API_LOCK();
     using namespace ssmq;
     if (!rbf_args_ok(D, N, x, par, P) || (!chol && !iK)) {
         set_error("rbf_factor: bad argument");
@@ -1250,6 +1252,7 @@ extern "C" int ssmq_rbf_factor(int D, int N, const double *x, const double *par,
 
 extern "C" int ssmq_rbf_exp_kxkx(int D, int N, const double *x, const double *par0, const double *par1, int scaling,
                                  double *Q) {
+    SSMQ_API_LOCK();
     using namespace ssmq;
     if (!rbf_args_ok(D, N, x, par0, 1) || !par1 || !Q) {
         set_error("rbf_exp_kxkx: bad argument");
@@ -1289,6 +1292,7 @@ __global__ void k_bs_moments(int D, int N, int NB, const double *__restrict__ x,
 
 extern "C" int ssmq_bs_moments(int D, int N, const double *x, const double *par, const int32_t *mulind, int NB, double *px,
                                double *xpx, double *pxpx, double *kxpx, double *vand) {
+    SSMQ_API_LOCK();
     using namespace ssmq;
     if (D < 1 || D > SSMQ_MAX_DIM || NB < 1 || !mulind || N < 0 || ((kxpx || vand) && (!x || N < 1)) || (kxpx && !par)) {
         set_error("bs_moments: bad argument");
@@ -1332,6 +1336,7 @@ extern "C" int ssmq_bs_moments(int D, int N, const double *x, const double *par,
 extern "C" int ssmq_weights_gp(int D, int N, const double *xi, const double *par, int P, double jitter, double *wm,
                                double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R, double *model_var,
                                double *integral_var, int32_t *status) {
+    SSMQ_API_LOCK();
     return ssmq::weights_impl(0, D, N, xi, par, P, jitter, nullptr, 0, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var,
                               status);
 }
@@ -1342,6 +1347,7 @@ extern "C" int ssmq_weights_gp(int D, int N, const double *xi, const double *par
 extern "C" int ssmq_weights_tp(int D, int N, const double *xi, const double *par, int P, double jitter, double *wm,
                                double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R, double *model_var,
                                double *integral_var, int32_t *status) {
+    SSMQ_API_LOCK();
     return ssmq_weights_gp(D, N, xi, par, P, jitter, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var, status);
 }
 
@@ -1349,6 +1355,7 @@ extern "C" int ssmq_weights_bs(int D, int N, const double *xi, const double *par
                                const int32_t *mulind, int NB, double *wm, double *Wc, double *Wcc, double *iK,
                                double *q, double *Q, double *R, double *model_var, double *integral_var,
                                int32_t *status) {
+    SSMQ_API_LOCK();
     if (NB < 1) {
         ssmq::set_error("weights_bs: NB must be >= 1");
         return SSMQ_E_ARG;
@@ -1360,6 +1367,7 @@ extern "C" int ssmq_weights_bs(int D, int N, const double *xi, const double *par
 extern "C" int ssmq_variances_bs(int D, int N, const double *xi, const double *par, int P, double jitter,
                                  const int32_t *mulind, int NB, double *model_var, double *integral_var,
                                  int32_t *status) {
+    SSMQ_API_LOCK();
     if (NB < 1) {
         ssmq::set_error("variances_bs: NB must be >= 1");
         return SSMQ_E_ARG;

@@ -62,6 +62,8 @@ bool wide_full_uses_wave(int D, int E, int N);
 bool wide_full_uses_tile(int D, int E, int N);
 hipError_t launch_apply_tile(const WideArgs &a, int64_t B, hipStream_t s);
 bool tile_pitch_ok(const WideArgs &a);
+// ... its condition on the plane pitch alone (what the route / kernel-name query of ssmq_api.hip can know)
+inline bool tile_ld_ok(int64_t ld) { return ld < ((int64_t)1 << 29); }
 // evaluation pass of the two-pass matrix-core route, one wave per trajectory (fx_out, chol_out, mean_f, mrow_out, status)
 hipError_t launch_eval_wave(const WideArgs &a, int64_t B, hipStream_t s);
 

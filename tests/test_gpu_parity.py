@@ -2168,6 +2168,45 @@ def test_streamed_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
         assert np.array_equal(mf3, mf[perm]) and np.array_equal(cf3, cf[perm]) and np.array_equal(cfx3, cfx[perm])
 
 
+def test_calls_from_several_threads_on_different_handles(amd):
+    """"functions are re-entrant across handles".  The library's state is process-global, so every compute entry
+    point holds one lock (include/ssmq.h, conventions): threads that hammer different transforms (ctypes releases the GIL
+    inside each call) must get exactly the results of the same calls made one after the other."""
+    import threading
+    from ssmtoybox_amd import ssmod as sm
+    rng = np.random.default_rng(5)
+    jobs = []
+    for D, model in ((1, sm.UNGMTransition()), (5, sm.ReentryVehicle2DTransition()), (2, sm.Pendulum2DTransition(dt=0.01)),
+                     (5, sm.CoordinatedTurnTransition())):
+        tf = amd.GaussianProcessTransform(D, D, gp_par(D, 3.0)) if D != 2 else amd.UnscentedTransform(D)
+        B = 777 + 64 * D
+        base = {1: [0.5], 2: [1.5, 0.0], 5: [6500.4, 349.14, -1.8093, -6.7967, 0.6932]}[D] if not isinstance(model, sm.CoordinatedTurnTransition) \
+            else [1000.0, 300.0, 1000.0, 0.0, -0.05]
+        means = np.asarray(base) + 1e-2 * rng.standard_normal((B, D))
+        a = rng.standard_normal((B, D, D)) * 1e-2
+        covs = np.einsum('bij,bkj->bik', a, a) + 1e-6 * np.eye(D)
+        jobs.append((tf, model.dyn_eval, means, covs))
+    serial = [tf.apply_batch(f, m, c, 1.0) for tf, f, m, c in jobs]
+    results, errors = [None] * len(jobs), []
+
+    def work(i):
+        try:
+            tf, f, m, c = jobs[i]
+            for _ in range(25):
+                out = tf.apply_batch(f, m, c, 1.0)
+            results[i] = out
+        except Exception as e:        # noqa: BLE001
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    for got, ref in zip(results, serial):
+        assert got is not None and all(np.array_equal(g, r) for g, r in zip(got, ref))
+
+
 def test_state_index_with_more_than_eight_entries(amd):
     """A measurement-type integrand that reads 10 selected entries of a 13-dimensional state (state_index of 10 entries):
     the device integrand evaluates on the selected sub-state (generic kernel), as the oracle's restatement of

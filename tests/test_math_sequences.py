@@ -87,6 +87,13 @@ def test_sincos_absolute_error_for_large_angles(mathlib):
 def test_sincos_propagates_nan_and_inf(mathlib):
     s, c = sincos(mathlib, np.array([np.nan, np.inf, -np.inf]))
     assert np.isnan(s).all() and np.isnan(c).all()
+    # out of the stated domain (|x| > 2^30: an overflowed quadrant count would be undefined behaviour and garbage): NaN, so that
+    # a diverged state fails the next factorisation visibly; the largest in-domain angles still come out right
+    s, c = sincos(mathlib, np.array([1.05e9, -3e9, 2.0 ** 31 * 1.6, 1e300, -1e18]))
+    assert np.isnan(s[1:]).all() and np.isnan(c[1:]).all() and not np.isnan(s[0])
+    edge = np.array([2.0 ** 30, -(2.0 ** 30), 2.0 ** 30 - 0.5])
+    s, c = sincos(mathlib, edge)
+    assert np.abs(s - np.sin(edge.astype(np.longdouble))).max() < 1e-12 and np.abs(c - np.cos(edge.astype(np.longdouble))).max() < 1e-12
     s, c = sincos(mathlib, np.array([0.0, -0.0]))
     assert np.array_equal(s, [0.0, 0.0]) and np.array_equal(c, [1.0, 1.0])
 
