@@ -476,10 +476,17 @@ def measure_c5_degree7(amd, B=10000, iters=5, with_cpu=True):
         buf.buf.free()
     st.free()
     tbuf.free()
-    flop = 2.0 * B * D * float(N) * N
+    flop = 2.0 * B * D * float(N) * N + 2.0 * B * D * D * N + 2.0 * B * D * N * D      # algorithmic, as for N = 201
     tfs = flop / (ms * 1e-3) / 1e12
+    nkb = (N + 15) // 16
+    # executed by k_bq_stream: per 16-row tile nkb (nkb + 1) / 2 + nkb tile steps x 4 instructions + nkb x 8 in C = T fx'
+    flop_exec = ((B + 5) // 6) * 4 * ((nkb * (nkb + 1) // 2 + nkb) * 4 + nkb * 8) * 2048.0 if name == 'k_bq_stream' else None
     rec = {'kernel': name, 'points': int(N), 'ms_per_launch': ms, 'transforms_per_s': B / (ms * 1e-3), 'bound': 'mfma',
            'achieved': tfs, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tfs / F64_MFMA_PEAK_TF, 'flop_per_launch': flop,
+           'executed_flop_per_launch': flop_exec,
+           'executed_frac': (flop_exec / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TF) if flop_exec else None,
+           'traffic': pmc_traffic_named('k_bq_stream') if name == 'k_bq_stream' else None,
+           'algorithmic_bytes': 8.0 * B * (D + D * D + D + D * D + D * D),
            'weights_s': t_weights, 'max_scaled_err_vs_oracle': err, 'weights_rel_err_vs_oracle': w_err,
            'check': 'device weights + device transform against ORACLE weights + oracle transform (the oracle weights are pinned to '
                     'the reference on this point set: tests/golden/g12_large_weights.npz); cond(K) = 8.3e5, so 64 cond eps = 1.2e-8',
@@ -1144,16 +1151,26 @@ def main():
         # both matrix-core products and the covariance epilogue; FX never reaches HBM): its matrix-core arithmetic is the
         # main product on 16-row tiles of 224 columns plus the second product of the covariance epilogue
         name_full = c5.tf.kernel_name(__import__('ssmtoybox_amd').ssmod.Smooth10DTransition().dyn_eval)
-        flop_full = 2.0 * c5.M * c5.NP * (c5.NP + 16) + 2.0 * c5.M * c5.NP * 32
+        # flop, both ways (N = 201 points, E = D = 10, B = 1e4):
+        #   algorithmic (the dense products as the reference forms them): 2 B E N^2 (fx Wc) + 2 B E^2 N ((fx Wc) fx')
+        #     + 2 B E N D (fx Wcc')
+        #   executed on the matrix cores by k_bq_fused since round 4 (Wc = S + S': the zero k-blocks of the triangle are skipped):
+        #     per 16-row tile 13 14 / 2 + 13 = 104 tile steps x 4 instructions in the main product + 13 x 8 in C = T fx'; 2048 flop each
+        Nn, Ee, Bb = 201, 10, 10000
+        flop_alg = 2.0 * Bb * Ee * Nn * Nn + 2.0 * Bb * Ee * Ee * Nn + 2.0 * Bb * Ee * Nn * 10
+        tiles = (Bb + 5) // 6
+        flop_exec = tiles * 4 * (104 * 4 + 13 * 8) * 2048.0 if name_full == 'k_bq_fused' else 2.0 * c5.M * c5.NP * (c5.NP + 16) + 2.0 * c5.M * c5.NP * 32
         alg_bytes = 10000 * 8.0 * (10 + 100 + 10 + 100 + 100) + 4.0 * 10000
         tr = pmc_traffic_named('k_bq_fused') if name_full == 'k_bq_fused' else None
         out['roofline_c5']['full_transform'] = {
-            'kernel': name_full, 'ms_per_launch': ms_full, 'bound': 'mfma', 'flop_per_launch': flop_full,
-            'achieved': flop_full / (ms_full * 1e-3) / 1e12, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-            'frac': flop_full / (ms_full * 1e-3) / 1e12 / F64_MFMA_PEAK_TF, 'algorithmic_bytes': alg_bytes, 'traffic': tr,
+            'kernel': name_full, 'ms_per_launch': ms_full, 'bound': 'mfma', 'flop_per_launch': flop_alg,
+            'achieved': flop_alg / (ms_full * 1e-3) / 1e12, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+            'frac': flop_alg / (ms_full * 1e-3) / 1e12 / F64_MFMA_PEAK_TF,
+            'executed_flop_per_launch': flop_exec, 'executed_frac': flop_exec / (ms_full * 1e-3) / 1e12 / F64_MFMA_PEAK_TF,
+            'algorithmic_bytes': alg_bytes, 'traffic': tr,
             'traffic_over_algorithmic': (tr / alg_bytes) if tr else None,
-            'note': 'two-pass route (k_eval_wave + k_fxwc_cov_mfma, SSMQ_NO_BQ_FUSED=1): 0.332-0.337 ms, 618 MB of HBM '
-                    'traffic (profiles/r03_a_bench.json, pmc_traffic.json at bd95560)'}
+            'note': 'frac counts the ALGORITHMIC flop (dense fx Wc fx\' etc.); the kernel executes fewer (executed_*): it forms '
+                    'fx Wc fx\' as C + C\' with C = (fx tril(Wc)) fx\'.  Round 3 (full product): 0.290-0.293 ms'}
         if cb5:
             out['roofline_c5']['cpu_baseline'] = cb5
         out['roofline_c5']['unisolvent_n21'] = measure_c5_unisolvent(amd)

@@ -498,21 +498,17 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     fill_fpar(f, &a.fp);
     a.fp.ttab = ttab;
     if (streamed) {
-        // one launch, persistent workgroups (one per CU), each with its own block of FX scratch
-        hipDeviceProp_t prop;
-        int dev = 0;
-        SSMQ_HIP(hipGetDevice(&dev));
-        static int cus_dev = -1, cus = 0;
-        if (cus_dev != dev) {
-            SSMQ_HIP(hipGetDeviceProperties(&prop, dev));
-            cus = prop.multiProcessorCount;
-            cus_dev = dev;
-        }
-        double *fx, *tt, *chol;
-        const size_t n_sc = bq_stream_scratch_doubles(h->N, cus);
-        if ((rc = gemm_scratch((int64_t)n_sc, 1, 0, 0, &fx, &tt, &chol, true))) return rc;
+        // two launches: (1) one wave per trajectory: factor, points, integrand values FX, factors; (2) the streamed product whose
+        // epilogues form mean, covariance and cross-covariance (ssmq_bq_stream.hip)
+        const int kb = (h->N + 15) / 16, lda = kb * 16;
+        const int64_t M = B * h->E;
+        double *fx, *tt, *mrow, *chol;
+        if ((rc = big_scratch(M, lda, 0, 0, B, h->D, &fx, &tt, &mrow, &chol))) return rc;
+        WideArgs e = a;
+        e.fx_ld = lda; e.fx_out = fx; e.mrow_out = mrow; e.chol_out = chol;
+        if ((rc = hip_fail(launch_eval_wave(e, B, stream()), "k_eval_wave"))) return rc;
         const WideLayout wl = wide_layout(h->D, h->E, h->N, h->form);
-        return launch_bq_stream(a, h->d_sx_pan, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, fx, cus, stream());
+        return launch_bq_stream(a, h->d_sx_pan, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, fx, chol, lda, stream());
     }
     if (big) {
         const bool bq = h->form == SSMQ_FORM_BQ, tpb = bq && h->tp_nu > 0.0;

@@ -354,7 +354,9 @@ struct Fn<SSMQ_F_BEARING_MEAS> {
     __device__ __forceinline__ void eval(const double *x, double *o) const {
 #pragma unroll
         for (int s = 0; s < E; ++s) {
-            if (s < SSMQ_MAX_FPAR / 2) o[s] = atan2_nr(x[1] - fp->p[2 * s + 1], x[0] - fp->p[2 * s]);
+            // (2 s < n_par: the generic kernels pass E = SSMQ_MAX_FIDX and an output array of their compile-time bound on D and E,
+            // which is below 8 for small shapes - one bearing per sensor and no more)
+            if (s < SSMQ_MAX_FPAR / 2 && 2 * s < fp->n_par) o[s] = atan2_nr(x[1] - fp->p[2 * s + 1], x[0] - fp->p[2 * s]);
         }
     }
 };

@@ -78,10 +78,9 @@ int launch_bq_fused(const WideArgs &a, const double *X, const double *emv, int e
 // ... the same for any larger point set, the point axis tiled (ssmq_bq_stream.hip)
 bool bq_stream_supported(int D, int E, int N);
 size_t bq_stream_x_doubles(int N);
-size_t bq_stream_scratch_doubles(int N, int grid);
 void bq_stream_pack(int D, int N, const double *Wc, const double *Wcc, const double *wm, double *X);
-int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, double *scratch,
-                     int grid, hipStream_t s);
+int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, const double *fx,
+                     const double *chol, int64_t lda, hipStream_t s);
 int launch_fxwc_cov_mfma(int NP, const double *A, const double *X, int64_t M, int lda, const double *mean_rows,
                          const double *chol, const double *emv, int emv_broadcast, const double *cov_add,
                          double cov_scale, double ccov_scale, int E, int D, double *cov_f, double *cov_fx, int64_t es,

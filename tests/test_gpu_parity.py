@@ -167,6 +167,7 @@ def test_blocked_matrix_core_route(amd, golden, monkeypatch, kind, pstr, deg, na
     T = FX [Wc | Wcc'] by column blocks of 256 on the matrix cores (and fx iK for the t-process), per-trajectory rest
     (k_apply_big) - against the oracle with the device's own weights, and against the LDS-resident workgroup kernel where the
     shape fits it."""
+    monkeypatch.setenv('SSMQ_NO_BQ_STREAM', '1')       # (BQ shapes with a symmetric Wc would take k_bq_stream: its own test)
     if os.environ.get('SSMQ_NO_MFMA'):
         pytest.skip('the matrix-core routes are switched off in this run (tools/alt_paths.sh)')
     g = golden('g3_apply')
@@ -2108,14 +2109,14 @@ def test_one_launch_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
 
 @pytest.mark.parametrize('D, pstr, ppar, N, E', [(6, 'gh', {'degree': 3}, 729, 6), (6, 'gh', {'degree': 3}, 729, 7),
                                                  (3, 'gh', {'degree': 7}, 343, 8), (10, 'fs', {'degree': 7}, 1181, 8),
-                                                 (4, 'gh', {'degree': 4}, 256, 6), (2, 'gh', {'degree': 15}, 225, 7)])
+                                                 (4, 'gh', {'degree': 4}, 256, 6), (2, 'gh', {'degree': 15}, 225, 7),
+                                                 (3, 'gh', {'degree': 7}, 343, 2), (4, 'gh', {'degree': 4}, 256, 4), (5, 'gh', {'degree': 4}, 1024, 1)])
 def test_streamed_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
-    """k_bq_stream (ssmq_bq_stream.hip: the one-launch route for 209 ... 4096 points - persistent workgroups, integrand values
-    through a per-workgroup scratch block in fragment order, S = tril(Wc) by panels of 13 column tiles, C + C' epilogue) over
-    its shape space beside configs[4]: output dimensions 6, 7, 8 (10, 9, 8 trajectories per 64-row tile), point counts with a
-    partial last panel / a single k-block past a panel boundary / exactly 16 k-blocks, the register (D <= 8) and the LDS
-    factorisation (D = 10 with a state index), batches that end in a partial tile, more tiles than workgroups, a covariance
-    that is not positive definite.  Against the blocked route (SSMQ_NO_BQ_STREAM) at rounding level and against the oracle."""
+    """k_bq_stream (ssmq_bq_stream.hip: the route for 209 ... 4096 points - k_eval_wave, then the streamed product with S =
+    tril(Wc) by panels of 13 column tiles and the C + C' epilogue) over its shape space beside configs[4]: output dimensions
+    1 ... 8 (64 ... 8 trajectories per 64-row tile), point counts with a partial last panel / a single k-block past a panel
+    boundary / exactly 16 k-blocks / 64 k-blocks, batches that end in a partial tile, a covariance that is not positive
+    definite.  Against the blocked route (SSMQ_NO_BQ_STREAM) at rounding level and against the oracle."""
     from ssmtoybox_amd import ssmod as sm
     if os.environ.get('SSMQ_NO_MFMA') or os.environ.get('SSMQ_NO_BQ_STREAM'):
         pytest.skip('the matrix-core routes are switched off')
