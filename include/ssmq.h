@@ -365,6 +365,13 @@ int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_
                        int shared_y, double time, const double *GQG, const double *R, double *post_mean,
                        double *post_cov, double *loglik, int32_t *status);
 
+/* ssmq_gp_theta_step with a time of its own per item (times [P]): items of different time steps in one call. */
+int ssmq_gp_theta_step_times(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                             const ssmq_integrand *f_obs, int64_t P, const double *par_dyn, const double *par_obs,
+                             double jitter, const double *mean, const double *cov, int shared_state, const double *y,
+                             int shared_y, const double *times, const double *GQG, const double *R, double *post_mean,
+                             double *post_cov, double *loglik, int32_t *status);
+
 /*
  * Batched Laplace step of the marginalised filter (ssinf.py:1243-1273 _param_posterior_moments: one scipy BFGS run per
  * trajectory and time step in the reference; research/tpq/tpq_base.py:175-192 loops over trajectories): B independent
@@ -393,6 +400,28 @@ int ssmq_gp_marginal_laplace_batch(ssmq_transform *h_dyn, const ssmq_integrand *
                                    const double *cov, const double *y, double time, const double *GQG, const double *R,
                                    const double *prior_mean, const double *prior_cov, double fd_step, double *theta,
                                    double *hess_inv, int32_t *status, int32_t *iters, int64_t *rounds);
+
+/*
+ * The whole marginalised filter (ssinf.py:66-118 around :1083-1273) for B trajectories, every trajectory at its own pace: each
+ * walks Laplace step (BFGS as above) -> mixture over the NP parameter sigma points -> next time step by itself, and every device
+ * round (ONE ssmq_gp_theta_step_times) serves whatever the unfinished trajectories wait for.  Rounds = the longest trajectory's
+ * total, not the sum over the time steps of the slowest one's.
+ * y [B][T][Y]; x0_mean [D], x0_cov [D*D]; q_mean [dq] / q_cov [dq*dq] for dynamics that take their noise as an argument (h_dyn is
+ * then a (D + dq) -> D transform, GQG = NULL), else NULL; prior_mean [P], prior_cov [P*P] of the log-parameters at step 1 (each
+ * step's posterior is the next step's prior); upts [P][NP] unit sigma points and uwts [NP] weights of the parameter mixture
+ * (the reference: spherical-radial, NP = 2 P); time index of step k is k (ssinf.py:1088-1122 as called from :101-110).
+ * fm [B][T][D], fP [B][T][D*D] filtered moments (NaN from the step at which a trajectory failed); failed [B]: 0, or the step at
+ * which a kernel matrix / covariance / Laplace covariance stopped being positive definite (the reference raises there);
+ * theta_last [B][P], pcov_last [B][P*P] (may be NULL): the last parameter posterior; stats [3] (may be NULL): device rounds,
+ * BFGS iterations, theta items.  Host arrays; synchronous.
+ */
+int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                  const ssmq_integrand *f_obs, int64_t B, int T, double jitter, const double *y,
+                                  const double *x0_mean, const double *x0_cov, const double *q_mean, const double *q_cov,
+                                  const double *GQG, const double *R, const double *prior_mean, const double *prior_cov,
+                                  const double *upts, const double *uwts, int NP, double fd_step, double param_jitter,
+                                  double *fm, double *fP, int32_t *failed, double *theta_last, double *pcov_last,
+                                  int64_t *stats);
 
 /*
  * Unit sigma-point sets and classical quadrature weights, host code (no device needed):

@@ -149,6 +149,17 @@ _PROTOTYPES = {
                                                       c_double_p, c_double_p, ctypes.c_double, c_double_p, c_double_p,
                                                       c_double_p, c_double_p, ctypes.c_double, c_double_p, c_double_p,
                                                       c_int32_p, c_int32_p, ctypes.POINTER(ctypes.c_int64)]),
+    'ssmq_gp_theta_step_times': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
+                                                ctypes.POINTER(Integrand), ctypes.c_int64, c_double_p, c_double_p,
+                                                ctypes.c_double, c_double_p, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int,
+                                                c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                                c_int32_p]),
+    'ssmq_gp_marginal_filter_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
+                                                     ctypes.POINTER(Integrand), ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                                     c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                                     c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_int,
+                                                     ctypes.c_double, ctypes.c_double, c_double_p, c_double_p, c_int32_p,
+                                                     c_double_p, c_double_p, ctypes.POINTER(ctypes.c_int64)]),
     'ssmq_bfgs_lockstep_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
                                                c_double_p, c_double_p, c_int32_p, c_int32_p, ctypes.POINTER(ctypes.c_int64)]),
     'ssmq_points_count': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int]),

@@ -1903,12 +1903,43 @@ void drop_theta_step_graphs() { drop_theta_graphs(); }
 
 // One filter step per parameter item: weights(theta_dyn) -> dyn transform -> + GQG -> weights(theta_obs) -> obs transform
 // -> + R -> measurement update and log N(y | y_mean, P_y).  Everything between the host arrays stays on the device.
+static int gp_theta_step_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                              const ssmq_integrand *f_obs, int64_t P, const double *par_dyn, const double *par_obs,
+                              double jitter, const double *mean, const double *cov, int shared_state,
+                              const double *y, int shared_y, double time, const double *times, const double *GQG, const double *R,
+                              double *post_mean, double *post_cov, double *loglik, int32_t *status);
+
 extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
                                   const ssmq_integrand *f_obs, int64_t P, const double *par_dyn, const double *par_obs,
                                   double jitter, const double *mean, const double *cov, int shared_state,
                                   const double *y, int shared_y, double time, const double *GQG, const double *R,
                                   double *post_mean, double *post_cov, double *loglik, int32_t *status) {
     SSMQ_API_LOCK();
+    return gp_theta_step_impl(h_dyn, f_dyn, h_obs, f_obs, P, par_dyn, par_obs, jitter, mean, cov, shared_state, y, shared_y, time,
+                              nullptr, GQG, R, post_mean, post_cov, loglik, status);
+}
+
+// the same with a time of its own per item (times [P]): items of different time steps in one call - the batched marginalised
+// filter lets every trajectory run ahead at its own pace (csrc/ssmq_marginal.hip)
+extern "C" int ssmq_gp_theta_step_times(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                        const ssmq_integrand *f_obs, int64_t P, const double *par_dyn, const double *par_obs,
+                                        double jitter, const double *mean, const double *cov, int shared_state,
+                                        const double *y, int shared_y, const double *times, const double *GQG, const double *R,
+                                        double *post_mean, double *post_cov, double *loglik, int32_t *status) {
+    SSMQ_API_LOCK();
+    if (!times) {
+        set_error("gp_theta_step_times: times is NULL");
+        return SSMQ_E_ARG;
+    }
+    return gp_theta_step_impl(h_dyn, f_dyn, h_obs, f_obs, P, par_dyn, par_obs, jitter, mean, cov, shared_state, y, shared_y, 0.0,
+                              times, GQG, R, post_mean, post_cov, loglik, status);
+}
+
+static int gp_theta_step_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                              const ssmq_integrand *f_obs, int64_t P, const double *par_dyn, const double *par_obs,
+                              double jitter, const double *mean, const double *cov, int shared_state,
+                              const double *y, int shared_y, double time, const double *times, const double *GQG, const double *R,
+                              double *post_mean, double *post_cov, double *loglik, int32_t *status) {
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || P < 0 || P > 0x7fffffff || !par_dyn || !par_obs || !mean || !cov || !y ||
         !post_mean || !post_cov || !loglik) {
         set_error("gp_theta_step: bad argument");
@@ -1940,7 +1971,7 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     // BFGS iteration with a handful of items: forty allocations and three synchronisations per call were 310 us) -----------
     // input block, same layout on host and device:  xi_dyn | xi_obs | par_dyn | par_obs | mean | cov | y (planes) | GQG | R | t
     const size_t n_in = (size_t)Din * Nd + (size_t)D * No + (size_t)P * (1 + Din) + (size_t)P * (1 + D) +
-                        (size_t)ns * (Din + Din * Din) + (size_t)ld * Y + (size_t)D * D + (size_t)Y * Y + 1;
+                        (size_t)ns * (Din + Din * Din) + (size_t)ld * Y + (size_t)D * D + (size_t)Y * Y + (times ? (size_t)ld : 1);
     // work planes: m_pr D | P_pr D*D | C_xx D*D | y_mean Y | P_y Y*Y | P_yx Y*D, then the output block m_fi D | P_fi D*D |
     // loglik 1 | merged status (int32), then the five partial status vectors
     const size_t n_mid = (size_t)D + (size_t)D * D + (size_t)D * Din + Y + (size_t)Y * Y + (size_t)Y * D;
@@ -1974,7 +2005,11 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
         h += (size_t)ld * Y;
         if (GQG) put(GQG, (size_t)D * D); else { memset(h, 0, sizeof(double) * D * D); h += (size_t)D * D; }
         if (R) put(R, (size_t)Y * Y); else { memset(h, 0, sizeof(double) * Y * Y); h += (size_t)Y * Y; }
-        *h++ = time;
+        if (times) {
+            for (int64_t i = 0; i < ld; ++i) *h++ = i < P ? times[i] : 0.0;
+        } else {
+            *h++ = time;
+        }
     }
     double *in = (double *)(dev + off_in);
     double *xid = in; in += (size_t)Din * Nd;
@@ -2025,7 +2060,7 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     int32_t *st_all = (int32_t *)w;
     WideArgs a;
     memset(&a, 0, sizeof(a));
-    a.D = Din; a.E = D; a.N = Nd; a.form = SSMQ_FORM_BQ; a.mode = SSMQ_WIDE_FULL; a.fid = f_dyn->id; a.time_stride = 0;
+    a.D = Din; a.E = D; a.N = Nd; a.form = SSMQ_FORM_BQ; a.mode = SSMQ_WIDE_FULL; a.fid = f_dyn->id; a.time_stride = times ? 1 : 0;
     a.emv_mode = h_dyn->emv_mode; a.tp_nu = 0.0; a.cov_scale = a.ccov_scale = 1.0;
     a.consts = cd; a.consts_stride = cld.total; a.cov_add = gq;
     a.mean = min_; a.cov = cin; a.time = tt; a.es_in = 1; a.bs_mean = shared_state ? 0 : Din;
@@ -2053,7 +2088,7 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
     {
         std::vector<uint64_t> key = {(uint64_t)(uintptr_t)dev, (uint64_t)(uintptr_t)hin, (uint64_t)(uintptr_t)g_stage.hout, (uint64_t)P,
                                      (uint64_t)Din, (uint64_t)D, (uint64_t)Y, (uint64_t)Nd, (uint64_t)No, (uint64_t)shared_state,
-                                     (uint64_t)h_dyn->emv_mode, (uint64_t)h_obs->emv_mode, (uint64_t)total, (uint64_t)two_launch};
+                                     (uint64_t)h_dyn->emv_mode, (uint64_t)h_obs->emv_mode, (uint64_t)total, (uint64_t)two_launch, (uint64_t)(times ? 1 : 0)};
         uint64_t jb;
         memcpy(&jb, &jitter, sizeof(jb));
         key.push_back(jb);

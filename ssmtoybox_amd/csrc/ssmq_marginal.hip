@@ -208,17 +208,242 @@ struct Evaluator {
     virtual ~Evaluator() {}
 };
 
+// One trajectory's optimiser takes the objective values at its pending point r.xt (vals[0]) and at the forward-difference
+// points (vals[1 + i]: r.xt + fd_step e_i) and either finishes (r.phase = PH_DONE, r.status) or leaves the next point in r.xt.
+void bfgs_advance(Run &r, int P, double fd_step, const double *vals) {
+    const double gtol = 1e-5, inf = std::numeric_limits<double>::infinity();
+    const int maxiter = 200 * P, per = P + 1;
+    // value and gradient at xt (non-finite -> +inf as the Python objective, ssmtoybox_amd/ssinf.py)
+    double val[kMaxPar + 1], gt[kMaxPar];
+    for (int j = 0; j < per; ++j) {
+        const double v = vals[j];
+        val[j] = std::isfinite(v) ? v : inf;
+    }
+    for (int i = 0; i < P; ++i) gt[i] = (val[i + 1] - val[0]) / ((r.xt[i] + fd_step) - r.xt[i]);
+    const double ft = val[0];
+    bool start_iteration = false;
+    if (r.phase == PH_INIT) {
+        r.old_fval = ft;
+        double n2 = 0.0, gmax = 0.0;
+        for (int i = 0; i < P; ++i) {
+            r.g[i] = gt[i];
+            n2 += gt[i] * gt[i];
+            gmax = (std::isnan(gt[i]) || std::isnan(gmax)) ? NAN : std::fmax(gmax, std::fabs(gt[i]));   // numpy's max keeps NaN
+        }
+        r.old_old_fval = r.old_fval + std::sqrt(n2) / 2;
+        if (!(gmax > gtol)) {            // (a NaN gradient ends the loop as in SciPy: `while gnorm > gtol`)
+            r.phase = PH_DONE;
+            r.status = (std::isnan(gmax) || std::isnan(ft)) ? SSMQ_BFGS_NAN : 0;
+            return;
+        }
+        start_iteration = true;
+    } else {                             // PH_LINE / PH_LINE2: a trial step has been evaluated
+        double dphi = 0.0;
+        for (int i = 0; i < P; ++i) dphi += gt[i] * r.pk[i];
+        const double c1 = 1e-4, c2 = 0.9, amax = 1e100;
+        const double phi0 = r.old_fval, derphi0 = r.derphi0;
+        bool accepted = false, to_second = false, failed = false;
+        double next = 0.0;                 // the next trial step, if neither
+        if (r.phase == PH_LINE) {
+            double stp = r.stp;
+            const Task t = dcsrch_iterate(r.ls, stp, ft, dphi, T_FG);
+            if (t == T_FG) {
+                ++r.ls_iter;
+                if (!std::isfinite(stp) || r.ls_iter >= 100) to_second = true;
+                else next = stp;
+            } else if (t == T_CONV) {
+                accepted = true;
+            } else {                       // WARNING / ERROR: SciPy goes on with line_search_wolfe2
+                to_second = true;
+            }
+        } else if (!r.zoom) {              // scalar_search_wolfe2, iteration w2_i, alpha1 = r.stp evaluated
+            const double alpha1 = r.stp, phi_a1 = ft, derphi_a1 = dphi;
+            auto start_zoom = [&](double a_lo, double a_hi, double phi_lo, double phi_hi, double derphi_lo) {
+                r.zoom = true; r.z_i = 0;
+                r.a_lo = a_lo; r.a_hi = a_hi; r.phi_lo = phi_lo; r.phi_hi = phi_hi; r.derphi_lo = derphi_lo;
+                r.phi_rec = phi0; r.a_rec = 0.0;
+            };
+            if (r.w2_i >= 10) {            // for ... else: maxiter reached; the last evaluated step is returned
+                accepted = true;
+            } else if (alpha1 == 0.0) {
+                failed = true;
+            } else if ((phi_a1 > phi0 + c1 * alpha1 * derphi0) || ((phi_a1 >= r.w2_phi_a0) && r.w2_i > 0)) {
+                start_zoom(r.w2_alpha0, alpha1, r.w2_phi_a0, phi_a1, r.w2_derphi_a0);
+            } else if (std::fabs(derphi_a1) <= -c2 * derphi0) {
+                accepted = true;
+            } else if (derphi_a1 >= 0) {
+                start_zoom(alpha1, r.w2_alpha0, phi_a1, r.w2_phi_a0, derphi_a1);
+            } else {
+                const double alpha2 = std::fmin(2 * alpha1, amax);
+                r.w2_alpha0 = alpha1; r.w2_phi_a0 = phi_a1; r.w2_derphi_a0 = derphi_a1;
+                ++r.w2_i;
+                next = alpha2;
+            }
+        } else {                           // _zoom: a_j = r.stp evaluated
+            const double a_j = r.stp, phi_aj = ft, derphi_aj = dphi;
+            if ((phi_aj > phi0 + c1 * a_j * derphi0) || (phi_aj >= r.phi_lo)) {
+                r.phi_rec = r.phi_hi; r.a_rec = r.a_hi; r.a_hi = a_j; r.phi_hi = phi_aj;
+            } else {
+                if (std::fabs(derphi_aj) <= -c2 * derphi0) {
+                    accepted = true;
+                } else {
+                    if (derphi_aj * (r.a_hi - r.a_lo) >= 0) {
+                        r.phi_rec = r.phi_hi; r.a_rec = r.a_hi; r.a_hi = r.a_lo; r.phi_hi = r.phi_lo;
+                    } else {
+                        r.phi_rec = r.phi_lo; r.a_rec = r.a_lo;
+                    }
+                    r.a_lo = a_j; r.phi_lo = phi_aj; r.derphi_lo = derphi_aj;
+                }
+            }
+            if (!accepted) {
+                ++r.z_i;
+                if (r.z_i > 10) failed = true;
+            }
+        }
+        if (to_second) {
+            // scalar_search_wolfe2 from the same point and direction: first trial step as for the first search
+            double alpha1 = 1.0;
+            if (derphi0 != 0) alpha1 = std::fmin(1.0, 1.01 * 2 * (phi0 - r.old_old_fval) / derphi0);
+            if (alpha1 < 0) alpha1 = 1.0;
+            alpha1 = std::fmin(alpha1, amax);
+            r.phase = PH_LINE2;
+            r.zoom = false; r.w2_i = 0;
+            r.w2_alpha0 = 0.0; r.w2_phi_a0 = phi0; r.w2_derphi_a0 = derphi0;
+            next = alpha1;
+        }
+        if (failed) {                      // _LineSearchError: "Desired error not necessarily achieved due to precision loss"
+            r.phase = PH_DONE;
+            r.status = SSMQ_BFGS_PRECISION_LOSS;
+            return;
+        }
+        if (!accepted) {
+            if (r.phase == PH_LINE2 && r.zoom) {
+                // the next trial step of _zoom: cubic, else quadratic interpolation, else bisection
+                const double dalpha = r.a_hi - r.a_lo;
+                const double a = dalpha < 0 ? r.a_hi : r.a_lo, b = dalpha < 0 ? r.a_lo : r.a_hi;
+                double a_j = 0.0;
+                bool have = false;
+                const double cchk = 0.2 * dalpha;
+                if (r.z_i > 0) have = cubicmin(r.a_lo, r.phi_lo, r.derphi_lo, r.a_hi, r.phi_hi, r.a_rec, r.phi_rec, &a_j);
+                if (r.z_i == 0 || !have || a_j > b - cchk || a_j < a + cchk) {
+                    const double qchk = 0.1 * dalpha;
+                    have = quadmin(r.a_lo, r.phi_lo, r.derphi_lo, r.a_hi, r.phi_hi, &a_j);
+                    if (!have || a_j > b - qchk || a_j < a + qchk) a_j = r.a_lo + 0.5 * dalpha;
+                }
+                next = a_j;
+            }
+            r.stp = next;
+            for (int i = 0; i < P; ++i) r.xt[i] = r.x[i] + next * r.pk[i];
+            return;
+        }
+        // accepted: alpha_k = stp, the last evaluated step
+        const double alpha = r.stp;
+        double sk[kMaxPar], yk[kMaxPar], pn = 0.0, gmax = 0.0;
+        for (int i = 0; i < P; ++i) {
+            sk[i] = alpha * r.pk[i];
+            r.x[i] = r.x[i] + sk[i];
+            yk[i] = gt[i] - r.g[i];
+            r.g[i] = gt[i];
+            pn += r.pk[i] * r.pk[i];
+            gmax = (std::isnan(gt[i]) || std::isnan(gmax)) ? NAN : std::fmax(gmax, std::fabs(gt[i]));
+        }
+        r.old_old_fval = r.old_fval;
+        r.old_fval = ft;
+        ++r.k;
+        if (!(gmax > gtol) && !std::isnan(gmax)) {
+            r.phase = PH_DONE;
+            r.status = 0;
+            return;
+        }
+        if (alpha * std::sqrt(pn) <= 0.0) {      // xrtol = 0
+            r.phase = PH_DONE;
+            r.status = std::isnan(gmax) ? SSMQ_BFGS_NAN : 0;
+            return;
+        }
+        if (!std::isfinite(r.old_fval)) {
+            r.phase = PH_DONE;
+            r.status = SSMQ_BFGS_PRECISION_LOSS;
+            return;
+        }
+        double rho_inv = 0.0;
+        for (int i = 0; i < P; ++i) rho_inv += yk[i] * sk[i];
+        const double rho = rho_inv == 0.0 ? 1000.0 : 1.0 / rho_inv;
+        // Hk = (I - sk yk' rho) Hk (I - yk sk' rho) + rho sk sk'
+        double A2[kMaxPar * kMaxPar], HA[kMaxPar * kMaxPar], Hn[kMaxPar * kMaxPar];
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j < P; ++j) A2[i * P + j] = (i == j ? 1.0 : 0.0) - yk[i] * sk[j] * rho;
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j < P; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < P; ++k) s += r.H[i * P + k] * A2[k * P + j];
+                HA[i * P + j] = s;
+            }
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j < P; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < P; ++k) s += ((i == k ? 1.0 : 0.0) - sk[i] * yk[k] * rho) * HA[k * P + j];
+                Hn[i * P + j] = s + rho * sk[i] * sk[j];
+            }
+        std::memcpy(r.H, Hn, sizeof(double) * P * P);
+        if (std::isnan(gmax)) {                  // `while gnorm > gtol` ends on NaN
+            r.phase = PH_DONE;
+            r.status = SSMQ_BFGS_NAN;
+            return;
+        }
+        if (r.k >= maxiter) {
+            r.phase = PH_DONE;
+            r.status = SSMQ_BFGS_MAXITER;
+            return;
+        }
+        start_iteration = true;
+    }
+    if (start_iteration) {
+        // pk = -Hk gfk; scalar_search_wolfe1's first trial step; DCSRCH "START"
+        double dphi0 = 0.0;
+        for (int i = 0; i < P; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < P; ++j) s += r.H[i * P + j] * r.g[j];
+            r.pk[i] = -s;
+        }
+        for (int i = 0; i < P; ++i) dphi0 += r.g[i] * r.pk[i];
+        r.derphi0 = dphi0;
+        double alpha1 = 1.0;
+        if (dphi0 != 0) {
+            alpha1 = std::fmin(1.0, 1.01 * 2 * (r.old_fval - r.old_old_fval) / dphi0);
+            if (alpha1 < 0) alpha1 = 1.0;
+        }
+        r.ls = Dcsrch();
+        double stp = alpha1;
+        const Task t = dcsrch_iterate(r.ls, stp, r.old_fval, dphi0, T_START);
+        if (t != T_FG || !std::isfinite(stp)) {
+            // the first search refuses to start (e.g. not a descent direction): scalar_search_wolfe2 from its first step
+            r.phase = PH_LINE2;
+            r.zoom = false; r.w2_i = 0;
+            r.w2_alpha0 = 0.0; r.w2_phi_a0 = r.old_fval; r.w2_derphi_a0 = dphi0;
+            stp = std::fmin(alpha1, 1e100);
+        } else {
+            r.ls_iter = 1;
+            r.phase = PH_LINE;
+        }
+        r.stp = stp;
+        for (int i = 0; i < P; ++i) r.xt[i] = r.x[i] + stp * r.pk[i];
+    }
+}
+
+void bfgs_start(Run &r, int P, const double *x0) {
+    r = Run();
+    for (int i = 0; i < P; ++i) r.x[i] = r.xt[i] = x0[i];
+    for (int i = 0; i < P * P; ++i) r.H[i] = 0.0;
+    for (int i = 0; i < P; ++i) r.H[i * P + i] = 1.0;
+}
+
 // B BFGS runs in lock step.  theta [B][P] start points in / minimisers out; skip[b] != 0: trajectory b is not run (status kept).
 int bfgs_lockstep(int64_t B, int P, double fd_step, Evaluator &ev, double *theta, double *hess_inv, int32_t *status, int32_t *iters,
                   int64_t *rounds_out) {
-    const double gtol = 1e-5, inf = std::numeric_limits<double>::infinity();
-    const int maxiter = 200 * P;
     std::vector<Run> run((size_t)B);
     for (int64_t b = 0; b < B; ++b) {
         Run &r = run[b];
-        for (int i = 0; i < P; ++i) r.x[i] = r.xt[i] = theta[(size_t)b * P + i];
-        for (int i = 0; i < P * P; ++i) r.H[i] = 0.0;
-        for (int i = 0; i < P; ++i) r.H[i * P + i] = 1.0;
+        bfgs_start(r, P, theta + (size_t)b * P);
         if (status[b] != 0) {
             r.phase = PH_DONE;
             r.status = status[b];
@@ -246,225 +471,7 @@ int bfgs_lockstep(int64_t B, int P, double fd_step, Evaluator &ev, double *theta
         const int rc = ev.eval(items, traj.data(), rows.data(), vals.data());
         if (rc < 0) return rc;
         ++rounds;
-        for (int64_t w = 0; w < nw; ++w) {
-            Run &r = run[want[w]];
-            // value and gradient at xt (non-finite -> +inf as the Python objective, ssmtoybox_amd/ssinf.py)
-            double val[kMaxPar + 1], gt[kMaxPar];
-            for (int j = 0; j < per; ++j) {
-                const double v = vals[(size_t)(w * per + j)];
-                val[j] = std::isfinite(v) ? v : inf;
-            }
-            for (int i = 0; i < P; ++i) gt[i] = (val[i + 1] - val[0]) / ((r.xt[i] + fd_step) - r.xt[i]);
-            const double ft = val[0];
-            bool start_iteration = false;
-            if (r.phase == PH_INIT) {
-                r.old_fval = ft;
-                double n2 = 0.0, gmax = 0.0;
-                for (int i = 0; i < P; ++i) {
-                    r.g[i] = gt[i];
-                    n2 += gt[i] * gt[i];
-                    gmax = (std::isnan(gt[i]) || std::isnan(gmax)) ? NAN : std::fmax(gmax, std::fabs(gt[i]));   // numpy's max keeps NaN
-                }
-                r.old_old_fval = r.old_fval + std::sqrt(n2) / 2;
-                if (!(gmax > gtol)) {            // (a NaN gradient ends the loop as in SciPy: `while gnorm > gtol`)
-                    r.phase = PH_DONE;
-                    r.status = (std::isnan(gmax) || std::isnan(ft)) ? SSMQ_BFGS_NAN : 0;
-                    continue;
-                }
-                start_iteration = true;
-            } else {                             // PH_LINE / PH_LINE2: a trial step has been evaluated
-                double dphi = 0.0;
-                for (int i = 0; i < P; ++i) dphi += gt[i] * r.pk[i];
-                const double c1 = 1e-4, c2 = 0.9, amax = 1e100;
-                const double phi0 = r.old_fval, derphi0 = r.derphi0;
-                bool accepted = false, to_second = false, failed = false;
-                double next = 0.0;                 // the next trial step, if neither
-                if (r.phase == PH_LINE) {
-                    double stp = r.stp;
-                    const Task t = dcsrch_iterate(r.ls, stp, ft, dphi, T_FG);
-                    if (t == T_FG) {
-                        ++r.ls_iter;
-                        if (!std::isfinite(stp) || r.ls_iter >= 100) to_second = true;
-                        else next = stp;
-                    } else if (t == T_CONV) {
-                        accepted = true;
-                    } else {                       // WARNING / ERROR: SciPy goes on with line_search_wolfe2
-                        to_second = true;
-                    }
-                } else if (!r.zoom) {              // scalar_search_wolfe2, iteration w2_i, alpha1 = r.stp evaluated
-                    const double alpha1 = r.stp, phi_a1 = ft, derphi_a1 = dphi;
-                    auto start_zoom = [&](double a_lo, double a_hi, double phi_lo, double phi_hi, double derphi_lo) {
-                        r.zoom = true; r.z_i = 0;
-                        r.a_lo = a_lo; r.a_hi = a_hi; r.phi_lo = phi_lo; r.phi_hi = phi_hi; r.derphi_lo = derphi_lo;
-                        r.phi_rec = phi0; r.a_rec = 0.0;
-                    };
-                    if (r.w2_i >= 10) {            // for ... else: maxiter reached; the last evaluated step is returned
-                        accepted = true;
-                    } else if (alpha1 == 0.0) {
-                        failed = true;
-                    } else if ((phi_a1 > phi0 + c1 * alpha1 * derphi0) || ((phi_a1 >= r.w2_phi_a0) && r.w2_i > 0)) {
-                        start_zoom(r.w2_alpha0, alpha1, r.w2_phi_a0, phi_a1, r.w2_derphi_a0);
-                    } else if (std::fabs(derphi_a1) <= -c2 * derphi0) {
-                        accepted = true;
-                    } else if (derphi_a1 >= 0) {
-                        start_zoom(alpha1, r.w2_alpha0, phi_a1, r.w2_phi_a0, derphi_a1);
-                    } else {
-                        const double alpha2 = std::fmin(2 * alpha1, amax);
-                        r.w2_alpha0 = alpha1; r.w2_phi_a0 = phi_a1; r.w2_derphi_a0 = derphi_a1;
-                        ++r.w2_i;
-                        next = alpha2;
-                    }
-                } else {                           // _zoom: a_j = r.stp evaluated
-                    const double a_j = r.stp, phi_aj = ft, derphi_aj = dphi;
-                    if ((phi_aj > phi0 + c1 * a_j * derphi0) || (phi_aj >= r.phi_lo)) {
-                        r.phi_rec = r.phi_hi; r.a_rec = r.a_hi; r.a_hi = a_j; r.phi_hi = phi_aj;
-                    } else {
-                        if (std::fabs(derphi_aj) <= -c2 * derphi0) {
-                            accepted = true;
-                        } else {
-                            if (derphi_aj * (r.a_hi - r.a_lo) >= 0) {
-                                r.phi_rec = r.phi_hi; r.a_rec = r.a_hi; r.a_hi = r.a_lo; r.phi_hi = r.phi_lo;
-                            } else {
-                                r.phi_rec = r.phi_lo; r.a_rec = r.a_lo;
-                            }
-                            r.a_lo = a_j; r.phi_lo = phi_aj; r.derphi_lo = derphi_aj;
-                        }
-                    }
-                    if (!accepted) {
-                        ++r.z_i;
-                        if (r.z_i > 10) failed = true;
-                    }
-                }
-                if (to_second) {
-                    // scalar_search_wolfe2 from the same point and direction: first trial step as for the first search
-                    double alpha1 = 1.0;
-                    if (derphi0 != 0) alpha1 = std::fmin(1.0, 1.01 * 2 * (phi0 - r.old_old_fval) / derphi0);
-                    if (alpha1 < 0) alpha1 = 1.0;
-                    alpha1 = std::fmin(alpha1, amax);
-                    r.phase = PH_LINE2;
-                    r.zoom = false; r.w2_i = 0;
-                    r.w2_alpha0 = 0.0; r.w2_phi_a0 = phi0; r.w2_derphi_a0 = derphi0;
-                    next = alpha1;
-                }
-                if (failed) {                      // _LineSearchError: "Desired error not necessarily achieved due to precision loss"
-                    r.phase = PH_DONE;
-                    r.status = SSMQ_BFGS_PRECISION_LOSS;
-                    continue;
-                }
-                if (!accepted) {
-                    if (r.phase == PH_LINE2 && r.zoom) {
-                        // the next trial step of _zoom: cubic, else quadratic interpolation, else bisection
-                        const double dalpha = r.a_hi - r.a_lo;
-                        const double a = dalpha < 0 ? r.a_hi : r.a_lo, b = dalpha < 0 ? r.a_lo : r.a_hi;
-                        double a_j = 0.0;
-                        bool have = false;
-                        const double cchk = 0.2 * dalpha;
-                        if (r.z_i > 0) have = cubicmin(r.a_lo, r.phi_lo, r.derphi_lo, r.a_hi, r.phi_hi, r.a_rec, r.phi_rec, &a_j);
-                        if (r.z_i == 0 || !have || a_j > b - cchk || a_j < a + cchk) {
-                            const double qchk = 0.1 * dalpha;
-                            have = quadmin(r.a_lo, r.phi_lo, r.derphi_lo, r.a_hi, r.phi_hi, &a_j);
-                            if (!have || a_j > b - qchk || a_j < a + qchk) a_j = r.a_lo + 0.5 * dalpha;
-                        }
-                        next = a_j;
-                    }
-                    r.stp = next;
-                    for (int i = 0; i < P; ++i) r.xt[i] = r.x[i] + next * r.pk[i];
-                    continue;
-                }
-                // accepted: alpha_k = stp, the last evaluated step
-                const double alpha = r.stp;
-                double sk[kMaxPar], yk[kMaxPar], pn = 0.0, xn = 0.0, gmax = 0.0;
-                for (int i = 0; i < P; ++i) {
-                    sk[i] = alpha * r.pk[i];
-                    r.x[i] = r.x[i] + sk[i];
-                    yk[i] = gt[i] - r.g[i];
-                    r.g[i] = gt[i];
-                    pn += r.pk[i] * r.pk[i];
-                    xn += r.x[i] * r.x[i];
-                    gmax = (std::isnan(gt[i]) || std::isnan(gmax)) ? NAN : std::fmax(gmax, std::fabs(gt[i]));
-                }
-                r.old_old_fval = r.old_fval;
-                r.old_fval = ft;
-                ++r.k;
-                if (!(gmax > gtol) && !std::isnan(gmax)) {
-                    r.phase = PH_DONE;
-                    r.status = 0;
-                    continue;
-                }
-                if (alpha * std::sqrt(pn) <= 0.0) {      // xrtol = 0
-                    r.phase = PH_DONE;
-                    r.status = std::isnan(gmax) ? SSMQ_BFGS_NAN : 0;
-                    continue;
-                }
-                if (!std::isfinite(r.old_fval)) {
-                    r.phase = PH_DONE;
-                    r.status = SSMQ_BFGS_PRECISION_LOSS;
-                    continue;
-                }
-                double rho_inv = 0.0;
-                for (int i = 0; i < P; ++i) rho_inv += yk[i] * sk[i];
-                const double rho = rho_inv == 0.0 ? 1000.0 : 1.0 / rho_inv;
-                // Hk = (I - sk yk' rho) Hk (I - yk sk' rho) + rho sk sk'
-                double A2[kMaxPar * kMaxPar], HA[kMaxPar * kMaxPar], Hn[kMaxPar * kMaxPar];
-                for (int i = 0; i < P; ++i)
-                    for (int j = 0; j < P; ++j) A2[i * P + j] = (i == j ? 1.0 : 0.0) - yk[i] * sk[j] * rho;
-                for (int i = 0; i < P; ++i)
-                    for (int j = 0; j < P; ++j) {
-                        double s = 0.0;
-                        for (int k = 0; k < P; ++k) s += r.H[i * P + k] * A2[k * P + j];
-                        HA[i * P + j] = s;
-                    }
-                for (int i = 0; i < P; ++i)
-                    for (int j = 0; j < P; ++j) {
-                        double s = 0.0;
-                        for (int k = 0; k < P; ++k) s += ((i == k ? 1.0 : 0.0) - sk[i] * yk[k] * rho) * HA[k * P + j];
-                        Hn[i * P + j] = s + rho * sk[i] * sk[j];
-                    }
-                std::memcpy(r.H, Hn, sizeof(double) * P * P);
-                if (std::isnan(gmax)) {                  // `while gnorm > gtol` ends on NaN
-                    r.phase = PH_DONE;
-                    r.status = SSMQ_BFGS_NAN;
-                    continue;
-                }
-                if (r.k >= maxiter) {
-                    r.phase = PH_DONE;
-                    r.status = SSMQ_BFGS_MAXITER;
-                    continue;
-                }
-                start_iteration = true;
-            }
-            if (start_iteration) {
-                // pk = -Hk gfk; scalar_search_wolfe1's first trial step; DCSRCH "START"
-                double dphi0 = 0.0;
-                for (int i = 0; i < P; ++i) {
-                    double s = 0.0;
-                    for (int j = 0; j < P; ++j) s += r.H[i * P + j] * r.g[j];
-                    r.pk[i] = -s;
-                }
-                for (int i = 0; i < P; ++i) dphi0 += r.g[i] * r.pk[i];
-                r.derphi0 = dphi0;
-                double alpha1 = 1.0;
-                if (dphi0 != 0) {
-                    alpha1 = std::fmin(1.0, 1.01 * 2 * (r.old_fval - r.old_old_fval) / dphi0);
-                    if (alpha1 < 0) alpha1 = 1.0;
-                }
-                r.ls = Dcsrch();
-                double stp = alpha1;
-                const Task t = dcsrch_iterate(r.ls, stp, r.old_fval, dphi0, T_START);
-                if (t != T_FG || !std::isfinite(stp)) {
-                    // the first search refuses to start (e.g. not a descent direction): scalar_search_wolfe2 from its first step
-                    r.phase = PH_LINE2;
-                    r.zoom = false; r.w2_i = 0;
-                    r.w2_alpha0 = 0.0; r.w2_phi_a0 = r.old_fval; r.w2_derphi_a0 = dphi0;
-                    stp = std::fmin(alpha1, 1e100);
-                } else {
-                    r.ls_iter = 1;
-                    r.phase = PH_LINE;
-                }
-                r.stp = stp;
-                for (int i = 0; i < P; ++i) r.xt[i] = r.x[i] + stp * r.pk[i];
-            }
-        }
+        for (int64_t w = 0; w < nw; ++w) bfgs_advance(run[want[w]], P, fd_step, &vals[(size_t)(w * per)]);
     }
     for (int64_t b = 0; b < B; ++b) {
         const Run &r = run[b];
@@ -590,4 +597,233 @@ extern "C" int ssmq_gp_marginal_laplace_batch(ssmq_transform *h_dyn, const ssmq_
         }
     }
     return bfgs_lockstep(B, P, fd_step, ev, theta, hess_inv, status, iters, rounds_out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The whole marginalised filter for B trajectories, every trajectory at its own pace.
+//
+// ssmq_gp_marginal_laplace_batch keeps the trajectories in lock step PER TIME STEP: a step costs as many device rounds as its
+// slowest trajectory needs (a few run 50 BFGS iterations on a noisy objective), and the others wait.  Trajectories are
+// independent across time steps as well (research/tpq/tpq_base.py:175-192 loops over them), so here each one walks
+// ssinf.py:66-118 / 1083-1273 by itself - Laplace step (BFGS), marginalisation over the parameter sigma points, next time
+// step - and a round sends whatever every unfinished trajectory is waiting for, with its own time index
+// (ssmq_gp_theta_step_times): (param_dim + 1) objective points or NP marginalisation points.  The number of rounds is the
+// LONGEST trajectory's total, not the sum over the steps of the slowest one's.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Traj {
+    int k = 1;                      // time step being worked on (1 .. T)
+    int mode = 0;                   // 0: optimising (BFGS), 1: waiting for the marginalisation points, 2: finished / failed
+    Run run;
+    double xm[SSMQ_MAX_DIM], xP[SSMQ_MAX_DIM * SSMQ_MAX_DIM];          // filtered state moments
+    double pm[kMaxPar], pc[kMaxPar * kMaxPar], Lp[kMaxPar * kMaxPar], logdet2 = 0;   // parameter prior of this step, its factor
+    double pts[kMaxPar * 2 * kMaxPar];                                  // [NP][P] marginalisation points of this step
+};
+
+bool chol_lower(const double *C, int P, double *L, double *logdet2) {
+    double ld = 0.0;
+    for (int i = 0; i < P * P; ++i) L[i] = 0.0;
+    for (int j = 0; j < P; ++j) {
+        double s = C[j * P + j];
+        for (int k = 0; k < j; ++k) s -= L[j * P + k] * L[j * P + k];
+        if (!(s > 0.0)) return false;
+        const double ljj = std::sqrt(s);
+        L[j * P + j] = ljj;
+        ld += 2.0 * std::log(ljj);
+        for (int i = j + 1; i < P; ++i) {
+            double t = C[i * P + j];
+            for (int k = 0; k < j; ++k) t -= L[i * P + k] * L[j * P + k];
+            L[i * P + j] = t / ljj;
+        }
+    }
+    if (logdet2) *logdet2 = ld;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                                             const ssmq_integrand *f_obs, int64_t B, int T, double jitter, const double *y,
+                                             const double *x0_mean, const double *x0_cov, const double *q_mean,
+                                             const double *q_cov, const double *GQG, const double *R, const double *prior_mean,
+                                             const double *prior_cov, const double *upts, const double *uwts, int NP,
+                                             double fd_step, double param_jitter, double *fm, double *fP, int32_t *failed,
+                                             double *theta_last, double *pcov_last, int64_t *stats) {
+    SSMQ_API_LOCK();
+    if (!h_dyn || !h_obs || !f_dyn || !f_obs || B < 0 || T < 0 || (B > 0 && T > 0 && (!y || !x0_mean || !x0_cov || !prior_mean ||
+        !prior_cov || !upts || !uwts || !fm || !fP || !failed))) {
+        set_error("marginal_filter_batch: null argument");
+        return SSMQ_E_ARG;
+    }
+    const int Din = h_dyn->D, D = h_dyn->E, Y = h_obs->E, dq = Din - D;
+    const int Pd = Din + 1, Po = h_obs->D + 1, P = Pd + Po;
+    if (P > kMaxPar || NP < 1 || NP > 2 * kMaxPar || dq < 0 || (dq > 0 && (!q_mean || !q_cov))) {
+        set_error("marginal_filter_batch: bad shape (parameters, parameter points, or noise moments of augmented dynamics missing)");
+        return SSMQ_E_ARG;
+    }
+    if (stats) stats[0] = stats[1] = stats[2] = 0;
+    if (B == 0 || T == 0) return SSMQ_OK;
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    std::vector<Traj> tr((size_t)B);
+    for (int64_t i = 0; i < (int64_t)B * T * D; ++i) fm[i] = nan;
+    for (int64_t i = 0; i < (int64_t)B * T * D * D; ++i) fP[i] = nan;
+    auto begin_step = [&](Traj &t, int64_t b) {        // the Laplace step of time step t.k starts from the prior (t.pm, t.pc)
+        if (!chol_lower(t.pc, P, t.Lp, &t.logdet2)) {  // numpy.linalg.cholesky would raise in _param_log_prior
+            t.mode = 2;
+            failed[b] = t.k;
+            return;
+        }
+        bfgs_start(t.run, P, t.pm);
+        t.mode = 0;
+    };
+    for (int64_t b = 0; b < B; ++b) {
+        Traj &t = tr[b];
+        std::memcpy(t.xm, x0_mean, sizeof(double) * D);
+        std::memcpy(t.xP, x0_cov, sizeof(double) * D * D);
+        std::memcpy(t.pm, prior_mean, sizeof(double) * P);
+        std::memcpy(t.pc, prior_cov, sizeof(double) * P * P);
+        failed[b] = 0;
+        begin_step(t, b);
+    }
+    auto log_prior = [&](const Traj &t, const double *th) {
+        double v[kMaxPar], q = 0.0;
+        for (int i = 0; i < P; ++i) {
+            double s = th[i] - t.pm[i];
+            for (int k = 0; k < i; ++k) s -= t.Lp[i * P + k] * v[k];
+            v[i] = s / t.Lp[i * P + i];
+            q += v[i] * v[i];
+        }
+        return -0.5 * (q + t.logdet2 + P * std::log(2.0 * M_PI));
+    };
+    std::vector<int64_t> who, first;
+    std::vector<double> rows, pd, po, mm, cc, yy, tt, ll, om, oc;
+    std::vector<int32_t> st;
+    const double inf = std::numeric_limits<double>::infinity();
+    int64_t rounds = 0, iters = 0, total_items = 0;
+    for (;;) {
+        who.clear(); first.clear();
+        int64_t items = 0;
+        for (int64_t b = 0; b < B; ++b)
+            if (tr[b].mode != 2) {
+                who.push_back(b);
+                first.push_back(items);
+                items += tr[b].mode == 0 ? P + 1 : NP;
+            }
+        if (who.empty()) break;
+        rows.resize((size_t)items * P); pd.resize((size_t)items * Pd); po.resize((size_t)items * Po);
+        mm.resize((size_t)items * Din); cc.assign((size_t)items * Din * Din, 0.0); yy.resize((size_t)items * Y); tt.resize((size_t)items);
+        ll.resize((size_t)items); om.resize((size_t)items * D); oc.resize((size_t)items * D * D); st.assign((size_t)items, 0);
+        for (size_t w = 0; w < who.size(); ++w) {
+            const int64_t b = who[w];
+            const Traj &t = tr[b];
+            const int n = t.mode == 0 ? P + 1 : NP;
+            for (int j = 0; j < n; ++j) {
+                const int64_t it = first[w] + j;
+                double *row = &rows[(size_t)it * P];
+                if (t.mode == 0)
+                    for (int i = 0; i < P; ++i) row[i] = t.run.xt[i] + ((j == i + 1) ? fd_step : 0.0);
+                else
+                    for (int i = 0; i < P; ++i) row[i] = t.pts[(size_t)j * P + i];
+                for (int i = 0; i < P; ++i) {
+                    const double e = std::exp(row[i]);            // the kernel parameters are exp(theta)
+                    if (i < Pd) pd[(size_t)it * Pd + i] = e;
+                    else po[(size_t)it * Po + (i - Pd)] = e;
+                }
+                // [mean; q_mean], blockdiag(cov, Q) for dynamics that take their noise as an argument (ssinf.py:1174-1176)
+                double *m = &mm[(size_t)it * Din], *c = &cc[(size_t)it * Din * Din];
+                for (int i = 0; i < D; ++i) {
+                    m[i] = t.xm[i];
+                    for (int k = 0; k < D; ++k) c[i * Din + k] = t.xP[i * D + k];
+                }
+                for (int i = 0; i < dq; ++i) {
+                    m[D + i] = q_mean[i];
+                    for (int k = 0; k < dq; ++k) c[(D + i) * Din + D + k] = q_cov[i * dq + k];
+                }
+                std::memcpy(&yy[(size_t)it * Y], y + ((size_t)b * T + (t.k - 1)) * Y, sizeof(double) * Y);
+                tt[(size_t)it] = (double)t.k;
+            }
+        }
+        const int rc = ssmq_gp_theta_step_times(h_dyn, f_dyn, h_obs, f_obs, items, pd.data(), po.data(), jitter, mm.data(), cc.data(), 0,
+                                                yy.data(), 0, tt.data(), GQG, R, om.data(), oc.data(), ll.data(), st.data());
+        if (rc < 0) return rc;
+        ++rounds;
+        total_items += items;
+        for (size_t w = 0; w < who.size(); ++w) {
+            const int64_t b = who[w];
+            Traj &t = tr[b];
+            if (t.mode == 0) {
+                double vals[kMaxPar + 1];
+                for (int j = 0; j <= P; ++j) {
+                    const int64_t it = first[w] + j;
+                    const double v = -ll[(size_t)it] - log_prior(t, &rows[(size_t)it * P]);
+                    vals[j] = std::isfinite(v) ? v : inf;
+                }
+                bfgs_advance(t.run, P, fd_step, vals);
+                if (t.run.phase != PH_DONE) continue;
+                iters += t.run.k;
+                // Laplace posterior (ssinf.py:1272-1273) and its sigma points (:1103-1106)
+                double pcn[kMaxPar * kMaxPar], L[kMaxPar * kMaxPar];
+                bool fin = true;
+                for (int i = 0; i < P; ++i) {
+                    t.pm[i] = t.run.x[i];
+                    fin = fin && std::isfinite(t.pm[i]);
+                    for (int k = 0; k < P; ++k) {
+                        pcn[i * P + k] = t.run.H[i * P + k] + (i == k ? param_jitter : 0.0);
+                        fin = fin && std::isfinite(pcn[i * P + k]);
+                    }
+                }
+                if (!fin || !chol_lower(pcn, P, L, nullptr)) {
+                    t.mode = 2;
+                    failed[b] = t.k;
+                    continue;
+                }
+                std::memcpy(t.pc, pcn, sizeof(double) * P * P);
+                for (int j = 0; j < NP; ++j)
+                    for (int i = 0; i < P; ++i) {
+                        double s = t.pm[i];
+                        for (int k = 0; k <= i; ++k) s += L[i * P + k] * upts[(size_t)k * NP + j];
+                        t.pts[(size_t)j * P + i] = s;
+                    }
+                t.mode = 1;
+            } else {
+                // mixture over the parameter points (ssinf.py:1108-1115): plain weighted sums of the conditional moments
+                bool ok = true;
+                for (int j = 0; j < NP; ++j) ok = ok && st[(size_t)(first[w] + j)] == 0;
+                double xm[SSMQ_MAX_DIM], xP[SSMQ_MAX_DIM * SSMQ_MAX_DIM];
+                for (int i = 0; i < D; ++i) xm[i] = 0.0;
+                for (int i = 0; i < D * D; ++i) xP[i] = 0.0;
+                for (int j = 0; j < NP; ++j) {
+                    const int64_t it = first[w] + j;
+                    for (int i = 0; i < D; ++i) xm[i] += om[(size_t)it * D + i] * uwts[j];
+                    for (int i = 0; i < D * D; ++i) xP[i] += oc[(size_t)it * D * D + i] * uwts[j];
+                }
+                for (int i = 0; i < D; ++i) ok = ok && std::isfinite(xm[i]);
+                for (int i = 0; i < D * D; ++i) ok = ok && std::isfinite(xP[i]);
+                if (!ok) {                               // where forward_pass raises LinAlgError for this trajectory
+                    t.mode = 2;
+                    failed[b] = t.k;
+                    continue;
+                }
+                std::memcpy(t.xm, xm, sizeof(double) * D);
+                std::memcpy(t.xP, xP, sizeof(double) * D * D);
+                std::memcpy(fm + ((size_t)b * T + (t.k - 1)) * D, xm, sizeof(double) * D);
+                std::memcpy(fP + ((size_t)b * T + (t.k - 1)) * D * D, xP, sizeof(double) * D * D);
+                if (t.k == T) {
+                    t.mode = 2;
+                } else {
+                    ++t.k;
+                    begin_step(t, b);
+                }
+            }
+        }
+    }
+    for (int64_t b = 0; b < B; ++b) {
+        if (theta_last) std::memcpy(theta_last + (size_t)b * P, tr[b].pm, sizeof(double) * P);
+        if (pcov_last) std::memcpy(pcov_last + (size_t)b * P * P, tr[b].pc, sizeof(double) * P * P);
+    }
+    if (stats) {
+        stats[0] = rounds; stats[1] = iters; stats[2] = total_items;
+    }
+    return SSMQ_OK;
 }

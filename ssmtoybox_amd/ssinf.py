@@ -617,8 +617,49 @@ class MarginalInference(GaussianInference):
 
     def forward_pass_batch(self, data, **kwargs):
         """data (dim_y, T, B) -> (D, T, B), (D, D, T, B): the Monte-Carlo loop around forward_pass (research/tpq/tpq_base.py:175-192;
-        every trajectory from the prior, as `reset()` leaves the filter) with ALL trajectories advanced together.  Per time step:
-        the Laplace step of every trajectory in lock step (`laplace_batch`: B x (param_dim + 1) theta items per device call), then the
+        every trajectory from the prior, as `reset()` leaves the filter), ONE call of `ssmq_gp_marginal_filter_batch`
+        (csrc/ssmq_marginal.hip): every trajectory walks its own Laplace steps (BFGS), mixtures over the parameter points and time
+        steps, and each device round serves whatever the unfinished trajectories are waiting for - the number of rounds is the
+        longest trajectory's, not the sum over the steps of the slowest one's (forward_pass_batch_stepwise).
+        `batch_failed[b]` = the step at which trajectory b failed (where forward_pass raises LinAlgError), 0 otherwise; its
+        moments are NaN from that step on.  `batch_stats`: device rounds, BFGS iterations, theta items."""
+        c = self._theta_static()
+        lib = _lib.load()
+        data = np.asarray(data, dtype=np.float64)
+        Y, T, B = data.shape
+        D, P = self.mod_dyn.dim_state, self.param_dim
+        self.reset()
+        y = np.ascontiguousarray(data.transpose(2, 1, 0))                      # (B, T, Y)
+        dp = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(_lib.c_double_p)   # noqa: E731
+        additive = self.mod_dyn.noise_additive
+        qm = None if additive else np.ascontiguousarray(np.atleast_1d(self.q_mean), dtype=np.float64)
+        qc = None if additive else np.ascontiguousarray(np.atleast_2d(self.q_cov), dtype=np.float64)
+        x0m, x0c = np.ascontiguousarray(self.x0_mean, dtype=np.float64), np.ascontiguousarray(self.x0_cov, dtype=np.float64)
+        pm0, pc0 = np.ascontiguousarray(self.param_prior_mean, dtype=np.float64), np.ascontiguousarray(self.param_prior_cov, dtype=np.float64)
+        upts, uwts = np.ascontiguousarray(self.param_upts, dtype=np.float64), np.ascontiguousarray(self.param_wts, dtype=np.float64)
+        fm, fP = np.empty((B, T, D)), np.empty((B, T, D, D))
+        failed = np.zeros(B, dtype=np.int32)
+        th, pcl = np.empty((B, P)), np.empty((B, P, P))
+        stats = (ctypes.c_int64 * 3)()
+        keep = (y, qm, qc, x0m, x0c, pm0, pc0, upts, uwts)                     # alive for the duration of the call
+        _lib.check(lib.ssmq_gp_marginal_filter_batch(
+            c['h_dyn'], ctypes.byref(c['f_dyn']), c['h_obs'], ctypes.byref(c['f_obs']), B, T, float(self.tf_dyn.model.kernel.jitter),
+            dp(y), dp(x0m), dp(x0c), dp(qm), dp(qc), dp(c['gqg']), dp(c['rr']), dp(pm0), dp(pc0), dp(upts), dp(uwts),
+            int(self.param_pts_num), float(self.fd_step), float(self.param_jitter[0, 0]), dp(fm), dp(fP),
+            failed.ctypes.data_as(_lib.c_int32_p), dp(th), dp(pcl), stats), 'ssmq_gp_marginal_filter_batch')
+        del keep
+        self.batch_failed = failed.astype(np.int64)
+        self.batch_stats = dict(rounds=int(stats[0]), iterations=int(stats[1]), items=int(stats[2]), fallbacks=0)
+        self.param_mean, self.param_cov = th[-1], pcl[-1]
+        self.fi_mean = np.ascontiguousarray(fm.transpose(2, 1, 0))
+        self.fi_cov = np.ascontiguousarray(fP.transpose(2, 3, 1, 0))
+        if B and T and not failed[-1]:
+            self.x_mean_fi, self.x_cov_fi = fm[-1, -1].copy(), fP[-1, -1].copy()
+        return self.fi_mean, self.fi_cov
+
+    def forward_pass_batch_stepwise(self, data, **kwargs):
+        """The same with the trajectories in lock step PER TIME STEP (round 4's first version, kept as a second route to the same
+        numbers): the Laplace step of every trajectory (`laplace_batch`: B x (param_dim + 1) theta items per device call), then the
         marginalisation over the 2 param_dim parameter sigma points of every trajectory in ONE call (B x 2 param_dim items).
         `batch_failed[b]` = the step at which trajectory b failed (where forward_pass raises LinAlgError), 0 otherwise; its
         moments are NaN from that step on.  `batch_stats`: device rounds, BFGS iterations."""

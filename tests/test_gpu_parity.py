@@ -1327,10 +1327,19 @@ def test_marginal_filter_batched_monte_carlo(amd, golden):
     e0 = np.abs(fmb[:, :, 0] - g['fwd_fm'][:, :T]) / np.maximum(1.0, np.abs(g['fwd_fm'][:, :T]))
     assert e0[:, 0].max() < 1e-4 and np.median(e0) < 1e-2
     # device calls: the lock step needs as many rounds as the SLOWEST trajectory of a step, not their sum
-    assert stats['rounds'] < 0.25 * (stats['iterations'] * 2 + B * T)
+    assert stats['rounds'] < 0.25 * (stats['iterations'] * 2 + B * T) and stats['fallbacks'] == 0
     # a batch of one is the same computation
     fm1, fP1 = alg.forward_pass_batch(data[:, :, 3:4])
     assert np.array_equal(fm1[..., 0], fmb[..., 3]) and np.array_equal(fP1[..., 0], fPb[..., 3])
+    # ... and so is the route that keeps the trajectories in lock step per time step (laplace_batch + one marginalisation call):
+    # same optimiser, same device items; only the host-side mixture sums differ in their order of summation
+    fmw, fPw = alg.forward_pass_batch_stepwise(data)
+    stw = dict(alg.batch_stats)
+    both = np.isfinite(fmw).all(axis=(0, 1)) & ok
+    ew = np.abs(fmb - fmw)[..., both] / np.maximum(1.0, np.abs(fmw[..., both]))
+    assert within(np.median(ew), 2e-4, 'batched marginal filter: own-pace route vs per-step lock step, means (median)')
+    assert stats['rounds'] < stw['rounds']                 # the longest trajectory's total against the sum of the slowest per step
+    print('rounds: own pace', stats['rounds'], 'per-step lock step', stw['rounds'])
 
 
 def test_marginal_filter_smoother_and_nonadditive_dynamics(amd, golden):
