@@ -97,7 +97,34 @@ def measure_theta_step(calls=1000):
             alg.theta_step(theta, m0, P0, y, 1)
         blocks.append((time.perf_counter() - t0) / (calls // 5) * 1e6)
     us = float(np.median(blocks))
-    return {'us_per_call': us, 'us_per_call_best_block': float(min(blocks)), 'items': P, 'theta_steps_per_s': P / (us * 1e-6), 'launches_per_call': 2,
+    # the same entry point at the item count of the batched marginalised filter: 8 192 items with a state of their own each
+    # (B (param_dim + 1) objective points of one optimiser round)
+    n_big = 8192
+    th_big = 0.1 * rng.standard_normal((n_big, alg.param_dim))
+    m_big, P_big = np.tile(m0, (n_big, 1)), np.tile(P0, (n_big, 1, 1))
+    y_big = rng.standard_normal((n_big, 1))
+    for _ in range(3):
+        alg.theta_step(th_big, m_big, P_big, y_big, 1)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        alg.theta_step(th_big, m_big, P_big, y_big, 1)
+    big_s = (time.perf_counter() - t0) / 10
+    # ... and the batched filter itself: UNGM, B = 1024 trajectories x T = 10 steps, every trajectory at its own pace
+    du = ssmod.UNGMTransition(ssmod.GaussRV(1), ssmod.GaussRV(1, cov=np.array([[10.0]])))
+    ou = ssmod.UNGMMeasurement(ssmod.GaussRV(1), 1)
+    mg = ssinf.MarginalizedGaussianProcessKalman(du, ou, 'rbf', 'sr')
+    _, yu = simulate_ungm(1024, 10, 5)
+    du_data = np.ascontiguousarray(yu[None])
+    mg.forward_pass_batch(du_data[:, :, :64])
+    t0 = time.perf_counter()
+    mg.forward_pass_batch(du_data)
+    mg_s = time.perf_counter() - t0
+    batch = {'us_per_trajectory_step': 1e6 * mg_s / (1024 * 10), 'ms_per_time_step': 1e3 * mg_s / 10, 'trajectories': 1024, 'time_steps': 10,
+             'device_rounds': mg.batch_stats['rounds'], 'bfgs_iterations': mg.batch_stats['iterations'], 'theta_items': mg.batch_stats['items'],
+             'failed_trajectories': int((mg.batch_failed > 0).sum()),
+             'workload': 'MarginalizedGaussianProcessKalman.forward_pass_batch on UNGM (ssmq_gp_marginal_filter_batch: B BFGS runs, one theta '
+                         'step per round; the reference: one scipy BFGS per trajectory and step, ~1.5 ms per trajectory-step here)'}
+    return {'items_8192_ms_per_call': 1e3 * big_s, 'items_8192_per_s': n_big / big_s, 'marginal_filter_batch': batch, 'us_per_call': us, 'us_per_call_best_block': float(min(blocks)), 'items': P, 'theta_steps_per_s': P / (us * 1e-6), 'launches_per_call': 2,
             'kernels': ['k_theta_weights', 'k_theta_chain'],
             'workload': 'MarginalizedGaussianProcessKalman.theta_step, pendulum 2-D + 1-D measurement, spherical-radial points, '
                         '%d parameter items (param_dim + 1), host arrays in and out' % P}

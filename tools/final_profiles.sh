@@ -2,7 +2,7 @@
 # Produces the artefacts committed under profiles/: bench JSON, rocprofv3 kernel stats of the same command, PMC traffic.
 set -e
 export TMPDIR=/tmp
-tag=${1:-r03_final}
+tag=${1:-r04_final}
 out=gpurun_out/$tag
 mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
