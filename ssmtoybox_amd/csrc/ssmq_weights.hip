@@ -17,6 +17,8 @@
 //      solution columns in registers (one CU alone is instruction-bound on the 2 N^3 / 3 multiply-adds);
 //   3. k_weights<1024>, stage 2: expectations and the weight algebra, every N x N x N product through LDS tiles with
 //      4 x 4 register blocks and operands fetched one slab ahead.
+// Beyond N = 201 (the degree-7 rule at D = 10: 1 181 points) the factor no longer fits a CU: blocked Cholesky, inverse and the two
+// N^3 products as many-workgroup launches (k_wb_*, further down), the rest in stages 3 / 4 of k_weights<1024>.
 // The algebra follows the reference step by step (explicit inverse, symmetrisation, jitter placement) because the
 // results are only reproducible to cond(K) eps, not because it is the best-conditioned route.
 #include <algorithm>
@@ -50,6 +52,33 @@ struct WgtArgs {
 };
 
 __device__ __forceinline__ void bsync() { __syncthreads(); }
+
+// offsets (doubles) of the blocks of one parameter row's workspace; the launcher of the large-N route needs M1, M2 and T4 too
+struct WgtCarve {
+    int64_t gA, gX, M1, M2, zs, nrm, V, Z, G, iG, kx, T1, T2, bv, Dm, T3, T4, end;
+    __host__ __device__ WgtCarve(int64_t D, int64_t N, int64_t NB) {
+        int64_t w = 0;
+        const int64_t nn = N * N;
+        gA = w; w += nn;
+        gX = w; w += nn;
+        M1 = w; w += nn;
+        M2 = w; w += nn;
+        zs = w; w += D * N;       // length-scale-normalised points
+        nrm = w; w += N;
+        V = w; w += N * NB;       // Vandermonde (N x NB)
+        Z = w; w += NB * N;       // V' iK
+        G = w; w += NB * NB;      // V' iK V + 1e-8 I  -> Cholesky factor
+        iG = w; w += NB * NB;     // its inverse ("iViKV")
+        kx = w; w += N * NB;      // E[k(x, x_n) p_q(x)]
+        T1 = w; w += nn;
+        T2 = w; w += nn;
+        bv = w; w += NB;
+        Dm = w; w += D * NB;      // D = R Z' - xpx       (D x NB)
+        T3 = w; w += nn;
+        T4 = w; w += nn;
+        end = w;
+    }
+};
 
 // C (M x N, ldc) = op(A) op(B); op(A) is M x K, op(B) is K x N.  Block-cooperative; ends with a barrier.
 __device__ void gemm(double *C, int ldc, const double *A, int lda, bool ta, const double *B, int ldb, bool tb, int M,
@@ -354,6 +383,329 @@ __device__ void gemm_tiled(double *tile, double *C, int ldc, const double *A, in
     bsync();
 }
 
+// ---- point sets beyond the CU-resident route (N > 201; the degree-7 rule at D = 10 has 1 181 points) ---------------------
+// One workgroup per parameter row spent 0.98 s on N = 1 181 (factor, inverse and products of one row on ONE CU out of 256).
+// The three O(N^3) parts go to many workgroups, one launch per dependency level:
+//   k_wb_kmatrix                       K + jitter I, element per thread
+//   k_wb_chol_panel / k_wb_chol_update right-looking Cholesky in 64-column blocks: every workgroup of a panel launch factors the
+//                                      64 x 64 diagonal block itself (LDS), workgroup 0 stores it, the others solve 64 rows of the
+//                                      panel each; the update launch subtracts the panel's outer product from the trailing
+//                                      lower triangle, one 64 x 64 tile per workgroup.  Every element receives its updates one k
+//                                      at a time in ascending k, as chol_block applies them: the factor is the same, bit for bit.
+//                                      The transposed factor is written into the (otherwise unused) upper triangle.
+//   k_wb_inverse                       cho_solve against I: a WAVE owns CPW columns in registers (slot q of lane l = row 64 q + l),
+//                                      rows of L for the forward pass, rows of L' (the upper triangle) for the backward pass
+//   k_wb_gemm                          C = A B, one 64 x 64 tile per workgroup, the sums in gemm_tiled's order
+// The remaining algebra (all of it O(N^2 NB) or less) stays in k_weights<1024>, split at the two large products (stage 3 / 4).
+constexpr int kCb = 64, kCbPitch = kCb + 1;
+constexpr size_t kCbLds = sizeof(double) * (2 * kCb * kCbPitch + kCb);
+
+__global__ __launch_bounds__(256) void k_wb_kmatrix(const WgtArgs a) {
+    const int p = blockIdx.y, N = a.N, D = a.D;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.status[p] = 0;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)N * N) return;
+    const double *par = a.par + (int64_t)p * (1 + D);
+    const int i = (int)(idx / N), j = (int)(idx % N);
+    double ni = 0.0, nj = 0.0, dot = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double sl = 1.0 / par[1 + d];
+        const double zi = sl * a.xi[d * N + i], zj = sl * a.xi[d * N + j];
+        ni += zi * zi;
+        nj += zj * zj;
+        dot += zi * zj;
+    }
+    const double mh = (ni + nj) - 2.0 * dot;
+    a.work[(int64_t)p * a.work_stride + idx] = exp(0.0 - 0.5 * mh) + (i == j ? a.jitter : 0.0);
+}
+
+// grid (row chunks from the diagonal block downwards, P)
+__global__ __launch_bounds__(256) void k_wb_chol_panel(int N, int kb, double *__restrict__ work, int64_t work_stride,
+                                                       int32_t *status) {
+    extern __shared__ __align__(16) double sm[];
+    double *sD = sm, *sR = sm + kCb * kCbPitch, *sInv = sR + kCb * kCbPitch;
+    const int p = blockIdx.y, tid = threadIdx.x;
+    if (status[p] != 0) return;
+    double *A = work + (int64_t)p * work_stride;
+    const int c0 = kb * kCb, bs = min(kCb, N - c0);
+    for (int idx = tid; idx < bs * bs; idx += 256) {
+        const int i = idx / bs, j = idx % bs;
+        sD[i * kCbPitch + j] = (j <= i) ? A[(int64_t)(c0 + i) * N + c0 + j] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < bs; ++k) {
+        const double pv = sD[k * kCbPitch + k];
+        if (!(pv > 0.0)) {                       // uniform: every thread of every workgroup of the launch reads the same pivot
+            if (blockIdx.x == 0 && tid == 0) status[p] = 1;
+            return;
+        }
+        const double lkk = sqrt(pv), r = 1.0 / lkk;
+        __syncthreads();
+        if (tid == 0) { sD[k * kCbPitch + k] = lkk; sInv[k] = r; }
+        for (int i = k + 1 + tid; i < bs; i += 256) sD[i * kCbPitch + k] *= r;
+        __syncthreads();
+        const int m = bs - k - 1;
+        for (int idx = tid; idx < m * m; idx += 256) {
+            const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+            if (j <= i) sD[i * kCbPitch + j] -= sD[i * kCbPitch + k] * sD[j * kCbPitch + k];
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        for (int idx = tid; idx < bs * bs; idx += 256) {
+            const int i = idx / bs, j = idx % bs;
+            if (j <= i) {
+                const double v = sD[i * kCbPitch + j];
+                A[(int64_t)(c0 + i) * N + c0 + j] = v;
+                if (j < i) A[(int64_t)(c0 + j) * N + c0 + i] = v;
+            }
+        }
+        return;
+    }
+    // 64 rows of the panel below the diagonal block (bs == 64 whenever there is such a row)
+    const int r0 = c0 + kCb * blockIdx.x, nr = min(kCb, N - r0);
+    for (int idx = tid; idx < nr * kCb; idx += 256) {
+        const int t = idx / kCb, k = idx % kCb;
+        sR[t * kCbPitch + k] = A[(int64_t)(r0 + t) * N + c0 + k];
+    }
+    __syncthreads();
+    if (tid < nr) {
+        double *row = sR + tid * kCbPitch;
+        for (int k = 0; k < kCb; ++k) {
+            const double l = row[k] * sInv[k];
+            row[k] = l;
+            for (int j = k + 1; j < kCb; ++j) row[j] -= l * sD[j * kCbPitch + k];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nr * kCb; idx += 256) {
+        const int t = idx / kCb, k = idx % kCb;
+        A[(int64_t)(r0 + t) * N + c0 + k] = sR[t * kCbPitch + k];
+    }
+    for (int idx = tid; idx < nr * kCb; idx += 256) {
+        const int k = idx / nr, t = idx % nr;
+        A[(int64_t)(c0 + k) * N + r0 + t] = sR[t * kCbPitch + k];   // L' into the upper triangle
+    }
+}
+
+// grid (tile pairs ti >= tj of the trailing triangle, P)
+__global__ __launch_bounds__(256) void k_wb_chol_update(int N, int kb, double *__restrict__ work, int64_t work_stride,
+                                                        const int32_t *status) {
+    extern __shared__ __align__(16) double sm[];
+    double *sI = sm, *sJ = sm + kCb * kCbPitch;
+    const int p = blockIdx.y, tid = threadIdx.x;
+    if (status[p] != 0) return;
+    double *A = work + (int64_t)p * work_stride;
+    const int c0 = kb * kCb, t0 = c0 + kCb;
+    const int bx = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * bx + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > bx) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= bx) ++ti;
+    const int tj = bx - ti * (ti + 1) / 2;
+    const int i0 = t0 + kCb * ti, j0 = t0 + kCb * tj;
+    for (int idx = tid; idx < kCb * kCb; idx += 256) {
+        const int t = idx / kCb, k = idx % kCb;
+        sI[t * kCbPitch + k] = (i0 + t < N) ? A[(int64_t)(i0 + t) * N + c0 + k] : 0.0;
+        sJ[t * kCbPitch + k] = (j0 + t < N) ? A[(int64_t)(j0 + t) * N + c0 + k] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gi = i0 + 4 * ty + r, gj = j0 + 4 * tx + q;
+            acc[r][q] = (gi < N && gj <= gi) ? A[(int64_t)gi * N + gj] : 0.0;
+        }
+    for (int k = 0; k < kCb; ++k) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = sI[(4 * ty + r) * kCbPitch + k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = sJ[(4 * tx + q) * kCbPitch + k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r][q] -= av[r] * bv[q];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gi = i0 + 4 * ty + r, gj = j0 + 4 * tx + q;
+            if (gi < N && gj <= gi) A[(int64_t)gi * N + gj] = acc[r][q];
+        }
+}
+
+// sum over the 64 lanes of a wave, to every lane (as a uniform value): the DPP row sums, then one lane of each row
+__device__ __forceinline__ double wave_sum(double v) {
+    v = row_sum(v);
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * r);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * r);
+        s += __hiloint2double(hi, lo);
+    }
+    return s;
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {      // lane: uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// grid (ceil(N / (4 CPW)), P), 256 threads = 4 waves, each with CPW columns of the inverse; N <= 64 S.  The matrix holds L in
+// its lower triangle and L' in the upper one; the solution columns go to gX TRANSPOSED (row c of gX = column c of the
+// inverse: coalesced; the caller symmetrises 0.5 (X + X'), which does not care).
+template <int S, int CPW>
+__global__ __launch_bounds__(256) void k_wb_inverse(int N, double *__restrict__ work, int64_t work_stride, const int32_t *status) {
+    const int p = blockIdx.y;
+    if (status[p] != 0) return;
+    const double *A = work + (int64_t)p * work_stride;
+    double *Xt = work + (int64_t)p * work_stride + (int64_t)N * N;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int cb = (blockIdx.x * 4 + wave) * CPW;
+    if (cb >= N) return;
+    double x[CPW][S];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int q = 0; q < S; ++q) x[c][q] = 0.0;
+    const int qb = cb >> 6;
+    // forward: y_i = (e_c[i] - sum_{k < i} L[i][k] y_k) / L[i][i], y_k = 0 for k < c
+#pragma unroll
+    for (int qi = 0; qi < S; ++qi) {
+        if (qi < qb || 64 * qi >= N) continue;
+        for (int ii = 0; ii < 64; ++ii) {
+            const int i = 64 * qi + ii;
+            if (i < cb || i >= N) continue;
+            const double *row = A + (int64_t)i * N;
+            double sp[CPW];
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) sp[c] = 0.0;
+#pragma unroll
+            for (int q = 0; q <= qi; ++q) {
+                if (q < qb) continue;
+                const bool in = q < qi || lane < ii;
+                const double l = in ? row[64 * q + lane] : 0.0;
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) sp[c] += l * x[c][q];
+            }
+            const double dii = row[i];
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const double s = wave_sum(sp[c]);
+                const double y = (i >= cb + c) ? div_nr((i == cb + c ? 1.0 : 0.0) - s, dii) : 0.0;
+                x[c][qi] = (lane == ii) ? y : x[c][qi];
+            }
+        }
+    }
+    // backward: x_i = (y_i - sum_{k > i} L[k][i] x_k) / L[i][i];  L[k][i] = A[i][k] for k > i
+#pragma unroll
+    for (int qi = S - 1; qi >= 0; --qi) {
+        if (64 * qi >= N) continue;
+        for (int ii = 63; ii >= 0; --ii) {
+            const int i = 64 * qi + ii;
+            if (i >= N) continue;
+            const double *row = A + (int64_t)i * N;
+            double sp[CPW];
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) sp[c] = 0.0;
+#pragma unroll
+            for (int q = qi; q < S; ++q) {
+                if (64 * q >= N) continue;
+                const int k = 64 * q + lane;
+                const bool in = (q > qi || lane > ii) && k < N;
+                const double l = in ? row[k] : 0.0;
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) sp[c] += l * x[c][q];
+            }
+            const double dii = row[i];
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const double s = wave_sum(sp[c]);
+                const double v = div_nr(lane_value(x[c][qi], ii) - s, dii);
+                x[c][qi] = (lane == ii) ? v : x[c][qi];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        if (cb + c >= N) continue;
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            const int k = 64 * q + lane;
+            if (k < N) Xt[(int64_t)(cb + c) * N + k] = x[c][q];
+        }
+    }
+}
+
+// C (M x N, ldc) = A (M x K, row-major) B (K x N, row-major): grid (ceil(N / 64), ceil(M / 64), P), 256 threads, 4 x 4 outputs per
+// thread, K in slabs of 16 fetched one slab ahead; k ascends inside every output's sum exactly as in gemm_tiled.
+__global__ __launch_bounds__(256) void k_wb_gemm(double *__restrict__ Cb, int64_t c_stride, int ldc, const double *__restrict__ Ab,
+                                                 int64_t a_stride, int lda, const double *__restrict__ Bb, int64_t b_stride, int ldb,
+                                                 int M, int N, int K, const int32_t *status) {
+    constexpr int TM = 64, TK = 16, TP = TM + 4, PER = TK * TM / 256;
+    __shared__ __align__(16) double sA[TK * TP], sB[TK * TP];
+    const int p = blockIdx.z, tid = threadIdx.x;
+    if (status[p] != 0) return;
+    const double *A = Ab + p * a_stride, *B = Bb + p * b_stride;
+    double *C = Cb + p * c_stride;
+    const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TM;
+    const int tx = tid & 15, ty = tid >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r][q] = 0.0;
+    double ra[PER], rb[PER];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * 256;
+            const int ii = idx / TK, kk = idx % TK;
+            const int gi = i0 + ii, gk = k0 + kk;
+            ra[u] = (gi < M && gk < K) ? A[(int64_t)gi * lda + gk] : 0.0;
+            const int kb = idx / TM, jj = idx % TM;
+            const int gj = j0 + jj, gkb = k0 + kb;
+            rb[u] = (gj < N && gkb < K) ? B[(int64_t)gkb * ldb + gj] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += TK) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * 256;
+            sA[(idx % TK) * TP + idx / TK] = ra[u];
+            sB[(idx / TM) * TP + idx % TM] = rb[u];
+        }
+        __syncthreads();
+        if (k0 + TK < K) fetch(k0 + TK);
+#pragma unroll
+        for (int kk = 0; kk < TK; ++kk) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[r] = sA[kk * TP + ty * 4 + r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = sB[kk * TP + tx * 4 + q];
+            if (k0 + kk < K) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[r][q] += av[r] * bv[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gi = i0 + ty * 4 + r, gj = j0 + tx * 4 + q;
+            if (gi < M && gj < N) C[(int64_t)gi * ldc + gj] = acc[r][q];
+        }
+}
+
 __device__ double block_sum(double v, double *red) {
     // all threads of the block -> one value (to every thread); waves added in index order
 #pragma unroll
@@ -418,12 +770,8 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
     const double alpha = par[0];
     double *w = o.work;
     // workspace carve-up (global); A and X move to LDS when they fit
-    double *gA = w; w += N * N;
-    double *gX = w; w += N * N;
-    double *M1 = w; w += N * N;
-    double *M2 = w; w += N * N;
-    double *zs = w; w += D * N;       // length-scale-normalised points
-    double *nrm = w; w += N;
+    const WgtCarve cv(D, N, NB);
+    double *gA = w + cv.gA, *gX = w + cv.gX, *M1 = w + cv.M1, *M2 = w + cv.M2, *zs = w + cv.zs, *nrm = w + cv.nrm;
     const bool large = a.use_lds == 2;       // N > 64: packed factor in LDS, tiles afterwards (1024 threads)
     double *A = a.use_lds == 1 ? lds : gA;
     double *X = a.use_lds == 1 ? lds + N * N : gX;
@@ -444,7 +792,11 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
     }
     bsync();
     bool pd = true;
-    if (a.stage != 2) {
+    // stages 3 / 4 (point sets beyond the CU-resident route): the factor, the inverse (in gX, transposed - symmetrised below) and
+    // the two N x N x N products come from the k_wb_* launches; stage 3 runs up to the products, stage 4 from there
+    const bool front = a.stage != 4;
+    if (a.stage == 4 && *o.status != 0) return;  // stage 3 has poisoned the outputs (or flagged the polynomial part)
+    if (a.stage < 2) {
     for (int idx = tid; idx < N * N; idx += kWgtBlock) {
         const int i = idx / N, j = idx % N;
         if (large && j > i) continue;
@@ -477,10 +829,12 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
         if (tid == 0) { *o.mv = nan; *o.iv = nan; }
         return;
     }
-    if (a.stage == 0) chol_inverse(A, X, N);     // stage 2: k_weights_inverse has filled X
-    for (int idx = tid; idx < N * N; idx += kWgtBlock) {
-        const int i = idx / N, j = idx % N;
-        oiK[idx] = 0.5 * (X[i * N + j] + X[j * N + i]);
+    if (a.stage == 0) chol_inverse(A, X, N);     // stages 2 / 3: k_weights_inverse / k_wb_inverse has filled X
+    if (front) {
+        for (int idx = tid; idx < N * N; idx += kWgtBlock) {
+            const int i = idx / N, j = idx % N;
+            oiK[idx] = 0.5 * (X[i * N + j] + X[j * N + i]);
+        }
     }
     bsync();
     const double *iK = oiK;
@@ -495,6 +849,7 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
     cq = 1.0 / sqrt(cq);   // det(Lam^-1 + I) ** -0.5
     cQ = 1.0 / sqrt(cQ);   // det(2 Lam^-1 + I) ** -0.5
     const double kbar = alpha * alpha * (1.0 / sqrt(ck));
+    if (front) {
     for (int n = tid; n < N; n += kWgtBlock) {
         double s = 0.0;
         for (int d = 0; d < D; ++d) {
@@ -531,14 +886,20 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
             oQ[idx] = cQ * exp(e);
         }
     }
+    }   // front
     bsync();
 
     if (NB == 0) {
         // ---- GP weights (bq/bqmod.py:495-523) -------------------------------------------------------------------------
-        GEMM(owm, N, oq, N, false, iK, N, false, 1, N, N);          // wm = q iK
-        GEMM(M1, N, oQ, N, false, iK, N, false, N, N, N);           // M1 = Q iK
-        GEMM(M2, N, iK, N, false, M1, N, false, N, N, N);           // M2 = iK Q iK
-        GEMM(oWcc, N, oR, N, false, iK, N, false, D, N, N);         // Wcc = R iK
+        if (front) {
+            GEMM(owm, N, oq, N, false, iK, N, false, 1, N, N);          // wm = q iK
+            GEMM(oWcc, N, oR, N, false, iK, N, false, D, N, N);         // Wcc = R iK
+        }
+        if (a.stage == 3) return;                                       // M1, M2: two k_wb_gemm launches
+        if (a.stage != 4) {
+            GEMM(M1, N, oQ, N, false, iK, N, false, N, N, N);           // M1 = Q iK
+            GEMM(M2, N, iK, N, false, M1, N, false, N, N, N);           // M2 = iK Q iK
+        }
         for (int idx = tid; idx < N * N; idx += kWgtBlock) {
             const int i = idx / N, j = idx % N;
             oWc[idx] = 0.5 * (M2[i * N + j] + M2[j * N + i]);
@@ -555,14 +916,9 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
     }
 
     // ---- Bayes-Sard weights (bq/bqmod.py:893-992) -----------------------------------------------------------------------
-    double *V = w; w += N * NB;       // Vandermonde (N x NB)
-    double *Z = w; w += NB * N;       // V' iK
-    double *G = w; w += NB * NB;      // V' iK V + 1e-8 I  -> Cholesky factor
-    double *iG = w; w += NB * NB;     // its inverse ("iViKV")
-    double *kx = w; w += N * NB;      // E[k(x, x_n) p_q(x)]
-    double *T1 = w; w += N * N;
-    double *T2 = w; w += N * N;
-    double *bv = w; w += NB;
+    double *V = w + cv.V, *Z = w + cv.Z, *G = w + cv.G, *iG = w + cv.iG, *kx = w + cv.kx, *T1 = w + cv.T1, *T2 = w + cv.T2,
+           *bv = w + cv.bv;
+    if (front) {
     for (int idx = tid; idx < N * NB; idx += kWgtBlock)
         bs_basis_entry(D, N, NB, idx / NB, idx % NB, a.xi, a.mulind, s_sil, V[idx], kx[idx]);
     bsync();
@@ -577,6 +933,7 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
         return;
     }
     chol_inverse(G, iG, NB);                                 // cho_solve(cho_factor(.), I): not symmetrised
+    }   // front
     const double ks2 = alpha * alpha;
     if (NB == N && !a.var_mode) {
         // pi-unisolvent points: weights from the inverse Vandermonde matrix only (:952-961)
@@ -620,9 +977,8 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
     // general case NB < N (:963-982)
     double *Am = T1;                     // A = V iViKV          (N x NB)
     double *Bm = T2;                     // B                    (NB x NB)
-    double *Dm = w; w += D * NB;         // D = R Z' - xpx       (D x NB)
-    double *T3 = w; w += N * N;
-    double *T4 = w; w += N * N;
+    double *Dm = w + cv.Dm, *T3 = w + cv.T3, *T4 = w + cv.T4;
+    if (front) {
     GEMM(Am, NB, V, NB, false, iG, NB, false, N, NB, NB);
     // b = Z q - px
     for (int i = tid; i < NB; i += kWgtBlock) {
@@ -657,8 +1013,12 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
     GEMM(T4, N, T3, NB, false, Am, NB, true, N, N, NB);                     // A B A'      (N x N)
     for (int idx = tid; idx < N * N; idx += kWgtBlock) T4[idx] = oQ[idx] - T4[idx];
     bsync();
-    GEMM(M1, N, T4, N, false, iK, N, false, N, N, N);
-    GEMM(M2, N, iK, N, false, M1, N, false, N, N, N);
+    }   // front
+    if (a.stage == 3) return;                                // M1 = T4 iK, M2 = iK M1: two k_wb_gemm launches
+    if (a.stage != 4) {
+        GEMM(M1, N, T4, N, false, iK, N, false, N, N, N);
+        GEMM(M2, N, iK, N, false, M1, N, false, N, N, N);
+    }
     for (int idx = tid; idx < N * N; idx += kWgtBlock) {
         const int i = idx / N, j = idx % N;
         oWc[idx] = 0.5 * (M2[i * N + j] + M2[j * N + i]);
@@ -669,11 +1029,14 @@ __device__ void weights_body(const WgtArgs &a, const WgtOut &o, int p, double *l
     bsync();
     GEMM(oWcc, N, T3, N, false, iK, N, false, D, N, N);
     // model_var = ks2 (1 - tr(Q iK) + tr(B iViKV)); integral_var = kbar - q' iK q + b' iViKV b
-    GEMM(M1, N, oQ, N, false, iK, N, false, N, N, N);
+    // tr(Q iK): only the diagonal of the product is needed - the same sums, in the same order, as the full N x N x N product
+    // this used to take (iK is symmetric bit for bit, so its row n serves as its column n)
     GEMM(T3, NB, Bm, NB, false, iG, NB, false, NB, NB, NB);
     double tr1 = 0.0, tr2 = 0.0, qq = 0.0, bb = 0.0;
     for (int n = tid; n < N; n += kWgtBlock) {
-        tr1 += M1[n * N + n];
+        double d1 = 0.0;
+        for (int k = 0; k < N; ++k) d1 += oQ[n * N + k] * iK[n * N + k];
+        tr1 += d1;
         double s = 0.0;
         for (int k = 0; k < N; ++k) s += iK[n * N + k] * oq[k];
         qq += oq[n] * s;
@@ -783,6 +1146,60 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
         attr_epoch = ssmq::device_epoch();
     }
     const bool staged = packed <= lds_cap && N <= kInvLanes * kInvSlots && !getenv("SSMQ_WEIGHTS_NO_LDS");
+    const bool unisolvent = a.NB == N && !a.var_mode;      // N x N LU inverse in one workgroup: not a large-N case in practice
+    if (!staged && !unisolvent && !getenv("SSMQ_WEIGHTS_ONE_WG")) {
+        // factor, inverse and the two N^3 products on many workgroups (k_wb_*), the rest in k_weights<1024> stages 3 and 4
+        static unsigned wb_epoch = 0;
+        if (wb_epoch != ssmq::device_epoch()) {
+            SSMQ_HIP(hipFuncSetAttribute((const void *)k_wb_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCbLds));
+            SSMQ_HIP(hipFuncSetAttribute((const void *)k_wb_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCbLds));
+            wb_epoch = ssmq::device_epoch();
+        }
+        a.use_lds = 0;
+        a.tiled = 1;
+        const int P = a.P, nblk = (N + kCb - 1) / kCb;
+        hipLaunchKernelGGL(k_wb_kmatrix, dim3((unsigned)((nn + 255) / 256), P), dim3(256), 0, s, a);
+        for (int kb = 0; kb < nblk; ++kb) {
+            hipLaunchKernelGGL(k_wb_chol_panel, dim3(nblk - kb, P), dim3(256), kCbLds, s, N, kb, a.work, a.work_stride, a.status);
+            const int m = nblk - kb - 1;
+            if (m > 0)
+                hipLaunchKernelGGL(k_wb_chol_update, dim3(m * (m + 1) / 2, P), dim3(256), kCbLds, s, N, kb, a.work, a.work_stride,
+                                   a.status);
+        }
+        int rc = hip_fail(hipGetLastError(), "k_wb_chol");
+        if (rc) return rc;
+        const int slots = (N + 63) / 64;
+#define SSMQ_WB_INV(S, CPW) \
+        hipLaunchKernelGGL((k_wb_inverse<S, CPW>), dim3((N + 4 * CPW - 1) / (4 * CPW), P), dim3(256), 0, s, N, a.work, a.work_stride, \
+                           a.status)
+        if (slots <= 12) SSMQ_WB_INV(12, 2);
+        else if (slots <= 20) SSMQ_WB_INV(20, 2);
+        else if (slots <= 32) SSMQ_WB_INV(32, 1);
+        else SSMQ_WB_INV(64, 1);
+#undef SSMQ_WB_INV
+        if ((rc = hip_fail(hipGetLastError(), "k_wb_inverse"))) return rc;
+        a.stage = 3;
+        hipLaunchKernelGGL(k_weights<1024>, dim3(P), dim3(1024), tiles, s, a);
+        const int NB = a.NB;
+        const WgtCarve cv(a.D, N, NB);
+        const int64_t off_m1 = cv.M1, off_m2 = cv.M2, off_t4 = cv.T4;
+        if (cv.end > a.work_stride) {
+            set_error("weights: workspace smaller than its carve-up");
+            return SSMQ_E_ARG;
+        }
+        const dim3 gg((N + 63) / 64, (N + 63) / 64, P);
+        if (NB == 0)
+            hipLaunchKernelGGL(k_wb_gemm, gg, dim3(256), 0, s, a.work + off_m1, a.work_stride, N, a.Q, (int64_t)nn, N, a.iK,
+                               (int64_t)nn, N, N, N, N, a.status);
+        else
+            hipLaunchKernelGGL(k_wb_gemm, gg, dim3(256), 0, s, a.work + off_m1, a.work_stride, N, a.work + off_t4, a.work_stride, N,
+                               a.iK, (int64_t)nn, N, N, N, N, a.status);
+        hipLaunchKernelGGL(k_wb_gemm, gg, dim3(256), 0, s, a.work + off_m2, a.work_stride, N, a.iK, (int64_t)nn, N, a.work + off_m1,
+                           a.work_stride, N, N, N, N, a.status);
+        a.stage = 4;
+        hipLaunchKernelGGL(k_weights<1024>, dim3(P), dim3(1024), tiles, s, a);
+        return hip_fail(hipGetLastError(), "k_weights(large)");
+    }
     if (!staged) {
         // K, its factor and its inverse in the (L2-resident) workspace; the products still run through LDS tiles - the same
         // sums in the same order as gemm(), which streamed both operands of every dot product from L2 (N = 1 181: 2.5 s)

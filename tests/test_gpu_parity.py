@@ -2632,6 +2632,59 @@ def test_theta_batched_weights_large(amd):
             assert within(rel_err(w[key][i], ref[key]), capped(bar, what), what)
 
 
+def test_many_workgroup_weights_route(amd, monkeypatch):
+    """Point sets beyond the CU-resident route (N > 201): factor, inverse and the two N^3 products on many workgroups
+    (k_wb_*, csrc/ssmq_weights.hip) against the single-workgroup route of earlier rounds (SSMQ_WEIGHTS_ONE_WG=1), three
+    parameter rows in one call, the middle one not positive definite (NaN length scale): status and NaN outputs for that row
+    only.  GP on N = 300 random points at D = 3, then Bayes-Sard (10 basis functions) through the transform on the same set
+    shape (N = 343: Gauss-Hermite degree 7 at D = 3)."""
+    from ssmtoybox_amd.bq.bqkern import device_gp_weights
+    from ssmtoybox_amd import _lib as _amdlib
+    rng = np.random.default_rng(12)
+    pts = rng.standard_normal((3, 300))
+    pars = np.array([[1.0, 0.6, 0.7, 0.5], [1.0, np.nan, 1.0, 1.0], [1.3, 0.4, 0.5, 0.6]])
+    monkeypatch.delenv('SSMQ_WEIGHTS_ONE_WG', raising=False)
+    with pytest.raises(np.linalg.LinAlgError):
+        device_gp_weights(pts, pars)
+    rows = pars[[0, 2]]
+    new = device_gp_weights(pts, rows)
+    monkeypatch.setenv('SSMQ_WEIGHTS_ONE_WG', '1')
+    old = device_gp_weights(pts, rows)
+    monkeypatch.delenv('SSMQ_WEIGHTS_ONE_WG')
+    assert not new['status'].any() and not old['status'].any()
+    for i in range(2):
+        cond = np.linalg.cond(orc.rbf_eval(rows[i], pts, scaling=False) + 1e-8 * np.eye(300))
+        assert np.array_equal(new['Q'][i], old['Q'][i]) and np.array_equal(new['q'][i], old['q'][i])
+        for key, bar in (('iK', 64 * cond * 2.2e-16), ('wm', 64 * cond * 2.2e-16), ('Wcc', 64 * cond * 2.2e-16),
+                         ('Wc', 8 * cond ** 2 * 2.2e-16)):
+            what = 'many-workgroup weights row {} {} vs one workgroup'.format(i, key)
+            assert within(rel_err(new[key][i], old[key][i]), capped(max(1e-12, bar), what), what)
+        assert np.array_equal(new['Wc'][i], new['Wc'][i].T)
+    # the status of the row that fails, next to two that do not (low-level call: the wrapper raises on the first failure)
+    lib = _amdlib.load()
+    x, px = _amdlib.as_c(pts)
+    par, pp = _amdlib.as_c(pars)
+    wm, Wc = _amdlib.out_c((3, 300)), _amdlib.out_c((3, 300, 300))
+    st = np.zeros(3, dtype=np.int32)
+    rc = lib.ssmq_weights_gp(3, 300, px, pp, 3, 1e-8, wm[1], Wc[1], None, None, None, None, None, None, None,
+                             st.ctypes.data_as(_amdlib.c_int32_p))
+    assert rc == 2 and list(st) == [0, 1, 0]
+    assert np.isnan(wm[0][1]).all() and np.isnan(Wc[0][1]).all()
+    assert np.array_equal(wm[0][0], new['wm'][0]) and np.array_equal(Wc[0][2], new['Wc'][1])
+    # Bayes-Sard, general branch
+    mi = np.array([[0, 1, 0, 0, 2, 1, 1, 0, 0, 0], [0, 0, 1, 0, 0, 1, 0, 2, 1, 0], [0, 0, 0, 1, 0, 0, 1, 0, 1, 2]])
+    par = np.array([[1.0, 1.2, 1.1, 1.3]])
+    tn = amd.BayesSardTransform(3, 3, par, mi, 'gh', {'degree': 7})
+    monkeypatch.setenv('SSMQ_WEIGHTS_ONE_WG', '1')
+    to = amd.BayesSardTransform(3, 3, par, mi, 'gh', {'degree': 7})
+    monkeypatch.delenv('SSMQ_WEIGHTS_ONE_WG')
+    assert tn.model.points.shape[1] == 343
+    cond = np.linalg.cond(orc.rbf_eval(par[0], tn.model.points, scaling=False) + 1e-8 * np.eye(343))
+    for key, bar in (('wm', 64 * cond * 2.2e-16), ('Wcc', 64 * cond * 2.2e-16), ('Wc', 8 * cond ** 2 * 2.2e-16)):
+        what = 'many-workgroup Bayes-Sard weights {} vs one workgroup'.format(key)
+        assert within(rel_err(getattr(tn, key), getattr(to, key)), capped(max(1e-12, bar), what), what)
+
+
 def test_launch_loop_graph_follows_weight_updates(amd, golden, monkeypatch):
     """The launch-loop path caches its 3 T launches as a hipGraph.  Replacing a transform's weights keeps the handle and
     its constant-block addresses, but may change WHICH kernel variant qualifies (the LDL' fast path is withdrawn and its
