@@ -501,11 +501,13 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         // two launches: (1) one wave per trajectory: factor, points, integrand values FX, factors; (2) the streamed product whose
         // epilogues form mean, covariance and cross-covariance (ssmq_bq_stream.hip)
         const int kb = (h->N + 15) / 16, lda = kb * 16;
-        const int64_t M = B * h->E;
+        // FX in fragment order: blocks of 64 / E trajectories, 64 rows each (ssmq_wide.h: fx_frag)
+        const int tpw = bq_stream_tpw(h->E);
+        const int64_t M = (B + tpw - 1) / tpw * 64;
         double *fx, *tt, *mrow, *chol;
         if ((rc = big_scratch(M, lda, 0, 0, B, h->D, &fx, &tt, &mrow, &chol))) return rc;
         WideArgs e = a;
-        e.fx_ld = lda; e.fx_out = fx; e.mrow_out = mrow; e.chol_out = chol;
+        e.fx_ld = lda; e.fx_out = fx; e.mrow_out = mrow; e.chol_out = chol; e.fx_frag = tpw;
         if ((rc = hip_fail(launch_eval_wave(e, B, stream()), "k_eval_wave"))) return rc;
         const WideLayout wl = wide_layout(h->D, h->E, h->N, h->form);
         return launch_bq_stream(a, h->d_sx_pan, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, fx, chol, lda, stream());

@@ -381,9 +381,21 @@ __global__ __launch_bounds__(64 * kEvalWaves) void k_eval_wave(const WideArgs a,
             for (int e = 0; e < DM; ++e) macc[e] += o[e] * w;
         }
         if (n < fl) {
+            if (a.fx_frag) {
+                const int64_t blk = b / a.fx_frag;
+                const int lr0 = (int)(b - blk * a.fx_frag) * E;
+                double *tile0 = a.fx_out + blk * 64 * fl + (int64_t)(n >> 4) * 256 + 64 * ((n & 15) >> 2) + (n & 3);
 #pragma unroll
-            for (int e = 0; e < DM; ++e)
-                if (e < E) rows[(int64_t)e * fl + n] = n < N ? (ok ? o[e] : nan) : 0.0;
+                for (int e = 0; e < DM; ++e)
+                    if (e < E) {
+                        const int lr = lr0 + e;
+                        tile0[(int64_t)(lr >> 4) * 16 * fl + 4 * (lr & 15)] = n < N ? (ok ? o[e] : nan) : 0.0;
+                    }
+            } else {
+#pragma unroll
+                for (int e = 0; e < DM; ++e)
+                    if (e < E) rows[(int64_t)e * fl + n] = n < N ? (ok ? o[e] : nan) : 0.0;
+            }
         }
     }
 #pragma unroll

@@ -28,50 +28,46 @@ namespace ssmq {
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
-constexpr int kPanT = 13;                       // column tiles of S per panel
-constexpr int kPanW = 16 * kPanT;               // 208 columns
-constexpr int kPanX = kPanW + 16;               // panel row in memory: 208 columns of S + the G tile (panel 0 only)
+constexpr int kPanT = 16;                       // column tiles of S per panel: two per wave
+constexpr int kPanW = 16 * kPanT;               // 256 columns
+constexpr int kFrag = 256;                      // doubles of one 16 x 16 tile in fragment order
+constexpr int kCholLds = 960;                   // doubles of LDS for the block's Cholesky factors
 
 struct BqStreamArgs {
     int32_t D, E, N, emv_broadcast, tpw, nkb, npan;   // nkb: k-blocks of 16 points = column tiles of S; npan: panels
-    int64_t B, lda;                                    // FX [B E][lda], lda >= 16 nkb, zero beyond N
+    int64_t B, lda;                                    // FX in fragment order (WideArgs::fx_frag = tpw), lda = 16 nkb, zero beyond N
     const double *fx, *chol;                           // k_eval_wave's outputs: values (NaN rows where the factorisation failed), factors [B][D][D]
-    const double *X;        // [npan][16 nkb][224]: panel p = columns 208 p .. of S, then (p = 0) [Wcc' | wm]; zero-padded
+    const double *X;        // [npan][nkb][16 tiles][2][64][2] S in fragment order, then [nkb][2][64][2] the G tile [Wcc' | wm]
     const double *emv, *cov_add;                       // [E * E]; cov_add or null
     double cov_scale, ccov_scale;
     double *mean_f, *cov_f, *cov_fx;                   // element e of trajectory b at ptr[e * es + b]
     int64_t es;
 };
 
-struct StepIt {             // (panel, k-block) of one step of the flattened main loop; kb runs DOWN within a panel
+struct StepIt {             // (panel, k-block) of one step of a wave's flattened main loop; kb runs DOWN within a panel
     int p, kb;
 };
 
 __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
-    constexpr int TB = 512, RT = 4, KS = 16;
-    constexpr int NT = kPanT, NX = kPanX, LB = NX + 4;
-    constexpr int C0 = (NT + 2) / 2;               // 7 accumulator tiles per wave: S tiles 2 t + ch of the panel; G at GT of half GCH
-    constexpr int GCH = NT & 1, GT = NT >> 1;
-    constexpr int kGroup = 2;
-    constexpr int KBS = 1;                          // k-blocks per step (2: half the barriers, but 30 spilled registers with the staggered halves)
+    constexpr int TB = 512, RT = 4, NW = 8, NT = kPanT;
     extern __shared__ __align__(16) double lds[];
     const int D = g.D, E = g.E;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int lip = 4 * (li & 3) + (li >> 2);
-    const int rt = wave % RT, ch = wave / RT;
-    const int TPW = g.tpw, rows = TPW * E;
+    const int TPW = g.tpw;
     const int nkb = g.nkb, npan = g.npan;
     const int64_t bw0 = (int64_t)blockIdx.x * TPW;
     const int nb = (int)((g.B - bw0) < (int64_t)TPW ? (g.B - bw0) : (int64_t)TPW);
     const int vrows = nb * E;
-    double *slab = lds;                             // [2 buffers][2 k-blocks][KS][LB]
-    double *sP = slab + 4 * KS * LB;                // [2][RT][64][8] parts of C (a G wave's slot first serves as its G tile)
-    double *sev = sP + 2 * RT * 64 * 8, *sca = sev + 256;
+    double *sP = lds;                               // [NW][RT][64][8] every wave's part of C
+    double *sG = sP + NW * RT * 64 * 8;             // [NW][64][4] every wave's part of the G tile
+    double *sev = sG + NW * 64 * 4, *sca = sev + 256;
     double *smr = sca + 256;                        // [64] transformed means by row
-    int *spair = (int *)(smr + 64);                 // [64] (e, e2) pairs
+    double *sL = smr + 64;                          // [TPW][D][D] Cholesky factors of this block's trajectories, if they fit kCholLds
+    int *spair = (int *)(sL + kCholLds);            // [64] (e, e2) pairs
     int *srow = spair + 64;                         // [64] row -> (trajectory << 8) | output index
     if (tid < 64) {
         const int gq = tid / E;
@@ -87,216 +83,180 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
         sev[tid] = g.emv[tid];
         sca[tid] = g.cov_add ? g.cov_add[tid] : 0.0;
     }
-    const int sr = tid >> 5, shf = (tid >> 4) & 1, sc16 = tid & 15;
-    auto phys = [](int k) { return 4 * (k & 3) + (k >> 2); };
-    // a step = TWO k-blocks (kb, kb - 1; the second one missing at the end of a panel with an odd number of them): one workgroup
-    // barrier per 32 points.  (One per 16 measured 17 % of the launch in barrier waits: 4.28 against 3.55 ms with the barriers
-    // compiled out.)
+    // the factors the cross-covariance needs at the very end: requested now, read from LDS then (straight from memory they were
+    // ~30 dependent reads per lane with every other wave waiting at the barrier)
+    const bool factors_in_lds = TPW * D * D <= kCholLds;     // (many one-output trajectories per block: from memory, as before)
+    if (factors_in_lds)
+        for (int idx = tid; idx < nb * D * D; idx += TB) sL[idx] = g.chol[bw0 * D * D + idx];
+    // This wave's column tiles of every panel: tA = wave and tB = 15 - wave.  Within a panel the k-blocks run DOWN to the panel's
+    // own 16 (the diagonal region), where tile t has work for kb >= 16 p + t only: the pair (w, 15 - w) gives every wave the same
+    // 17 tile steps there.  A wave's steps of panel p: kb = nkb - 1 ... 16 p + wave.
+    // (Panel 0 runs down to kb = 0 for every wave: the G tile [Wcc' | wm] is spread over the waves as (row tile wave & 3) x
+    // (k-blocks of parity wave >> 2), 37 tile steps each, with the FX fragments the step has loaded anyway.)
+    const int tA = wave, tB = NT - 1 - wave;
+    auto lo = [&](int p) { return p == 0 ? 0 : NT * p + wave; };
     auto next_it = [&](StepIt it) {
-        if (it.kb - KBS >= NT * it.p) return StepIt{it.p, it.kb - KBS};
-        return StepIt{it.p + 1, nkb - 1};
+        if (it.kb - 1 >= lo(it.p)) return StepIt{it.p, it.kb - 1};
+        const int p = it.p + 1;
+        if (p < npan && lo(p) <= nkb - 1) return StepIt{p, nkb - 1};
+        return StepIt{npan, nkb - 1};
     };
-    // this wave's 16 rows of FX: rows beyond the tile's valid ones (a last, partial tile; the 4 padding rows of a 60-row tile) read
-    // the tile's last valid row - their results are never stored
-    const int64_t row0 = bw0 * E;
-    const int myrow = (16 * rt + li) < vrows ? (16 * rt + li) : vrows - 1;
-    const double *fxrow = g.fx + (row0 + myrow) * g.lda + lg;
-    // Every request of a step is UNCONDITIONAL (an invalid step repeats the last valid addresses; slab columns a diagonal step does
-    // not need are read all the same) and the steps run in straight-line groups of kGroup: the compiler's s_waitcnt placement
-    // counts requests, and any request under a condition - or a loop header - makes it wait for ALL outstanding ones.
-    const StepIt last_it{npan - 1, (KBS == 2 && NT * (npan - 1) + 1 < nkb) ? NT * (npan - 1) + 1 : NT * (npan - 1)};
-    auto valid_it = [&](StepIt it) { return it.p < npan ? it : last_it; };
-    double breg[2][C0], afs[2][4];        // (fragments: ONE step ahead is a 2.8 us lead with two k-blocks per step)
-    // second k-block of a step: kb - 1, or (at the end of a panel with an odd number of k-blocks) kb once more - read, never used
-    auto second = [&](StepIt it) { return it.kb - 1 >= NT * it.p ? it.kb - 1 : it.kb; };
-    auto load_b = [&](StepIt it0) {
+    auto valid_it = [&](StepIt it) { return it.p < npan ? it : StepIt{0, nkb - 1}; };
+    // FX in fragment order (WideArgs::fx_frag): this block's 64 rows are [4 row tiles][nkb][64 lanes][4].  Rows beyond the block's
+    // valid ones (a last, partial block; the 4 padding rows of a 60-row block) hold whatever the buffer held: a row of FX only ever
+    // meets its own accumulator column, and those are never stored.
+    const double *fxb = g.fx + (int64_t)blockIdx.x * 64 * g.lda;
+    const int tile_ld = nkb * kFrag;               // doubles from one row tile of the block to the next
+    const double *Xg = g.X + (size_t)npan * nkb * NT * kFrag;
+    // operands of a step, requested ONE step ahead straight into registers (fragment order in memory: a lane's four k values of a
+    // tile are two 16-byte pieces, each piece contiguous over the wave).  Every request is unconditional - an invalid step repeats
+    // a valid address - and the steps run in straight-line pairs, so that the compiler's s_waitcnt placement can count them.
+    v4d av[2][RT], gv[2];
+    v2d bv[2][2][2];
+    auto load_step = [&](StepIt it0, auto set_c) {
+        constexpr int set = decltype(set_c)::value;
+#ifdef BQS_SAME_ADDR
+        const StepIt it = StepIt{0, nkb - 1};
+#else
         const StepIt it = valid_it(it0);
-        const double *pa = g.X + ((size_t)it.p * nkb * KS + (size_t)it.kb * KS + sr) * NX + 16 * shf + sc16;
-        const double *pb = g.X + ((size_t)it.p * nkb * KS + (size_t)second(it) * KS + sr) * NX + 16 * shf + sc16;
+#endif
 #pragma unroll
-        for (int j = 0; j < C0; ++j) {
-            breg[0][j] = pa[32 * j];
-            if constexpr (KBS == 2) breg[1][j] = pb[32 * j];
-        }
-    };
-    auto park_b = [&](int buf) {
-        double *dst = slab + buf * 2 * KS * LB + phys(sr) * LB + 16 * shf + sc16;
+        for (int rt = 0; rt < RT; ++rt) av[set][rt] = *(const v4d *)(fxb + rt * tile_ld + it.kb * kFrag + 4 * lane);
+        const double *pb = g.X + ((size_t)it.p * nkb + it.kb) * (NT * kFrag) + 2 * lane;
 #pragma unroll
-        for (int j = 0; j < C0; ++j) {
-            dst[32 * j] = breg[0][j];
-            if constexpr (KBS == 2) dst[KS * LB + 32 * j] = breg[1][j];
+        for (int h = 0; h < 2; ++h) {
+            bv[set][0][h] = *(const v2d *)(pb + tA * kFrag + 128 * h);
+            bv[set][1][h] = *(const v2d *)(pb + tB * kFrag + 128 * h);
         }
+        gv[set] = *(const v4d *)(Xg + (size_t)it.kb * kFrag + 4 * lane);
     };
-    auto load_af = [&](StepIt it0) {            // lane (li, lg): FX[row][16 kb + lg + 4 s], s = 0 .. 3, both k-blocks
-        const StepIt it = valid_it(it0);
-        const double *pa = fxrow + KS * it.kb, *pb = fxrow + KS * second(it);
+    v4d accA[RT], accB[RT], gacc = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            afs[0][s] = pa[4 * s];
-            if constexpr (KBS == 2) afs[1][s] = pb[4 * s];
-        }
-    };
+    for (int rt = 0; rt < RT; ++rt) accA[rt] = accB[rt] = v4d{0.0, 0.0, 0.0, 0.0};
+    double *sx = sP + (size_t)wave * RT * 64 * 8 + lane * 8;       // + rt * 512: this wave's part of C for row tile rt
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sx[rt * 512 + i] = 0.0;
+    const int grt = wave & 3, gpar = wave >> 2;         // the G tile: row tile grt at the k-blocks of parity gpar
     StepIt c0{0, nkb - 1};
-    StepIt c1 = next_it(c0), c2 = next_it(c1);
-    load_b(c0);
-    load_af(c0);
-    park_b(0);
-    load_b(c1);
-    double *sx = sP + ((ch * RT + rt) * 64 + lane) * 8;     // this wave's part of C lives in LDS between the panels
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sx[i] = 0.0;
-    __syncthreads();
-    v4d acc[C0];
-#pragma unroll
-    for (int t = 0; t < C0; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-    const int woff = 4 * lg * LB + 16 * ch + lip, goff = 4 * lg * LB + 16 * NT + lip;
-    const int s0 = (16 * rt / E) * E;             // first row of the first trajectory that intersects this wave's row tile
-    auto mma = [&](auto na_c, const double *sb, const double (&af)[4]) {
-        constexpr int NA = decltype(na_c)::value;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            double w[NA];
-#pragma unroll
-            for (int t = 0; t < NA; ++t) w[t] = sb[woff + s * LB + 32 * t];
-#pragma unroll
-            for (int t = 0; t < NA; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[t], af[s], acc[t], 0, 0, 0);
-        }
-    };
+    StepIt c1 = next_it(c0);
+    load_step(c0, std::integral_constant<int, 0>{});
+    __syncthreads();                                // the tables
+    // C += T_p FX_p' for this wave's tiles of panel p, then the accumulators are cleared: acc (T', S columns x rows) is the A
+    // operand as it stands, the FX rows of the trajectories that meet the row tile are B
     auto panel_end = [&](int p) {
-        const int ntp = nkb - NT * p;
-        if (p == 0 && ch == GCH) {
-            // mean and cross-covariance from the G tile (as k_bq_fused 4a), the factor from k_eval_wave's output
-            const int lr = 16 * rt + li;
-            const bool valid = lr < vrows;
-            const int gi = srow[lr] >> 8, e = srow[lr] & 255;
-            const int64_t b = bw0 + (valid ? gi : 0);
-            const double *Lb = g.chol + b * D * D;
-            const v4d gt = acc[GT];
-            if (lg == 3) {
-                smr[lr] = gt[3];
-                if (valid) g.mean_f[(int64_t)e * g.es + b] = gt[3];
-            }
-            double *sg = sP + ((GCH * RT + rt) * 64) * 8;     // this wave's own slot (512 doubles), zeroed again below
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sg[li * 16 + 4 * lg + r] = gt[r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int j = lg; j < D; j += 4) {
-                double pq = 0.0;
-                for (int d = 0; d <= j; ++d) pq += sg[li * 16 + d] * Lb[j * D + d];
-                if (valid) g.cov_fx[(int64_t)(e * D + j) * g.es + b] = pq * g.ccov_scale;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sx[i] = 0.0;
-        }
-        // C += T_p FX_p': this wave's tiles of the panel against the rows of the trajectories that meet its row tile.  Straight-
-        // line code: the FX fragments of tile t + 1 are requested before the eight matrix instructions of tile t are issued.  Tiles
-        // this panel does not have (the last panel; tile GT of the G half) multiply accumulators that are zero / are skipped.
-        const int r0 = (s0 + li) < vrows ? (s0 + li) : vrows - 1, r1 = (s0 + 16 + li) < vrows ? (s0 + 16 + li) : vrows - 1;
-        const double *f0p = g.fx + (row0 + r0) * g.lda + 4 * lg, *f1p = g.fx + (row0 + r1) * g.lda + 4 * lg;
-        const int nmine = ((ntp < NT ? ntp : NT) - ch + 1) >> 1;         // S tiles of this wave in this panel
-        v4d acc2[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
-        v4d f[2][2];
-        auto ldf = [&](int t, v4d (&dst)[2]) {
-            const int tc = t < nmine ? t : 0;
-            const int col = 16 * (NT * p + 2 * tc + ch);
-            dst[0] = *(const v4d *)(f0p + col);
-            dst[1] = *(const v4d *)(f1p + col);
-        };
-        ldf(0, f[0]);
-#pragma unroll
-        for (int t = 0; t < GT; ++t) {
-            ldf(t + 1, f[(t + 1) & 1]);
+        for (int rt = 0; rt < RT; ++rt) {
+            const int s0 = (16 * rt / E) * E;     // first row of the first trajectory that intersects row tile rt
+            const int r0 = (s0 + li) < vrows ? (s0 + li) : vrows - 1, r1 = (s0 + 16 + li) < vrows ? (s0 + 16 + li) : vrows - 1;
+            // row r, points 16 kb + 4 lg ...: tile (r >> 4, kb), lane (r & 15) + 16 lg
+            const double *f0p = fxb + (r0 >> 4) * tile_ld + 4 * ((r0 & 15) + 16 * lg) + NT * p * kFrag;
+            const double *f1p = fxb + (r1 >> 4) * tile_ld + 4 * ((r1 & 15) + 16 * lg) + NT * p * kFrag;
+            const int cB = (NT * p + tB < nkb) ? tB : tA;          // a tile beyond the last one: accB is zero, any address does
+            const v4d fa0 = *(const v4d *)(f0p + tA * kFrag), fa1 = *(const v4d *)(f1p + tA * kFrag);
+            const v4d fb0 = *(const v4d *)(f0p + cB * kFrag), fb1 = *(const v4d *)(f1p + cB * kFrag);
+            v4d c2a = v4d{0.0, 0.0, 0.0, 0.0}, c2b = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                acc2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[t][r], f[t & 1][0][r], acc2[0], 0, 0, 0);
-                acc2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[t][r], f[t & 1][1][r], acc2[1], 0, 0, 0);
+                c2a = __builtin_amdgcn_mfma_f64_16x16x4f64(accA[rt][r], fa0[r], c2a, 0, 0, 0);
+                c2b = __builtin_amdgcn_mfma_f64_16x16x4f64(accA[rt][r], fa1[r], c2b, 0, 0, 0);
             }
-        }
-        if (ch != GCH) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                acc2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[GT][r], f[GT & 1][0][r], acc2[0], 0, 0, 0);
-                acc2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[GT][r], f[GT & 1][1][r], acc2[1], 0, 0, 0);
+                c2a = __builtin_amdgcn_mfma_f64_16x16x4f64(accB[rt][r], fb0[r], c2a, 0, 0, 0);
+                c2b = __builtin_amdgcn_mfma_f64_16x16x4f64(accB[rt][r], fb1[r], c2b, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sx[rt * 512 + r] += c2a[r];
+                sx[rt * 512 + 4 + r] += c2b[r];
+            }
+            accA[rt] = accB[rt] = v4d{0.0, 0.0, 0.0, 0.0};
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sx[4 * h + r] += acc2[h][r];
-#pragma unroll
-        for (int t = 0; t < C0; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-    };
-    auto half_step = [&](const double *sb, const double (&af)[4], int kb, bool on) {
-        const int kbl = kb - NT * c0.p, ntp = nkb - NT * c0.p;
-        int na = (kbl - ch + 2) >> 1;
-        const int cap = ((ntp < NT ? ntp : NT) - ch + 1) >> 1;
-        na = na < cap ? na : cap;
-        if (!on) na = 0;                                // padding step of the last group / missing second k-block
-        if (on && c0.p == 0 && ch == GCH) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc[GT] = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[goff + s * LB], af[s], acc[GT], 0, 0, 0);
-        }
-        if (na == 7) mma(std::integral_constant<int, 7>{}, sb, af);
-        if (na == 6) mma(std::integral_constant<int, 6>{}, sb, af);
-        if (na == 5) mma(std::integral_constant<int, 5>{}, sb, af);
-        if (na == 4) mma(std::integral_constant<int, 4>{}, sb, af);
-        if (na == 3) mma(std::integral_constant<int, 3>{}, sb, af);
-        if (na == 2) mma(std::integral_constant<int, 2>{}, sb, af);
-        if (na == 1) mma(std::integral_constant<int, 1>{}, sb, af);
     };
     auto step = [&](auto par_c) {
         constexpr int PAR = decltype(par_c)::value;
-        const double afa[4] = {afs[0][0], afs[0][1], afs[0][2], afs[0][3]};
-        const double afb[4] = {afs[1][0], afs[1][1], afs[1][2], afs[1][3]};
-        const double *sb = slab + PAR * 2 * KS * LB;
+        load_step(c1, std::integral_constant<int, PAR ^ 1>{});
         const bool on = c0.p < npan;
-        // The two waves of a SIMD (row tile rt, halves ch = 0 / 1) run the step's two parts in OPPOSITE order - half 0 moves data
-        // first (slabs of step q + 1 into LDS, requests for q + 2), then multiplies; half 1 multiplies first - so that one wave's
-        // matrix instructions cover the other's stores, requests and waits.  Both in the same order left the matrix pipe idle
-        // while both moved data: the barrier keeps the eight waves in phase (3.55 ms with the barriers compiled out, 4.28 with).
-        if (ch == 0) {
-            park_b(PAR ^ 1);
-            load_b(c2);
-            load_af(c1);
-            half_step(sb, afa, c0.kb, on);
-            if constexpr (KBS == 2) half_step(sb + KS * LB, afb, c0.kb - 1, on && c0.kb - 1 >= NT * c0.p);
-        } else {
-            half_step(sb, afa, c0.kb, on);
-            if constexpr (KBS == 2) half_step(sb + KS * LB, afb, c0.kb - 1, on && c0.kb - 1 >= NT * c0.p);
-            park_b(PAR ^ 1);
-            load_b(c2);
-            load_af(c1);
+        const int kbl = c0.kb - NT * c0.p;
+#ifdef BQS_NO_MMA
+        if (on) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) asm volatile("" ::"v"(av[PAR][rt]));
+            asm volatile("" ::"v"(bv[PAR][0][0]), "v"(bv[PAR][0][1]), "v"(bv[PAR][1][0]), "v"(bv[PAR][1][1]), "v"(gv[PAR]));
+            if (c0.kb == lo(c0.p)) panel_end(c0.p);
         }
-        // a barrier for the LDS slabs only: __syncthreads() is also a fence on global memory, i.e. s_waitcnt vmcnt(0) - every
-        // request issued ahead (next slabs, fragments of the step after next) would be waited for at the end of EVERY step
-#ifdef BQS_NO_BARRIER
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (false) {
 #else
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (on) {
 #endif
-        if (on && c0.kb - KBS < NT * c0.p) panel_end(c0.p);
-        c0 = c1; c1 = c2; c2 = next_it(c2);
+            if (kbl >= tA) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double b = bv[PAR][0][s >> 1][s & 1];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) accA[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, av[PAR][rt][s], accA[rt], 0, 0, 0);
+                }
+            }
+            if (kbl >= tB) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double b = bv[PAR][1][s >> 1][s & 1];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) accB[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, av[PAR][rt][s], accB[rt], 0, 0, 0);
+                }
+            }
+            if (c0.p == 0 && (c0.kb & 1) == gpar) {
+                // (four branches, not a selected operand: the compiler turns a select over av[] into an indexed read of the array in
+                // scratch memory - and stores every fragment there the moment it arrives)
+#define SSMQ_G_TILE(RTG) \
+                _Pragma("unroll") for (int s = 0; s < 4; ++s) \
+                    gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[PAR][s], av[PAR][RTG][s], gacc, 0, 0, 0);
+                if (grt == 0) { SSMQ_G_TILE(0) } else if (grt == 1) { SSMQ_G_TILE(1) } else if (grt == 2) { SSMQ_G_TILE(2) } else { SSMQ_G_TILE(3) }
+#undef SSMQ_G_TILE
+            }
+            if (c0.kb == lo(c0.p)) panel_end(c0.p);
+        }
+        c0 = c1; c1 = next_it(c1);
     };
-    static_assert(kGroup % 2 == 0, "register sets and slab buffers alternate with the step");
 #ifdef BQS_SKIP_MAIN
     while (false) {
 #else
     while (c0.p < npan) {
 #endif
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+    }
 #pragma unroll
-        for (int u = 0; u < kGroup; u += 2) {
-            step(std::integral_constant<int, 0>{});
-            step(std::integral_constant<int, 1>{});
+    for (int r = 0; r < 4; ++r) sG[(wave * 64 + lane) * 4 + r] = gacc[r];
+    __syncthreads();
+    // ---- mean and cross-covariance from the G tile (as k_bq_fused 4a), the factor from k_eval_wave's output -------------------------
+    if (wave < RT) {
+        const int rt = wave, lr = 16 * rt + li;
+        const bool valid = lr < vrows;
+        const int gi = srow[lr] >> 8, e = srow[lr] & 255;
+        const int64_t b = bw0 + (valid ? gi : 0);
+        const double *Lb = factors_in_lds ? sL + (valid ? gi : 0) * D * D : g.chol + b * D * D;
+        const v4d gt = *(const v4d *)(sG + (wave * 64 + lane) * 4) + *(const v4d *)(sG + ((wave + 4) * 64 + lane) * 4);
+        if (lg == 3) {
+            smr[lr] = gt[3];
+            if (valid) g.mean_f[(int64_t)e * g.es + b] = gt[3];
+        }
+        double *sg = sG + wave * 256;                  // this wave's own slot: [row li][column 4 lg + r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sg[li * 16 + 4 * lg + r] = gt[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = lg; j < D; j += 4) {
+            double pq = 0.0;
+            for (int d = 0; d <= j; ++d) pq += sg[li * 16 + d] * Lb[j * D + d];
+            if (valid) g.cov_fx[(int64_t)(e * D + j) * g.es + b] = pq * g.ccov_scale;
         }
     }
-    // ---- all parts of C meet in LDS; fx Wc fx' = C + C' ---------------------------------------------------------------------------
     __syncthreads();
+    // ---- all parts of C meet in LDS; fx Wc fx' = C + C' ---------------------------------------------------------------------------
     for (int idx = tid; idx < nb * npair; idx += TB) {
         const int p = idx / nb, gi = idx - p * nb;
         const int e = spair[p] >> 4, e2 = spair[p] & 15;
@@ -304,7 +264,10 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
         auto cval = [&](int la, int lb) {
             const int rta = la >> 4, i = la & 15, j = lb - (16 * rta / E) * E;
             const int at = ((rta * 64) + (j & 15) + 16 * (i & 3)) * 8 + 4 * (j >> 4) + (i >> 2);
-            return sP[at] + sP[RT * 64 * 8 + at];
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += sP[w * RT * 64 * 8 + at];
+            return v;
         };
         const int64_t b = bw0 + gi;
         const int ie = e * E + e2, it = e2 * E + e;
@@ -317,34 +280,46 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
     }
 }
 
-constexpr size_t kStreamLds = sizeof(double) * (4 * 16 * (kPanX + 4) + 2 * 4 * 64 * 8 + 256 + 256 + 64) + sizeof(int) * 128;
+constexpr size_t kStreamLds = sizeof(double) * (8 * 4 * 64 * 8 + 8 * 64 * 4 + 256 + 256 + 64 + kCholLds) + sizeof(int) * 128;
 
 }  // namespace
 
 int bq_stream_panels(int N) { return (N + kPanW - 1) / kPanW; }
 int bq_stream_kblocks(int N) { return (N + 15) / 16; }
-size_t bq_stream_x_doubles(int N) { return (size_t)bq_stream_panels(N) * bq_stream_kblocks(N) * 16 * kPanX; }
+int bq_stream_tpw(int E) { return 64 / E; }
+size_t bq_stream_x_doubles(int N) { return ((size_t)bq_stream_panels(N) * kPanT + 1) * bq_stream_kblocks(N) * kFrag; }
 
 // BQ transform (not the t-process one), one constant block for the batch, 208 < N <= SSMQ_MAX_PTS, a symmetric Wc; whole
 // trajectories fill at least 3/4 of a 64-row tile for every E <= 10
 bool bq_stream_supported(int D, int E, int N) {
     if (getenv("SSMQ_NO_BQ_STREAM") || getenv("SSMQ_NO_MFMA")) return false;
-    if (N <= kPanW || N > SSMQ_MAX_PTS) return false;
+    if (N <= 208 || N > SSMQ_MAX_PTS) return false;
     return D >= 1 && D <= 15 && E >= 1 && E <= 10;      // D <= 15: column 15 of the G tile carries wm
 }
 
-// X in the panel layout of BqStreamArgs from the natural-layout weights (host): S = tril(Wc) with half the diagonal
+// X in the fragment layout of BqStreamArgs from the natural-layout weights (host): S = tril(Wc) with half the diagonal.
+// Tile (k-block kb, column tile ct): lane (li, lg) holds rows k = 16 kb + 4 lg + s, s = 0 .. 3, of column 16 ct + lip(li),
+// lip(li) = 4 (li & 3) + (li >> 2) - the accumulator rows of the f64 matrix instruction are lg + 4 r, and the second product
+// reads its operand straight out of the accumulators with the points 4 lg + r in its k slots.
 void bq_stream_pack(int D, int N, const double *Wc, const double *Wcc, const double *wm, double *X) {
     const int npan = bq_stream_panels(N), nkb = bq_stream_kblocks(N);
-    const size_t per = (size_t)nkb * 16 * kPanX;
-    for (size_t i = 0; i < per * npan; ++i) X[i] = 0.0;
+    const size_t total = bq_stream_x_doubles(N);
+    for (size_t i = 0; i < total; ++i) X[i] = 0.0;
+    auto at = [](int lane, int s) { return (size_t)(s >> 1) * 128 + 2 * lane + (s & 1); };
     for (int k = 0; k < N; ++k) {
+        const int kb = k >> 4, lg = (k & 15) >> 2, s = k & 3;
         for (int j = 0; j <= k; ++j) {
-            const int p = j / kPanW;
-            X[(size_t)p * per + (size_t)k * kPanX + (j - p * kPanW)] = j == k ? 0.5 * Wc[(size_t)k * N + k] : Wc[(size_t)k * N + j];
+            const int ct = j >> 4, p = ct / kPanT, t = ct - p * kPanT, c = j & 15;
+            const int li = 4 * (c & 3) + (c >> 2);      // lip(li) == c  (the permutation is its own inverse)
+            X[(((size_t)p * nkb + kb) * kPanT + t) * kFrag + at(li + 16 * lg, s)] =
+                j == k ? 0.5 * Wc[(size_t)k * N + k] : Wc[(size_t)k * N + j];
         }
-        for (int d = 0; d < D && d < 16; ++d) X[(size_t)k * kPanX + kPanW + d] = Wcc[(size_t)d * N + k];
-        if (D <= 15) X[(size_t)k * kPanX + kPanW + 15] = wm[k];
+        double *G = X + (size_t)npan * nkb * kPanT * kFrag + (size_t)kb * kFrag;
+        for (int c = 0; c < 16; ++c) {
+            const int li = 4 * (c & 3) + (c >> 2);
+            const double v = c < D ? Wcc[(size_t)c * N + k] : (c == 15 && D <= 15) ? wm[k] : 0.0;
+            G[4 * (li + 16 * lg) + s] = v;
+        }
     }
 }
 
@@ -354,7 +329,7 @@ int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int 
                      const double *chol, int64_t lda, hipStream_t s) {
     if (B <= 0) return SSMQ_OK;
     if (!bq_stream_supported(a.D, a.E, a.N) || a.consts_stride != 0 || a.form != SSMQ_FORM_BQ || a.tp_nu > 0.0 ||
-        lda < 16 * bq_stream_kblocks(a.N) || (lda & 3) || a.bs_mf != 1 || a.bs_cf != 1 || a.bs_cfx != 1) {
+        lda != 16 * bq_stream_kblocks(a.N) || a.bs_mf != 1 || a.bs_cf != 1 || a.bs_cfx != 1) {
         set_error("bq_stream: shape not supported");
         return SSMQ_E_UNSUPPORTED;
     }
@@ -365,7 +340,7 @@ int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int 
         attr_epoch = device_epoch();
     }
     BqStreamArgs g;
-    g.D = a.D; g.E = a.E; g.N = a.N; g.emv_broadcast = emv_broadcast; g.tpw = 64 / a.E;
+    g.D = a.D; g.E = a.E; g.N = a.N; g.emv_broadcast = emv_broadcast; g.tpw = bq_stream_tpw(a.E);
     g.nkb = bq_stream_kblocks(a.N); g.npan = bq_stream_panels(a.N);
     g.B = B; g.lda = lda; g.fx = fx; g.chol = chol; g.X = X; g.emv = emv; g.cov_add = a.cov_add;
     g.cov_scale = a.cov_scale; g.ccov_scale = a.ccov_scale; g.mean_f = a.mean_f; g.cov_f = a.cov_f; g.cov_fx = a.cov_fx; g.es = a.es_out;

@@ -77,6 +77,7 @@ bool bq_fused_supported(int D, int E, int N);
 int launch_bq_fused(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, hipStream_t s);
 // ... the same for any larger point set, the point axis tiled (ssmq_bq_stream.hip)
 bool bq_stream_supported(int D, int E, int N);
+int bq_stream_tpw(int E);          // trajectories per 64-row block of FX (fragment order, WideArgs::fx_frag)
 size_t bq_stream_x_doubles(int N);
 void bq_stream_pack(int D, int N, const double *Wc, const double *Wcc, const double *wm, double *X);
 int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, const double *fx,

@@ -52,6 +52,11 @@ struct WideArgs {
     const double *t_in;
     double *mrow_out;       // k_eval_wave: transformed means as rows b E + e, for the GEMM epilogue
     int32_t wave_k;         // k_apply_wave: trajectories side by side in one wave (set by the launcher)
+    // k_eval_wave for k_bq_stream: FX in FRAGMENT order instead of rows - blocks of fx_frag trajectories (64 rows, the last ones
+    // unused), each [4 row tiles][fx_ld / 16 k-blocks][64 lanes][4]: value (row lr of the block, point n) at lane (lr & 15) +
+    // 16 ((n & 15) >> 2), slot n & 3 of tile (lr >> 4, n >> 4) - what a lane of the f64 matrix instruction takes as ONE 32-byte
+    // read, the wave's reads contiguous.  0: rows.
+    int32_t fx_frag;
     FPar fp;
 };
 
