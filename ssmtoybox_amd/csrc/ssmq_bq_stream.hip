@@ -1,25 +1,24 @@
 // BQ moment transform for LARGE point sets (209 ... 4096 points) in TWO launches: k_eval_wave (factor, sigma points, integrand
-// values FX to memory, row-major) and this kernel - k_bq_fused's product with the point axis tiled, nothing else through
-// memory.  (bq/bqmtran.py:158-223: mean = fx wm, cov = fx Wc fx' - mean mean' + emv, ccov = fx Wcc' L'.)
+// values FX to memory in fragment order - WideArgs::fx_frag) and this kernel - k_bq_fused's product with the point axis tiled,
+// nothing else through memory.  (bq/bqmtran.py:158-223: mean = fx wm, cov = fx Wc fx' - mean mean' + emv, ccov = fx Wcc' L'.)
 //
 // Round 3's route for these sizes was three launches - k_eval_wave, k_fxwc_mfma<16,1> (T = FX [Wc | Wcc'] by column blocks,
 // T to HBM: 0.95 GB written, read again), k_big_rest (per trajectory: T FX', the rest) - 9.1 GB of HBM traffic per 1e4
 // transforms at D = E = 10, N = 1181 for 25.6 MB of algorithmic bytes, and the full product fx Wc.  Here:
-//   * a 512-thread workgroup owns TPW whole trajectories = TPW E <= 64 consecutive rows of FX (4 row tiles of 16);
+//   * a 512-thread workgroup owns TPW whole trajectories = TPW E <= 64 rows of FX (4 row tiles of 16);
 //   * Wc = S + S' (S: lower triangle, half the diagonal), so fx Wc fx' = C + C' with C = (fx S) fx': the column tiles of S
-//     are processed in PANELS of 13 (208 columns: the accumulators of k_bq_fused, 7 tiles per wave, wave w on row tile w & 3 and
-//     on the column tiles of one parity); panel p needs the k-blocks kb >= 13 p only, and of its first 13 k-blocks only the
-//     tiles on or below the diagonal.  T never exists: when a panel's k loop ends, its accumulators are multiplied with the
-//     panel's FX columns (C += T_p FX_p') and cleared.  Panel 0 carries the G tile [Wcc' | wm]: cross-covariance and mean are
-//     by-products;
-//   * X slabs (16 k-rows x 224 columns; L2-resident, every workgroup walks the same sequence) double-buffered in LDS, requested
-//     one step ahead; FX fragments (16 rows x 16 k per wave and step) requested two steps ahead straight into registers;
+//     are processed in PANELS of 16 (256 columns); wave w owns column tiles w and 15 - w of every panel for all four row tiles
+//     (8 accumulator tiles).  Panel p needs the k-blocks kb >= 16 p only, and tile t of it only kb >= 16 p + t.  T never exists:
+//     when a wave's k loop of a panel ends, its accumulators are multiplied with the panel's FX columns (C += T_p FX_p') and
+//     cleared.  The G tile [Wcc' | wm] (cross-covariance, mean) is spread over the waves inside panel 0;
+//   * NO LDS staging, NO barrier in the main loop: both operands straight from memory into registers in fragment order (a lane's
+//     four k values of a tile = one 32-byte read, a wave's reads of a tile = 2 KB contiguous), requested one step ahead;
 //   * epilogue as k_bq_fused: all parts of C meet in LDS, one thread per (trajectory, e >= e2) forms C + C' and stores.
-// Matrix work per 64-row tile at N = 1181 (74 column tiles): 74 75 / 2 + 74 = 2 849 tile steps x 4 instructions per row tile against
+// Matrix work per 64-row block at N = 1181 (74 column tiles): 74 75 / 2 + 74 = 2 849 tile steps x 4 instructions per row tile against
 // 74 90 = 6 660 for the full [Wc | Wcc'] product.
-// (A first version of this round did everything in ONE launch - persistent workgroups, factor and integrand in chunks of 208
-// points through an LDS tile into a per-workgroup scratch block in fragment order: 4.19 ms per 1e4 transforms, of which 0.86 ms
-// were the chunk loop - its stores drained at every barrier - against 0.27 ms for k_eval_wave, whose waves fill the chip.)
+// (Earlier versions of this round, DESIGN.md 3.12: ONE launch with the integrand inside - 4.19 ms per 1e4 transforms; X slabs
+// double-buffered in LDS with a barrier per 16 points - 4.06 ms, the matrix pipe 59 % busy; this ownership with a row-major FX -
+// 3.71 ms, the texture path 4 x longer busy per fragment read than with contiguous ones.  Now 3.05-3.17 ms.)
 #include "ssmq_host.h"
 #include "ssmq_wide.h"
 #include <type_traits>
