@@ -54,6 +54,9 @@ def use_native():
     built on another machine may use instructions this one lacks) and switch to it.  Returns the compiler line, or the
     portable build's when the native build is not possible (no compiler on the box)."""
     global _lib, FLAGS
+    if os.environ.get('SSMQ_ORACLE_PORTABLE'):      # A/B of the two builds on one host (tools): keep the portable -O2 file
+        load()
+        return FLAGS
     try:
         subprocess.check_call(['make', '-B', '-C', _HERE, 'native'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         lib = ctypes.CDLL(os.path.join(_HERE, 'libssmq_oracle_native.so'))

@@ -119,9 +119,18 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
 #else
         const StepIt it = valid_it(it0);
 #endif
+#ifdef BQS_SAME_A
+        const int kba = nkb - 1;
+#else
+        const int kba = it.kb;
+#endif
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) av[set][rt] = *(const v4d *)(fxb + rt * tile_ld + it.kb * kFrag + 4 * lane);
+        for (int rt = 0; rt < RT; ++rt) av[set][rt] = *(const v4d *)(fxb + rt * tile_ld + kba * kFrag + 4 * lane);
+#ifdef BQS_SAME_B
+        const double *pb = g.X + ((size_t)0 * nkb + nkb - 1) * (NT * kFrag) + 2 * lane;
+#else
         const double *pb = g.X + ((size_t)it.p * nkb + it.kb) * (NT * kFrag) + 2 * lane;
+#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             bv[set][0][h] = *(const v2d *)(pb + tA * kFrag + 128 * h);
