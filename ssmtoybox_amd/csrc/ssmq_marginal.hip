@@ -16,6 +16,13 @@
 // second line search (line_search_wolfe2: DCSRCH ended in an ERROR or WARNING task) the trajectory is handed back with
 // status SSMQ_BFGS_FALLBACK and the caller finishes it with SciPy itself, from the start point - results as the serial path.
 #include "ssmq_host.h"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -612,6 +619,77 @@ extern "C" int ssmq_gp_marginal_laplace_batch(ssmq_transform *h_dyn, const ssmq_
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace {
 
+// The host side of a round (parameter rows in, optimiser steps out) is independent per trajectory: with a thousand trajectories
+// in flight it was 40 % of the call (17 + 23 of 101 ms at B = 1 024), so rounds with many active trajectories are cut into
+// chunks for a few worker threads that live for the duration of the call.  Small rounds (the long tail of a few slow
+// trajectories) run inline: waking the workers costs more than they would save.
+class Workers {
+public:
+    explicit Workers(int n) {
+        for (int i = 0; i < n; ++i) th_.emplace_back([this, i] { loop(i); });
+    }
+    ~Workers() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // fn(begin, end) over [0, n) in chunks, the calling thread included; returns when all of it is done
+    void run(size_t n, const std::function<void(size_t, size_t)> &fn) {
+        const size_t parts = th_.size() + 1;
+        if (th_.empty() || n < 256) {
+            fn(0, n);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            n_ = n;
+            chunk_ = (n + parts - 1) / parts;
+            pending_ = (int)th_.size();
+            ++gen_;
+        }
+        cv_.notify_all();
+        fn(0, std::min(n, chunk_));
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+    }
+
+private:
+    void loop(int i) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t, size_t)> *fn;
+            size_t b, e;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+                b = std::min(n_, chunk_ * (size_t)(i + 1));
+                e = std::min(n_, chunk_ * (size_t)(i + 2));
+            }
+            if (b < e) (*fn)(b, e);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t, size_t)> *fn_ = nullptr;
+    size_t n_ = 0, chunk_ = 0;
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
 struct Traj {
     int k = 1;                      // time step being worked on (1 .. T)
     int mode = 0;                   // 0: optimising (BFGS), 1: waiting for the marginalisation points, 2: finished / failed
@@ -701,7 +779,16 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
     std::vector<int32_t> st;
     const double inf = std::numeric_limits<double>::infinity();
     int64_t rounds = 0, iters = 0, total_items = 0;
+    // worker threads: SSMQ_MARGINAL_THREADS (0 = none), else up to 8 and never more than the trajectories could use
+    int n_workers = 7;
+    if (const char *e = getenv("SSMQ_MARGINAL_THREADS")) n_workers = std::max(0, atoi(e) - 1);
+    n_workers = (int)std::min<int64_t>(std::min<unsigned>((unsigned)n_workers, std::max(1u, std::thread::hardware_concurrency()) - 1), B / 256);
+    Workers pool(n_workers);
+    const bool timing = getenv("SSMQ_MARGINAL_TIMING") != nullptr;      // host-side budget of the rounds, printed at the end
+    double t_pack = 0.0, t_call = 0.0, t_adv = 0.0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
+        const double t0 = timing ? now() : 0.0;
         who.clear(); first.clear();
         int64_t items = 0;
         for (int64_t b = 0; b < B; ++b)
@@ -714,7 +801,8 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
         rows.resize((size_t)items * P); pd.resize((size_t)items * Pd); po.resize((size_t)items * Po);
         mm.resize((size_t)items * Din); cc.assign((size_t)items * Din * Din, 0.0); yy.resize((size_t)items * Y); tt.resize((size_t)items);
         ll.resize((size_t)items); om.resize((size_t)items * D); oc.resize((size_t)items * D * D); st.assign((size_t)items, 0);
-        for (size_t w = 0; w < who.size(); ++w) {
+        pool.run(who.size(), [&](size_t w0, size_t w1) {
+        for (size_t w = w0; w < w1; ++w) {
             const int64_t b = who[w];
             const Traj &t = tr[b];
             const int n = t.mode == 0 ? P + 1 : NP;
@@ -744,12 +832,18 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
                 tt[(size_t)it] = (double)t.k;
             }
         }
+        });
+        const double t1 = timing ? now() : 0.0;
         const int rc = ssmq_gp_theta_step_times(h_dyn, f_dyn, h_obs, f_obs, items, pd.data(), po.data(), jitter, mm.data(), cc.data(), 0,
                                                 yy.data(), 0, tt.data(), GQG, R, om.data(), oc.data(), ll.data(), st.data());
         if (rc < 0) return rc;
+        const double t2 = timing ? now() : 0.0;
         ++rounds;
         total_items += items;
-        for (size_t w = 0; w < who.size(); ++w) {
+        std::atomic<int64_t> iters_round{0};
+        pool.run(who.size(), [&](size_t w0, size_t w1) {
+        int64_t iters_mine = 0;
+        for (size_t w = w0; w < w1; ++w) {
             const int64_t b = who[w];
             Traj &t = tr[b];
             if (t.mode == 0) {
@@ -761,7 +855,7 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
                 }
                 bfgs_advance(t.run, P, fd_step, vals);
                 if (t.run.phase != PH_DONE) continue;
-                iters += t.run.k;
+                iters_mine += t.run.k;
                 // Laplace posterior (ssinf.py:1272-1273) and its sigma points (:1103-1106)
                 double pcn[kMaxPar * kMaxPar], L[kMaxPar * kMaxPar];
                 bool fin = true;
@@ -817,7 +911,17 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
                 }
             }
         }
+        iters_round += iters_mine;
+        });
+        iters += iters_round.load();
+        if (timing) {
+            const double t3 = now();
+            t_pack += t1 - t0; t_call += t2 - t1; t_adv += t3 - t2;
+        }
     }
+    if (timing)
+        fprintf(stderr, "marginal_filter_batch: %lld rounds, %lld items: pack %.2f ms, theta step %.2f ms, optimiser / mixtures %.2f ms\n",
+                (long long)rounds, (long long)total_items, 1e3 * t_pack, 1e3 * t_call, 1e3 * t_adv);
     for (int64_t b = 0; b < B; ++b) {
         if (theta_last) std::memcpy(theta_last + (size_t)b * P, tr[b].pm, sizeof(double) * P);
         if (pcov_last) std::memcpy(pcov_last + (size_t)b * P * P, tr[b].pc, sizeof(double) * P * P);
