@@ -87,7 +87,9 @@ typedef struct ssmq_integrand {
 /* Form of the moment equations. */
 enum ssmq_form {
     SSMQ_FORM_BQ = 0,    /* bq/bqmtran.py:158-223: mean = fx wm; cov = fx Wc fx' - mean mean' + emv; ccov = fx Wcc' L' */
-    SSMQ_FORM_SIGMA = 1  /* mtran.py:141-149: centred, diagonal Wc: cov = dfx diag(wc) dfx'; ccov = dfx diag(wc) (x-m)' */
+    SSMQ_FORM_SIGMA = 1, /* mtran.py:141-149: centred, diagonal Wc: cov = dfx diag(wc) dfx'; ccov = dfx diag(wc) (x-m)' */
+    SSMQ_FORM_TAYLOR1 = 2 /* mtran.py:49-59 (LinearizationTransform): mean = f(m); J = df/dx(m); ccov = J cov; cov = ccov J'.
+                             Handles of this form come from ssmq_transform_create_linear only */
 };
 
 /* How the expected model variance enters the covariance (bq/bqmtran.py:198 `model_var * I_out`). */
@@ -229,6 +231,12 @@ ssmq_transform *ssmq_transform_create(int D, int E, int N, int form, const doubl
  * research/tpq/tpq_ungm.py:114-124, research/bsq/bsq_tracking.py:276-281).  Any pointer may be NULL = keep. */
 int ssmq_transform_update(ssmq_transform *h, const double *xi, const double *wm, const double *Wc, const double *Wcc,
                           const double *emv, int emv_mode, double tp_nu, const double *tp_iK);
+/* The linearisation transform of ExtendedKalman (mtran.py:49-59: LinearizationTransform.apply; ssinf.py:347-357): no points and
+ * no weights - mean_f = f(mean), cov_fx = J cov, cov_f = cov_fx J' with the model's own Jacobian (the seven models whose
+ * dyn_fcn_dx / meas_fcn_dx the reference implements: UNGM, UNGM with non-additive noise, pendulum, constant velocity; every
+ * other integrand: SSMQ_E_UNSUPPORTED at apply time, where the reference's Jacobian is None).  The handle goes wherever a
+ * transform handle goes (ssmq_apply_batch[_dev], the filter / smoother entry points: time loop as a launch loop). */
+ssmq_transform *ssmq_transform_create_linear(int D, int E);
 void ssmq_transform_destroy(ssmq_transform *h);
 int ssmq_transform_dims(const ssmq_transform *h, int *D, int *E, int *N);
 

@@ -616,6 +616,53 @@ def apply_sigma(fid, mean, cov, t, pts, wm, wc_diag, p=(), state_index=None):
     return moments_sigma(fx, x, mean, wm, wc_diag)
 
 
+def jacobian(fid, x, t, p=()):
+    """Jacobian of integrand `fid` w.r.t. its own inputs at column x, for the models whose dyn_fcn_dx / meas_fcn_dx the
+    reference implements (every other one returns None there): ssmod.py:271-272 (UNGM), :305-306 (UNGM, noise as input),
+    :363-365 (pendulum), :848-852 (constant velocity - the TRANSPOSE of the transition matrix, as written there),
+    :1063-1064, :1088-1089, :1117-1118 (their measurement functions)."""
+    if fid == F_UNGM_DYN:
+        return np.array([[0.5 + 25 * (1 - x[0] ** 2) / (1 + x[0] ** 2) ** 2]])
+    if fid == F_UNGMNA_DYN:
+        return np.array([[0.5 + 25 * (1 - x[0] ** 2) / (1 + x[0] ** 2) ** 2, 8 * np.cos(1.2 * t)]])
+    if fid == F_PENDULUM_DYN:
+        return np.array([[1.0, p[0]], [-9.81 * p[0] * np.cos(x[0]), 1.0]])
+    if fid == F_CV_DYN:
+        dt = p[0]
+        return np.array([[1, dt, 0, 0], [0, 1, 0, 0], [0, 0, 1, dt], [0, 0, 0, 1]], dtype=float).T
+    if fid == F_UNGM_MEAS:
+        return np.array([[0.1 * x[0]]])
+    if fid == F_UNGMNA_MEAS:
+        return np.array([[0.1 * x[1] * x[0], 0.05 * x[0] ** 2]])
+    if fid == F_PENDULUM_MEAS:
+        return np.array([[np.cos(x[0])]])
+    return None
+
+
+def apply_linear(fid, mean, cov, t, p=(), state_index=None):
+    """Linearisation transform, mtran.py:49-59: mean_f = f(mean), cov_fx = J cov, cov_f = cov_fx J'.  The Jacobian is placed
+    into the columns of the full input as MeasurementModel.meas_eval does (ssmod.py:985-1009): through the state index, or -
+    without one - by `out[:, None] = jac`, which numpy BROADCASTS when jac has one column and the input more (the pendulum's
+    measurement on its 2-D state gets cos(x0) in both columns); kept."""
+    D = mean.shape[0]
+    xs = mean if state_index is None else mean[np.asarray(state_index)]
+    mean_f = integrand(fid, xs, t, p)
+    js = jacobian(fid, xs, t, p)
+    if js is None:
+        raise ValueError('integrand {} has no Jacobian'.format(fid))
+    J = np.zeros((mean_f.shape[0], D))
+    if state_index is not None:
+        J[:, np.asarray(state_index)[:js.shape[1]]] = js
+    elif js.shape[1] == D:
+        J[:] = js
+    elif js.shape[1] == 1:
+        J[:] = js                      # broadcast over the columns
+    else:
+        raise ValueError('a Jacobian of 1 < columns < D without a state index cannot be placed')
+    cov_fx = J.dot(cov)
+    return mean_f, cov_fx.dot(J.T), cov_fx
+
+
 # --------------------------------------------------------------------------------------------------------------
 # filter recursions around the path (callers; SURVEY.md 8f-1)
 # --------------------------------------------------------------------------------------------------------------

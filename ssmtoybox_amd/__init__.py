@@ -7,7 +7,7 @@ and ctypes.  No PyTorch, no NumPy fallback: without libssmq.so and a GPU the com
 """
 from ._lib import SsmqError, device_count, set_device, device_name  # noqa: F401
 from .mtran import (MomentTransform, SigmaPointTransform, UnscentedTransform, SphericalRadialTransform,  # noqa: F401
-                    GaussHermiteTransform, FullySymmetricStudentTransform, MonteCarloTransform)
+                    GaussHermiteTransform, FullySymmetricStudentTransform, MonteCarloTransform, LinearizationTransform)
 from .bq.bqmtran import (BQTransform, GaussianProcessTransform, BayesSardTransform,  # noqa: F401
                          StudentTProcessTransform)
 

@@ -91,6 +91,7 @@ _PROTOTYPES = {
                                          c_int32_p, ctypes.c_int, c_double_p, c_double_p, c_int32_p]),
     'ssmq_transform_create': (ctypes.c_void_p, [ctypes.c_int] * 4 + [c_double_p] * 5 + [ctypes.c_int, ctypes.c_double,
                                                                                        c_double_p]),
+    'ssmq_transform_create_linear': (ctypes.c_void_p, [ctypes.c_int, ctypes.c_int]),
     'ssmq_transform_update': (ctypes.c_int, [ctypes.c_void_p] + [c_double_p] * 5 + [ctypes.c_int, ctypes.c_double,
                                                                                     c_double_p]),
     'ssmq_transform_destroy': (None, [ctypes.c_void_p]),

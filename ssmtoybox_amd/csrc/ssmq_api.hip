@@ -442,6 +442,20 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     FInfo fi;
     int rc = check_integrand(h, f, &fi);
     if (rc) return rc;
+    if (h->form == SSMQ_FORM_TAYLOR1) {
+        // the linearisation transform (mtran.py:49-59): no points, no weights, one launch (ssmq_linear.hip)
+        if (kernel_name) *kernel_name = "k_linearize";
+        if (dry_run || B <= 0) return SSMQ_OK;
+        if (!d_mean || !d_cov || !d_mean_f || !d_cov_f || !d_cov_fx || !d_status || (fi.uses_time && !d_time) || ld < B) {
+            set_error("apply: null pointer or ld < B");
+            return SSMQ_E_ARG;
+        }
+        FPar fp;
+        fill_fpar(f, &fp);
+        fp.ttab = ttab;
+        return launch_linearize(h->D, h->E, fi.din, f, fp, B, ld, d_mean, d_cov, d_time, d_time ? time_stride : 0, d_mean_f, d_cov_f,
+                                d_cov_fx, d_status, d_cov_add, cov_scale, ccov_scale, stream());
+    }
     const int tp = h->tp_nu > 0.0 ? 1 : 0;
     const int sel = sel_pattern(f, fi.din);
     const SmallEntry *se = nullptr;
@@ -825,9 +839,28 @@ ssmq_transform *ssmq_transform_create(int D, int E, int N, int form, const doubl
     return h;
 }
 
+// The linearisation transform has neither points nor weights; the handle keeps a one-point placeholder block so that every
+// code path that sizes or frees constants finds what it expects.
+ssmq_transform *ssmq_transform_create_linear(int D, int E) {
+    if (D < 1 || D > SSMQ_MAX_DIM || E < 1 || E > SSMQ_MAX_DIM) {
+        set_error("transform_create_linear: bad argument");
+        return nullptr;
+    }
+    std::vector<double> xi((size_t)D, 0.0);
+    const double one = 1.0;
+    ssmq_transform *h = ssmq_transform_create(D, E, 1, SSMQ_FORM_SIGMA, xi.data(), &one, &one, nullptr, nullptr, SSMQ_EMV_DIAG, 0.0,
+                                              nullptr);
+    if (h) h->form = SSMQ_FORM_TAYLOR1;
+    return h;
+}
+
 int ssmq_transform_update(ssmq_transform *h, const double *xi, const double *wm, const double *Wc, const double *Wcc,
                           const double *emv, int emv_mode, double tp_nu, const double *tp_iK) {
     SSMQ_API_LOCK();
+    if (h && h->form == SSMQ_FORM_TAYLOR1) {
+        set_error("transform_update: the linearisation transform has no constants");
+        return SSMQ_E_ARG;
+    }
     if (!h) return SSMQ_E_ARG;
     const int D = h->D, E = h->E, N = h->N;
     if (xi) h->xi.assign(xi, xi + D * N);
@@ -1078,6 +1111,10 @@ int ssmq_apply_batch(ssmq_transform *h, const ssmq_integrand *f, int64_t B, cons
 int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, const double *cov, double *x,
                             double *chol, int32_t *status) {
     SSMQ_API_LOCK();
+    if (h && h->form == SSMQ_FORM_TAYLOR1) {
+        set_error("the linearisation transform has no sigma points");
+        return SSMQ_E_UNSUPPORTED;
+    }
     if (!h || B < 0 || !mean || !cov || !x || !chol) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -1121,6 +1158,10 @@ int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, co
 int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const double *mean, const double *x,
                         const double *fx, double *mean_f, double *cov_f, double *cov_fx) {
     SSMQ_API_LOCK();
+    if (h && h->form == SSMQ_FORM_TAYLOR1) {
+        set_error("the linearisation transform has no sigma points");
+        return SSMQ_E_UNSUPPORTED;
+    }
     if (!h || B < 0 || !chol || !fx || !mean_f || !cov_f || !cov_fx) return SSMQ_E_ARG;
     if (h->form == SSMQ_FORM_SIGMA && (!mean || !x)) {
         set_error("apply_fx_batch: the centred form needs mean and x");
@@ -1227,6 +1268,10 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
 int ssmq_fxwc_batch_dev(ssmq_transform *h, int64_t M, const double *d_fx, int64_t ld_fx, double *d_t, int64_t ld_t,
                         int *n_padded) {
     SSMQ_API_LOCK();
+    if (h && h->form == SSMQ_FORM_TAYLOR1) {
+        set_error("the linearisation transform has no sigma points");
+        return SSMQ_E_UNSUPPORTED;
+    }
     if (!h || M < 0 || (M > 0 && (!d_fx || !d_t))) {
         set_error("fxwc_batch: bad argument");
         return SSMQ_E_ARG;
@@ -1406,7 +1451,7 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
     for (size_t i = 0; i + 8 <= sizeof(ssmq_integrand); i += 8) { uint64_t v; memcpy(&v, fb + i, 8); key.push_back(v); }
     key.push_back((uint64_t)h_dyn->emv_mode * 2 + (uint64_t)h_obs->emv_mode);
     key.push_back(((uint64_t)D << 48) | ((uint64_t)Y << 32) | ((uint64_t)h_dyn->N << 16) | (uint64_t)h_obs->N);
-    key.push_back(((uint64_t)h_dyn->form << 1) | (uint64_t)h_obs->form);
+    key.push_back(((uint64_t)h_dyn->form << 2) | (uint64_t)h_obs->form);
     key.push_back((uint64_t)(uintptr_t)h_obs->d_small);
     // which kernel variant apply_dev_impl picks depends on the fast paths the handle's CURRENT constants qualify for:
     // ssmq_transform_update keeps the block addresses but may withdraw SSMQ_OPT_LDL (and zero its factors)

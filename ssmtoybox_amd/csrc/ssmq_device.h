@@ -434,6 +434,63 @@ __device__ __forceinline__ void eval_integrand(int id, const double *xs, double 
 #undef SSMQ_CASE
 }
 
+// Jacobian of integrand `id` at xs with respect to its own inputs (the leading DIN of them): J[e * ldj + k] = d out_e / d xs_k.
+// Only the models whose dyn_fcn_dx / meas_fcn_dx the reference implements (ssmod.py:271-272, 305-306, 363-365, 848-852,
+// 1063-1064, 1088-1089, 1117-1118; every other model's returns None there and its ExtendedKalman raises).  Formulas as written
+// in the reference - including ConstantVelocity's, which returns the TRANSPOSE of its transition matrix (ssmod.py:848-852).
+// Returns false for an integrand without one.
+__device__ __forceinline__ bool jac_integrand(int id, const double *xs, double t, const FPar &fp, double *J, int ldj) {
+    switch (id) {
+        case SSMQ_F_UNGM_DYN: {
+            const double x2 = xs[0] * xs[0], d = 1.0 + x2;
+            J[0] = 0.5 + div_nr(25.0 * (1.0 - x2), d * d);
+            return true;
+        }
+        case SSMQ_F_UNGMNA_DYN: {
+            Fn<SSMQ_F_UNGMNA_DYN> fn;
+            fn.init(t, fp);                                  // c = cos(1.2 t), from the table where there is one
+            const double x2 = xs[0] * xs[0], d = 1.0 + x2;
+            J[0] = 0.5 + div_nr(25.0 * (1.0 - x2), d * d);
+            J[1] = 8.0 * fn.c;
+            return true;
+        }
+        case SSMQ_F_PENDULUM_DYN: {
+            const double dt = fp.p[0];
+            double sn, cs;
+            sincos_nr(xs[0], &sn, &cs);
+            J[0] = 1.0; J[1] = dt;
+            J[ldj] = -9.81 * dt * cs; J[ldj + 1] = 1.0;
+            return true;
+        }
+        case SSMQ_F_CV_DYN: {
+            const double dt = fp.p[0];
+            for (int e = 0; e < 4; ++e)
+                for (int k = 0; k < 4; ++k) J[e * ldj + k] = (e == k) ? 1.0 : 0.0;
+            J[1 * ldj + 0] = dt;                             // (the transpose of [[1, dt, 0, 0], [0, 1, 0, 0], [0, 0, 1, dt], [0, 0, 0, 1]])
+            J[3 * ldj + 2] = dt;
+            return true;
+        }
+        case SSMQ_F_UNGM_MEAS:
+            J[0] = 0.1 * xs[0];
+            return true;
+        case SSMQ_F_UNGMNA_MEAS:
+            J[0] = 0.1 * xs[1] * xs[0];
+            J[1] = 0.05 * (xs[0] * xs[0]);
+            return true;
+        case SSMQ_F_PENDULUM_MEAS: {
+            double sn, cs;
+            sincos_nr(xs[0], &sn, &cs);
+            J[0] = cs;
+            return true;
+        }
+        default: return false;
+    }
+}
+__host__ __device__ inline bool integrand_has_jacobian(int id) {
+    return id == SSMQ_F_UNGM_DYN || id == SSMQ_F_UNGMNA_DYN || id == SSMQ_F_PENDULUM_DYN || id == SSMQ_F_CV_DYN ||
+           id == SSMQ_F_UNGM_MEAS || id == SSMQ_F_UNGMNA_MEAS || id == SSMQ_F_PENDULUM_MEAS;
+}
+
 // Host: the time-dependent constant of integrand `id` for times 0..T-1 (what Fn<id>::init would compute), or false if the
 // integrand has none.  Evaluated with the host libm in fp64 - the reference evaluates np.cos on the host as well.
 __host__ inline bool time_table(int id, int T, double *out) {

@@ -80,6 +80,11 @@ bool bq_stream_supported(int D, int E, int N);
 int bq_stream_tpw(int E);          // trajectories per 64-row block of FX (fragment order, WideArgs::fx_frag)
 size_t bq_stream_x_doubles(int N);
 void bq_stream_pack(int D, int N, const double *Wc, const double *Wcc, const double *wm, double *X);
+// linearisation transform (ssmq_linear.hip): mean_f = f(mean), cov_fx = J cov, cov_f = cov_fx J' with the model's own Jacobian
+struct FPar;
+int launch_linearize(int D, int E, int din, const ssmq_integrand *f, const FPar &fp, int64_t B, int64_t ld, const double *d_mean,
+                     const double *d_cov, const double *d_time, int time_stride, double *d_mean_f, double *d_cov_f, double *d_cov_fx,
+                     int32_t *d_status, const double *d_cov_add, double cov_scale, double ccov_scale, hipStream_t s);
 int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, const double *fx,
                      const double *chol, int64_t lda, hipStream_t s);
 int launch_fxwc_cov_mfma(int NP, const double *A, const double *X, int64_t M, int lda, const double *mean_rows,

@@ -182,6 +182,44 @@ class _DeviceApply:
         return buf.value.decode()
 
 
+class LinearizationTransform(_DeviceApply, MomentTransform):
+    """First-order Taylor (linearisation) transform of the extended Kalman filter (mtran.py:49-59):
+    mean_f = f(mean), J = f(mean, dx=True), cov_fx = J cov, cov_f = cov_fx J' - one launch of `k_linearize`
+    (csrc/ssmq_linear.hip) for a batch.  `f` must be the bound dyn_eval / meas_eval of a model whose Jacobian the reference
+    implements (UNGM, UNGM with non-additive noise, pendulum, constant velocity: ssmod.py dyn_fcn_dx / meas_fcn_dx); for the
+    others the reference's Jacobian is None and its apply() raises - here `SsmqError` (SSMQ_E_UNSUPPORTED)."""
+
+    def __init__(self, dim):
+        self.dim = dim
+        self._dev = {}
+
+    def _handle_for(self, E):
+        h = self._dev.get(E)
+        if h is None:
+            h = _lib.load().ssmq_transform_create_linear(int(self.dim), int(E))
+            if not h:
+                raise _lib.SsmqError('ssmq_transform_create_linear failed: ' + _lib.last_error())
+            self._dev[E] = h
+        return h
+
+    def _num_points(self):
+        return 0
+
+    def apply_batch(self, f, mean, cov, time=0.0, fcn_pars=None, return_status=False):
+        if resolve_integrand(f) is None:
+            raise NotImplementedError('LinearizationTransform needs a built-in model (device integrand with a Jacobian)')
+        return super().apply_batch(f, mean, cov, time=time, fcn_pars=fcn_pars, return_status=return_status)
+
+    def __del__(self):
+        try:
+            lib = _lib.load()
+            for h in self._dev.values():
+                lib.ssmq_transform_destroy(ctypes.c_void_p(h))
+            self._dev = {}
+        except Exception:
+            pass
+
+
 """
 Sigma-point transforms.
 """

@@ -20,7 +20,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .mtran import (MomentTransform, UnscentedTransform, SphericalRadialTransform, GaussHermiteTransform,
+from .mtran import (MomentTransform, LinearizationTransform, UnscentedTransform, SphericalRadialTransform, GaussHermiteTransform,
                     FullySymmetricStudentTransform, resolve_integrand)
 from .bq.bqmtran import GaussianProcessTransform, BayesSardTransform, StudentTProcessTransform
 from .ssmod import TransitionModel, MeasurementModel
@@ -226,6 +226,14 @@ class CubatureKalman(GaussianInference):
 
     def __init__(self, dyn, obs):
         super().__init__(dyn, obs, SphericalRadialTransform(dyn.dim_in), SphericalRadialTransform(obs.dim_in))
+
+
+class ExtendedKalman(GaussianInference):
+    """Extended Kalman filter and smoother (ssinf.py:347-357): both transforms are linearisations around the mean.  Runs for
+    the models whose Jacobians the reference implements (its own test skips the others: tests/test_ssinf.py:96-101)."""
+
+    def __init__(self, dyn, obs):
+        super().__init__(dyn, obs, LinearizationTransform(dyn.dim_in), LinearizationTransform(obs.dim_in))
 
 
 class UnscentedKalman(GaussianInference):

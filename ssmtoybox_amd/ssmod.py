@@ -182,11 +182,17 @@ class TransitionModel:
 
     def dyn_eval(self, xq, time, dx=False):
         """Noise-additivity-aware evaluation (ssmod.py:129-166): additive models are evaluated at zero noise."""
-        if dx:
-            raise NotImplementedError('Jacobians are outside the moment-transform path')
+        if dx:                          # ssmod.py:153-165; None for the models without dyn_fcn_dx, as in the reference
+            if self.noise_additive:
+                return self.dyn_fcn_dx(xq, self.zero_q, time)
+            return self.dyn_fcn_dx(xq[:self.dim_state], xq[-self.dim_noise:], time)
         if self.noise_additive:
             return self.dyn_fcn(xq, self.zero_q, time)
         return self.dyn_fcn(xq[:self.dim_state], xq[-self.dim_noise:], time)
+
+    def dyn_fcn_dx(self, x, q, time):
+        """Jacobian of the dynamics (ssmod.py:105-127): implemented by UNGM, UNGM-NA, pendulum and constant velocity only."""
+        return None
 
 
 class UNGMTransition(TransitionModel):
@@ -196,6 +202,9 @@ class UNGMTransition(TransitionModel):
     def dyn_fcn(self, x, q, time):
         return np.asarray(0.5 * x[0] + 25 * (x[0] / (1 + x[0] ** 2)) + 8 * np.cos(1.2 * time)) + q
 
+    def dyn_fcn_dx(self, x, q, time):
+        return np.asarray([[0.5 + 25 * (1 - x[0] ** 2) / (1 + x[0] ** 2) ** 2]])          # ssmod.py:271-272
+
 
 class UNGMNATransition(TransitionModel):
     """ssmod.py:278-306 (non-additive noise: input [x, q])."""
@@ -203,6 +212,9 @@ class UNGMNATransition(TransitionModel):
 
     def dyn_fcn(self, x, q, time):
         return np.asarray(0.5 * x[0] + 25 * (x[0] / (1 + x[0] ** 2)) + 8 * q[0] * np.cos(1.2 * time))
+
+    def dyn_fcn_dx(self, x, q, time):
+        return np.asarray([[0.5 + 25 * (1 - x[0] ** 2) / (1 + x[0] ** 2) ** 2, 8 * np.cos(1.2 * time)]])   # ssmod.py:305-306
 
 
 class Pendulum2DTransition(TransitionModel):
@@ -219,6 +231,9 @@ class Pendulum2DTransition(TransitionModel):
 
     def dyn_fcn(self, x, q, time):
         return np.array([x[0] + x[1] * self.dt, x[1] - self.g * self.dt * np.sin(x[0])]) + q
+
+    def dyn_fcn_dx(self, x, r, time):
+        return np.array([[1.0, self.dt], [-self.g * self.dt * np.cos(x[0]), 1.0]])           # ssmod.py:363-365
 
 
 class ReentryVehicle1DTransition(TransitionModel):
@@ -362,6 +377,10 @@ class ConstantVelocity(TransitionModel):
     def dyn_fcn(self, x, q, time):
         return np.array([x[0] + self.dt * x[1], x[1], x[2] + self.dt * x[3], x[3]]) + self.noise_gain.dot(q)
 
+    def dyn_fcn_dx(self, x, q, time):
+        # ssmod.py:848-852 returns the TRANSPOSE of the transition matrix; kept as written
+        return np.array([[1, self.dt, 0, 0], [0, 1, 0, 0], [0, 0, 1, self.dt], [0, 0, 0, 1]]).T
+
 
 class MeasurementModel:
     """y_k = h(x_k, r_k, k)   (ssmod.py:863-1039)."""
@@ -418,7 +437,20 @@ class MeasurementModel:
     def meas_eval(self, xr, time, dx=False):
         """ssmod.py:960-1009."""
         if dx:
-            raise NotImplementedError('Jacobians are outside the moment-transform path')
+            # ssmod.py:985-1009, as written there: with state_index = None the assignment `out[:, None] = jac` broadcasts a
+            # one-column Jacobian into every state column (the device kernel does the same: csrc/ssmq_linear.hip)
+            if self.state_index is not None:
+                xr = xr[self.state_index]
+            if self.noise_additive:
+                out = np.zeros((self.dim_out, self.dim_state))
+                out[:, self.state_index] = self.meas_fcn_dx(xr, self.zero_r, time)
+                return out
+            x, r = xr[:self.dim_substate], xr[-self.dim_noise:]
+            out = np.zeros((self.dim_out, self.dim_state + self.dim_noise))
+            jac = self.meas_fcn_dx(x, r, time)
+            out[:, self.state_index] = jac[:, :self.dim_substate]
+            out[:, self.dim_state:] = jac[:, self.dim_substate:]
+            return out
         if self.noise_additive:
             if self.state_index is not None:
                 xr = xr[self.state_index]
@@ -428,6 +460,10 @@ class MeasurementModel:
             x = x[self.state_index]
         return self.meas_fcn(x, r, time)
 
+    def meas_fcn_dx(self, x, r, time):
+        """Jacobian of the measurement function (ssmod.py:937-958): UNGM, UNGM-NA and pendulum only."""
+        return None
+
 
 class UNGMMeasurement(MeasurementModel):
     """ssmod.py:1042-1064."""
@@ -435,6 +471,9 @@ class UNGMMeasurement(MeasurementModel):
 
     def meas_fcn(self, x, r, time):
         return np.asarray([0.05 * x[0] ** 2]) + r
+
+    def meas_fcn_dx(self, x, r, time):
+        return np.asarray([0.1 * x[0]])                                                    # ssmod.py:1063-1064
 
 
 class UNGMNAMeasurement(MeasurementModel):
@@ -444,6 +483,9 @@ class UNGMNAMeasurement(MeasurementModel):
     def meas_fcn(self, x, r, time):
         return np.asarray([0.05 * r[0] * x[0] ** 2])
 
+    def meas_fcn_dx(self, x, r, time):
+        return np.asarray([[0.1 * r[0] * x[0], 0.05 * x[0] ** 2]])                          # ssmod.py:1088-1089
+
 
 class Pendulum2DMeasurement(MeasurementModel):
     """ssmod.py:1092-1118."""
@@ -451,6 +493,9 @@ class Pendulum2DMeasurement(MeasurementModel):
 
     def meas_fcn(self, x, r, time):
         return np.array([np.sin(x[0])]) + r
+
+    def meas_fcn_dx(self, x, r, time):
+        return np.array([[np.cos(x[0])]])                                                  # ssmod.py:1117-1118
 
 
 class RangeMeasurement(MeasurementModel):

@@ -858,8 +858,76 @@ def g12_large_weights():
 
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G13: linearisation transform (mtran.py:49-59) and the extended Kalman filter / smoother (ssinf.py:347-357) on the models
+# whose Jacobians the reference implements (its own test skips the rest: tests/test_ssinf.py:96-101)
+# ---------------------------------------------------------------------------------------------------------------
+def g13_linear():
+    from ssmtoybox.mtran import LinearizationTransform
+    out = {}
+    rng = np.random.default_rng(13)
+    dt = 0.01
+    q2 = GaussRV(2, cov=0.01 * np.array([[(dt ** 3) / 3, (dt ** 2) / 2], [(dt ** 2) / 2, dt]]))
+    models = {
+        'ungm_dyn': (ssmod.UNGMTransition(GaussRV(1), GaussRV(1, cov=np.array([[10.0]]))), 'dyn'),
+        'ungmna_dyn': (ssmod.UNGMNATransition(GaussRV(1), GaussRV(1, cov=np.array([[10.0]]))), 'dyn'),
+        'pend_dyn': (ssmod.Pendulum2DTransition(GaussRV(2, mean=np.array([1.5, 0]), cov=0.01 * np.eye(2)), q2, dt=dt), 'dyn'),
+        'cv_dyn': (ssmod.ConstantVelocity(GaussRV(4), GaussRV(2), dt=0.5), 'dyn'),
+        'ungm_meas': (ssmod.UNGMMeasurement(GaussRV(1), 1), 'meas'),
+        'ungmna_meas': (ssmod.UNGMNAMeasurement(GaussRV(1), 1), 'meas'),
+        'pend_meas': (ssmod.Pendulum2DMeasurement(GaussRV(1, cov=np.array([[0.1]])), 2), 'meas'),
+        'pend_meas_idx': (ssmod.Pendulum2DMeasurement(GaussRV(1, cov=np.array([[0.1]])), 2, state_index=[0]), 'meas'),
+    }
+    for tag, (mod, kind) in models.items():
+        f = mod.dyn_eval if kind == 'dyn' else mod.meas_eval
+        D = mod.dim_in
+        tf = LinearizationTransform(D)
+        n = 6
+        means = rng.standard_normal((n, D))
+        a = rng.standard_normal((n, D, D))
+        covs = np.einsum('bij,bkj->bik', a, a) + 0.2 * np.eye(D)
+        times = np.arange(n, dtype=float)
+        mf, cf, cfx = [], [], []
+        for i in range(n):
+            # (a scalar time: with the 1-element array the filters pass, UNGMNATransition.dyn_fcn_dx builds a ragged list and
+            # NumPy >= 1.24 raises - which is also why there is no 'ungmna' filter below)
+            r = tf.apply(f, means[i], covs[i], float(times[i]))
+            mf.append(np.atleast_1d(r[0])), cf.append(np.atleast_2d(r[1])), cfx.append(np.atleast_2d(r[2]))
+        out[tag + '_mean'], out[tag + '_cov'], out[tag + '_time'] = means, covs, times
+        out[tag + '_mf'], out[tag + '_cf'], out[tag + '_cfx'] = np.array(mf), np.array(cf), np.array(cfx)
+    # extended Kalman filter + RTS smoother, the three set-ups of tests/test_ssinf.py:23-50
+    steps, seeds = 60, 5
+    setups = {
+        'ungm': (ssmod.UNGMTransition(GaussRV(1), GaussRV(1, cov=np.array([[10.0]]))), ssmod.UNGMMeasurement(GaussRV(1), 1)),
+        'pend': (ssmod.Pendulum2DTransition(GaussRV(2, mean=np.array([1.5, 0]), cov=0.01 * np.eye(2)), q2, dt=dt),
+                 ssmod.Pendulum2DMeasurement(GaussRV(1, cov=np.array([[0.1]])), 2)),
+    }
+    for k, (tag, (dyn, obs)) in enumerate(setups.items()):
+        np.random.seed(1300 + k)
+        x = dyn.simulate_discrete(steps, seeds)
+        y = obs.simulate_measurements(x)
+        D = dyn.dim_state
+        alg = ssinf.ExtendedKalman(dyn, obs)
+        fm, fc = np.full((D, steps, seeds), np.nan), np.full((D, D, steps, seeds), np.nan)
+        sm, sc = fm.copy(), fc.copy()
+        okm = np.ones(seeds, dtype=bool)
+        for s in range(seeds):
+            try:
+                fm[..., s], fc[..., s] = alg.forward_pass(y[..., s])
+                sm[..., s], sc[..., s] = alg.backward_pass()
+            except np.linalg.LinAlgError:
+                okm[s] = False
+            alg.reset()
+        out['ekf_' + tag + '_x'], out['ekf_' + tag + '_y'], out['ekf_' + tag + '_ok'] = x, y, okm
+        out['ekf_' + tag + '_fm'], out['ekf_' + tag + '_fc'] = fm, fc
+        out['ekf_' + tag + '_sm'], out['ekf_' + tag + '_sc'] = sm, sc
+    save('g13_linear', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13']
+    if 'g13' in which:
+        g13_linear()
     if 'g1' in which:
         g1_points()
     if 'g2' in which:

@@ -3131,3 +3131,117 @@ def test_config4_tpq_ct_bearing_1e4(amd):
     bars = (1e-10, 1e-9, 1e-8, 1e-6, 1e-4, 5e-2)     # measured maxima: 1.8e-12, 1.1e-11, 1.9e-10, 5.2e-8, 7.0e-6, 1.8e-3
     for k in range(T):
         assert within(float(np.max(rel[k])), bars[k], 'configs[3] TPQKF step %d max rel diff vs C oracle' % (k + 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# linearisation transform and the extended Kalman filter (mtran.py:49-59, ssinf.py:347-357; golden g13)
+# ---------------------------------------------------------------------------------------------------------------
+def _linear_models():
+    from ssmtoybox_amd import ssmod as sm
+    dt = 0.01
+    q2 = sm.GaussRV(2, cov=0.01 * np.array([[(dt ** 3) / 3, (dt ** 2) / 2], [(dt ** 2) / 2, dt]]))
+    return {
+        'ungm_dyn': (sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]]))), 'dyn', orc.F_UNGM_DYN, (), None),
+        'ungmna_dyn': (sm.UNGMNATransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]]))), 'dyn', orc.F_UNGMNA_DYN, (), None),
+        'pend_dyn': (sm.Pendulum2DTransition(sm.GaussRV(2, mean=np.array([1.5, 0]), cov=0.01 * np.eye(2)), q2, dt=dt), 'dyn',
+                     orc.F_PENDULUM_DYN, (dt,), None),
+        'cv_dyn': (sm.ConstantVelocity(sm.GaussRV(4), sm.GaussRV(2), dt=0.5), 'dyn', orc.F_CV_DYN, (0.5,), None),
+        'ungm_meas': (sm.UNGMMeasurement(sm.GaussRV(1), 1), 'meas', orc.F_UNGM_MEAS, (), None),
+        'ungmna_meas': (sm.UNGMNAMeasurement(sm.GaussRV(1), 1), 'meas', orc.F_UNGMNA_MEAS, (), None),
+        'pend_meas': (sm.Pendulum2DMeasurement(sm.GaussRV(1, cov=np.array([[0.1]])), 2), 'meas', orc.F_PENDULUM_MEAS, (), None),
+        'pend_meas_idx': (sm.Pendulum2DMeasurement(sm.GaussRV(1, cov=np.array([[0.1]])), 2, state_index=[0]), 'meas',
+                          orc.F_PENDULUM_MEAS, (), [0]),
+    }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['ungm_dyn', 'ungmna_dyn', 'pend_dyn', 'cv_dyn', 'ungm_meas', 'ungmna_meas', 'pend_meas', 'pend_meas_idx'])
+def test_linearization_transform_golden(amd, golden, tag):
+    """LinearizationTransform.apply (k_linearize through ssmq_apply_batch) against the reference's outputs (golden g13) one
+    input at a time, then one batch of 3000 inputs against the oracle; the host mirror of the model's Jacobian
+    (dyn_eval / meas_eval with dx=True) against the oracle's."""
+    g = golden('g13_linear')
+    mod, kind, fid, p, idx = _linear_models()[tag]
+    f = mod.dyn_eval if kind == 'dyn' else mod.meas_eval
+    D = mod.dim_in
+    tf = amd.LinearizationTransform(D)
+    assert tf.kernel_name(f) == 'k_linearize'
+    for i in range(g[tag + '_mean'].shape[0]):
+        mean, cov, t = g[tag + '_mean'][i], g[tag + '_cov'][i], g[tag + '_time'][i]
+        got = tf.apply(f, mean, cov, np.atleast_1d(t))
+        ref = (g[tag + '_mf'][i], g[tag + '_cf'][i], g[tag + '_cfx'][i])
+        for a, b, what in zip(got, ref, ('mean', 'cov', 'ccov')):
+            assert within(rel_err(a, b), 1e-12, 'g13 {} input {} {} vs the reference'.format(tag, i, what))
+        # host mirror of meas_eval / dyn_eval with dx=True: the Jacobian in the columns of the full input
+        J = f(mean, t, dx=True)
+        xs = mean if idx is None else mean[np.asarray(idx)]
+        js = orc.jacobian(fid, xs, t, p)
+        assert np.allclose(J.dot(cov), ref[2], rtol=1e-12, atol=1e-300), (tag, i, J, js)
+    rng = np.random.default_rng(5)
+    B = 3000
+    means = rng.standard_normal((B, D))
+    a = rng.standard_normal((B, D, D))
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.2 * np.eye(D)
+    times = np.arange(B, dtype=float) % 50
+    mf, cf, cfx, st = tf.apply_batch(f, means, covs, times, return_status=True)
+    assert not st.any()
+    worst = 0.0
+    for i in range(0, B, 37):
+        r = orc.apply_linear(fid, means[i], covs[i], times[i], p, idx)
+        for a_, b_ in zip((mf[i], cf[i], cfx[i]), r):
+            worst = max(worst, rel_err(a_, b_))
+    assert within(worst, 1e-12, 'k_linearize {} batch of 3000 vs oracle'.format(tag))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['ungm', 'pend'])
+def test_extended_kalman_golden(amd, golden, tag):
+    """ExtendedKalman forward pass and RTS smoother (launch loop of k_linearize / k_kalman_update, smoother kernel) against the
+    reference's runs (golden g13: the set-ups of its tests/test_ssinf.py)."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    g = golden('g13_linear')
+    y = g['ekf_' + tag + '_y']
+    if tag == 'ungm':
+        dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+        obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    else:
+        dt = 0.01
+        q2 = sm.GaussRV(2, cov=0.01 * np.array([[(dt ** 3) / 3, (dt ** 2) / 2], [(dt ** 2) / 2, dt]]))
+        dyn = sm.Pendulum2DTransition(sm.GaussRV(2, mean=np.array([1.5, 0]), cov=0.01 * np.eye(2)), q2, dt=dt)
+        obs = sm.Pendulum2DMeasurement(sm.GaussRV(1, cov=np.array([[0.1]])), 2)
+    alg = ssinf.ExtendedKalman(dyn, obs)
+    assert isinstance(alg.tf_dyn, amd.LinearizationTransform)
+    fm, fP = alg.forward_pass_batch(y)
+    assert within(rel_err(fm, g['ekf_' + tag + '_fm']), 1e-9, 'EKF {} filtered means vs the reference'.format(tag))
+    assert within(rel_err(fP, g['ekf_' + tag + '_fc']), 1e-9, 'EKF {} filtered covariances vs the reference'.format(tag))
+    sm_, sP = alg.backward_pass_batch()
+    assert within(rel_err(sm_, g['ekf_' + tag + '_sm']), 1e-8, 'EKF {} smoothed means vs the reference'.format(tag))
+    assert within(rel_err(sP, g['ekf_' + tag + '_sc']), 1e-8, 'EKF {} smoothed covariances vs the reference'.format(tag))
+    # one trajectory through the drop-in call
+    f1, P1 = alg.forward_pass(y[..., 0])
+    assert np.array_equal(f1, fm[..., 0]) and np.array_equal(P1, fP[..., 0])
+
+
+@pytest.mark.gpu
+def test_extended_kalman_nonadditive_and_unsupported(amd):
+    """UNGM with the noise as an input (the reference's own EKF run of this model stops in NumPy >= 1.24 on a ragged list in
+    dyn_fcn_dx, so the oracle's recursion is the comparison); a model without a Jacobian fails loudly, as the reference's does."""
+    from ssmtoybox_amd import ssinf, ssmod as sm, _lib as L
+    dyn = sm.UNGMNATransition(sm.GaussRV(1, mean=np.array([1.0])), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMNAMeasurement(sm.GaussRV(1), 1)
+    x = dyn.simulate_discrete(40, 6, seed=3)
+    y = obs.simulate_measurements(x, seed=4)
+    alg = ssinf.ExtendedKalman(dyn, obs)
+    fm, fP = alg.forward_pass_batch(y)
+    one, z1 = np.eye(1), np.zeros(1)
+    tf_dyn = lambda m, P, t: orc.apply_linear(orc.F_UNGMNA_DYN, m, P, t)
+    tf_obs = lambda m, P, t: orc.apply_linear(orc.F_UNGMNA_MEAS, m, P, t)
+    for s in range(y.shape[2]):
+        rm, rP = orc.gaussian_filter_aug(y[..., s], np.ones(1), one, z1, 10.0 * one, z1, one, one, tf_dyn, tf_obs, False, False)
+        assert within(rel_err(fm[..., s], rm), 1e-9, 'EKF ungmna means vs oracle')
+        assert within(rel_err(fP[..., s], rP), 1e-9, 'EKF ungmna covariances vs oracle')
+    rer = sm.ReentryVehicle2DTransition(sm.GaussRV(5, cov=np.eye(5)), sm.GaussRV(3, cov=np.eye(3)))
+    with pytest.raises(L.SsmqError, match='no Jacobian'):
+        amd.LinearizationTransform(5).apply(rer.dyn_eval, np.ones(5), np.eye(5), np.atleast_1d(0))
+    with pytest.raises(NotImplementedError):
+        amd.LinearizationTransform(2).apply(lambda x, p: x, np.ones(2), np.eye(2), np.atleast_1d(0))
