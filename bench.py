@@ -70,6 +70,51 @@ def pmc_traffic(kernel_name, grid=None):
     return hits[0].get('hbm_bytes_per_launch') if len(hits) == 1 else None
 
 
+def measure_linearize(B=1000000, iters=20):
+    """The linearisation transform of the extended Kalman filter (mtran.py:49-59; csrc/ssmq_linear.hip: k_linearize) on the
+    pendulum dynamics, B = 1e6 trajectories resident in HBM: an HBM-bound map, 8 (D + D^2 + E + E^2 + E D) = 128 algorithmic
+    bytes per trajectory.  Checked against the oracle on a few trajectories."""
+    import ssmtoybox_amd as amd
+    from ssmtoybox_amd import _lib, ssmod
+    from oracle import ssmq_oracle as orc
+    mod = ssmod.Pendulum2DTransition(ssmod.GaussRV(2), ssmod.GaussRV(2), dt=0.01)
+    D = E = 2
+    tf = amd.LinearizationTransform(D)
+    rng = np.random.default_rng(2)
+    means = rng.standard_normal((B, D))
+    a = rng.standard_normal((B, D, D))
+    covs = np.einsum('bij,bkj->bik', a, a) + 0.2 * np.eye(D)
+    mean, cov = _lib.SoA.from_host(means), _lib.SoA.from_host(covs)
+    mf, cf, cfx = _lib.SoA(E, B), _lib.SoA(E * E, B), _lib.SoA(E * D, B)
+    st = _lib.DeviceBuffer(4 * mean.ld)
+    tbuf = _lib.DeviceBuffer(8)
+    tbuf.upload(np.zeros(1))
+    f = mod.dyn_eval
+    settle(lambda: tf.apply_batch_dev(f, mean, cov, tbuf, mf, cf, cfx, st, 0), _lib.sync)
+    e0, e1 = _lib.Event(), _lib.Event()
+    e0.record()
+    for _ in range(iters):
+        tf.apply_batch_dev(f, mean, cov, tbuf, mf, cf, cfx, st, 0)
+    e1.record()
+    ms = e0.elapsed_ms(e1) / iters
+    g_mf, g_cf, g_cfx = mf.to_host(), cf.to_host((E, E)), cfx.to_host((E, D))
+    err = 0.0
+    for i in (0, B // 2, B - 1):
+        r = orc.apply_linear(orc.F_PENDULUM_DYN, means[i], covs[i], 0.0, (0.01,))
+        err = max(err, float(np.abs(g_mf[i] - r[0]).max() / np.abs(r[0]).max()), float(np.abs(g_cf[i] - r[1]).max() / np.abs(r[1]).max()),
+                  float(np.abs(g_cfx[i] - r[2]).max() / np.abs(r[2]).max()))
+    name = tf.kernel_name(f)
+    for buf in (mean, cov, mf, cf, cfx):
+        buf.buf.free()
+    st.free()
+    tbuf.free()
+    nbytes = 8.0 * B * (D + D * D + E + E * E + E * D)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {'kernel': name, 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+            'ms_per_launch': ms, 'bytes_per_launch': nbytes, 'transforms_per_s': B / (ms * 1e-3), 'max_rel_err_vs_oracle': err,
+            'workload': 'LinearizationTransform (the transform of ExtendedKalman), pendulum dynamics D=E=2, B=1e6'}
+
+
 def measure_theta_step(calls=1000):
     """Latency of the theta-batched step of the marginalised GPQ filter (`ssmq_gp_theta_step`, one call =
     weights of both transforms, time update, measurement transform, Kalman update and log-likelihood for every parameter
@@ -1214,6 +1259,7 @@ def main():
         out['roofline_c5']['degree7_as_worded'] = measure_c5_degree7(amd, with_cpu=with_cpu)
     if rank == 0 and single and not args.no_mt6:
         out['theta_step'] = measure_theta_step()
+        out['roofline_linear'] = measure_linearize()
     if rank == 0:
         result_out.write(json.dumps(out) + '\n')
         result_out.flush()
