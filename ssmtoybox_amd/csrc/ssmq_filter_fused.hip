@@ -57,6 +57,14 @@ template <> struct HasTimeTable<SSMQ_F_UNGMNA_DYN> { static constexpr bool value
 // STU: -1 Gaussian or Studentian recursion decided at run time (a.sscale / a.student_dof), 0 / 1 fixed at compile time
 // (scalar-state kernels: on a 105-instruction step the run-time form costs two branches, three multiplications by a
 // scale of one and their operand moves - 5 us of a 43 us pass).
+#ifdef SSMQ_FUSED_NO_STORE          // A/B builds: the time loop without its stores / with ordinary (temporal) stores
+#undef SSMQ_STORE
+#define SSMQ_STORE(dst, v) asm volatile("" ::"v"(v))
+#endif
+#ifdef SSMQ_FUSED_PLAIN_STORE
+#undef SSMQ_STORE
+#define SSMQ_STORE(dst, v) (dst) = (v)
+#endif
 #ifndef SSMQ_FUSED_FORCE_OCC
 #define SSMQ_FUSED_FORCE_OCC 0   // A/B builds (tools/build_variant.sh): waves per SIMD requested for every instantiation
 #endif
@@ -87,9 +95,15 @@ __global__ __launch_bounds__(kSmallBlock, (SSMQ_FUSED_FORCE_OCC ? SSMQ_FUSED_FOR
     constexpr bool kScalar = (D == 1 && Y == 1);
     const double nan = __builtin_nan("");
     int32_t agg = 0;       // !kScalar: 1 + first failing step;  kScalar: number of steps completed without a NaN
-    double ynext[Y];       // the measurement of step k + 1 is requested one step ahead: its HBM latency hides behind step k
+#ifndef SSMQ_FUSED_YAHEAD
+#define SSMQ_FUSED_YAHEAD 1          // A/B builds: how many steps ahead the measurements are requested
+#endif
+    constexpr int YA = SSMQ_FUSED_YAHEAD;
+    double ynext[YA][Y];   // the measurement of step k + 1 is requested one step ahead: its HBM latency hides behind step k
 #pragma unroll
-    for (int i = 0; i < Y; ++i) ynext[i] = a.y[(int64_t)i * ld + b];
+    for (int q = 0; q < YA; ++q)
+#pragma unroll
+        for (int i = 0; i < Y; ++i) ynext[q][i] = a.y[((int64_t)(q < a.T ? q : a.T - 1) * Y + i) * ld + b];
     // Per-step scalars (time-table entries of the integrands, the Studentian scale) are requested one step ahead as
     // well: consumed in the step that loads them they put a scalar-cache round trip on the chain of every step.
     FPar fd = a.fd, fo = a.fo;
@@ -108,20 +122,27 @@ __global__ __launch_bounds__(kSmallBlock, (SSMQ_FUSED_FORCE_OCC ? SSMQ_FUSED_FOR
 #pragma unroll
     for (int i = 0; i < D * (D + 1) / 2; ++i) pin_v(Pl[i]);
 #pragma unroll
-    for (int i = 0; i < Y; ++i) pin_v(ynext[i]);
+    for (int q = 0; q < YA; ++q)
+#pragma unroll
+        for (int i = 0; i < Y; ++i) pin_v(ynext[q][i]);
 #pragma unroll 1
     for (int k = 0; k < a.T; ++k) {
         const double t = (double)k;  // both transforms of step k + 1 use time index k (ssinf.py:104, 276-288)
         double ycur[Y];
 #pragma unroll
-        for (int i = 0; i < Y; ++i) ycur[i] = ynext[i];
+        for (int i = 0; i < Y; ++i) ycur[i] = ynext[0][i];
+#pragma unroll
+        for (int q = 0; q + 1 < YA; ++q)
+#pragma unroll
+            for (int i = 0; i < Y; ++i) ynext[q][i] = ynext[q + 1][i];
         if constexpr (kTTd) fd.tval = tdn;
         if constexpr (kTTo) fo.tval = ton;
         const double sc = scn;
         {   // next step's inputs; the last step re-requests its own (no branch in the loop body)
             const int kn = (k + 1 < a.T) ? k + 1 : k;
+            const int ky = (k + YA < a.T) ? k + YA : a.T - 1;
 #pragma unroll
-            for (int i = 0; i < Y; ++i) ynext[i] = a.y[((int64_t)kn * Y + i) * ld + b];
+            for (int i = 0; i < Y; ++i) ynext[YA - 1][i] = a.y[((int64_t)ky * Y + i) * ld + b];
             if constexpr (kTTd) tdn = ttd[kn];
             if constexpr (kTTo) ton = tto[kn];
             if (stu_scale) scn = ssc[kn];
