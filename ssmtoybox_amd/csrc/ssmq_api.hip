@@ -518,13 +518,27 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         // FX in fragment order: blocks of 64 / E trajectories, 64 rows each (ssmq_wide.h: fx_frag)
         const int tpw = bq_stream_tpw(h->E);
         const int64_t M = (B + tpw - 1) / tpw * 64;
+        // the last, partly empty round of workgroups is cut by panel (ssmq_bq_stream.hip: bq_stream_split): room for the parts
+        static int cus = 0;
+        static unsigned cus_epoch = ~0u;
+        if (cus_epoch != device_epoch()) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            SSMQ_HIP(hipGetDevice(&dev));
+            SSMQ_HIP(hipGetDeviceProperties(&prop, dev));
+            cus = prop.multiProcessorCount;
+            cus_epoch = device_epoch();
+        }
+        const size_t parts_n = bq_stream_parts_doubles(h->E, h->N, B, cus);
+        const int ldt = (int)((parts_n + (size_t)M - 1) / (size_t)M);
         double *fx, *tt, *mrow, *chol;
-        if ((rc = big_scratch(M, lda, 0, 0, B, h->D, &fx, &tt, &mrow, &chol))) return rc;
+        if ((rc = big_scratch(M, lda, ldt, ldt ? 1 : 0, B, h->D, &fx, &tt, &mrow, &chol))) return rc;
         WideArgs e = a;
         e.fx_ld = lda; e.fx_out = fx; e.mrow_out = mrow; e.chol_out = chol; e.fx_frag = tpw;
         if ((rc = hip_fail(launch_eval_wave(e, B, stream()), "k_eval_wave"))) return rc;
         const WideLayout wl = wide_layout(h->D, h->E, h->N, h->form);
-        return launch_bq_stream(a, h->d_sx_pan, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, fx, chol, lda, stream());
+        return launch_bq_stream(a, h->d_sx_pan, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, fx, chol, lda, cus,
+                                parts_n ? tt : nullptr, stream());
     }
     if (big) {
         const bool bq = h->form == SSMQ_FORM_BQ, tpb = bq && h->tp_nu > 0.0;

@@ -43,6 +43,12 @@ struct BqStreamArgs {
     double cov_scale, ccov_scale;
     double *mean_f, *cov_f, *cov_fx;                   // element e of trajectory b at ptr[e * es + b]
     int64_t es;
+    // Workgroups [0, n_whole) run whole blocks; the n_tail blocks behind them - what would be a last, partly empty round of
+    // workgroups on the chip - are cut by PANEL: unit n_whole + p n_tail + j is panel p of block n_whole + j (panel-major, i.e.
+    // longest first) and leaves its waves' parts of C in parts[p][trajectory of the tail][pair][2][8]; k_bq_stream_finish adds them
+    // up in the order a whole block does - a trajectory's result does not depend on where in a batch it sits.
+    int32_t n_whole, n_tail;
+    double *parts;
 };
 
 struct StepIt {             // (panel, k-block) of one step of a wave's flattened main loop; kb runs DOWN within a panel
@@ -58,7 +64,14 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
     const int li = lane & 15, lg = lane >> 4;
     const int TPW = g.tpw;
     const int nkb = g.nkb, npan = g.npan;
-    const int64_t bw0 = (int64_t)blockIdx.x * TPW;
+    int blk = blockIdx.x, p_lo = 0, p_hi = npan - 1;
+    const bool partial = (int)blockIdx.x >= g.n_whole;
+    if (partial) {
+        const int u = (int)blockIdx.x - g.n_whole;
+        p_lo = p_hi = u / g.n_tail;
+        blk = g.n_whole + (u - p_lo * g.n_tail);
+    }
+    const int64_t bw0 = (int64_t)blk * TPW;
     const int nb = (int)((g.B - bw0) < (int64_t)TPW ? (g.B - bw0) : (int64_t)TPW);
     const int vrows = nb * E;
     double *sP = lds;                               // [NW][RT][64][8] every wave's part of C
@@ -97,14 +110,14 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
     auto next_it = [&](StepIt it) {
         if (it.kb - 1 >= lo(it.p)) return StepIt{it.p, it.kb - 1};
         const int p = it.p + 1;
-        if (p < npan && lo(p) <= nkb - 1) return StepIt{p, nkb - 1};
+        if (p <= p_hi && lo(p) <= nkb - 1) return StepIt{p, nkb - 1};
         return StepIt{npan, nkb - 1};
     };
     auto valid_it = [&](StepIt it) { return it.p < npan ? it : StepIt{0, nkb - 1}; };
     // FX in fragment order (WideArgs::fx_frag): this block's 64 rows are [4 row tiles][nkb][64 lanes][4].  Rows beyond the block's
     // valid ones (a last, partial block; the 4 padding rows of a 60-row block) hold whatever the buffer held: a row of FX only ever
     // meets its own accumulator column, and those are never stored.
-    const double *fxb = g.fx + (int64_t)blockIdx.x * 64 * g.lda;
+    const double *fxb = g.fx + (int64_t)blk * 64 * g.lda;
     const int tile_ld = nkb * kFrag;               // doubles from one row tile of the block to the next
     const double *Xg = g.X + (size_t)npan * nkb * NT * kFrag;
     // operands of a step, requested ONE step ahead straight into registers (fragment order in memory: a lane's four k values of a
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) sx[rt * 512 + i] = 0.0;
     const int grt = wave & 3, gpar = wave >> 2;         // the G tile: row tile grt at the k-blocks of parity gpar
-    StepIt c0{0, nkb - 1};
+    StepIt c0 = (lo(p_lo) <= nkb - 1) ? StepIt{p_lo, nkb - 1} : StepIt{npan, nkb - 1};   // (a wave without a tile in this panel)
     StepIt c1 = next_it(c0);
     load_step(c0, std::integral_constant<int, 0>{});
     __syncthreads();                                // the tables
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
     for (int r = 0; r < 4; ++r) sG[(wave * 64 + lane) * 4 + r] = gacc[r];
     __syncthreads();
     // ---- mean and cross-covariance from the G tile (as k_bq_fused 4a), the factor from k_eval_wave's output -------------------------
-    if (wave < RT) {
+    if (wave < RT && p_lo == 0) {
         const int rt = wave, lr = 16 * rt + li;
         const bool valid = lr < vrows;
         const int gi = srow[lr] >> 8, e = srow[lr] & 255;
@@ -269,23 +282,69 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
         const int p = idx / nb, gi = idx - p * nb;
         const int e = spair[p] >> 4, e2 = spair[p] & 15;
         const int l1 = gi * E + e, l2 = gi * E + e2;
-        auto cval = [&](int la, int lb) {
+        auto cat = [&](int la, int lb) {
             const int rta = la >> 4, i = la & 15, j = lb - (16 * rta / E) * E;
-            const int at = ((rta * 64) + (j & 15) + 16 * (i & 3)) * 8 + 4 * (j >> 4) + (i >> 2);
+            return ((rta * 64) + (j & 15) + 16 * (i & 3)) * 8 + 4 * (j >> 4) + (i >> 2);
+        };
+        auto cval = [&](int at) {
             double v = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += sP[w * RT * 64 * 8 + at];
             return v;
         };
         const int64_t b = bw0 + gi;
+        if (partial) {
+            // every wave's part of the two entries, this panel only: k_bq_stream_finish adds the panels per wave (the order in
+            // which a whole block's wave accumulates them), then the waves, then applies the formula below - the same bits
+            double *dst = g.parts + (((size_t)p_lo * g.n_tail * TPW + (size_t)(blk - g.n_whole) * TPW + gi) * npair + p) * (2 * NW);
+            const int a1 = cat(l1, l2), a2 = cat(l2, l1);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                dst[w] = sP[w * RT * 64 * 8 + a1];
+                dst[NW + w] = sP[w * RT * 64 * 8 + a2];
+            }
+            continue;
+        }
         const int ie = e * E + e2, it = e2 * E + e;
         const bool use = (e == e2) || g.emv_broadcast;
         const double em = use ? sev[ie] : 0.0;
-        double v = (cval(l1, l2) + cval(l2, l1) - smr[l1] * smr[l2] + em) * g.cov_scale;
+        double v = (__builtin_fma(-smr[l1], smr[l2], cval(cat(l1, l2)) + cval(cat(l2, l1))) + em) * g.cov_scale;
         if (g.cov_add) v += sca[ie];
         g.cov_f[(int64_t)ie * g.es + b] = v;
         if (e2 != e) g.cov_f[(int64_t)it * g.es + b] = v;
     }
+}
+
+// grid over (tail trajectory, pair): cov = (sum over panels of the parts, in panel order, - mean mean' + emv) scale + cov_add
+__global__ __launch_bounds__(256) void k_bq_stream_finish(const BqStreamArgs g) {
+    const int E = g.E, npair = E * (E + 1) / 2, TPW = g.tpw;
+    const int64_t nt = (int64_t)g.n_tail * TPW;                     // trajectory slots of the tail (the last block may be partial)
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nt * npair) return;
+    const int64_t j = idx / npair;
+    const int p = (int)(idx - j * npair);
+    const int64_t b = (int64_t)g.n_whole * TPW + j;
+    if (b >= g.B) return;
+    int e = 0;
+    while ((e + 1) * (e + 2) / 2 <= p) ++e;
+    const int e2 = p - e * (e + 1) / 2;
+    constexpr int NW = 8;
+    double c[2] = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            double sw = 0.0;                                          // what this wave's LDS slot holds in a whole block
+            for (int q = 0; q < g.npan; ++q) sw += g.parts[(((size_t)q * nt + j) * npair + p) * (2 * NW) + h * NW + w];
+            c[h] += sw;
+        }
+    const int ie = e * E + e2, it = e2 * E + e;
+    const bool use = (e == e2) || g.emv_broadcast;
+    const double em = use ? g.emv[ie] : 0.0;
+    double v = (__builtin_fma(-g.mean_f[(int64_t)e * g.es + b], g.mean_f[(int64_t)e2 * g.es + b], c[0] + c[1]) + em) * g.cov_scale;
+    if (g.cov_add) v += g.cov_add[ie];
+    g.cov_f[(int64_t)ie * g.es + b] = v;
+    if (e2 != e) g.cov_f[(int64_t)it * g.es + b] = v;
 }
 
 constexpr size_t kStreamLds = sizeof(double) * (8 * 4 * 64 * 8 + 8 * 64 * 4 + 256 + 256 + 64 + kCholLds) + sizeof(int) * 128;
@@ -295,6 +354,25 @@ constexpr size_t kStreamLds = sizeof(double) * (8 * 4 * 64 * 8 + 8 * 64 * 4 + 25
 int bq_stream_panels(int N) { return (N + kPanW - 1) / kPanW; }
 int bq_stream_kblocks(int N) { return (N + 15) / 16; }
 int bq_stream_tpw(int E) { return 64 / E; }
+
+// How many blocks of a batch run whole and how many - the last, partly empty round of workgroups on `cus` compute units - are
+// cut by panel (BqStreamArgs::n_whole / n_tail).  1 667 blocks on 256 CUs are 6.51 rounds: the seventh costs a whole block's time
+// with half the chip idle; cut into 5 x 131 units dealt longest first it costs about half of that.
+static void bq_stream_split(int64_t nblocks, int npan, int cus, int *n_whole, int *n_tail) {
+    *n_whole = (int)nblocks;
+    *n_tail = 0;
+    if (npan < 2 || cus < 1 || getenv("SSMQ_BQ_STREAM_NO_SPLIT")) return;
+    const int64_t rem = nblocks % cus;
+    if (rem == 0 || 5 * rem > 3 * cus) return;      // a last round that is more than 60 % full: leave it
+    *n_tail = (int)rem;
+    *n_whole = (int)(nblocks - rem);
+}
+size_t bq_stream_parts_doubles(int E, int N, int64_t B, int cus) {
+    const int tpw = bq_stream_tpw(E);
+    int nw, nt;
+    bq_stream_split((B + tpw - 1) / tpw, bq_stream_panels(N), cus, &nw, &nt);
+    return (size_t)bq_stream_panels(N) * nt * tpw * (E * (E + 1) / 2) * 16;      // per pair: 8 waves x the two entries (e, e2), (e2, e)
+}
 size_t bq_stream_x_doubles(int N) { return ((size_t)bq_stream_panels(N) * kPanT + 1) * bq_stream_kblocks(N) * kFrag; }
 
 // BQ transform (not the t-process one), one constant block for the batch, 208 < N <= SSMQ_MAX_PTS, a symmetric Wc; whole
@@ -334,7 +412,7 @@ void bq_stream_pack(int D, int N, const double *Wc, const double *Wcc, const dou
 // a: WideArgs of the whole transform (outputs, scales, cov_add; unit batch strides); fx [B E][lda] and chol [B][D][D] as
 // k_eval_wave left them (lda >= 16 ceil(N / 16), zero beyond N)
 int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, const double *fx,
-                     const double *chol, int64_t lda, hipStream_t s) {
+                     const double *chol, int64_t lda, int cus, double *parts, hipStream_t s) {
     if (B <= 0) return SSMQ_OK;
     if (!bq_stream_supported(a.D, a.E, a.N) || a.consts_stride != 0 || a.form != SSMQ_FORM_BQ || a.tp_nu > 0.0 ||
         lda != 16 * bq_stream_kblocks(a.N) || a.bs_mf != 1 || a.bs_cf != 1 || a.bs_cfx != 1) {
@@ -353,8 +431,16 @@ int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int 
     g.B = B; g.lda = lda; g.fx = fx; g.chol = chol; g.X = X; g.emv = emv; g.cov_add = a.cov_add;
     g.cov_scale = a.cov_scale; g.ccov_scale = a.ccov_scale; g.mean_f = a.mean_f; g.cov_f = a.cov_f; g.cov_fx = a.cov_fx; g.es = a.es_out;
     const int64_t tiles = (B + g.tpw - 1) / g.tpw;
-    hipLaunchKernelGGL(k_bq_stream, dim3((unsigned)tiles), dim3(512), kStreamLds, s, g);
-    return hip_fail(hipGetLastError(), "k_bq_stream");
+    bq_stream_split(tiles, g.npan, parts ? cus : 0, &g.n_whole, &g.n_tail);
+    g.parts = parts;
+    hipLaunchKernelGGL(k_bq_stream, dim3((unsigned)(g.n_whole + (int64_t)g.n_tail * g.npan)), dim3(512), kStreamLds, s, g);
+    int rc = hip_fail(hipGetLastError(), "k_bq_stream");
+    if (!rc && g.n_tail > 0) {
+        const int64_t items = (int64_t)g.n_tail * g.tpw * (g.E * (g.E + 1) / 2);
+        hipLaunchKernelGGL(k_bq_stream_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, g);
+        rc = hip_fail(hipGetLastError(), "k_bq_stream_finish");
+    }
+    return rc;
 }
 
 }  // namespace ssmq

@@ -85,8 +85,9 @@ struct FPar;
 int launch_linearize(int D, int E, int din, const ssmq_integrand *f, const FPar &fp, int64_t B, int64_t ld, const double *d_mean,
                      const double *d_cov, const double *d_time, int time_stride, double *d_mean_f, double *d_cov_f, double *d_cov_fx,
                      int32_t *d_status, const double *d_cov_add, double cov_scale, double ccov_scale, hipStream_t s);
+size_t bq_stream_parts_doubles(int E, int N, int64_t B, int cus);   // scratch for the panel-wise tail of a batch (0: no tail is cut)
 int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int emv_broadcast, int64_t B, const double *fx,
-                     const double *chol, int64_t lda, hipStream_t s);
+                     const double *chol, int64_t lda, int cus, double *parts, hipStream_t s);
 int launch_fxwc_cov_mfma(int NP, const double *A, const double *X, int64_t M, int lda, const double *mean_rows,
                          const double *chol, const double *emv, int emv_broadcast, const double *cov_add,
                          double cov_scale, double ccov_scale, int E, int D, double *cov_f, double *cov_fx, int64_t es,

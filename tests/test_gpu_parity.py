@@ -2124,7 +2124,7 @@ def test_one_launch_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
                                                  (3, 'gh', {'degree': 7}, 343, 2), (4, 'gh', {'degree': 4}, 256, 4), (5, 'gh', {'degree': 4}, 1024, 1)])
 def test_streamed_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
     """k_bq_stream (ssmq_bq_stream.hip: the route for 209 ... 4096 points - k_eval_wave, then the streamed product with S =
-    tril(Wc) by panels of 13 column tiles and the C + C' epilogue) over its shape space beside configs[4]: output dimensions
+    tril(Wc) by panels of 16 column tiles and the C + C' epilogue) over its shape space beside configs[4]: output dimensions
     1 ... 8 (64 ... 8 trajectories per 64-row tile), point counts with a partial last panel / a single k-block past a panel
     boundary / exactly 16 k-blocks / 64 k-blocks, batches that end in a partial tile, a covariance that is not positive
     definite.  Against the blocked route (SSMQ_NO_BQ_STREAM) at rounding level and against the oracle."""
@@ -2157,6 +2157,12 @@ def test_streamed_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
         bad = B - 2                                            # in the last, partial tile
         covs[bad] = -np.eye(D)
         mf, cf, cfx, st = tf.apply_batch(fn, means, covs, 0.0, return_status=True)
+        # the last, partly empty round of workgroups is cut by panel (bq_stream_split) and summed in the whole-block order: same bits
+        monkeypatch.setenv('SSMQ_BQ_STREAM_NO_SPLIT', '1')
+        mf0, cf0, cfx0, st0 = tf.apply_batch(fn, means, covs, 0.0, return_status=True)
+        monkeypatch.delenv('SSMQ_BQ_STREAM_NO_SPLIT')
+        assert np.array_equal(mf, mf0, equal_nan=True) and np.array_equal(cf, cf0, equal_nan=True) and \
+            np.array_equal(cfx, cfx0, equal_nan=True) and np.array_equal(st, st0)
         monkeypatch.setenv('SSMQ_NO_BQ_STREAM', '1')
         assert tf.kernel_name(fn) == other
         mf2, cf2, cfx2, st2 = tf.apply_batch(fn, means, covs, 0.0, return_status=True)

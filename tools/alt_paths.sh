@@ -3,8 +3,8 @@
 # instead of the fused filter kernels, dense instead of fast-path transform kernels, three-pass instead of two-pass
 # matrix-core route, generic kernel instead of the matrix cores, L2-resident instead of LDS-resident large-N weights,
 # one wave per trajectory in the generic kernel, the wave kernel instead of the matrix-core tile kernel, the tile kernel's
-# D = 16 mean path, the two-pass matrix-core route instead of the one-launch kernel, the launch-per-stage theta step, the blocked route instead of k_bq_stream, the single-workgroup large-N weights, the run-time-size linearisation kernel.  The size tests are left out (they take the default paths anyway).
-for v in SSMQ_NO_FUSED SSMQ_NO_FASTPATH SSMQ_NO_FUSED_COV SSMQ_NO_MFMA SSMQ_WEIGHTS_NO_LDS SSMQ_WIDE_ONE_WAVE SSMQ_NO_WAVE SSMQ_NO_TILE SSMQ_TILE_NO_MROW SSMQ_NO_BQ_FUSED SSMQ_NO_THETA_FUSED SSMQ_NO_BQ_STREAM SSMQ_WEIGHTS_ONE_WG SSMQ_LINEAR_GENERIC; do
+# D = 16 mean path, the two-pass matrix-core route instead of the one-launch kernel, the launch-per-stage theta step, the blocked route instead of k_bq_stream, the single-workgroup large-N weights, the run-time-size linearisation kernel, k_bq_stream without the panel-wise tail.  The size tests are left out (they take the default paths anyway).
+for v in SSMQ_NO_FUSED SSMQ_NO_FASTPATH SSMQ_NO_FUSED_COV SSMQ_NO_MFMA SSMQ_WEIGHTS_NO_LDS SSMQ_WIDE_ONE_WAVE SSMQ_NO_WAVE SSMQ_NO_TILE SSMQ_TILE_NO_MROW SSMQ_NO_BQ_FUSED SSMQ_NO_THETA_FUSED SSMQ_NO_BQ_STREAM SSMQ_WEIGHTS_ONE_WG SSMQ_LINEAR_GENERIC SSMQ_BQ_STREAM_NO_SPLIT; do
   echo "== $v=1"
   env $v=1 timeout -k 10 300 python -m pytest tests -m gpu -q -k "not sixteen_million and not at_scale and not config3 and not full_batch" > gpurun_out/pytest_env_$v.log 2>&1
   tail -2 gpurun_out/pytest_env_$v.log
