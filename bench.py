@@ -176,12 +176,13 @@ def measure_theta_step(calls=1000):
 
 
 def pmc_traffic_named(prefix):
-    """HBM bytes per launch of the ONE entry of profiles/pmc_traffic.json whose kernel name starts with `prefix`."""
+    """HBM bytes per launch of the ONE entry of profiles/pmc_traffic.json whose kernel name (what stands before its template
+    arguments and the grid) is `prefix`."""
     try:
         table = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
     except (OSError, ValueError):
         return None
-    hits = [rec for key, rec in table.items() if key.startswith(prefix)]
+    hits = [rec for key, rec in table.items() if key.split('@')[0].split('<')[0] == prefix]
     return hits[0].get('hbm_bytes_per_launch') if len(hits) == 1 else None
 
 
@@ -557,15 +558,15 @@ def measure_c5_degree7(amd, B=10000, iters=5, with_cpu=True):
     # `frac` counts what the matrix cores EXECUTE (the kernel forms fx Wc fx' as C + C': half the dense product); the dense
     # (algorithmic) count divided by the same time is reported beside it and may exceed the peak
     tfe = (flop_exec / (ms * 1e-3) / 1e12) if flop_exec else tfs
-    tr_s, tr_e = pmc_traffic_named('k_bq_stream'), pmc_traffic_named('k_eval_wave')
+    tr_s, tr_e, tr_f = pmc_traffic_named('k_bq_stream'), pmc_traffic_named('k_eval_wave'), pmc_traffic_named('k_bq_stream_finish')
     rec = {'kernel': name, 'points': int(N), 'ms_per_launch': ms, 'transforms_per_s': B / (ms * 1e-3), 'bound': 'mfma',
            'achieved': tfe, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tfe / F64_MFMA_PEAK_TF,
            'flop_per_launch': flop_exec if flop_exec else flop, 'executed_flop_per_launch': flop_exec,
            'executed_frac': (flop_exec / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TF) if flop_exec else None,
            'algorithmic_flop_per_launch': flop, 'algorithmic_tflops': tfs, 'algorithmic_over_peak': tfs / F64_MFMA_PEAK_TF,
-           'launches': ['k_eval_wave', 'k_bq_stream'] if name == 'k_bq_stream' else None,
-           'traffic': (tr_s + tr_e) if (name == 'k_bq_stream' and tr_s and tr_e) else None,
-           'traffic_by_launch': {'k_eval_wave': tr_e, 'k_bq_stream': tr_s} if name == 'k_bq_stream' else None,
+           'launches': ['k_eval_wave', 'k_bq_stream', 'k_bq_stream_finish'] if name == 'k_bq_stream' else None,
+           'traffic': (tr_s + tr_e + (tr_f or 0.0)) if (name == 'k_bq_stream' and tr_s and tr_e) else None,
+           'traffic_by_launch': {'k_eval_wave': tr_e, 'k_bq_stream': tr_s, 'k_bq_stream_finish': tr_f} if name == 'k_bq_stream' else None,
            'algorithmic_bytes': 8.0 * B * (D + D * D + D + D * D + D * D),
            'weights_s': t_weights, 'max_scaled_err_vs_oracle': err, 'weights_rel_err_vs_oracle': w_err,
            'check': 'device weights + device transform against ORACLE weights + oracle transform (the oracle weights are pinned to '
