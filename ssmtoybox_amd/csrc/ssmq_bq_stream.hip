@@ -11,8 +11,10 @@
 //     (8 accumulator tiles).  Panel p needs the k-blocks kb >= 16 p only, and tile t of it only kb >= 16 p + t.  T never exists:
 //     when a wave's k loop of a panel ends, its accumulators are multiplied with the panel's FX columns (C += T_p FX_p') and
 //     cleared.  The G tile [Wcc' | wm] (cross-covariance, mean) is spread over the waves inside panel 0;
-//   * NO LDS staging, NO barrier in the main loop: both operands straight from memory into registers in fragment order (a lane's
-//     four k values of a tile = one 32-byte read, a wave's reads of a tile = 2 KB contiguous), requested one step ahead;
+//   * NO LDS staging, no data-carrying barrier in the main loop: both operands straight from memory into registers in fragment order
+//     (a lane's four k values of a tile = one 32-byte read, a wave's reads of a tile = 2 KB contiguous), requested one step ahead; a bare
+//     rendezvous every 16 regular steps keeps the eight waves close enough for the FX fragments one has fetched to be still in L2
+//     when the others ask (3.7 instead of 6-10 GB of L2-miss reads at the same 3.1 ms);
 //   * epilogue as k_bq_fused: all parts of C meet in LDS, one thread per (trajectory, e >= e2) forms C + C' and stores.
 // Matrix work per 64-row block at N = 1181 (74 column tiles): 74 75 / 2 + 74 = 2 849 tile steps x 4 instructions per row tile against
 // 74 90 = 6 660 for the full [Wc | Wcc'] product.
@@ -106,7 +108,12 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
     // (Panel 0 runs down to kb = 0 for every wave: the G tile [Wcc' | wm] is spread over the waves as (row tile wave & 3) x
     // (k-blocks of parity wave >> 2), 37 tile steps each, with the FX fragments the step has loaded anyway.)
     const int tA = wave, tB = NT - 1 - wave;
+#ifndef BQS_RENDEZVOUS
+#define BQS_RENDEZVOUS 16       // the eight waves meet every BQS_RENDEZVOUS steps of the regular (below-diagonal) part of a panel;
+                                // 0: never (A/B builds: 3.1 ms either way, 6-10 GB of L2-miss reads instead of 3.7)
+#endif
     auto lo = [&](int p) { return p == 0 ? 0 : NT * p + wave; };
+    int nstep = 0;
     auto next_it = [&](StepIt it) {
         if (it.kb - 1 >= lo(it.p)) return StepIt{it.p, it.kb - 1};
         const int p = it.p + 1;
@@ -238,6 +245,13 @@ __global__ __launch_bounds__(512, 1) void k_bq_stream(const BqStreamArgs g) {
 #undef SSMQ_G_TILE
             }
             if (c0.kb == lo(c0.p)) panel_end(c0.p);
+        }
+        if constexpr (BQS_RENDEZVOUS > 0) {
+            // Every wave runs every step below a panel's diagonal region (kb >= 16 (p + 1)), so counting those gives all eight the
+            // same number of barriers: a bare rendezvous, no memory operation waits for it.  It keeps the waves within a few steps
+            // of each other where they all do the same work, so that the FX fragments one of them has fetched are still in L2
+            // when the others ask; in the diagonal region (different work per wave, equal per SIMD) they run freely.
+            if (on && kbl >= NT && (++nstep % BQS_RENDEZVOUS) == 0) asm volatile("s_barrier" ::: "memory");
         }
         c0 = c1; c1 = next_it(c1);
     };
