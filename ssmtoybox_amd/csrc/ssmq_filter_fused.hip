@@ -140,7 +140,9 @@ __global__ __launch_bounds__(kSmallBlock, (SSMQ_FUSED_FORCE_OCC ? SSMQ_FUSED_FOR
         const double sc = scn;
         {   // next step's inputs; the last step re-requests its own (no branch in the loop body)
             const int kn = (k + 1 < a.T) ? k + 1 : k;
-            const int ky = (k + YA < a.T) ? k + YA : a.T - 1;
+            // (YA == 1 keeps the ONE index kn for the plane and the time tables: a second one, equal in value, cost the loop its
+            // strength-reduced addresses and the headline pass 2 us - 32.3 -> 34.3 - before it was noticed in the bench line)
+            const int ky = YA == 1 ? kn : ((k + YA < a.T) ? k + YA : a.T - 1);
 #pragma unroll
             for (int i = 0; i < Y; ++i) ynext[YA - 1][i] = a.y[((int64_t)ky * Y + i) * ld + b];
             if constexpr (kTTd) tdn = ttd[kn];
