@@ -824,6 +824,7 @@ int ssmq_status_first(const int32_t *d_status, int64_t B, int64_t *first) {
 ssmq_transform *ssmq_transform_create(int D, int E, int N, int form, const double *xi, const double *wm,
                                       const double *Wc, const double *Wcc, const double *emv, int emv_mode,
                                       double tp_nu, const double *tp_iK) {
+    SSMQ_API_LOCK();
     if (D < 1 || D > SSMQ_MAX_DIM || E < 1 || E > SSMQ_MAX_DIM || N < 1 || N > SSMQ_MAX_PTS ||
         (form != SSMQ_FORM_BQ && form != SSMQ_FORM_SIGMA) || !xi || !wm || !Wc || (form == SSMQ_FORM_BQ && !Wcc) ||
         (tp_nu > 0.0 && !tp_iK) || (emv_mode != SSMQ_EMV_DIAG && emv_mode != SSMQ_EMV_BROADCAST)) {
@@ -856,6 +857,7 @@ ssmq_transform *ssmq_transform_create(int D, int E, int N, int form, const doubl
 // The linearisation transform has neither points nor weights; the handle keeps a one-point placeholder block so that every
 // code path that sizes or frees constants finds what it expects.
 ssmq_transform *ssmq_transform_create_linear(int D, int E) {
+    SSMQ_API_LOCK();
     if (D < 1 || D > SSMQ_MAX_DIM || E < 1 || E > SSMQ_MAX_DIM) {
         set_error("transform_create_linear: bad argument");
         return nullptr;
