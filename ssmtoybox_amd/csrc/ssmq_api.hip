@@ -273,7 +273,7 @@ static int upload_consts(ssmq_transform *h) {
         }
         SSMQ_HIP(hipStreamSynchronize(stream()));   // xpad goes out of scope
     }
-    if (!sigma && N > 208 && !getenv("SSMQ_NO_MFMA")) {
+    if (!sigma && bq_stream_supported(D, E, N)) {
         // one-launch route for these sizes (k_bq_stream): S = tril(Wc), half the diagonal, by panels - a Wc symmetric to the last
         // bit only (see d_sx_pad above)
         bool symmetric = bq_stream_supported(D, E, N) && h->tp_nu <= 0.0;

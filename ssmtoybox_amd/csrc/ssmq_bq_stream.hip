@@ -393,7 +393,9 @@ size_t bq_stream_x_doubles(int N) { return ((size_t)bq_stream_panels(N) * kPanT 
 // trajectories fill at least 3/4 of a 64-row tile for every E <= 10
 bool bq_stream_supported(int D, int E, int N) {
     if (getenv("SSMQ_NO_BQ_STREAM") || getenv("SSMQ_NO_MFMA")) return false;
-    if (N <= 208 || N > SSMQ_MAX_PTS) return false;
+    // (A/B: SSMQ_BQ_STREAM_MIN_N lowers the bound - the two-launch route at N = 201 against k_bq_fused)
+    const char *mn = getenv("SSMQ_BQ_STREAM_MIN_N");
+    if (N <= (mn ? atoi(mn) : 208) || N > SSMQ_MAX_PTS) return false;
     return D >= 1 && D <= 15 && E >= 1 && E <= 10;      // D <= 15: column 15 of the G tile carries wm
 }
 
