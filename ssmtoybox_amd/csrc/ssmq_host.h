@@ -22,7 +22,7 @@ struct ssmq_transform {
     double *d_wcx_pad = nullptr;
     // ... and [S | Wcc' | wm] with S = tril(sym(Wc)), half the diagonal (Wc = S + S'): the one-launch routes skip the zero blocks
     double *d_sx_pad = nullptr;
-    // ... and for point sets beyond that route's instantiations (208 < N): S by panels of 208 columns, G tile in panel 0
+    // ... and for point sets beyond that route's instantiations (208 < N): S in fragment order by panels of 256 columns, then the G tile
     // (ssmq_bq_stream.hip: bq_stream_pack), or null
     double *d_sx_pan = nullptr;
     // point sets without an instantiation of that route (N > 64): Wc (and iK for the t-process) as column blocks of
