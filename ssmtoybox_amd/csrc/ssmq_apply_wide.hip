@@ -731,8 +731,14 @@ __global__ __launch_bounds__(64 * kWaveWaves) void k_theta_chain(const ThetaChai
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wid = (int64_t)blockIdx.x * kWaveWaves + wave;
     double *lw = lds + (size_t)wave * c.lds_per_wave;
-#define SSMQ_AGENT_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_wave_barrier(); \
-                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); } while (0)
+#ifndef SSMQ_CHAIN_SCOPE
+// The predictive moments travel from the first transform to the second through their global planes, written and read back by
+// lanes of ONE wave: workgroup scope orders that (one CU, one L1).  Agent scope - which on this part also writes the L2 back -
+// was what rounds 3-4 used: 3 us more per call (65 -> 62 us at 5 items), same results.
+#define SSMQ_CHAIN_SCOPE "workgroup"
+#endif
+#define SSMQ_AGENT_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, SSMQ_CHAIN_SCOPE); __builtin_amdgcn_wave_barrier(); \
+                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SSMQ_CHAIN_SCOPE); } while (0)
     const int K = c.dyn.wave_k, G = 64 / K, gi = lane / G, gl = lane - gi * G;
     const int64_t b = wid * K + gi;
     if (wid * K >= B) return;
