@@ -291,8 +291,12 @@ __global__ __launch_bounds__(BLOCK) void k_apply_wide(const WideArgs a) {
 constexpr int kEvalWaves = 4;
 // DM: compile-time bound on D and E (the unrolled per-point loops run to DM, predicated on the run-time sizes)
 // FC: integrand fixed at compile time (no switch, no select chain for a state index it does not take), or -1
+#ifndef SSMQ_EVAL_OCC
+#define SSMQ_EVAL_OCC 0          // A/B builds: waves per SIMD requested of the compiler (0: its own choice, 4 at 110 registers;
+                                // 5 / 6 / 8 spill and cost the N = 1181 route 2 / 10 / 14 %: round 4, tools/c5_deg7.py)
+#endif
 template <int DM, int FC = -1>
-__global__ __launch_bounds__(64 * kEvalWaves) void k_eval_wave(const WideArgs a, int64_t B) {
+__global__ __launch_bounds__(64 * kEvalWaves, (SSMQ_EVAL_OCC ? SSMQ_EVAL_OCC : 1)) void k_eval_wave(const WideArgs a, int64_t B) {
     __shared__ double s_all[kEvalWaves][SSMQ_MAX_DIM * SSMQ_MAX_DIM + SSMQ_MAX_DIM];
     const int D = a.D, E = a.E, N = a.N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
