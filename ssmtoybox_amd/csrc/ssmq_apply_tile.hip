@@ -348,24 +348,37 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
             const int nt = (int)(left < (int64_t)(kTileWaves * G) ? left : (int64_t)(kTileWaves * G));
             const int pp = (nt + 1) >> 1;                               // pieces of two trajectories per plane
             const double *sall = lds + tg.frag_doubles + tg.in_doubles;
-            for (int id = threadIdx.x; id < n_planes * pp; id += 64 * kTileWaves) {
-                const int p = id / pp, k = id - p * pp;
-                const int t0 = 2 * k, t1 = t0 + 1;
-                const int w0 = t0 / G, w1 = t1 / G;
-                const double v0 = sall[(size_t)w0 * tg.wave_doubles + (t0 - w0 * G) * per_traj + p];
-                const double v1 = t1 < nt ? sall[(size_t)w1 * tg.wave_doubles + (t1 - w1 * G) * per_traj + p] : 0.0;
-                double *dst;
-                if (p < E) dst = (double *)((char *)(a.mean_f + bc + t0) + (uint64_t)(uint32_t)p * eo8);
-                else if (p < E + E * E) dst = (double *)((char *)(a.cov_f + bc + t0) + (uint64_t)(uint32_t)(p - E) * eo8);
-                else dst = (double *)((char *)(a.cov_fx + bc + t0) + (uint64_t)(uint32_t)(p - E - E * E) * eo8);
-                if (t1 < nt && out16) {
-                    typedef double v2d __attribute__((ext_vector_type(2)));
-                    *(v2d *)dst = v2d{v0, v1};
-                } else {
-                    dst[0] = v0;
-                    if (t1 < nt) dst[1] = v1;
+            // GC > 0: a full chunk of 4 GC trajectories with the group count at compile time - the index maps below are divisions
+            // by constants (multiply-shift); at run-time divisors they were 150 of the kernel's 540 vector instructions per
+            // trajectory (profiles/r04_tile_sq.txt), in a kernel whose vector and matrix instructions share one pipe
+            auto store_chunk = [&](auto gc_c) {
+                constexpr int GC = decltype(gc_c)::value;
+                const int gg = GC > 0 ? GC : G, ppc = GC > 0 ? 2 * GC : pp;
+                for (int id = threadIdx.x; id < n_planes * ppc; id += 64 * kTileWaves) {
+                    const int p = id / ppc, k = id - p * ppc;
+                    const int t0 = 2 * k, t1 = t0 + 1;
+                    const int w0 = t0 / gg, w1 = t1 / gg;
+                    const double v0 = sall[(size_t)w0 * tg.wave_doubles + (t0 - w0 * gg) * per_traj + p];
+                    const double v1 = t1 < nt ? sall[(size_t)w1 * tg.wave_doubles + (t1 - w1 * gg) * per_traj + p] : 0.0;
+                    double *dst;
+                    if (p < E) dst = (double *)((char *)(a.mean_f + bc + t0) + (uint64_t)(uint32_t)p * eo8);
+                    else if (p < E + E * E) dst = (double *)((char *)(a.cov_f + bc + t0) + (uint64_t)(uint32_t)(p - E) * eo8);
+                    else dst = (double *)((char *)(a.cov_fx + bc + t0) + (uint64_t)(uint32_t)(p - E - E * E) * eo8);
+                    if (t1 < nt && out16) {
+                        typedef double v2d __attribute__((ext_vector_type(2)));
+                        *(v2d *)dst = v2d{v0, v1};
+                    } else {
+                        dst[0] = v0;
+                        if (t1 < nt) dst[1] = v1;
+                    }
                 }
-            }
+            };
+            const bool full = nt == kTileWaves * G;
+            if (full && G == 3) store_chunk(std::integral_constant<int, 3>{});
+            else if (full && G == 4) store_chunk(std::integral_constant<int, 4>{});
+            else if (full && G == 2) store_chunk(std::integral_constant<int, 2>{});
+            else if (full && G == 1) store_chunk(std::integral_constant<int, 1>{});
+            else store_chunk(std::integral_constant<int, 0>{});
         }
         __syncthreads();         // the next group's inputs and outputs overwrite the slices
     }
