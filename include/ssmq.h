@@ -112,6 +112,8 @@ int ssmq_set_device(int device);
  * first (ssmq_set_device), otherwise the library would move to that thread's default device. */
 int ssmq_current_device(void);
 int ssmq_device_name(char *buf, int len);
+/* PCI bus id ("0000:c1:00.0", len >= 13) of that device: what tells N ranks of one node apart in a scaling record. */
+int ssmq_device_pci_bus_id(char *buf, int len);
 
 /* ---- device memory, layout conversion, timing (plumbing) ---------------------------------------------------- */
 int ssmq_malloc(void **dptr, size_t bytes);

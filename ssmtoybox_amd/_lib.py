@@ -65,6 +65,7 @@ _PROTOTYPES = {
     'ssmq_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     'ssmq_set_device': (ctypes.c_int, [ctypes.c_int]),
     'ssmq_device_name': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    'ssmq_device_pci_bus_id': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'ssmq_malloc': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]),
     'ssmq_free': (ctypes.c_int, [ctypes.c_void_p]),
     'ssmq_memcpy_h2d': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
@@ -266,6 +267,12 @@ def set_device(dev):
 def device_name():
     buf = ctypes.create_string_buffer(256)
     check(load().ssmq_device_name(buf, 256), 'ssmq_device_name')
+    return buf.value.decode()
+
+
+def device_pci_bus_id():
+    buf = ctypes.create_string_buffer(64)
+    check(load().ssmq_device_pci_bus_id(buf, 64), 'ssmq_device_pci_bus_id')
     return buf.value.decode()
 
 

@@ -695,6 +695,16 @@ int ssmq_device_name(char *buf, int len) {
     snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
     return SSMQ_OK;
 }
+int ssmq_device_pci_bus_id(char *buf, int len) {
+    SSMQ_API_LOCK();
+    if (!buf || len < 13) return SSMQ_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0;
+    SSMQ_HIP(hipGetDevice(&dev));
+    SSMQ_HIP(hipDeviceGetPCIBusId(buf, len, dev));
+    return SSMQ_OK;
+}
 
 int ssmq_malloc(void **dptr, size_t bytes) {
     SSMQ_API_LOCK();

@@ -354,9 +354,16 @@ struct Fn<SSMQ_F_BEARING_MEAS> {
     __device__ __forceinline__ void eval(const double *x, double *o) const {
 #pragma unroll
         for (int s = 0; s < E; ++s) {
-            // (2 s < n_par: the generic kernels pass E = SSMQ_MAX_FIDX and an output array of their compile-time bound on D and E,
-            // which is below 8 for small shapes - one bearing per sensor and no more)
-            if (s < SSMQ_MAX_FPAR / 2 && 2 * s < fp->n_par) o[s] = atan2_nr(x[1] - fp->p[2 * s + 1], x[0] - fp->p[2 * s]);
+            // The register kernels (k_apply_small, k_filter_fused) instantiate with E = the sensor count: the loop bound is the
+            // only bound, no run-time test inside the unrolled body (round 4 had one here: +34 % VALU, 44 scratch instructions in
+            // the configs[3] filter).  The generic kernels pass E = SSMQ_MAX_FIDX and an output array of their compile-time
+            // bound on D and E, below 8 for small shapes: there, one bearing per sensor (2 s < n_par) and no more.
+            if constexpr (E == SSMQ_MAX_FIDX) {
+                if (s < SSMQ_MAX_FPAR / 2 && 2 * s < fp->n_par) o[s] = atan2_nr(x[1] - fp->p[2 * s + 1], x[0] - fp->p[2 * s]);
+            } else {
+                static_assert(E <= SSMQ_MAX_FPAR / 2, "one (x, y) pair of integrand constants per sensor");
+                o[s] = atan2_nr(x[1] - fp->p[2 * s + 1], x[0] - fp->p[2 * s]);
+            }
         }
     }
 };
