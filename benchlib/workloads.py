@@ -156,7 +156,7 @@ class FilterBench:
         self.h_obs = self.alg.tf_obs._handle_for(Y)
         self.gqg, self.pg = _lib.as_c(self.alg.G.dot(self.alg.q_cov).dot(self.alg.G.T))
         self.rr, self.pr = _lib.as_c(self.alg.r_cov)
-        self.kernel = self.alg.kernel_name()
+        self.kernel = self.alg.kernel_name(B)
 
     def step(self):
         lib = self._lib.load()

@@ -538,6 +538,11 @@ int ssmq_student_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand 
 /* Name of the kernel(s) ssmq_filter_forward_dev would run for this pair of transforms (for profiles). */
 int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
                             const ssmq_integrand *f_obs, char *buf, int len);
+/* ... for a batch of B trajectories: batches that leave most of the device idle run the time loop with the sigma points of every
+ * transform shared out over the waves of a workgroup (k_filter_wsplit, csrc/ssmq_filter_wsplit.hip); B = 0: the kernel of
+ * saturated batches. */
+int ssmq_filter_kernel_name_batch(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
+                                  const ssmq_integrand *f_obs, int64_t B, char *buf, int len);
 
 /*
  * The path's only collective: independent Monte-Carlo trajectories shard across ranks, one process per

@@ -184,6 +184,8 @@ _PROTOTYPES = {
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p]),
     'ssmq_filter_kernel_name': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
                                                ctypes.POINTER(Integrand), ctypes.c_char_p, ctypes.c_int]),
+    'ssmq_filter_kernel_name_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
+                                                     ctypes.POINTER(Integrand), ctypes.c_int64, ctypes.c_char_p, ctypes.c_int]),
     'ssmq_rbf_eval': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, c_double_p,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p]),
     'ssmq_rbf_factor': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,

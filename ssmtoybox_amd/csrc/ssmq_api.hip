@@ -175,6 +175,20 @@ static int upload_consts(ssmq_transform *h) {
                 w[cw.iK + i * N + j] = h->iK[i * N + j];
             }
     }
+    // per-point records (const_layout: rec / rs); record N stays zero
+    for (int n = 0; n < N; ++n) {
+        double *r = s.data() + cs.rec + (size_t)n * cs.rs;
+        for (int d = 0; d < D; ++d) r[d] = h->xi[d * N + n];
+        r[D] = h->wm[n];
+        if (sigma) {
+            r[D + 1] = h->Wc[n];
+        } else {
+            for (int d = 0; d < D; ++d) r[D + 1 + d] = h->Wcc[d * N + n];
+            for (int i = 0; i < N; ++i) r[2 * D + 1 + i] = h->Wc[i * N + n];
+            if (h->tp_nu > 0.0)
+                for (int i = 0; i < N; ++i) r[2 * D + 1 + N + i] = h->iK[i * N + n];
+        }
+    }
     // ---- optional fast paths (ssmq_apply_small.h: SSMQ_OPT_LDL / SSMQ_OPT_UT), each verified before it is offered ----
     h->opt_mask = 0;
     if (!sigma) {
@@ -2341,13 +2355,18 @@ extern "C" int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integra
 
 extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,
                                        const ssmq_transform *h_obs, const ssmq_integrand *f_obs, char *buf, int len) {
+    return ssmq_filter_kernel_name_batch(h_dyn, f_dyn, h_obs, f_obs, 0, buf, len);
+}
+
+extern "C" int ssmq_filter_kernel_name_batch(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
+                                             const ssmq_integrand *f_obs, int64_t B, char *buf, int len) {
     SSMQ_API_LOCK();
-    if (!h_dyn || !h_obs || !f_dyn || !f_obs || !buf || len <= 0) return SSMQ_E_ARG;
+    if (!h_dyn || !h_obs || !f_dyn || !f_obs || !buf || len <= 0 || B < 0) return SSMQ_E_ARG;
     FInfo fio;
     if (!integrand_info(f_obs->id, &fio)) return SSMQ_E_ARG;
     const char *name = nullptr;
     int rc = getenv("SSMQ_NO_FUSED") ? 0
-                                     : try_launch_fused(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), 0, 0, 0,
+                                     : try_launch_fused(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), B, 0, 0,
                                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                         nullptr, nullptr, &name, true, nullptr, 0.0, nullptr, nullptr);
     if (rc < 0) return rc;

@@ -29,7 +29,7 @@ struct FPar {
 // Offsets (in doubles) into a transform's constant block in HBM; every thread reads it with wave-uniform addresses,
 // so the loads are scalar (s_load) and the block stays in the scalar cache / L2.
 struct ConstLayout {
-    int32_t xi, wm, Wc, Wcc, emv, iK, zero, ldlU, ldlD, utc, total;
+    int32_t xi, wm, Wc, Wcc, emv, iK, zero, ldlU, ldlD, utc, rec, rs, total;
 };
 __host__ __device__ constexpr inline ConstLayout const_layout(int D, int E, int N, int form) {
     ConstLayout c{};
@@ -44,7 +44,13 @@ __host__ __device__ constexpr inline ConstLayout const_layout(int D, int E, int 
     c.ldlU = c.zero + E * E;   // [N][N]: column j of the unit lower factor U of Wc = U diag(d) U', contiguous
     c.ldlD = c.ldlU + N * N;   // [N]
     c.utc = c.ldlD + N;        // [2]: scale c of unscented-type points [0 | c I | -c I]
-    c.total = c.utc + 2;
+    // per-point records for the kernels that pick their sigma points at run time (ssmq_filter_wsplit.hip: wave w takes points w,
+    // w + W, ...): everything point n contributes, contiguous, so that ONE base pointer per point serves every scalar load -
+    //   centred form:  xi_n [D] | wm_n | wc_n            uncentred BQ form:  xi_n [D] | wm_n | Wcc[:, n] [D] | Wc[:, n] [N] | iK[:, n] [N]
+    // N + 1 records, the last one all zeros: the "point" of a wave that has run out of points (weight 0, evaluated at the mean).
+    c.rec = c.utc + 2;
+    c.rs = form == SSMQ_FORM_SIGMA ? D + 2 : 2 * D + 1 + 2 * N;
+    c.total = c.rec + (N + 1) * c.rs;
     return c;
 }
 

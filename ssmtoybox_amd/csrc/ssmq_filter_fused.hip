@@ -8,51 +8,11 @@
 // The input-state cross-covariance of the dynamics transform is only consumed by the smoother (ssinf.py:105-107,
 // 325-344) and is not formed in the forward pass.
 #include <cstdlib>
-#include "ssmq_apply_small.h"
+#include "ssmq_fused.h"
 #include <type_traits>
 #include "ssmq_host.h"
 
 namespace ssmq {
-
-struct FusedArgs {
-    const double *y;        // [T][Y][ld]
-    const double *m0, *P0;  // [D][ld], [D*D][ld]
-    double *fm, *fP;        // [T][D][ld], [T][D*D][ld]
-    int32_t *status;        // [B]: 0 or 1 + first failing step
-    const double *c_dyn, *c_obs, *gqg, *rr;
-    int64_t B, ld;
-    int32_t T, emv_dyn, emv_obs, lpw;   // lpw: active lanes (trajectories) per wave
-    double nu_dyn, nu_obs;
-    // Studentian recursion (ssinf.py:634-736): per-step scale (dof_pr - 2) / dof_pr [T] (null = Gaussian filter), the
-    // filter's dof for the measurement-update rescaling; gqg / rr then hold G q_smat G' and r_smat
-    const double *sscale;
-    double student_dof;
-    FPar fd, fo;
-};
-
-template <int D, int E>
-struct RegSink {
-    double mf[E];
-    double cv[E * (E + 1) / 2];
-    double cx[E][D];
-    __device__ __forceinline__ void mean(int e, double v) { mf[e] = v; }
-    __device__ __forceinline__ void cov(int e, int e2, double v) { cv[SSMQ_PK(e, e2)] = v; }
-    __device__ __forceinline__ void ccov(int e, int d, double v) { cx[e][d] = v; }
-};
-template <int D, int E>
-struct RegSinkNoCross {
-    double mf[E];
-    double cv[E * (E + 1) / 2];
-    __device__ __forceinline__ void mean(int e, double v) { mf[e] = v; }
-    __device__ __forceinline__ void cov(int e, int e2, double v) { cv[SSMQ_PK(e, e2)] = v; }
-    __device__ __forceinline__ void ccov(int, int, double) {}
-};
-
-// Integrands whose time dependence is a per-step constant tabulated on the host (time_table() in ssmq_device.h): the
-// fused loops fetch the entry of the next step one step ahead instead of loading (or re-evaluating) it on the chain.
-template <int F> struct HasTimeTable { static constexpr bool value = false; };
-template <> struct HasTimeTable<SSMQ_F_UNGM_DYN> { static constexpr bool value = true; };
-template <> struct HasTimeTable<SSMQ_F_UNGMNA_DYN> { static constexpr bool value = true; };
 
 // STU: -1 Gaussian or Studentian recursion decided at run time (a.sscale / a.student_dof), 0 / 1 fixed at compile time
 // (scalar-state kernels: on a 105-instruction step the run-time form costs two branches, three multiplications by a
@@ -570,6 +530,24 @@ int try_launch_fused_aug(const ssmq_transform *hd, const ssmq_integrand *fd, con
     return 0;
 }
 
+int try_launch_wsplit(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho, const ssmq_integrand *fo,
+                      int sel_obs, int64_t B, int64_t ld, int T, const double *d_y, const double *d_m0, const double *d_P0,
+                      const double *d_gqg, const double *d_rr, double *d_fm, double *d_fP, int32_t *d_status, hipStream_t s,
+                      const char **name, bool dry_run, const double *d_sscale, double student_dof, int cus);
+
+// compute units of the library's device (the wave-split kernel is chosen by how many workgroups the device can spread out)
+static int device_cus() {
+    static int cus = 0;
+    static unsigned epoch = ~0u;
+    if (epoch != device_epoch() || !cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        epoch = device_epoch();
+    }
+    return cus > 0 ? cus : 256;
+}
+
 // Returns 1 if a fused kernel was launched, 0 if none exists for this combination, < 0 on error.
 int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho,
                      const ssmq_integrand *fo, int sel_obs, int64_t B, int64_t ld, int T, const double *d_y,
@@ -577,6 +555,12 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
                      double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run,
                      const double *d_sscale, double student_dof, const double *d_ttab_dyn, const double *d_ttab_obs) {
     if (hd->form != ho->form || (hd->tp_nu > 0.0) != (ho->tp_nu > 0.0) || sel_obs < 0 || fd->n_idx > 0) return 0;
+    if (!dry_run || B > 0) {
+        // batches that leave most of the chip idle: sigma points shared out over the waves of a workgroup (ssmq_filter_wsplit.hip)
+        const int rw = try_launch_wsplit(hd, fd, ho, fo, sel_obs, B, ld, T, d_y, d_m0, d_P0, d_gqg, d_rr, d_fm, d_fP, d_status, s, name,
+                                         dry_run, d_sscale, student_dof, dry_run ? 256 : device_cus());
+        if (rw != 0) return rw;
+    }
     const int tp = hd->tp_nu > 0.0 ? 1 : 0;
     const int both = hd->opt_mask & ho->opt_mask;
     const int want[2] = {both & (tp || hd->form == SSMQ_FORM_SIGMA ? SSMQ_OPT_UT : 3), 0};

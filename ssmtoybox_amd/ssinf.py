@@ -52,18 +52,19 @@ class GaussianInference:
     def _additive(self):
         return self.mod_dyn.noise_additive and self.mod_obs.noise_additive
 
-    def kernel_name(self):
-        """Which kernel(s) the device filter loop runs for this filter (one fused kernel, or a replayed hipGraph)."""
+    def kernel_name(self, batch=0):
+        """Which kernel(s) the device filter loop runs for this filter (one fused kernel, or a replayed hipGraph) on a batch of
+        `batch` trajectories (0: a batch that fills the device; small batches of some systems run k_filter_wsplit)."""
         if not self._additive:
             return ('k_filter_fused_aug (one kernel for the time loop) where instantiated, else a launch loop of 5 T '
                     'launches (k_augment | apply dyn | k_augment | apply obs | k_kalman_update)')
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
         f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
         buf = ctypes.create_string_buffer(512)
-        _lib.check(_lib.load().ssmq_filter_kernel_name(ctypes.c_void_p(self.tf_dyn._handle_for(e_dyn)),
-                                                       ctypes.byref(f_dyn),
-                                                       ctypes.c_void_p(self.tf_obs._handle_for(e_obs)),
-                                                       ctypes.byref(f_obs), buf, 512), 'ssmq_filter_kernel_name')
+        _lib.check(_lib.load().ssmq_filter_kernel_name_batch(ctypes.c_void_p(self.tf_dyn._handle_for(e_dyn)),
+                                                             ctypes.byref(f_dyn),
+                                                             ctypes.c_void_p(self.tf_obs._handle_for(e_obs)),
+                                                             ctypes.byref(f_obs), int(batch), buf, 512), 'ssmq_filter_kernel_name_batch')
         return buf.value.decode()
 
     def forward_pass(self, data):

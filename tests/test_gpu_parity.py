@@ -3251,3 +3251,114 @@ def test_extended_kalman_nonadditive_and_unsupported(amd):
         amd.LinearizationTransform(5).apply(rer.dyn_eval, np.ones(5), np.eye(5), np.atleast_1d(0))
     with pytest.raises(NotImplementedError):
         amd.LinearizationTransform(2).apply(lambda x, p: x, np.ones(2), np.eye(2), np.atleast_1d(0))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# k_filter_wsplit: the time loop with the sigma points of every transform shared out over the W waves of a workgroup
+# (csrc/ssmq_filter_wsplit.hip).  Default choice: the t-process form at batches that leave most of the device idle (configs[3]);
+# SSMQ_FUSED_WSPLIT = 0 / 2 / 4 forces the register kernel / a wave count where one is instantiated.
+# ---------------------------------------------------------------------------------------------------------------
+def _wsplit_filters(seed):
+    """(name, filter, measurements (Y, T, B), C-oracle transforms + arguments) for the three instantiated systems, B not a
+    multiple of 64 (the idle lanes of the last workgroup take part in every barrier and store nothing)."""
+    from oracle import c_oracle as co
+    from bench import simulate_reentry
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    out = []
+    B, T = 200, 12
+    x, y, m0, P0, Q, G, R = simulate_reentry(B, T, seed)
+    dyn = sm.ReentryVehicle2DTransition(sm.GaussRV(5, m0, P0), sm.GaussRV(3, cov=Q))
+    obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=R), 5)
+    alg = ssinf.UnscentedKalman(dyn, obs)
+    sp = lambda tf, E, ci: co.make_transform(1, tf.unit_sp.shape[0], E, tf.unit_sp, tf.wm, np.diag(tf.Wc).copy(), integrand=ci)   # noqa: E731
+    out.append(('ukf reentry 5-D', alg, y, sp(alg.tf_dyn, 5, co.Integrand.make(orc.F_REENTRY2D_DYN, (0.1,))),
+                sp(alg.tf_obs, 2, co.Integrand.make(orc.F_RADAR2D_MEAS, (0.0, 0.0))), m0, P0, G.dot(Q).dot(G.T), R, 2e-8, 2e-8))
+    mi = np.hstack((np.zeros((5, 1)), np.eye(5), 2 * np.eye(5))).astype(int)
+    alg = ssinf.BayesSardKalman(dyn, obs, np.array([[1.0] + [1.0] * 5]), np.array([[1.0, 0.9, 0.9] + [1e4] * 3]), mi, mi, 'ut')
+    alg.tf_dyn.model.model_var = 2e-6 * np.eye(5)
+    alg.tf_obs.model.model_var = 0 * np.eye(2)
+    out.append(('bsqkf reentry 5-D', alg, y, _c_bq_transform(alg.tf_dyn, 5, co.Integrand.make(orc.F_REENTRY2D_DYN, (0.1,))),
+                _c_bq_transform(alg.tf_obs, 2, co.Integrand.make(orc.F_RADAR2D_MEAS, (0.0, 0.0))), m0, P0, G.dot(Q).dot(G.T), R, 1e-3, 1e-2))
+    x, y, m0, P0, Q, G, R = simulate_reentry(B, T, seed + 1, True)
+    dyn6 = sm.ReentryVehicle2DBiasTransition(sm.GaussRV(6, m0, P0), sm.GaussRV(4, cov=Q))
+    obs6 = sm.Radar2DMeasurement(sm.GaussRV(2, cov=R), 6)
+    alg = ssinf.UnscentedKalman(dyn6, obs6)
+    out.append(('ukf reentry 6-D', alg, y, sp(alg.tf_dyn, 6, co.Integrand.make(orc.F_REENTRY2D_BIAS_DYN, (0.1,))),
+                sp(alg.tf_obs, 2, co.Integrand.make(orc.F_RADAR2D_MEAS, (0.0, 0.0))), m0, P0, G.dot(Q).dot(G.T), R, 2e-8, 2e-8))
+    # configs[3]: t-process quadrature Kalman filter, coordinated turn + four bearings
+    m0 = np.array([1000, 300, 1000, 0, np.deg2rad(-3.0)])
+    P0 = np.diag([100, 10, 100, 10, 0.1])
+    dt, r1, r2 = 0.1, 0.1, 1.75e-4
+    A = np.array([[dt ** 3 / 3, dt ** 2 / 2], [dt ** 2 / 2, dt]])
+    Q = np.zeros((5, 5))
+    Q[:2, :2], Q[2:4, 2:4], Q[4, 4] = r1 * A, r1 * A, r2 * dt
+    Rn = 10e-3 * np.eye(4)
+    dync = sm.CoordinatedTurnTransition(sm.GaussRV(5, m0, P0), sm.GaussRV(5, cov=Q), dt=dt)
+    obsc = sm.BearingMeasurement(sm.GaussRV(4, cov=Rn), 5, state_index=[0, 2], sensor_pos=SENSORS)
+    Tc = 4
+    d_x, d_y, ld = sm.simulate_dev(dync, obsc, Tc, B, seed=seed)
+    yc = d_y.download((Tc, 4, ld))[:, :, :B].transpose(1, 0, 2)
+    d_x.free()
+    d_y.free()
+    par = np.array([[1.0, 100, 100, 100, 100, 1]])
+    alg = ssinf.StudentProcessKalman(dync, obsc, par, par)
+    nu = float(alg.tf_dyn.model.nu)
+    out.append(('tpqkf ct + bearings', alg, yc, _c_bq_transform(alg.tf_dyn, 5, co.Integrand.make(orc.F_CT_DYN, (dt,)), nu, 1),
+                _c_bq_transform(alg.tf_obs, 4, co.Integrand.make(orc.F_BEARING_MEAS, tuple(SENSORS.reshape(-1)), (0, 2)), nu, 1),
+                m0, P0, Q, Rn, 1e-8, 1e-7))
+    return out
+
+
+def test_wsplit_filters_match_oracle_and_register_kernel(amd, monkeypatch):
+    """Every wave count of the wave-split time loop, and the register kernel it replaces, against the C oracle on the same
+    trajectories (pre-failure steps, means in standard deviations, covariances entry-scaled) and against each other: partial sums
+    re-associate, nothing else changes."""
+    from oracle import c_oracle as co
+    for name, alg, y, (td, k1), (to, k2), m0, P0, GQG, R, tol_m, tol_P in _wsplit_filters(51):
+        T, B = y.shape[1], y.shape[2]
+        cfm, cfP, cst = co.filter_forward(td, to, np.ascontiguousarray(y.transpose(2, 1, 0)), m0, P0, GQG, R, threads=8)
+        cfm, cfP = cfm.transpose(2, 1, 0), cfP.transpose(2, 3, 1, 0)
+        runs = {}
+        for mode in ('0', '2', '4'):
+            monkeypatch.setenv('SSMQ_FUSED_WSPLIT', mode)
+            kn = alg.kernel_name(B)
+            assert ('k_filter_wsplit' in kn and kn.endswith('W=%s>' % mode)) if mode != '0' else 'k_filter_fused<' in kn, kn
+            fm, fP = alg.forward_pass_batch(y, raise_on_failure=False)
+            runs[mode] = (fm.copy(), fP.copy(), alg.status.copy())
+            _compare_filter_prefix(fm, fP, alg.status, cfm, cfP, cst, T, '%s, wave-split mode %s vs C oracle' % (name, mode), tol_m, tol_P)
+        monkeypatch.delenv('SSMQ_FUSED_WSPLIT')
+        for mode in ('2', '4'):
+            assert np.array_equal(runs[mode][2], runs['0'][2]), name
+            _compare_filter_prefix(runs[mode][0], runs[mode][1], runs[mode][2], runs['0'][0], runs['0'][1], runs['0'][2], T,
+                                   '%s, W=%s vs the register kernel' % (name, mode), tol_m, tol_P)
+        # a second call with the same mode replays nothing stale: bitwise the same
+        monkeypatch.setenv('SSMQ_FUSED_WSPLIT', '2')
+        fm2, fP2 = alg.forward_pass_batch(y, raise_on_failure=False)
+        monkeypatch.delenv('SSMQ_FUSED_WSPLIT')
+        assert np.array_equal(fm2, runs['2'][0], equal_nan=True) and np.array_equal(fP2, runs['2'][1], equal_nan=True)
+
+
+def test_wsplit_default_choice_and_failures(amd, monkeypatch):
+    """What is picked without the switch: the wave-split loop for the t-process form while the batch leaves SIMDs idle, the
+    register kernel for saturated batches and for every other form (measured slower there: profiles/r05_wsplit.txt).  A
+    trajectory whose covariance is not positive definite fails at the same step in both kernels and is NaN from there on."""
+    monkeypatch.delenv('SSMQ_FUSED_WSPLIT', raising=False)
+    flt = _wsplit_filters(52)
+    ukf, tpq = flt[0][1], flt[3][1]
+    assert 'k_filter_fused<' in ukf.kernel_name(200) and 'k_filter_fused<' in ukf.kernel_name(100000)
+    assert 'k_filter_wsplit' in tpq.kernel_name(10000) and 'W=2>' in tpq.kernel_name(10000)
+    assert 'k_filter_fused<' in tpq.kernel_name(100000) and 'k_filter_fused<' in tpq.kernel_name()
+    name, alg, y, _, _, m0, P0, GQG, R, _, _ = flt[3]
+    B = y.shape[2]
+    x0c = np.tile(P0, (B, 1, 1))
+    x0c[3] = -np.eye(5)                  # not positive definite from the start
+    x0c[70, 0, 0] = np.nan
+    res = {}
+    for mode in ('0', '2', '4'):
+        monkeypatch.setenv('SSMQ_FUSED_WSPLIT', mode)
+        fm, fP = alg.forward_pass_batch(y, x0_mean=np.tile(m0, (B, 1)), x0_cov=x0c, raise_on_failure=False)
+        res[mode] = (fm.copy(), alg.status.copy())
+        assert alg.status[3] == 1 and alg.status[70] == 1 and np.all(np.isnan(fm[:, :, 3])) and np.all(np.isnan(fP[:, :, :, 70]))
+        assert np.all(np.isfinite(fm[:, :, alg.status == 0]))
+    monkeypatch.delenv('SSMQ_FUSED_WSPLIT')
+    assert np.array_equal(res['0'][1], res['2'][1]) and np.array_equal(res['0'][1], res['4'][1])
