@@ -392,9 +392,12 @@ int ssmq_gp_theta_step_times(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn,
  * mean [B][Din], cov [B][Din*Din] (augmented as for ssmq_gp_theta_step), y [B][Y], prior_mean [B][P], prior_cov [B][P*P],
  * theta [B][P]: start points in (normally the prior means), minimisers out; hess_inv [B][P*P] the BFGS inverse Hessian.
  * status[b]: 0 converged, SSMQ_BFGS_MAXITER / _PRECISION_LOSS / _NAN = scipy's warnflag 1 / 2 / 3 (theta / hess_inv as scipy
- * leaves them), SSMQ_BFGS_FALLBACK: the line search ended where scipy switches to its second one - the caller finishes this
- * trajectory itself (scipy.optimize.minimize from the start point), SSMQ_BFGS_PRIOR_NOT_PD.  iters[b] (may be NULL): BFGS
- * iterations; *rounds (may be NULL): device calls made.  Host arrays; synchronous.
+ * leaves them), SSMQ_BFGS_PRIOR_NOT_PD.  (SSMQ_BFGS_FALLBACK is kept for binary compatibility and no longer returned: where
+ * scipy switches to its second line search, scalar_search_wolfe2 / _zoom, the state machine follows it.)  An objective point
+ * that the reference's objective would RAISE on (kernel matrix or covariance not positive definite: LinAlgError out of
+ * scipy.optimize.minimize, ssinf.py:1153-1241) is a value of +inf here and the search continues; NaN is tested before maxiter
+ * (scipy: the other way round).  iters[b] (may be NULL): BFGS iterations; *rounds (may be NULL): device calls made.  Host
+ * arrays; synchronous.
  */
 enum { SSMQ_BFGS_MAXITER = 1, SSMQ_BFGS_PRECISION_LOSS = 2, SSMQ_BFGS_NAN = 3, SSMQ_BFGS_FALLBACK = 100, SSMQ_BFGS_PRIOR_NOT_PD = 101 };
 /*

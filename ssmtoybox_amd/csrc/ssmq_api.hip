@@ -2196,7 +2196,10 @@ static int gp_theta_step_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn
         ThetaGraph *tg = nullptr;
         for (auto &g : g_theta_graphs)
             if (g.key == key) tg = &g;
-        if (two_launch || getenv("SSMQ_NO_THETA_GRAPH")) {   // two launches + two copies: replay measured no faster (52 us either way)
+        // two launches + two copies: replay measured no faster (52 us either way).  Per-item times = the batched marginalised
+        // filter, whose item count changes from round to round: every new count would be captured, instantiated and evict an
+        // older entry of the six-slot cache without ever being replayed.
+        if (two_launch || times || getenv("SSMQ_NO_THETA_GRAPH")) {
             if ((rc = enqueue())) return rc;
         } else if (!tg) {
             if (g_theta_graphs.size() >= 6) {       // the oldest entry goes, not all of them (a filter alternates between two item counts)

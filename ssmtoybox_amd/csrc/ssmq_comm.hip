@@ -29,6 +29,7 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
+bool g_stub_marker = false;   // the loaded librccl is the stand-in of tests/stub_rccl (see host_staging)
 comm_t g_comm = nullptr;
 int g_rank = 0, g_world = 1;
 double *g_dbuf = nullptr;
@@ -66,6 +67,12 @@ int load_rccl() {
         return SSMQ_E_UNSUPPORTED;
     }
     g_rccl.lib = h;
+    g_stub_marker = dlsym(h, "ssmq_stub_rccl_marker") != nullptr;
+    if (getenv("SSMQ_COMM_HOST_STAGING") && getenv("SSMQ_COMM_HOST_STAGING")[0] == '1' && !g_stub_marker) {
+        ssmq::set_error("ssmq_comm: SSMQ_COMM_HOST_STAGING=1 is a test hook for the stand-in librccl (tests/stub_rccl); the library "
+                        "that was loaded is not the stand-in");
+        return SSMQ_E_UNSUPPORTED;
+    }
     return SSMQ_OK;
 }
 
@@ -78,10 +85,11 @@ int nccl_fail(int rc, const char *what) {
 // SSMQ_COMM_HOST_STAGING=1: the buffers handed to ncclAllReduce are the caller's HOST arrays and no HIP call is made - for
 // the stand-in librccl of tests/test_rccl_stub.py (which reduces through files), so that everything around the collective -
 // id publication, ncclCommInitRank on every rank, op codes, barrier, destroy - runs on a machine without a GPU.  Never set it
-// with the real RCCL.
+// with the real RCCL: the switch is honoured only if the loaded library exports `ssmq_stub_rccl_marker`, which only the
+// stand-in does - with the real library host pointers would otherwise reach ncclAllReduce.
 bool host_staging() {
-    static const bool on = getenv("SSMQ_COMM_HOST_STAGING") && getenv("SSMQ_COMM_HOST_STAGING")[0] == '1';
-    return on;
+    static const bool asked = getenv("SSMQ_COMM_HOST_STAGING") && getenv("SSMQ_COMM_HOST_STAGING")[0] == '1';
+    return asked && g_stub_marker;
 }
 
 int allreduce(double *buf, int64_t n, int op) {
@@ -143,9 +151,10 @@ int ssmq_comm_init(int rank, int world, const char *id, int len) {
     g_rank = rank;
     g_world = world;
     if (world == 1 && !id) return SSMQ_OK;   // single process: every reduction is the identity, RCCL is not loaded
-    int rc = host_staging() ? SSMQ_OK : ssmq::ensure_device();   // the communicator binds to the calling thread's current device
+    int rc = load_rccl();                                        // (first: host_staging() depends on what was loaded)
     if (rc) return rc;
-    if ((rc = load_rccl())) return rc;
+    rc = host_staging() ? SSMQ_OK : ssmq::ensure_device();       // the communicator binds to the calling thread's current device
+    if (rc) return rc;
     UniqueId u;
     memcpy(u.internal, id, kIdBytes);
     // RCCL prints a version banner on stdout while the communicator is created; callers own stdout (bench.py prints one

@@ -12,10 +12,17 @@
 // for method='BFGS' with jac=True and default options: _minimize_bfgs (gtol 1e-5 on the max-norm, maxiter 200 n, initial
 // inverse Hessian I, "old_old_fval = f0 + |g0| / 2"), line_search_wolfe1 -> scalar_search_wolfe1 (c1 1e-4, c2 0.9, amin 1e-100,
 // amax 1e100, xtol 1e-14, at most 100 trial steps) -> MINPACK-2's DCSRCH / DCSTEP (More' & Thuente; SciPy's _dcsrch.py), written
-// as a per-trajectory state machine because the function values arrive a round later.  Where SciPy would fall back to its
-// second line search (line_search_wolfe2: DCSRCH ended in an ERROR or WARNING task) the trajectory is handed back with
-// status SSMQ_BFGS_FALLBACK and the caller finishes it with SciPy itself, from the start point - results as the serial path.
+// as a per-trajectory state machine because the function values arrive a round later.  Where SciPy falls back to its second
+// line search (line_search_wolfe2: DCSRCH ended in an ERROR or WARNING task, or refused to start) the state machine goes on
+// with scalar_search_wolfe2 / _zoom as well (PH_LINE2 below); the status SSMQ_BFGS_FALLBACK of round 3's first version
+// ("the caller finishes this trajectory with SciPy") is no longer produced.
+// Two deliberate differences from the reference's serial path, both where its objective RAISES: an objective point whose
+// kernel matrix / covariance is not positive definite (or whose value is not finite) counts as +inf here and the search goes
+// on - numpy.linalg.LinAlgError propagates out of scipy.optimize.minimize in the reference and ends that trajectory's
+// forward_pass (ssinf.py:1088-1122); the batch instead reports it through `failed` only if the Laplace covariance or a
+// marginalisation point then fails.  And NaN is tested before maxiter (SciPy: warnflag 1 before 3).
 #include "ssmq_host.h"
+#include "ssmq_bfgs.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -32,182 +39,8 @@ using namespace ssmq;
 
 namespace {
 
-constexpr int kMaxPar = 2 * (SSMQ_MAX_DIM + 1);
-
-struct Dcsrch {            // scipy/optimize/_dcsrch.py: class DCSRCH (state), _iterate
-    int stage = 0;
-    bool brackt = false;
-    double ginit = 0, gtest = 0, gx = 0, gy = 0, finit = 0, fx = 0, fy = 0, stx = 0, sty = 0, stmin = 0, stmax = 0, width = 0, width1 = 0;
-    double ftol = 1e-4, gtol = 0.9, xtol = 1e-14, stpmin = 1e-100, stpmax = 1e100;
-};
-enum Task { T_START, T_FG, T_CONV, T_WARN, T_ERROR };
-
-double sgn(double v) { return (v > 0) - (v < 0); }
-double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// _dcsrch.py: dcstep
-void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp, double fp, double dp, bool &brackt,
-            double stpmin, double stpmax) {
-    const double sgnd = sgn(dp) * sgn(dx);
-    double stpf, stpc, stpq;
-    if (fp > fx) {
-        const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
-        const double s = std::fmax(std::fabs(theta), std::fmax(std::fabs(dx), std::fabs(dp)));
-        double gamma = s * std::sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
-        if (stp < stx) gamma *= -1;
-        const double p = (gamma - dx) + theta, q = ((gamma - dx) + gamma) + dp, r = p / q;
-        stpc = stx + r * (stp - stx);
-        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
-        stpf = std::fabs(stpc - stx) <= std::fabs(stpq - stx) ? stpc : stpc + (stpq - stpc) / 2.0;
-        brackt = true;
-    } else if (sgnd < 0.0) {
-        const double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
-        const double s = std::fmax(std::fabs(theta), std::fmax(std::fabs(dx), std::fabs(dp)));
-        double gamma = s * std::sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
-        if (stp > stx) gamma *= -1;
-        const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dx, r = p / q;
-        stpc = stp + r * (stx - stp);
-        stpq = stp + (dp / (dp - dx)) * (stx - stp);
-        stpf = std::fabs(stpc - stp) > std::fabs(stpq - stp) ? stpc : stpq;
-        brackt = true;
-    } else if (std::fabs(dp) < std::fabs(dx)) {
-        const double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
-        const double s = std::fmax(std::fabs(theta), std::fmax(std::fabs(dx), std::fabs(dp)));
-        double gamma = s * std::sqrt(std::fmax(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
-        if (stp > stx) gamma = -gamma;
-        const double p = (gamma - dp) + theta, q = (gamma + (dx - dp)) + gamma, r = p / q;
-        if (r < 0 && gamma != 0) stpc = stp + r * (stx - stp);
-        else if (stp > stx) stpc = stpmax;
-        else stpc = stpmin;
-        stpq = stp + (dp / (dp - dx)) * (stx - stp);
-        if (brackt) {
-            stpf = std::fabs(stpc - stp) < std::fabs(stpq - stp) ? stpc : stpq;
-            if (stp > stx) stpf = std::fmin(stp + 0.66 * (sty - stp), stpf);
-            else stpf = std::fmax(stp + 0.66 * (sty - stp), stpf);
-        } else {
-            stpf = std::fabs(stpc - stp) > std::fabs(stpq - stp) ? stpc : stpq;
-            stpf = clipd(stpf, stpmin, stpmax);
-        }
-    } else {
-        if (brackt) {
-            const double theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
-            const double s = std::fmax(std::fabs(theta), std::fmax(std::fabs(dy), std::fabs(dp)));
-            double gamma = s * std::sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
-            if (stp > sty) gamma = -gamma;
-            const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dy, r = p / q;
-            stpc = stp + r * (sty - stp);
-            stpf = stpc;
-        } else if (stp > stx) {
-            stpf = stpmax;
-        } else {
-            stpf = stpmin;
-        }
-    }
-    if (fp > fx) {
-        sty = stp; fy = fp; dy = dp;
-    } else {
-        if (sgnd < 0) {
-            sty = stx; fy = fx; dy = dx;
-        }
-        stx = stp; fx = fp; dx = dp;
-    }
-    stp = stpf;
-}
-
-// _dcsrch.py: DCSRCH._iterate.  Returns the next task; stp is updated in place.
-Task dcsrch_iterate(Dcsrch &d, double &stp, double f, double g, Task task) {
-    const double p5 = 0.5, p66 = 0.66, xtrapl = 1.1, xtrapu = 4.0;
-    if (task == T_START) {
-        if (stp < d.stpmin || stp > d.stpmax || g >= 0) return T_ERROR;
-        d.brackt = false;
-        d.stage = 1;
-        d.finit = f; d.ginit = g; d.gtest = d.ftol * d.ginit;
-        d.width = d.stpmax - d.stpmin; d.width1 = d.width / p5;
-        d.stx = 0.0; d.fx = d.finit; d.gx = d.ginit;
-        d.sty = 0.0; d.fy = d.finit; d.gy = d.ginit;
-        d.stmin = 0; d.stmax = stp + xtrapu * stp;
-        return T_FG;
-    }
-    const double ftest = d.finit + stp * d.gtest;
-    if (d.stage == 1 && f <= ftest && g >= 0) d.stage = 2;
-    Task out = T_FG;
-    if (d.brackt && (stp <= d.stmin || stp >= d.stmax)) out = T_WARN;
-    if (d.brackt && d.stmax - d.stmin <= d.xtol * d.stmax) out = T_WARN;
-    if (stp == d.stpmax && f <= ftest && g <= d.gtest) out = T_WARN;
-    if (stp == d.stpmin && (f > ftest || g >= d.gtest)) out = T_WARN;
-    if (f <= ftest && std::fabs(g) <= d.gtol * -d.ginit) out = T_CONV;
-    if (out == T_WARN || out == T_CONV) return out;
-    if (d.stage == 1 && f <= d.fx && f > ftest) {
-        const double fm = f - stp * d.gtest;
-        double fxm = d.fx - d.stx * d.gtest, fym = d.fy - d.sty * d.gtest;
-        const double gm = g - d.gtest;
-        double gxm = d.gx - d.gtest, gym = d.gy - d.gtest;
-        dcstep(d.stx, fxm, gxm, d.sty, fym, gym, stp, fm, gm, d.brackt, d.stmin, d.stmax);
-        d.fx = fxm + d.stx * d.gtest; d.fy = fym + d.sty * d.gtest;
-        d.gx = gxm + d.gtest; d.gy = gym + d.gtest;
-    } else {
-        dcstep(d.stx, d.fx, d.gx, d.sty, d.fy, d.gy, stp, f, g, d.brackt, d.stmin, d.stmax);
-    }
-    if (d.brackt) {
-        if (std::fabs(d.sty - d.stx) >= p66 * d.width1) stp = d.stx + p5 * (d.sty - d.stx);
-        d.width1 = d.width;
-        d.width = std::fabs(d.sty - d.stx);
-    }
-    if (d.brackt) {
-        d.stmin = std::fmin(d.stx, d.sty);
-        d.stmax = std::fmax(d.stx, d.sty);
-    } else {
-        d.stmin = stp + xtrapl * (stp - d.stx);
-        d.stmax = stp + xtrapu * (stp - d.stx);
-    }
-    stp = clipd(stp, d.stpmin, d.stpmax);
-    if ((d.brackt && (stp <= d.stmin || stp >= d.stmax)) || (d.brackt && d.stmax - d.stmin <= d.xtol * d.stmax)) stp = d.stx;
-    return T_FG;
-}
-
-// _linesearch.py: _cubicmin / _quadmin (None = false: an arithmetic error or a non-finite result)
-bool cubicmin(double a, double fa, double fpa, double b, double fb, double c, double fc, double *xmin) {
-    const double C = fpa, db = b - a, dc = c - a;
-    const double denom = (db * dc) * (db * dc) * (db - dc);
-    const double r0 = fb - fa - C * db, r1 = fc - fa - C * dc;
-    double A = dc * dc * r0 + -(db * db) * r1, Bq = -(dc * dc * dc) * r0 + db * db * db * r1;
-    if (denom == 0.0 || !std::isfinite(denom) || !std::isfinite(A) || !std::isfinite(Bq)) return false;
-    A /= denom;
-    Bq /= denom;
-    const double radical = Bq * Bq - 3 * A * C;
-    if (!(radical >= 0.0) || A == 0.0 || !std::isfinite(radical)) return false;
-    const double x = a + (-Bq + std::sqrt(radical)) / (3 * A);
-    if (!std::isfinite(x)) return false;
-    *xmin = x;
-    return true;
-}
-bool quadmin(double a, double fa, double fpa, double b, double fb, double *xmin) {
-    const double D = fa, C = fpa, db = b - a * 1.0;
-    if (db * db == 0.0) return false;
-    const double Bq = (fb - D - C * db) / (db * db);
-    if (Bq == 0.0 || !std::isfinite(Bq)) return false;
-    const double x = a - C / (2.0 * Bq);
-    if (!std::isfinite(x)) return false;
-    *xmin = x;
-    return true;
-}
-
-enum Phase { PH_INIT, PH_LINE, PH_LINE2, PH_DONE };
-
-struct Run {               // _minimize_bfgs' locals of one trajectory
-    Phase phase = PH_INIT;
-    int k = 0, ls_iter = 0, status = 0;
-    double x[kMaxPar], g[kMaxPar], pk[kMaxPar], xt[kMaxPar], H[kMaxPar * kMaxPar];
-    double old_fval = 0, old_old_fval = 0, derphi0 = 0, stp = 0;
-    Dcsrch ls;
-    Task task = T_START;
-    // second line search (scipy _linesearch.py: scalar_search_wolfe2 / _zoom), entered where the first one gives up
-    int w2_i = 0, z_i = 0;
-    bool zoom = false;
-    double w2_alpha0 = 0, w2_phi_a0 = 0, w2_derphi_a0 = 0;
-    double a_lo = 0, a_hi = 0, phi_lo = 0, phi_hi = 0, derphi_lo = 0, phi_rec = 0, a_rec = 0;
-};
-
+using namespace ssmq_bfgs;
+using Run = RunT<kMaxPar>;
 
 // values of the objective at n rows of parameters: rows [n][P], `traj[i]` = the trajectory row i belongs to; vals [n]
 struct Evaluator {
@@ -217,233 +50,6 @@ struct Evaluator {
 
 // One trajectory's optimiser takes the objective values at its pending point r.xt (vals[0]) and at the forward-difference
 // points (vals[1 + i]: r.xt + fd_step e_i) and either finishes (r.phase = PH_DONE, r.status) or leaves the next point in r.xt.
-void bfgs_advance(Run &r, int P, double fd_step, const double *vals) {
-    const double gtol = 1e-5, inf = std::numeric_limits<double>::infinity();
-    const int maxiter = 200 * P, per = P + 1;
-    // value and gradient at xt (non-finite -> +inf as the Python objective, ssmtoybox_amd/ssinf.py)
-    double val[kMaxPar + 1], gt[kMaxPar];
-    for (int j = 0; j < per; ++j) {
-        const double v = vals[j];
-        val[j] = std::isfinite(v) ? v : inf;
-    }
-    for (int i = 0; i < P; ++i) gt[i] = (val[i + 1] - val[0]) / ((r.xt[i] + fd_step) - r.xt[i]);
-    const double ft = val[0];
-    bool start_iteration = false;
-    if (r.phase == PH_INIT) {
-        r.old_fval = ft;
-        double n2 = 0.0, gmax = 0.0;
-        for (int i = 0; i < P; ++i) {
-            r.g[i] = gt[i];
-            n2 += gt[i] * gt[i];
-            gmax = (std::isnan(gt[i]) || std::isnan(gmax)) ? NAN : std::fmax(gmax, std::fabs(gt[i]));   // numpy's max keeps NaN
-        }
-        r.old_old_fval = r.old_fval + std::sqrt(n2) / 2;
-        if (!(gmax > gtol)) {            // (a NaN gradient ends the loop as in SciPy: `while gnorm > gtol`)
-            r.phase = PH_DONE;
-            r.status = (std::isnan(gmax) || std::isnan(ft)) ? SSMQ_BFGS_NAN : 0;
-            return;
-        }
-        start_iteration = true;
-    } else {                             // PH_LINE / PH_LINE2: a trial step has been evaluated
-        double dphi = 0.0;
-        for (int i = 0; i < P; ++i) dphi += gt[i] * r.pk[i];
-        const double c1 = 1e-4, c2 = 0.9, amax = 1e100;
-        const double phi0 = r.old_fval, derphi0 = r.derphi0;
-        bool accepted = false, to_second = false, failed = false;
-        double next = 0.0;                 // the next trial step, if neither
-        if (r.phase == PH_LINE) {
-            double stp = r.stp;
-            const Task t = dcsrch_iterate(r.ls, stp, ft, dphi, T_FG);
-            if (t == T_FG) {
-                ++r.ls_iter;
-                if (!std::isfinite(stp) || r.ls_iter >= 100) to_second = true;
-                else next = stp;
-            } else if (t == T_CONV) {
-                accepted = true;
-            } else {                       // WARNING / ERROR: SciPy goes on with line_search_wolfe2
-                to_second = true;
-            }
-        } else if (!r.zoom) {              // scalar_search_wolfe2, iteration w2_i, alpha1 = r.stp evaluated
-            const double alpha1 = r.stp, phi_a1 = ft, derphi_a1 = dphi;
-            auto start_zoom = [&](double a_lo, double a_hi, double phi_lo, double phi_hi, double derphi_lo) {
-                r.zoom = true; r.z_i = 0;
-                r.a_lo = a_lo; r.a_hi = a_hi; r.phi_lo = phi_lo; r.phi_hi = phi_hi; r.derphi_lo = derphi_lo;
-                r.phi_rec = phi0; r.a_rec = 0.0;
-            };
-            if (r.w2_i >= 10) {            // for ... else: maxiter reached; the last evaluated step is returned
-                accepted = true;
-            } else if (alpha1 == 0.0) {
-                failed = true;
-            } else if ((phi_a1 > phi0 + c1 * alpha1 * derphi0) || ((phi_a1 >= r.w2_phi_a0) && r.w2_i > 0)) {
-                start_zoom(r.w2_alpha0, alpha1, r.w2_phi_a0, phi_a1, r.w2_derphi_a0);
-            } else if (std::fabs(derphi_a1) <= -c2 * derphi0) {
-                accepted = true;
-            } else if (derphi_a1 >= 0) {
-                start_zoom(alpha1, r.w2_alpha0, phi_a1, r.w2_phi_a0, derphi_a1);
-            } else {
-                const double alpha2 = std::fmin(2 * alpha1, amax);
-                r.w2_alpha0 = alpha1; r.w2_phi_a0 = phi_a1; r.w2_derphi_a0 = derphi_a1;
-                ++r.w2_i;
-                next = alpha2;
-            }
-        } else {                           // _zoom: a_j = r.stp evaluated
-            const double a_j = r.stp, phi_aj = ft, derphi_aj = dphi;
-            if ((phi_aj > phi0 + c1 * a_j * derphi0) || (phi_aj >= r.phi_lo)) {
-                r.phi_rec = r.phi_hi; r.a_rec = r.a_hi; r.a_hi = a_j; r.phi_hi = phi_aj;
-            } else {
-                if (std::fabs(derphi_aj) <= -c2 * derphi0) {
-                    accepted = true;
-                } else {
-                    if (derphi_aj * (r.a_hi - r.a_lo) >= 0) {
-                        r.phi_rec = r.phi_hi; r.a_rec = r.a_hi; r.a_hi = r.a_lo; r.phi_hi = r.phi_lo;
-                    } else {
-                        r.phi_rec = r.phi_lo; r.a_rec = r.a_lo;
-                    }
-                    r.a_lo = a_j; r.phi_lo = phi_aj; r.derphi_lo = derphi_aj;
-                }
-            }
-            if (!accepted) {
-                ++r.z_i;
-                if (r.z_i > 10) failed = true;
-            }
-        }
-        if (to_second) {
-            // scalar_search_wolfe2 from the same point and direction: first trial step as for the first search
-            double alpha1 = 1.0;
-            if (derphi0 != 0) alpha1 = std::fmin(1.0, 1.01 * 2 * (phi0 - r.old_old_fval) / derphi0);
-            if (alpha1 < 0) alpha1 = 1.0;
-            alpha1 = std::fmin(alpha1, amax);
-            r.phase = PH_LINE2;
-            r.zoom = false; r.w2_i = 0;
-            r.w2_alpha0 = 0.0; r.w2_phi_a0 = phi0; r.w2_derphi_a0 = derphi0;
-            next = alpha1;
-        }
-        if (failed) {                      // _LineSearchError: "Desired error not necessarily achieved due to precision loss"
-            r.phase = PH_DONE;
-            r.status = SSMQ_BFGS_PRECISION_LOSS;
-            return;
-        }
-        if (!accepted) {
-            if (r.phase == PH_LINE2 && r.zoom) {
-                // the next trial step of _zoom: cubic, else quadratic interpolation, else bisection
-                const double dalpha = r.a_hi - r.a_lo;
-                const double a = dalpha < 0 ? r.a_hi : r.a_lo, b = dalpha < 0 ? r.a_lo : r.a_hi;
-                double a_j = 0.0;
-                bool have = false;
-                const double cchk = 0.2 * dalpha;
-                if (r.z_i > 0) have = cubicmin(r.a_lo, r.phi_lo, r.derphi_lo, r.a_hi, r.phi_hi, r.a_rec, r.phi_rec, &a_j);
-                if (r.z_i == 0 || !have || a_j > b - cchk || a_j < a + cchk) {
-                    const double qchk = 0.1 * dalpha;
-                    have = quadmin(r.a_lo, r.phi_lo, r.derphi_lo, r.a_hi, r.phi_hi, &a_j);
-                    if (!have || a_j > b - qchk || a_j < a + qchk) a_j = r.a_lo + 0.5 * dalpha;
-                }
-                next = a_j;
-            }
-            r.stp = next;
-            for (int i = 0; i < P; ++i) r.xt[i] = r.x[i] + next * r.pk[i];
-            return;
-        }
-        // accepted: alpha_k = stp, the last evaluated step
-        const double alpha = r.stp;
-        double sk[kMaxPar], yk[kMaxPar], pn = 0.0, gmax = 0.0;
-        for (int i = 0; i < P; ++i) {
-            sk[i] = alpha * r.pk[i];
-            r.x[i] = r.x[i] + sk[i];
-            yk[i] = gt[i] - r.g[i];
-            r.g[i] = gt[i];
-            pn += r.pk[i] * r.pk[i];
-            gmax = (std::isnan(gt[i]) || std::isnan(gmax)) ? NAN : std::fmax(gmax, std::fabs(gt[i]));
-        }
-        r.old_old_fval = r.old_fval;
-        r.old_fval = ft;
-        ++r.k;
-        if (!(gmax > gtol) && !std::isnan(gmax)) {
-            r.phase = PH_DONE;
-            r.status = 0;
-            return;
-        }
-        if (alpha * std::sqrt(pn) <= 0.0) {      // xrtol = 0
-            r.phase = PH_DONE;
-            r.status = std::isnan(gmax) ? SSMQ_BFGS_NAN : 0;
-            return;
-        }
-        if (!std::isfinite(r.old_fval)) {
-            r.phase = PH_DONE;
-            r.status = SSMQ_BFGS_PRECISION_LOSS;
-            return;
-        }
-        double rho_inv = 0.0;
-        for (int i = 0; i < P; ++i) rho_inv += yk[i] * sk[i];
-        const double rho = rho_inv == 0.0 ? 1000.0 : 1.0 / rho_inv;
-        // Hk = (I - sk yk' rho) Hk (I - yk sk' rho) + rho sk sk'
-        double A2[kMaxPar * kMaxPar], HA[kMaxPar * kMaxPar], Hn[kMaxPar * kMaxPar];
-        for (int i = 0; i < P; ++i)
-            for (int j = 0; j < P; ++j) A2[i * P + j] = (i == j ? 1.0 : 0.0) - yk[i] * sk[j] * rho;
-        for (int i = 0; i < P; ++i)
-            for (int j = 0; j < P; ++j) {
-                double s = 0.0;
-                for (int k = 0; k < P; ++k) s += r.H[i * P + k] * A2[k * P + j];
-                HA[i * P + j] = s;
-            }
-        for (int i = 0; i < P; ++i)
-            for (int j = 0; j < P; ++j) {
-                double s = 0.0;
-                for (int k = 0; k < P; ++k) s += ((i == k ? 1.0 : 0.0) - sk[i] * yk[k] * rho) * HA[k * P + j];
-                Hn[i * P + j] = s + rho * sk[i] * sk[j];
-            }
-        std::memcpy(r.H, Hn, sizeof(double) * P * P);
-        if (std::isnan(gmax)) {                  // `while gnorm > gtol` ends on NaN
-            r.phase = PH_DONE;
-            r.status = SSMQ_BFGS_NAN;
-            return;
-        }
-        if (r.k >= maxiter) {
-            r.phase = PH_DONE;
-            r.status = SSMQ_BFGS_MAXITER;
-            return;
-        }
-        start_iteration = true;
-    }
-    if (start_iteration) {
-        // pk = -Hk gfk; scalar_search_wolfe1's first trial step; DCSRCH "START"
-        double dphi0 = 0.0;
-        for (int i = 0; i < P; ++i) {
-            double s = 0.0;
-            for (int j = 0; j < P; ++j) s += r.H[i * P + j] * r.g[j];
-            r.pk[i] = -s;
-        }
-        for (int i = 0; i < P; ++i) dphi0 += r.g[i] * r.pk[i];
-        r.derphi0 = dphi0;
-        double alpha1 = 1.0;
-        if (dphi0 != 0) {
-            alpha1 = std::fmin(1.0, 1.01 * 2 * (r.old_fval - r.old_old_fval) / dphi0);
-            if (alpha1 < 0) alpha1 = 1.0;
-        }
-        r.ls = Dcsrch();
-        double stp = alpha1;
-        const Task t = dcsrch_iterate(r.ls, stp, r.old_fval, dphi0, T_START);
-        if (t != T_FG || !std::isfinite(stp)) {
-            // the first search refuses to start (e.g. not a descent direction): scalar_search_wolfe2 from its first step
-            r.phase = PH_LINE2;
-            r.zoom = false; r.w2_i = 0;
-            r.w2_alpha0 = 0.0; r.w2_phi_a0 = r.old_fval; r.w2_derphi_a0 = dphi0;
-            stp = std::fmin(alpha1, 1e100);
-        } else {
-            r.ls_iter = 1;
-            r.phase = PH_LINE;
-        }
-        r.stp = stp;
-        for (int i = 0; i < P; ++i) r.xt[i] = r.x[i] + stp * r.pk[i];
-    }
-}
-
-void bfgs_start(Run &r, int P, const double *x0) {
-    r = Run();
-    for (int i = 0; i < P; ++i) r.x[i] = r.xt[i] = x0[i];
-    for (int i = 0; i < P * P; ++i) r.H[i] = 0.0;
-    for (int i = 0; i < P; ++i) r.H[i * P + i] = 1.0;
-}
-
 // B BFGS runs in lock step.  theta [B][P] start points in / minimisers out; skip[b] != 0: trajectory b is not run (status kept).
 int bfgs_lockstep(int64_t B, int P, double fd_step, Evaluator &ev, double *theta, double *hess_inv, int32_t *status, int32_t *iters,
                   int64_t *rounds_out) {
@@ -698,26 +304,6 @@ struct Traj {
     double pm[kMaxPar], pc[kMaxPar * kMaxPar], Lp[kMaxPar * kMaxPar], logdet2 = 0;   // parameter prior of this step, its factor
     double pts[kMaxPar * 2 * kMaxPar];                                  // [NP][P] marginalisation points of this step
 };
-
-bool chol_lower(const double *C, int P, double *L, double *logdet2) {
-    double ld = 0.0;
-    for (int i = 0; i < P * P; ++i) L[i] = 0.0;
-    for (int j = 0; j < P; ++j) {
-        double s = C[j * P + j];
-        for (int k = 0; k < j; ++k) s -= L[j * P + k] * L[j * P + k];
-        if (!(s > 0.0)) return false;
-        const double ljj = std::sqrt(s);
-        L[j * P + j] = ljj;
-        ld += 2.0 * std::log(ljj);
-        for (int i = j + 1; i < P; ++i) {
-            double t = C[i * P + j];
-            for (int k = 0; k < j; ++k) t -= L[i * P + k] * L[j * P + k];
-            L[i * P + j] = t / ljj;
-        }
-    }
-    if (logdet2) *logdet2 = ld;
-    return true;
-}
 
 }  // namespace
 

@@ -1158,6 +1158,13 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
         a.use_lds = 0;
         a.tiled = 1;
         const int P = a.P, nblk = (N + kCb - 1) / kCb;
+        // the workspace carve-up is checked BEFORE the first kernel that writes into it is queued
+        const int NB = a.NB;
+        const WgtCarve cv(a.D, N, NB);
+        if (cv.end > a.work_stride) {
+            set_error("weights: workspace smaller than its carve-up");
+            return SSMQ_E_ARG;
+        }
         hipLaunchKernelGGL(k_wb_kmatrix, dim3((unsigned)((nn + 255) / 256), P), dim3(256), 0, s, a);
         for (int kb = 0; kb < nblk; ++kb) {
             hipLaunchKernelGGL(k_wb_chol_panel, dim3(nblk - kb, P), dim3(256), kCbLds, s, N, kb, a.work, a.work_stride, a.status);
@@ -1180,13 +1187,7 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
         if ((rc = hip_fail(hipGetLastError(), "k_wb_inverse"))) return rc;
         a.stage = 3;
         hipLaunchKernelGGL(k_weights<1024>, dim3(P), dim3(1024), tiles, s, a);
-        const int NB = a.NB;
-        const WgtCarve cv(a.D, N, NB);
         const int64_t off_m1 = cv.M1, off_m2 = cv.M2, off_t4 = cv.T4;
-        if (cv.end > a.work_stride) {
-            set_error("weights: workspace smaller than its carve-up");
-            return SSMQ_E_ARG;
-        }
         const dim3 gg((N + 63) / 64, (N + 63) / 64, P);
         if (NB == 0)
             hipLaunchKernelGGL(k_wb_gemm, gg, dim3(256), 0, s, a.work + off_m1, a.work_stride, N, a.Q, (int64_t)nn, N, a.iK,

@@ -106,3 +106,7 @@ int ncclCommDestroy(ncclComm_t c) {
 }
 
 const char *ncclGetErrorString(int rc) { return rc == 0 ? "success" : rc == 6 ? "stub: a rank did not arrive" : "stub error"; }
+
+/* only this stand-in exports the marker: libssmq honours SSMQ_COMM_HOST_STAGING=1 (host pointers handed to ncclAllReduce) only
+ * when the library it loaded has it (csrc/ssmq_comm.hip: host_staging) */
+int ssmq_stub_rccl_marker(void) { return 1; }
