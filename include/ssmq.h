@@ -417,14 +417,22 @@ int ssmq_gp_marginal_laplace_batch(ssmq_transform *h_dyn, const ssmq_integrand *
 /*
  * The whole marginalised filter (ssinf.py:66-118 around :1083-1273) for B trajectories, every trajectory at its own pace: each
  * walks Laplace step (BFGS as above) -> mixture over the NP parameter sigma points -> next time step by itself, and every device
- * round (ONE ssmq_gp_theta_step_times) serves whatever the unfinished trajectories wait for.  Rounds = the longest trajectory's
- * total, not the sum over the time steps of the slowest one's.
+ * round (ONE theta step) serves whatever the unfinished trajectories wait for.  Rounds = the longest trajectory's total, not
+ * the sum over the time steps of the slowest one's.  Where the theta step has its two-launch route and P <= 16 the trajectories'
+ * state machines live ON THE DEVICE (round 5: pack | theta step | advance are five launches per round, nothing is copied or
+ * waited for per round; every eighth round one integer comes back); SSMQ_MARGINAL_HOST_ROUNDS=1 keeps them on the host.
  * y [B][T][Y]; x0_mean [D], x0_cov [D*D]; q_mean [dq] / q_cov [dq*dq] for dynamics that take their noise as an argument (h_dyn is
  * then a (D + dq) -> D transform, GQG = NULL), else NULL; prior_mean [P], prior_cov [P*P] of the log-parameters at step 1 (each
  * step's posterior is the next step's prior); upts [P][NP] unit sigma points and uwts [NP] weights of the parameter mixture
  * (the reference: spherical-radial, NP = 2 P); time index of step k is k (ssinf.py:1088-1122 as called from :101-110).
- * fm [B][T][D], fP [B][T][D*D] filtered moments (NaN from the step at which a trajectory failed); failed [B]: 0, or the step at
- * which a kernel matrix / covariance / Laplace covariance stopped being positive definite (the reference raises there);
+ * fm [B][T][D], fP [B][T][D*D] filtered moments (NaN from the step at which a trajectory failed); failed [B]: 0, or
+ * step + 65536 reason (T < 65536) for the step at which the reference would raise numpy.linalg.LinAlgError - reason 1: the
+ * step's parameter prior is not positive definite (_param_log_prior); 2 / 3: the Laplace posterior hess_inv + jitter is not
+ * finite / not positive definite (the Cholesky factor of _measurement_update's parameter sigma points, ssinf.py:1103-1106);
+ * 4: a parameter sigma point's filter step failed (kernel matrix or covariance not positive definite); 5: the mixture moments
+ * are not finite.  Reasons 2-3 depend on the path BFGS took through a noisy objective (forward-difference gradients): a
+ * trajectory that fails so in one implementation of the same optimiser may pass in another (tests/test_gpu_parity.py:
+ * test_marginal_filter_failures_are_the_reference_s_linalg_errors);
  * theta_last [B][P], pcov_last [B][P*P] (may be NULL): the last parameter posterior; stats [3] (may be NULL): device rounds,
  * BFGS iterations, theta items.  Host arrays; synchronous.
  */

@@ -1961,10 +1961,10 @@ int launch_gauss_logpdf(int Y, int64_t B, int64_t ld, const double *y, const dou
 bool gp_theta_weights_fits(int D0, int N0, int D1, int N1);
 int gp_theta_weights_pair(const int D[2], const int E[2], const int N[2], const double *const d_xi[2],
                           const double *const d_par[2], int P, double jitter, double *const d_consts[2],
-                          int32_t *const d_status[2]);
+                          int32_t *const d_status[2], const int32_t *d_count = nullptr);
 bool theta_chain_supported(int Din, int D, int Y, int Nd, int No);
 hipError_t launch_theta_chain(const WideArgs &dyn, const WideArgs &obs, const UpdArgs &upd, const double *y, double *loglik,
-                              const int32_t *merge, int32_t *merge_out, int64_t B, hipStream_t s);
+                              const int32_t *merge, int32_t *merge_out, int64_t B, hipStream_t s, const int32_t *d_count = nullptr);
 }
 
 
@@ -2247,6 +2247,118 @@ static int gp_theta_step_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn
     }
     return first;
 }
+
+// ---- the theta-batched step with its items ALREADY on the device and their number in device memory --------------------------
+// (the device-resident rounds of the batched marginalised filter, ssmq_marginal.hip: no host copy and no synchronisation per
+// round; the kernels are the two of gp_theta_step_impl's two-launch route, launched on an upper bound of the item count.)
+namespace ssmq {
+bool theta_dev_supported(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs, const ssmq_integrand *f_obs) {
+    if (!h_dyn || !h_obs || !f_dyn || !f_obs) return false;
+    const int Din = h_dyn->D, D = h_dyn->E, Y = h_obs->E, Nd = h_dyn->N, No = h_obs->N;
+    if (Din < D || h_obs->D != D || h_dyn->form != SSMQ_FORM_BQ || h_obs->form != SSMQ_FORM_BQ || h_dyn->tp_nu > 0.0 || h_obs->tp_nu > 0.0)
+        return false;
+    FInfo fi;
+    if (check_integrand(h_dyn, f_dyn, &fi) || check_integrand(h_obs, f_obs, &fi))
+        return false;
+    return theta_chain_supported(Din, D, Y, Nd, No) && gp_theta_weights_fits(Din, Nd, D, No);
+}
+
+size_t theta_dev_bytes(const ssmq_transform *h_dyn, const ssmq_transform *h_obs, int64_t cap) {
+    ThetaDev t;
+    return theta_dev_carve(t, h_dyn, h_obs, cap, nullptr);
+}
+
+// lays the arena out (base may be null: size only); returns its size in bytes
+size_t theta_dev_carve(ThetaDev &t, const ssmq_transform *h_dyn, const ssmq_transform *h_obs, int64_t cap, void *base) {
+    const int Din = h_dyn->D, D = h_dyn->E, Y = h_obs->E, Nd = h_dyn->N, No = h_obs->N;
+    const int64_t ld = (cap + 63) / 64 * 64;
+    const WideLayout cld = wide_layout(Din, D, Nd, SSMQ_FORM_BQ), clo = wide_layout(D, Y, No, SSMQ_FORM_BQ);
+    t.Din = Din; t.D = D; t.Y = Y; t.Nd = Nd; t.No = No; t.cap = cap; t.ld = ld;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? (char *)base + off : nullptr;
+        off += (bytes + 255) / 256 * 256;
+        return p;
+    };
+    t.xid = (double *)take(sizeof(double) * Din * Nd);
+    t.xio = (double *)take(sizeof(double) * D * No);
+    t.gq = (double *)take(sizeof(double) * D * D);
+    t.rr = (double *)take(sizeof(double) * Y * Y);
+    t.pard = (double *)take(sizeof(double) * cap * (1 + Din));
+    t.paro = (double *)take(sizeof(double) * cap * (1 + D));
+    t.mean = (double *)take(sizeof(double) * cap * Din);
+    t.cov = (double *)take(sizeof(double) * cap * Din * Din);
+    t.ysoa = (double *)take(sizeof(double) * ld * Y);
+    t.tt = (double *)take(sizeof(double) * ld);
+    t.cd = (double *)take(sizeof(double) * cap * cld.total);
+    t.co = (double *)take(sizeof(double) * cap * clo.total);
+    t.mid = (double *)take(sizeof(double) * ld * ((size_t)D + (size_t)D * D + (size_t)D * Din + Y + (size_t)Y * Y + (size_t)Y * D));
+    t.m_fi = (double *)take(sizeof(double) * ld * D);
+    t.P_fi = (double *)take(sizeof(double) * ld * D * D);
+    t.ll = (double *)take(sizeof(double) * ld);
+    t.st_all = (int32_t *)take(sizeof(int32_t) * ld);
+    t.st5 = (int32_t *)take(sizeof(int32_t) * 5 * ld);
+    return off;
+}
+
+// uploads what does not change between rounds: the unit points of both transforms, G Q G' (zeros for dynamics that take their
+// noise as an argument) and R
+int theta_dev_upload_static(const ThetaDev &t, const ssmq_transform *h_dyn, const ssmq_transform *h_obs, const double *GQG, const double *R,
+                            hipStream_t s) {
+    SSMQ_HIP(hipMemcpyAsync(t.xid, h_dyn->xi.data(), sizeof(double) * t.Din * t.Nd, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(t.xio, h_obs->xi.data(), sizeof(double) * t.D * t.No, hipMemcpyHostToDevice, s));
+    if (GQG) SSMQ_HIP(hipMemcpyAsync(t.gq, GQG, sizeof(double) * t.D * t.D, hipMemcpyHostToDevice, s));
+    else SSMQ_HIP(hipMemsetAsync(t.gq, 0, sizeof(double) * t.D * t.D, s));
+    if (R) SSMQ_HIP(hipMemcpyAsync(t.rr, R, sizeof(double) * t.Y * t.Y, hipMemcpyHostToDevice, s));
+    else SSMQ_HIP(hipMemsetAsync(t.rr, 0, sizeof(double) * t.Y * t.Y, s));
+    SSMQ_HIP(hipStreamSynchronize(s));        // (the host vectors may go away)
+    return SSMQ_OK;
+}
+
+// weights of both transforms, then transform -> transform -> update -> log-likelihood per item: two launches covering
+// `bound` items (>= the count the kernels read from *d_count; 0 < bound <= t.cap)
+int theta_dev_enqueue(const ThetaDev &t, const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
+                      const ssmq_integrand *f_obs, double jitter, int64_t bound, const int32_t *d_count, hipStream_t s) {
+    if (bound < 1 || bound > t.cap) {
+        set_error("theta_dev_enqueue: bad bound");
+        return SSMQ_E_ARG;
+    }
+    const int Din = t.Din, D = t.D, Y = t.Y, Nd = t.Nd, No = t.No;
+    const int64_t ld = t.ld;
+    const WideLayout cld = wide_layout(Din, D, Nd, SSMQ_FORM_BQ), clo = wide_layout(D, Y, No, SSMQ_FORM_BQ);
+    int32_t *st_wd = t.st5, *st_wo = st_wd + ld, *st_td = st_wo + ld, *st_to = st_td + ld, *st_up = st_to + ld;
+    int rc;
+    {
+        const int dd[2] = {Din, D}, ee[2] = {D, Y}, nn[2] = {Nd, No};
+        const double *const xx[2] = {t.xid, t.xio}, *const pp[2] = {t.pard, t.paro};
+        double *const cc[2] = {t.cd, t.co};
+        int32_t *const ss[2] = {st_wd, st_wo};
+        if ((rc = gp_theta_weights_pair(dd, ee, nn, xx, pp, (int)bound, jitter, cc, ss, d_count))) return rc;
+    }
+    double *w = t.mid;
+    double *m_pr = w; w += ld * D;
+    double *P_pr = w; w += ld * D * D;
+    double *C_xx = w; w += ld * D * Din;
+    double *y_mean = w; w += ld * Y;
+    double *P_y = w; w += ld * Y * Y;
+    double *P_yx = w;
+    WideArgs a;
+    memset(&a, 0, sizeof(a));
+    a.D = Din; a.E = D; a.N = Nd; a.form = SSMQ_FORM_BQ; a.mode = SSMQ_WIDE_FULL; a.fid = f_dyn->id; a.time_stride = 1;
+    a.emv_mode = h_dyn->emv_mode; a.tp_nu = 0.0; a.cov_scale = a.ccov_scale = 1.0;
+    a.consts = t.cd; a.consts_stride = cld.total; a.cov_add = t.gq;
+    a.mean = t.mean; a.cov = t.cov; a.time = t.tt; a.es_in = 1; a.bs_mean = Din; a.bs_cov = (int64_t)Din * Din;
+    a.mean_f = m_pr; a.cov_f = P_pr; a.cov_fx = C_xx; a.es_out = ld; a.bs_mf = a.bs_cf = a.bs_cfx = 1; a.status = st_td;
+    fill_fpar(f_dyn, &a.fp);
+    const WideArgs a_dyn = a;
+    a.D = D; a.E = Y; a.N = No; a.fid = f_obs->id; a.emv_mode = h_obs->emv_mode; a.consts = t.co; a.consts_stride = clo.total;
+    a.cov_add = t.rr; a.mean = m_pr; a.cov = P_pr; a.es_in = ld; a.bs_mean = a.bs_cov = 1;
+    a.mean_f = y_mean; a.cov_f = P_y; a.cov_fx = P_yx; a.status = st_to;
+    fill_fpar(f_obs, &a.fp);
+    const UpdArgs u{m_pr, P_pr, y_mean, P_y, P_yx, t.ysoa, t.m_fi, t.P_fi, st_up, nullptr, nullptr, bound, ld, 0, D, Y, 0.0, nullptr, D};
+    return hip_fail(launch_theta_chain(a_dyn, a, u, t.ysoa, t.ll, st_wd, t.st_all, bound, s, d_count), "k_theta_chain(device rounds)");
+}
+}  // namespace ssmq
 
 extern "C" int ssmq_simulate_rv_dev(const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, int D, int Y, const ssmq_rv *x0,
                                     const ssmq_rv *q, const ssmq_rv *r, const double *G, int dyn_additive, int obs_additive,

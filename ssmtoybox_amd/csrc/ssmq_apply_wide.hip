@@ -727,11 +727,13 @@ struct ThetaChainArgs {
     const int32_t *merge;       // five flag vectors, pitch upd.ld
     int32_t *merge_out;
     int32_t lds_per_wave;       // doubles
+    const int32_t *count;       // null, or the number of items on the device (B of the launch is then an upper bound)
 };
 
 template <int DM, bool GEN>
-__global__ __launch_bounds__(64 * kWaveWaves) void k_theta_chain(const ThetaChainArgs c, int64_t B) {
+__global__ __launch_bounds__(64 * kWaveWaves) void k_theta_chain(const ThetaChainArgs c, int64_t B_launch) {
     extern __shared__ __align__(16) double lds[];
+    const int64_t B = c.count ? (int64_t)*c.count : B_launch;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wid = (int64_t)blockIdx.x * kWaveWaves + wave;
     double *lw = lds + (size_t)wave * c.lds_per_wave;
@@ -793,9 +795,10 @@ static hipError_t launch_chain_one(const ThetaChainArgs &c, int64_t B, size_t ld
 
 // dyn / obs: WideArgs of the two transforms as for launch_apply_wide (mode FULL, form BQ); upd: the update's arguments
 hipError_t launch_theta_chain(const WideArgs &dyn, const WideArgs &obs, const UpdArgs &upd, const double *y, double *loglik,
-                              const int32_t *merge, int32_t *merge_out, int64_t B, hipStream_t s) {
+                              const int32_t *merge, int32_t *merge_out, int64_t B, hipStream_t s, const int32_t *d_count) {
     ThetaChainArgs c;
     c.dyn = dyn; c.obs = obs; c.upd = upd; c.y = y; c.loglik = loglik; c.merge = merge; c.merge_out = merge_out;
+    c.count = d_count;
     const int K = std::min(wave_groups(dyn.D, dyn.E, dyn.N, false), wave_groups(obs.D, obs.E, obs.N, false));
     c.dyn.wave_k = c.obs.wave_k = K;
     const int per_item = std::max((wave_lds_doubles(dyn.D, dyn.E, dyn.N, false) + 1) & ~1, (wave_lds_doubles(obs.D, obs.E, obs.N, false) + 1) & ~1);

@@ -190,7 +190,7 @@ struct RunT {            // _minimize_bfgs' locals of one trajectory; PM: compil
 };
 
 template <int PM>
-SSMQ_BFGS_HD void bfgs_advance(RunT<PM> &r, int P, double fd_step, const double *vals) {
+SSMQ_BFGS_HD inline __attribute__((always_inline)) void bfgs_advance(RunT<PM> &r, int P, double fd_step, const double *vals) {
     const double gtol = 1e-5, inf = __builtin_huge_val();
     const int maxiter = 200 * P, per = P + 1;
     // value and gradient at xt (non-finite -> +inf as the Python objective, ssmtoybox_amd/ssinf.py)

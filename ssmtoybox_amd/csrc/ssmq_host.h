@@ -113,6 +113,26 @@ struct BigRest {
 };
 int launch_big_rest(const BigRest &r, int64_t B, hipStream_t s);
 
+// theta-batched step on items that are already on the device, their number read from device memory (ssmq_api.hip; used by the
+// device-resident rounds of ssmq_gp_marginal_filter_batch, ssmq_marginal.hip)
+struct ThetaDev {
+    int Din, D, Y, Nd, No;
+    int64_t cap, ld;                                     // items the arena holds; plane pitch
+    double *pard, *paro, *mean, *cov, *ysoa, *tt;        // per item, filled by the caller: kernel parameters [cap][1 + Din] / [cap][1 + D],
+                                                         // state moments [cap][Din] / [cap][Din Din], measurement planes [Y][ld], time [ld]
+    double *m_fi, *P_fi, *ll;                            // results: planes [D][ld], [D D][ld], log-likelihood [ld]
+    int32_t *st_all;                                     // merged status flags [ld]
+    double *xid, *xio, *gq, *rr, *cd, *co, *mid;         // internal: unit points, noise terms, constant blocks, work planes
+    int32_t *st5;
+};
+bool theta_dev_supported(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs, const ssmq_integrand *f_obs);
+size_t theta_dev_bytes(const ssmq_transform *h_dyn, const ssmq_transform *h_obs, int64_t cap);
+size_t theta_dev_carve(ThetaDev &t, const ssmq_transform *h_dyn, const ssmq_transform *h_obs, int64_t cap, void *base);
+int theta_dev_upload_static(const ThetaDev &t, const ssmq_transform *h_dyn, const ssmq_transform *h_obs, const double *GQG, const double *R,
+                            hipStream_t s);
+int theta_dev_enqueue(const ThetaDev &t, const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
+                      const ssmq_integrand *f_obs, double jitter, int64_t bound, const int32_t *d_count, hipStream_t s);
+
 // trajectory / measurement simulator (ssmq_simulate.hip)
 struct SimRv {
     int kind, dim, ncomp, off;      // off: doubles into the constants block (alpha | mean | chol)

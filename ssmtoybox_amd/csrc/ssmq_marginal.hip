@@ -42,6 +42,10 @@ namespace {
 using namespace ssmq_bfgs;
 using Run = RunT<kMaxPar>;
 
+// why a trajectory left the batch (failed[b] = step + 65536 reason; include/ssmq.h)
+enum { WHY_PRIOR_NOT_PD = 1, WHY_LAPLACE_NOT_FINITE = 2, WHY_LAPLACE_NOT_PD = 3, WHY_MIXTURE_ITEM = 4, WHY_MIXTURE_NOT_FINITE = 5 };
+__host__ __device__ inline int32_t why(int k, int reason) { return k < 65536 ? k + 65536 * reason : k; }
+
 // values of the objective at n rows of parameters: rows [n][P], `traj[i]` = the trajectory row i belongs to; vals [n]
 struct Evaluator {
     virtual int eval(int64_t n, const int64_t *traj, const double *rows, double *vals) = 0;
@@ -305,6 +309,367 @@ struct Traj {
     double pts[kMaxPar * 2 * kMaxPar];                                  // [NP][P] marginalisation points of this step
 };
 
+// ---- device-resident rounds ------------------------------------------------------------------------------------------------------
+// The same filter with the per-trajectory state machines ON THE DEVICE: one thread per trajectory packs the points it is
+// waiting for straight into the theta step's device arena (k_mg_scan: item offsets by a block-wide scan; k_mg_fill), the theta
+// step runs on them with the item count read from device memory (theta_dev_enqueue: k_theta_weights, k_theta_chain), and the same
+// thread takes the values and advances its optimiser / mixture / time step (k_mg_advance: bfgs_advance of ssmq_bfgs.h, the code the
+// host rounds run).  The host only queues rounds - five launches each, no copy, no synchronisation - and every kRoundsPerCheck
+// rounds reads ONE integer back: the number of unfinished trajectories, which is also the bound of the next launches' grids.
+// Round 4's host rounds cost ~85 us each (55 us of which copies, synchronisation and host turn-around: DESIGN.md 3.13) and
+// the number of rounds is set by the ONE longest trajectory.
+constexpr int kRoundsPerCheck = 8;
+
+template <int PM>
+struct TrajD {
+    int k, mode;                     // time step being worked on (1 .. T); 0: optimising, 1: waiting for the mixture points, 2: done / failed
+    RunT<PM> run;
+    double xm[SSMQ_MAX_DIM], xP[SSMQ_MAX_DIM * SSMQ_MAX_DIM];
+    double pm[PM], pc[PM * PM], Lp[PM * PM], logdet2;
+    double pts[PM * 2 * PM];         // [NP][P]
+};
+
+struct MgArgs {
+    void *traj;
+    int64_t B;
+    int32_t T, P, Pd, Po, NP, D, Din, Y, dq;
+    const double *y;                 // [B][T][Y]
+    const double *x0_mean, *x0_cov, *prior_mean, *prior_cov, *q_mean, *q_cov, *upts, *uwts;
+    double fd_step, param_jitter;
+    int32_t *first;                  // [B] item offset of every trajectory in this round
+    signed char *modes;              // [B] TrajD::mode of every trajectory, compact (what the scan reads)
+    int32_t *count;                  // [0] items of this round, [1] unfinished trajectories, [2] rounds that had items
+    unsigned long long *totals;      // [0] items, [1] BFGS iterations
+    ThetaDev th;
+    double *fm, *fP;                 // [B][T][D], [B][T][D D], NaN where nothing was produced
+    int32_t *failed;                 // [B]
+};
+
+template <int PM>
+__device__ void mg_begin_step(TrajD<PM> &t, const MgArgs &a, int64_t b) {
+    if (!chol_lower(t.pc, a.P, t.Lp, &t.logdet2)) {     // numpy.linalg.cholesky would raise in _param_log_prior
+        t.mode = 2;
+        a.failed[b] = why(t.k, WHY_PRIOR_NOT_PD);
+        return;
+    }
+    bfgs_start(t.run, a.P, t.pm);
+    t.mode = 0;
+}
+
+template <int PM>
+__global__ void k_mg_init(const MgArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    TrajD<PM> &t = ((TrajD<PM> *)a.traj)[b];
+    t.k = 1;
+    for (int i = 0; i < a.D; ++i) t.xm[i] = a.x0_mean[i];
+    for (int i = 0; i < a.D * a.D; ++i) t.xP[i] = a.x0_cov[i];
+    for (int i = 0; i < a.P; ++i) t.pm[i] = a.prior_mean[i];
+    for (int i = 0; i < a.P * a.P; ++i) t.pc[i] = a.prior_cov[i];
+    a.failed[b] = 0;
+    mg_begin_step(t, a, b);
+    a.modes[b] = (signed char)t.mode;
+}
+
+// item offsets of this round (one workgroup; trajectories in order, so the item order is the host rounds'): every thread takes
+// four consecutive trajectories (their modes from the compact mirror a.modes), wave prefix sums by shuffles, the four wave totals
+// through LDS
+template <int PM>
+__global__ __launch_bounds__(256) void k_mg_scan(const MgArgs a) {
+    __shared__ int32_t wtot[4], wact[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0, act = 0;
+    for (int64_t base = 0; base < a.B; base += 1024) {
+        int n[4], mine = 0, alive = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t b = base + 4 * (int64_t)threadIdx.x + q;
+            const int mode = b < a.B ? (int)a.modes[b] : 2;
+            n[q] = mode == 0 ? a.P + 1 : (mode == 1 ? a.NP : 0);
+            mine += n[q];
+            alive += mode != 2;
+        }
+        int incl = mine, asum = alive;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+            asum += __shfl_xor(asum, off, 64);
+        }
+        if (lane == 63) wtot[wave] = incl;
+        if (lane == 0) wact[wave] = asum;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        int run = before + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t b = base + 4 * (int64_t)threadIdx.x + q;
+            if (b < a.B) a.first[b] = run;
+            run += n[q];
+        }
+        carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        act += wact[0] + wact[1] + wact[2] + wact[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.count[0] = carry;
+        a.count[1] = act;
+        if (carry > 0) {
+            a.count[2] += 1;
+            a.totals[0] += (unsigned long long)carry;
+        }
+    }
+}
+
+// the points trajectory b waits for, as items of the theta step (what the host rounds pack into rows / pd / po / mm / cc / yy / tt);
+// one thread per (trajectory, item slot): `per` = max(P + 1, NP) slots per trajectory
+template <int PM>
+__global__ void k_mg_fill(const MgArgs a, int per) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = tid / per;
+    const int j = (int)(tid - b * per);
+    if (b >= a.B) return;
+    const TrajD<PM> &t = ((const TrajD<PM> *)a.traj)[b];
+    if (t.mode == 2) return;
+    const int P = a.P, Pd = a.Pd, Po = a.Po, D = a.D, Din = a.Din, Y = a.Y, dq = a.dq;
+    const int n = t.mode == 0 ? P + 1 : a.NP;
+    if (j >= n) return;
+    const int64_t ld = a.th.ld;
+    const int64_t it = (int64_t)a.first[b] + j;
+    for (int i = 0; i < P; ++i) {
+        const double row = t.mode == 0 ? t.run.xt[i] + ((j == i + 1) ? a.fd_step : 0.0) : t.pts[(size_t)j * P + i];
+        const double e = exp(row);                         // the kernel parameters are exp(theta)
+        if (i < Pd) a.th.pard[(size_t)it * Pd + i] = e;
+        else a.th.paro[(size_t)it * Po + (i - Pd)] = e;
+    }
+    // [mean; q_mean], blockdiag(cov, Q) for dynamics that take their noise as an argument (ssinf.py:1174-1176)
+    double *m = a.th.mean + (size_t)it * Din, *c = a.th.cov + (size_t)it * Din * Din;
+    for (int i = 0; i < Din * Din; ++i) c[i] = 0.0;
+    for (int i = 0; i < D; ++i) {
+        m[i] = t.xm[i];
+        for (int k = 0; k < D; ++k) c[i * Din + k] = t.xP[i * D + k];
+    }
+    for (int i = 0; i < dq; ++i) {
+        m[D + i] = a.q_mean[i];
+        for (int k = 0; k < dq; ++k) c[(D + i) * Din + D + k] = a.q_cov[i * dq + k];
+    }
+    for (int k = 0; k < Y; ++k) a.th.ysoa[(size_t)k * ld + it] = a.y[((size_t)b * a.T + (t.k - 1)) * Y + k];
+    a.th.tt[it] = (double)t.k;
+}
+
+// PX: the parameter count at compile time (= PM), or 0 = a.P at run time.  With PX every loop of the optimiser has a constant trip
+// count: unrolled, its small arrays in registers - at run-time bounds they are indexed private memory and the kernel took
+// 40 us per round for 1 024 trajectories (a wave walks the union of its lanes' branches, a few thousand dependent instructions).
+template <int PM, int PX>
+__device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b);
+
+// sixteen trajectories per wave (every fourth lane): a wave walks the union of its lanes' branches, fewer lanes = fewer of them
+template <int PM, int PX>
+__global__ __launch_bounds__(64) void k_mg_advance(const MgArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 2);
+    if ((threadIdx.x & 3) != 0 || b >= a.B) return;
+    if (a.modes[b] == 2) return;
+    mg_advance_one<PM, PX>(a, b);
+    a.modes[b] = (signed char)((const TrajD<PM> *)a.traj)[b].mode;
+}
+
+template <int PM, int PX>
+__device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b) {
+    TrajD<PM> &t = ((TrajD<PM> *)a.traj)[b];
+    const int P = PX ? PX : a.P, D = a.D, NP = a.NP, T = a.T;
+    const int64_t ld = a.th.ld, f0 = a.first[b];
+    const double inf = __builtin_huge_val();
+    if (t.mode == 0) {
+        // The optimiser works on a LOCAL copy of its state (private memory: lane-interleaved and cached) and writes it back
+        // once: on the 3 KB-strided structs themselves every one of its few hundred dependent accesses was a cache miss of its
+        // own (38 us per round for 1 024 trajectories).
+        RunT<PM> run = t.run;
+        double vals[PM + 1];
+        for (int j = 0; j <= P; ++j) {
+            // log N(theta | prior) at the row as it was evaluated (ssinf.py:1200-1218)
+            double v[PM], q = 0.0;
+            for (int i = 0; i < P; ++i) {
+                const double th = run.xt[i] + ((j == i + 1) ? a.fd_step : 0.0);
+                double s = th - t.pm[i];
+                for (int k = 0; k < i; ++k) s -= t.Lp[i * P + k] * v[k];
+                v[i] = s / t.Lp[i * P + i];
+                q += v[i] * v[i];
+            }
+            const double lp = -0.5 * (q + t.logdet2 + P * log(2.0 * M_PI));
+            const double val = -a.th.ll[f0 + j] - lp;
+            vals[j] = __builtin_isfinite(val) ? val : inf;
+        }
+        bfgs_advance(run, P, a.fd_step, vals);
+        t.run = run;
+        if (run.phase != PH_DONE) return;
+        atomicAdd(&a.totals[1], (unsigned long long)run.k);
+        // Laplace posterior (ssinf.py:1272-1273) and its sigma points (:1103-1106)
+        double pcn[PM * PM], L[PM * PM];
+        bool fin = true;
+        for (int i = 0; i < P; ++i) {
+            t.pm[i] = run.x[i];
+            fin = fin && __builtin_isfinite(t.pm[i]);
+            for (int k = 0; k < P; ++k) {
+                pcn[i * P + k] = run.H[i * P + k] + (i == k ? a.param_jitter : 0.0);
+                fin = fin && __builtin_isfinite(pcn[i * P + k]);
+            }
+        }
+        if (!fin || !chol_lower(pcn, P, L, nullptr)) {
+            t.mode = 2;
+            a.failed[b] = why(t.k, fin ? WHY_LAPLACE_NOT_PD : WHY_LAPLACE_NOT_FINITE);
+            return;
+        }
+        for (int i = 0; i < P * P; ++i) t.pc[i] = pcn[i];
+        for (int j = 0; j < NP; ++j)
+            for (int i = 0; i < P; ++i) {
+                double s = t.pm[i];
+                for (int k = 0; k <= i; ++k) s += L[i * P + k] * a.upts[(size_t)k * NP + j];
+                t.pts[(size_t)j * P + i] = s;
+            }
+        t.mode = 1;
+    } else {
+        // mixture over the parameter points (ssinf.py:1108-1115): plain weighted sums of the conditional moments
+        bool ok = true;
+        for (int j = 0; j < NP; ++j) ok = ok && a.th.st_all[f0 + j] == 0;
+        const bool items_ok = ok;
+        double xm[SSMQ_MAX_DIM], xP[SSMQ_MAX_DIM * SSMQ_MAX_DIM];
+        for (int i = 0; i < D; ++i) xm[i] = 0.0;
+        for (int i = 0; i < D * D; ++i) xP[i] = 0.0;
+        for (int j = 0; j < NP; ++j) {
+            const int64_t it = f0 + j;
+            const double w = a.uwts[j];
+            for (int i = 0; i < D; ++i) xm[i] += a.th.m_fi[(size_t)i * ld + it] * w;
+            for (int i = 0; i < D * D; ++i) xP[i] += a.th.P_fi[(size_t)i * ld + it] * w;
+        }
+        for (int i = 0; i < D; ++i) ok = ok && __builtin_isfinite(xm[i]);
+        for (int i = 0; i < D * D; ++i) ok = ok && __builtin_isfinite(xP[i]);
+        if (!ok) {                               // where forward_pass raises LinAlgError for this trajectory
+            t.mode = 2;
+            a.failed[b] = why(t.k, items_ok ? WHY_MIXTURE_NOT_FINITE : WHY_MIXTURE_ITEM);
+            return;
+        }
+        for (int i = 0; i < D; ++i) {
+            t.xm[i] = xm[i];
+            a.fm[((size_t)b * T + (t.k - 1)) * D + i] = xm[i];
+        }
+        for (int i = 0; i < D * D; ++i) {
+            t.xP[i] = xP[i];
+            a.fP[((size_t)b * T + (t.k - 1)) * D * D + i] = xP[i];
+        }
+        if (t.k == T) {
+            t.mode = 2;
+        } else {
+            ++t.k;
+            mg_begin_step(t, a, b);
+        }
+    }
+}
+
+template <int PM>
+__global__ void k_mg_finish(const MgArgs a, double *theta_last, double *pcov_last) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const TrajD<PM> &t = ((const TrajD<PM> *)a.traj)[b];
+    for (int i = 0; i < a.P; ++i) theta_last[(size_t)b * a.P + i] = t.pm[i];
+    for (int i = 0; i < a.P * a.P; ++i) pcov_last[(size_t)b * a.P * a.P + i] = t.pc[i];
+}
+
+// Returns SSMQ_OK having produced everything, SSMQ_E_UNSUPPORTED if this shape has no device-resident route (the caller then runs
+// the host rounds), or an error.
+template <int PM, int PX>
+int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs, const ssmq_integrand *f_obs,
+                                 int64_t B, int T, double jitter, const double *y, const double *x0_mean, const double *x0_cov,
+                                 const double *q_mean, const double *q_cov, const double *GQG, const double *R, const double *prior_mean,
+                                 const double *prior_cov, const double *upts, const double *uwts, int NP, double fd_step,
+                                 double param_jitter, double *fm, double *fP, int32_t *failed, double *theta_last, double *pcov_last,
+                                 int64_t *stats) {
+    const int Din = h_dyn->D, D = h_dyn->E, Y = h_obs->E, dq = Din - D;
+    const int Pd = Din + 1, Po = h_obs->D + 1, P = Pd + Po;
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = stream();
+    const int per = std::max(P + 1, NP);
+    const int64_t cap = B * per;
+    if (cap > 0x7fffffff / 2) return SSMQ_E_UNSUPPORTED;
+    // one arena: theta step | trajectory states | offsets and counters | inputs | outputs
+    auto al = [](size_t n) { return (n + 255) / 256 * 256; };
+    const size_t th_bytes = theta_dev_bytes(h_dyn, h_obs, cap);
+    const size_t n_fm = (size_t)B * T * D, n_fP = (size_t)B * T * D * D;
+    const size_t statics = (size_t)D + (size_t)D * D + P + (size_t)P * P + dq + (size_t)dq * dq + (size_t)P * NP + NP;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
+    const size_t o_th = take(th_bytes), o_tr = take(sizeof(TrajD<PM>) * (size_t)B), o_first = take(sizeof(int32_t) * (size_t)B), o_modes = take((size_t)B),
+                 o_count = take(sizeof(int32_t) * 4), o_tot = take(sizeof(unsigned long long) * 2), o_y = take(sizeof(double) * (size_t)B * T * Y),
+                 o_st = take(sizeof(double) * statics), o_fm = take(sizeof(double) * n_fm), o_fP = take(sizeof(double) * n_fP),
+                 o_failed = take(sizeof(int32_t) * (size_t)B), o_tl = take(sizeof(double) * (size_t)B * P),
+                 o_pl = take(sizeof(double) * (size_t)B * P * P);
+    char *dev = nullptr;
+    SSMQ_HIP(hipMalloc((void **)&dev, off));
+    struct Free { char *p; ~Free() { if (p) hipFree(p); } } guard{dev};
+    MgArgs a;
+    memset(&a, 0, sizeof(a));
+    theta_dev_carve(a.th, h_dyn, h_obs, cap, dev + o_th);
+    a.traj = dev + o_tr; a.B = B; a.T = T; a.P = P; a.Pd = Pd; a.Po = Po; a.NP = NP; a.D = D; a.Din = Din; a.Y = Y; a.dq = dq;
+    a.first = (int32_t *)(dev + o_first); a.modes = (signed char *)(dev + o_modes); a.count = (int32_t *)(dev + o_count); a.totals = (unsigned long long *)(dev + o_tot);
+    a.y = (const double *)(dev + o_y);
+    a.fd_step = fd_step; a.param_jitter = param_jitter;
+    a.fm = (double *)(dev + o_fm); a.fP = (double *)(dev + o_fP); a.failed = (int32_t *)(dev + o_failed);
+    // what the trajectories share: one host block, one copy
+    std::vector<double> hs(statics);
+    {
+        double *h = hs.data(), *d = (double *)(dev + o_st);
+        auto put = [&](const double *src, size_t n, const double **dst) {
+            if (n) std::memcpy(h, src, sizeof(double) * n);
+            *dst = d;
+            h += n; d += n;
+        };
+        put(x0_mean, D, &a.x0_mean); put(x0_cov, (size_t)D * D, &a.x0_cov); put(prior_mean, P, &a.prior_mean);
+        put(prior_cov, (size_t)P * P, &a.prior_cov); put(q_mean, dq, &a.q_mean); put(q_cov, (size_t)dq * dq, &a.q_cov);
+        put(upts, (size_t)P * NP, &a.upts); put(uwts, NP, &a.uwts);
+    }
+    SSMQ_HIP(hipMemcpyAsync(dev + o_st, hs.data(), sizeof(double) * statics, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemcpyAsync(dev + o_y, y, sizeof(double) * (size_t)B * T * Y, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipMemsetAsync(dev + o_count, 0, sizeof(int32_t) * 4, s));
+    SSMQ_HIP(hipMemsetAsync(dev + o_tot, 0, sizeof(unsigned long long) * 2, s));
+    SSMQ_HIP(hipMemsetAsync(dev + o_fm, 0xff, sizeof(double) * (n_fm + 0), s));      // all-ones bit pattern: a NaN
+    SSMQ_HIP(hipMemsetAsync(dev + o_fP, 0xff, sizeof(double) * n_fP, s));
+    if ((rc = theta_dev_upload_static(a.th, h_dyn, h_obs, GQG, R, s))) return rc;
+    const unsigned tb = 64, tg = (unsigned)((B + tb - 1) / tb);
+    hipLaunchKernelGGL(k_mg_init<PM>, dim3(tg), dim3(tb), 0, s, a);
+    int64_t active = B;
+    int32_t hc[4] = {0, 0, 0, 0};
+    while (active > 0) {
+        const int64_t bound = active * per;                 // no trajectory comes back: an upper bound for the coming rounds
+        for (int r = 0; r < kRoundsPerCheck; ++r) {
+            hipLaunchKernelGGL(k_mg_scan<PM>, dim3(1), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_mg_fill<PM>, dim3((unsigned)((B * per + 255) / 256)), dim3(256), 0, s, a, per);
+            if ((rc = theta_dev_enqueue(a.th, h_dyn, f_dyn, h_obs, f_obs, jitter, bound, a.count, s))) return rc;
+            hipLaunchKernelGGL((k_mg_advance<PM, PX>), dim3((unsigned)((B + 15) / 16)), dim3(64), 0, s, a);
+        }
+        if ((rc = hip_fail(hipGetLastError(), "marginal filter: device rounds"))) return rc;
+        SSMQ_HIP(hipMemcpyAsync(hc, a.count, sizeof(hc), hipMemcpyDeviceToHost, s));
+        SSMQ_HIP(hipStreamSynchronize(s));
+        // count[1] is what the LAST scan saw, before that round's advance: one more scan settles it once it is small
+        if (hc[1] == 0) break;
+        active = hc[1];
+    }
+    hipLaunchKernelGGL(k_mg_finish<PM>, dim3(tg), dim3(tb), 0, s, a, (double *)(dev + o_tl), (double *)(dev + o_pl));
+    SSMQ_HIP(hipMemcpyAsync(fm, a.fm, sizeof(double) * n_fm, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(fP, a.fP, sizeof(double) * n_fP, hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(failed, a.failed, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    if (theta_last) SSMQ_HIP(hipMemcpyAsync(theta_last, dev + o_tl, sizeof(double) * (size_t)B * P, hipMemcpyDeviceToHost, s));
+    if (pcov_last) SSMQ_HIP(hipMemcpyAsync(pcov_last, dev + o_pl, sizeof(double) * (size_t)B * P * P, hipMemcpyDeviceToHost, s));
+    unsigned long long tot[2] = {0, 0};
+    SSMQ_HIP(hipMemcpyAsync(hc, a.count, sizeof(hc), hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipMemcpyAsync(tot, a.totals, sizeof(tot), hipMemcpyDeviceToHost, s));
+    SSMQ_HIP(hipStreamSynchronize(s));
+    if (stats) {
+        stats[0] = hc[2]; stats[1] = (int64_t)tot[1]; stats[2] = (int64_t)tot[0];
+    }
+    return SSMQ_OK;
+}
+
 }  // namespace
 
 extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
@@ -328,6 +693,18 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
     }
     if (stats) stats[0] = stats[1] = stats[2] = 0;
     if (B == 0 || T == 0) return SSMQ_OK;
+    // the state machines on the device where the theta step has its two-launch route and the parameter count an instantiation
+    // (SSMQ_MARGINAL_HOST_ROUNDS=1: the host rounds below, round 4's route, kept as the second implementation of the same filter)
+    if (!getenv("SSMQ_MARGINAL_HOST_ROUNDS") && P <= 16 && NP <= 32 && theta_dev_supported(h_dyn, f_dyn, h_obs, f_obs)) {
+#define SSMQ_MG_DEV(PM, PX) marginal_filter_batch_device<PM, PX>(h_dyn, f_dyn, h_obs, f_obs, B, T, jitter, y, x0_mean, x0_cov, q_mean, q_cov, GQG, R, \
+                                                              prior_mean, prior_cov, upts, uwts, NP, fd_step, param_jitter, fm, fP, failed,      \
+                                                              theta_last, pcov_last, stats)
+        // (P = D + Din + 2: 4 scalar state, 5 scalar state with its noise as an argument, 6 / 8 two / three states)
+        const int rc = P == 4 ? SSMQ_MG_DEV(4, 4) : P == 5 ? SSMQ_MG_DEV(5, 5) : P == 6 ? SSMQ_MG_DEV(6, 6) : P == 8 ? SSMQ_MG_DEV(8, 8)
+                                                                                                       : SSMQ_MG_DEV(16, 0);
+#undef SSMQ_MG_DEV
+        if (rc != SSMQ_E_UNSUPPORTED) return rc;
+    }
     const double nan = std::numeric_limits<double>::quiet_NaN();
     std::vector<Traj> tr((size_t)B);
     for (int64_t i = 0; i < (int64_t)B * T * D; ++i) fm[i] = nan;
@@ -335,7 +712,7 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
     auto begin_step = [&](Traj &t, int64_t b) {        // the Laplace step of time step t.k starts from the prior (t.pm, t.pc)
         if (!chol_lower(t.pc, P, t.Lp, &t.logdet2)) {  // numpy.linalg.cholesky would raise in _param_log_prior
             t.mode = 2;
-            failed[b] = t.k;
+            failed[b] = why(t.k, WHY_PRIOR_NOT_PD);
             return;
         }
         bfgs_start(t.run, P, t.pm);
@@ -455,7 +832,7 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
                 }
                 if (!fin || !chol_lower(pcn, P, L, nullptr)) {
                     t.mode = 2;
-                    failed[b] = t.k;
+                    failed[b] = why(t.k, fin ? WHY_LAPLACE_NOT_PD : WHY_LAPLACE_NOT_FINITE);
                     continue;
                 }
                 std::memcpy(t.pc, pcn, sizeof(double) * P * P);
@@ -470,6 +847,7 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
                 // mixture over the parameter points (ssinf.py:1108-1115): plain weighted sums of the conditional moments
                 bool ok = true;
                 for (int j = 0; j < NP; ++j) ok = ok && st[(size_t)(first[w] + j)] == 0;
+                const bool items_ok = ok;
                 double xm[SSMQ_MAX_DIM], xP[SSMQ_MAX_DIM * SSMQ_MAX_DIM];
                 for (int i = 0; i < D; ++i) xm[i] = 0.0;
                 for (int i = 0; i < D * D; ++i) xP[i] = 0.0;
@@ -482,7 +860,7 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
                 for (int i = 0; i < D * D; ++i) ok = ok && std::isfinite(xP[i]);
                 if (!ok) {                               // where forward_pass raises LinAlgError for this trajectory
                     t.mode = 2;
-                    failed[b] = t.k;
+                    failed[b] = why(t.k, items_ok ? WHY_MIXTURE_NOT_FINITE : WHY_MIXTURE_ITEM);
                     continue;
                 }
                 std::memcpy(t.xm, xm, sizeof(double) * D);

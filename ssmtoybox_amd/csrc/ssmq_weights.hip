@@ -1390,6 +1390,8 @@ struct ThetaWgtArgs {
     WgtArgs w[2];
     double *consts[2];
     int32_t E[2];
+    const int32_t *count;      // null, or the number of items on the device (the grid then covers an upper bound): the
+                               // device-resident rounds of the batched marginalised filter (ssmq_marginal.hip)
 };
 
 static size_t theta_weights_lds_doubles(int D, int N) {
@@ -1399,6 +1401,7 @@ static size_t theta_weights_lds_doubles(int D, int N) {
 
 __global__ __launch_bounds__(256) void k_theta_weights(const ThetaWgtArgs t) {
     extern __shared__ __align__(16) double lds[];
+    if (t.count && (int)blockIdx.x >= *t.count) return;      // (whole workgroup: before any barrier)
     const bool second = blockIdx.y != 0;
     const WgtArgs a = second ? t.w[1] : t.w[0];
     double *consts = second ? t.consts[1] : t.consts[0];
@@ -1442,10 +1445,11 @@ bool gp_theta_weights_fits(int D0, int N0, int D1, int N1) {
 // constant blocks d_consts[i] [P][wide_layout(D, E, N, BQ).total], flags d_status[i] [P].  Enqueued, nothing allocated.
 int gp_theta_weights_pair(const int D[2], const int E[2], const int N[2], const double *const d_xi[2],
                           const double *const d_par[2], int P, double jitter, double *const d_consts[2],
-                          int32_t *const d_status[2]) {
+                          int32_t *const d_status[2], const int32_t *d_count) {
     hipStream_t s = stream();
     ThetaWgtArgs t;
     memset(&t, 0, sizeof(t));
+    t.count = d_count;
     size_t lds = 0;
     int threads = 64;
     for (int i = 0; i < 2; ++i) {

@@ -669,9 +669,12 @@ class MarginalInference(GaussianInference):
             int(self.param_pts_num), float(self.fd_step), float(self.param_jitter[0, 0]), dp(fm), dp(fP),
             failed.ctypes.data_as(_lib.c_int32_p), dp(th), dp(pcl), stats), 'ssmq_gp_marginal_filter_batch')
         del keep
-        self.batch_failed = failed.astype(np.int64)
+        self.batch_failed = (failed & 0xffff).astype(np.int64) if T < 65536 else failed.astype(np.int64)
+        # why (include/ssmq.h): 1 prior not PD, 2 / 3 Laplace covariance not finite / not PD, 4 a mixture point's step failed, 5 mixture not finite
+        self.batch_failed_reason = (failed >> 16).astype(np.int64) if T < 65536 else np.zeros(B, dtype=np.int64)
         self.batch_stats = dict(rounds=int(stats[0]), iterations=int(stats[1]), items=int(stats[2]), fallbacks=0)
         self.param_mean, self.param_cov = th[-1], pcl[-1]
+        self.batch_param_mean, self.batch_param_cov = th, pcl      # every trajectory's last parameter posterior (B, P), (B, P, P)
         self.fi_mean = np.ascontiguousarray(fm.transpose(2, 1, 0))
         self.fi_cov = np.ascontiguousarray(fP.transpose(2, 3, 1, 0))
         if B and T and not failed[-1]:

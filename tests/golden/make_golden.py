@@ -698,6 +698,44 @@ class _RecordingMarginal(ssinf.MarginalizedGaussianProcessKalman):
         self.rec.append((self.param_mean.copy(), self.param_cov.copy()))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G14: what the REFERENCE's marginalised filter does on the measurement sequences on which the build's batched filter reports
+# failed trajectories (bench.py's UNGM batch: simulate_ungm(1024, 10, seed 5)) - and on a few it completes
+# ---------------------------------------------------------------------------------------------------------------
+def g14_marginal_failures():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from benchlib.workloads import simulate_ungm
+    _, y = simulate_ungm(1024, 10, 5)                       # (T, B)
+    # 373: fails in every route of the build (a parameter sigma point whose kernel matrix is not positive definite);
+    # 770 / 400 / 903 / 547 / 556: failed in ONE of the build's routes (device rounds / host rounds, round 5) and in no other;
+    # 0, 1, 2, 5: complete everywhere
+    idx = np.array([373, 770, 400, 903, 547, 556, 0, 1, 2, 5])
+    T = y.shape[0]
+    raised = np.zeros(idx.size, dtype=np.int64)            # step at which forward_pass's loop raises, 0 = completes
+    kind = []
+    fm = np.full((idx.size, T), np.nan)
+    fc = np.full((idx.size, T), np.nan)
+    tm = np.full((idx.size, T, 4), np.nan)
+    for i, b in enumerate(idx):
+        dyn = ssmod.UNGMTransition(GaussRV(1, cov=np.atleast_2d(1.0)), GaussRV(1, cov=np.atleast_2d(10.0)))
+        obs = ssmod.UNGMMeasurement(GaussRV(1, cov=np.atleast_2d(1.0)), 1)
+        alg = ssinf.MarginalizedGaussianProcessKalman(dyn, obs, 'rbf', 'sr')
+        what = ''
+        for kk in range(1, T + 1):                          # StateSpaceInference.forward_pass (ssinf.py:101-112)
+            try:
+                alg._time_update(kk - 1)
+                alg._measurement_update(y[kk - 1, b:b + 1], kk)
+            except Exception as e:                          # noqa: BLE001 - the exception type is the finding
+                raised[i] = kk
+                what = type(e).__name__ + ': ' + str(e)[:80]
+                break
+            fm[i, kk - 1], fc[i, kk - 1] = alg.x_mean_fi[0], alg.x_cov_fi[0, 0]
+            tm[i, kk - 1] = alg.param_mean
+        kind.append(what)
+        print('g14: trajectory', b, 'raised at step' if raised[i] else 'completed', raised[i] or '', what)
+    save('g14_marginal_failures', idx=idx, y=y[:, idx], raised=raised, kind=np.array(kind), fm=fm, fc=fc, tm=tm)
+
+
 def g11_marginal_smoother():
     out = {}
     rng = np.random.default_rng(11)
@@ -925,7 +963,7 @@ def g13_linear():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14']
     if 'g13' in which:
         g13_linear()
     if 'g1' in which:
@@ -950,5 +988,7 @@ if __name__ == '__main__':
         g10_referee()
     if 'g11' in which:
         g11_marginal_smoother()
+    if 'g14' in which:
+        g14_marginal_failures()
     if 'g12' in which:
         g12_large_weights()
