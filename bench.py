@@ -32,6 +32,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+SETTLE_S = 0.06          # continuous untimed passes before the warm-up passes (clock ramp-up after the idle set-up)
 
 from benchlib.common import (HBM_PEAK_GBS, CLOCK_HZ, F64_MFMA_PEAK_TF, pmc_traffic, pmc_traffic_named, pmc_issue,     # noqa: E402,F401
                              issue_block, settle, timed_passes, cpu_port_info, host_cores, c_port_transforms,
@@ -104,6 +105,11 @@ def main():
             raise SystemExit('bench.py: --total-batch {} leaves rank {} of {} without trajectories'.format(
                 args.total_batch, rank, world))
     wl = FilterBench(amd, B, T, seed=1 + rank, workload=args.workload, filt=args.filter)
+    # The device has idled through the set-up above (uploads, weights, host-side simulation) and needs ~50 ms of continuous work
+    # before its clocks are back up (tools/thermal_check.py): at the driver's --warmup 5 --steps 20 the contract's 0.65 ms region
+    # otherwise starts on a device that is still ramping (34.4 us per pass against 32.9 for the blocks timed right after it).
+    # Untimed, before the W warm-up passes, and said in the record (config.settle_s).
+    settle(wl.step, _lib.sync, SETTLE_S)
     for _ in range(args.warmup):
         wl.step()
     comm.barrier()                      # common start: device synchronisation + barrier on every rank
@@ -147,6 +153,7 @@ def main():
                        '{} on {} (D={}, Y={}), {} MC trajectories per GPU x T={}'.format(args.filter, args.workload, wl.D,
                                                                                        wl.Y, B, T),
                        'mc_per_gpu': B, 'mc_total': b_total, 'time_steps': T, 'parallelism': 'mc-shard x{}'.format(world),
+                       'settle_s': SETTLE_S,
                        'per_rank_kernel_ms': [float(v) for v in slot[:world]],
                        'per_rank_trajectories': [int(round(v)) for v in slot[world:]],
                        'allreduce_us': allreduce_us, 'allreduce_bytes': 8 * n_packed,

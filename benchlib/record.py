@@ -52,7 +52,7 @@ def compact_record(detail):
     out = {k: _num(detail.get(k), 10) for k in CONTRACT_KEYS if k in detail}
     cfg = detail.get('config', {})
     out['config'] = {k: _num(cfg[k]) for k in ('workload', 'mc_per_gpu', 'mc_total', 'time_steps', 'parallelism', 'collective',
-                                               'allreduce_us', 'allreduce_bytes', 'launcher', 'devices', 'distinct_devices',
+                                               'allreduce_us', 'allreduce_bytes', 'settle_s', 'launcher', 'devices', 'distinct_devices',
                                                'comm_world') if k in cfg}
     for k, v in out['config'].items():
         if isinstance(v, str) and len(v) > 200:

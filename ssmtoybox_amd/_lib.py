@@ -263,6 +263,8 @@ def device_count():
 
 
 def set_device(dev):
+    if '_scratch_pool' in globals():
+        _scratch_pool.flush()         # blocks of the device the library is leaving
     check(load().ssmq_set_device(int(dev)), 'ssmq_set_device')
 
 
@@ -329,6 +331,68 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class _ScratchPool:
+    """Device blocks handed back by the batch entry points, kept for the next call: hipFree synchronises the device and unmaps
+    (1.1 ms for the six buffers of a forward_pass_batch at B = 1e4, T = 100 - half of that call, tools/api_breakdown.py).  At
+    most `limit` bytes are kept; a block serves requests between half its size and its size.  Flushed when the library moves to
+    another device."""
+    limit = 4 << 30
+
+    def __init__(self):
+        self.blocks = []          # (capacity, ptr), oldest first
+        self.cached = 0
+
+    def take(self, nbytes):
+        best = None
+        for i, (cap, ptr) in enumerate(self.blocks):
+            if nbytes <= cap <= 2 * nbytes + 4096 and (best is None or cap < self.blocks[best][0]):
+                best = i
+        if best is None:
+            return None
+        cap, ptr = self.blocks.pop(best)
+        self.cached -= cap
+        return cap, ptr
+
+    def give(self, cap, ptr):
+        self.blocks.append((cap, ptr))
+        self.cached += cap
+        while self.cached > self.limit and self.blocks:
+            c, p = self.blocks.pop(0)
+            self.cached -= c
+            load().ssmq_free(ctypes.c_void_p(p))
+
+    def flush(self):
+        for c, p in self.blocks:
+            load().ssmq_free(ctypes.c_void_p(p))
+        self.blocks, self.cached = [], 0
+
+
+_scratch_pool = _ScratchPool()
+
+
+class ScratchBuffer(DeviceBuffer):
+    """A DeviceBuffer whose free() returns the block to the pool instead of the driver (contents are undefined on reuse, as
+    they are after hipMalloc)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        got = _scratch_pool.take(max(self.nbytes, 8))
+        if got is None:
+            DeviceBuffer.__init__(self, nbytes)
+            self.capacity = max(self.nbytes, 8)
+        else:
+            self.capacity, self.ptr = got
+
+    def free(self):
+        if self.ptr:
+            _scratch_pool.give(self.capacity, self.ptr)
+            self.ptr = None
+
+
+def scratch(nbytes):
+    return ScratchBuffer(nbytes)
 
 
 def upload_study(arr, n_elem, ld, dst):

@@ -172,7 +172,7 @@ class GaussianInference:
         ld = (B + 63) // 64 * 64
         # (dim_y, T, B) -> planes [T][Y][ld]: a row permutation, done between the caller's array and the library's pinned
         # staging block (`ssmq_upload_planes`)
-        d_y = _lib.DeviceBuffer(8 * T * Y * ld)
+        d_y = _lib.scratch(8 * T * Y * ld)
         _lib.upload_study(data, Y, ld, d_y)
         m0 = np.broadcast_to(self.x0_mean, (B, D)) if x0_mean is None else np.asarray(x0_mean, dtype=np.float64)
         P0 = np.broadcast_to(self._initial_cov(), (B, D, D)) if x0_cov is None else np.asarray(x0_cov, dtype=np.float64)
@@ -182,16 +182,16 @@ class GaussianInference:
         Pbuf[:, :B] = P0.reshape(B, D * D).T
         if ld > B:       # padding lanes are never read (b >= B), keep them PD anyway
             Pbuf[:, B:] = np.eye(D).reshape(-1, 1)
-        d_m0, d_P0 = _lib.DeviceBuffer(mbuf.nbytes), _lib.DeviceBuffer(Pbuf.nbytes)
+        d_m0, d_P0 = _lib.scratch(mbuf.nbytes), _lib.scratch(Pbuf.nbytes)
         d_m0.upload(mbuf)
         d_P0.upload(Pbuf)
-        d_fm, d_fP = _lib.DeviceBuffer(8 * T * D * ld), _lib.DeviceBuffer(8 * T * D * D * ld)
-        d_st = _lib.DeviceBuffer(4 * ld)
+        d_fm, d_fP = _lib.scratch(8 * T * D * ld), _lib.scratch(8 * T * D * D * ld)
+        d_st = _lib.scratch(4 * ld)
         f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
         f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
         h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
         if smooth:
-            d_sm, d_sP = _lib.DeviceBuffer(8 * T * D * ld), _lib.DeviceBuffer(8 * T * D * D * ld)
+            d_sm, d_sP = _lib.scratch(8 * T * D * ld), _lib.scratch(8 * T * D * D * ld)
             if not self._additive:
                 self._launch_aug(lib, h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, d_fm, d_fP, d_st, d_sm, d_sP)
             else:

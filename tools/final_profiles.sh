@@ -2,11 +2,11 @@
 # Produces the artefacts committed under profiles/: bench JSON, rocprofv3 kernel stats of the same command, PMC traffic.
 set -e
 export TMPDIR=/tmp
-tag=${1:-r04_final}
+tag=${1:-r05_final}
 out=gpurun_out/$tag
 mkdir -p $out
-python bench.py > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline > $out/bench_prof.json 2> $out/bench_prof.err
+python bench.py --detail $out/bench_detail.json > $out/bench.json 2> $out/bench.err      # bench.json: the result line (what the driver keeps)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline --detail $out/bench_prof_detail.json > $out/bench_prof.json 2> $out/bench_prof.err
 bash profiles/collect_pmc.sh $out/pmc > $out/pmc.log 2>&1
 bash tools/pmc_fused.sh $out/pmc_fused > $out/pmc_fused.log 2>&1
 python profiles/pmc_summary.py $out/pmc > $out/pmc_traffic.json
@@ -25,6 +25,12 @@ with open(out + '/kernel_stats_by_grid.csv', 'w') as f:
     for (name, grid), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
         f.write('"%s",%d,%d,%.1f,%d,%d\n' % (name, grid, len(v), sum(v) / len(v), min(v), max(v)))
 PY
-cat $out/bench.json
+tail -1 $out/bench.json
 head -8 $out/kernel_stats.csv | cut -c1-160
 cat $out/pmc_traffic.json
+# performance gate against the previous round's trace (profiles/r04_h_bench_kernel_stats_by_grid.csv), as a markdown table
+prev=$(ls profiles/r04_h_bench_kernel_stats_by_grid.csv 2>/dev/null | tail -1)
+if [ -n "$prev" ]; then
+    python3 tools/perf_gate.py "$prev" $out/kernel_stats_by_grid.csv --markdown --matched-only > $out/perf_gate.md 2> $out/perf_gate.err || echo "perf_gate: REGRESSION (see $out/perf_gate.err)"
+    cat $out/perf_gate.err
+fi

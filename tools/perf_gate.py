@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--alias', action='append', default=[], help='OLD=NEW substring replacement applied to names of the old file')
     ap.add_argument('--allow', action='append', default=[], help='substring of a kernel name whose slowdown is accepted (say why in profiles/README.md)')
     ap.add_argument('--markdown', action='store_true')
+    ap.add_argument('--matched-only', action='store_true', help='leave out the pairs present in only one file')
     a = ap.parse_args()
     aliases = [tuple(s.split('=', 1)) for s in a.alias]
     rows, bad = compare(load(a.old), load(a.new), a.tolerance, a.min_us, aliases)
@@ -78,6 +79,8 @@ def main():
         print('| kernel | grid | old us | new us | new / old | |')
         print('|---|---|---|---|---|---|')
     for name, grid, o, n, ratio, verdict in rows:
+        if a.matched_only and ratio is None:
+            continue
         f = lambda v, fmt='%.1f': '-' if v is None else fmt % v      # noqa: E731
         if a.markdown:
             print('| `{}` | {} | {} | {} | {} | {} |'.format(short(name), grid, f(o), f(n), f(ratio, '%.3f'), verdict))
