@@ -314,7 +314,7 @@ struct Traj {
 // waiting for straight into the theta step's device arena (k_mg_scan: item offsets by a block-wide scan; k_mg_fill), the theta
 // step runs on them with the item count read from device memory (theta_dev_enqueue: k_theta_weights, k_theta_chain), and the same
 // thread takes the values and advances its optimiser / mixture / time step (k_mg_advance: bfgs_advance of ssmq_bfgs.h, the code the
-// host rounds run).  The host only queues rounds - five launches each, no copy, no synchronisation - and every kRoundsPerCheck
+// host rounds run).  The host only queues rounds - four or five launches each, no copy, no synchronisation - and every kRoundsPerCheck
 // rounds reads ONE integer back: the number of unfinished trajectories, which is also the bound of the next launches' grids.
 // Round 4's host rounds cost ~85 us each (55 us of which copies, synchronisation and host turn-around: DESIGN.md 3.13) and
 // the number of rounds is set by the ONE longest trajectory.
@@ -424,19 +424,71 @@ __global__ __launch_bounds__(256) void k_mg_scan(const MgArgs a) {
 
 // the points trajectory b waits for, as items of the theta step (what the host rounds pack into rows / pd / po / mm / cc / yy / tt);
 // one thread per (trajectory, item slot): `per` = max(P + 1, NP) slots per trajectory
-template <int PM>
-__global__ void k_mg_fill(const MgArgs a, int per) {
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t b = tid / per;
-    const int j = (int)(tid - b * per);
-    if (b >= a.B) return;
+// SCAN: the item offsets are formed HERE, by every workgroup for its own trajectories (256 / per of them) from the compact mode
+// mirror - a sweep over B bytes per workgroup instead of a kernel of its own (k_mg_scan: 4.4 us + a launch gap per round); used
+// while that sweep is short (B <= 8 192).  Workgroup 0 also leaves the round's item and trajectory counts.
+template <int PM, bool SCAN>
+__global__ __launch_bounds__(256) void k_mg_fill(const MgArgs a, int per) {
+    int64_t b;
+    int j;
+    int32_t first_b = 0;
+    if constexpr (SCAN) {
+        __shared__ int32_t red[3][4], nloc[64];
+        const int tpb = 256 / per;                                  // trajectories of this workgroup (per <= 32: >= 8)
+        const int lb = threadIdx.x / per;
+        j = threadIdx.x - lb * per;
+        const int64_t b_first = (int64_t)blockIdx.x * tpb;
+        b = b_first + lb;
+        int pre = 0, tot = 0, act = 0;
+        for (int64_t i = threadIdx.x; i < a.B; i += 256) {
+            const int mode = (int)a.modes[i];
+            const int n = mode == 0 ? a.P + 1 : (mode == 1 ? a.NP : 0);
+            tot += n;
+            act += mode != 2;
+            if (i < b_first) pre += n;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            pre += __shfl_xor(pre, off, 64);
+            tot += __shfl_xor(tot, off, 64);
+            act += __shfl_xor(act, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6] = pre; red[1][threadIdx.x >> 6] = tot; red[2][threadIdx.x >> 6] = act;
+        }
+        if (threadIdx.x < 64) {
+            const int64_t bb = b_first + threadIdx.x;
+            const int mode = (threadIdx.x < tpb && bb < a.B) ? (int)a.modes[bb] : 2;
+            nloc[threadIdx.x] = mode == 0 ? a.P + 1 : (mode == 1 ? a.NP : 0);
+        }
+        __syncthreads();
+        first_b = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        for (int l = 0; l < lb && l < tpb; ++l) first_b += nloc[l];
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const int total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            a.count[0] = total;
+            a.count[1] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+            if (total > 0) {
+                a.count[2] += 1;
+                a.totals[0] += (unsigned long long)total;
+            }
+        }
+        if (lb >= tpb || b >= a.B) return;
+        if (j == 0) a.first[b] = first_b;
+    } else {
+        const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        b = tid / per;
+        j = (int)(tid - b * per);
+        if (b >= a.B) return;
+        first_b = a.first[b];
+    }
     const TrajD<PM> &t = ((const TrajD<PM> *)a.traj)[b];
     if (t.mode == 2) return;
     const int P = a.P, Pd = a.Pd, Po = a.Po, D = a.D, Din = a.Din, Y = a.Y, dq = a.dq;
     const int n = t.mode == 0 ? P + 1 : a.NP;
     if (j >= n) return;
     const int64_t ld = a.th.ld;
-    const int64_t it = (int64_t)a.first[b] + j;
+    const int64_t it = (int64_t)first_b + j;
     for (int i = 0; i < P; ++i) {
         const double row = t.mode == 0 ? t.run.xt[i] + ((j == i + 1) ? a.fd_step : 0.0) : t.pts[(size_t)j * P + i];
         const double e = exp(row);                         // the kernel parameters are exp(theta)
@@ -464,11 +516,16 @@ __global__ void k_mg_fill(const MgArgs a, int per) {
 template <int PM, int PX>
 __device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b);
 
-// sixteen trajectories per wave (every fourth lane): a wave walks the union of its lanes' branches, fewer lanes = fewer of them
+// kAdvPerWave trajectories per wave (every (64 / kAdvPerWave)-th lane): a wave walks the union of its lanes' branches, fewer
+// lanes = fewer of them
+#ifndef SSMQ_MG_ADV_PER_WAVE
+#define SSMQ_MG_ADV_PER_WAVE 8
+#endif
+constexpr int kAdvPerWave = SSMQ_MG_ADV_PER_WAVE;
 template <int PM, int PX>
 __global__ __launch_bounds__(64) void k_mg_advance(const MgArgs a) {
-    const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 2);
-    if ((threadIdx.x & 3) != 0 || b >= a.B) return;
+    const int64_t b = (int64_t)blockIdx.x * kAdvPerWave + threadIdx.x / (64 / kAdvPerWave);
+    if (threadIdx.x % (64 / kAdvPerWave) != 0 || b >= a.B) return;
     if (a.modes[b] == 2) return;
     mg_advance_one<PM, PX>(a, b);
     a.modes[b] = (signed char)((const TrajD<PM> *)a.traj)[b].mode;
@@ -639,13 +696,19 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
     hipLaunchKernelGGL(k_mg_init<PM>, dim3(tg), dim3(tb), 0, s, a);
     int64_t active = B;
     int32_t hc[4] = {0, 0, 0, 0};
+    const bool fused_scan = B <= 8192 && per <= 32 && !getenv("SSMQ_MARGINAL_SCAN_KERNEL");
+    const int64_t tpb_fill = 256 / per;
     while (active > 0) {
         const int64_t bound = active * per;                 // no trajectory comes back: an upper bound for the coming rounds
         for (int r = 0; r < kRoundsPerCheck; ++r) {
-            hipLaunchKernelGGL(k_mg_scan<PM>, dim3(1), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(k_mg_fill<PM>, dim3((unsigned)((B * per + 255) / 256)), dim3(256), 0, s, a, per);
+            if (fused_scan) {
+                hipLaunchKernelGGL((k_mg_fill<PM, true>), dim3((unsigned)((B + tpb_fill - 1) / tpb_fill)), dim3(256), 0, s, a, per);
+            } else {
+                hipLaunchKernelGGL(k_mg_scan<PM>, dim3(1), dim3(256), 0, s, a);
+                hipLaunchKernelGGL((k_mg_fill<PM, false>), dim3((unsigned)((B * per + 255) / 256)), dim3(256), 0, s, a, per);
+            }
             if ((rc = theta_dev_enqueue(a.th, h_dyn, f_dyn, h_obs, f_obs, jitter, bound, a.count, s))) return rc;
-            hipLaunchKernelGGL((k_mg_advance<PM, PX>), dim3((unsigned)((B + 15) / 16)), dim3(64), 0, s, a);
+            hipLaunchKernelGGL((k_mg_advance<PM, PX>), dim3((unsigned)((B + kAdvPerWave - 1) / kAdvPerWave)), dim3(64), 0, s, a);
         }
         if ((rc = hip_fail(hipGetLastError(), "marginal filter: device rounds"))) return rc;
         SSMQ_HIP(hipMemcpyAsync(hc, a.count, sizeof(hc), hipMemcpyDeviceToHost, s));
