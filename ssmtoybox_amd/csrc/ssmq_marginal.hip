@@ -314,11 +314,12 @@ struct Traj {
 // waiting for straight into the theta step's device arena (k_mg_scan: item offsets by a block-wide scan; k_mg_fill), the theta
 // step runs on them with the item count read from device memory (theta_dev_enqueue: k_theta_weights, k_theta_chain), and the same
 // thread takes the values and advances its optimiser / mixture / time step (k_mg_advance: bfgs_advance of ssmq_bfgs.h, the code the
-// host rounds run).  The host only queues rounds - four or five launches each, no copy, no synchronisation - and every kRoundsPerCheck
-// rounds reads ONE integer back: the number of unfinished trajectories, which is also the bound of the next launches' grids.
+// host rounds run).  The host only queues rounds - four or five launches each, no copy, no synchronisation - a few ahead of the
+// progress the device reports through two integers in pinned host memory (unfinished trajectories - also the bound of the next
+// launches' grids - and scans done).
 // Round 4's host rounds cost ~85 us each (55 us of which copies, synchronisation and host turn-around: DESIGN.md 3.13) and
 // the number of rounds is set by the ONE longest trajectory.
-constexpr int kRoundsPerCheck = 8;
+constexpr int kRoundsAhead = 12;       // rounds queued ahead of the device's progress
 
 template <int PM>
 struct TrajD {
@@ -338,7 +339,8 @@ struct MgArgs {
     double fd_step, param_jitter;
     int32_t *first;                  // [B] item offset of every trajectory in this round
     signed char *modes;              // [B] TrajD::mode of every trajectory, compact (what the scan reads)
-    int32_t *count;                  // [0] items of this round, [1] unfinished trajectories, [2] rounds that had items
+    int32_t *count;                  // [0] items of this round, [1] unfinished trajectories, [2] rounds that had items, [3] scans done
+    volatile int32_t *hflag;         // pinned host memory the device writes after every scan: [0] unfinished trajectories, [1] scans done
     unsigned long long *totals;      // [0] items, [1] BFGS iterations
     ThetaDev th;
     double *fm, *fP;                 // [B][T][D], [B][T][D D], NaN where nothing was produced
@@ -354,6 +356,19 @@ __device__ void mg_begin_step(TrajD<PM> &t, const MgArgs &a, int64_t b) {
     }
     bfgs_start(t.run, a.P, t.pm);
     t.mode = 0;
+}
+
+// what the host steers by, written to pinned host memory after every scan (ONE thread): the number of unfinished trajectories, then -
+// behind a system-scope fence - the number of scans done.  The host never waits for a round: it keeps a few rounds queued ahead
+// of the scan count it sees and stops queueing when a scan has found nothing unfinished.
+__device__ __forceinline__ void mg_publish(const MgArgs &a, int unfinished) {
+    const int seq = a.count[3] + 1;
+    a.count[3] = seq;
+    if (a.hflag) {
+        a.hflag[0] = unfinished;
+        __threadfence_system();
+        a.hflag[1] = seq;
+    }
 }
 
 template <int PM>
@@ -419,6 +434,7 @@ __global__ __launch_bounds__(256) void k_mg_scan(const MgArgs a) {
             a.count[2] += 1;
             a.totals[0] += (unsigned long long)carry;
         }
+        mg_publish(a, act);
     }
 }
 
@@ -472,6 +488,7 @@ __global__ __launch_bounds__(256) void k_mg_fill(const MgArgs a, int per) {
                 a.count[2] += 1;
                 a.totals[0] += (unsigned long long)total;
             }
+            mg_publish(a, a.count[1]);
         }
         if (lb >= tpb || b >= a.B) return;
         if (j == 0) a.first[b] = first_b;
@@ -693,29 +710,43 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
     SSMQ_HIP(hipMemsetAsync(dev + o_fP, 0xff, sizeof(double) * n_fP, s));
     if ((rc = theta_dev_upload_static(a.th, h_dyn, h_obs, GQG, R, s))) return rc;
     const unsigned tb = 64, tg = (unsigned)((B + tb - 1) / tb);
+    static volatile int32_t *hf = nullptr;          // 64 bytes of pinned, device-visible host memory, kept for the process
+    if (!hf) {
+        void *p = nullptr;
+        SSMQ_HIP(hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped));
+        hf = (volatile int32_t *)p;
+    }
+    hf[0] = (int32_t)std::min<int64_t>(B, 0x7fffffff);
+    hf[1] = 0;
+    a.hflag = hf;
     hipLaunchKernelGGL(k_mg_init<PM>, dim3(tg), dim3(tb), 0, s, a);
-    int64_t active = B;
     int32_t hc[4] = {0, 0, 0, 0};
     const bool fused_scan = B <= 8192 && per <= 32 && !getenv("SSMQ_MARGINAL_SCAN_KERNEL");
     const int64_t tpb_fill = 256 / per;
-    while (active > 0) {
-        const int64_t bound = active * per;                 // no trajectory comes back: an upper bound for the coming rounds
-        for (int r = 0; r < kRoundsPerCheck; ++r) {
-            if (fused_scan) {
-                hipLaunchKernelGGL((k_mg_fill<PM, true>), dim3((unsigned)((B + tpb_fill - 1) / tpb_fill)), dim3(256), 0, s, a, per);
-            } else {
-                hipLaunchKernelGGL(k_mg_scan<PM>, dim3(1), dim3(256), 0, s, a);
-                hipLaunchKernelGGL((k_mg_fill<PM, false>), dim3((unsigned)((B * per + 255) / 256)), dim3(256), 0, s, a, per);
-            }
-            if ((rc = theta_dev_enqueue(a.th, h_dyn, f_dyn, h_obs, f_obs, jitter, bound, a.count, s))) return rc;
-            hipLaunchKernelGGL((k_mg_advance<PM, PX>), dim3((unsigned)((B + kAdvPerWave - 1) / kAdvPerWave)), dim3(64), 0, s, a);
+    // Rounds are queued kRoundsAhead ahead of the scan count the device reports through pinned host memory; nothing in this loop
+    // waits for the device (round 5's first version synchronised every eighth round: a bubble of a copy and a launch each time).
+    // The number of unfinished trajectories only falls, so the latest value seen bounds the grids of every round queued after it.
+    int64_t launched = 0;
+    for (;;) {
+        const int32_t seen = hf[1];
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const int32_t unfinished = hf[0];
+        if (seen > 0 && unfinished == 0) break;               // a scan found every trajectory done: what is queued finds nothing to do
+        if (launched - seen >= kRoundsAhead) {
+            std::this_thread::yield();
+            continue;
         }
+        const int64_t bound = std::max<int64_t>(1, unfinished) * per;
+        if (fused_scan) {
+            hipLaunchKernelGGL((k_mg_fill<PM, true>), dim3((unsigned)((B + tpb_fill - 1) / tpb_fill)), dim3(256), 0, s, a, per);
+        } else {
+            hipLaunchKernelGGL(k_mg_scan<PM>, dim3(1), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_mg_fill<PM, false>), dim3((unsigned)((B * per + 255) / 256)), dim3(256), 0, s, a, per);
+        }
+        if ((rc = theta_dev_enqueue(a.th, h_dyn, f_dyn, h_obs, f_obs, jitter, bound, a.count, s))) return rc;
+        hipLaunchKernelGGL((k_mg_advance<PM, PX>), dim3((unsigned)((B + kAdvPerWave - 1) / kAdvPerWave)), dim3(64), 0, s, a);
         if ((rc = hip_fail(hipGetLastError(), "marginal filter: device rounds"))) return rc;
-        SSMQ_HIP(hipMemcpyAsync(hc, a.count, sizeof(hc), hipMemcpyDeviceToHost, s));
-        SSMQ_HIP(hipStreamSynchronize(s));
-        // count[1] is what the LAST scan saw, before that round's advance: one more scan settles it once it is small
-        if (hc[1] == 0) break;
-        active = hc[1];
+        ++launched;
     }
     hipLaunchKernelGGL(k_mg_finish<PM>, dim3(tg), dim3(tb), 0, s, a, (double *)(dev + o_tl), (double *)(dev + o_pl));
     SSMQ_HIP(hipMemcpyAsync(fm, a.fm, sizeof(double) * n_fm, hipMemcpyDeviceToHost, s));
