@@ -727,12 +727,25 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
     // waits for the device (round 5's first version synchronised every eighth round: a bubble of a copy and a launch each time).
     // The number of unfinished trajectories only falls, so the latest value seen bounds the grids of every round queued after it.
     int64_t launched = 0;
+    int32_t last_seen = -1;
+    auto last_progress = std::chrono::steady_clock::now();
     for (;;) {
         const int32_t seen = hf[1];
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         const int32_t unfinished = hf[0];
         if (seen > 0 && unfinished == 0) break;               // a scan found every trajectory done: what is queued finds nothing to do
         if (launched - seen >= kRoundsAhead) {
+            // every wait in this library has an end: a device that reports no scan for a minute is asked for its error
+            if (seen != last_seen) {
+                last_seen = seen;
+                last_progress = std::chrono::steady_clock::now();
+            } else if (std::chrono::steady_clock::now() - last_progress > std::chrono::seconds(60)) {
+                SSMQ_HIP(hipStreamSynchronize(s));
+                if (hf[1] == seen) {
+                    set_error("marginal_filter_batch: the device rounds made no progress");
+                    return SSMQ_E_HIP;
+                }
+            }
             std::this_thread::yield();
             continue;
         }
