@@ -1963,6 +1963,13 @@ int gp_theta_weights_pair(const int D[2], const int E[2], const int N[2], const 
                           const double *const d_par[2], int P, double jitter, double *const d_consts[2],
                           int32_t *const d_status[2], const int32_t *d_count = nullptr);
 bool theta_chain_supported(int Din, int D, int Y, int Nd, int No);
+// ... and for the small systems one lane per item, everything in registers (ssmq_theta_item.hip)
+bool theta_item_supported(int Din, int D, int Y, int Nd, int No);
+int launch_theta_item(int Din, int D, int Y, int Nd, int No, const ssmq_integrand *f_dyn, const ssmq_integrand *f_obs, int emv_dyn,
+                      int emv_obs, const double *xid, const double *xio, const double *pard, const double *paro, const double *mean,
+                      const double *cov, int64_t bs_mean, int64_t bs_cov, const double *ysoa, const double *time, int time_stride,
+                      const double *gq, const double *rr, double jitter, double *m_fi, double *P_fi, double *ll, int32_t *st_all,
+                      int64_t ld, int64_t bound, const int32_t *d_count, hipStream_t s);
 hipError_t launch_theta_chain(const WideArgs &dyn, const WideArgs &obs, const UpdArgs &upd, const double *y, double *loglik,
                               const int32_t *merge, int32_t *merge_out, int64_t B, hipStream_t s, const int32_t *d_count = nullptr);
 }
@@ -2117,10 +2124,22 @@ static int gp_theta_step_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn
     // marginalisation: 2 param_dim); 89 -> 76 us per call at P = 7
     // two launches - k_theta_weights (both transforms' weights, LDS-resident) and k_theta_chain (transform -> transform ->
     // update -> log-likelihood by the wave that owns the item) - where the point sets fit; else the launch per stage
-    const bool two_launch = theta_chain_supported(Din, D, Y, Nd, No) && gp_theta_weights_fits(Din, Nd, D, No);
+    // ... or ONE launch with a lane per item for the small systems (k_theta_item, round 5)
+    const bool item_route = theta_item_supported(Din, D, Y, Nd, No);
+    const bool two_launch = item_route || (theta_chain_supported(Din, D, Y, Nd, No) && gp_theta_weights_fits(Din, Nd, D, No));
     auto enqueue = [&]() -> int {
     int rc;
     SSMQ_HIP(hipMemcpyAsync(dev + off_in, hin, sizeof(double) * n_in, hipMemcpyHostToDevice, s));
+    if (item_route) {
+        double *wo_ = (double *)(dev + off_out);
+        double *m_fi = wo_, *P_fi = wo_ + ld * D, *ll = P_fi + ld * D * D;
+        if ((rc = launch_theta_item(Din, D, Y, Nd, No, f_dyn, f_obs, h_dyn->emv_mode, h_obs->emv_mode, xid, xio, pard, paro, min_, cin,
+                                    shared_state ? 0 : Din, shared_state ? 0 : (int64_t)Din * Din, ysoa, tt, times ? 1 : 0, gq, rr, jitter,
+                                    m_fi, P_fi, ll, (int32_t *)(ll + ld), ld, P, nullptr, s)))
+            return rc;
+        SSMQ_HIP(hipMemcpyAsync(g_stage.hout, dev + off_out, out_bytes, hipMemcpyDeviceToHost, s));
+        return SSMQ_OK;
+    }
     if (!two_launch) {
         SSMQ_HIP(hipMemsetAsync(st_wd, 0, sizeof(int32_t) * 5 * ld, s));
         if ((rc = gp_weights_wide_consts(Din, D, Nd, xid, pard, (int)P, jitter, cd, st_wd, dev + off_ws, ws_d))) return rc;
@@ -2260,7 +2279,7 @@ bool theta_dev_supported(const ssmq_transform *h_dyn, const ssmq_integrand *f_dy
     FInfo fi;
     if (check_integrand(h_dyn, f_dyn, &fi) || check_integrand(h_obs, f_obs, &fi))
         return false;
-    return theta_chain_supported(Din, D, Y, Nd, No) && gp_theta_weights_fits(Din, Nd, D, No);
+    return theta_item_supported(Din, D, Y, Nd, No) || (theta_chain_supported(Din, D, Y, Nd, No) && gp_theta_weights_fits(Din, Nd, D, No));
 }
 
 size_t theta_dev_bytes(const ssmq_transform *h_dyn, const ssmq_transform *h_obs, int64_t cap) {
@@ -2325,6 +2344,10 @@ int theta_dev_enqueue(const ThetaDev &t, const ssmq_transform *h_dyn, const ssmq
     }
     const int Din = t.Din, D = t.D, Y = t.Y, Nd = t.Nd, No = t.No;
     const int64_t ld = t.ld;
+    if (theta_item_supported(Din, D, Y, Nd, No))
+        return launch_theta_item(Din, D, Y, Nd, No, f_dyn, f_obs, h_dyn->emv_mode, h_obs->emv_mode, t.xid, t.xio, t.pard, t.paro, t.mean, t.cov,
+                                 Din, (int64_t)Din * Din, t.ysoa, t.tt, 1, t.gq, t.rr, jitter, t.m_fi, t.P_fi, t.ll, t.st_all, ld, bound,
+                                 d_count, s);
     const WideLayout cld = wide_layout(Din, D, Nd, SSMQ_FORM_BQ), clo = wide_layout(D, Y, No, SSMQ_FORM_BQ);
     int32_t *st_wd = t.st5, *st_wo = st_wd + ld, *st_td = st_wo + ld, *st_to = st_td + ld, *st_up = st_to + ld;
     int rc;
