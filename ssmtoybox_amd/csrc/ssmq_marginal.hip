@@ -23,6 +23,7 @@
 // marginalisation point then fails.  And NaN is tested before maxiter (SciPy: warnflag 1 before 3).
 #include "ssmq_host.h"
 #include "ssmq_bfgs.h"
+#include "ssmq_theta_item.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -530,8 +531,18 @@ __global__ __launch_bounds__(256) void k_mg_fill(const MgArgs a, int per) {
 // PX: the parameter count at compile time (= PM), or 0 = a.P at run time.  With PX every loop of the optimiser has a constant trip
 // count: unrolled, its small arrays in registers - at run-time bounds they are indexed private memory and the kernel took
 // 40 us per round for 1 024 trajectories (a wave walks the union of its lanes' branches, a few thousand dependent instructions).
-template <int PM, int PX>
-__device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b);
+// where a trajectory's item results of this round are: the theta step's device arena (rounds route) ...
+struct ArenaResults {
+    const ThetaDev &th;
+    int64_t f0;
+    __device__ __forceinline__ double ll(int j) const { return th.ll[f0 + j]; }
+    __device__ __forceinline__ int32_t st(int j) const { return th.st_all[f0 + j]; }
+    __device__ __forceinline__ double m(int i, int j) const { return th.m_fi[(size_t)i * th.ld + f0 + j]; }
+    __device__ __forceinline__ double P(int i, int j) const { return th.P_fi[(size_t)i * th.ld + f0 + j]; }
+};
+
+template <int PM, int PX, class Res>
+__device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b, const Res &res);
 
 // kAdvPerWave trajectories per wave (every (64 / kAdvPerWave)-th lane): a wave walks the union of its lanes' branches, fewer
 // lanes = fewer of them
@@ -544,15 +555,14 @@ __global__ __launch_bounds__(64) void k_mg_advance(const MgArgs a) {
     const int64_t b = (int64_t)blockIdx.x * kAdvPerWave + threadIdx.x / (64 / kAdvPerWave);
     if (threadIdx.x % (64 / kAdvPerWave) != 0 || b >= a.B) return;
     if (a.modes[b] == 2) return;
-    mg_advance_one<PM, PX>(a, b);
+    mg_advance_one<PM, PX>(a, b, ArenaResults{a.th, (int64_t)a.first[b]});
     a.modes[b] = (signed char)((const TrajD<PM> *)a.traj)[b].mode;
 }
 
-template <int PM, int PX>
-__device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b) {
+template <int PM, int PX, class Res>
+__device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b, const Res &res) {
     TrajD<PM> &t = ((TrajD<PM> *)a.traj)[b];
     const int P = PX ? PX : a.P, D = a.D, NP = a.NP, T = a.T;
-    const int64_t ld = a.th.ld, f0 = a.first[b];
     const double inf = __builtin_huge_val();
     if (t.mode == 0) {
         // The optimiser works on a LOCAL copy of its state (private memory: lane-interleaved and cached) and writes it back
@@ -571,7 +581,7 @@ __device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b) {
                 q += v[i] * v[i];
             }
             const double lp = -0.5 * (q + t.logdet2 + P * log(2.0 * M_PI));
-            const double val = -a.th.ll[f0 + j] - lp;
+            const double val = -res.ll(j) - lp;
             vals[j] = __builtin_isfinite(val) ? val : inf;
         }
         bfgs_advance(run, P, a.fd_step, vals);
@@ -605,16 +615,15 @@ __device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b) {
     } else {
         // mixture over the parameter points (ssinf.py:1108-1115): plain weighted sums of the conditional moments
         bool ok = true;
-        for (int j = 0; j < NP; ++j) ok = ok && a.th.st_all[f0 + j] == 0;
+        for (int j = 0; j < NP; ++j) ok = ok && res.st(j) == 0;
         const bool items_ok = ok;
         double xm[SSMQ_MAX_DIM], xP[SSMQ_MAX_DIM * SSMQ_MAX_DIM];
         for (int i = 0; i < D; ++i) xm[i] = 0.0;
         for (int i = 0; i < D * D; ++i) xP[i] = 0.0;
         for (int j = 0; j < NP; ++j) {
-            const int64_t it = f0 + j;
             const double w = a.uwts[j];
-            for (int i = 0; i < D; ++i) xm[i] += a.th.m_fi[(size_t)i * ld + it] * w;
-            for (int i = 0; i < D * D; ++i) xP[i] += a.th.P_fi[(size_t)i * ld + it] * w;
+            for (int i = 0; i < D; ++i) xm[i] += res.m(i, j) * w;
+            for (int i = 0; i < D * D; ++i) xP[i] += res.P(i, j) * w;
         }
         for (int i = 0; i < D; ++i) ok = ok && __builtin_isfinite(xm[i]);
         for (int i = 0; i < D * D; ++i) ok = ok && __builtin_isfinite(xP[i]);
@@ -648,6 +657,146 @@ __global__ void k_mg_finish(const MgArgs a, double *theta_last, double *pcov_las
     for (int i = 0; i < a.P; ++i) theta_last[(size_t)b * a.P + i] = t.pm[i];
     for (int i = 0; i < a.P * a.P; ++i) pcov_last[(size_t)b * a.P * a.P + i] = t.pc[i];
 }
+
+// ---- the whole filter in ONE launch (small systems) --------------------------------------------------------------------------------
+// Trajectories never interact, and with the theta step of an item a per-lane device function (ssmq_theta_item.h) nothing in a
+// round needs another kernel: a group of PER = max(P + 1, NP) lanes owns a trajectory, every lane of the group evaluates ONE of
+// the points the trajectory waits for, the group's first lane takes the values and advances the trajectory's state machine, and
+// the wave (64 / PER trajectories) loops until all of its trajectories are through their T steps or have failed.  No scan, no
+// packing, no kernel boundary and no host between two evaluations; the exit condition is per wave and every path of the state
+// machine is bounded (BFGS: 200 P iterations of at most 100 + 10 + 10 line-search evaluations).  Item inputs and results cross
+// lanes through a few hundred bytes of LDS per trajectory.  Same arithmetic as the rounds route - same device functions, same
+// exp / log - so the two agree bit for bit (tests/test_gpu_parity.py::test_marginal_filter_one_launch_matches_device_rounds).
+struct MgItem {
+    int32_t fid_dyn, fid_obs, emv_dyn, emv_obs;
+    FPar fpd, fpo;
+    double jitter;
+};
+
+template <int TPW, int PER, int D>
+struct LdsResults {
+    const double (*ll_)[PER];
+    const double (*m_)[PER][D];
+    const double (*P_)[PER][D * D];
+    const int32_t (*st_)[PER];
+    int g;
+    __device__ __forceinline__ double ll(int j) const { return ll_[g][j]; }
+    __device__ __forceinline__ int32_t st(int j) const { return st_[g][j]; }
+    __device__ __forceinline__ double m(int i, int j) const { return m_[g][j][i]; }
+    __device__ __forceinline__ double P(int i, int j) const { return P_[g][j][i]; }
+};
+
+template <int PX, int DIN, int D, int Y, int ND, int NO>
+__global__ __launch_bounds__(64) void k_mg_persistent(const MgArgs a, const MgItem it) {
+    constexpr int PER = 2 * PX, TPW = 64 / PER, PM = PX, Pd = DIN + 1, dq = DIN - D;
+    __shared__ double s_row[TPW][PER][PX], s_xm[TPW][D], s_xP[TPW][D * D], s_y[TPW][Y], s_t[TPW];
+    __shared__ int32_t s_n[TPW];
+    __shared__ double o_ll[TPW][PER], o_m[TPW][PER][D], o_P[TPW][PER][D * D];
+    __shared__ int32_t o_st[TPW][PER];
+    const int lane = threadIdx.x, g = lane / PER, j = lane - g * PER;
+    const int64_t b = (int64_t)blockIdx.x * TPW + g;
+    const bool in_group = g < TPW;
+    const bool member = in_group && b < a.B;
+    const bool leader = member && j == 0;
+    TrajD<PM> *tp = (TrajD<PM> *)a.traj + (member ? b : 0);
+    if (leader) {
+        TrajD<PM> &t = *tp;
+        t.k = 1;
+        for (int i = 0; i < D; ++i) t.xm[i] = a.x0_mean[i];
+        for (int i = 0; i < D * D; ++i) t.xP[i] = a.x0_cov[i];
+        for (int i = 0; i < PX; ++i) t.pm[i] = a.prior_mean[i];
+        for (int i = 0; i < PX * PX; ++i) t.pc[i] = a.prior_cov[i];
+        a.failed[b] = 0;
+        mg_begin_step(t, a, b);
+    }
+    int32_t rounds = 0;
+    unsigned long long items = 0;
+    for (;;) {
+        // ---- the group's first lane says what the trajectory waits for -------------------------------------------------------------
+        if (in_group && j == 0) {
+            int n = 0;
+            if (leader && tp->mode != 2) {
+                const TrajD<PM> &t = *tp;
+                n = t.mode == 0 ? PX + 1 : a.NP;
+                for (int jj = 0; jj < n; ++jj)
+                    for (int i = 0; i < PX; ++i)
+                        s_row[g][jj][i] = t.mode == 0 ? t.run.xt[i] + ((jj == i + 1) ? a.fd_step : 0.0) : t.pts[(size_t)jj * PX + i];
+                for (int i = 0; i < D; ++i) s_xm[g][i] = t.xm[i];
+                for (int i = 0; i < D * D; ++i) s_xP[g][i] = t.xP[i];
+                for (int i = 0; i < Y; ++i) s_y[g][i] = a.y[((size_t)b * a.T + (t.k - 1)) * Y + i];
+                s_t[g] = (double)t.k;
+            }
+            s_n[g] = n;
+        }
+        __syncthreads();
+        int any = 0;
+#pragma unroll
+        for (int gg = 0; gg < TPW; ++gg) any += s_n[gg];
+        if (any == 0) break;                                   // (the same for every lane of the wave)
+        ++rounds;
+        items += (unsigned long long)any;
+        // ---- one point per lane: the theta-conditioned filter step ------------------------------------------------------------------
+        if (member && j < s_n[g]) {
+            double par_d[Pd], par_o[D + 1], m[DIN], cv[DIN][DIN], yv[Y], m_fi[D], P_fi[D][D], ll;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                const double e = exp(s_row[g][j][i]);          // the kernel parameters are exp(theta)
+                if (i < Pd) par_d[i] = e;
+                else par_o[i - Pd] = e;
+            }
+            // [mean; q_mean], blockdiag(cov, Q) for dynamics that take their noise as an argument (ssinf.py:1174-1176)
+#pragma unroll
+            for (int i = 0; i < DIN; ++i)
+#pragma unroll
+                for (int k = 0; k < DIN; ++k) cv[i][k] = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                m[i] = s_xm[g][i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) cv[i][k] = s_xP[g][i * D + k];
+            }
+#pragma unroll
+            for (int i = 0; i < dq; ++i) {
+                m[D + i] = a.q_mean[i];
+#pragma unroll
+                for (int k = 0; k < dq; ++k) cv[D + i][D + k] = a.q_cov[i * dq + k];
+            }
+#pragma unroll
+            for (int i = 0; i < Y; ++i) yv[i] = s_y[g][i];
+            const int32_t st = theta_item::theta_item_core<DIN, D, Y, ND, NO>(it.fid_dyn, it.fid_obs, it.fpd, it.fpo, it.emv_dyn, it.emv_obs,
+                                                                            a.th.xid, a.th.xio, par_d, par_o, m, cv, yv, s_t[g], a.th.gq,
+                                                                            a.th.rr, it.jitter, m_fi, P_fi, ll);
+            o_ll[g][j] = ll;
+            o_st[g][j] = st;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                o_m[g][j][d] = m_fi[d];
+#pragma unroll
+                for (int d2 = 0; d2 < D; ++d2) o_P[g][j][d * D + d2] = P_fi[d][d2];
+            }
+        }
+        __syncthreads();
+        // ---- ... and advances: optimiser step, or Laplace posterior and its sigma points, or the mixture and the next time step ----------
+        if (leader && s_n[g] > 0) mg_advance_one<PM, PX>(a, b, LdsResults<TPW, PER, D>{o_ll, o_m, o_P, o_st, g});
+        __syncthreads();
+    }
+    if (lane == 0) {
+        atomicMax(&a.count[2], rounds);
+        atomicAdd(&a.totals[0], items);
+    }
+}
+
+typedef void (*mg_persistent_kernel)(const MgArgs, const MgItem);
+struct MgPersistentEntry {
+    int P, Din, D, Y, Nd, No;
+    mg_persistent_kernel k;
+};
+#define SSMQ_MGP(PX, DIN, D, Y, ND, NO) {PX, DIN, D, Y, ND, NO, &k_mg_persistent<PX, DIN, D, Y, ND, NO>}
+// the shapes of k_theta_item (ssmq_theta_item.hip): P = Din + D + 2 log-parameters
+const MgPersistentEntry kMgPersistent[] = {
+    SSMQ_MGP(4, 1, 1, 1, 2, 2), SSMQ_MGP(4, 1, 1, 1, 3, 3), SSMQ_MGP(5, 2, 1, 1, 4, 2), SSMQ_MGP(5, 2, 1, 1, 5, 3), SSMQ_MGP(6, 2, 2, 1, 4, 4),
+    SSMQ_MGP(6, 2, 2, 1, 5, 5),
+};
 
 // Returns SSMQ_OK having produced everything, SSMQ_E_UNSUPPORTED if this shape has no device-resident route (the caller then runs
 // the host rounds), or an error.
@@ -719,8 +868,24 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
     hf[0] = (int32_t)std::min<int64_t>(B, 0x7fffffff);
     hf[1] = 0;
     a.hflag = hf;
-    hipLaunchKernelGGL(k_mg_init<PM>, dim3(tg), dim3(tb), 0, s, a);
+    // the whole filter in one launch where the item step is a per-lane device function (k_mg_persistent); SSMQ_MARGINAL_ROUNDS=1
+    // keeps the rounds below (the route of every other shape)
     int32_t hc[4] = {0, 0, 0, 0};
+    const MgPersistentEntry *pe = nullptr;
+    if (!getenv("SSMQ_MARGINAL_ROUNDS") && !getenv("SSMQ_NO_THETA_ITEM") && NP == 2 * P && PX == P)
+        for (const MgPersistentEntry &e : kMgPersistent)
+            if (e.P == P && e.Din == Din && e.D == D && e.Y == Y && e.Nd == h_dyn->N && e.No == h_obs->N) pe = &e;
+    if (pe) {
+        MgItem it;
+        memset(&it, 0, sizeof(it));
+        it.fid_dyn = f_dyn->id; it.fid_obs = f_obs->id; it.emv_dyn = h_dyn->emv_mode; it.emv_obs = h_obs->emv_mode; it.jitter = jitter;
+        fill_fpar(f_dyn, &it.fpd);
+        fill_fpar(f_obs, &it.fpo);
+        const int tpw = 64 / (2 * P);
+        hipLaunchKernelGGL(pe->k, dim3((unsigned)((B + tpw - 1) / tpw)), dim3(64), 0, s, a, it);
+        if ((rc = hip_fail(hipGetLastError(), "k_mg_persistent"))) return rc;
+    } else {
+    hipLaunchKernelGGL(k_mg_init<PM>, dim3(tg), dim3(tb), 0, s, a);
     const bool fused_scan = B <= 8192 && per <= 32 && !getenv("SSMQ_MARGINAL_SCAN_KERNEL");
     const int64_t tpb_fill = 256 / per;
     // Rounds are queued kRoundsAhead ahead of the scan count the device reports through pinned host memory; nothing in this loop
@@ -761,6 +926,7 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
         if ((rc = hip_fail(hipGetLastError(), "marginal filter: device rounds"))) return rc;
         ++launched;
     }
+    }   // rounds route
     hipLaunchKernelGGL(k_mg_finish<PM>, dim3(tg), dim3(tb), 0, s, a, (double *)(dev + o_tl), (double *)(dev + o_pl));
     SSMQ_HIP(hipMemcpyAsync(fm, a.fm, sizeof(double) * n_fm, hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipMemcpyAsync(fP, a.fP, sizeof(double) * n_fP, hipMemcpyDeviceToHost, s));

@@ -3426,6 +3426,50 @@ def test_marginal_filter_device_rounds_match_host_rounds(amd, monkeypatch):
     assert np.median(np.abs(fna - fnh)[..., okn] / np.maximum(1.0, np.abs(fnh[..., okn]))) < 5e-3
 
 
+def test_marginal_filter_one_launch_matches_device_rounds(amd, monkeypatch):
+    """The one-launch route of the batched marginalised filter (k_mg_persistent: a group of lanes per trajectory loops over
+    evaluate | advance inside one kernel) against the device rounds (fill | k_theta_item | advance, three launches per round): the
+    same device functions on the same values in the same order - the results are EQUAL, failures and BFGS iteration counts
+    included.  UNGM (P = 4), UNGM with its noise as an argument (P = 5) and the pendulum (P = 6)."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    from bench import simulate_ungm
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    _, y = simulate_ungm(203, 6, 21)
+    cases = [
+        ('ungm', ssinf.MarginalizedGaussianProcessKalman(
+            sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]]))), obs, 'rbf', 'sr'), np.ascontiguousarray(y[None])),
+        ('ungm-na', ssinf.MarginalizedGaussianProcessKalman(
+            sm.UNGMNATransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]]))), obs, 'rbf', 'ut'),
+         np.ascontiguousarray(y[None, :3, :37])),
+    ]
+    x0 = sm.GaussRV(2, mean=np.array([1.5, 0.0]), cov=0.01 * np.eye(2))
+    pdyn = sm.Pendulum2DTransition(x0, sm.GaussRV(2, cov=np.diag([1e-4, 1e-3])), 0.05)
+    pobs = sm.Pendulum2DMeasurement(sm.GaussRV(1, cov=np.array([[0.1]])), 2)
+    rng = np.random.default_rng(3)
+    xs = np.empty((2, 4, 24))
+    x = x0.mean[:, None] + 0.1 * rng.standard_normal((2, 24))
+    for k in range(4):
+        x = np.stack([x[0] + 0.05 * x[1], x[1] - 9.81 * 0.05 * np.sin(x[0])]) + np.sqrt([[1e-4], [1e-3]]) * rng.standard_normal((2, 24))
+        xs[:, k] = x
+    yp = np.sin(xs[:1]) + np.sqrt(0.1) * rng.standard_normal((1, 4, 24))
+    cases.append(('pendulum', ssinf.MarginalizedGaussianProcessKalman(pdyn, pobs, 'rbf', 'sr'), np.ascontiguousarray(yp)))
+    for name, alg, data in cases:
+        monkeypatch.delenv('SSMQ_MARGINAL_ROUNDS', raising=False)
+        f1, P1 = alg.forward_pass_batch(data)
+        s1, b1, th1 = dict(alg.batch_stats), alg.batch_failed.copy(), alg.batch_param_mean.copy()
+        monkeypatch.setenv('SSMQ_MARGINAL_ROUNDS', '1')
+        f2, P2 = alg.forward_pass_batch(data)
+        s2, b2, th2 = dict(alg.batch_stats), alg.batch_failed.copy(), alg.batch_param_mean.copy()
+        monkeypatch.delenv('SSMQ_MARGINAL_ROUNDS')
+        print('marginal filter %s: one launch %s | rounds %s | failed %d' % (name, s1, s2, int((b1 != 0).sum())))
+        assert np.isfinite(f1).any()
+        assert np.array_equal(b1, b2), name
+        assert np.array_equal(f1, f2, equal_nan=True) and np.array_equal(P1, P2, equal_nan=True), name
+        assert np.array_equal(th1, th2, equal_nan=True), name
+        assert s1['iterations'] == s2['iterations'] and s1['items'] == s2['items'], name
+        assert 0 < s1['rounds'] <= s2['rounds'], name          # the longest wave's loop count against the batch's rounds
+
+
 def test_marginal_filter_failures_are_the_reference_s_linalg_errors(amd, golden):
     """The few trajectories of a batch that the marginalised filter reports as failed (bench.py: 2-3 of 1 024 on the UNGM batch).
 
