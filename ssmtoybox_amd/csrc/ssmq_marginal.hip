@@ -541,8 +541,8 @@ struct ArenaResults {
     __device__ __forceinline__ double P(int i, int j) const { return th.P_fi[(size_t)i * th.ld + f0 + j]; }
 };
 
-template <int PM, int PX, class Res>
-__device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b, const Res &res);
+template <int PM, int PX, class Res, bool IN_PLACE = false>
+__device__ __forceinline__ void mg_advance_one(TrajD<PM> &t, const MgArgs &a, int64_t b, const Res &res);
 
 // kAdvPerWave trajectories per wave (every (64 / kAdvPerWave)-th lane): a wave walks the union of its lanes' branches, fewer
 // lanes = fewer of them
@@ -555,20 +555,22 @@ __global__ __launch_bounds__(64) void k_mg_advance(const MgArgs a) {
     const int64_t b = (int64_t)blockIdx.x * kAdvPerWave + threadIdx.x / (64 / kAdvPerWave);
     if (threadIdx.x % (64 / kAdvPerWave) != 0 || b >= a.B) return;
     if (a.modes[b] == 2) return;
-    mg_advance_one<PM, PX>(a, b, ArenaResults{a.th, (int64_t)a.first[b]});
+    mg_advance_one<PM, PX>(((TrajD<PM> *)a.traj)[b], a, b, ArenaResults{a.th, (int64_t)a.first[b]});
     a.modes[b] = (signed char)((const TrajD<PM> *)a.traj)[b].mode;
 }
 
-template <int PM, int PX, class Res>
-__device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b, const Res &res) {
-    TrajD<PM> &t = ((TrajD<PM> *)a.traj)[b];
+template <int PM, int PX, class Res, bool IN_PLACE>
+__device__ __forceinline__ void mg_advance_one(TrajD<PM> &t, const MgArgs &a, int64_t b, const Res &res) {
     const int P = PX ? PX : a.P, D = a.D, NP = a.NP, T = a.T;
     const double inf = __builtin_huge_val();
     if (t.mode == 0) {
         // The optimiser works on a LOCAL copy of its state (private memory: lane-interleaved and cached) and writes it back
         // once: on the 3 KB-strided structs themselves every one of its few hundred dependent accesses was a cache miss of its
         // own (38 us per round for 1 024 trajectories).
-        RunT<PM> run = t.run;
+        // (IN_PLACE: the state is in LDS - k_mg_persistent - and the optimiser works on it where it is)
+        RunT<PM> run_copy;
+        if constexpr (!IN_PLACE) run_copy = t.run;
+        RunT<PM> &run = IN_PLACE ? t.run : run_copy;
         double vals[PM + 1];
         for (int j = 0; j <= P; ++j) {
             // log N(theta | prior) at the row as it was evaluated (ssinf.py:1200-1218)
@@ -585,7 +587,7 @@ __device__ __forceinline__ void mg_advance_one(const MgArgs &a, int64_t b, const
             vals[j] = __builtin_isfinite(val) ? val : inf;
         }
         bfgs_advance(run, P, a.fd_step, vals);
-        t.run = run;
+        if constexpr (!IN_PLACE) t.run = run;
         if (run.phase != PH_DONE) return;
         atomicAdd(&a.totals[1], (unsigned long long)run.k);
         // Laplace posterior (ssinf.py:1272-1273) and its sigma points (:1103-1106)
@@ -689,7 +691,6 @@ struct LdsResults {
 template <int PX, int DIN, int D, int Y, int ND, int NO>
 __global__ __launch_bounds__(64) void k_mg_persistent(const MgArgs a, const MgItem it) {
     constexpr int PER = 2 * PX, TPW = 64 / PER, PM = PX, Pd = DIN + 1, dq = DIN - D;
-    __shared__ double s_row[TPW][PER][PX], s_xm[TPW][D], s_xP[TPW][D * D], s_y[TPW][Y], s_t[TPW];
     __shared__ int32_t s_n[TPW];
     __shared__ double o_ll[TPW][PER], o_m[TPW][PER][D], o_P[TPW][PER][D * D];
     __shared__ int32_t o_st[TPW][PER];
@@ -698,7 +699,12 @@ __global__ __launch_bounds__(64) void k_mg_persistent(const MgArgs a, const MgIt
     const bool in_group = g < TPW;
     const bool member = in_group && b < a.B;
     const bool leader = member && j == 0;
-    TrajD<PM> *tp = (TrajD<PM> *)a.traj + (member ? b : 0);
+    // The trajectories' states live in LDS for the length of the kernel (3 KB each): the optimiser reads and writes its state
+    // every round - on the arena's 3 KB-strided structs each of those accesses is an L2 round trip on the wave's critical path -
+    // and the lanes of the group read the point they are to evaluate straight from it.
+    static_assert(sizeof(TrajD<PM>) % sizeof(double) == 0, "TrajD: a whole number of doubles");
+    __shared__ double s_traj[TPW][sizeof(TrajD<PM>) / sizeof(double)];      // (raw: the struct has member initialisers)
+    TrajD<PM> *tp = reinterpret_cast<TrajD<PM> *>(s_traj[in_group ? g : 0]);
     if (leader) {
         TrajD<PM> &t = *tp;
         t.k = 1;
@@ -709,26 +715,11 @@ __global__ __launch_bounds__(64) void k_mg_persistent(const MgArgs a, const MgIt
         a.failed[b] = 0;
         mg_begin_step(t, a, b);
     }
+    if (in_group && j == 0) s_n[g] = leader ? (tp->mode == 0 ? PX + 1 : (tp->mode == 1 ? a.NP : 0)) : 0;
+    __syncthreads();
     int32_t rounds = 0;
     unsigned long long items = 0;
     for (;;) {
-        // ---- the group's first lane says what the trajectory waits for -------------------------------------------------------------
-        if (in_group && j == 0) {
-            int n = 0;
-            if (leader && tp->mode != 2) {
-                const TrajD<PM> &t = *tp;
-                n = t.mode == 0 ? PX + 1 : a.NP;
-                for (int jj = 0; jj < n; ++jj)
-                    for (int i = 0; i < PX; ++i)
-                        s_row[g][jj][i] = t.mode == 0 ? t.run.xt[i] + ((jj == i + 1) ? a.fd_step : 0.0) : t.pts[(size_t)jj * PX + i];
-                for (int i = 0; i < D; ++i) s_xm[g][i] = t.xm[i];
-                for (int i = 0; i < D * D; ++i) s_xP[g][i] = t.xP[i];
-                for (int i = 0; i < Y; ++i) s_y[g][i] = a.y[((size_t)b * a.T + (t.k - 1)) * Y + i];
-                s_t[g] = (double)t.k;
-            }
-            s_n[g] = n;
-        }
-        __syncthreads();
         int any = 0;
 #pragma unroll
         for (int gg = 0; gg < TPW; ++gg) any += s_n[gg];
@@ -737,10 +728,13 @@ __global__ __launch_bounds__(64) void k_mg_persistent(const MgArgs a, const MgIt
         items += (unsigned long long)any;
         // ---- one point per lane: the theta-conditioned filter step ------------------------------------------------------------------
         if (member && j < s_n[g]) {
+            const TrajD<PM> &t = *tp;
+            const int mode = t.mode;
             double par_d[Pd], par_o[D + 1], m[DIN], cv[DIN][DIN], yv[Y], m_fi[D], P_fi[D][D], ll;
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
-                const double e = exp(s_row[g][j][i]);          // the kernel parameters are exp(theta)
+                const double row = mode == 0 ? t.run.xt[i] + ((j == i + 1) ? a.fd_step : 0.0) : t.pts[(size_t)j * PX + i];
+                const double e = exp(row);                     // the kernel parameters are exp(theta)
                 if (i < Pd) par_d[i] = e;
                 else par_o[i - Pd] = e;
             }
@@ -751,9 +745,9 @@ __global__ __launch_bounds__(64) void k_mg_persistent(const MgArgs a, const MgIt
                 for (int k = 0; k < DIN; ++k) cv[i][k] = 0.0;
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                m[i] = s_xm[g][i];
+                m[i] = t.xm[i];
 #pragma unroll
-                for (int k = 0; k < D; ++k) cv[i][k] = s_xP[g][i * D + k];
+                for (int k = 0; k < D; ++k) cv[i][k] = t.xP[i * D + k];
             }
 #pragma unroll
             for (int i = 0; i < dq; ++i) {
@@ -762,9 +756,9 @@ __global__ __launch_bounds__(64) void k_mg_persistent(const MgArgs a, const MgIt
                 for (int k = 0; k < dq; ++k) cv[D + i][D + k] = a.q_cov[i * dq + k];
             }
 #pragma unroll
-            for (int i = 0; i < Y; ++i) yv[i] = s_y[g][i];
+            for (int i = 0; i < Y; ++i) yv[i] = a.y[((size_t)b * a.T + (t.k - 1)) * Y + i];
             const int32_t st = theta_item::theta_item_core<DIN, D, Y, ND, NO>(it.fid_dyn, it.fid_obs, it.fpd, it.fpo, it.emv_dyn, it.emv_obs,
-                                                                            a.th.xid, a.th.xio, par_d, par_o, m, cv, yv, s_t[g], a.th.gq,
+                                                                            a.th.xid, a.th.xio, par_d, par_o, m, cv, yv, (double)t.k, a.th.gq,
                                                                             a.th.rr, it.jitter, m_fi, P_fi, ll);
             o_ll[g][j] = ll;
             o_st[g][j] = st;
@@ -776,9 +770,18 @@ __global__ __launch_bounds__(64) void k_mg_persistent(const MgArgs a, const MgIt
             }
         }
         __syncthreads();
-        // ---- ... and advances: optimiser step, or Laplace posterior and its sigma points, or the mixture and the next time step ----------
-        if (leader && s_n[g] > 0) mg_advance_one<PM, PX>(a, b, LdsResults<TPW, PER, D>{o_ll, o_m, o_P, o_st, g});
+        // ---- the group's first lane advances: optimiser step, or Laplace posterior and its sigma points, or the mixture and the next
+        // time step - and says what the trajectory waits for next
+        if (leader && s_n[g] > 0) {
+            mg_advance_one<PM, PX, LdsResults<TPW, PER, D>, true>(*tp, a, b, LdsResults<TPW, PER, D>{o_ll, o_m, o_P, o_st, g});
+            s_n[g] = tp->mode == 0 ? PX + 1 : (tp->mode == 1 ? a.NP : 0);
+        }
         __syncthreads();
+    }
+    if (leader) {                                              // what k_mg_finish reads: the last step's parameter posterior
+        TrajD<PM> &o = ((TrajD<PM> *)a.traj)[b];
+        for (int i = 0; i < PX; ++i) o.pm[i] = tp->pm[i];
+        for (int i = 0; i < PX * PX; ++i) o.pc[i] = tp->pc[i];
     }
     if (lane == 0) {
         atomicMax(&a.count[2], rounds);
@@ -823,7 +826,7 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
     const size_t o_th = take(th_bytes), o_tr = take(sizeof(TrajD<PM>) * (size_t)B), o_first = take(sizeof(int32_t) * (size_t)B), o_modes = take((size_t)B),
-                 o_count = take(sizeof(int32_t) * 4), o_tot = take(sizeof(unsigned long long) * 2), o_y = take(sizeof(double) * (size_t)B * T * Y),
+                 o_count = take(sizeof(int32_t) * 4), o_tot = take(sizeof(unsigned long long) * 8), o_y = take(sizeof(double) * (size_t)B * T * Y),
                  o_st = take(sizeof(double) * statics), o_fm = take(sizeof(double) * n_fm), o_fP = take(sizeof(double) * n_fP),
                  o_failed = take(sizeof(int32_t) * (size_t)B), o_tl = take(sizeof(double) * (size_t)B * P),
                  o_pl = take(sizeof(double) * (size_t)B * P * P);
@@ -854,7 +857,7 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
     SSMQ_HIP(hipMemcpyAsync(dev + o_st, hs.data(), sizeof(double) * statics, hipMemcpyHostToDevice, s));
     SSMQ_HIP(hipMemcpyAsync(dev + o_y, y, sizeof(double) * (size_t)B * T * Y, hipMemcpyHostToDevice, s));
     SSMQ_HIP(hipMemsetAsync(dev + o_count, 0, sizeof(int32_t) * 4, s));
-    SSMQ_HIP(hipMemsetAsync(dev + o_tot, 0, sizeof(unsigned long long) * 2, s));
+    SSMQ_HIP(hipMemsetAsync(dev + o_tot, 0, sizeof(unsigned long long) * 8, s));
     SSMQ_HIP(hipMemsetAsync(dev + o_fm, 0xff, sizeof(double) * (n_fm + 0), s));      // all-ones bit pattern: a NaN
     SSMQ_HIP(hipMemsetAsync(dev + o_fP, 0xff, sizeof(double) * n_fP, s));
     if ((rc = theta_dev_upload_static(a.th, h_dyn, h_obs, GQG, R, s))) return rc;
@@ -933,7 +936,7 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
     SSMQ_HIP(hipMemcpyAsync(failed, a.failed, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
     if (theta_last) SSMQ_HIP(hipMemcpyAsync(theta_last, dev + o_tl, sizeof(double) * (size_t)B * P, hipMemcpyDeviceToHost, s));
     if (pcov_last) SSMQ_HIP(hipMemcpyAsync(pcov_last, dev + o_pl, sizeof(double) * (size_t)B * P * P, hipMemcpyDeviceToHost, s));
-    unsigned long long tot[2] = {0, 0};
+    unsigned long long tot[8] = {0, 0};
     SSMQ_HIP(hipMemcpyAsync(hc, a.count, sizeof(hc), hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipMemcpyAsync(tot, a.totals, sizeof(tot), hipMemcpyDeviceToHost, s));
     SSMQ_HIP(hipStreamSynchronize(s));
