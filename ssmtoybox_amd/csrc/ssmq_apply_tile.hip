@@ -29,6 +29,12 @@ namespace ssmq {
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+#ifndef SSMQ_TILE_ALIAS
+#define SSMQ_TILE_ALIAS 0
+#endif
+#ifndef SSMQ_TILE_LATE_FETCH
+#define SSMQ_TILE_LATE_FETCH 1      // round 5: 0.2507 -> 0.2385 ms (D = E = 10, N = 21, B = 1e5; tools/tile_ab.sh)
+#endif
 constexpr int kTileWaves = 4;
 
 struct TileGeom {
@@ -36,23 +42,32 @@ struct TileGeom {
     int frag_doubles;     // workgroup-shared operand fragments
     int per_traj;         // a trajectory's part of the wave slice: factor + mean + FX tile (in_doubles), then its outputs [mean | cov | ccov]
     int in_doubles;
+    int out_off;          // where in a trajectory's part its outputs go
     int wave_doubles;     // per-wave slice
 };
 // k-steps a point set is padded to (the kernel is instantiated for these; padding = zero fragments, no loop guards)
 __host__ __device__ constexpr inline int tile_ksm(int N) {
     return N <= 16 ? 4 : N <= 24 ? 6 : N <= 32 ? 8 : N <= 52 ? 13 : 16;
 }
-__host__ __device__ inline TileGeom tile_geom(int D, int E, int N, bool tp) {
+__host__ __device__ inline TileGeom tile_geom(int D, int E, int N, bool tp, bool mrow = false) {
     TileGeom g;
     g.KS = tile_ksm(N);
     g.KSP = g.KS | 1;                       // odd pitch: the 64 lanes of a fragment read fall on distinct banks
     g.NB = (g.KS + 3) / 4;
     g.G = 64 / N < 4 ? 64 / N : 4;
     g.GL = 64 / g.G;
-    g.frag_doubles = 64 * ((tp ? 2 : 1) * g.NB * g.KS + 2 * g.KS) + N * (D | 1);     // + unit points [N][D | 1]
+    g.frag_doubles = 64 * ((tp ? 2 : 1) * g.NB * g.KS + (mrow ? 1 : 2) * g.KS) + N * (D | 1);     // + unit points [N][D | 1]; no wm fragments where the mean rides in Wcc
     g.frag_doubles = (g.frag_doubles + 1) & ~1;
     g.in_doubles = D * D + D + E * 4 * g.KSP;
+#if SSMQ_TILE_ALIAS
+    // the outputs of a trajectory overwrite its own inputs (read into registers by then): 54 KB per workgroup at D = E = 10,
+    // N = 21 instead of 74 - three workgroups per CU
+    g.out_off = 0;
+    g.per_traj = g.in_doubles > E + E * E + E * D ? g.in_doubles : E + E * E + E * D;
+#else
+    g.out_off = g.in_doubles;
     g.per_traj = g.in_doubles + E + E * E + E * D;
+#endif
     g.wave_doubles = g.G * g.per_traj + 2 + 64 + 16;   // per trajectory: factor + mean + FX tile; status words, column slots
     g.wave_doubles = (g.wave_doubles + 1) & ~1;
     return g;
@@ -75,24 +90,24 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
     constexpr int KSM = KS, NBM = (KS + 3) / 4, NB = NBM, KSP = KS | 1;
     const int D = a.D, E = a.E, N = a.N;
     const bool tp = a.tp_nu > 0.0, sigma = a.form == SSMQ_FORM_SIGMA;
-    const TileGeom tg = tile_geom(D, E, N, tp);
+    // BQ form, D <= 15: row 15 of the Wcc operand is free and carries wm, so the transformed mean comes out of the
+    // cross-covariance product (accumulator register 3 of the lanes q = 3) instead of a separate sum + cross-lane adds
+    const bool mrow = !sigma && D <= 15 && a.wave_k == 0;     // (wave_k = 1: SSMQ_TILE_NO_MROW, to test the D = 16 path on smaller models)
+    const TileGeom tg = tile_geom(D, E, N, tp, mrow);
     const int G = tg.G, GL = tg.GL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const WideLayout cl = wide_layout(D, E, N, a.form);
     const double *cs = a.consts;
     const double nan = __builtin_nan("");
-    // BQ form, D <= 15: row 15 of the Wcc operand is free and carries wm, so the transformed mean comes out of the
-    // cross-covariance product (accumulator register 3 of the lanes q = 3) instead of a separate sum + cross-lane adds
-    const bool mrow = !sigma && D <= 15 && a.wave_k == 0;     // (wave_k = 1: SSMQ_TILE_NO_MROW, to test the D = 16 path on smaller models)
     const int kq = mrow ? 3 : 0;                      // the k sub-index whose lanes hold the mean for the m m' product
 
     // ---- operand fragments of the constants, once per workgroup ---------------------------------------------------------
     double *fWc = lds;                              // [NB][KS][64]  lane (c, q): Wc[16 blk + c][4 s + q]
     double *fIK = fWc + NB * KS * 64;               // the same of iK (t-process only)
     double *fWcc = fIK + (tp ? NB * KS * 64 : 0);   // [KS][64]      lane (c, q): Wcc[c][4 s + q]
-    double *fWm = fWcc + KS * 64;                   // [KS][64]      lane (c, q): wm[4 s + q]
-    double *sXi = fWm + KS * 64;                    // [N][D | 1]    unit sigma points
+    double *fWm = fWcc + KS * 64;                   // [KS][64]      lane (c, q): wm[4 s + q]  (not with mrow)
+    double *sXi = fWm + (mrow ? 0 : KS * 64);       // [N][D | 1]    unit sigma points
     for (int i = threadIdx.x; i < N * D; i += 64 * kTileWaves) sXi[(i / D) * (D | 1) + i % D] = cs[cl.xiT + i];
     for (int i = threadIdx.x; i < NB * KS * 64; i += 64 * kTileWaves) {
         const int l = i & 63, s = (i >> 6) % KS, blk = (i >> 6) / KS;
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
         if (d < D && n < N) w = sigma ? cs[cl.xiT + n * D + d] * cs[cl.Wc + n] : cs[cl.Wcc + d * N + n];
         if (mrow && d == 15 && n < N) w = cs[cl.wm + n];      // BQ form: the mean rides along as row 15 of P' = Wcc FX'
         fWcc[i] = w;
-        fWm[i] = n < N ? cs[cl.wm + n] : 0.0;
+        if (!mrow) fWm[i] = n < N ? cs[cl.wm + n] : 0.0;
     }
     // ---- the wave's slice: factor + mean and FX tile per trajectory --------------------------------------------------------
     double *wbase = lds + tg.frag_doubles + (size_t)wave * tg.wave_doubles;
@@ -184,7 +199,9 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
 #pragma unroll
         for (int k = 0; k < DM; ++k) rowv[k] = in_row[k];
         const double my_m = in_m;
+#if !SSMQ_TILE_LATE_FETCH
         fetch(grp + grp_step < n_groups ? grp + grp_step : (grp < n_groups ? grp : n_groups - 1));
+#endif
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < DM; ++j) {
@@ -253,14 +270,28 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
 #pragma unroll
             for (int e = 0; e < DM; ++e)                 // a covariance that is not positive definite poisons every output
                 if (e < E) sfx[e * 4 * KSP + pos] = ok ? o[e] : nan;
+#if SSMQ_TILE_ALIAS
+            // the previous iteration's outputs lay over this tile: its padding (points N ... 4 KS - 1) is zeroed again
+            for (int np = N + gl; np < 4 * KS; np += GL) {
+                const int pp = (np & 3) * KSP + (np >> 2);
+#pragma unroll
+                for (int e = 0; e < DM; ++e)
+                    if (e < E) sfx[e * 4 * KSP + pp] = 0.0;
+            }
+#endif
         }
         SSMQ_WAVE_SYNC();
         // The next group's inputs (requested at the top of this iteration) are taken into registers NOW, while nothing else is
         // outstanding: the compiler would otherwise wait for them at their first use, after this iteration's stores have been
         // issued - and the in-order memory counter then makes that wait cover every store acknowledgement as well.
+#if SSMQ_TILE_LATE_FETCH
+        // (requested HERE: the rows are not live across the integrand, the kernel's register peak; the matrix phase covers the trip)
+        fetch(grp + grp_step < n_groups ? grp + grp_step : (grp < n_groups ? grp : n_groups - 1));
+#else
 #pragma unroll
         for (int k = 0; k < DM; ++k) asm volatile("" : "+v"(in_row[k]));
         asm volatile("" : "+v"(in_m));
+#endif
         // ---- 3. one trajectory at a time on the matrix cores; lane (c, q) = column c, k sub-index q ------------------------------
         for (int g = 0; g < G; ++g) {
             const int64_t bb = b0 + g;
@@ -318,7 +349,7 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
             const double am = (q == kq) ? mc : 0.0;
             if (!sigma) cov = __builtin_amdgcn_mfma_f64_16x16x4f64(-am, am, cov, 0, 0, 0);
             // ---- outputs of this trajectory into its part of the slice: [mean | cov (e2 <= e1 mirrored) | ccov] ------------------------
-            double *so = wbase + g * per_traj + tg.in_doubles;
+            double *so = wbase + g * per_traj + tg.out_off;
             if (q == kq && c < E) so[c] = mc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -341,13 +372,18 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
         //         4 G consecutive doubles (96 bytes at G = 3), written as 16-byte pieces by neighbouring lanes.  (Round 3 stored
         //         from the accumulators: every lane 8 bytes to a plane of its own, 24-byte fragments per plane and wave - 1.03 M
         //         store instructions and 426 MB of partial-sector writes for a 168 MB payload at D = E = 10, N = 21, B = 1e5.) -----
+#if SSMQ_TILE_LATE_FETCH
+#pragma unroll
+        for (int k = 0; k < DM; ++k) asm volatile("" : "+v"(in_row[k]));      // (taken before the stores are issued, see above)
+        asm volatile("" : "+v"(in_m));
+#endif
         __syncthreads();
         {
             const int64_t bc = (grp - wave) * G;                        // first trajectory of the workgroup's chunk
             const int64_t left = B - bc;
             const int nt = (int)(left < (int64_t)(kTileWaves * G) ? left : (int64_t)(kTileWaves * G));
             const int pp = (nt + 1) >> 1;                               // pieces of two trajectories per plane
-            const double *sall = lds + tg.frag_doubles + tg.in_doubles;
+            const double *sall = lds + tg.frag_doubles + tg.out_off;
             // GC > 0: a full chunk of 4 GC trajectories with the group count at compile time - the index maps below are divisions
             // by constants (multiply-shift); at run-time divisors they were 150 of the kernel's 540 vector instructions per
             // trajectory (profiles/r04_tile_sq.txt), in a kernel whose vector and matrix instructions share one pipe
@@ -386,7 +422,10 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
 
 template <int DM, int KS, int FC>
 hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
-    const TileGeom tg = tile_geom(a.D, a.E, a.N, a.tp_nu > 0.0);
+    WideArgs aw = a;
+    aw.wave_k = getenv("SSMQ_TILE_NO_MROW") ? 1 : 0;
+    const bool mrow = a.form != SSMQ_FORM_SIGMA && a.D <= 15 && aw.wave_k == 0;
+    const TileGeom tg = tile_geom(a.D, a.E, a.N, a.tp_nu > 0.0, mrow);
     const size_t lds = sizeof(double) * ((size_t)tg.frag_doubles + (size_t)kTileWaves * tg.wave_doubles);
     if (lds > 48 * 1024) {     // per device and instantiation; a cheap call, rare shapes
         hipError_t e = hipFuncSetAttribute((const void *)k_apply_tile<DM, KS, FC>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -396,8 +435,11 @@ hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
     const int64_t groups = (B + tg.G - 1) / tg.G, blocks = (groups + kTileWaves - 1) / kTileWaves;
     // a few workgroups per CU, each walking its share of the batch: the constants' fragments are built once per workgroup
     const int64_t cap = 256 * SSMQ_TILE_WGS_PER_CU;
-    WideArgs aw = a;
-    aw.wave_k = getenv("SSMQ_TILE_NO_MROW") ? 1 : 0;
+    if (getenv("SSMQ_TILE_DEBUG")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_apply_tile<DM, KS, FC>, 64 * kTileWaves, lds);
+        fprintf(stderr, "k_apply_tile: %zu bytes of LDS, %d workgroups per CU\n", lds, nb);
+    }
     hipLaunchKernelGGL((k_apply_tile<DM, KS, FC>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(64 * kTileWaves), lds, s,
                        aw, B);
     return hipGetLastError();
