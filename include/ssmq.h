@@ -16,14 +16,19 @@
  *   - return value: 0 ok; > 0 = 1 + index of the first batch item whose input covariance is not positive definite
  *     (the reference raises numpy.linalg.LinAlgError there: bq/bqmtran.py:98, mtran.py:139); < 0 error
  *     (SSMQ_E_*); ssmq_last_error() gives the text.  No exception crosses the ABI.
- *   - a transform handle is bound to the device that was current when it was created.  The library keeps process-global
- *     state - one HIP stream, grow-only workspaces and pinned staging blocks, cached launch graphs, the communicator.
- *     Threads: every compute entry point takes one process-wide (recursive) lock for its duration, so calls from several
- *     threads - on the same handle or on different ones - are safe and run one after the other; the *_dev entry points stay
- *     asynchronous with respect to the device (they queue on the library's stream and return).  The ssmq_comm_* entry points
- *     are outside that lock and belong to one thread.  One process per GPU is the intended deployment; a
- *     process that drives several devices does so one call at a time through ssmq_set_device(), which drops the caches of the
- *     device it leaves.
+ *   - a transform handle is bound to the device that was current when it was created.
+ *     Threads (round 5): every calling thread has a CONTEXT of its own - one HIP stream and the caches that belong to a stream
+ *     (grow-only workspaces, pinned staging blocks, captured launch graphs).  Calls of different threads on different handles
+ *     run concurrently, on the host and - stream by stream - on the device.  A handle is locked for the duration of every
+ *     entry point that takes it (two handles in address order), so calls of several threads on the SAME handle are safe and
+ *     run one after the other; a thread that picks up a handle last used by another thread first waits for that thread's
+ *     stream, so constants uploaded or buffers built there are complete.  The *_dev entry points queue on the CALLING
+ *     thread's stream and return; ssmq_sync() / events / copies act on that stream.  Device buffers the caller hands from one
+ *     thread to another are the caller's to order (ssmq_sync() in the thread that queued the work), as with any per-thread
+ *     stream.  A thread that ends returns its context (stream and caches intact) to a pool for the next new thread.  The
+ *     ssmq_comm_* entry points belong to one thread.  One process per GPU is the intended deployment: HIP's
+ *     current device is per thread and starts at 0, so a thread's first call moves it to the device of the last
+ *     ssmq_set_device(); a context that finds its thread on another device drops its caches and binds there.
  *   - there is NO CPU fallback anywhere behind this ABI: without a usable gfx950 device every compute entry point
  *     returns SSMQ_E_HIP.
  */

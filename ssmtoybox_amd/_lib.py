@@ -341,32 +341,41 @@ class _ScratchPool:
     limit = 4 << 30
 
     def __init__(self):
+        import threading
         self.blocks = []          # (capacity, ptr), oldest first
         self.cached = 0
+        self.lock = threading.Lock()     # threads have their own streams (include/ssmq.h): a block comes back only after the
+                                         # thread that used it has synchronised (every caller downloads its results first)
 
     def take(self, nbytes):
-        best = None
-        for i, (cap, ptr) in enumerate(self.blocks):
-            if nbytes <= cap <= 2 * nbytes + 4096 and (best is None or cap < self.blocks[best][0]):
-                best = i
-        if best is None:
-            return None
-        cap, ptr = self.blocks.pop(best)
-        self.cached -= cap
-        return cap, ptr
+        with self.lock:
+            best = None
+            for i, (cap, ptr) in enumerate(self.blocks):
+                if nbytes <= cap <= 2 * nbytes + 4096 and (best is None or cap < self.blocks[best][0]):
+                    best = i
+            if best is None:
+                return None
+            cap, ptr = self.blocks.pop(best)
+            self.cached -= cap
+            return cap, ptr
 
     def give(self, cap, ptr):
-        self.blocks.append((cap, ptr))
-        self.cached += cap
-        while self.cached > self.limit and self.blocks:
-            c, p = self.blocks.pop(0)
-            self.cached -= c
+        drop = []
+        with self.lock:
+            self.blocks.append((cap, ptr))
+            self.cached += cap
+            while self.cached > self.limit and self.blocks:
+                c, p = self.blocks.pop(0)
+                self.cached -= c
+                drop.append(p)
+        for p in drop:
             load().ssmq_free(ctypes.c_void_p(p))
 
     def flush(self):
-        for c, p in self.blocks:
+        with self.lock:
+            blocks, self.blocks, self.cached = self.blocks, [], 0
+        for c, p in blocks:
             load().ssmq_free(ctypes.c_void_p(p))
-        self.blocks, self.cached = [], 0
 
 
 _scratch_pool = _ScratchPool()

@@ -1,6 +1,7 @@
 // C ABI of libssmq (include/ssmq.h): device plumbing, transform handles, kernel dispatch.  No CPU fallback exists
 // behind these entry points: every compute call ends in a HIP kernel launch or returns an error.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -15,15 +16,8 @@
 namespace ssmq {
 
 static thread_local std::string g_err;
-static hipStream_t g_stream = nullptr;
-static int g_stream_dev = -1;
 
 void set_error(const std::string &msg) { g_err = msg; }
-
-std::recursive_mutex &api_mutex() {
-    static std::recursive_mutex m;
-    return m;
-}
 
 int hip_fail(hipError_t e, const char *what) {
     if (e == hipSuccess) return SSMQ_OK;
@@ -31,10 +25,49 @@ int hip_fail(hipError_t e, const char *what) {
     return SSMQ_E_HIP;
 }
 
-// Process-wide caches that hold memory / graphs of ONE device (the matrix-core scratch, the filter workspace with its
-// captured launch loop, per-function attributes): dropped when the calling thread's current device changes, so that a
-// workspace or graph of the previous device is never used from the new device's stream.  The library keeps one stream
-// and one set of caches: one device at a time per process, calls serialised by the caller (include/ssmq.h).
+// ---- per-thread contexts (ssmq_host.h) ------------------------------------------------------------------------------------
+namespace {
+struct CtxRegistry {
+    std::mutex mu;                 // guards the free list, and every creation / destruction of a context's stream
+    std::vector<Ctx *> free_list;
+};
+CtxRegistry &registry() {          // leaked on purpose: threads may end after the static destructors have run
+    static CtxRegistry *r = new CtxRegistry;
+    return *r;
+}
+std::atomic<unsigned> g_epoch_counter{0};
+std::atomic<int> g_preferred_device{-1};     // the device of the last ssmq_set_device(): where a new thread starts
+struct CtxHolder {
+    Ctx *c = nullptr;
+    ~CtxHolder() {                 // the thread ends: its context (stream, caches) goes back to the pool as it is
+        if (!c) return;
+        CtxRegistry &r = registry();
+        std::lock_guard<std::mutex> l(r.mu);
+        r.free_list.push_back(c);
+        c = nullptr;
+    }
+};
+thread_local CtxHolder t_holder;
+thread_local bool t_first_call = true;
+}  // namespace
+
+Ctx &ctx() {
+    if (!t_holder.c) {
+        CtxRegistry &r = registry();
+        std::lock_guard<std::mutex> l(r.mu);
+        if (!r.free_list.empty()) {
+            t_holder.c = r.free_list.back();
+            r.free_list.pop_back();
+        } else {
+            t_holder.c = new Ctx;
+        }
+    }
+    return *t_holder.c;
+}
+
+// Caches that hold memory / graphs of ONE device (the matrix-core scratch, the filter workspace with its captured launch
+// loop, staging blocks): the calling thread's context drops them when it binds to another device, so that a workspace or graph
+// of the previous device is never used from the new device's stream.
 void reset_device_caches();
 
 int ensure_device() {
@@ -46,22 +79,61 @@ int ensure_device() {
     }
     int dev = 0;
     SSMQ_HIP(hipGetDevice(&dev));
-    if (g_stream == nullptr || g_stream_dev != dev) {
-        if (g_stream != nullptr) {          // leaving a device: finish its work, release what was cached on it
-            hipSetDevice(g_stream_dev);
-            hipStreamSynchronize(g_stream);
+    if (t_first_call) {            // HIP's current device is per thread and starts at 0: a new thread starts where the library is
+        t_first_call = false;
+        const int pref = g_preferred_device.load();
+        if (pref >= 0 && pref < n && pref != dev) {
+            SSMQ_HIP(hipSetDevice(pref));
+            dev = pref;
+        }
+    }
+    Ctx &c = ctx();
+    if (c.stream == nullptr || c.dev != dev) {
+        std::lock_guard<std::mutex> l(registry().mu);
+        if (c.stream != nullptr) {          // leaving a device: finish the context's work, release what it cached there
+            hipSetDevice(c.dev);
+            hipStreamSynchronize(c.stream);
             reset_device_caches();
-            hipStreamDestroy(g_stream);
-            g_stream = nullptr;
+            hipStreamDestroy(c.stream);
+            c.stream = nullptr;
             SSMQ_HIP(hipSetDevice(dev));
         }
-        SSMQ_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-        g_stream_dev = dev;
+        SSMQ_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        c.dev = dev;
+        c.epoch = ++g_epoch_counter;
     }
     return SSMQ_OK;
 }
 
-hipStream_t stream() { return g_stream; }
+hipStream_t stream() { return ctx().stream; }
+unsigned device_epoch() { return ctx().epoch; }
+
+HandleGuard::HandleGuard(const ssmq_transform *h0, const ssmq_transform *h1) : a(h0), b(h1) {
+    if (b == a) b = nullptr;
+    if (!a) { a = b; b = nullptr; }
+    if (a && b && b < a) std::swap(a, b);          // two handles: always in address order
+    if (a) a->mu.lock();
+    if (b) b->mu.lock();
+    if (!a) return;
+    (void)ensure_device();                         // (a failure is reported by the entry point's own call)
+    Ctx &me = ctx();
+    for (const ssmq_transform *h : {a, b}) {
+        if (!h || (h->owner == &me && h->owner_epoch == me.epoch)) continue;
+        if (h->owner) {
+            // last used from another context: what that context queued on its stream - uploads of the handle's constants, buffers
+            // built on first use, kernels still reading them - is complete before this one goes on
+            std::lock_guard<std::mutex> l(registry().mu);
+            const Ctx *o = (const Ctx *)h->owner;
+            if (o->stream && o->epoch == h->owner_epoch) hipStreamSynchronize(o->stream);
+        }
+        h->owner = &me;
+        h->owner_epoch = me.epoch;
+    }
+}
+HandleGuard::~HandleGuard() {
+    if (b) b->mu.unlock();
+    if (a) a->mu.unlock();
+}
 
 void fill_fpar(const ssmq_integrand *f, FPar *fp) {
     memset(fp, 0, sizeof(*fp));
@@ -400,8 +472,8 @@ static int check_integrand(const ssmq_transform *h, const ssmq_integrand *f, FIn
 // Grow-only scratch of the matrix-core route (asynchronous callers cannot own temporaries): FX and T = FX Wc as
 // (B E) x NP row-major, the Cholesky factors [B][D][D].
 constexpr int64_t kGemmMinRows = 256;
-static void *g_gemm_ws = nullptr;
-static size_t g_gemm_ws_bytes = 0;
+#define g_gemm_ws (ssmq::ctx().gemm_ws)                  // (the calling thread's context: ssmq_host.h)
+#define g_gemm_ws_bytes (ssmq::ctx().gemm_ws_bytes)
 static int gemm_scratch(int64_t M, int NP, int64_t B, int D, double **fx, double **tt, double **chol, bool fused = false) {
     // three-pass route: FX | T | factors; two-pass route: FX | transformed means as rows | factors
     const size_t n_fx = (size_t)M * NP, n_t = fused ? (size_t)M : n_fx,
@@ -533,8 +605,8 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
         const int tpw = bq_stream_tpw(h->E);
         const int64_t M = (B + tpw - 1) / tpw * 64;
         // the last, partly empty round of workgroups is cut by panel (ssmq_bq_stream.hip: bq_stream_split): room for the parts
-        static int cus = 0;
-        static unsigned cus_epoch = ~0u;
+        static thread_local int cus = 0;
+        static thread_local unsigned cus_epoch = ~0u;
         if (cus_epoch != device_epoch()) {
             int dev = 0;
             hipDeviceProp_t prop;
@@ -646,7 +718,12 @@ struct StagingArena {
         dev_bytes = hin_bytes = hout_bytes = 0;
     }
 };
-StagingArena g_stage;
+StagingArena &stage_of_ctx() {
+    Ctx &c = ssmq::ctx();
+    if (!c.stage) c.stage = new StagingArena;
+    return *(StagingArena *)c.stage;
+}
+#define g_stage (stage_of_ctx())
 
 // memcpy between caller memory and the pinned blocks; large blocks on several threads (one core moves ~8 GB/s, which
 // would cost more than the PCIe transfer it feeds)
@@ -677,7 +754,6 @@ int ssmq_version(void) { return SSMQ_VERSION; }
 const char *ssmq_last_error(void) { return g_err.c_str(); }
 
 int ssmq_device_count(int *n) {
-    SSMQ_API_LOCK();
     if (!n) return SSMQ_E_ARG;
     *n = 0;
     hipError_t e = hipGetDeviceCount(n);
@@ -688,17 +764,16 @@ int ssmq_device_count(int *n) {
     return SSMQ_OK;
 }
 int ssmq_set_device(int device) {
-    SSMQ_API_LOCK();
     SSMQ_HIP(hipSetDevice(device));
+    t_first_call = false;
+    g_preferred_device.store(device);            // threads that make their first call from now on start here
     return ensure_device();
 }
 int ssmq_current_device(void) {
-    SSMQ_API_LOCK();
     if (ensure_device()) return -1;
-    return g_stream_dev;
+    return ctx().dev;
 }
 int ssmq_device_name(char *buf, int len) {
-    SSMQ_API_LOCK();
     if (!buf || len <= 0) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -710,7 +785,6 @@ int ssmq_device_name(char *buf, int len) {
     return SSMQ_OK;
 }
 int ssmq_device_pci_bus_id(char *buf, int len) {
-    SSMQ_API_LOCK();
     if (!buf || len < 13) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -721,7 +795,6 @@ int ssmq_device_pci_bus_id(char *buf, int len) {
 }
 
 int ssmq_malloc(void **dptr, size_t bytes) {
-    SSMQ_API_LOCK();
     if (!dptr) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -729,13 +802,11 @@ int ssmq_malloc(void **dptr, size_t bytes) {
     return SSMQ_OK;
 }
 int ssmq_free(void *dptr) {
-    SSMQ_API_LOCK();
     if (!dptr) return SSMQ_OK;
     SSMQ_HIP(hipFree(dptr));
     return SSMQ_OK;
 }
 int ssmq_memcpy_h2d(void *dst, const void *src, size_t bytes) {
-    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream()));
@@ -743,7 +814,6 @@ int ssmq_memcpy_h2d(void *dst, const void *src, size_t bytes) {
     return SSMQ_OK;
 }
 int ssmq_memcpy_d2h(void *dst, const void *src, size_t bytes) {
-    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream()));
@@ -751,21 +821,18 @@ int ssmq_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     return SSMQ_OK;
 }
 int ssmq_memcpy_d2d(void *dst, const void *src, size_t bytes) {
-    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream()));
     return SSMQ_OK;
 }
 int ssmq_memset(void *dptr, int value, size_t bytes) {
-    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipMemsetAsync(dptr, value, bytes, stream()));
     return SSMQ_OK;
 }
 int ssmq_sync(void) {
-    SSMQ_API_LOCK();
     int rc = ensure_device();
     if (rc) return rc;
     SSMQ_HIP(hipStreamSynchronize(stream()));
@@ -773,7 +840,6 @@ int ssmq_sync(void) {
 }
 
 int ssmq_aos_to_soa(const double *d_aos, double *d_soa, int n, int64_t B, int64_t ld) {
-    SSMQ_API_LOCK();
     if (!d_aos || !d_soa || n <= 0 || B < 0 || ld < B) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -783,7 +849,6 @@ int ssmq_aos_to_soa(const double *d_aos, double *d_soa, int n, int64_t B, int64_
     return hip_fail(hipGetLastError(), "k_aos_to_soa");
 }
 int ssmq_soa_to_aos(const double *d_soa, double *d_aos, int n, int64_t B, int64_t ld) {
-    SSMQ_API_LOCK();
     if (!d_aos || !d_soa || n <= 0 || B < 0 || ld < B) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -794,7 +859,6 @@ int ssmq_soa_to_aos(const double *d_soa, double *d_aos, int n, int64_t B, int64_
 }
 
 int ssmq_event_create(void **ev) {
-    SSMQ_API_LOCK();
     if (!ev) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -804,19 +868,16 @@ int ssmq_event_create(void **ev) {
     return SSMQ_OK;
 }
 int ssmq_event_destroy(void *ev) {
-    SSMQ_API_LOCK();
     if (!ev) return SSMQ_OK;
     SSMQ_HIP(hipEventDestroy((hipEvent_t)ev));
     return SSMQ_OK;
 }
 int ssmq_event_record(void *ev) {
-    SSMQ_API_LOCK();
     if (!ev) return SSMQ_E_ARG;
     SSMQ_HIP(hipEventRecord((hipEvent_t)ev, stream()));
     return SSMQ_OK;
 }
 int ssmq_event_elapsed_ms(void *start, void *stop, float *ms) {
-    SSMQ_API_LOCK();
     if (!start || !stop || !ms) return SSMQ_E_ARG;
     SSMQ_HIP(hipEventSynchronize((hipEvent_t)stop));
     SSMQ_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
@@ -824,7 +885,6 @@ int ssmq_event_elapsed_ms(void *start, void *stop, float *ms) {
 }
 
 int ssmq_status_first(const int32_t *d_status, int64_t B, int64_t *first) {
-    SSMQ_API_LOCK();
     if (!d_status || !first || B < 0) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -848,7 +908,6 @@ int ssmq_status_first(const int32_t *d_status, int64_t B, int64_t *first) {
 ssmq_transform *ssmq_transform_create(int D, int E, int N, int form, const double *xi, const double *wm,
                                       const double *Wc, const double *Wcc, const double *emv, int emv_mode,
                                       double tp_nu, const double *tp_iK) {
-    SSMQ_API_LOCK();
     if (D < 1 || D > SSMQ_MAX_DIM || E < 1 || E > SSMQ_MAX_DIM || N < 1 || N > SSMQ_MAX_PTS ||
         (form != SSMQ_FORM_BQ && form != SSMQ_FORM_SIGMA) || !xi || !wm || !Wc || (form == SSMQ_FORM_BQ && !Wcc) ||
         (tp_nu > 0.0 && !tp_iK) || (emv_mode != SSMQ_EMV_DIAG && emv_mode != SSMQ_EMV_BROADCAST)) {
@@ -881,7 +940,6 @@ ssmq_transform *ssmq_transform_create(int D, int E, int N, int form, const doubl
 // The linearisation transform has neither points nor weights; the handle keeps a one-point placeholder block so that every
 // code path that sizes or frees constants finds what it expects.
 ssmq_transform *ssmq_transform_create_linear(int D, int E) {
-    SSMQ_API_LOCK();
     if (D < 1 || D > SSMQ_MAX_DIM || E < 1 || E > SSMQ_MAX_DIM) {
         set_error("transform_create_linear: bad argument");
         return nullptr;
@@ -896,7 +954,7 @@ ssmq_transform *ssmq_transform_create_linear(int D, int E) {
 
 int ssmq_transform_update(ssmq_transform *h, const double *xi, const double *wm, const double *Wc, const double *Wcc,
                           const double *emv, int emv_mode, double tp_nu, const double *tp_iK) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h);
     if (h && h->form == SSMQ_FORM_TAYLOR1) {
         set_error("transform_update: the linearisation transform has no constants");
         return SSMQ_E_ARG;
@@ -921,8 +979,11 @@ int ssmq_transform_update(ssmq_transform *h, const double *xi, const double *wm,
 }
 
 void ssmq_transform_destroy(ssmq_transform *h) {
-    SSMQ_API_LOCK();
     if (!h) return;
+    {   // whatever context used the handle last has finished with its device blocks (the guard waits for that stream) ...
+        SSMQ_HANDLE_LOCK(h);
+        if (ssmq::stream()) hipStreamSynchronize(ssmq::stream());
+    }   // ... and nobody may hold the handle any more: destroying it while another thread uses it is the caller's error
     if (h->d_small) hipFree(h->d_small);
     if (h->d_wide) hipFree(h->d_wide);
     if (h->d_wc_pad) hipFree(h->d_wc_pad);
@@ -935,7 +996,7 @@ void ssmq_transform_destroy(ssmq_transform *h) {
 }
 
 int ssmq_transform_dims(const ssmq_transform *h, int *D, int *E, int *N) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h);
     if (!h) return SSMQ_E_ARG;
     if (D) *D = h->D;
     if (E) *E = h->E;
@@ -947,7 +1008,7 @@ int ssmq_transform_dims(const ssmq_transform *h, int *D, int *E, int *N) {
 int ssmq_apply_batch_dev(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_t ld, const double *d_mean,
                          const double *d_cov, const double *d_time, int time_stride, double *d_mean_f,
                          double *d_cov_f, double *d_cov_fx, int32_t *d_status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h);
     if (!h || !f) return SSMQ_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -956,7 +1017,7 @@ int ssmq_apply_batch_dev(ssmq_transform *h, const ssmq_integrand *f, int64_t B, 
 }
 
 int ssmq_apply_kernel_name(const ssmq_transform *h, const ssmq_integrand *f, char *buf, int len) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h);
     if (!h || !f || !buf || len <= 0) return SSMQ_E_ARG;
     const char *name = nullptr;
     int rc = apply_dev_impl(const_cast<ssmq_transform *>(h), f, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
@@ -1009,7 +1070,6 @@ constexpr size_t kPlaneChunkBytes = size_t(128) << 20;
 }  // namespace
 
 int ssmq_upload_planes(const double *host, int n_outer, int n_elem, int64_t B, int64_t ld, double *d_planes) {
-    SSMQ_API_LOCK();
     if (!host || !d_planes || n_outer < 0 || n_elem < 1 || B < 0 || ld < B) {
         set_error("upload_planes: bad argument");
         return SSMQ_E_ARG;
@@ -1031,7 +1091,6 @@ int ssmq_upload_planes(const double *host, int n_outer, int n_elem, int64_t B, i
 }
 
 int ssmq_download_planes(const double *d_planes, int n_outer, int n_elem, int64_t B, int64_t ld, double *host) {
-    SSMQ_API_LOCK();
     if (!host || !d_planes || n_outer < 0 || n_elem < 1 || B < 0 || ld < B) {
         set_error("download_planes: bad argument");
         return SSMQ_E_ARG;
@@ -1055,7 +1114,7 @@ int ssmq_download_planes(const double *d_planes, int n_outer, int n_elem, int64_
 int ssmq_apply_batch(ssmq_transform *h, const ssmq_integrand *f, int64_t B, const double *mean, const double *cov,
                      const double *time, int time_stride, double *mean_f, double *cov_f, double *cov_fx,
                      int32_t *status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h);
     if (!h || !f || B < 0 || !mean || !cov || !mean_f || !cov_f || !cov_fx) {
         set_error("apply_batch: null argument");
         return SSMQ_E_ARG;
@@ -1150,7 +1209,7 @@ int ssmq_apply_batch(ssmq_transform *h, const ssmq_integrand *f, int64_t B, cons
 
 int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, const double *cov, double *x,
                             double *chol, int32_t *status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h);
     if (h && h->form == SSMQ_FORM_TAYLOR1) {
         set_error("the linearisation transform has no sigma points");
         return SSMQ_E_UNSUPPORTED;
@@ -1197,7 +1256,7 @@ int ssmq_sigma_points_batch(ssmq_transform *h, int64_t B, const double *mean, co
 
 int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const double *mean, const double *x,
                         const double *fx, double *mean_f, double *cov_f, double *cov_fx) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h);
     if (h && h->form == SSMQ_FORM_TAYLOR1) {
         set_error("the linearisation transform has no sigma points");
         return SSMQ_E_UNSUPPORTED;
@@ -1307,7 +1366,7 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
 // T = FX Wc on the matrix cores for device-resident integrand values (the GEMM-shaped stage of a large-N BQ transform)
 int ssmq_fxwc_batch_dev(ssmq_transform *h, int64_t M, const double *d_fx, int64_t ld_fx, double *d_t, int64_t ld_t,
                         int *n_padded) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h);
     if (h && h->form == SSMQ_FORM_TAYLOR1) {
         set_error("the linearisation transform has no sigma points");
         return SSMQ_E_UNSUPPORTED;
@@ -1335,7 +1394,6 @@ int ssmq_fxwc_batch_dev(ssmq_transform *h, int64_t M, const double *d_fx, int64_
 int ssmq_kalman_update_dev(int D, int Y, int64_t B, int64_t ld, const double *d_m_pr, const double *d_P_pr,
                            const double *d_y_mean, const double *d_P_y, const double *d_P_yx, const double *d_y,
                            double *d_m_fi, double *d_P_fi, int32_t *d_status) {
-    SSMQ_API_LOCK();
     if (D < 1 || Y < 1 || B < 0 || ld < B || !d_m_pr || !d_P_pr || !d_y_mean || !d_P_y || !d_P_yx || !d_y || !d_m_fi ||
         !d_P_fi || !d_status)
         return SSMQ_E_ARG;
@@ -1394,7 +1452,12 @@ struct FilterCache {
         key.clear();
     }
 };
-FilterCache g_fc;
+FilterCache &fc_of_ctx() {
+    Ctx &c = ssmq::ctx();
+    if (!c.fc) c.fc = new FilterCache;
+    return *(FilterCache *)c.fc;
+}
+#define g_fc (fc_of_ctx())
 // drops the captured loop on every exit of a scope whose temporaries the graph points into
 struct GraphDropGuard {
     ~GraphDropGuard() { g_fc.drop_graph(); }
@@ -1404,11 +1467,8 @@ struct GraphDropGuard {
 namespace ssmq {
 void reset_wide_attributes();
 void drop_staging_arena();
-static unsigned g_device_epoch = 1;
-unsigned device_epoch() { return g_device_epoch; }
 void drop_theta_step_graphs();
 void reset_device_caches() {
-    ++g_device_epoch;
     g_fc.drop_graph();
     drop_theta_step_graphs();
     g_fc.consts_ok = false;
@@ -1595,7 +1655,7 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
                                        const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                                        const double *d_m0, const double *d_P0, const double *GQG, const double *R,
                                        double *d_fm, double *d_fP, int32_t *d_status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     return filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, GQG, R, d_fm, d_fP, d_status,
                                nullptr, 0.0);
 }
@@ -1755,7 +1815,7 @@ extern "C" int ssmq_filter_forward_aug_dev(ssmq_transform *h_dyn, const ssmq_int
                                            const double *q_mean, const double *q_cov, int dq, const double *r_mean,
                                            const double *r_cov, int dr, double *d_fm, double *d_fP,
                                            int32_t *d_status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     return filter_forward_aug_impl(h_dyn, f_dyn, h_obs, f_obs, dim_state, B, ld, T, d_y, d_m0, d_P0, q_mean, q_cov, dq,
                                    r_mean, r_cov, dr, d_fm, d_fP, d_status, nullptr, nullptr, nullptr, nullptr);
 }
@@ -1775,7 +1835,7 @@ extern "C" int ssmq_filter_smooth_aug_dev(ssmq_transform *h_dyn, const ssmq_inte
                                           const double *q_mean, const double *q_cov, int dq, const double *r_mean,
                                           const double *r_cov, int dr, double *d_fm, double *d_fP, double *d_sm,
                                           double *d_sP, int32_t *d_status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     if (!h_dyn || !d_sm || !d_sP || dim_state <= 0 || dq < 0 || B < 0 || T < 0 || ld < B) {
         set_error("filter_smooth_aug: bad argument");
         return SSMQ_E_ARG;
@@ -1807,7 +1867,6 @@ extern "C" int ssmq_filter_smooth_aug_dev(ssmq_transform *h_dyn, const ssmq_inte
 extern "C" int ssmq_rts_backward_dev(int D, int64_t B, int64_t ld, int T, const double *d_fm, const double *d_fP,
                                      const double *d_pm, const double *d_pP, const double *d_pC, double *d_sm, double *d_sP,
                                      int32_t *d_status) {
-    SSMQ_API_LOCK();
     if (D < 1 || B < 0 || T < 0 || ld < B || !d_fm || !d_fP || !d_pm || !d_pP || !d_pC || !d_sm || !d_sP || !d_status) {
         set_error("rts_backward: bad argument");
         return SSMQ_E_ARG;
@@ -1826,7 +1885,7 @@ extern "C" int ssmq_filter_smooth_dev(ssmq_transform *h_dyn, const ssmq_integran
                                       const ssmq_integrand *f_obs, int64_t B, int64_t ld, int T, const double *d_y,
                                       const double *d_m0, const double *d_P0, const double *GQG, const double *R,
                                       double *d_fm, double *d_fP, double *d_sm, double *d_sP, int32_t *d_status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     if (!h_dyn || !d_sm || !d_sP || B < 0 || T < 0 || ld < B) {
         set_error("filter_smooth: bad argument");
         return SSMQ_E_ARG;
@@ -1864,7 +1923,7 @@ extern "C" int ssmq_student_filter_forward_dev(ssmq_transform *h_dyn, const ssmq
                                                const double *d_S0, const double *GqG, const double *r_smat,
                                                const double *scale, double dof, double *d_fm, double *d_fP,
                                                int32_t *d_status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     if (!scale || !(dof > 0.0)) {
         set_error("student_filter_forward: scale[T] and dof > 0 are required");
         return SSMQ_E_ARG;
@@ -1941,13 +2000,11 @@ extern "C" int ssmq_error_sums_width(int D) { return D >= 1 && D <= SSMQ_MAX_DIM
 
 extern "C" int ssmq_error_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm,
                                    const double *d_fP, const int32_t *d_status, double *sums) {
-    SSMQ_API_LOCK();
     return metrics_impl(1, D, B, ld, T, d_x, d_fm, d_fP, d_status, nullptr, sums);
 }
 
 extern "C" int ssmq_lcr_sums_dev(int D, int64_t B, int64_t ld, int T, const double *d_x, const double *d_fm,
                                  const double *d_fP, const int32_t *d_status, const double *mse, double *sums) {
-    SSMQ_API_LOCK();
     return metrics_impl(2, D, B, ld, T, d_x, d_fm, d_fP, d_status, mse, sums);
 }
 
@@ -1982,7 +2039,12 @@ struct ThetaGraph {
     hipGraph_t graph;
     hipGraphExec_t exec;
 };
-std::vector<ThetaGraph> g_theta_graphs;
+std::vector<ThetaGraph> &theta_graphs_of_ctx() {
+    Ctx &c = ssmq::ctx();
+    if (!c.theta_graphs) c.theta_graphs = new std::vector<ThetaGraph>;
+    return *(std::vector<ThetaGraph> *)c.theta_graphs;
+}
+#define g_theta_graphs (theta_graphs_of_ctx())
 void drop_theta_graphs() {
     for (auto &g : g_theta_graphs) {
         if (g.exec) hipGraphExecDestroy(g.exec);
@@ -2008,7 +2070,7 @@ extern "C" int ssmq_gp_theta_step(ssmq_transform *h_dyn, const ssmq_integrand *f
                                   double jitter, const double *mean, const double *cov, int shared_state,
                                   const double *y, int shared_y, double time, const double *GQG, const double *R,
                                   double *post_mean, double *post_cov, double *loglik, int32_t *status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     return gp_theta_step_impl(h_dyn, f_dyn, h_obs, f_obs, P, par_dyn, par_obs, jitter, mean, cov, shared_state, y, shared_y, time,
                               nullptr, GQG, R, post_mean, post_cov, loglik, status);
 }
@@ -2020,7 +2082,7 @@ extern "C" int ssmq_gp_theta_step_times(ssmq_transform *h_dyn, const ssmq_integr
                                         double jitter, const double *mean, const double *cov, int shared_state,
                                         const double *y, int shared_y, const double *times, const double *GQG, const double *R,
                                         double *post_mean, double *post_cov, double *loglik, int32_t *status) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     if (!times) {
         set_error("gp_theta_step_times: times is NULL");
         return SSMQ_E_ARG;
@@ -2387,7 +2449,6 @@ extern "C" int ssmq_simulate_rv_dev(const ssmq_integrand *f_dyn, const ssmq_inte
                                     const ssmq_rv *q, const ssmq_rv *r, const double *G, int dyn_additive, int obs_additive,
                                     int64_t B, int64_t ld, int T, int continuous, double dt, uint64_t seed,
                                     uint64_t traj_offset, double *d_x, double *d_y) {
-    SSMQ_API_LOCK();
     const int mode = (f_dyn ? 1 : 0) | (f_obs ? 2 : 0);
     auto rv_ok = [](const ssmq_rv *v, int dim) {
         return v && v->dim == dim && v->chol && v->kind >= SSMQ_RV_GAUSS && v->kind <= SSMQ_RV_MIXTURE &&
@@ -2479,7 +2540,6 @@ extern "C" int ssmq_simulate_dev(const ssmq_integrand *f_dyn, const ssmq_integra
                                  const double *x0_mean, const double *x0_chol, const double *q_mean,
                                  const double *q_chol, const double *G, const double *r_mean, const double *r_chol,
                                  uint64_t seed, uint64_t traj_offset, double *d_x, double *d_y) {
-    SSMQ_API_LOCK();
     ssmq_rv x0{SSMQ_RV_GAUSS, D, 1, 0, 0.0, x0_mean, x0_chol, nullptr};
     ssmq_rv q{SSMQ_RV_GAUSS, dq, 1, 0, 0.0, q_mean, q_chol, nullptr};
     ssmq_rv r{SSMQ_RV_GAUSS, dr, 1, 0, 0.0, r_mean, r_chol, nullptr};
@@ -2498,7 +2558,7 @@ extern "C" int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_i
 
 extern "C" int ssmq_filter_kernel_name_batch(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
                                              const ssmq_integrand *f_obs, int64_t B, char *buf, int len) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || !buf || len <= 0 || B < 0) return SSMQ_E_ARG;
     FInfo fio;
     if (!integrand_info(f_obs->id, &fio)) return SSMQ_E_ARG;

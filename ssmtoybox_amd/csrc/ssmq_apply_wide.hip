@@ -780,7 +780,7 @@ bool theta_chain_supported(int Din, int D, int Y, int Nd, int No) {
 
 template <int DM, bool GEN>
 static hipError_t launch_chain_one(const ThetaChainArgs &c, int64_t B, size_t lds, hipStream_t s) {
-    static unsigned attr_epoch = 0;
+    static thread_local unsigned attr_epoch = 0;
     if (lds > 48 * 1024 && attr_epoch != device_epoch()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_theta_chain<DM, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 64);
@@ -827,21 +827,21 @@ static size_t wide_lds_bytes_for(const WideArgs &a) {
 }
 
 // hipFuncSetAttribute is per device: ensure_device() clears the flag when the current device changes
-static bool attr_set = false;
-void reset_wide_attributes() { attr_set = false; }
+static thread_local unsigned attr_set_epoch = 0;       // (per thread context: ssmq_host.h)
+void reset_wide_attributes() { attr_set_epoch = 0; }
 
 hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s) {
     if (a.mode == SSMQ_WIDE_FULL && a.consts_stride == 0 && wide_full_uses_tile(a.D, a.E, a.N) && tile_pitch_ok(a)) return launch_apply_tile(a, B, s);
     if (wave_route(a)) return launch_apply_wave(a, B, s);
     const size_t lds = wide_lds_bytes_for(a);
-    if (!attr_set) {
+    if (attr_set_epoch != device_epoch()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_apply_wide<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 64);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_apply_wide<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 64);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set_epoch = device_epoch();
     }
     if ((int64_t)a.E * a.N >= 1024 && !getenv("SSMQ_WIDE_ONE_WAVE"))
         hipLaunchKernelGGL(k_apply_wide<256>, dim3((unsigned)B), dim3(256), lds, s, a);

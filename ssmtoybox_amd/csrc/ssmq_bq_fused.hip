@@ -481,7 +481,7 @@ int fused_dm(const WideArgs *a, int D, int E) {
 
 template <int NT, int DM, int FC, int WAVES>
 hipError_t launch_fused_one(const BqFusedArgs &g, size_t lds, hipStream_t s) {
-    static unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
+    static thread_local unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
     if (attr_epoch != device_epoch()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_bq_fused<NT, DM, FC, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            WAVES == 4 ? 80 * 1024 : 160 * 1024);

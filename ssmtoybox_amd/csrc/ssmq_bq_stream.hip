@@ -435,7 +435,7 @@ int launch_bq_stream(const WideArgs &a, const double *X, const double *emv, int 
         set_error("bq_stream: shape not supported");
         return SSMQ_E_UNSUPPORTED;
     }
-    static unsigned attr_epoch = 0;
+    static thread_local unsigned attr_epoch = 0;
     if (attr_epoch != device_epoch()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_bq_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStreamLds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_bq_stream)");

@@ -537,8 +537,8 @@ int try_launch_wsplit(const ssmq_transform *hd, const ssmq_integrand *fd, const 
 
 // compute units of the library's device (the wave-split kernel is chosen by how many workgroups the device can spread out)
 static int device_cus() {
-    static int cus = 0;
-    static unsigned epoch = ~0u;
+    static thread_local int cus = 0;
+    static thread_local unsigned epoch = ~0u;
     if (epoch != device_epoch() || !cus) {
         int dev = 0;
         hipDeviceProp_t p;

@@ -422,7 +422,7 @@ static hipError_t launch_wsplit(const FusedArgs &a, hipStream_t s) {
     constexpr size_t lds = (W == 4 && need < 81 * 1024) ? 81 * 1024 : need;
     static_assert(lds <= 160 * 1024, "exchange areas exceed the LDS of a CU");
     auto kern = k_filter_wsplit<D, Y, ND, NO, FD, FO, FORM, TP, SELO, W>;
-    static unsigned attr_epoch = ~0u;
+    static thread_local unsigned attr_epoch = ~0u;
     if (attr_epoch != device_epoch()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kGemmBlock, 2) void k_fxwc_cov_mfma(const double *_
 template <int NT>
 hipError_t launch_cov(const double *A, const double *X, int64_t M, int lda, const CovEpilogue &ep, hipStream_t s) {
     constexpr size_t lds = sizeof(double) * 2 * 16 * (NT * 16 + 16 + 4);
-    static unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
+    static thread_local unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
     if (attr_epoch != device_epoch()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_fxwc_cov_mfma<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
@@ -306,7 +306,7 @@ template <int NT, int RT>
 hipError_t launch_rt(const double *A, const double *Bm, double *T, int64_t M, int lda, int ldt, hipStream_t s, int KB = NT,
                      int ncb = 1) {
     constexpr size_t lds = sizeof(double) * 2 * 16 * (NT * 16 + 4);
-    static unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
+    static thread_local unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
     if (attr_epoch != device_epoch()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_fxwc_mfma<NT, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);

@@ -30,23 +30,49 @@ struct ssmq_transform {
     double *d_wc_blk = nullptr, *d_ik_blk = nullptr;
     int big_kb = 0, big_ncb = 0;   // k blocks of 16 points; column blocks of [Wc | pad to 16 big_kb | Wcc'] (big_ncb)
     uint32_t generation = 0;   // bumped by every upload of constants (create / update)
+    // Threads (include/ssmq.h, conventions): every entry point that takes this handle holds `mu` for its duration; `owner` /
+    // `owner_epoch` name the thread context (its stream) that used the handle last - another context waits for that stream
+    // before it touches the handle's device blocks (ssmq::HandleGuard).
+    mutable std::recursive_mutex mu;
+    mutable void *owner = nullptr;
+    mutable unsigned owner_epoch = 0;
 };
 
 namespace ssmq {
 
 void set_error(const std::string &msg);
-// The library's state is process-global (one stream, grow-only workspaces, staging blocks, graph caches): every compute entry
-// point of the C ABI holds this lock for its duration, so calls from several threads - on the same or on different handles -
-// are safe and run one after the other.  Recursive: entry points call each other (ssmq_gp_marginal_laplace_batch ->
-// ssmq_gp_theta_step).  The communicator entry points (ssmq_comm_*) do not take it: ncclCommInitRank may block for good on a
-// helper thread (mcshard.RcclComm) and must not take the rest of the library with it.
-std::recursive_mutex &api_mutex();
-#define SSMQ_API_LOCK() std::lock_guard<std::recursive_mutex> ssmq_api_lock_guard_(ssmq::api_mutex())
+// Threads.  Every calling thread has its own CONTEXT: a HIP stream and the caches that belong to a stream (grow-only workspaces,
+// pinned staging blocks, captured launch graphs).  Calls of different threads on different handles run concurrently - on the
+// host and, stream by stream, on the device.  Contexts are pooled: a thread that ends hands its context (stream and caches
+// intact) to the next new thread.  A handle is locked for the duration of every entry point that takes it (HandleGuard; two
+// handles in address order), and a context that picks up a handle last used by another one waits for that context's stream
+// first, so that constants uploaded or buffers built there are complete.  Device buffers the CALLER passes between threads are
+// the caller's to order (ssmq_sync() in the thread that queued the work), as with any per-thread stream.  The communicator entry
+// points (ssmq_comm_*) belong to one thread.
+struct Ctx {
+    hipStream_t stream = nullptr;
+    int dev = -1;
+    unsigned epoch = 0;                      // unique per (context, device binding): per-device function attributes, cached graphs
+    void *gemm_ws = nullptr;                 // scratch of the matrix-core routes (ssmq_api.hip)
+    size_t gemm_ws_bytes = 0;
+    void *stage = nullptr, *fc = nullptr, *theta_graphs = nullptr;      // ssmq_api.hip: StagingArena, FilterCache, theta graphs
+    void *pinned_flags = nullptr;            // 64 bytes of pinned host memory the device rounds report through (ssmq_marginal.hip)
+};
+Ctx &ctx();
+struct HandleGuard {
+    const ssmq_transform *a, *b;
+    explicit HandleGuard(const ssmq_transform *h0, const ssmq_transform *h1 = nullptr);
+    ~HandleGuard();
+    HandleGuard(const HandleGuard &) = delete;
+    HandleGuard &operator=(const HandleGuard &) = delete;
+};
+#define SSMQ_HANDLE_LOCK(...) ssmq::HandleGuard ssmq_handle_guard_(__VA_ARGS__)
 int hip_fail(hipError_t e, const char *what);
 hipStream_t stream();
 int ensure_device();
-// Bumped whenever the library moves to another device (reset_device_caches): per-function attributes
-// (hipFuncAttributeMaxDynamicSharedMemorySize) are per device and must be set again after a change.
+// The calling thread's context epoch: a new value whenever the context binds to a device (reset_device_caches); per-function
+// attributes (hipFuncAttributeMaxDynamicSharedMemorySize) are per device and are set again when a thread sees a new value
+// (the `static thread_local unsigned attr_epoch` of the launchers).
 unsigned device_epoch();
 
 #define SSMQ_HIP(call)                                        \

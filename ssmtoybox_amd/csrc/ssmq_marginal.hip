@@ -174,7 +174,7 @@ extern "C" int ssmq_gp_marginal_laplace_batch(ssmq_transform *h_dyn, const ssmq_
                                               const double *cov, const double *y, double time, const double *GQG, const double *R,
                                               const double *prior_mean, const double *prior_cov, double fd_step, double *theta,
                                               double *hess_inv, int32_t *status, int32_t *iters, int64_t *rounds_out) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || B < 0 || (B > 0 && (!mean || !cov || !y || !prior_mean || !prior_cov || !theta ||
                                                                      !hess_inv || !status))) {
         set_error("marginal_laplace_batch: null argument");
@@ -862,12 +862,9 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
     SSMQ_HIP(hipMemsetAsync(dev + o_fP, 0xff, sizeof(double) * n_fP, s));
     if ((rc = theta_dev_upload_static(a.th, h_dyn, h_obs, GQG, R, s))) return rc;
     const unsigned tb = 64, tg = (unsigned)((B + tb - 1) / tb);
-    static volatile int32_t *hf = nullptr;          // 64 bytes of pinned, device-visible host memory, kept for the process
-    if (!hf) {
-        void *p = nullptr;
-        SSMQ_HIP(hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped));
-        hf = (volatile int32_t *)p;
-    }
+    Ctx &cx = ctx();                                // 64 bytes of pinned, device-visible host memory, kept with the thread's context
+    if (!cx.pinned_flags) SSMQ_HIP(hipHostMalloc(&cx.pinned_flags, 64, hipHostMallocPortable | hipHostMallocMapped));
+    volatile int32_t *hf = (volatile int32_t *)cx.pinned_flags;
     hf[0] = (int32_t)std::min<int64_t>(B, 0x7fffffff);
     hf[1] = 0;
     a.hflag = hf;
@@ -955,7 +952,7 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
                                              const double *prior_cov, const double *upts, const double *uwts, int NP,
                                              double fd_step, double param_jitter, double *fm, double *fP, int32_t *failed,
                                              double *theta_last, double *pcov_last, int64_t *stats) {
-    SSMQ_API_LOCK();
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     if (!h_dyn || !h_obs || !f_dyn || !f_obs || B < 0 || T < 0 || (B > 0 && T > 0 && (!y || !x0_mean || !x0_cov || !prior_mean ||
         !prior_cov || !upts || !uwts || !fm || !fP || !failed))) {
         set_error("marginal_filter_batch: null argument");

@@ -1139,7 +1139,7 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(k_weights<256>, dim3(a.P), dim3(threads), sizeof(double) * 2 * nn, s, a);
         return hip_fail(hipGetLastError(), "k_weights");
     }
-    static unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
+    static thread_local unsigned attr_epoch = 0;   // per-device attribute: set again after a device change
     if (attr_epoch != ssmq::device_epoch()) {
         SSMQ_HIP(hipFuncSetAttribute((const void *)k_weights<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         SSMQ_HIP(hipFuncSetAttribute((const void *)k_weights_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
@@ -1149,7 +1149,7 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
     const bool unisolvent = a.NB == N && !a.var_mode;      // N x N LU inverse in one workgroup: not a large-N case in practice
     if (!staged && !unisolvent && !getenv("SSMQ_WEIGHTS_ONE_WG")) {
         // factor, inverse and the two N^3 products on many workgroups (k_wb_*), the rest in k_weights<1024> stages 3 and 4
-        static unsigned wb_epoch = 0;
+        static thread_local unsigned wb_epoch = 0;
         if (wb_epoch != ssmq::device_epoch()) {
             SSMQ_HIP(hipFuncSetAttribute((const void *)k_wb_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCbLds));
             SSMQ_HIP(hipFuncSetAttribute((const void *)k_wb_chol_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCbLds));
@@ -1462,7 +1462,7 @@ int gp_theta_weights_pair(const int D[2], const int E[2], const int N[2], const 
         lds = std::max(lds, sizeof(double) * theta_weights_lds_doubles(D[i], N[i]));
         if (N[i] > 8 || getenv("SSMQ_WEIGHTS_WIDE_BLOCK")) threads = 256;     // as launch_weights
     }
-    static unsigned attr_epoch = 0;
+    static thread_local unsigned attr_epoch = 0;
     if (lds > 48 * 1024 && attr_epoch != ssmq::device_epoch()) {
         SSMQ_HIP(hipFuncSetAttribute((const void *)k_theta_weights, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         attr_epoch = ssmq::device_epoch();
@@ -1604,7 +1604,6 @@ static bool rbf_args_ok(int D, int N, const double *x, const double *par, int P)
 
 extern "C" int ssmq_rbf_eval(int D, int N1, const double *x1, int N2, const double *x2, const double *par, int P,
                              int scaling, int diag, double *K) {
-    SSMQ_API_LOCK();
     using namespace ssmq;
     if (!x2) { x2 = x1; N2 = N1; }
     if (!rbf_args_ok(D, N1, x1, par, P) || N2 < 1 || N2 > SSMQ_MAX_PTS || !K || (diag && N1 != N2)) {
@@ -1633,7 +1632,6 @@ extern "C" int ssmq_rbf_eval(int D, int N1, const double *x1, int N2, const doub
 
 extern "C" int ssmq_rbf_factor(int D, int N, const double *x, const double *par, int P, int scaling, double jitter,
                                const double *rhs, double *chol, double *iK, int32_t *status) {
-    SSMQ_API_LOCK();
     using namespace ssmq;
     if (!rbf_args_ok(D, N, x, par, P) || (!chol && !iK)) {
         set_error("rbf_factor: bad argument");
@@ -1674,7 +1672,6 @@ extern "C" int ssmq_rbf_factor(int D, int N, const double *x, const double *par,
 
 extern "C" int ssmq_rbf_exp_kxkx(int D, int N, const double *x, const double *par0, const double *par1, int scaling,
                                  double *Q) {
-    SSMQ_API_LOCK();
     using namespace ssmq;
     if (!rbf_args_ok(D, N, x, par0, 1) || !par1 || !Q) {
         set_error("rbf_exp_kxkx: bad argument");
@@ -1714,7 +1711,6 @@ __global__ void k_bs_moments(int D, int N, int NB, const double *__restrict__ x,
 
 extern "C" int ssmq_bs_moments(int D, int N, const double *x, const double *par, const int32_t *mulind, int NB, double *px,
                                double *xpx, double *pxpx, double *kxpx, double *vand) {
-    SSMQ_API_LOCK();
     using namespace ssmq;
     if (D < 1 || D > SSMQ_MAX_DIM || NB < 1 || !mulind || N < 0 || ((kxpx || vand) && (!x || N < 1)) || (kxpx && !par)) {
         set_error("bs_moments: bad argument");
@@ -1758,7 +1754,6 @@ extern "C" int ssmq_bs_moments(int D, int N, const double *x, const double *par,
 extern "C" int ssmq_weights_gp(int D, int N, const double *xi, const double *par, int P, double jitter, double *wm,
                                double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R, double *model_var,
                                double *integral_var, int32_t *status) {
-    SSMQ_API_LOCK();
     return ssmq::weights_impl(0, D, N, xi, par, P, jitter, nullptr, 0, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var,
                               status);
 }
@@ -1769,7 +1764,6 @@ extern "C" int ssmq_weights_gp(int D, int N, const double *xi, const double *par
 extern "C" int ssmq_weights_tp(int D, int N, const double *xi, const double *par, int P, double jitter, double *wm,
                                double *Wc, double *Wcc, double *iK, double *q, double *Q, double *R, double *model_var,
                                double *integral_var, int32_t *status) {
-    SSMQ_API_LOCK();
     return ssmq_weights_gp(D, N, xi, par, P, jitter, wm, Wc, Wcc, iK, q, Q, R, model_var, integral_var, status);
 }
 
@@ -1777,7 +1771,6 @@ extern "C" int ssmq_weights_bs(int D, int N, const double *xi, const double *par
                                const int32_t *mulind, int NB, double *wm, double *Wc, double *Wcc, double *iK,
                                double *q, double *Q, double *R, double *model_var, double *integral_var,
                                int32_t *status) {
-    SSMQ_API_LOCK();
     if (NB < 1) {
         ssmq::set_error("weights_bs: NB must be >= 1");
         return SSMQ_E_ARG;
@@ -1789,7 +1782,6 @@ extern "C" int ssmq_weights_bs(int D, int N, const double *xi, const double *par
 extern "C" int ssmq_variances_bs(int D, int N, const double *xi, const double *par, int P, double jitter,
                                  const int32_t *mulind, int NB, double *model_var, double *integral_var,
                                  int32_t *status) {
-    SSMQ_API_LOCK();
     if (NB < 1) {
         ssmq::set_error("variances_bs: NB must be >= 1");
         return SSMQ_E_ARG;

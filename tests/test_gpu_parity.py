@@ -2202,9 +2202,10 @@ def test_streamed_bq_route_shapes(amd, monkeypatch, D, pstr, ppar, N, E):
 
 
 def test_calls_from_several_threads_on_different_handles(amd):
-    """"functions are re-entrant across handles".  The library's state is process-global, so every compute entry
-    point holds one lock (include/ssmq.h, conventions): threads that hammer different transforms (ctypes releases the GIL
-    inside each call) must get exactly the results of the same calls made one after the other."""
+    """"functions are re-entrant across handles".  Every calling thread has a context of its own - a stream and the
+    caches that belong to it (include/ssmq.h, conventions) - and a handle is locked only for the entry point that uses it:
+    threads that hammer different transforms (ctypes releases the GIL inside each call) run concurrently and must get exactly
+    the results of the same calls made one after the other."""
     import threading
     from ssmtoybox_amd import ssmod as sm
     rng = np.random.default_rng(5)
@@ -2238,6 +2239,78 @@ def test_calls_from_several_threads_on_different_handles(amd):
     assert not errors, errors
     for got, ref in zip(results, serial):
         assert got is not None and all(np.array_equal(g, r) for g, r in zip(got, ref))
+
+
+def test_threads_share_a_handle_and_filters_run_on_their_own_streams(amd):
+    """The other two cases of the threading contract (include/ssmq.h): (a) several threads on the SAME handle - the handle's lock
+    serialises them and a context that takes the handle over waits for the stream that used it last (here: the main thread's,
+    which uploaded new constants just before); (b) whole filters (fused time loop, cached workspace and launch graph per
+    context) from four threads at once, each on its own objects, then on objects created by the main thread.  Results EQUAL
+    to the serial ones; contexts of threads that ended are reused (a fifth round of threads finds them)."""
+    import threading
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    from bench import simulate_ungm
+    rng = np.random.default_rng(11)
+    D = 5
+    tf = amd.GaussianProcessTransform(D, D, gp_par(D, 3.0))
+    f = sm.ReentryVehicle2DTransition().dyn_eval
+    means = np.asarray([6500.4, 349.14, -1.8093, -6.7967, 0.6932]) + 1e-2 * rng.standard_normal((1500, D))
+    a = rng.standard_normal((1500, D, D)) * 1e-2
+    covs = np.einsum('bij,bkj->bik', a, a) + 1e-6 * np.eye(D)
+    results, errors = {}, []
+
+    def run(threads):
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(300)
+        assert not errors, errors
+
+    # (a) same handle; the constants change between the rounds (uploaded from the main thread's stream)
+    for par in (3.0, 1.7):
+        tf.wm, tf.Wc, tf.Wcc = tf.weights(gp_par(D, par))       # new weights: the next apply uploads new constant blocks
+        ref = tf.apply_batch(f, means, covs, 1.0)
+
+        def same(i):
+            try:
+                for _ in range(10):
+                    results[('a', i)] = tf.apply_batch(f, means, covs, 1.0)
+            except Exception as e:        # noqa: BLE001
+                errors.append((i, repr(e)))
+        run([threading.Thread(target=same, args=(i,)) for i in range(4)])
+        for i in range(4):
+            assert all(np.array_equal(g, r) for g, r in zip(results[('a', i)], ref)), (par, i)
+
+    # (b) whole filters
+    def make(kind):
+        dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+        obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+        if kind == 0:
+            return ssinf.GaussianProcessKalman(dyn, obs, np.array([[1.0, 3.0]]), np.array([[1.0, 3.0]]), points='sr')
+        if kind == 1:
+            return ssinf.UnscentedKalman(dyn, obs)
+        if kind == 2:
+            return ssinf.CubatureKalman(dyn, obs)
+        return ssinf.GaussHermiteKalman(dyn, obs, deg=5)
+    data = []
+    for kind in range(4):
+        _, y = simulate_ungm(2000 + 64 * kind, 40, 30 + kind)
+        data.append(np.ascontiguousarray(y[None]))
+    main_algs = [make(k) for k in range(4)]
+    serial = [tuple(x.copy() for x in main_algs[k].forward_pass_batch(data[k])) for k in range(4)]
+
+    def filt(k, alg):
+        try:
+            alg = alg or make(k)
+            for _ in range(8):
+                out = alg.forward_pass_batch(data[k])
+            results[('b', k)] = tuple(x.copy() for x in out)
+        except Exception as e:        # noqa: BLE001
+            errors.append((k, repr(e)))
+    for own in (True, False, True, False, True):
+        run([threading.Thread(target=filt, args=(k, None if own else main_algs[k])) for k in range(4)])
+        for k in range(4):
+            assert all(np.array_equal(g, r) for g, r in zip(results[('b', k)], serial[k])), (own, k)
 
 
 def test_state_index_with_more_than_eight_entries(amd):
