@@ -13,9 +13,24 @@ from benchlib import record  # noqa: E402
 
 def canned():
     """Full records of earlier rounds (the 16-21 kB lines that used to be printed), newest last."""
-    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0[4-9]_*_bench.json')) +
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r04_*_bench.json')) +
                    glob.glob(os.path.join(ROOT, 'profiles', 'r0[5-9]_*_bench_detail.json')))
     return [(os.path.basename(p), json.load(open(p))) for p in paths]
+
+
+def published_lines():
+    """The result lines of round 5 on (profiles/rNN_*_bench.json: what bench.py printed last, as the driver keeps it)."""
+    return sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0[5-9]_*_bench.json')))
+
+
+@pytest.mark.parametrize('path', published_lines())
+def test_published_result_lines_are_what_the_driver_can_keep(path):
+    raw = open(path).read().strip()
+    assert '\n' not in raw and len(raw.encode()) < 4096, (path, len(raw))
+    rec = json.loads(raw, parse_constant=lambda c: pytest.fail('non-strict JSON constant ' + c))
+    for k in record.REQUIRED_KEYS:
+        assert k in rec, k
+    assert rec['roofline']['target_frac'] >= 0.40 and rec['cpu_baseline']['cpu_model']
 
 
 @pytest.mark.parametrize('name,detail', canned())
