@@ -30,7 +30,8 @@ def pmc_traffic(kernel_name, grid=None):
     import re
     base = kernel_name.split('<')[0]
     nums = [int(v) for v in re.findall(r'=(\d+)', kernel_name)]
-    if 'fused' in base:
+    chunked = 'chunked' in base      # k_filter_chunked (csrc/ssmq_filter_chunked.hip): as many waves as the chip holds, not ld threads
+    if 'fused' in base or chunked:
         # reported name: <D=,Y=,ND=,NO=,F_DYN,F_OBS,FORM,TP=,SELO=,OPT=>; profile: <D,Y,ND,NO,FD,FO,FORM,TP,SELO,OPT,STU>
         want = nums[:4] + [1 if 'SSMQ_FORM_SIGMA' in kernel_name else 0] + nums[4:7]
         pick = lambda t: t[:4] + t[6:10]
@@ -44,7 +45,7 @@ def pmc_traffic(kernel_name, grid=None):
         have = [int(v) for v in re.findall(r'-?\d+', key.split('<', 1)[1].split('>')[0])]
         if pick(have) == want:
             hits.append(rec)
-    if grid is not None:
+    if grid is not None and not chunked:
         hits = [r for r in hits if int(r.get('grid', -1)) == int(grid)]
     return hits[0].get('hbm_bytes_per_launch') if len(hits) == 1 else None
 
@@ -163,7 +164,8 @@ def pmc_issue(kernel):
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_fused_sq.csv')))      # the latest round's summary
     path = found[-1] if found else os.path.join(ROOT, 'profiles', 'r02_fused_sq.csv')
-    if not kernel.startswith('k_filter_fused<'):
+    base = kernel.split('<')[0]
+    if base not in ('k_filter_fused', 'k_filter_chunked'):
         return None
     nums = [int(v) for v in re.findall(r'=(\d+)', kernel)]
     if len(nums) < 7:
@@ -172,7 +174,7 @@ def pmc_issue(kernel):
     rows = {}
     try:
         for r in csv.DictReader(open(path)):
-            if 'k_filter_fused<' not in r['kernel']:
+            if base + '<' not in r['kernel']:
                 continue
             t = [int(v) for v in re.findall(r'-?\d+', r['kernel'].split('<', 1)[1].split('>')[0])]
             if len(t) >= 10 and t[:4] + t[6:10] == want:

@@ -20,6 +20,11 @@ struct FusedArgs {
     const double *sscale;
     double student_dof;
     FPar fd, fo;
+    // chunked, self-scheduling passes (ssmq_filter_chunked.hip): steps per chunk, blocks of lpw trajectories, the work queue and
+    // the state a chunk hands to the next one of its block
+    int32_t t_chunk, n_blocks;
+    int32_t *queue;
+    double *hand;
 };
 
 template <int D, int E>

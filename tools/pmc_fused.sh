@@ -12,7 +12,7 @@ python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-want = ('k_filter_fused', 'k_filter_wsplit', 'k_apply_small<6', 'k_fxwc', 'k_eval_wave', 'k_apply_tile', 'k_apply_wave', 'k_big_rest', 'k_bq_fused', 'k_bq_stream')
+want = ('k_filter_fused', 'k_filter_chunked', 'k_filter_wsplit', 'k_apply_small<6', 'k_fxwc', 'k_eval_wave', 'k_apply_tile', 'k_apply_wave', 'k_big_rest', 'k_bq_fused', 'k_bq_stream')
 for sub in ('a', 'b'):
     for path in glob.glob(root + '/' + sub + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(path)):
