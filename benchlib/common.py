@@ -196,10 +196,12 @@ def issue_block(kernel, T, ms_per_launch):
     valu_wave = pm['SQ_INSTS_VALU'] / waves
     peak = CLOCK_HZ / 4.0       # one fp64 VALU instruction per 4 cycles per SIMD
     achieved = valu_wave / (ms_per_launch * 1e-3)
+    chunked = kernel.startswith('k_filter_chunked')     # a wave per wave SLOT there: each runs the chunks of several blocks
     return {'bound': 'fp64-issue', 'unit': 'VALU instructions/s per wave', 'achieved': achieved, 'peak': peak,
             'frac': achieved / peak, 'kernel': kernel,
-            'valu_instructions_per_wave_per_step': valu_wave / T,
-            'salu_instructions_per_wave_per_step': pm['SQ_INSTS_SALU'] / waves / T,
+            'valu_instructions_per_wave_per_step': None if chunked else valu_wave / T,
+            'salu_instructions_per_wave_per_step': None if chunked else pm['SQ_INSTS_SALU'] / waves / T,
+            'valu_instructions_per_wave': valu_wave,
             'pmc': {'source': 'profiles/r0*_fused_sq.csv, latest (rocprofv3 --pmc, tools/pmc_fused.sh)',
                     'frac_valu_x4_over_wave_cycles': pm['SQ_INSTS_VALU'] / pm['SQ_WAVE_CYCLES'],
                     'active_inst_valu_over_wave_cycles': pm['SQ_ACTIVE_INST_VALU'] / pm['SQ_WAVE_CYCLES'],
