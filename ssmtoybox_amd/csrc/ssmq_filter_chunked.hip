@@ -6,23 +6,23 @@
 // has the SIMD to itself: reentry UKF, B = 12 500 (every wave alone) 0.221 ms, B = 1e5 0.456 ms = 2.06 x for 1.53 x the waves
 // per SIMD.  BASELINE configs[2] is exactly that batch.
 //
-// Here the T steps of a block of 64 trajectories are cut into chunks, and the chunks that are READY (their predecessor is complete)
-// wait in a FIFO for whichever wave is free - the kernel is launched with every wave slot of the chip (two per SIMD where the
-// registers allow, else one).  With more slots than blocks a block that finishes a chunk on a SIMD it shares is picked up by an
-// idle wave on a SIMD with a free issue port; the wave that ran it goes idle: the chains of chunks rotate through the fast and the
-// slow positions and all end together, at total work / total issue rate instead of at the pace of the doubly occupied SIMDs.
-// With fewer slots than blocks (one wave per SIMD) every slot simply stays busy until the queue is empty.
-//   * FIFO: q[0] = head (items taken), q[1] = continuations pushed, slots[i] = block | chunk << 24 of the i-th continuation
-//     (-1: not pushed yet).  Item idx < n_blocks is chunk 0 of block idx; item idx >= n_blocks waits for
-//     slots[idx - n_blocks].  n_items = n_chunks n_blocks is known, so nothing wraps and a wave whose index is beyond it ends.
-//     No wait is circular: if every wave waited, every taken item would be complete and every continuation pushed - then the
-//     indices the waves hold are beyond the end.  Every wait is bounded all the same (~seconds; then the block is marked failed).
-//   * State: a chunk leaves (mean, lower triangle of the covariance, status word) - what its registers hold, so the RESULTS ARE THE
-//     BITS OF THE WHOLE-PASS KERNEL - in a hand-over buffer, and its successor, possibly on another XCD, reads it from there.  The
-//     eight L2 caches of the chip are not coherent with each other: an agent-scope release is an L2 write-back per chunk, measured
-//     at ~0.5 us EACH and serial per XCD (a first version: 1.2 ms per pass against 0.45).  So the hand-over (and the queue words)
-//     go through SYSTEM-scope atomic accesses, which bypass the non-coherent levels, ordered by the wave's own store counter
-//     (workgroup-scope release = s_waitcnt): state stores complete -> slot.  The filter outputs keep their streaming stores.
+// Here the n_blocks x T block-steps of a batch are laid end to end (block-major) and cut into as many equal STRIPS as the chip has
+// SIMDs; one wave per strip.  A strip of L = T n_blocks / n_strips > T block-steps is: the tail of a block its left neighbour began,
+// some whole blocks, the head of a block its right neighbour will finish.  Every wave runs its HEAD piece first and leaves the
+// state for the neighbour, then its whole blocks, then the TAIL piece - whose predecessor state was published by the neighbour as
+// the first thing it did, a whole strip ago: one hand-over per wave, nobody waits, and every SIMD carries the same number of steps
+// to within one: the launch lasts 1.53 wave-times instead of 2.
+//   * State: a piece leaves (mean, lower triangle of the covariance, status word) - what its registers hold, so the RESULTS ARE THE
+//     BITS OF THE WHOLE-PASS KERNEL - in a hand-over buffer, and the piece that continues the block, on another CU and possibly
+//     another XCD, reads it from there.  The eight L2 caches of the chip are not coherent with each other: an agent-scope release
+//     is an L2 write-back, measured at ~0.5 us EACH and serial per XCD.  So the hand-over and its flag go through SYSTEM-scope
+//     atomic accesses, which bypass the non-coherent levels, ordered by the wave's own store counter (workgroup-scope release =
+//     s_waitcnt): state stores complete -> flag.  The filter outputs keep their streaming stores.
+//   * A first design dealt chunks of a few steps from a ready FIFO to free waves (profiles/r05_chunked.txt): correct, same bits, but
+//     every chunk boundary costs ~6 us of exposed memory round trips and equal chunks quantise again (9.16 rounds of chunks are 10):
+//     0.459 -> 0.432 ms.  The strips: 0.455 -> 0.405 ms (reentry UKF 5-D, B = 1e5), 0.584 -> 0.514 (6-D), 0.448 -> 0.285 at B = 7e4
+//     (1 094 blocks: 1.07 rounds instead of 2) - the balanced figure at the ~2.07 GHz the chip holds with every SIMD busy.
+//   * Every wait is bounded (~seconds; then the block's trajectories are marked failed at step 0) although none is ever long.
 #include "ssmq_filter_fused_kernel.h"
 
 namespace ssmq {
@@ -30,42 +30,43 @@ namespace {
 
 template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT>
 __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : ((D >= 5 && FORM == SSMQ_FORM_SIGMA) ? SSMQ_FUSED_OCC_D5_SIGMA : 2))) void k_filter_chunked(const FusedArgs a) {
-    __shared__ int32_t s_item;
-    const int n_chunks = (a.T + a.t_chunk - 1) / a.t_chunk;
-    const int n_items = n_chunks * a.n_blocks;
-    int32_t *slots = a.queue + 16;        // [n_items - n_blocks]: block | chunk << 24 of the i-th continuation, -1 until it is pushed
-    // (a wave takes at most every item once: the bound makes the loop finite whatever the queue holds)
-    for (int taken = 0; taken <= n_items; ++taken) {
-        if (threadIdx.x == 0) s_item = atomicAdd(a.queue, 1);
-        __syncthreads();
-        const int idx = __builtin_amdgcn_readfirstlane(s_item);
-        __syncthreads();
-        if (idx >= n_items) break;
-        int blk = idx, c = 0;
-        if (idx >= a.n_blocks) {
-            int spins = 0, v;
-            for (;;) {
-                v = __hip_atomic_load(&slots[idx - a.n_blocks], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (v >= 0 || ++spins > (1 << 22)) break;
+    // strip blockIdx.x of gridDim.x: block-steps [p0, p1) of the block-major order
+    const int64_t total = (int64_t)a.n_blocks * a.T;
+    const int64_t p0 = total * blockIdx.x / gridDim.x, p1 = total * (blockIdx.x + 1) / gridDim.x;
+    if (p1 <= p0) return;
+    const int b0 = (int)(p0 / a.T), k0 = (int)(p0 - (int64_t)b0 * a.T);            // first block of the strip, its first step here
+    const int b1 = (int)((p1 - 1) / a.T), k1 = (int)(p1 - (int64_t)b1 * a.T);      // last block, one past its last step here
+    int32_t *flag = a.queue;                                                      // [n_blocks]: 1 = the head piece's state is in a.hand
+    // the pieces in the order they are run: 1. the head of the last block (the right neighbour finishes it; not if the strip ends
+    // on a block boundary), 2. the whole blocks, 3. the tail of the first block, from the state the left neighbour left as ITS
+    // first piece.  (One call site for the pass: it is the whole time loop, inlined.)
+    const bool head = k1 < a.T && (b1 > b0 || k0 == 0), tail = k0 > 0;
+    const int w0 = b0 + (tail ? 1 : 0), w1 = b1 + ((k1 == a.T) ? 1 : 0);          // whole blocks [w0, w1)
+    const int n_pieces = (head ? 1 : 0) + (w1 > w0 ? w1 - w0 : 0) + (tail ? 1 : 0);
+    for (int i = 0; i < n_pieces; ++i) {
+        const int j = i - (head ? 1 : 0);
+        const bool is_head = head && i == 0, is_tail = tail && i == n_pieces - 1;
+        const int blk = is_head ? b1 : (is_tail ? b0 : w0 + j);
+        const int kb = is_tail ? k0 : 0, ke = is_head ? k1 : ((is_tail && b1 == b0) ? k1 : a.T);
+        if (is_tail) {
+            int spins = 0;
+            while (__hip_atomic_load(&flag[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+                if (++spins > (1 << 22)) break;
                 __builtin_amdgcn_s_sleep(32);
             }
-            if (v < 0) break;              // (never seen: a continuation that did not arrive within seconds ends the wave)
-            v = __builtin_amdgcn_readfirstlane(v);
-            blk = v & 0xffffff;
-            c = v >> 24;
+            if (spins > (1 << 22)) {        // (never seen)
+                const int64_t b = (int64_t)blk * a.lpw + threadIdx.x;
+                if ((int)threadIdx.x < a.lpw && b < a.B) a.status[b] = 1;
+                break;
+            }
         }
-        const int k0 = c * a.t_chunk, k1 = k0 + a.t_chunk < a.T ? k0 + a.t_chunk : a.T;
-        const bool last = k1 == a.T;
         if ((int)threadIdx.x < a.lpw)   // (STU = -1: the instantiation of the whole-pass kernel of these shapes - with the recursion
             // type fixed at compile time other products are contracted into multiply-adds and the last bits differ)
-            fused_pass<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, -1, true>(a, (uint32_t)blk, k0, k1, c == 0, last);
-        if (!last) {
+            fused_pass<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, -1, true>(a, (uint32_t)blk, kb, ke, kb == 0, ke == a.T);
+        if (is_head) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the state stores have completed (s_waitcnt) ...
             __syncthreads();
-            if (threadIdx.x == 0) {                                      // ... then the continuation is published
-                const int t = atomicAdd(a.queue + 1, 1);
-                __hip_atomic_store(&slots[t], blk | ((c + 1) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            if (threadIdx.x == 0) __hip_atomic_store(&flag[blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // ... then the flag
         }
     }
 }
@@ -96,7 +97,7 @@ const ChunkedEntry kChunked[] = {
     SSMQ_CH(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 10, 1),
 };
 
-struct QueueBuf {          // per thread context, grow-only: queue words + hand-over buffer
+struct QueueBuf {          // per thread context, grow-only: flags + hand-over buffer
     char *p = nullptr;
     size_t n = 0;          // bytes
     unsigned epoch = 0;
@@ -106,20 +107,14 @@ thread_local QueueBuf t_queue;
 }  // namespace
 
 // 1: launched; 0: this shape / batch keeps the whole-pass kernel; < 0: error.
-// Default: taken for the kernels that hold ONE wave per SIMD (the centred 5-D forms, every 6-D shape) when the batch has more blocks
-// than SIMDs and whole passes would cost at least 10 % more wave-times (ceil(x) against x, x = blocks per SIMD).  Measured
-// (tools/chunked_time.py, B = 1e5, T = 50; profiles/r05_chunked.txt): reentry UKF 5-D 0.459 -> 0.432 ms, 6-D 0.594 -> 0.547; the
-// kernels that hold two waves per SIMD LOSE 7-11 % (Bayes-Sard / GPQ 5-D) and keep the whole pass.  Why not the ideal (total work at
-// full issue rate: 0.34 ms for the 5-D UKF): a hand-over is four dependent round trips to memory (state stores acknowledged,
-// queue atomic, slot store; slot load, state loads: ~12 us per chunk of 40 us) that a wave alone on its SIMD cannot hide, and with
-// two waves per SIMD (256 registers, 24 spilled) the pass is slower than the two rounds it replaces (0.548 ms).
-// SSMQ_FUSED_CHUNKED=0 never; =1 wherever a kernel exists (same batch condition); = n > 1: chunks of n steps, any batch.  The
-// results ARE the whole-pass kernel's bits in every variant (test_chunked_time_loop_is_bitwise_the_whole_pass).
+// Default: taken when the batch has more blocks than the chip has SIMDs and whole passes would cost at least 5 % more wave-times
+// (ceil(x) against x, x = blocks per SIMD).  SSMQ_FUSED_CHUNKED=0 never; = n > 1: n strips (tests: any batch).
+// The results ARE the whole-pass kernel's bits (test_chunked_time_loop_is_bitwise_the_whole_pass).
 int try_launch_chunked(const FusedArgs &a0, int fd, int fo, int D, int Y, int ND, int NO, int form, int tp, int selo, int opt, int cus,
                        hipStream_t s, bool dry_run, const char **name) {
     const char *ev = getenv("SSMQ_FUSED_CHUNKED");
     const int force = ev ? atoi(ev) : -1;
-    if (force == 0 || a0.sscale != nullptr || a0.student_dof > 0.0 || (!dry_run && a0.T < 4)) return 0;
+    if (force == 0 || a0.sscale != nullptr || a0.student_dof > 0.0 || (!dry_run && a0.T < 2)) return 0;
     const ChunkedEntry *e = nullptr;
     for (const ChunkedEntry &c : kChunked)
         if (c.fd == fd && c.fo == fo && c.D == D && c.Y == Y && c.ND == ND && c.NO == NO && c.form == form && c.tp == tp && c.selo == selo &&
@@ -128,26 +123,22 @@ int try_launch_chunked(const FusedArgs &a0, int fd, int fo, int D, int Y, int ND
     if (!e) return 0;
     const int64_t n_blocks = (a0.B + a0.lpw - 1) / a0.lpw, simds = 4 * (int64_t)cus;
     if (n_blocks >= (int64_t)1 << 24) return 0;
-    if (force <= 1) {
+    int64_t strips = simds;
+    if (force > 1) {
+        strips = force;
+    } else {
         const double x = (double)n_blocks / (double)simds;
-        if (x <= 1.0 || std::ceil(x) < 1.1 * x) return 0;
+        if (x <= 1.0 || std::ceil(x) < 1.05 * x) return 0;
     }
-    // (register allocation as the whole-pass kernel's launch bounds: one wave per SIMD = four 64-thread blocks per CU; the
-    // occupancy query needs a device, the name query has none)
-    const bool one_per_simd = D >= 6 || (D >= 5 && form == SSMQ_FORM_SIGMA && SSMQ_FUSED_OCC_D5_SIGMA == 1);
-    if (force < 0 && !one_per_simd) return 0;
+    if (strips >= n_blocks) return 0;              // (a strip must be longer than a block: one open piece at either end)
     if (name) *name = e->name;
     if (dry_run) return 1;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)e->k, kSmallBlock, 0) != hipSuccess || per_cu < 1) return 0;
     FusedArgs a = a0;
     a.n_blocks = (int32_t)n_blocks;
-    a.t_chunk = force > 1 ? force : std::max(4, (a.T + 5) / 6);
-    const int64_t n_chunks = (a.T + a.t_chunk - 1) / a.t_chunk, n_items = n_chunks * n_blocks;
-    // queue words: [16] head, continuations pushed | slots [n_items - n_blocks];  hand-over: [n_blocks][NS + 1][64]
-    if (n_chunks > 127) return 0;
-    const size_t q_words = 16 + (size_t)(n_items - n_blocks), ns = (size_t)D + (size_t)D * (D + 1) / 2 + 1;
-    const size_t q_bytes = (sizeof(int32_t) * q_words + 255) / 256 * 256, need = q_bytes + sizeof(double) * (size_t)n_blocks * ns * 64;
+    a.t_chunk = 0;
+    // flags [n_blocks] | hand-over [n_blocks][NS + 1][64]
+    const size_t ns = (size_t)D + (size_t)D * (D + 1) / 2 + 1;
+    const size_t q_bytes = (sizeof(int32_t) * (size_t)n_blocks + 255) / 256 * 256, need = q_bytes + sizeof(double) * (size_t)n_blocks * ns * 64;
     if (t_queue.epoch != device_epoch() || t_queue.n < need) {
         if (t_queue.p && t_queue.epoch == device_epoch()) {
             SSMQ_HIP(hipStreamSynchronize(s));
@@ -160,11 +151,8 @@ int try_launch_chunked(const FusedArgs &a0, int fd, int fo, int D, int Y, int ND
     }
     a.queue = (int32_t *)t_queue.p;
     a.hand = (double *)(t_queue.p + q_bytes);
-    SSMQ_HIP(hipMemsetAsync(a.queue, 0, sizeof(int32_t) * 16, s));
-    if (n_items > n_blocks) SSMQ_HIP(hipMemsetAsync(a.queue + 16, 0xff, sizeof(int32_t) * (size_t)(n_items - n_blocks), s));
-    const int64_t resident = (int64_t)per_cu * cus;
-    const unsigned grid = (unsigned)std::min<int64_t>(resident, n_items);
-    hipLaunchKernelGGL(e->k, dim3(grid), dim3(kSmallBlock), 0, s, a);
+    SSMQ_HIP(hipMemsetAsync(a.queue, 0, sizeof(int32_t) * (size_t)n_blocks, s));
+    hipLaunchKernelGGL(e->k, dim3((unsigned)strips), dim3(kSmallBlock), 0, s, a);
     const int rc = hip_fail(hipGetLastError(), "k_filter_chunked");
     return rc ? rc : 1;
 }

@@ -3427,13 +3427,13 @@ def test_wsplit_filters_match_oracle_and_register_kernel(amd, monkeypatch):
 
 
 def test_chunked_time_loop_is_bitwise_the_whole_pass(amd, monkeypatch):
-    """k_filter_chunked (csrc/ssmq_filter_chunked.hip; opt-in, SSMQ_FUSED_CHUNKED): the time loop of a block of trajectories cut into
-    chunks that free waves take from a FIFO, the state handed from chunk to chunk through memory - mean, covariance triangle and
-    status word as the registers held them.  The results must be the BITS of the whole-pass kernel, failures included, for
-    every chunk length, with more blocks than wave slots and with fewer."""
+    """k_filter_chunked (csrc/ssmq_filter_chunked.hip): the block-steps of a batch cut into equal strips, one wave per strip; a block
+    that straddles two strips is begun by one wave and finished by another from the state - mean, covariance triangle, status word
+    as the registers held them - handed over through memory.  The results must be the BITS of the whole-pass kernel, failures
+    included, for any number of strips (SSMQ_FUSED_CHUNKED = n) and for the default choice."""
     from benchlib.workloads import FilterBench
-    for wl_name, filt, B, T in (('reentry5', 'ukf', 70000, 23), ('reentry6', 'ukf', 9000, 12), ('reentry5', 'bsqkf', 30000, 10),
-                                ('ct', 'ukf', 20000, 20)):
+    for wl_name, filt, B, T, modes in (('reentry5', 'ukf', 70000, 23, ('1', '100', '333', '1000')), ('reentry6', 'ukf', 9000, 12, ('7', '100', '140')),
+                                       ('reentry5', 'bsqkf', 30000, 10, ('64', '400')), ('ct', 'ukf', 20000, 20, ('5', '300'))):
         monkeypatch.setenv('SSMQ_FUSED_CHUNKED', '0')
         wl = FilterBench(amd, B, T, 5, wl_name, filt)
         if wl_name == 'reentry5' and filt == 'ukf':       # some trajectories that fail on the way: not-PD initial covariances
@@ -3444,7 +3444,7 @@ def test_chunked_time_loop_is_bitwise_the_whole_pass(amd, monkeypatch):
         wl.step()
         ref = wl.results()
         assert np.isfinite(ref[0]).any()
-        for mode in ('1', '4', '7', str(T)):
+        for mode in modes:
             monkeypatch.setenv('SSMQ_FUSED_CHUNKED', mode)
             wl.d_fm.upload(np.zeros((T, wl.D, wl.ld)))      # (what is compared was written by this pass)
             wl.step()
@@ -3452,8 +3452,10 @@ def test_chunked_time_loop_is_bitwise_the_whole_pass(amd, monkeypatch):
             assert all(np.array_equal(g, r, equal_nan=True) for g, r in zip(got, ref)), (wl_name, filt, mode)
         if wl_name == 'reentry5' and filt == 'ukf':
             assert (ref[2] != 0).sum() >= B // 977 - 1
+            monkeypatch.delenv('SSMQ_FUSED_CHUNKED')
+            assert 'k_filter_chunked<' in wl.alg.kernel_name(B)       # 1 094 blocks on 1 024 SIMDs: the default takes the strips
         wl.free()
-    monkeypatch.delenv('SSMQ_FUSED_CHUNKED')
+    monkeypatch.delenv('SSMQ_FUSED_CHUNKED', raising=False)
 
 
 def test_wsplit_default_choice_and_failures(amd, monkeypatch):
@@ -3463,13 +3465,13 @@ def test_wsplit_default_choice_and_failures(amd, monkeypatch):
     monkeypatch.delenv('SSMQ_FUSED_WSPLIT', raising=False)
     flt = _wsplit_filters(52)
     ukf, tpq = flt[0][1], flt[3][1]
-    # (the wave split is not for the unscented reentry filter; at 1e5 trajectories - 1 563 blocks on 1 024 SIMDs - its one-wave-per-SIMD
-    # kernel runs as chunks from a queue, csrc/ssmq_filter_chunked.hip, below that as the whole pass)
+    # (the wave split is not for the unscented reentry filter; at 1e5 trajectories - 1 563 blocks on 1 024 SIMDs - the five- and
+    # six-state time loops run as equal strips of block-steps, csrc/ssmq_filter_chunked.hip, below the SIMD count as whole passes)
     assert 'k_filter_fused<' in ukf.kernel_name(200) and 'k_filter_fused<' in ukf.kernel_name(60000)
     if 'SSMQ_FUSED_CHUNKED' not in os.environ:           # (tools/alt_paths.sh runs the suite with the choice forced either way)
         assert 'k_filter_chunked<' in ukf.kernel_name(100000)
     assert 'k_filter_wsplit' in tpq.kernel_name(10000) and 'W=2>' in tpq.kernel_name(10000)
-    assert 'k_filter_fused<' in tpq.kernel_name() and ('SSMQ_FUSED_CHUNKED' in os.environ or 'k_filter_fused<' in tpq.kernel_name(100000))
+    assert 'k_filter_fused<' in tpq.kernel_name() and ('SSMQ_FUSED_CHUNKED' in os.environ or 'k_filter_chunked<' in tpq.kernel_name(100000))
     name, alg, y, _, _, m0, P0, GQG, R, _, _ = flt[3]
     B = y.shape[2]
     x0c = np.tile(P0, (B, 1, 1))

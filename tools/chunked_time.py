@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""k_filter_chunked (time loop in chunks dealt from a queue, csrc/ssmq_filter_chunked.hip) against k_filter_fused (a wave keeps its
-trajectories for all T steps) on the same device-resident batches: time per pass (HIP events), and whether the results are the
-same BITS (they must be: a chunk starts from what its predecessor stored)."""
+"""k_filter_chunked (the block-steps of a batch in equal strips, one wave per strip, csrc/ssmq_filter_chunked.hip) against
+k_filter_fused (a wave keeps its trajectories for all T steps) on the same device-resident batches: time per pass (HIP events), and
+whether the results are the same BITS (they must be: a piece starts from the state its predecessor handed over)."""
 import os
 import sys
 
@@ -16,7 +16,7 @@ amd.set_device(0)
 cases = [('reentry5', 'ukf', 100000, 50), ('reentry5', 'bsqkf', 100000, 50), ('reentry6', 'ukf', 100000, 50), ('reentry5', 'gpqkf', 100000, 50),
          ('reentry5', 'ukf', 70000, 50), ('reentry5', 'ukf', 140000, 50), ('reentry5', 'ukf', 200000, 50), ('reentry5', 'ukf', 12500, 50),
          ('ct', 'ukf', 100000, 20)]
-modes = [('0', 'whole pass'), ('1', 'chunked, auto'), ('4', 'chunks of 4'), ('7', 'chunks of 7'), ('13', 'chunks of 13'), ('25', 'chunks of 25')]
+modes = [('0', 'whole pass'), ('1', 'strips, auto'), ('512', '512 strips'), ('768', '768 strips'), ('1024', '1024 strips'), ('1400', '1400 strips')]
 if len(sys.argv) > 1:
     cases = cases[:int(sys.argv[1])]
 for wl_name, filt, B, T in cases:
