@@ -28,7 +28,10 @@
 namespace ssmq {
 namespace {
 
-template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT>
+// STU: the recursion-type parameter of the whole-pass kernel of the shape (ssmq_filter_fused.hip: -1 decided at run time for the
+// larger shapes, 0 = Gaussian fixed at compile time for the scalar ones) - with another value other products are contracted into
+// multiply-adds and the last bits differ.
+template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT, int STU>
 __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : ((D >= 5 && FORM == SSMQ_FORM_SIGMA) ? SSMQ_FUSED_OCC_D5_SIGMA : 2))) void k_filter_chunked(const FusedArgs a) {
     // strip blockIdx.x of gridDim.x: block-steps [p0, p1) of the block-major order
     const int64_t total = (int64_t)a.n_blocks * a.T;
@@ -60,9 +63,7 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : ((D >= 5 && FORM == SSMQ
                 break;
             }
         }
-        if ((int)threadIdx.x < a.lpw)   // (STU = -1: the instantiation of the whole-pass kernel of these shapes - with the recursion
-            // type fixed at compile time other products are contracted into multiply-adds and the last bits differ)
-            fused_pass<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, -1, true>(a, (uint32_t)blk, kb, ke, kb == 0, ke == a.T);
+        if ((int)threadIdx.x < a.lpw) fused_pass<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, STU, true>(a, (uint32_t)blk, kb, ke, kb == 0, ke == a.T);
         if (is_head) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the state stores have completed (s_waitcnt) ...
             __syncthreads();
@@ -78,7 +79,7 @@ struct ChunkedEntry {
     const char *name;
 };
 #define SSMQ_CH_ONE(FD, FO, D, Y, N, FORM, TP, SELO, OPT)                                                  \
-    {FD, FO, D, Y, N, N, FORM, TP, SELO, OPT, &k_filter_chunked<D, Y, N, N, FD, FO, FORM, TP, SELO, OPT>, \
+    {FD, FO, D, Y, N, N, FORM, TP, SELO, OPT, &k_filter_chunked<D, Y, N, N, FD, FO, FORM, TP, SELO, OPT, (D == 1 ? 0 : -1)>, \
      "k_filter_chunked<D=" #D ",Y=" #Y ",ND=" #N ",NO=" #N "," #FD "," #FO "," #FORM ",TP=" #TP ",SELO=" #SELO ",OPT=" #OPT ">"}
 // the shapes of ssmq_filter_fused.hip's table with five or six states (what a step of them costs makes a chunk of a few steps long
 // against the hand-over: a queue atomic, D + D (D + 1) / 2 loads); unscented and spherical-radial point sets
@@ -89,6 +90,9 @@ struct ChunkedEntry {
     SSMQ_CH(FD, FO, D, Y, N, SELO), SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 3), SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 1, SELO, 2), \
     SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_SIGMA, 0, SELO, 2)
 const ChunkedEntry kChunked[] = {
+    // (NOT the scalar UNGM filters: a 36-register kernel with a dependent chain of 125 instructions per step lives on many waves per
+    // SIMD - one strip per SIMD ran the bench headline's kernel at 0.083 ms against 0.063 at B = 1e5 and 0.25 against 0.13 at 2e5,
+    // 4 096 strips break even; profiles/r05_chunked.txt)
     SSMQ_CH_FAST(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
     SSMQ_CH_FAST(SSMQ_F_REENTRY2D_BIAS_DYN, SSMQ_F_RADAR2D_MEAS, 6, 2, 13, 0),
     SSMQ_CH_FAST(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 11, 1),
