@@ -1478,6 +1478,10 @@ void reset_device_caches() {
     drop_gemm_scratch();
     drop_staging_arena();
     reset_wide_attributes();
+    Ctx &c = ctx();
+    if (c.strip_buf) hipFree(c.strip_buf);
+    c.strip_buf = nullptr;
+    c.strip_bytes = 0;
 }
 }  // namespace ssmq
 

@@ -101,13 +101,6 @@ const ChunkedEntry kChunked[] = {
     SSMQ_CH(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 10, 1),
 };
 
-struct QueueBuf {          // per thread context, grow-only: flags + hand-over buffer
-    char *p = nullptr;
-    size_t n = 0;          // bytes
-    unsigned epoch = 0;
-};
-thread_local QueueBuf t_queue;
-
 }  // namespace
 
 // 1: launched; 0: this shape / batch keeps the whole-pass kernel; < 0: error.
@@ -143,18 +136,19 @@ int try_launch_chunked(const FusedArgs &a0, int fd, int fo, int D, int Y, int ND
     // flags [n_blocks] | hand-over [n_blocks][NS + 1][64]
     const size_t ns = (size_t)D + (size_t)D * (D + 1) / 2 + 1;
     const size_t q_bytes = (sizeof(int32_t) * (size_t)n_blocks + 255) / 256 * 256, need = q_bytes + sizeof(double) * (size_t)n_blocks * ns * 64;
-    if (t_queue.epoch != device_epoch() || t_queue.n < need) {
-        if (t_queue.p && t_queue.epoch == device_epoch()) {
+    Ctx &cx = ctx();       // the buffer belongs to the thread's context (pooled; dropped with the context's other caches on a device change)
+    if (cx.strip_bytes < need) {
+        if (cx.strip_buf) {
             SSMQ_HIP(hipStreamSynchronize(s));
-            hipFree(t_queue.p);
+            hipFree(cx.strip_buf);
         }
-        t_queue = QueueBuf{};
-        SSMQ_HIP(hipMalloc((void **)&t_queue.p, need + need / 4));
-        t_queue.n = need + need / 4;
-        t_queue.epoch = device_epoch();
+        cx.strip_buf = nullptr;
+        cx.strip_bytes = 0;
+        SSMQ_HIP(hipMalloc(&cx.strip_buf, need + need / 4));
+        cx.strip_bytes = need + need / 4;
     }
-    a.queue = (int32_t *)t_queue.p;
-    a.hand = (double *)(t_queue.p + q_bytes);
+    a.queue = (int32_t *)cx.strip_buf;
+    a.hand = (double *)((char *)cx.strip_buf + q_bytes);
     SSMQ_HIP(hipMemsetAsync(a.queue, 0, sizeof(int32_t) * (size_t)n_blocks, s));
     hipLaunchKernelGGL(e->k, dim3((unsigned)strips), dim3(kSmallBlock), 0, s, a);
     const int rc = hip_fail(hipGetLastError(), "k_filter_chunked");

@@ -57,6 +57,8 @@ struct Ctx {
     size_t gemm_ws_bytes = 0;
     void *stage = nullptr, *fc = nullptr, *theta_graphs = nullptr;      // ssmq_api.hip: StagingArena, FilterCache, theta graphs
     void *pinned_flags = nullptr;            // 64 bytes of pinned host memory the device rounds report through (ssmq_marginal.hip)
+    void *strip_buf = nullptr;               // flags + hand-over buffer of the strip schedule (ssmq_filter_chunked.hip), grow-only
+    size_t strip_bytes = 0;
 };
 Ctx &ctx();
 struct HandleGuard {
