@@ -2241,26 +2241,6 @@ def test_calls_from_several_threads_on_different_handles(amd):
         assert got is not None and all(np.array_equal(g, r) for g, r in zip(got, ref))
 
 
-def test_cxx_threads_through_the_c_abi(amd, tmp_path):
-    """A C++ consumer of include/ssmq.h with no Python in between (tools/micro/threads_rate.cpp: points, GP weights, transform
-    handles, device buffers and the fused filter, all through the C ABI): K host threads, each with its own filter on its own
-    context / stream, must reproduce the single-thread results bit for bit - and the library must link and run from plain C++."""
-    import shutil
-    import subprocess
-    if not shutil.which('g++'):
-        pytest.skip('no g++ on this box')
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / 'threads_rate')
-    subprocess.run(['g++', '-O2', '-std=c++17', '-I' + os.path.join(root, 'include'), os.path.join(root, 'tools', 'micro', 'threads_rate.cpp'),
-                    '-o', exe, '-L' + os.path.join(root, 'ssmtoybox_amd'), '-lssmq', '-lpthread',
-                    '-Wl,-rpath,' + os.path.join(root, 'ssmtoybox_amd')], check=True, timeout=120)
-    out = subprocess.run([exe, '1', '3'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
-    print(out.stdout)
-    assert out.returncode == 0, out.stdout
-    lines = [ln for ln in out.stdout.splitlines() if 'thread(s)' in ln]
-    assert len(lines) == 2 and all('EQUAL' in ln for ln in lines), out.stdout
-
-
 def test_threads_share_a_handle_and_filters_run_on_their_own_streams(amd):
     """The other two cases of the threading contract (include/ssmq.h): (a) several threads on the SAME handle - the handle's lock
     serialises them and a context that takes the handle over waits for the stream that used it last (here: the main thread's,

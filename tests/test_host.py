@@ -262,3 +262,21 @@ def test_degree7_fully_symmetric_rule_is_exact_to_degree_7():
                                wm.ctypes.data_as(_lib.c_double_p), None) == N
         assert np.allclose(xi, x, rtol=1e-14, atol=0) and np.allclose(wm, w, rtol=1e-10, atol=1e-12)
     assert FS(10, degree=7).unit_sp.shape == (10, 1181)
+
+
+def test_cxx_consumer_of_the_c_abi_builds(tmp_path):
+    """tools/micro/threads_rate.cpp - a C++ program that drives whole filters through include/ssmq.h from several threads (run on the
+    GPU box by tools/micro/run_threads_rate.sh, from a fresh shell: a process that has initialised the GPU must not start it) - compiles
+    against the header and links against libssmq.so: every entry point it uses is declared and exported."""
+    import shutil
+    import subprocess
+    if not shutil.which('g++'):
+        pytest.skip('no g++ here')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, 'ssmtoybox_amd')
+    if not os.path.exists(os.path.join(lib, 'libssmq.so')):
+        pytest.skip('libssmq.so not built')
+    res = subprocess.run(['g++', '-O1', '-std=c++17', '-Wall', '-I' + os.path.join(root, 'include'),
+                          os.path.join(root, 'tools', 'micro', 'threads_rate.cpp'), '-o', str(tmp_path / 'threads_rate'), '-L' + lib, '-lssmq',
+                          '-lpthread', '-Wl,-rpath,' + lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout
