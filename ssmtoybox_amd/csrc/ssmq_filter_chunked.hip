@@ -33,9 +33,16 @@ namespace {
 // multiply-adds and the last bits differ.
 template <int D, int Y, int ND, int NO, int FD, int FO, int FORM, int TP, int SELO, int OPT, int STU>
 __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : ((D >= 5 && FORM == SSMQ_FORM_SIGMA) ? SSMQ_FUSED_OCC_D5_SIGMA : 2))) void k_filter_chunked(const FusedArgs a) {
-    // strip blockIdx.x of gridDim.x: block-steps [p0, p1) of the block-major order
+    // The strip index is TAKEN (one atomic per wave), not read off blockIdx: a strip waits only for its left neighbour, and a wave
+    // that holds index s took it after s - 1 was taken by a wave that is running - whatever order the hardware starts workgroups in,
+    // and whatever else keeps part of the chip busy (the ordered-block-id rule of decoupled look-back scans).
+    __shared__ int32_t s_strip;
+    if (threadIdx.x == 0) s_strip = atomicAdd(a.queue + a.n_blocks, 1);
+    __syncthreads();
+    const int64_t strip = __builtin_amdgcn_readfirstlane(s_strip);
+    // block-steps [p0, p1) of the block-major order
     const int64_t total = (int64_t)a.n_blocks * a.T;
-    const int64_t p0 = total * blockIdx.x / gridDim.x, p1 = total * (blockIdx.x + 1) / gridDim.x;
+    const int64_t p0 = total * strip / gridDim.x, p1 = total * (strip + 1) / gridDim.x;
     if (p1 <= p0) return;
     const int b0 = (int)(p0 / a.T), k0 = (int)(p0 - (int64_t)b0 * a.T);            // first block of the strip, its first step here
     const int b1 = (int)((p1 - 1) / a.T), k1 = (int)(p1 - (int64_t)b1 * a.T);      // last block, one past its last step here
@@ -133,9 +140,9 @@ int try_launch_chunked(const FusedArgs &a0, int fd, int fo, int D, int Y, int ND
     FusedArgs a = a0;
     a.n_blocks = (int32_t)n_blocks;
     a.t_chunk = 0;
-    // flags [n_blocks] | hand-over [n_blocks][NS + 1][64]
+    // flags [n_blocks], strip counter | hand-over [n_blocks][NS + 1][64]
     const size_t ns = (size_t)D + (size_t)D * (D + 1) / 2 + 1;
-    const size_t q_bytes = (sizeof(int32_t) * (size_t)n_blocks + 255) / 256 * 256, need = q_bytes + sizeof(double) * (size_t)n_blocks * ns * 64;
+    const size_t q_bytes = (sizeof(int32_t) * ((size_t)n_blocks + 1) + 255) / 256 * 256, need = q_bytes + sizeof(double) * (size_t)n_blocks * ns * 64;
     Ctx &cx = ctx();       // the buffer belongs to the thread's context (pooled; dropped with the context's other caches on a device change)
     if (cx.strip_bytes < need) {
         if (cx.strip_buf) {
@@ -149,7 +156,7 @@ int try_launch_chunked(const FusedArgs &a0, int fd, int fo, int D, int Y, int ND
     }
     a.queue = (int32_t *)cx.strip_buf;
     a.hand = (double *)((char *)cx.strip_buf + q_bytes);
-    SSMQ_HIP(hipMemsetAsync(a.queue, 0, sizeof(int32_t) * (size_t)n_blocks, s));
+    SSMQ_HIP(hipMemsetAsync(a.queue, 0, sizeof(int32_t) * ((size_t)n_blocks + 1), s));
     hipLaunchKernelGGL(e->k, dim3((unsigned)strips), dim3(kSmallBlock), 0, s, a);
     const int rc = hip_fail(hipGetLastError(), "k_filter_chunked");
     return rc ? rc : 1;
