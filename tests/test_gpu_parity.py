@@ -3458,6 +3458,41 @@ def test_chunked_time_loop_is_bitwise_the_whole_pass(amd, monkeypatch):
     monkeypatch.delenv('SSMQ_FUSED_CHUNKED', raising=False)
 
 
+def test_strip_kernels_from_several_threads_at_once(amd, monkeypatch):
+    """Three threads launch k_filter_chunked (1 024 strips each) at the same time on their own streams: the strips of the launches
+    compete for the chip's wave slots, so part of every grid starts late - a strip may only ever wait for a strip whose index was
+    taken before its own.  Results: the whole-pass kernel's bits, for every thread and repetition."""
+    import threading
+    from benchlib.workloads import FilterBench
+    B, T = 70000, 12
+    monkeypatch.setenv('SSMQ_FUSED_CHUNKED', '0')
+    ref_wl = FilterBench(amd, B, T, 9, 'reentry5', 'ukf')
+    ref_wl.step()
+    ref = ref_wl.results()
+    ref_wl.free()
+    monkeypatch.delenv('SSMQ_FUSED_CHUNKED')
+    results, errors = {}, []
+
+    def work(i):
+        try:
+            wl = FilterBench(amd, B, T, 9, 'reentry5', 'ukf')          # (same seed: same data as the reference run)
+            assert 'k_filter_chunked<' in wl.alg.kernel_name(B)
+            for _ in range(30):
+                wl.step()
+            results[i] = wl.results()
+            wl.free()
+        except Exception as e:        # noqa: BLE001
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    for i in range(3):
+        assert all(np.array_equal(g, r, equal_nan=True) for g, r in zip(results[i], ref)), i
+
+
 def test_wsplit_default_choice_and_failures(amd, monkeypatch):
     """What is picked without the switch: the wave-split loop for the t-process form while the batch leaves SIMDs idle, the
     register kernel for saturated batches and for every other form (measured slower there: profiles/r05_wsplit.txt).  A
