@@ -88,8 +88,8 @@ struct ChunkedEntry {
 #define SSMQ_CH_ONE(FD, FO, D, Y, N, FORM, TP, SELO, OPT)                                                  \
     {FD, FO, D, Y, N, N, FORM, TP, SELO, OPT, &k_filter_chunked<D, Y, N, N, FD, FO, FORM, TP, SELO, OPT, (D == 1 ? 0 : -1)>, \
      "k_filter_chunked<D=" #D ",Y=" #Y ",ND=" #N ",NO=" #N "," #FD "," #FO "," #FORM ",TP=" #TP ",SELO=" #SELO ",OPT=" #OPT ">"}
-// the shapes of ssmq_filter_fused.hip's table with five or six states (what a step of them costs makes a chunk of a few steps long
-// against the hand-over: a queue atomic, D + D (D + 1) / 2 loads); unscented and spherical-radial point sets
+// the shapes of ssmq_filter_fused.hip's table with five or six states (2 000+ vector instructions per step: one wave keeps a SIMD's
+// issue port busy by itself); unscented and spherical-radial point sets
 #define SSMQ_CH(FD, FO, D, Y, N, SELO)                                  \
     SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 0), SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 1, SELO, 0), \
     SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_SIGMA, 0, SELO, 0)

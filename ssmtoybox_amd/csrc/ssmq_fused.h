@@ -20,9 +20,9 @@ struct FusedArgs {
     const double *sscale;
     double student_dof;
     FPar fd, fo;
-    // chunked, self-scheduling passes (ssmq_filter_chunked.hip): steps per chunk, blocks of lpw trajectories, the work queue and
-    // the state a chunk hands to the next one of its block
-    int32_t t_chunk, n_blocks;
+    // the strip schedule (ssmq_filter_chunked.hip): blocks of lpw trajectories; queue = hand-over flags [n_blocks] + the strip
+    // counter; hand = the state a piece leaves for the piece that continues its block, [n_blocks][D + D (D + 1) / 2 + 1][64]
+    int32_t t_chunk, n_blocks;     // (t_chunk: unused since the strips)
     int32_t *queue;
     double *hand;
 };
