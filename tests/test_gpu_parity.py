@@ -3433,7 +3433,8 @@ def test_chunked_time_loop_is_bitwise_the_whole_pass(amd, monkeypatch):
     included, for any number of strips (SSMQ_FUSED_CHUNKED = n) and for the default choice."""
     from benchlib.workloads import FilterBench
     for wl_name, filt, B, T, modes in (('reentry5', 'ukf', 70000, 23, ('1', '100', '333', '1000')), ('reentry6', 'ukf', 9000, 12, ('7', '100', '140')),
-                                       ('reentry5', 'bsqkf', 30000, 10, ('64', '400')), ('ct', 'ukf', 20000, 20, ('5', '300'))):
+                                       ('reentry5', 'bsqkf', 30000, 10, ('64', '400')), ('ct', 'ukf', 20000, 20, ('5', '300')),
+                                       ('ct', 'tpqkf', 70000, 6, ('1', '700')), ('reentry5', 'gpqkf', 70000, 9, ('1',))):
         monkeypatch.setenv('SSMQ_FUSED_CHUNKED', '0')
         wl = FilterBench(amd, B, T, 5, wl_name, filt)
         if wl_name == 'reentry5' and filt == 'ukf':       # some trajectories that fail on the way: not-PD initial covariances
