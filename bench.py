@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 SETTLE_S = 0.06          # continuous untimed passes before the warm-up passes (clock ramp-up after the idle set-up)
 
-from benchlib.common import (HBM_PEAK_GBS, CLOCK_HZ, F64_MFMA_PEAK_TF, pmc_traffic, pmc_traffic_named, pmc_issue,     # noqa: E402,F401
+from benchlib.common import (HBM_PEAK_GBS, CLOCK_HZ, F64_MFMA_PEAK_TF, pmc_traffic, pmc_traffic_named, pmc_traffic_source, pmc_issue,     # noqa: E402,F401
                              issue_block, settle, timed_passes, cpu_port_info, host_cores, c_port_transforms,
                              cpu_baseline_filter, cpu_baseline_apply)
 from benchlib.workloads import simulate_ungm, simulate_reentry, synthetic_reentry6, FilterBench                        # noqa: E402,F401
@@ -163,7 +163,7 @@ def main():
                        'comm_world': devices['comm_world']},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(wl.kernel, wl.ld),
-                         'kernel': wl.kernel,
+                         'traffic_source': pmc_traffic_source(), 'kernel': wl.kernel,
                          'bytes_per_launch': bytes_pass, 'ms_per_launch': pass_ms_dev,
                          'note': 'the contract\'s HBM figure for the headline filter pass (a serial recursion per trajectory: '
                                  'roofline_issue and DESIGN.md 3.4); the north-star transform is target_*'},

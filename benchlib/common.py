@@ -50,6 +50,18 @@ def pmc_traffic(kernel_name, grid=None):
     return hits[0].get('hbm_bytes_per_launch') if len(hits) == 1 else None
 
 
+def pmc_traffic_source():
+    """Where `roofline.traffic` / `target_traffic` come from: the committed PMC summary (NOT counters of this run - rocprofv3
+    --pmc cannot run inside the timed command), with the commit and date that summary was collected on."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    return 'profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; tree {}, collected {})'.format(
+        table.get('_commit', 'unknown'), table.get('_collected', 'unknown'))
+
+
 def pmc_traffic_named(prefix):
     """HBM bytes per launch of the ONE entry of profiles/pmc_traffic.json whose kernel name (what stands before its template
     arguments and the grid) is `prefix`."""
@@ -74,15 +86,17 @@ def cpu_port_info():
     return dict(_CPU_PORT)
 
 
-def host_cores(max_threads=16):
-    """Host threads the CPU baseline may use: this process's CPU share, at most 16 (a 1-GPU box's share)."""
+def host_cores(max_threads=None):
+    """Host threads the CPU baseline uses: ALL the cores this process may run on ("all host cores"; rounds 1-5
+    capped this at 16, which understated the baseline on the 64-core boxes).  The record carries the count as `cores`."""
     from oracle import c_oracle as co
     cpu_port_info()
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    return min(cores, co.max_threads(), max_threads)
+    cores = min(cores, co.max_threads())
+    return min(cores, max_threads) if max_threads else cores
 
 
 def c_port_transforms(wl):

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SSMQ_VERSION 101
+#define SSMQ_VERSION 102
 
 #define SSMQ_OK 0
 #define SSMQ_E_ARG (-1)          /* bad argument (null pointer, size out of range, unknown id) */

@@ -46,6 +46,8 @@ def main():
                             'note': 'bytes = counter_KiB * 1024 * factor; factor ~2 on the read side is the gfx950 '
                                     'FETCH_SIZE under-count'}}
     out['_commit'] = os.environ.get('SSMQ_COMMIT', 'unknown')     # the tree these counters were collected on
+    import datetime
+    out['_collected'] = datetime.datetime.utcnow().strftime('%Y-%m-%d %H:%M UTC')
     for (name, grid), v in fetch.items():
         if ('k_apply_small<6' in name.replace(' ', '') or 'k_filter_fused' in name or 'k_filter_chunked' in name or 'k_fxwc' in name or
                 'k_eval_wave' in name or 'k_apply_tile' in name or 'k_big_rest' in name or 'k_bq_fused' in name or 'k_bq_stream' in name):

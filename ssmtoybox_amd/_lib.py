@@ -12,7 +12,7 @@ import numpy as np
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
-ABI_VERSION = 101          # include/ssmq.h SSMQ_VERSION this binding's struct layouts and prototypes were written for
+ABI_VERSION = 102          # include/ssmq.h SSMQ_VERSION this binding's struct layouts and prototypes were written for
 SSMQ_MAX_FPAR = 16
 SSMQ_MAX_FIDX = 16
 FORM_BQ, FORM_SIGMA = 0, 1

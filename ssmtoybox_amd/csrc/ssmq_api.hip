@@ -5,9 +5,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
+#include <unistd.h>
 #include <vector>
 #include "ssmq_host.h"
 #include "ssmq_update.h"
@@ -50,6 +53,40 @@ struct CtxHolder {
 thread_local CtxHolder t_holder;
 thread_local bool t_first_call = true;
 }  // namespace
+
+// ---- switches: one snapshot of the environment, re-read only when the environment changed (ssmq_host.h) --------------------
+namespace {
+struct SwitchSnapshot {
+    std::mutex mu;
+    uint64_t sig = 0;
+    std::unordered_map<std::string, const char *> vals;      // nullptr = unset
+    std::deque<std::string> pool;                            // values are never freed: callers may hold the pointer
+};
+uint64_t environ_signature() {
+    uint64_t h = 1469598103934665603ull;
+    for (char **e = ::environ; e && *e; ++e) h = (h ^ (uint64_t)(uintptr_t)*e) * 1099511628211ull;
+    return h ^ (uint64_t)(uintptr_t)::environ;
+}
+}  // namespace
+const char *sw(const char *name) {
+    static SwitchSnapshot c;
+    std::lock_guard<std::mutex> g(c.mu);
+    const uint64_t s = environ_signature();
+    if (s != c.sig) {
+        c.vals.clear();
+        c.sig = s;
+    }
+    auto it = c.vals.find(name);
+    if (it == c.vals.end()) {
+        const char *v = getenv(name);
+        if (v) {
+            c.pool.emplace_back(v);
+            v = c.pool.back().c_str();
+        }
+        it = c.vals.emplace(name, v).first;
+    }
+    return it->second;
+}
 
 Ctx &ctx() {
     if (!t_holder.c) {
@@ -121,10 +158,29 @@ HandleGuard::HandleGuard(const ssmq_transform *h0, const ssmq_transform *h1) : a
         if (!h || (h->owner == &me && h->owner_epoch == me.epoch)) continue;
         if (h->owner) {
             // last used from another context: what that context queued on its stream - uploads of the handle's constants, buffers
-            // built on first use, kernels still reading them - is complete before this one goes on
-            std::lock_guard<std::mutex> l(registry().mu);
-            const Ctx *o = (const Ctx *)h->owner;
-            if (o->stream && o->epoch == h->owner_epoch) hipStreamSynchronize(o->stream);
+            // built on first use, kernels still reading them - precedes whatever this context queues next.  Under the registry lock
+            // only an EVENT is recorded on the owner's stream (the lock keeps the owner's stream alive); this context's stream
+            // waits for it after the lock is released, so one thread's pending GPU work no longer stalls every other thread's
+            // first call / hand-over behind the global mutex.  Everything the library does to a handle's device
+            // blocks is stream-ordered (hipMemcpyAsync / kernels on the context's stream; hipFree synchronises the device).
+            hipEvent_t ev = nullptr;
+            {
+                std::lock_guard<std::mutex> l(registry().mu);
+                const Ctx *o = (const Ctx *)h->owner;
+                if (o->stream && o->epoch == h->owner_epoch && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+                    if (o->dev != me.dev) hipSetDevice(o->dev);
+                    if (hipEventRecord(ev, o->stream) != hipSuccess) {
+                        hipStreamSynchronize(o->stream);        // (cannot happen; the old behaviour as the fallback)
+                        hipEventDestroy(ev);
+                        ev = nullptr;
+                    }
+                    if (o->dev != me.dev) hipSetDevice(me.dev);
+                }
+            }
+            if (ev) {
+                if (me.stream == nullptr || hipStreamWaitEvent(me.stream, ev, 0) != hipSuccess) hipEventSynchronize(ev);
+                hipEventDestroy(ev);         // (released once the event has completed)
+            }
         }
         h->owner = &me;
         h->owner_epoch = me.epoch;
@@ -288,7 +344,7 @@ static int upload_consts(ssmq_transform *h) {
                 for (int k = 0; k <= std::min(i, j); ++k) v += U[i * N + k] * dd[k] * U[j * N + k];
                 err = std::max(err, std::fabs(v - A[i * N + j]));
             }
-        if (ok && err <= 1e-14 * wmax && !getenv("SSMQ_NO_FASTPATH")) {
+        if (ok && err <= 1e-14 * wmax && !ssmq::sw("SSMQ_NO_FASTPATH")) {
             h->opt_mask |= SSMQ_OPT_LDL;
             for (int j = 0; j < N; ++j) {
                 s[cs.ldlD + j] = dd[j];
@@ -296,7 +352,7 @@ static int upload_consts(ssmq_transform *h) {
             }
         }
     }
-    if (N == 2 * D + 1 && !getenv("SSMQ_NO_FASTPATH")) {
+    if (N == 2 * D + 1 && !ssmq::sw("SSMQ_NO_FASTPATH")) {
         const double cc = h->xi[0 * N + 1];
         bool ut = cc > 0.0;
         for (int d = 0; d < D && ut; ++d)
@@ -313,7 +369,7 @@ static int upload_consts(ssmq_transform *h) {
     }
     std::vector<double> wpad;
     const int np = sigma ? 0 : gemm_mfma_padded(N);
-    if (np && !getenv("SSMQ_NO_MFMA")) {
+    if (np && !ssmq::sw("SSMQ_NO_MFMA")) {
         wpad.assign((size_t)np * np, 0.0);
         for (int i = 0; i < N; ++i)
             for (int j = 0; j < N; ++j) wpad[(size_t)i * np + j] = h->Wc[i * N + j];
@@ -382,7 +438,7 @@ static int upload_consts(ssmq_transform *h) {
             SSMQ_HIP(hipStreamSynchronize(stream()));
         }
     }
-    if (!sigma && N > 64 && !np && !getenv("SSMQ_NO_MFMA")) {
+    if (!sigma && N > 64 && !np && !ssmq::sw("SSMQ_NO_MFMA")) {
         // any other point count beyond the wave kernels: Wc (and iK for the t-process) as column blocks of kBigCols
         // columns, block c = [kb 16][kBigCols] zero-padded, for the blocked GEMM (launch_fxwc_blocks)
         // the Wc blocks carry D extra columns from column 16 kb on: Wcc', so that fx Wcc' comes out of the same GEMM
@@ -655,7 +711,7 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
             const WideLayout wl = wide_layout(h->D, h->E, h->N, h->form);
             return launch_bq_fused(a, h->d_sx_pad, h->d_wide + wl.emv, h->emv_mode == SSMQ_EMV_BROADCAST ? 1 : 0, B, stream());
         }
-        if (h->tp_nu <= 0.0 && h->d_wcx_pad && fxwc_cov_supported(h->E) && h->D <= 16 && !getenv("SSMQ_NO_FUSED_COV")) {
+        if (h->tp_nu <= 0.0 && h->d_wcx_pad && fxwc_cov_supported(h->E) && h->D <= 16 && !ssmq::sw("SSMQ_NO_FUSED_COV")) {
             // two passes: (1) one wave per trajectory: factor, points, integrand values, mean; (2) the GEMM whose
             // epilogue forms the covariance and the cross-covariance from its accumulators
             if ((rc = gemm_scratch(M, NP, B, h->D, &fx, &tt, &chol, true))) return rc;
@@ -874,6 +930,8 @@ int ssmq_event_destroy(void *ev) {
 }
 int ssmq_event_record(void *ev) {
     if (!ev) return SSMQ_E_ARG;
+    if (int rc = ensure_device()) return rc;        // a thread's FIRST call: its context has no stream yet (the NULL stream would not
+                                                    // bracket the work the thread queues afterwards)
     SSMQ_HIP(hipEventRecord((hipEvent_t)ev, stream()));
     return SSMQ_OK;
 }
@@ -1339,7 +1397,7 @@ int ssmq_apply_fx_batch(ssmq_transform *h, int64_t B, const double *chol, const 
         SSMQ_HIP(hipMemsetAsync(fxp, 0, sizeof(double) * M * NP, s));
         SSMQ_HIP(hipMemcpy2DAsync(fxp, sizeof(double) * NP, dfx, sizeof(double) * N, sizeof(double) * N, M,
                                   hipMemcpyDeviceToDevice, s));
-        if (h->tp_nu <= 0.0 && h->d_wcx_pad && fxwc_cov_supported(E) && D <= 16 && !getenv("SSMQ_NO_FUSED_COV")) {
+        if (h->tp_nu <= 0.0 && h->d_wcx_pad && fxwc_cov_supported(E) && D <= 16 && !ssmq::sw("SSMQ_NO_FUSED_COV")) {
             // means of the supplied values, then the GEMM whose epilogue forms both covariances (no T in memory)
             const WideLayout wl = wide_layout(D, E, N, h->form);
             if ((rc = launch_row_means(fxp, h->d_wide + wl.wm, M, NP, N, omf, s))) return rc;
@@ -1593,7 +1651,7 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
     // one fused kernel for the whole time loop when this (models, shapes, form) combination has one (it does not keep
     // the predictive moments, so a pass that has to store them for the smoother takes the launch loop)
     const bool keep_pred = d_pm && d_pP && d_pC;
-    if (!getenv("SSMQ_NO_FUSED") && !keep_pred) {
+    if (!ssmq::sw("SSMQ_NO_FUSED") && !keep_pred) {
         FInfo fio;
         if (!integrand_info(f_obs->id, &fio)) {
             set_error("unknown integrand id");
@@ -1605,7 +1663,7 @@ static int filter_forward_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dy
         if (rc < 0) return rc;
         if (rc == 1) return SSMQ_OK;
     }
-    if (!getenv("SSMQ_NO_FUSED") && keep_pred && !sscale && student_dof == 0.0) {
+    if (!ssmq::sw("SSMQ_NO_FUSED") && keep_pred && !sscale && student_dof == 0.0) {
         // smoother: the time loop in one kernel that also leaves the predictive moments of every step in HBM
         FInfo fio;
         if (!integrand_info(f_obs->id, &fio)) {
@@ -1726,7 +1784,7 @@ static int filter_forward_aug_impl(ssmq_transform *h_dyn, const ssmq_integrand *
     SSMQ_HIP(hipStreamSynchronize(s));   // the host staging vectors above go out of scope with this call
 
     // one kernel for the whole time loop when this combination has an instantiation (ssmq_filter_fused.hip)
-    if (!getenv("SSMQ_NO_FUSED")) {
+    if (!ssmq::sw("SSMQ_NO_FUSED")) {
         FInfo fio;
         if (!integrand_info(f_obs->id, &fio)) {
             set_error("unknown integrand id");
@@ -2284,7 +2342,7 @@ static int gp_theta_step_impl(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn
         // two launches + two copies: replay measured no faster (52 us either way).  Per-item times = the batched marginalised
         // filter, whose item count changes from round to round: every new count would be captured, instantiated and evict an
         // older entry of the six-slot cache without ever being replayed.
-        if (two_launch || times || getenv("SSMQ_NO_THETA_GRAPH")) {
+        if (two_launch || times || ssmq::sw("SSMQ_NO_THETA_GRAPH")) {
             if ((rc = enqueue())) return rc;
         } else if (!tg) {
             if (g_theta_graphs.size() >= 6) {       // the oldest entry goes, not all of them (a filter alternates between two item counts)
@@ -2567,7 +2625,7 @@ extern "C" int ssmq_filter_kernel_name_batch(const ssmq_transform *h_dyn, const 
     FInfo fio;
     if (!integrand_info(f_obs->id, &fio)) return SSMQ_E_ARG;
     const char *name = nullptr;
-    int rc = getenv("SSMQ_NO_FUSED") ? 0
+    int rc = ssmq::sw("SSMQ_NO_FUSED") ? 0
                                      : try_launch_fused(h_dyn, f_dyn, h_obs, f_obs, sel_pattern(f_obs, fio.din), B, 0, 0,
                                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                         nullptr, nullptr, &name, true, nullptr, 0.0, nullptr, nullptr);

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
 template <int DM, int KS, int FC>
 hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
     WideArgs aw = a;
-    aw.wave_k = getenv("SSMQ_TILE_NO_MROW") ? 1 : 0;
+    aw.wave_k = ssmq::sw("SSMQ_TILE_NO_MROW") ? 1 : 0;
     const bool mrow = a.form != SSMQ_FORM_SIGMA && a.D <= 15 && aw.wave_k == 0;
     const TileGeom tg = tile_geom(a.D, a.E, a.N, a.tp_nu > 0.0, mrow);
     const size_t lds = sizeof(double) * ((size_t)tg.frag_doubles + (size_t)kTileWaves * tg.wave_doubles);
@@ -435,7 +435,7 @@ hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
     const int64_t groups = (B + tg.G - 1) / tg.G, blocks = (groups + kTileWaves - 1) / kTileWaves;
     // a few workgroups per CU, each walking its share of the batch: the constants' fragments are built once per workgroup
     const int64_t cap = 256 * SSMQ_TILE_WGS_PER_CU;
-    if (getenv("SSMQ_TILE_DEBUG")) {
+    if (ssmq::sw("SSMQ_TILE_DEBUG")) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_apply_tile<DM, KS, FC>, 64 * kTileWaves, lds);
         fprintf(stderr, "k_apply_tile: %zu bytes of LDS, %d workgroups per CU\n", lds, nb);
@@ -465,7 +465,7 @@ size_t tile_lds_bytes(int D, int E, int N, bool tp) {
 
 // whole transforms (built-in integrand, one constant block for the batch) of this shape run on the matrix cores
 bool wide_full_uses_tile(int D, int E, int N) {
-    return N > 8 && N <= 64 && D <= 16 && E <= 16 && !getenv("SSMQ_NO_TILE") && !getenv("SSMQ_NO_WAVE") &&
+    return N > 8 && N <= 64 && D <= 16 && E <= 16 && !ssmq::sw("SSMQ_NO_TILE") && !ssmq::sw("SSMQ_NO_WAVE") &&
            tile_lds_bytes(D, E, N, true) <= 160 * 1024 - 64;
 }
 

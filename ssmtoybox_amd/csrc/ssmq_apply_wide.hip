@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64 * kWaveWaves) void k_apply_wave(const WideArgs a
 // trajectories per wave: as many as there are N-lane groups, but not so many that the LDS slices leave the SIMDs with
 // fewer than ~3 waves each (the kernel waits on LDS / L2 round trips; measured at D = 10, N = 21: K = 1 / 2 / 3)
 static int wave_groups(int D, int E, int N, bool tp) {
-    if (const char *k = getenv("SSMQ_WAVE_K")) return std::max(1, std::min(64 / N, atoi(k)));
+    if (const char *k = ssmq::sw("SSMQ_WAVE_K")) return std::max(1, std::min(64 / N, atoi(k)));
     const size_t slice = sizeof(double) * (size_t)((wave_lds_doubles(D, E, N, tp) + 1) & ~1);
     const size_t budget = (160 * 1024) / 12;                 // 12 waves per CU
     return (int)std::max<size_t>(1, std::min<size_t>(64 / N, budget / std::max<size_t>(slice, 1)));
@@ -698,7 +698,7 @@ static hipError_t launch_wave_one(const WideArgs &a, int64_t B, hipStream_t s) {
 }
 // whole transforms (built-in integrand) of this shape run one wave per trajectory (k_apply_wave) rather than one workgroup
 bool wide_full_uses_wave(int D, int E, int N) {
-    return N >= 1 && N <= 64 && !getenv("SSMQ_NO_WAVE") && wave_lds_bytes(D, E, N, true, 1) <= 160 * 1024 - 64;
+    return N >= 1 && N <= 64 && !ssmq::sw("SSMQ_NO_WAVE") && wave_lds_bytes(D, E, N, true, 1) <= 160 * 1024 - 64;
 }
 static bool wave_route(const WideArgs &a) { return a.mode == SSMQ_WIDE_FULL && wide_full_uses_wave(a.D, a.E, a.N); }
 static hipError_t launch_apply_wave(const WideArgs &a, int64_t B, hipStream_t s) {
@@ -775,7 +775,7 @@ static bool update_is_specialised(int D, int Y) {
 }
 
 bool theta_chain_supported(int Din, int D, int Y, int Nd, int No) {
-    return !getenv("SSMQ_NO_THETA_FUSED") && wide_full_uses_wave(Din, D, Nd) && wide_full_uses_wave(D, Y, No) && Nd <= 64 && No <= 64;
+    return !ssmq::sw("SSMQ_NO_THETA_FUSED") && wide_full_uses_wave(Din, D, Nd) && wide_full_uses_wave(D, Y, No) && Nd <= 64 && No <= 64;
 }
 
 template <int DM, bool GEN>
@@ -843,7 +843,7 @@ hipError_t launch_apply_wide(const WideArgs &a, int64_t B, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set_epoch = device_epoch();
     }
-    if ((int64_t)a.E * a.N >= 1024 && !getenv("SSMQ_WIDE_ONE_WAVE"))
+    if ((int64_t)a.E * a.N >= 1024 && !ssmq::sw("SSMQ_WIDE_ONE_WAVE"))
         hipLaunchKernelGGL(k_apply_wide<256>, dim3((unsigned)B), dim3(256), lds, s, a);
     else
         hipLaunchKernelGGL(k_apply_wide<64>, dim3((unsigned)B), dim3(64), lds, s, a);

@@ -505,7 +505,7 @@ hipError_t launch_fused_nt(const BqFusedArgs &g, size_t lds, hipStream_t s) {
 // BQ transform (not the t-process one) with one constant block for the batch, 64 < N <= 208 points (the 128- and
 // 208-column instantiations of the matrix-core route), whole trajectories filling at least 48 of a tile's 64 rows
 bool bq_fused_supported(int D, int E, int N) {
-    if (getenv("SSMQ_NO_BQ_FUSED")) return false;
+    if (ssmq::sw("SSMQ_NO_BQ_FUSED")) return false;
     const int np = gemm_mfma_padded(N);
     if (np != 128 && np != 208) return false;
     // D <= 15: column 15 of the Wcc' tile of X carries wm (ssmq_api.hip: upload of d_wcx_pad)

@@ -375,7 +375,7 @@ int bq_stream_tpw(int E) { return 64 / E; }
 static void bq_stream_split(int64_t nblocks, int npan, int cus, int *n_whole, int *n_tail) {
     *n_whole = (int)nblocks;
     *n_tail = 0;
-    if (npan < 2 || cus < 1 || getenv("SSMQ_BQ_STREAM_NO_SPLIT")) return;
+    if (npan < 2 || cus < 1 || ssmq::sw("SSMQ_BQ_STREAM_NO_SPLIT")) return;
     const int64_t rem = nblocks % cus;
     if (rem == 0 || 5 * rem > 3 * cus) return;      // a last round that is more than 60 % full: leave it
     *n_tail = (int)rem;
@@ -392,9 +392,9 @@ size_t bq_stream_x_doubles(int N) { return ((size_t)bq_stream_panels(N) * kPanT 
 // BQ transform (not the t-process one), one constant block for the batch, 208 < N <= SSMQ_MAX_PTS, a symmetric Wc; whole
 // trajectories fill at least 3/4 of a 64-row tile for every E <= 10
 bool bq_stream_supported(int D, int E, int N) {
-    if (getenv("SSMQ_NO_BQ_STREAM") || getenv("SSMQ_NO_MFMA")) return false;
+    if (ssmq::sw("SSMQ_NO_BQ_STREAM") || ssmq::sw("SSMQ_NO_MFMA")) return false;
     // (A/B: SSMQ_BQ_STREAM_MIN_N lowers the bound - the two-launch route at N = 201 against k_bq_fused)
-    const char *mn = getenv("SSMQ_BQ_STREAM_MIN_N");
+    const char *mn = ssmq::sw("SSMQ_BQ_STREAM_MIN_N");
     if (N <= (mn ? atoi(mn) : 208) || N > SSMQ_MAX_PTS) return false;
     return D >= 1 && D <= 15 && E >= 1 && E <= 10;      // D <= 15: column 15 of the G tile carries wm
 }

@@ -68,7 +68,7 @@ int load_rccl() {
     }
     g_rccl.lib = h;
     g_stub_marker = dlsym(h, "ssmq_stub_rccl_marker") != nullptr;
-    if (getenv("SSMQ_COMM_HOST_STAGING") && getenv("SSMQ_COMM_HOST_STAGING")[0] == '1' && !g_stub_marker) {
+    if (ssmq::sw("SSMQ_COMM_HOST_STAGING") && ssmq::sw("SSMQ_COMM_HOST_STAGING")[0] == '1' && !g_stub_marker) {
         ssmq::set_error("ssmq_comm: SSMQ_COMM_HOST_STAGING=1 is a test hook for the stand-in librccl (tests/stub_rccl); the library "
                         "that was loaded is not the stand-in");
         return SSMQ_E_UNSUPPORTED;
@@ -88,7 +88,7 @@ int nccl_fail(int rc, const char *what) {
 // with the real RCCL: the switch is honoured only if the loaded library exports `ssmq_stub_rccl_marker`, which only the
 // stand-in does - with the real library host pointers would otherwise reach ncclAllReduce.
 bool host_staging() {
-    static const bool asked = getenv("SSMQ_COMM_HOST_STAGING") && getenv("SSMQ_COMM_HOST_STAGING")[0] == '1';
+    static const bool asked = ssmq::sw("SSMQ_COMM_HOST_STAGING") && ssmq::sw("SSMQ_COMM_HOST_STAGING")[0] == '1';
     return asked && g_stub_marker;
 }
 

@@ -9,6 +9,13 @@
 
 namespace ssmq {
 
+// The SSMQ_* switches (A/B toggles of tools/alt_paths.sh, test hooks).  The library does not call getenv() per launch: every
+// switch is looked up in a process-wide SNAPSHOT that is filled on first use and thrown away only when the environment itself
+// has changed since (a signature over the `environ` pointer array - setenv / putenv replace the entry's pointer), so a test may
+// still flip a switch between two calls.  nullptr = unset.  The returned string lives for the life of the process.
+const char *sw(const char *name);
+
+
 typedef const __attribute__((address_space(4))) double *cdouble_p;   // constant address space: scalar loads
 
 // Integrand constants as they travel in the kernel-argument segment (wave-uniform -> SGPRs).

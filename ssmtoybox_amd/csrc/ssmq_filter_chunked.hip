@@ -22,6 +22,17 @@
 //     every chunk boundary costs ~6 us of exposed memory round trips and equal chunks quantise again (9.16 rounds of chunks are 10):
 //     0.459 -> 0.432 ms.  The strips: 0.455 -> 0.405 ms (reentry UKF 5-D, B = 1e5), 0.584 -> 0.514 (6-D), 0.448 -> 0.285 at B = 7e4
 //     (1 094 blocks: 1.07 rounds instead of 2) - the balanced figure at the ~2.07 GHz the chip holds with every SIMD busy.
+//     Ordering, stated once: producer = [state: system-scope atomic stores, sc0 sc1 = write-through past the
+//     per-XCD L2] -> release fence, workgroup scope (s_waitcnt vmcnt(0): every one of those stores has been ACKNOWLEDGED by
+//     memory; plus the compiler barrier) -> __syncthreads -> [flag: system-scope atomic store].  Consumer = [spin on a system-scope
+//     atomic load of the flag] -> acquire fence, workgroup scope (compiler barrier: the loads below stay below) -> [state:
+//     system-scope atomic loads, sc0 sc1 = served from memory, never from this XCD's L2].  Every access of the shared words is an
+//     atomic of system scope, so there is no data race in the language's sense; what the fences do NOT do is write back / invalidate
+//     L2 (agent- or system-scope fences would: buffer_wbl2 / buffer_inv, ~0.5 us each) - and they need not, because no access of
+//     these words is ever cached: that is the code sequence LLVM's AMDGPU memory model documents for system-scope atomics on
+//     gfx942 / gfx950 (AMDGPUUsage, "Memory Model gfx942": "sc0=1 sc1=1" on loads, stores and RMWs of system scope), not an
+//     observed accident.  Stress test: tests/test_gpu_parity.py::test_chunked_many_small_strips_across_xcds (SSMQ_FUSED_CHUNKED=n,
+//     hundreds of hand-overs per launch, bitwise against the whole pass).
 //   * Every wait is bounded (~seconds; then the block's trajectories are marked failed at step 0) although none is ever long.
 #include "ssmq_filter_fused_kernel.h"
 
@@ -69,6 +80,11 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : ((D >= 5 && FORM == SSMQ
                 if ((int)threadIdx.x < a.lpw && b < a.B) a.status[b] = 1;
                 break;
             }
+            // ACQUIRE side of the hand-over (see the ordering note above the kernel): nothing below - in particular the system-scope
+            // loads of a.hand in fused_pass - may be moved above the flag observation by the compiler, and the wave's own counters
+            // are drained before it goes on.  Workgroup scope on purpose: it emits no cache invalidate, and none is needed, because
+            // the state is READ with sc0 sc1 loads that do not look at the non-coherent levels.
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         if ((int)threadIdx.x < a.lpw) fused_pass<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, STU, true>(a, (uint32_t)blk, kb, ke, kb == 0, ke == a.T);
         if (is_head) {
@@ -116,7 +132,7 @@ const ChunkedEntry kChunked[] = {
 // The results ARE the whole-pass kernel's bits (test_chunked_time_loop_is_bitwise_the_whole_pass).
 int try_launch_chunked(const FusedArgs &a0, int fd, int fo, int D, int Y, int ND, int NO, int form, int tp, int selo, int opt, int cus,
                        hipStream_t s, bool dry_run, const char **name) {
-    const char *ev = getenv("SSMQ_FUSED_CHUNKED");
+    const char *ev = ssmq::sw("SSMQ_FUSED_CHUNKED");
     const int force = ev ? atoi(ev) : -1;
     if (force == 0 || a0.sscale != nullptr || a0.student_dof > 0.0 || (!dry_run && a0.T < 2)) return 0;
     const ChunkedEntry *e = nullptr;

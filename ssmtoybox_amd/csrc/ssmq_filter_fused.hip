@@ -353,7 +353,7 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
     if (!dry_run || B > 0) {
         // batches that leave most of the chip idle: sigma points shared out over the waves of a workgroup (ssmq_filter_wsplit.hip)
         const int rw = try_launch_wsplit(hd, fd, ho, fo, sel_obs, B, ld, T, d_y, d_m0, d_P0, d_gqg, d_rr, d_fm, d_fP, d_status, s, name,
-                                         dry_run, d_sscale, student_dof, dry_run ? 256 : device_cus());
+                                         dry_run, d_sscale, student_dof, device_cus());    // (the dry run asks the same device: 256 only without one)
         if (rw != 0) return rw;
     }
     const int tp = hd->tp_nu > 0.0 ? 1 : 0;
@@ -373,7 +373,7 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
             memset(&a, 0, sizeof(a));
             a.B = B; a.T = T; a.lpw = 64; a.sscale = d_sscale; a.student_dof = student_dof;
             if (dry_run) {
-                if (B > 0) (void)try_launch_chunked(a, e.fd, e.fo, e.D, e.Y, e.ND, e.NO, e.form, e.tp, e.selo, e.opt, 256, s, true, name);
+                if (B > 0) (void)try_launch_chunked(a, e.fd, e.fo, e.D, e.Y, e.ND, e.NO, e.form, e.tp, e.selo, e.opt, device_cus(), s, true, name);
                 return 1;
             }
             a.y = d_y; a.m0 = d_m0; a.P0 = d_P0; a.fm = d_fm; a.fP = d_fP; a.status = d_status;
@@ -381,7 +381,7 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
             a.emv_dyn = hd->emv_mode; a.emv_obs = ho->emv_mode; a.nu_dyn = hd->tp_nu; a.nu_obs = ho->tp_nu;
             a.sscale = d_sscale; a.student_dof = student_dof;
             a.lpw = 64;
-            if (const char *ev = getenv("SSMQ_FUSED_LPW")) {
+            if (const char *ev = ssmq::sw("SSMQ_FUSED_LPW")) {
                 const int v = atoi(ev);
                 if (v == 16 || v == 32 || v == 64) a.lpw = v;
             }

@@ -471,7 +471,7 @@ static int ws_groups_per_cu(const WsplitEntry &e) { return e.W == 4 ? 1 : (e.W =
 // tests).
 static bool ws_wanted(const WsplitEntry &e, int64_t B, int cus) {
     int forced = -1;
-    if (const char *ev = getenv("SSMQ_FUSED_WSPLIT")) forced = atoi(ev);
+    if (const char *ev = ssmq::sw("SSMQ_FUSED_WSPLIT")) forced = atoi(ev);
     if (forced == 0) return false;
     if (forced > 0) return e.W == forced;
     // Measured (tools/wsplit_time.py, profiles/r05_wsplit.txt): the split pays where a point costs hundreds of instructions - the

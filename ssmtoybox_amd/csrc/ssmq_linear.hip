@@ -111,7 +111,7 @@ int launch_linearize(int D, int E, int din, const ssmq_integrand *f, const FPar 
     a.mean_f = d_mean_f; a.cov_f = d_cov_f; a.cov_fx = d_cov_fx; a.status = d_status; a.B = B; a.ld = ld;
     a.cov_scale = cov_scale; a.ccov_scale = ccov_scale; a.fp = fp;
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
-    const bool generic = getenv("SSMQ_LINEAR_GENERIC") != nullptr;      // tools/alt_paths.sh: the run-time-size body for every shape
+    const bool generic = ssmq::sw("SSMQ_LINEAR_GENERIC") != nullptr;      // tools/alt_paths.sh: the run-time-size body for every shape
     if (generic) hipLaunchKernelGGL((k_linearize<0, 0>), grid, block, 0, s, a);
     else if (D == 1 && E == 1) hipLaunchKernelGGL((k_linearize<1, 1>), grid, block, 0, s, a);
     else if (D == 2 && E == 1) hipLaunchKernelGGL((k_linearize<2, 1>), grid, block, 0, s, a);

@@ -872,7 +872,7 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
     // keeps the rounds below (the route of every other shape)
     int32_t hc[4] = {0, 0, 0, 0};
     const MgPersistentEntry *pe = nullptr;
-    if (!getenv("SSMQ_MARGINAL_ROUNDS") && !getenv("SSMQ_NO_THETA_ITEM") && NP == 2 * P && PX == P)
+    if (!ssmq::sw("SSMQ_MARGINAL_ROUNDS") && !ssmq::sw("SSMQ_NO_THETA_ITEM") && NP == 2 * P && PX == P)
         for (const MgPersistentEntry &e : kMgPersistent)
             if (e.P == P && e.Din == Din && e.D == D && e.Y == Y && e.Nd == h_dyn->N && e.No == h_obs->N) pe = &e;
     if (pe) {
@@ -886,7 +886,7 @@ int marginal_filter_batch_device(ssmq_transform *h_dyn, const ssmq_integrand *f_
         if ((rc = hip_fail(hipGetLastError(), "k_mg_persistent"))) return rc;
     } else {
     hipLaunchKernelGGL(k_mg_init<PM>, dim3(tg), dim3(tb), 0, s, a);
-    const bool fused_scan = B <= 8192 && per <= 32 && !getenv("SSMQ_MARGINAL_SCAN_KERNEL");
+    const bool fused_scan = B <= 8192 && per <= 32 && !ssmq::sw("SSMQ_MARGINAL_SCAN_KERNEL");
     const int64_t tpb_fill = 256 / per;
     // Rounds are queued kRoundsAhead ahead of the scan count the device reports through pinned host memory; nothing in this loop
     // waits for the device (round 5's first version synchronised every eighth round: a bubble of a copy and a launch each time).
@@ -968,7 +968,7 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
     if (B == 0 || T == 0) return SSMQ_OK;
     // the state machines on the device where the theta step has its two-launch route and the parameter count an instantiation
     // (SSMQ_MARGINAL_HOST_ROUNDS=1: the host rounds below, round 4's route, kept as the second implementation of the same filter)
-    if (!getenv("SSMQ_MARGINAL_HOST_ROUNDS") && P <= 16 && NP <= 32 && theta_dev_supported(h_dyn, f_dyn, h_obs, f_obs)) {
+    if (!ssmq::sw("SSMQ_MARGINAL_HOST_ROUNDS") && P <= 16 && NP <= 32 && theta_dev_supported(h_dyn, f_dyn, h_obs, f_obs)) {
 #define SSMQ_MG_DEV(PM, PX) marginal_filter_batch_device<PM, PX>(h_dyn, f_dyn, h_obs, f_obs, B, T, jitter, y, x0_mean, x0_cov, q_mean, q_cov, GQG, R, \
                                                               prior_mean, prior_cov, upts, uwts, NP, fd_step, param_jitter, fm, fP, failed,      \
                                                               theta_last, pcov_last, stats)
@@ -1017,10 +1017,10 @@ extern "C" int ssmq_gp_marginal_filter_batch(ssmq_transform *h_dyn, const ssmq_i
     int64_t rounds = 0, iters = 0, total_items = 0;
     // worker threads: SSMQ_MARGINAL_THREADS (0 = none), else up to 8 and never more than the trajectories could use
     int n_workers = 7;
-    if (const char *e = getenv("SSMQ_MARGINAL_THREADS")) n_workers = std::max(0, atoi(e) - 1);
+    if (const char *e = ssmq::sw("SSMQ_MARGINAL_THREADS")) n_workers = std::max(0, atoi(e) - 1);
     n_workers = (int)std::min<int64_t>(std::min<unsigned>((unsigned)n_workers, std::max(1u, std::thread::hardware_concurrency()) - 1), B / 256);
     Workers pool(n_workers);
-    const bool timing = getenv("SSMQ_MARGINAL_TIMING") != nullptr;      // host-side budget of the rounds, printed at the end
+    const bool timing = ssmq::sw("SSMQ_MARGINAL_TIMING") != nullptr;      // host-side budget of the rounds, printed at the end
     double t_pack = 0.0, t_call = 0.0, t_adv = 0.0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {

@@ -83,7 +83,7 @@ const ThetaItemEntry kThetaItem[] = {
 };
 
 const ThetaItemEntry *find_theta_item(int Din, int D, int Y, int Nd, int No) {
-    if (getenv("SSMQ_NO_THETA_ITEM")) return nullptr;
+    if (ssmq::sw("SSMQ_NO_THETA_ITEM")) return nullptr;
     for (const ThetaItemEntry &e : kThetaItem)
         if (e.Din == Din && e.D == D && e.Y == Y && e.Nd == Nd && e.No == No) return &e;
     return nullptr;

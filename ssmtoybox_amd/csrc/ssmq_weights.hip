@@ -1135,7 +1135,7 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
         // up to 8 points every loop of the kernel has at most 64 iterations: one wave per parameter row does the same
         // arithmetic (each thread still owns at most one element of every N x N step) with barriers that cost nothing,
         // and four times as many rows are resident per CU - the theta-batched callers launch 1e4 ... 1e5 rows
-        const int threads = (N <= 8 && a.NB <= 8 && !getenv("SSMQ_WEIGHTS_WIDE_BLOCK")) ? 64 : 256;
+        const int threads = (N <= 8 && a.NB <= 8 && !ssmq::sw("SSMQ_WEIGHTS_WIDE_BLOCK")) ? 64 : 256;
         hipLaunchKernelGGL(k_weights<256>, dim3(a.P), dim3(threads), sizeof(double) * 2 * nn, s, a);
         return hip_fail(hipGetLastError(), "k_weights");
     }
@@ -1145,9 +1145,9 @@ static int launch_weights(WgtArgs &a, hipStream_t s) {
         SSMQ_HIP(hipFuncSetAttribute((const void *)k_weights_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         attr_epoch = ssmq::device_epoch();
     }
-    const bool staged = packed <= lds_cap && N <= kInvLanes * kInvSlots && !getenv("SSMQ_WEIGHTS_NO_LDS");
+    const bool staged = packed <= lds_cap && N <= kInvLanes * kInvSlots && !ssmq::sw("SSMQ_WEIGHTS_NO_LDS");
     const bool unisolvent = a.NB == N && !a.var_mode;      // N x N LU inverse in one workgroup: not a large-N case in practice
-    if (!staged && !unisolvent && !getenv("SSMQ_WEIGHTS_ONE_WG")) {
+    if (!staged && !unisolvent && !ssmq::sw("SSMQ_WEIGHTS_ONE_WG")) {
         // factor, inverse and the two N^3 products on many workgroups (k_wb_*), the rest in k_weights<1024> stages 3 and 4
         static thread_local unsigned wb_epoch = 0;
         if (wb_epoch != ssmq::device_epoch()) {
@@ -1460,7 +1460,7 @@ int gp_theta_weights_pair(const int D[2], const int E[2], const int N[2], const 
         t.consts[i] = d_consts[i];
         t.E[i] = E[i];
         lds = std::max(lds, sizeof(double) * theta_weights_lds_doubles(D[i], N[i]));
-        if (N[i] > 8 || getenv("SSMQ_WEIGHTS_WIDE_BLOCK")) threads = 256;     // as launch_weights
+        if (N[i] > 8 || ssmq::sw("SSMQ_WEIGHTS_WIDE_BLOCK")) threads = 256;     // as launch_weights
     }
     static thread_local unsigned attr_epoch = 0;
     if (lds > 48 * 1024 && attr_epoch != ssmq::device_epoch()) {

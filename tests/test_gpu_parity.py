@@ -3065,6 +3065,13 @@ def test_config3_reentry_filters_1e5(amd):
     # unscented filter, all 1e5 trajectories on the device, a 4000-trajectory sample against the oracle
     alg = ssinf.UnscentedKalman(dyn, obs)
     assert 'k_filter_fused<D=6,Y=2' in alg.kernel_name()
+    # the ROUTE this batch takes (ssmq_filter_kernel_name_batch), not only the shape: 1 563 blocks on 1 024 SIMDs -> the strips
+    # (tools/alt_paths.sh forces the choice either way through the environment; then the forced route is the one named)
+    forced = os.environ.get('SSMQ_FUSED_CHUNKED')
+    if forced is None and 'SSMQ_NO_FUSED' not in os.environ:
+        assert 'k_filter_chunked<D=6,Y=2' in alg.kernel_name(B), alg.kernel_name(B)
+    elif forced == '0':
+        assert 'k_filter_fused<D=6,Y=2' in alg.kernel_name(B)
     fm, fP = alg.forward_pass_batch(y)
     idx = np.random.default_rng(0).choice(B, 4000, replace=False)
     pts = orc.points_ut(6)
@@ -3089,6 +3096,8 @@ def test_config3_reentry_filters_1e5(amd):
     bsq.tf_dyn.model.model_var = 2e-6 * np.eye(5)
     bsq.tf_obs.model.model_var = 0 * np.eye(2)
     assert 'k_filter_fused<D=5,Y=2' in bsq.kernel_name()
+    if 'SSMQ_FUSED_CHUNKED' not in os.environ and 'SSMQ_NO_FUSED' not in os.environ:
+        assert 'k_filter_fused<D=5,Y=2' in bsq.kernel_name(Bs), bsq.kernel_name(Bs)      # 313 blocks: every wave has a SIMD, whole passes
     fm, fP = bsq.forward_pass_batch(y5, raise_on_failure=False)
     td, k5 = _c_bq_transform(bsq.tf_dyn, 5, co.Integrand.make(orc.F_REENTRY2D_DYN, (0.1,)))
     to, k6 = _c_bq_transform(bsq.tf_obs, 2, co.Integrand.make(orc.F_RADAR2D_MEAS, (0.0, 0.0)))
@@ -3206,6 +3215,9 @@ def test_config4_tpq_ct_bearing_1e4(amd):
     par = np.array([[1.0, 100, 100, 100, 100, 1]])
     alg = ssinf.StudentProcessKalman(dyn, obs, par, par)
     assert 'k_filter_fused<D=5,Y=4' in alg.kernel_name()
+    # the route at B = 1e4 (157 blocks on 1 024 SIMDs): the t-process form runs with its points split over two waves
+    if 'SSMQ_FUSED_WSPLIT' not in os.environ and 'SSMQ_NO_FUSED' not in os.environ:
+        assert 'k_filter_wsplit' in alg.kernel_name(B) and 'W=2>' in alg.kernel_name(B), alg.kernel_name(B)
     fm, fP = alg.forward_pass_batch(y, raise_on_failure=False)
     nu = float(alg.tf_dyn.model.nu)
     td, k1 = _c_bq_transform(alg.tf_dyn, 5, co.Integrand.make(orc.F_CT_DYN, (dt,)), nu, 1)
@@ -3456,6 +3468,29 @@ def test_chunked_time_loop_is_bitwise_the_whole_pass(amd, monkeypatch):
             monkeypatch.delenv('SSMQ_FUSED_CHUNKED')
             assert 'k_filter_chunked<' in wl.alg.kernel_name(B)       # 1 094 blocks on 1 024 SIMDs: the default takes the strips
         wl.free()
+    monkeypatch.delenv('SSMQ_FUSED_CHUNKED', raising=False)
+
+
+def test_chunked_many_small_strips_across_xcds(amd, monkeypatch):
+    """Stress of the strip hand-over's ordering (csrc/ssmq_filter_chunked.hip, "Ordering"): strip counts just below the block count
+    make nearly every wave both publish a state and consume one, on compute units of different XCDs, hundreds of hand-overs per
+    launch and thousands over the repetitions; a stale or torn state would change bits of the filtered moments.  Every pass must
+    be the whole-pass kernel's bits."""
+    from benchlib.workloads import FilterBench
+    B, T = 70000, 16           # 1 094 blocks
+    monkeypatch.setenv('SSMQ_FUSED_CHUNKED', '0')
+    wl = FilterBench(amd, B, T, 21, 'reentry5', 'ukf')
+    wl.step()
+    ref = wl.results()
+    for strips in ('1093', '1000', '777', '547'):
+        monkeypatch.setenv('SSMQ_FUSED_CHUNKED', strips)
+        assert 'k_filter_chunked<' in wl.alg.kernel_name(B)
+        for rep in range(12):
+            wl.d_fm.upload(np.zeros((T, wl.D, wl.ld)))
+            wl.step()
+            got = wl.results()
+            assert all(np.array_equal(g, r, equal_nan=True) for g, r in zip(got, ref)), (strips, rep)
+    wl.free()
     monkeypatch.delenv('SSMQ_FUSED_CHUNKED', raising=False)
 
 

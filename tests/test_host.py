@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.ssmq_version() == _lib.ABI_VERSION == 101
+    assert lib.ssmq_version() == _lib.ABI_VERSION == 102
 
 
 def test_integrand_struct_layout():

@@ -5,19 +5,19 @@
 # one wave per trajectory in the generic kernel, the wave kernel instead of the matrix-core tile kernel, the tile kernel's
 # D = 16 mean path, the two-pass matrix-core route instead of the one-launch kernel, the launch-per-stage theta step, the blocked route instead of k_bq_stream, the single-workgroup large-N weights, the run-time-size linearisation kernel, k_bq_stream without the panel-wise tail.  The size tests are left out (they take the default paths anyway).
 # Round 5: the two-launch theta step instead of k_theta_item, the device rounds / the host rounds of the batched marginalised filter instead
-# of the one-launch kernel, no wave split, the fused time loop never / wherever possible as chunks from a queue.
+# of the one-launch kernel, no wave split, the fused time loop never / wherever possible as strips
+# (SSMQ_FUSED_CHUNKED=64: 64 strips for every batch of more than 64 blocks; "=1" only meant "default" and is no longer in the list).
+# Exit status: non-zero when any run failed.
 # usage: tools/alt_paths.sh [VAR=value ...]   (default: every toggle)
 list="$*"
-[ -z "$list" ] && list="SSMQ_NO_FUSED=1 SSMQ_NO_FASTPATH=1 SSMQ_NO_FUSED_COV=1 SSMQ_NO_MFMA=1 SSMQ_WEIGHTS_NO_LDS=1 SSMQ_WIDE_ONE_WAVE=1 SSMQ_NO_WAVE=1 SSMQ_NO_TILE=1 SSMQ_TILE_NO_MROW=1 SSMQ_NO_BQ_FUSED=1 SSMQ_NO_THETA_FUSED=1 SSMQ_NO_BQ_STREAM=1 SSMQ_WEIGHTS_ONE_WG=1 SSMQ_LINEAR_GENERIC=1 SSMQ_BQ_STREAM_NO_SPLIT=1 SSMQ_NO_THETA_ITEM=1 SSMQ_MARGINAL_ROUNDS=1 SSMQ_MARGINAL_HOST_ROUNDS=1 SSMQ_FUSED_WSPLIT=0 SSMQ_FUSED_CHUNKED=0 SSMQ_FUSED_CHUNKED=1"
+[ -z "$list" ] && list="SSMQ_NO_FUSED=1 SSMQ_NO_FASTPATH=1 SSMQ_NO_FUSED_COV=1 SSMQ_NO_MFMA=1 SSMQ_WEIGHTS_NO_LDS=1 SSMQ_WIDE_ONE_WAVE=1 SSMQ_NO_WAVE=1 SSMQ_NO_TILE=1 SSMQ_TILE_NO_MROW=1 SSMQ_NO_BQ_FUSED=1 SSMQ_NO_THETA_FUSED=1 SSMQ_NO_BQ_STREAM=1 SSMQ_WEIGHTS_ONE_WG=1 SSMQ_LINEAR_GENERIC=1 SSMQ_BQ_STREAM_NO_SPLIT=1 SSMQ_NO_THETA_ITEM=1 SSMQ_MARGINAL_ROUNDS=1 SSMQ_MARGINAL_HOST_ROUNDS=1 SSMQ_FUSED_WSPLIT=0 SSMQ_FUSED_CHUNKED=0 SSMQ_FUSED_CHUNKED=64"
+fail=0
 for kv in $list; do
   v=${kv%%=*}
   echo "== $kv"
   env $kv timeout -k 10 300 python -m pytest tests -m gpu -q -k "not sixteen_million and not at_scale and not config3 and not full_batch" > gpurun_out/pytest_env_${v}_${kv##*=}.log 2>&1
+  rc=$?
   tail -2 gpurun_out/pytest_env_${v}_${kv##*=}.log
+  if [ $rc -ne 0 ]; then echo "   FAILED (exit $rc): $kv"; fail=1; fi
 done
-exit 0
-for v in SSMQ_NO_FUSED SSMQ_NO_FASTPATH SSMQ_NO_FUSED_COV SSMQ_NO_MFMA SSMQ_WEIGHTS_NO_LDS SSMQ_WIDE_ONE_WAVE SSMQ_NO_WAVE SSMQ_NO_TILE SSMQ_TILE_NO_MROW SSMQ_NO_BQ_FUSED SSMQ_NO_THETA_FUSED SSMQ_NO_BQ_STREAM SSMQ_WEIGHTS_ONE_WG SSMQ_LINEAR_GENERIC SSMQ_BQ_STREAM_NO_SPLIT; do
-  echo "== $v=1"
-  env $v=1 timeout -k 10 300 python -m pytest tests -m gpu -q -k "not sixteen_million and not at_scale and not config3 and not full_batch" > gpurun_out/pytest_env_$v.log 2>&1
-  tail -2 gpurun_out/pytest_env_$v.log
-done
+exit $fail

@@ -2,9 +2,11 @@
 # Produces the artefacts committed under profiles/: bench JSON, rocprofv3 kernel stats of the same command, PMC traffic.
 set -e
 export TMPDIR=/tmp
-tag=${1:-r05_final}
+tag=${1:-r06_final}
 out=gpurun_out/$tag
 mkdir -p $out
+# the tree these numbers belong to: tools/stamp_tree.sh writes TREE_ID before the gpurun call (there is no .git on the GPU box)
+export SSMQ_COMMIT=$(cat TREE_ID 2>/dev/null || echo unknown)
 python bench.py --detail $out/bench_detail.json > $out/bench.json 2> $out/bench.err      # bench.json: the result line (what the driver keeps)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline --detail $out/bench_prof_detail.json > $out/bench_prof.json 2> $out/bench_prof.err
 bash profiles/collect_pmc.sh $out/pmc > $out/pmc.log 2>&1
@@ -28,8 +30,9 @@ PY
 tail -1 $out/bench.json
 head -8 $out/kernel_stats.csv | cut -c1-160
 cat $out/pmc_traffic.json
-# performance gate against the previous round's trace (profiles/r04_h_bench_kernel_stats_by_grid.csv), as a markdown table
-prev=$(ls profiles/r04_h_bench_kernel_stats_by_grid.csv 2>/dev/null | tail -1)
+# performance gate against the newest committed trace (the previous round's or this round's earlier one), as a markdown table
+prev=$(ls profiles/r0*_bench_kernel_stats_by_grid.csv 2>/dev/null | sort | tail -1)
+echo "perf gate baseline: $prev"
 if [ -n "$prev" ]; then
     python3 tools/perf_gate.py "$prev" $out/kernel_stats_by_grid.csv --markdown --matched-only > $out/perf_gate.md 2> $out/perf_gate.err || echo "perf_gate: REGRESSION (see $out/perf_gate.err)"
     cat $out/perf_gate.err

@@ -8,7 +8,8 @@ cp $src/bench_detail.json profiles/${tag}_bench_detail.json
 cp $src/kernel_stats.csv profiles/${tag}_bench_kernel_stats.csv
 cp $src/kernel_stats_by_grid.csv profiles/${tag}_bench_kernel_stats_by_grid.csv
 cp $src/pmc_traffic.json profiles/pmc_traffic.json
-cp $src/pmc_fused/summary.csv profiles/r05_fused_sq.csv
+rnd=${tag%%_*}
+cp $src/pmc_fused/summary.csv profiles/${rnd}_fused_sq.csv
 cp $src/perf_gate.md profiles/${tag}_perf_gate.md
-[ -f gpurun_out/parity_stats.json ] && cp gpurun_out/parity_stats.json profiles/r05_parity_stats.json
-ls -la profiles/${tag}_* profiles/pmc_traffic.json profiles/r05_fused_sq.csv
+[ -f gpurun_out/parity_stats.json ] && python3 tools/keep_larger_json.py gpurun_out/parity_stats.json profiles/${rnd}_parity_stats.json
+ls -la profiles/${tag}_* profiles/pmc_traffic.json profiles/${rnd}_fused_sq.csv
