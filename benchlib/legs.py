@@ -328,6 +328,107 @@ def measure_c5_degree7(amd, B=10000, iters=5, with_cpu=True):
     return rec
 
 
+class Study6Bench:
+    """The six filters of the reference's UNGM studies (UKF, CKF, GHKF-5, GPQKF, TPQKF, BSQKF; research/bsq/bsq_ungm.py:132-137,
+    research/tpq/tpq_base.py:175-192) over the SAME B x T measurements, device-resident: one after the other
+    (ssmq_filter_forward_dev six times) and as one launch graph (ssmq_filter_forward_multi_dev)."""
+
+    def __init__(self, amd, B, T, seed):
+        from ssmtoybox_amd import _lib, ssmod as sm, ssinf
+        from ssmtoybox_amd.mtran import resolve_integrand
+        from benchlib.workloads import simulate_ungm
+        self._lib, self.B, self.T = _lib, B, T
+        self.ld = ld = (B + 63) // 64 * 64
+        dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+        obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+        par, mi = np.array([[1.0, 3.0]]), np.array([[0, 1, 2]])
+        self.names = ['ukf', 'ckf', 'ghkf5', 'gpqkf', 'tpqkf', 'bsqkf']
+        self.algs = [ssinf.UnscentedKalman(dyn, obs), ssinf.CubatureKalman(dyn, obs), ssinf.GaussHermiteKalman(dyn, obs, deg=5),
+                     ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut'),
+                     ssinf.StudentProcessKalman(dyn, obs, par, par, 'rbf', 'ut'), ssinf.BayesSardKalman(dyn, obs, par, par, mi, mi, 'ut')]
+        _, y = simulate_ungm(B, T, seed)
+        ybuf = np.zeros((T, 1, ld))
+        ybuf[:, 0, :B] = y
+        self.d_y = _lib.DeviceBuffer(ybuf.nbytes)
+        self.d_y.upload(ybuf)
+        mb, Pb = np.zeros((1, ld)), np.ones((1, ld))
+        self.d_m0, self.d_P0 = _lib.DeviceBuffer(mb.nbytes), _lib.DeviceBuffer(Pb.nbytes)
+        self.d_m0.upload(mb)
+        self.d_P0.upload(Pb)
+        self.f_dyn, _ = resolve_integrand(dyn.dyn_eval)
+        self.f_obs, _ = resolve_integrand(obs.meas_eval)
+        self.gqg, self.pg = _lib.as_c(np.array([[10.0]]))
+        self.rr, self.pr = _lib.as_c(np.array([[1.0]]))
+        self.out, self.out2 = [], []
+        self.jobs = (_lib.FilterJob * len(self.algs))()
+        for i, a in enumerate(self.algs):
+            bufs = [(_lib.DeviceBuffer(8 * T * ld), _lib.DeviceBuffer(8 * T * ld), _lib.DeviceBuffer(4 * ld)) for _ in range(2)]
+            self.out.append(bufs[0])
+            self.out2.append(bufs[1])
+            j = self.jobs[i]
+            j.h_dyn, j.f_dyn = a.tf_dyn._handle_for(1), ctypes.pointer(self.f_dyn)
+            j.h_obs, j.f_obs = a.tf_obs._handle_for(1), ctypes.pointer(self.f_obs)
+            j.B, j.ld, j.T = B, ld, T
+            j.d_y, j.d_m0, j.d_P0 = self.d_y.ptr, self.d_m0.ptr, self.d_P0.ptr
+            j.GQG, j.R = self.pg, self.pr
+            j.d_fm, j.d_fP, j.d_status = bufs[0][0].ptr, bufs[0][1].ptr, bufs[0][2].ptr
+
+    def _single(self, i, bufs):
+        j = self.jobs[i]
+        self._lib.check(self._lib.load().ssmq_filter_forward_dev(
+            ctypes.c_void_p(j.h_dyn), j.f_dyn, ctypes.c_void_p(j.h_obs), j.f_obs, self.B, self.ld, self.T, ctypes.c_void_p(self.d_y.ptr),
+            ctypes.c_void_p(self.d_m0.ptr), ctypes.c_void_p(self.d_P0.ptr), self.pg, self.pr, ctypes.c_void_p(bufs[0].ptr),
+            ctypes.c_void_p(bufs[1].ptr), ctypes.c_void_p(bufs[2].ptr)), 'ssmq_filter_forward_dev')
+
+    def _timed(self, step, blocks=5, per=20):
+        settle(step, self._lib.sync)
+        times = []
+        for _ in range(blocks):
+            e0, e1 = self._lib.Event(), self._lib.Event()
+            e0.record()
+            for _ in range(per):
+                step()
+            e1.record()
+            times.append(e0.elapsed_ms(e1) / per)
+        return float(np.median(times))
+
+    def time_single(self, i):
+        return self._timed(lambda: self._single(i, self.out2[i]))
+
+    def time_serial(self):
+        def step():
+            for i in range(len(self.algs)):
+                self._single(i, self.out2[i])
+        return self._timed(step)
+
+    def time_multi(self):
+        lib = self._lib.load()
+        return self._timed(lambda: self._lib.check(lib.ssmq_filter_forward_multi_dev(len(self.algs), self.jobs),
+                                                   'ssmq_filter_forward_multi_dev'))
+
+    def check(self):
+        """The multi-launch's outputs against the single calls', bit for bit."""
+        lib = self._lib.load()
+        for i in range(len(self.algs)):
+            self._single(i, self.out2[i])
+        self._lib.check(lib.ssmq_filter_forward_multi_dev(len(self.algs), self.jobs), 'ssmq_filter_forward_multi_dev')
+        self._lib.sync()
+        T, ld = self.T, self.ld
+        ok = True
+        for a, b in zip(self.out, self.out2):
+            ok = ok and np.array_equal(a[0].download((T, ld)), b[0].download((T, ld)), equal_nan=True)
+            ok = ok and np.array_equal(a[1].download((T, ld)), b[1].download((T, ld)), equal_nan=True)
+            ok = ok and np.array_equal(a[2].download((ld,), dtype=np.int32), b[2].download((ld,), dtype=np.int32))
+        return bool(ok)
+
+    def free(self):
+        for bufs in self.out + self.out2:
+            for b in bufs:
+                b.free()
+        for b in (self.d_y, self.d_m0, self.d_P0):
+            b.free()
+
+
 class Mt6Bench:
     """Batched GPQ moment transform, D = E = 6, N = 13, B = 1e5, rotating buffer sets (> 256 MB in total so that the
     Infinity Cache cannot hold the working set between launches)."""

@@ -551,6 +551,34 @@ int ssmq_student_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integrand 
                                     const double *d_m0, const double *d_S0, const double *GqG, const double *r_smat,
                                     const double *scale, double dof, double *d_fm, double *d_fP, int32_t *d_status);
 
+/*
+ * A independent filters in ONE launch (round 6; ABI 102).  The reference's studies run several filters over the same
+ * measurements one after the other (research/bsq/bsq_ungm.py:132-137, research/tpq/tpq_base.py:175-192); a pass of 1e4
+ * trajectories occupies a sixth of the device, so the passes of a study fit side by side.  Each job is one call of
+ * ssmq_filter_forward_dev (scale == NULL, dof == 0) or of ssmq_student_filter_forward_dev (scale [T] host, dof > 0) with
+ * the same argument meaning; jobs may share d_y / d_m0 / d_P0 (read only) but not their outputs.  The calling thread's
+ * stream forks into one branch per job inside a captured launch graph and joins again: the jobs run concurrently on the
+ * device, every job is its own fused time-loop kernel (the results are the bits of the single calls), and a repeated call
+ * with the same job list is one graph launch.  Jobs whose (models, shapes, form) have no fused kernel run after the graph,
+ * one by one, through the ordinary path.  Asynchronous on the calling thread's stream; d_status as for the single calls.
+ * At most 64 jobs.  The strip schedule (k_filter_chunked) is not used for the jobs of a multi-launch.
+ */
+typedef struct ssmq_filter_job {
+    ssmq_transform *h_dyn;
+    const ssmq_integrand *f_dyn;
+    ssmq_transform *h_obs;
+    const ssmq_integrand *f_obs;
+    int64_t B, ld;
+    int32_t T, reserved;
+    const double *d_y, *d_m0, *d_P0; /* device: [T][Y][ld], [D][ld], [D*D][ld] */
+    const double *GQG, *R;           /* host: [D*D], [Y*Y] (NULL = zeros) */
+    double *d_fm, *d_fP;             /* device: [T][D][ld], [T][D*D][ld] */
+    int32_t *d_status;               /* device: [ld] */
+    const double *scale;             /* host [T]: Studentian recursion (with dof > 0), NULL for the Gaussian filters */
+    double dof;
+} ssmq_filter_job;
+int ssmq_filter_forward_multi_dev(int n_jobs, const ssmq_filter_job *jobs);
+
 /* Name of the kernel(s) ssmq_filter_forward_dev would run for this pair of transforms (for profiles). */
 int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
                             const ssmq_integrand *f_obs, char *buf, int len);

@@ -58,6 +58,16 @@ class Rv(ctypes.Structure):
 
 RV_GAUSS, RV_STUDENT, RV_MIXTURE = 0, 1, 2
 
+
+class FilterJob(ctypes.Structure):
+    """struct ssmq_filter_job: one filter of ssmq_filter_forward_multi_dev (the arguments of ssmq_filter_forward_dev /
+    ssmq_student_filter_forward_dev)."""
+    _fields_ = [('h_dyn', ctypes.c_void_p), ('f_dyn', ctypes.POINTER(Integrand)), ('h_obs', ctypes.c_void_p),
+                ('f_obs', ctypes.POINTER(Integrand)), ('B', ctypes.c_int64), ('ld', ctypes.c_int64), ('T', ctypes.c_int32),
+                ('reserved', ctypes.c_int32), ('d_y', ctypes.c_void_p), ('d_m0', ctypes.c_void_p), ('d_P0', ctypes.c_void_p),
+                ('GQG', c_double_p), ('R', c_double_p), ('d_fm', ctypes.c_void_p), ('d_fP', ctypes.c_void_p),
+                ('d_status', ctypes.c_void_p), ('scale', c_double_p), ('dof', ctypes.c_double)]
+
 _PROTOTYPES = {
     # name: (restype, argtypes)
     'ssmq_version': (ctypes.c_int, []),
@@ -118,6 +128,7 @@ _PROTOTYPES = {
                                                ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                c_double_p, c_double_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_void_p]),
+    'ssmq_filter_forward_multi_dev': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(FilterJob)]),
     'ssmq_filter_forward_aug_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
                                                    ctypes.POINTER(Integrand), ctypes.c_int, ctypes.c_int64,
                                                    ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

@@ -145,6 +145,39 @@ int ensure_device() {
 hipStream_t stream() { return ctx().stream; }
 unsigned device_epoch() { return ctx().epoch; }
 
+// A context that picks up handle `h` (locked by the caller) after another context used it: see HandleGuard.
+static void adopt_handle(const ssmq_transform *h, Ctx &me) {
+    if (!h || (h->owner == &me && h->owner_epoch == me.epoch)) return;
+    if (h->owner) {
+        // last used from another context: what that context queued on its stream - uploads of the handle's constants, buffers
+        // built on first use, kernels still reading them - precedes whatever this context queues next.  Under the registry lock
+        // only an EVENT is recorded on the owner's stream (the lock keeps the owner's stream alive); this context's stream
+        // waits for it after the lock is released, so one thread's pending GPU work no longer stalls every other thread's
+        // first call / hand-over behind the global mutex.  Everything the library does to a handle's device
+        // blocks is stream-ordered (hipMemcpyAsync / kernels on the context's stream; hipFree synchronises the device).
+        hipEvent_t ev = nullptr;
+        {
+            std::lock_guard<std::mutex> l(registry().mu);
+            const Ctx *o = (const Ctx *)h->owner;
+            if (o->stream && o->epoch == h->owner_epoch && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+                if (o->dev != me.dev) hipSetDevice(o->dev);
+                if (hipEventRecord(ev, o->stream) != hipSuccess) {
+                    hipStreamSynchronize(o->stream);        // (cannot happen; the old behaviour as the fallback)
+                    hipEventDestroy(ev);
+                    ev = nullptr;
+                }
+                if (o->dev != me.dev) hipSetDevice(me.dev);
+            }
+        }
+        if (ev) {
+            if (me.stream == nullptr || hipStreamWaitEvent(me.stream, ev, 0) != hipSuccess) hipEventSynchronize(ev);
+            hipEventDestroy(ev);         // (released once the event has completed)
+        }
+    }
+    h->owner = &me;
+    h->owner_epoch = me.epoch;
+}
+
 HandleGuard::HandleGuard(const ssmq_transform *h0, const ssmq_transform *h1) : a(h0), b(h1) {
     if (b == a) b = nullptr;
     if (!a) { a = b; b = nullptr; }
@@ -154,37 +187,20 @@ HandleGuard::HandleGuard(const ssmq_transform *h0, const ssmq_transform *h1) : a
     if (!a) return;
     (void)ensure_device();                         // (a failure is reported by the entry point's own call)
     Ctx &me = ctx();
-    for (const ssmq_transform *h : {a, b}) {
-        if (!h || (h->owner == &me && h->owner_epoch == me.epoch)) continue;
-        if (h->owner) {
-            // last used from another context: what that context queued on its stream - uploads of the handle's constants, buffers
-            // built on first use, kernels still reading them - precedes whatever this context queues next.  Under the registry lock
-            // only an EVENT is recorded on the owner's stream (the lock keeps the owner's stream alive); this context's stream
-            // waits for it after the lock is released, so one thread's pending GPU work no longer stalls every other thread's
-            // first call / hand-over behind the global mutex.  Everything the library does to a handle's device
-            // blocks is stream-ordered (hipMemcpyAsync / kernels on the context's stream; hipFree synchronises the device).
-            hipEvent_t ev = nullptr;
-            {
-                std::lock_guard<std::mutex> l(registry().mu);
-                const Ctx *o = (const Ctx *)h->owner;
-                if (o->stream && o->epoch == h->owner_epoch && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-                    if (o->dev != me.dev) hipSetDevice(o->dev);
-                    if (hipEventRecord(ev, o->stream) != hipSuccess) {
-                        hipStreamSynchronize(o->stream);        // (cannot happen; the old behaviour as the fallback)
-                        hipEventDestroy(ev);
-                        ev = nullptr;
-                    }
-                    if (o->dev != me.dev) hipSetDevice(me.dev);
-                }
-            }
-            if (ev) {
-                if (me.stream == nullptr || hipStreamWaitEvent(me.stream, ev, 0) != hipSuccess) hipEventSynchronize(ev);
-                hipEventDestroy(ev);         // (released once the event has completed)
-            }
-        }
-        h->owner = &me;
-        h->owner_epoch = me.epoch;
-    }
+    for (const ssmq_transform *h : {a, b}) adopt_handle(h, me);
+}
+MultiHandleGuard::MultiHandleGuard(std::vector<const ssmq_transform *> handles) : hs(std::move(handles)) {
+    hs.erase(std::remove(hs.begin(), hs.end(), nullptr), hs.end());
+    std::sort(hs.begin(), hs.end());
+    hs.erase(std::unique(hs.begin(), hs.end()), hs.end());
+    for (const ssmq_transform *h : hs) h->mu.lock();
+    if (hs.empty()) return;
+    (void)ensure_device();
+    Ctx &me = ctx();
+    for (const ssmq_transform *h : hs) adopt_handle(h, me);
+}
+MultiHandleGuard::~MultiHandleGuard() {
+    for (auto it = hs.rbegin(); it != hs.rend(); ++it) (*it)->mu.unlock();
 }
 HandleGuard::~HandleGuard() {
     if (b) b->mu.unlock();
@@ -365,6 +381,89 @@ static int upload_consts(ssmq_transform *h) {
         if (ut) {
             h->opt_mask |= SSMQ_OPT_UT;
             s[cs.utc] = cc;
+        }
+        // SSMQ_OPT_SYM: weights invariant under every reflection of the point set (swap of points 1 + k and 1 + D + k) up to the
+        // round-off of the weight computation: symmetrise, rebuild (wm, Wc, Wcc) from the symmetric parameters, accept if no
+        // weight moved by more than 2e-13 of the largest of its array; then the LDL' of the (D + 1) x (D + 1) symmetric block.
+        if (ut && !sigma && h->tp_nu <= 0.0) {
+            const int M = D + 1;
+            const double tol = 2e-13;
+            auto W = [&](int i, int j) { return h->Wc[(size_t)i * N + j]; };
+            std::vector<double> wms(M), gam(D), beta(D), Mt((size_t)M * M);
+            double dev_wm = 0.0, dev_wc = 0.0, dev_cc = 0.0, mx_wm = 0.0, mx_wc = 0.0, mx_cc = 0.0;
+            wms[0] = h->wm[0];
+            for (int k = 0; k < D; ++k) wms[1 + k] = 0.5 * (h->wm[1 + k] + h->wm[1 + D + k]);
+            for (int n = 0; n < N; ++n) {
+                mx_wm = std::max(mx_wm, std::fabs(h->wm[n]));
+                dev_wm = std::max(dev_wm, std::fabs(h->wm[n] - wms[n == 0 ? 0 : 1 + (n - 1) % D]));
+            }
+            for (int d = 0; d < D; ++d) {
+                gam[d] = 0.5 * (h->Wcc[(size_t)d * N + 1 + d] - h->Wcc[(size_t)d * N + 1 + D + d]);
+                for (int n = 0; n < N; ++n) {
+                    const double want = n == 1 + d ? gam[d] : (n == 1 + D + d ? -gam[d] : 0.0);
+                    mx_cc = std::max(mx_cc, std::fabs(h->Wcc[(size_t)d * N + n]));
+                    dev_cc = std::max(dev_cc, std::fabs(h->Wcc[(size_t)d * N + n] - want));
+                }
+            }
+            Mt[0] = W(0, 0);
+            for (int k = 0; k < D; ++k) {
+                const int p = 1 + k, q = 1 + D + k;
+                Mt[1 + k] = Mt[(size_t)(1 + k) * M] = 0.25 * (W(0, p) + W(0, q) + W(p, 0) + W(q, 0));
+                beta[k] = 0.25 * (W(p, p) + W(q, q) - W(p, q) - W(q, p));
+                for (int j = 0; j < D; ++j) {
+                    const int r = 1 + j, t = 1 + D + j;
+                    Mt[(size_t)(1 + k) * M + 1 + j] = 0.25 * (W(p, r) + W(p, t) + W(q, r) + W(q, t));
+                }
+            }
+            for (int i = 0; i < M; ++i)          // (symmetric by construction up to the asymmetry of Wc itself)
+                for (int j = 0; j < i; ++j) Mt[(size_t)i * M + j] = Mt[(size_t)j * M + i] = 0.5 * (Mt[(size_t)i * M + j] + Mt[(size_t)j * M + i]);
+            for (int i = 0; i < N; ++i)
+                for (int j = 0; j < N; ++j) {
+                    const int ci = i == 0 ? 0 : 1 + (i - 1) % D, cj = j == 0 ? 0 : 1 + (j - 1) % D;
+                    double want = Mt[(size_t)ci * M + cj];
+                    if (i != 0 && ci == cj) want += (i == j) ? beta[ci - 1] : -beta[ci - 1];
+                    mx_wc = std::max(mx_wc, std::fabs(W(i, j)));
+                    dev_wc = std::max(dev_wc, std::fabs(W(i, j) - want));
+                }
+            bool ok = dev_wm <= tol * mx_wm && dev_wc <= tol * mx_wc && dev_cc <= tol * mx_cc;
+            // Mt = Ut diag(d) Ut' with Ut unit UPPER triangular (the kernel meets the columns of G in increasing order): the LDL' of
+            // the index-reversed matrix, reversed back.  No pivoting; accepted only if it reproduces Mt to 1e-14.
+            std::vector<double> Lr((size_t)M * M, 0.0), dr(M, 0.0), Ut((size_t)M * M, 0.0), dd(M, 0.0);
+            auto Mr = [&](int i, int j) { return Mt[(size_t)(M - 1 - i) * M + (M - 1 - j)]; };
+            for (int j = 0; j < M && ok; ++j) {
+                double dj = Mr(j, j);
+                for (int k = 0; k < j; ++k) dj -= Lr[(size_t)j * M + k] * Lr[(size_t)j * M + k] * dr[k];
+                if (!(std::fabs(dj) > 1e-13 * mx_wc)) ok = false;
+                dr[j] = dj;
+                Lr[(size_t)j * M + j] = 1.0;
+                for (int i = j + 1; i < M && ok; ++i) {
+                    double v = Mr(i, j);
+                    for (int k = 0; k < j; ++k) v -= Lr[(size_t)i * M + k] * Lr[(size_t)j * M + k] * dr[k];
+                    Lr[(size_t)i * M + j] = v / dj;
+                }
+            }
+            for (int i = 0; i < M; ++i) {
+                dd[i] = dr[M - 1 - i];
+                for (int j = 0; j < M; ++j) Ut[(size_t)i * M + j] = Lr[(size_t)(M - 1 - i) * M + (M - 1 - j)];
+            }
+            double err = 0.0;
+            for (int i = 0; i < M && ok; ++i)
+                for (int j = 0; j < M; ++j) {
+                    double v = 0.0;
+                    for (int k = std::max(i, j); k < M; ++k) v += Ut[(size_t)i * M + k] * dd[k] * Ut[(size_t)j * M + k];
+                    err = std::max(err, std::fabs(v - Mt[(size_t)i * M + j]));
+                }
+            if (ok && err <= 1e-14 * mx_wc && (h->opt_mask & SSMQ_OPT_LDL) && !ssmq::sw("SSMQ_NO_SYM")) {
+                h->opt_mask |= SSMQ_OPT_SYM;
+                for (int j = 0; j < M; ++j) {
+                    double *r = s.data() + cs.sym + (size_t)j * cs.sym_rs;
+                    r[0] = wms[j];
+                    r[1] = dd[j];
+                    r[2] = j ? gam[j - 1] : 0.0;
+                    r[3] = j ? beta[j - 1] : 0.0;
+                    for (int i = 0; i < j; ++i) r[4 + i] = Ut[(size_t)i * M + j];
+                }
+            }
         }
     }
     std::vector<double> wpad;
@@ -603,8 +702,10 @@ int apply_dev_impl(ssmq_transform *h, const ssmq_integrand *f, int64_t B, int64_
     const SmallEntry *se = nullptr;
     if (sel >= 0) {
         // best available fast path first (TP keeps the dense covariance form; see SSMQ_OPT_* in ssmq_apply_small.h)
-        const int want[4] = {h->opt_mask & (tp ? SSMQ_OPT_UT : 3), h->opt_mask & SSMQ_OPT_UT, h->opt_mask & SSMQ_OPT_LDL & (tp ? 0 : 1), 0};
-        for (int k = 0; k < 4 && !se; ++k) se = find_small(f->id, h->D, h->E, h->N, h->form, tp, sel, want[k]);
+        const int want[5] = {(!tp && (h->opt_mask & 7) == 7) ? 7 : -1, h->opt_mask & (tp ? SSMQ_OPT_UT : 3), h->opt_mask & SSMQ_OPT_UT,
+                             h->opt_mask & SSMQ_OPT_LDL & (tp ? 0 : 1), 0};
+        for (int k = 0; k < 5 && !se; ++k)
+            if (want[k] >= 0) se = find_small(f->id, h->D, h->E, h->N, h->form, tp, sel, want[k]);
     }
     const bool wide_fits = wide_lds_bytes(h->D, h->E, h->N) <= 160 * 1024 - 64;
     // point sets beyond the wave kernels without a fused matrix-core instantiation: evaluation pass, blocked GEMM, rest
@@ -1526,6 +1627,7 @@ namespace ssmq {
 void reset_wide_attributes();
 void drop_staging_arena();
 void drop_theta_step_graphs();
+void drop_multi_cache();
 void reset_device_caches() {
     g_fc.drop_graph();
     drop_theta_step_graphs();
@@ -1536,6 +1638,7 @@ void reset_device_caches() {
     drop_gemm_scratch();
     drop_staging_arena();
     reset_wide_attributes();
+    drop_multi_cache();
     Ctx &c = ctx();
     if (c.strip_buf) hipFree(c.strip_buf);
     c.strip_buf = nullptr;
@@ -1720,6 +1823,240 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
     SSMQ_HANDLE_LOCK(h_dyn, h_obs);
     return filter_forward_impl(h_dyn, f_dyn, h_obs, f_obs, B, ld, T, d_y, d_m0, d_P0, GQG, R, d_fm, d_fP, d_status,
                                nullptr, 0.0);
+}
+
+// ---- A independent filters as ONE launch (round 6) -------------------------------------------------------------------------
+// The reference's studies run several filters over the same data, one after the other (research/bsq/bsq_ungm.py:132-137,
+// research/tpq/tpq_base.py:175-192).  A configs[1]-sized pass occupies 157 of the chip's 1 024 SIMDs, so A of them fit side by
+// side; what stood in the way was the launch path (round 5: six host threads reached 1.8 x).  Here the calling context's stream
+// forks into one branch per job inside a captured graph - each branch is the job's own fused time-loop kernel, so the RESULTS ARE
+// THE BITS of ssmq_filter_forward_dev / ssmq_student_filter_forward_dev - and joins again; a repeated call with the same jobs is one
+// hipGraphLaunch.  Jobs without a fused kernel run after the graph, one by one, through the ordinary path.
+namespace {
+struct MultiCache {
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> joined;
+    hipEvent_t fork = nullptr;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<uint64_t> key;
+    std::vector<char> fused;          // per job of the cached key: 1 = in the graph
+    void drop_graph() {
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph) hipGraphDestroy(graph);
+        exec = nullptr;
+        graph = nullptr;
+        key.clear();
+    }
+    void drop_all() {
+        drop_graph();
+        for (hipStream_t s : side) hipStreamDestroy(s);
+        for (hipEvent_t e : joined) hipEventDestroy(e);
+        if (fork) hipEventDestroy(fork);
+        side.clear();
+        joined.clear();
+        fork = nullptr;
+        if (ws) hipFree(ws);
+        ws = nullptr;
+        ws_bytes = 0;
+    }
+};
+MultiCache &multi_of_ctx() {
+    Ctx &c = ssmq::ctx();
+    if (!c.multi) c.multi = new MultiCache;
+    return *(MultiCache *)c.multi;
+}
+void key_bytes(std::vector<uint64_t> &key, const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t v; memcpy(&v, b + i, 8); key.push_back(v); }
+    if (i < n) { uint64_t v = 0; memcpy(&v, b + i, n - i); key.push_back(v); }
+}
+}  // namespace
+namespace ssmq {
+void drop_multi_cache() {
+    Ctx &c = ctx();
+    if (c.multi) ((MultiCache *)c.multi)->drop_all();
+}
+}  // namespace ssmq
+
+extern "C" int ssmq_filter_forward_multi_dev(int n_jobs, const ssmq_filter_job *jobs) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs) || n_jobs > 64) {
+        set_error("filter_forward_multi: bad job list (0 .. 64 jobs)");
+        return SSMQ_E_ARG;
+    }
+    if (n_jobs == 0) return SSMQ_OK;
+    std::vector<const ssmq_transform *> hs;
+    for (int i = 0; i < n_jobs; ++i) {
+        const ssmq_filter_job &j = jobs[i];
+        if (!j.h_dyn || !j.h_obs || !j.f_dyn || !j.f_obs || j.B < 0 || j.ld < j.B || j.T < 0 || !j.d_y || !j.d_m0 || !j.d_P0 || !j.d_fm ||
+            !j.d_fP || !j.d_status || (j.scale != nullptr) != (j.dof > 0.0)) {
+            set_error("filter_forward_multi: bad argument in job " + std::to_string(i));
+            return SSMQ_E_ARG;
+        }
+        if (j.h_dyn->E != j.h_dyn->D || j.h_obs->D != j.h_dyn->D) {
+            set_error("filter_forward_multi: additive-noise filter needs dyn (D -> D) and obs (D -> Y) transforms (job " + std::to_string(i) + ")");
+            return SSMQ_E_ARG;
+        }
+        for (int k = 0; k < i; ++k)
+            if (jobs[k].d_fm == j.d_fm || jobs[k].d_fP == j.d_fP || jobs[k].d_status == j.d_status) {
+                set_error("filter_forward_multi: jobs " + std::to_string(k) + " and " + std::to_string(i) + " share an output buffer");
+                return SSMQ_E_ARG;
+            }
+        hs.push_back(j.h_dyn);
+        hs.push_back(j.h_obs);
+    }
+    MultiHandleGuard guard(hs);
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = stream();
+    MultiCache &mc = multi_of_ctx();
+    // ---- the key: everything a captured launch depends on --------------------------------------------------------------------
+    std::vector<uint64_t> key = {(uint64_t)n_jobs};
+    for (int i = 0; i < n_jobs; ++i) {
+        const ssmq_filter_job &j = jobs[i];
+        const int D = j.h_dyn->D, Y = j.h_obs->E;
+        for (const void *p : {(const void *)j.h_dyn, (const void *)j.h_obs, (const void *)j.d_y, (const void *)j.d_m0, (const void *)j.d_P0,
+                              (const void *)j.d_fm, (const void *)j.d_fP, (const void *)j.d_status, (const void *)j.h_dyn->d_small,
+                              (const void *)j.h_obs->d_small})
+            key.push_back((uint64_t)(uintptr_t)p);
+        key.push_back((uint64_t)j.B); key.push_back((uint64_t)j.ld); key.push_back((uint64_t)j.T);
+        key_bytes(key, j.f_dyn, sizeof(ssmq_integrand));
+        key_bytes(key, j.f_obs, sizeof(ssmq_integrand));
+        key.push_back(((uint64_t)j.h_dyn->generation << 32) ^ (uint64_t)j.h_obs->generation);
+        key.push_back(((uint64_t)(uint32_t)j.h_dyn->opt_mask << 32) | (uint64_t)(uint32_t)j.h_obs->opt_mask);
+        key.push_back((uint64_t)j.h_dyn->emv_mode * 2 + (uint64_t)j.h_obs->emv_mode);
+        key_bytes(key, &j.h_dyn->tp_nu, 8); key_bytes(key, &j.h_obs->tp_nu, 8); key_bytes(key, &j.dof, 8);
+        if (j.GQG) key_bytes(key, j.GQG, sizeof(double) * D * D); else key.push_back(0);
+        if (j.R) key_bytes(key, j.R, sizeof(double) * Y * Y); else key.push_back(0);
+        if (j.scale) key_bytes(key, j.scale, sizeof(double) * j.T); else key.push_back(0);
+    }
+    key.push_back(ssmq::sw("SSMQ_NO_FUSED") ? 1 : 0);
+    key.push_back(ssmq::sw("SSMQ_MULTI_NO_GRAPH") ? 1 : 0);
+    auto run_rest = [&]() -> int {       // the jobs that are not in the graph, through the ordinary path, one by one
+        for (int i = 0; i < n_jobs; ++i) {
+            if (mc.fused[i]) continue;
+            const ssmq_filter_job &j = jobs[i];
+            const int r = filter_forward_impl(j.h_dyn, j.f_dyn, j.h_obs, j.f_obs, j.B, j.ld, j.T, j.d_y, j.d_m0, j.d_P0, j.GQG, j.R, j.d_fm,
+                                              j.d_fP, j.d_status, j.scale, j.dof);
+            if (r) return r;
+        }
+        return SSMQ_OK;
+    };
+    if (mc.exec && mc.key == key) {
+        SSMQ_HIP(hipGraphLaunch(mc.exec, s));
+        return run_rest();
+    }
+    mc.drop_graph();
+    // ---- per-job constants behind one allocation: G Q G', R, scale [T], the two time tables [T] ---------------------------------
+    size_t n_dbl = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const int D = jobs[i].h_dyn->D, Y = jobs[i].h_obs->E;
+        n_dbl += (size_t)D * D + (size_t)Y * Y + 3 * (size_t)jobs[i].T + 8;
+    }
+    if (mc.ws_bytes < sizeof(double) * n_dbl) {
+        SSMQ_HIP(hipStreamSynchronize(s));
+        if (mc.ws) hipFree(mc.ws);
+        mc.ws = nullptr;
+        mc.ws_bytes = 0;
+        SSMQ_HIP(hipMalloc(&mc.ws, sizeof(double) * n_dbl * 2));
+        mc.ws_bytes = sizeof(double) * n_dbl * 2;
+    }
+    std::vector<double> host(n_dbl, 0.0);
+    struct JobConsts { const double *gqg, *rr, *svec, *ttd, *tto; };
+    std::vector<JobConsts> jc(n_jobs);
+    {
+        size_t o = 0;
+        double *dev = (double *)mc.ws;
+        for (int i = 0; i < n_jobs; ++i) {
+            const ssmq_filter_job &j = jobs[i];
+            const int D = j.h_dyn->D, Y = j.h_obs->E, T = j.T;
+            jc[i].gqg = dev + o; if (j.GQG) memcpy(&host[o], j.GQG, sizeof(double) * D * D); o += (size_t)D * D;
+            jc[i].rr = dev + o; if (j.R) memcpy(&host[o], j.R, sizeof(double) * Y * Y); o += (size_t)Y * Y;
+            jc[i].svec = j.scale ? dev + o : nullptr; if (j.scale) memcpy(&host[o], j.scale, sizeof(double) * T); o += T;
+            const bool td = T > 0 && time_table(j.f_dyn->id, T, &host[o]);
+            jc[i].ttd = td ? dev + o : nullptr; o += T;
+            const bool to = T > 0 && time_table(j.f_obs->id, T, &host[o]);
+            jc[i].tto = to ? dev + o : nullptr; o += T;
+            o = (o + 7) / 8 * 8;
+        }
+    }
+    SSMQ_HIP(hipMemcpyAsync(mc.ws, host.data(), sizeof(double) * n_dbl, hipMemcpyHostToDevice, s));
+    SSMQ_HIP(hipStreamSynchronize(s));          // `host` goes out of scope; only when the job list changed
+    // ---- side streams and events -------------------------------------------------------------------------------------------
+    while ((int)mc.side.size() < n_jobs) {
+        hipStream_t ns = nullptr;
+        hipEvent_t ne = nullptr;
+        SSMQ_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        mc.side.push_back(ns);
+        SSMQ_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+        mc.joined.push_back(ne);
+    }
+    if (!mc.fork) SSMQ_HIP(hipEventCreateWithFlags(&mc.fork, hipEventDisableTiming));
+    // ---- which jobs have a fused kernel (dry run), then the fork / launch / join sequence, captured unless told otherwise -------
+    mc.fused.assign(n_jobs, 0);
+    std::vector<int> sel(n_jobs, -1);
+    const bool no_fused = ssmq::sw("SSMQ_NO_FUSED") != nullptr;
+    for (int i = 0; i < n_jobs && !no_fused; ++i) {
+        const ssmq_filter_job &j = jobs[i];
+        FInfo fio;
+        if (!integrand_info(j.f_obs->id, &fio)) {
+            set_error("unknown integrand id");
+            return SSMQ_E_ARG;
+        }
+        sel[i] = sel_pattern(j.f_obs, fio.din);
+        if (j.B == 0 || j.T == 0) continue;
+        const int r = try_launch_fused(j.h_dyn, j.f_dyn, j.h_obs, j.f_obs, sel[i], 0, j.ld, j.T, j.d_y, j.d_m0, j.d_P0, jc[i].gqg, jc[i].rr, j.d_fm,
+                                       j.d_fP, j.d_status, s, nullptr, true, jc[i].svec, j.dof, jc[i].ttd, jc[i].tto);
+        if (r < 0) return r;
+        mc.fused[i] = r == 1;
+    }
+    int n_fused = 0;
+    for (int i = 0; i < n_jobs; ++i) n_fused += mc.fused[i];
+    const bool capture = n_fused > 0 && !ssmq::sw("SSMQ_MULTI_NO_GRAPH");
+    Ctx &cx = ctx();
+    struct StripsOff {
+        Ctx &c;
+        explicit StripsOff(Ctx &c_) : c(c_) { c.no_strips = true; }
+        ~StripsOff() { c.no_strips = false; }
+    } strips_off(cx);
+    if (n_fused > 0) {
+        if (capture) SSMQ_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        rc = hip_fail(hipEventRecord(mc.fork, s), "hipEventRecord");
+        int b = 0;
+        for (int i = 0; i < n_jobs && !rc; ++i) {
+            if (!mc.fused[i]) continue;
+            const ssmq_filter_job &j = jobs[i];
+            hipStream_t bs = mc.side[b];
+            rc = hip_fail(hipStreamWaitEvent(bs, mc.fork, 0), "hipStreamWaitEvent");
+            if (!rc) {
+                const int r = try_launch_fused(j.h_dyn, j.f_dyn, j.h_obs, j.f_obs, sel[i], j.B, j.ld, j.T, j.d_y, j.d_m0, j.d_P0, jc[i].gqg, jc[i].rr,
+                                               j.d_fm, j.d_fP, j.d_status, bs, nullptr, false, jc[i].svec, j.dof, jc[i].ttd, jc[i].tto);
+                rc = r < 0 ? r : (r == 1 ? 0 : SSMQ_E_UNSUPPORTED);
+            }
+            if (!rc) rc = hip_fail(hipEventRecord(mc.joined[b], bs), "hipEventRecord");
+            if (!rc) rc = hip_fail(hipStreamWaitEvent(s, mc.joined[b], 0), "hipStreamWaitEvent");
+            ++b;
+        }
+        if (capture) {
+            hipGraph_t g = nullptr;
+            const hipError_t ce = hipStreamEndCapture(s, &g);
+            if (rc) {
+                if (g) hipGraphDestroy(g);
+                return rc;
+            }
+            SSMQ_HIP(ce);
+            mc.graph = g;
+            SSMQ_HIP(hipGraphInstantiate(&mc.exec, mc.graph, nullptr, nullptr, 0));
+            mc.key = key;
+            SSMQ_HIP(hipGraphLaunch(mc.exec, s));
+        } else if (rc) {
+            return rc;
+        }
+    }
+    return run_rest();
 }
 
 // Filters whose models take the noise as an argument (ssinf.py:271-272, 282-283, 294-295): the moments are augmented with

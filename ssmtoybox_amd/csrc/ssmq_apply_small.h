@@ -89,8 +89,19 @@ struct CoreParams {
 //   SSMQ_OPT_UT   the unit points are [0 | c I | -c I] (unscented / fully-symmetric degree 3 / spherical-radial with a
 //                 centre point): x_n = m +- c L[:, k] needs one FMA per coordinate instead of a row of L times xi_n.
 // Either changes only the order of floating-point operations (differences of a few ulp of the intermediate sums).
+//   SSMQ_OPT_SYM  (round 6; with SSMQ_OPT_UT, BQ form) the weights are invariant under each reflection x_k -> -x_k of the unscented
+//                 point set (swap of points 1 + k and 1 + D + k): what a kernel with a diagonal length-scale matrix gives on
+//                 these points (RBF: K, q, R, Q all commute with the reflections), up to the round-off of the weight
+//                 computation - the host accepts it only if symmetrising changes no weight by more than 2e-13 of the largest.
+//                 Then with S_k = f_{1+k} + f_{1+D+k}, A_k = f_{1+k} - f_{1+D+k}, G = [f_0 | S_1 .. S_D]:
+//                   mean = G wm_s;  fx Wcc' = [gam_d A_d]  (row d of Wcc is gam_d (e_{1+d} - e_{1+D+d})');
+//                   fx Wc fx' = G Mt G' + sum_k beta_k A_k A_k'  (Wc block-diagonalises: a dense (D+1) x (D+1) block on the
+//                   symmetric combinations, a DIAGONAL one on the antisymmetric), Mt = U diag(d) U' as SSMQ_OPT_LDL does for Wc.
+//                 D = E = 6, N = 13: 822 multiply-adds for the three reductions instead of 1 590 (the kernel: 2 559 -> ~1 800
+//                 vector instructions per wave, and it is bound by exactly those at two waves per SIMD: DESIGN.md 3.1).
 #define SSMQ_OPT_LDL 1
 #define SSMQ_OPT_UT 2
+#define SSMQ_OPT_SYM 4
 
 // m: mean; L: in = packed lower triangle of cov, out = its Cholesky factor.  Returns false if cov is not PD (results
 // are then garbage; the caller writes NaN).  Sink interface: mean(e, v), cov(e, e2, v) for e2 <= e, ccov(e, d, v).
@@ -116,6 +127,127 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
 
     constexpr bool kUT = (OPT & SSMQ_OPT_UT) != 0 && N == 2 * D + 1;
     const double utc = kUT ? c[cl.utc] : 0.0;
+    constexpr bool kSYM = (OPT & SSMQ_OPT_SYM) != 0 && kUT && FORM == SSMQ_FORM_BQ && !TP;
+    double mf[E];
+    if constexpr (kSYM) {
+        // ---- reflection-symmetric weights (SSMQ_OPT_SYM): ONE pass over the centre point and the D point pairs -----------------
+        // Step 0 is the centre point, step j = 1 + k the pair (1 + k, 1 + D + k): G_j = f+ + f-, A_k = f+ - f-.  Everything a step
+        // can finish is finished in that step: the mean and covariance sums advance (the symmetric block as Mt = Ut diag(d) Ut'
+        // with Ut unit UPPER triangular, so that g_j = G_j + sum_{i<j} Ut[i][j] G_i needs only the steps done so far), and column
+        // k of the cross-covariance - which only involves the pairs 0 .. k (L is lower triangular) - is complete and LEAVES after
+        // pair k.  The launch is bound by its 63 MB of stores (5.8 TB/s = 10.9 us) counted from the moment the first store can
+        // issue (tools/mt6_timeline.py): with the cross-covariance planes - 46 % of the output - leaving during the integrand
+        // evaluations instead of after them, the write pipe fills ~2 us earlier.  Constants per step: one record
+        // [wm_j, d_j, gam_k, beta_k, Ut[0..j-1][j]] (const_layout: sym, stride sym_rs).
+        constexpr int M = D + 1;
+        constexpr int RS = cl.sym_rs;
+        double G[E][M], cv[E * (E + 1) / 2], acc[E][D];
+#pragma unroll
+        for (int i = 0; i < E * (E + 1) / 2; ++i) cv[i] = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            mf[e] = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc[e][j] = 0.0;
+        }
+        SBuf<RS> rc_;
+        sload(rc_, SSMQ_LAUNDER_T(c) + cl.sym);
+        SSMQ_SPIN_T(rc_);
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            SBuf<RS> rn_;
+            if (j + 1 < M) sload(rn_, SSMQ_LAUNDER_T(c) + cl.sym + (j + 1) * RS);
+            const int k = j == 0 ? 0 : j - 1;
+            double A[E];
+            {
+                double x[D], xs[DIN], o[E];
+#pragma unroll
+                for (int d = 0; d < D; ++d) x[d] = (j != 0 && d >= k) ? m[d] + L[SSMQ_PK(d >= k ? d : k, k)] * utc : m[d];
+                select_inputs<D, DIN, SEL>(x, xs);
+                fn.template eval<E>(xs, o);
+                if (j == 0) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) G[e][0] = o[e];
+                } else {
+                    double o2[E];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) x[d] = (d >= k) ? m[d] - L[SSMQ_PK(d >= k ? d : k, k)] * utc : m[d];
+                    select_inputs<D, DIN, SEL>(x, xs);
+                    fn.template eval<E>(xs, o2);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        G[e][j] = o[e] + o2[e];
+                        A[e] = o[e] - o2[e];
+                    }
+                }
+            }
+            // mean
+#pragma unroll
+            for (int e = 0; e < E; ++e) mf[e] += G[e][j] * rc_.v[0];
+            // cross-covariance: column k is complete after pair k
+            if (NEED_CCOV && j != 0) {
+                const double gs = rc_.v[2] * cp.ccov_scale;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double g = A[e] * gs;
+#pragma unroll
+                    for (int jj = 0; jj < D; ++jj)
+                        if (jj >= k) acc[e][jj] += g * L[SSMQ_PK(jj >= k ? jj : k, k)];
+                    out.ccov(e, k, acc[e][k]);
+                }
+            }
+            // covariance: symmetric block (column j of Ut), antisymmetric block (beta_k A_k A_k')
+            {
+                double g[E], dg[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    double sacc = G[e][j];
+#pragma unroll
+                    for (int i = 0; i < M; ++i)
+                        if (i < j) sacc += G[e][i] * rc_.v[4 + i];
+                    g[e] = sacc;
+                    dg[e] = sacc * rc_.v[1];
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int e2 = 0; e2 <= e; ++e2) cv[SSMQ_PK(e, e2)] += dg[e] * g[e2];
+                if (j != 0) {
+                    double ba[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) ba[e] = A[e] * rc_.v[3];
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+#pragma unroll
+                        for (int e2 = 0; e2 <= e; ++e2) cv[SSMQ_PK(e, e2)] += ba[e] * A[e2];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < E * (E + 1) / 2; ++i) SSMQ_PIN_T(cv[i]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) SSMQ_PIN_T(mf[e]);
+            if (j + 1 < M) {
+                SSMQ_SPIN_T(rn_);
+                rc_ = rn_;
+            }
+            SSMQ_FENCE_T();
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) out.mean(e, mf[e]);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+#pragma unroll
+            for (int e2 = 0; e2 <= e; ++e2) {
+                const bool use = (e == e2) || (cp.emv_mode == SSMQ_EMV_BROADCAST);
+                const double em = use ? c[cl.emv + e * E + e2] : 0.0;
+                double v = cv[SSMQ_PK(e, e2)] - mf[e] * mf[e2] + em;
+                v = v * cp.cov_scale + cp.cadd[e * E + e2];
+                out.cov(e, e2, v);
+            }
+            SSMQ_FENCE_T();
+        }
+        return ok;
+    }
     double fx[E][N];
     SBuf<D> xic;
     if (!kUT) {
@@ -154,7 +286,6 @@ __device__ __forceinline__ bool moment_transform_core(const double (&m)[D], doub
         SSMQ_FENCE_T();
     }
 
-    double mf[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         double s = 0.0;
@@ -450,9 +581,29 @@ struct GlobalSink {
 // __launch_bounds__(64, 2): at least two waves per SIMD, i.e. at most 256 registers per lane.  The D = E = 6, N = 13
 // kernel needs ~270 without the bound (one wave per SIMD, no latency hiding at all); with it hipcc spills 8 registers
 // and B = 1e5 trajectories (1563 waves) are all resident at once.
+// Timing-only diagnostic builds of this header (tools/build_file_variant.sh; never defined in the product build):
+//   SSMQ_SMALL_LPW=n   n active lanes per wave (ceil(B / n) waves): the partial-wave launch the round-5 review asked to see measured
+//   SSMQ_DIAG_STAMP    every wave leaves [start, inputs arrived, last store issued, stores acknowledged] (100 MHz counter) and its
+//                      hardware id in g_small_stamps; read back with ssmq_diag_stamps() (tools/mt6_timeline.py)
+#ifdef SSMQ_DIAG_STAMP
+__device__ uint64_t g_small_stamps[8 * 32768];
+extern "C" int ssmq_diag_stamps(uint64_t *dst, int n_waves) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_small_stamps), sizeof(uint64_t) * 8 * (size_t)n_waves);
+}
+#endif
+#ifdef SSMQ_SMALL_LPW
+constexpr int kSmallLpw = SSMQ_SMALL_LPW;
+#else
+constexpr int kSmallLpw = kSmallBlock;
+#endif
+
 template <int D, int E, int N, int F, int FORM, int TP, int SEL, int OPT, bool NTS = false>
 __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs a) {
-    const uint32_t b = blockIdx.x * kSmallBlock + threadIdx.x;  // 32-bit lane offset: plane base stays scalar
+#ifdef SSMQ_DIAG_STAMP
+    const uint64_t t_start = wall_clock64();
+#endif
+    const uint32_t b = blockIdx.x * kSmallLpw + threadIdx.x;  // 32-bit lane offset: plane base stays scalar
+    if (kSmallLpw != kSmallBlock && (int)threadIdx.x >= kSmallLpw) return;
     if ((int64_t)b >= a.B) return;
     const int64_t ld = a.ld;
     double m[D], L[D * (D + 1) / 2];
@@ -472,11 +623,29 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs 
         for (int j = 0; j <= i; ++j) L[SSMQ_PK(i, j)] = a.cov[(i * D + j) * ld + b];
 #endif
     const double t = a.time[a.time_stride ? b : 0];
+#ifdef SSMQ_DIAG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint64_t t_loaded = wall_clock64();
+#endif
 
     CoreParams cp{(cdouble_p)a.consts, (cdouble_p)a.cov_add, a.emv_mode, a.tp_nu, a.cov_scale, a.ccov_scale};
     GlobalSink<D, E, NTS> sink{a.mean_f, a.cov_f, a.cov_fx, ld, b};
     const bool ok = moment_transform_core<D, E, N, F, FORM, TP, SEL, true, OPT>(m, L, t, a.fp, cp, sink);
     a.status[b] = ok ? 0 : 1;
+#ifdef SSMQ_DIAG_STAMP
+    {
+        asm volatile("" ::: "memory");
+        const uint64_t t_issued = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t t_done = wall_clock64();
+        if (threadIdx.x == 0 && blockIdx.x < 32768) {
+            uint64_t *o = g_small_stamps + 8 * (size_t)blockIdx.x;
+            o[0] = t_start; o[1] = t_loaded; o[2] = t_issued; o[3] = t_done;
+            o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID: wave / SIMD / CU / SH / SE
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+        }
+    }
+#endif
     if (!ok) {
         // the reference raises LinAlgError here (bq/bqmtran.py:98); a batch marks the item and poisons its outputs
         const double nan = __builtin_nan("");
@@ -493,7 +662,7 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_apply_small(const ApplyArgs 
 
 template <int D, int E, int N, int F, int FORM, int TP, int SEL, int OPT>
 inline hipError_t launch_apply_small(const ApplyArgs &a, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.B + kSmallBlock - 1) / kSmallBlock);
+    const unsigned grid = (unsigned)((a.B + kSmallLpw - 1) / kSmallLpw);
     if constexpr (OPT != 0) {   // the bandwidth-bound shapes: streaming stores for stand-alone calls (a.stream_out)
         if (a.stream_out) {
             hipLaunchKernelGGL((k_apply_small<D, E, N, F, FORM, TP, SEL, OPT, true>), dim3(grid), dim3(kSmallBlock), 0, s, a);

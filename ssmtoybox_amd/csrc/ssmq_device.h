@@ -36,7 +36,7 @@ struct FPar {
 // Offsets (in doubles) into a transform's constant block in HBM; every thread reads it with wave-uniform addresses,
 // so the loads are scalar (s_load) and the block stays in the scalar cache / L2.
 struct ConstLayout {
-    int32_t xi, wm, Wc, Wcc, emv, iK, zero, ldlU, ldlD, utc, rec, rs, total;
+    int32_t xi, wm, Wc, Wcc, emv, iK, zero, ldlU, ldlD, utc, sym, sym_rs, rec, rs, total;
 };
 __host__ __device__ constexpr inline ConstLayout const_layout(int D, int E, int N, int form) {
     ConstLayout c{};
@@ -55,7 +55,11 @@ __host__ __device__ constexpr inline ConstLayout const_layout(int D, int E, int 
     // w + W, ...): everything point n contributes, contiguous, so that ONE base pointer per point serves every scalar load -
     //   centred form:  xi_n [D] | wm_n | wc_n            uncentred BQ form:  xi_n [D] | wm_n | Wcc[:, n] [D] | Wc[:, n] [N] | iK[:, n] [N]
     // N + 1 records, the last one all zeros: the "point" of a wave that has run out of points (weight 0, evaluated at the mean).
-    c.rec = c.utc + 2;
+    // reflection-symmetric weights on unscented-type points (SSMQ_OPT_SYM in ssmq_apply_small.h), M = D + 1 step records of
+    // stride sym_rs: [wm_j, d_j, gam_k, beta_k, Ut[0][j] .. Ut[j-1][j], 0 ..] (k = j - 1; step 0 = the centre point)
+    c.sym = c.utc + 2;
+    c.sym_rs = (D + 1) + 4;
+    c.rec = c.sym + (D + 1) * c.sym_rs;
     c.rs = form == SSMQ_FORM_SIGMA ? D + 2 : 2 * D + 1 + 2 * N;
     c.total = c.rec + (N + 1) * c.rs;
     return c;

@@ -134,6 +134,7 @@ int try_launch_chunked(const FusedArgs &a0, int fd, int fo, int D, int Y, int ND
                        hipStream_t s, bool dry_run, const char **name) {
     const char *ev = ssmq::sw("SSMQ_FUSED_CHUNKED");
     const int force = ev ? atoi(ev) : -1;
+    if (!dry_run && ctx().no_strips) return 0;      // a job of a multi-filter launch (one hand-over buffer per context)
     if (force == 0 || a0.sscale != nullptr || a0.student_dof > 0.0 || (!dry_run && a0.T < 2)) return 0;
     const ChunkedEntry *e = nullptr;
     for (const ChunkedEntry &c : kChunked)

@@ -59,6 +59,10 @@ struct Ctx {
     void *pinned_flags = nullptr;            // 64 bytes of pinned host memory the device rounds report through (ssmq_marginal.hip)
     void *strip_buf = nullptr;               // flags + hand-over buffer of the strip schedule (ssmq_filter_chunked.hip), grow-only
     size_t strip_bytes = 0;
+    void *multi = nullptr;                   // ssmq_api.hip: MultiCache (side streams, events, constants and captured graph of
+                                             // ssmq_filter_forward_multi_dev)
+    bool no_strips = false;                  // set while a multi-filter launch is being built: the strip schedule owns ONE buffer
+                                             // per context and its jobs run concurrently
 };
 Ctx &ctx();
 struct HandleGuard {
@@ -69,6 +73,14 @@ struct HandleGuard {
     HandleGuard &operator=(const HandleGuard &) = delete;
 };
 #define SSMQ_HANDLE_LOCK(...) ssmq::HandleGuard ssmq_handle_guard_(__VA_ARGS__)
+// ... for any number of handles (ssmq_filter_forward_multi_dev): unique handles, locked in address order
+struct MultiHandleGuard {
+    std::vector<const ssmq_transform *> hs;
+    explicit MultiHandleGuard(std::vector<const ssmq_transform *> handles);
+    ~MultiHandleGuard();
+    MultiHandleGuard(const MultiHandleGuard &) = delete;
+    MultiHandleGuard &operator=(const MultiHandleGuard &) = delete;
+};
 int hip_fail(hipError_t e, const char *what);
 hipStream_t stream();
 int ensure_device();

@@ -11,9 +11,10 @@
     SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_BQ, 0, SEL, 0),     \
     SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_BQ, 1, SEL, 0),     \
     SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_SIGMA, 0, SEL, 0)
-// larger shapes additionally get the fast paths (SSMQ_OPT_LDL | SSMQ_OPT_UT for BQ, SSMQ_OPT_UT for the rest)
+// larger shapes additionally get the fast paths (SSMQ_OPT_LDL | SSMQ_OPT_UT [| SSMQ_OPT_SYM] for BQ, SSMQ_OPT_UT for the rest)
 #define SSMQ_SMALL_FAST(F, D, E, N, SEL)                     \
     SSMQ_SMALL(F, D, E, N, SEL),                             \
+    SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_BQ, 0, SEL, 7),     \
     SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_BQ, 0, SEL, 3),     \
     SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_BQ, 0, SEL, 1),     \
     SSMQ_SMALL_ONE(F, D, E, N, SSMQ_FORM_BQ, 1, SEL, 2),     \

@@ -222,6 +222,78 @@ class GaussianInference:
         return self.fi_mean, self.fi_cov
 
 
+def run_filters(algs, data, x0_mean=None, x0_cov=None, raise_on_failure=True):
+    """Several filters over the SAME measurements as one device launch - the loop `for alg in algs: alg.forward_pass(y)` of the
+    reference's studies (research/bsq/bsq_ungm.py:132-137, research/tpq/tpq_base.py:175-192), for data of shape (dim_y, T, B).
+    Returns [(fi_mean (D, T, B), fi_cov (D, D, T, B)), ...] in the order of `algs` and leaves `fi_mean / fi_cov / status` on
+    every filter, exactly what `alg.forward_pass_batch(data)` would have produced (the same kernels run, concurrently:
+    `ssmq_filter_forward_multi_dev`).  The filters must be additive-noise Gaussian / Studentian filters; they may differ in
+    models and state dimension, the measurements are uploaded once."""
+    lib = _lib.load()
+    data = np.asarray(data, dtype=np.float64)
+    Y, T, B = data.shape
+    ld = (B + 63) // 64 * 64
+    for a in algs:
+        if not isinstance(a, GaussianInference) or not a._additive:
+            raise NotImplementedError('run_filters: additive-noise Gaussian / Studentian filters only')
+        if a.mod_obs.dim_out != Y:
+            raise ValueError('run_filters: every filter must take the same measurements')
+    d_y = _lib.scratch(8 * T * Y * ld)
+    _lib.upload_study(data, Y, ld, d_y)
+    jobs = (_lib.FilterJob * len(algs))()
+    keep, bufs = [], []
+    for i, a in enumerate(algs):
+        a._data = data
+        D = a.mod_dyn.dim_state
+        m0 = np.broadcast_to(a.x0_mean, (B, D)) if x0_mean is None else np.asarray(x0_mean, dtype=np.float64)
+        P0 = np.broadcast_to(a._initial_cov(), (B, D, D)) if x0_cov is None else np.asarray(x0_cov, dtype=np.float64)
+        mbuf = np.zeros((D, ld))
+        mbuf[:, :B] = m0.T
+        Pbuf = np.zeros((D * D, ld))
+        Pbuf[:, :B] = P0.reshape(B, D * D).T
+        if ld > B:
+            Pbuf[:, B:] = np.eye(D).reshape(-1, 1)
+        d_m0, d_P0 = _lib.scratch(mbuf.nbytes), _lib.scratch(Pbuf.nbytes)
+        d_m0.upload(mbuf)
+        d_P0.upload(Pbuf)
+        d_fm, d_fP, d_st = _lib.scratch(8 * T * D * ld), _lib.scratch(8 * T * D * D * ld), _lib.scratch(4 * ld)
+        bufs.append((d_m0, d_P0, d_fm, d_fP, d_st))
+        f_dyn, e_dyn = resolve_integrand(a.mod_dyn.dyn_eval)
+        f_obs, e_obs = resolve_integrand(a.mod_obs.meas_eval)
+        student = isinstance(a, StudentianInference)
+        gqg, pg = _lib.as_c(a.G.dot(a.q_smat if student else a.q_cov).dot(a.G.T))
+        rr, pr = _lib.as_c(a.r_smat if student else a.r_cov)
+        keep += [f_dyn, f_obs, gqg, rr]
+        j = jobs[i]
+        j.h_dyn, j.f_dyn = a.tf_dyn._handle_for(e_dyn), ctypes.pointer(f_dyn)
+        j.h_obs, j.f_obs = a.tf_obs._handle_for(e_obs), ctypes.pointer(f_obs)
+        j.B, j.ld, j.T = B, ld, T
+        j.d_y, j.d_m0, j.d_P0 = d_y.ptr, d_m0.ptr, d_P0.ptr
+        j.GQG, j.R = pg, pr
+        j.d_fm, j.d_fP, j.d_status = d_fm.ptr, d_fP.ptr, d_st.ptr
+        if student:
+            sc, ps = _lib.as_c(a.scale_sequence(T))
+            keep.append(sc)
+            j.scale, j.dof = ps, float(a.dof)
+    _lib.check(lib.ssmq_filter_forward_multi_dev(len(algs), jobs), 'ssmq_filter_forward_multi_dev')
+    out, failed = [], None
+    for a, (d_m0, d_P0, d_fm, d_fP, d_st) in zip(algs, bufs):
+        D = a.mod_dyn.dim_state
+        a.fi_mean = _lib.download_study(d_fm, (D,), T, B, ld)
+        a.fi_cov = _lib.download_study(d_fP, (D, D), T, B, ld)
+        a.status = d_st.download((ld,), dtype=np.int32)[:B]
+        for buf in (d_m0, d_P0, d_fm, d_fP, d_st):
+            buf.free()
+        if a.status.any() and failed is None:
+            b = int(np.flatnonzero(a.status)[0])
+            failed = '{}: Matrix is not positive definite (trajectory {}, step {})'.format(type(a).__name__, b, int(a.status[b]) - 1)
+        out.append((a.fi_mean, a.fi_cov))
+    d_y.free()
+    if raise_on_failure and failed:
+        raise np.linalg.LinAlgError(failed)
+    return out
+
+
 class CubatureKalman(GaussianInference):
     """ssinf.py:360-371."""
 

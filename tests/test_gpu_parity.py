@@ -1852,11 +1852,13 @@ def test_fast_paths_match_dense(amd, monkeypatch):
     f6 = sm.ReentryVehicle2DBiasTransition(dt=0.1).dyn_eval
     f5 = sm.ReentryVehicle2DTransition(dt=0.1).dyn_eval
     h5 = sm.Radar2DMeasurement(sm.GaussRV(2), 5).meas_eval
-    cases = [(lambda: amd.GaussianProcessTransform(6, 6, gp_par(6, 3.0)), f6, 6, 'OPT=3'),
+    # (OPT=7: the weights are also reflection-symmetric to 2e-13 - length scale 3; at length scale 25 the ill-conditioned kernel
+    # matrix leaves an asymmetry of ~5e-7 in Wc and the host keeps OPT=3)
+    cases = [(lambda: amd.GaussianProcessTransform(6, 6, gp_par(6, 3.0)), f6, 6, 'OPT=7'),
              (lambda: amd.GaussianProcessTransform(5, 5, gp_par(5, 25.0)), f5, 5, 'OPT=3'),
              (lambda: amd.StudentTProcessTransform(5, 5, gp_par(5, 3.0)), f5, 5, 'OPT=2'),
              (lambda: amd.UnscentedTransform(5), f5, 5, 'OPT=2'),
-             (lambda: amd.GaussianProcessTransform(5, 2, gp_par(5, 3.0)), h5, 5, 'OPT=3'),
+             (lambda: amd.GaussianProcessTransform(5, 2, gp_par(5, 3.0)), h5, 5, 'OPT=7'),
              (lambda: amd.GaussianProcessTransform(5, 5, gp_par(5, 3.0), 'rbf', 'sr'), f5, 5, 'OPT=0')]
     for make, f, d, tag in cases:
         monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)
@@ -1870,6 +1872,14 @@ def test_fast_paths_match_dense(amd, monkeypatch):
         monkeypatch.delenv('SSMQ_NO_FASTPATH')
         for i in range(0, B, 97):
             assert_moments_close([a[i] for a in fast], [a[i] for a in dense], covs[i, :d, :d], what=(tag, i))
+        if tag == 'OPT=7':       # ... and against the LDL' kernel the symmetric one replaces (SSMQ_NO_SYM: tools/alt_paths.sh)
+            monkeypatch.setenv('SSMQ_NO_SYM', '1')
+            tf3 = make()
+            assert 'OPT=3' in tf3.kernel_name(f)
+            ldl = tf3.apply_batch(f, means[:, :d], covs[:, :d, :d], 0.0)
+            monkeypatch.delenv('SSMQ_NO_SYM')
+            for i in range(0, B, 97):
+                assert_moments_close([a[i] for a in fast], [a[i] for a in ldl], covs[i, :d, :d], what=(tag, 'vs OPT=3', i))
 
 
 def test_ungm_gpq_full_batch(amd):
@@ -2802,7 +2812,8 @@ def test_launch_loop_graph_follows_weight_updates(amd, golden, monkeypatch):
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     alg = make()
     f_dyn = dyn.dyn_eval
-    assert 'OPT=3' in alg.tf_dyn.kernel_name(f_dyn) and 'hipGraph' in alg.kernel_name()
+    kn = alg.tf_dyn.kernel_name(f_dyn)
+    assert ('OPT=3' in kn or 'OPT=7' in kn) and 'hipGraph' in alg.kernel_name()
     fm1, fP1 = alg.forward_pass_batch(y, raise_on_failure=False)
     fm1b, _ = alg.forward_pass_batch(y, raise_on_failure=False)          # replay of the captured loop
     assert np.array_equal(fm1, fm1b, equal_nan=True)
@@ -2811,7 +2822,7 @@ def test_launch_loop_graph_follows_weight_updates(amd, golden, monkeypatch):
     Wc2 = alg.tf_dyn.Wc.copy()
     Wc2[1, 0] += 1e-10 * np.max(np.abs(Wc2))
     alg.tf_dyn.Wc = Wc2
-    assert 'OPT=3' not in alg.tf_dyn.kernel_name(f_dyn)       # the dense kernel (no BQ instantiation with only the point-set fast path)
+    assert 'OPT=3' not in alg.tf_dyn.kernel_name(f_dyn) and 'OPT=7' not in alg.tf_dyn.kernel_name(f_dyn)       # the dense kernel (no BQ instantiation with only the point-set fast path)
     fm2, fP2 = alg.forward_pass_batch(y, raise_on_failure=False)
     fresh = make()
     fresh.tf_dyn.Wc = Wc2
@@ -3469,6 +3480,77 @@ def test_chunked_time_loop_is_bitwise_the_whole_pass(amd, monkeypatch):
             assert 'k_filter_chunked<' in wl.alg.kernel_name(B)       # 1 094 blocks on 1 024 SIMDs: the default takes the strips
         wl.free()
     monkeypatch.delenv('SSMQ_FUSED_CHUNKED', raising=False)
+
+
+def _ungm_study_filters(ssinf, sm, with_loop=False):
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    par = np.array([[1.0, 3.0]])
+    mi = np.array([[0, 1, 2]])
+    algs = [ssinf.UnscentedKalman(dyn, obs), ssinf.CubatureKalman(dyn, obs), ssinf.GaussHermiteKalman(dyn, obs, deg=5),
+            ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut'), ssinf.StudentProcessKalman(dyn, obs, par, par, 'rbf', 'ut'),
+            ssinf.BayesSardKalman(dyn, obs, par, par, mi, mi, 'ut')]
+    if with_loop:
+        algs.append(ssinf.GaussHermiteKalman(dyn, obs, deg=7))         # 7 points: no fused kernel, the launch loop after the graph
+    return algs
+
+
+def test_run_filters_is_the_serial_calls_bit_for_bit(amd, monkeypatch):
+    """ssinf.run_filters / ssmq_filter_forward_multi_dev: the six filters of the reference's UNGM studies (research/bsq/bsq_ungm.py:
+    132-137, research/tpq/tpq_base.py:175-192) over the same measurements as ONE launch graph - one branch per filter, each the
+    filter's own fused kernel - must give exactly what the filters give one after the other; also with a filter that has no
+    fused kernel in the list, with a Studentian filter, with filters of another model in the same call, on a replayed graph,
+    and without the graph (SSMQ_MULTI_NO_GRAPH)."""
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    from bench import simulate_ungm
+    B, T = 3000, 40
+    _, y = simulate_ungm(B, T, 77)
+    y = np.ascontiguousarray(y[None])
+    serial = [a.forward_pass_batch(y, raise_on_failure=False) + (a.status.copy(),) for a in _ungm_study_filters(ssinf, sm, True)]
+    for mode in ('graph', 'replay', 'nograph'):
+        if mode == 'nograph':
+            monkeypatch.setenv('SSMQ_MULTI_NO_GRAPH', '1')
+        algs = _ungm_study_filters(ssinf, sm, True) if mode != 'replay' else algs
+        assert 'k_filter_fused' in algs[0].kernel_name() and 'hipGraph' in algs[-1].kernel_name()
+        got = ssinf.run_filters(algs, y, raise_on_failure=False)
+        for i, (a, g, s) in enumerate(zip(algs, got, serial)):
+            assert np.array_equal(g[0], s[0], equal_nan=True) and np.array_equal(g[1], s[1], equal_nan=True), (mode, i, type(a).__name__)
+            assert np.array_equal(a.status, s[2]) and a.fi_mean is g[0]
+    monkeypatch.delenv('SSMQ_MULTI_NO_GRAPH')
+    # a Studentian filter and filters of a 5-D model in the same launch as scalar ones is not possible (other measurements), but
+    # filters of different kinds over the reentry measurements are: UKF, CKF, Bayes-Sard on the 5-D model
+    from bench import simulate_reentry
+    Br, Tr = 2500, 12
+    x5, y5, m5, P5, Q5, G5, R5 = simulate_reentry(Br, Tr, 5, False)
+    dyn5 = sm.ReentryVehicle2DTransition(sm.GaussRV(5, m5, P5), sm.GaussRV(3, cov=Q5))
+    obs5 = sm.Radar2DMeasurement(sm.GaussRV(2, cov=R5), 5)
+    mi = np.hstack((np.zeros((5, 1)), np.eye(5), 2 * np.eye(5))).astype(int)
+
+    def make5():
+        b = ssinf.BayesSardKalman(dyn5, obs5, np.array([[1.0, 1, 1, 1, 1, 1]]), np.array([[1.0, 0.9, 0.9, 1e4, 1e4, 1e4]]), mi, mi, 'ut')
+        b.tf_dyn.model.model_var = 2e-6 * np.eye(5)
+        b.tf_obs.model.model_var = 0 * np.eye(2)
+        return [ssinf.UnscentedKalman(dyn5, obs5), ssinf.CubatureKalman(dyn5, obs5), b]
+    serial = [a.forward_pass_batch(y5, raise_on_failure=False) for a in make5()]
+    got = ssinf.run_filters(make5(), y5, raise_on_failure=False)
+    for g, s in zip(got, serial):
+        assert np.array_equal(g[0], s[0], equal_nan=True) and np.array_equal(g[1], s[1], equal_nan=True)
+    # Studentian recursion as a job beside a Gaussian one (UNGM; ssmq_student_filter_forward_dev's arguments through `scale` / `dof`)
+    dynS = sm.UNGMTransition(sm.StudentRV(1), sm.StudentRV(1, scale=np.array([[10.0]])))
+    obsS = sm.UNGMMeasurement(sm.StudentRV(1), 1)
+    dynG = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obsG = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    ys = y
+    mk = lambda: [ssinf.FullySymmetricStudent(dynS, obsS), ssinf.UnscentedKalman(dynG, obsG)]
+    serial = [a.forward_pass_batch(ys, raise_on_failure=False) for a in mk()]
+    got = ssinf.run_filters(mk(), ys, raise_on_failure=False)
+    for g, s in zip(got, serial):
+        assert np.array_equal(g[0], s[0], equal_nan=True) and np.array_equal(g[1], s[1], equal_nan=True)
+    # argument errors: two jobs with one output buffer
+    from ssmtoybox_amd import _lib
+    lib = _lib.load()
+    jobs = (_lib.FilterJob * 2)()
+    assert lib.ssmq_filter_forward_multi_dev(2, jobs) == -1 and lib.ssmq_filter_forward_multi_dev(0, None) == 0
 
 
 def test_chunked_many_small_strips_across_xcds(amd, monkeypatch):

@@ -10,7 +10,7 @@
 # Exit status: non-zero when any run failed.
 # usage: tools/alt_paths.sh [VAR=value ...]   (default: every toggle)
 list="$*"
-[ -z "$list" ] && list="SSMQ_NO_FUSED=1 SSMQ_NO_FASTPATH=1 SSMQ_NO_FUSED_COV=1 SSMQ_NO_MFMA=1 SSMQ_WEIGHTS_NO_LDS=1 SSMQ_WIDE_ONE_WAVE=1 SSMQ_NO_WAVE=1 SSMQ_NO_TILE=1 SSMQ_TILE_NO_MROW=1 SSMQ_NO_BQ_FUSED=1 SSMQ_NO_THETA_FUSED=1 SSMQ_NO_BQ_STREAM=1 SSMQ_WEIGHTS_ONE_WG=1 SSMQ_LINEAR_GENERIC=1 SSMQ_BQ_STREAM_NO_SPLIT=1 SSMQ_NO_THETA_ITEM=1 SSMQ_MARGINAL_ROUNDS=1 SSMQ_MARGINAL_HOST_ROUNDS=1 SSMQ_FUSED_WSPLIT=0 SSMQ_FUSED_CHUNKED=0 SSMQ_FUSED_CHUNKED=64"
+[ -z "$list" ] && list="SSMQ_NO_FUSED=1 SSMQ_NO_FASTPATH=1 SSMQ_NO_FUSED_COV=1 SSMQ_NO_MFMA=1 SSMQ_WEIGHTS_NO_LDS=1 SSMQ_WIDE_ONE_WAVE=1 SSMQ_NO_WAVE=1 SSMQ_NO_TILE=1 SSMQ_TILE_NO_MROW=1 SSMQ_NO_BQ_FUSED=1 SSMQ_NO_THETA_FUSED=1 SSMQ_NO_BQ_STREAM=1 SSMQ_WEIGHTS_ONE_WG=1 SSMQ_LINEAR_GENERIC=1 SSMQ_BQ_STREAM_NO_SPLIT=1 SSMQ_NO_THETA_ITEM=1 SSMQ_MARGINAL_ROUNDS=1 SSMQ_MARGINAL_HOST_ROUNDS=1 SSMQ_FUSED_WSPLIT=0 SSMQ_FUSED_CHUNKED=0 SSMQ_FUSED_CHUNKED=64 SSMQ_NO_SYM=1"
 fail=0
 for kv in $list; do
   v=${kv%%=*}
