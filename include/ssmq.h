@@ -579,6 +579,30 @@ typedef struct ssmq_filter_job {
 } ssmq_filter_job;
 int ssmq_filter_forward_multi_dev(int n_jobs, const ssmq_filter_job *jobs);
 
+/*
+ * The drop-in forward pass with HOST arrays in the reference's layout (ssinf.py:66-118: forward_pass takes the measurements
+ * as an ndarray and returns ndarrays), pipelined (round 6; ABI 102): the pass runs as K launches over consecutive time blocks
+ * (k_filter_range: the whole-pass kernel's bits), the measurements of block k + 1 are uploaded and the filtered moments of
+ * block k - 1 downloaded while block k runs.
+ *   y (Y, T, B) host; m0 (D) and P0 (D, D) host, or (B, D) and (B, D, D) with SSMQ_PIPED_X0_PER_TRAJECTORY; GQG (D, D), R (Y, Y)
+ *   host or NULL; outputs fm (D, T, B), fP (D, D, T, B), status [B] host.  With SSMQ_PIPED_OUT_PINNED fm and fP are page-locked
+ *   (ssmq_pinned_alloc): the copy engine writes them in place, no staging copy.  n_blocks = 0: the library chooses K.
+ * Synchronous.  Gaussian recursion, additive noise; SSMQ_E_UNSUPPORTED when the (models, shapes, form) combination has no
+ * time-block kernel (UNGM with 2 / 3 / 5 points, the reentry and coordinated-turn shapes with unscented points have one) -
+ * the caller then uses ssmq_upload_planes / ssmq_filter_forward_dev / ssmq_download_planes.
+ */
+#define SSMQ_PIPED_OUT_PINNED 1
+#define SSMQ_PIPED_X0_PER_TRAJECTORY 2
+int ssmq_filter_forward_piped(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs,
+                              const ssmq_integrand *f_obs, int64_t B, int T, const double *y, const double *m0,
+                              const double *P0, const double *GQG, const double *R, double *fm, double *fP,
+                              int32_t *status, int flags, int n_blocks);
+/* Page-locked host memory from a process-wide pool (blocks are reused; at most 1 GiB is kept idle).  ssmq_pinned_is_block:
+ * 1 if p is the start of a live block. */
+int ssmq_pinned_alloc(size_t bytes, void **p);
+int ssmq_pinned_free(void *p);
+int ssmq_pinned_is_block(const void *p);
+
 /* Name of the kernel(s) ssmq_filter_forward_dev would run for this pair of transforms (for profiles). */
 int ssmq_filter_kernel_name(const ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, const ssmq_transform *h_obs,
                             const ssmq_integrand *f_obs, char *buf, int len);

@@ -129,6 +129,12 @@ _PROTOTYPES = {
                                                c_double_p, c_double_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_void_p]),
     'ssmq_filter_forward_multi_dev': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(FilterJob)]),
+    'ssmq_filter_forward_piped': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p, ctypes.POINTER(Integrand),
+                                                 ctypes.c_int64, ctypes.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    'ssmq_pinned_alloc': (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    'ssmq_pinned_free': (ctypes.c_int, [ctypes.c_void_p]),
+    'ssmq_pinned_is_block': (ctypes.c_int, [ctypes.c_void_p]),
     'ssmq_filter_forward_aug_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Integrand), ctypes.c_void_p,
                                                    ctypes.POINTER(Integrand), ctypes.c_int, ctypes.c_int64,
                                                    ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -413,6 +419,48 @@ class ScratchBuffer(DeviceBuffer):
 
 def scratch(nbytes):
     return ScratchBuffer(nbytes)
+
+
+class _PinnedOwner:
+    """Owns one block of ssmq_pinned_alloc; the block goes back to the library's pool when the last ndarray that views it is
+    collected."""
+
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        check(load().ssmq_pinned_alloc(ctypes.c_size_t(max(int(nbytes), 8)), ctypes.byref(p)), 'ssmq_pinned_alloc')
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr and _lib is not None:
+                _lib.ssmq_pinned_free(ctypes.c_void_p(self.ptr))
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+        self.ptr = None
+
+
+PINNED_RESULT_LIMIT = 256 << 20      # results larger than this (or once this much is out) are ordinary pageable arrays
+_pinned_out = [0]
+
+
+def pinned_empty(shape):
+    """An ndarray in page-locked memory (what `forward_pass_batch` returns when it pipelines its transfers: the copy engine
+    writes the result in place).  An ordinary array to its user - writable, owned by nobody else; the block returns to the
+    library's pool when the array is collected.  None when the request is over the limit for pinned results."""
+    import weakref
+    n = int(np.prod(shape))
+    if 8 * n > PINNED_RESULT_LIMIT or _pinned_out[0] + 8 * n > 4 * PINNED_RESULT_LIMIT:
+        return None
+    owner = _PinnedOwner(8 * n)
+    buf = (ctypes.c_double * max(n, 1)).from_address(owner.ptr)
+    buf._owner = owner                                   # the ctypes array (the ndarray's base) keeps the block alive
+    _pinned_out[0] += 8 * n
+    weakref.finalize(buf, _pinned_release, 8 * n)
+    return np.ctypeslib.as_array(buf)[:n].reshape(shape)
+
+
+def _pinned_release(nbytes):
+    _pinned_out[0] -= nbytes
 
 
 def upload_study(arr, n_elem, ld, dst):

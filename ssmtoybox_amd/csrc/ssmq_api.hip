@@ -5,7 +5,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1628,6 +1630,7 @@ void reset_wide_attributes();
 void drop_staging_arena();
 void drop_theta_step_graphs();
 void drop_multi_cache();
+void drop_pipe_cache();
 void reset_device_caches() {
     g_fc.drop_graph();
     drop_theta_step_graphs();
@@ -1639,6 +1642,7 @@ void reset_device_caches() {
     drop_staging_arena();
     reset_wide_attributes();
     drop_multi_cache();
+    drop_pipe_cache();
     Ctx &c = ctx();
     if (c.strip_buf) hipFree(c.strip_buf);
     c.strip_buf = nullptr;
@@ -2057,6 +2061,329 @@ extern "C" int ssmq_filter_forward_multi_dev(int n_jobs, const ssmq_filter_job *
         }
     }
     return run_rest();
+}
+
+// ---- the host-array forward pass as a pipeline of time blocks (round 6) --------------------------------------------------------
+// forward_pass returns host arrays (ssinf.py:66-118): at configs[1] 8 MB of measurements go up and 16 MB of filtered moments come
+// down around a 34 us kernel.  Upload, pass and downloads back to back cost 1.15 ms per call (round 5).  Here the pass runs as K
+// launches of k_filter_range (ssmq_filter_piped.hip: steps [kb, ke) of every trajectory, state handed from launch to launch, the
+// whole-pass kernel's bits), and three queues overlap: a copy-in stream feeds the measurements of block k + 1, the context's stream
+// runs block k, a copy-out stream brings block k - 1 back.  Outputs that live in page-locked memory (ssmq_pinned_alloc: what
+// ssmtoybox_amd hands out as the returned ndarrays) are written by the copy engine in the reference's (D, T, B) layout directly -
+// strided 2-D copies, no staging and no host-side memcpy of the 16 MB; pageable outputs go through the pinned staging block and a
+// pool of copy threads.
+namespace ssmq {
+int try_launch_range(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho, const ssmq_integrand *fo, int sel_obs,
+                     int64_t B, int64_t ld, int T, int kb, int ke, const double *d_y, const double *d_m0, const double *d_P0,
+                     const double *d_gqg, const double *d_rr, double *d_fm, double *d_fP, int32_t *d_status, double *hand, hipStream_t s,
+                     const char **name, bool dry_run, const double *d_ttab_dyn, const double *d_ttab_obs);
+size_t range_hand_doubles(int D);
+}
+namespace {
+// page-locked host blocks, pooled per process: hipHostMalloc of 16 MB costs milliseconds, a pooled block nothing
+struct PinnedPool {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> live;                 // block -> its (rounded) size
+    std::unordered_map<size_t, std::vector<void *>> idle;    // size -> free blocks
+    size_t idle_bytes = 0;
+    static size_t round(size_t b) { return (std::max<size_t>(b, 8) + 65535) / 65536 * 65536; }
+};
+PinnedPool &pinned_pool() {
+    static PinnedPool *p = new PinnedPool;      // (never destroyed: blocks may outlive static destruction order)
+    return *p;
+}
+constexpr size_t kPinnedIdleCap = size_t(1) << 30;
+
+// a few persistent threads for the row copies between caller memory and the pinned blocks (std::thread per call costs 30-50 us)
+struct CopyPool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> th;
+    std::function<void(int64_t, int64_t)> fn;
+    int64_t n = 0, chunk = 0;
+    std::atomic<int64_t> next{0};
+    int pending = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+    explicit CopyPool(int workers) {
+        for (int i = 0; i < workers; ++i)
+            th.emplace_back([this] {
+                uint64_t seen = 0;
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> l(mu);
+                        cv_work.wait(l, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                    }
+                    drain();
+                    std::lock_guard<std::mutex> l(mu);
+                    if (--pending == 0) cv_done.notify_all();
+                }
+            });
+    }
+    void drain() {
+        for (;;) {
+            const int64_t lo = next.fetch_add(chunk);
+            if (lo >= n) return;
+            fn(lo, std::min(n, lo + chunk));
+        }
+    }
+    // fn(lo, hi) over [0, n) in pieces of `chunk`; the caller works too; returns when everything is done
+    void run(int64_t n_, int64_t chunk_, std::function<void(int64_t, int64_t)> f) {
+        if (n_ <= chunk_ || th.empty()) {
+            f(0, n_);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(mu);
+            fn = std::move(f);
+            n = n_;
+            chunk = chunk_;
+            next = 0;
+            pending = (int)th.size();
+            ++gen;
+        }
+        cv_work.notify_all();
+        drain();
+        std::unique_lock<std::mutex> l(mu);
+        cv_done.wait(l, [&] { return pending == 0; });
+    }
+};
+CopyPool &copy_pool() {
+    static CopyPool *p = new CopyPool((int)std::max(1u, std::min(6u, std::thread::hardware_concurrency() / 2)));
+    return *p;
+}
+std::mutex g_copy_pool_mu;       // one user of the pool at a time (calls from several threads take turns; the copies are short)
+
+// rows of B doubles: planes row r = (t - t0) * n_elem + e of a block <-> host row (e, t) of an (n_elem, n_outer, B) array
+void copy_rows_pool(bool to_planes, double *host, double *pinned, int64_t t0, int64_t t1, int n_outer, int n_elem, int64_t B, int64_t ld) {
+    const int64_t rows = (t1 - t0) * n_elem;
+    const int64_t per = std::max<int64_t>(1, (128 * 1024) / std::max<int64_t>(B, 1));        // ~1 MB of doubles per piece
+    std::lock_guard<std::mutex> g(g_copy_pool_mu);
+    copy_pool().run(rows, per, [=](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            const int64_t t = t0 + r / n_elem, e = r % n_elem;
+            double *pl = pinned + r * ld, *hs = host + (e * n_outer + t) * B;
+            if (to_planes) {
+                memcpy(pl, hs, sizeof(double) * B);
+                if (ld > B) memset(pl + B, 0, sizeof(double) * (ld - B));
+            } else {
+                memcpy(hs, pl, sizeof(double) * B);
+            }
+        }
+    });
+}
+
+struct PipeCache {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> ev_in, ev_run, ev_out;
+    hipEvent_t ev_done = nullptr;       // the previous call's last use of the device block / pinned blocks
+    void drop() {
+        if (s_in) hipStreamDestroy(s_in);
+        if (s_out) hipStreamDestroy(s_out);
+        for (auto *v : {&ev_in, &ev_run, &ev_out}) {
+            for (hipEvent_t e : *v) hipEventDestroy(e);
+            v->clear();
+        }
+        s_in = s_out = nullptr;
+    }
+};
+}  // namespace
+namespace ssmq {
+void drop_pipe_cache() {
+    Ctx &c = ctx();
+    if (c.pipe) ((PipeCache *)c.pipe)->drop();
+}
+}  // namespace ssmq
+
+extern "C" int ssmq_pinned_alloc(size_t bytes, void **p) {
+    if (!p) return SSMQ_E_ARG;
+    *p = nullptr;
+    int rc = ensure_device();
+    if (rc) return rc;
+    PinnedPool &pp = pinned_pool();
+    const size_t sz = PinnedPool::round(bytes);
+    {
+        std::lock_guard<std::mutex> l(pp.mu);
+        auto it = pp.idle.find(sz);
+        if (it != pp.idle.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            pp.idle_bytes -= sz;
+            pp.live[*p] = sz;
+            return SSMQ_OK;
+        }
+    }
+    void *q = nullptr;
+    SSMQ_HIP(hipHostMalloc(&q, sz, hipHostMallocPortable));
+    std::lock_guard<std::mutex> l(pp.mu);
+    pp.live[q] = sz;
+    *p = q;
+    return SSMQ_OK;
+}
+extern "C" int ssmq_pinned_free(void *p) {
+    if (!p) return SSMQ_OK;
+    PinnedPool &pp = pinned_pool();
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> l(pp.mu);
+        auto it = pp.live.find(p);
+        if (it == pp.live.end()) {
+            set_error("pinned_free: not a block of ssmq_pinned_alloc");
+            return SSMQ_E_ARG;
+        }
+        sz = it->second;
+        pp.live.erase(it);
+        if (pp.idle_bytes + sz <= kPinnedIdleCap) {
+            pp.idle[sz].push_back(p);
+            pp.idle_bytes += sz;
+            return SSMQ_OK;
+        }
+    }
+    hipHostFree(p);
+    return SSMQ_OK;
+}
+extern "C" int ssmq_pinned_is_block(const void *p) {
+    PinnedPool &pp = pinned_pool();
+    std::lock_guard<std::mutex> l(pp.mu);
+    return pp.live.count(const_cast<void *>(p)) ? 1 : 0;
+}
+
+extern "C" int ssmq_filter_forward_piped(ssmq_transform *h_dyn, const ssmq_integrand *f_dyn, ssmq_transform *h_obs, const ssmq_integrand *f_obs,
+                                         int64_t B, int T, const double *y, const double *m0, const double *P0, const double *GQG,
+                                         const double *R, double *fm, double *fP, int32_t *status, int flags, int n_blocks) {
+    SSMQ_HANDLE_LOCK(h_dyn, h_obs);
+    if (!h_dyn || !h_obs || !f_dyn || !f_obs || B < 0 || T < 0 || !y || !m0 || !P0 || !fm || !fP || !status || n_blocks < 0) {
+        set_error("filter_forward_piped: bad argument");
+        return SSMQ_E_ARG;
+    }
+    const int D = h_dyn->D, Y = h_obs->E;
+    if (h_dyn->E != D || h_obs->D != D) {
+        set_error("filter_forward_piped: additive-noise filter needs dyn (D -> D) and obs (D -> Y) transforms");
+        return SSMQ_E_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0 || T == 0) {
+        for (int64_t b = 0; b < B; ++b) status[b] = 0;
+        return SSMQ_OK;
+    }
+    FInfo fio;
+    if (!integrand_info(f_obs->id, &fio)) {
+        set_error("unknown integrand id");
+        return SSMQ_E_ARG;
+    }
+    const int sel = sel_pattern(f_obs, fio.din);
+    const char *kname = nullptr;
+    if (ssmq::sw("SSMQ_NO_FUSED") || ssmq::sw("SSMQ_NO_PIPED") ||
+        try_launch_range(h_dyn, f_dyn, h_obs, f_obs, sel, B, 0, T, 0, T, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, &kname, true, nullptr, nullptr) != 1) {
+        set_error("filter_forward_piped: no time-block kernel for this (models, shapes, form) combination");
+        return SSMQ_E_UNSUPPORTED;
+    }
+    const bool out_pinned = (flags & SSMQ_PIPED_OUT_PINNED) != 0, per_traj = (flags & SSMQ_PIPED_X0_PER_TRAJECTORY) != 0;
+    const int64_t ld = (B + 63) / 64 * 64, nblk = ld / 64;
+    hipStream_t s = stream();
+    Ctx &cx = ctx();
+    if (!cx.pipe) cx.pipe = new PipeCache;
+    PipeCache &pc = *(PipeCache *)cx.pipe;
+    if (!pc.s_in) SSMQ_HIP(hipStreamCreateWithFlags(&pc.s_in, hipStreamNonBlocking));
+    if (!pc.s_out) SSMQ_HIP(hipStreamCreateWithFlags(&pc.s_out, hipStreamNonBlocking));
+    // ---- time blocks: ~2 MB of output per block, at most 16 -------------------------------------------------------------------
+    const size_t out_step = sizeof(double) * ((size_t)D + (size_t)D * D) * ld;
+    int K = n_blocks;
+    if (K == 0) {
+        const int64_t steps = std::max<int64_t>(1, (int64_t)((size_t(2) << 20) / out_step));
+        K = (int)std::max<int64_t>(1, std::min<int64_t>(16, T / steps));
+    }
+    K = std::max(1, std::min(K, T));
+    while ((int)pc.ev_in.size() < K) {
+        hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+        SSMQ_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        SSMQ_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        SSMQ_HIP(hipEventCreateWithFlags(&c, hipEventDisableTiming));
+        pc.ev_in.push_back(a); pc.ev_run.push_back(b); pc.ev_out.push_back(c);
+    }
+    // ---- device block and pinned staging (grow-only, per context) ---------------------------------------------------------------
+    const size_t n_y = (size_t)T * Y * ld, n_m = (size_t)D * ld, n_P = (size_t)D * D * ld, n_fm = (size_t)T * D * ld, n_fP = (size_t)T * D * D * ld;
+    const size_t n_c = ((size_t)D * D + (size_t)Y * Y + 2 * (size_t)T + 7) / 8 * 8, n_hand = (size_t)nblk * range_hand_doubles(D);
+    const size_t d_dbl = n_y + n_m + n_P + n_fm + n_fP + n_c + n_hand;
+    const size_t hin_dbl = n_y + n_m + n_P + n_c, hout_dbl = (out_pinned ? 0 : n_fm + n_fP);
+    // (the staging arena may be resized: nothing of an earlier call is in flight - every call ends with its last copy complete)
+    if ((rc = g_stage.reserve(sizeof(double) * d_dbl + sizeof(int32_t) * ld, sizeof(double) * hin_dbl, sizeof(double) * hout_dbl + sizeof(int32_t) * ld)))
+        return rc;
+    double *dv = (double *)g_stage.dev;
+    double *d_y = dv; dv += n_y;
+    double *d_m0 = dv; dv += n_m;
+    double *d_P0 = dv; dv += n_P;
+    double *d_fm = dv; dv += n_fm;
+    double *d_fP = dv; dv += n_fP;
+    double *d_c = dv; dv += n_c;
+    double *d_hand = dv; dv += n_hand;
+    int32_t *d_st = (int32_t *)dv;
+    double *hin = (double *)g_stage.hin;
+    double *h_y = hin, *h_m0 = hin + n_y, *h_P0 = h_m0 + n_m, *h_c = h_P0 + n_P;
+    double *h_fm = (double *)g_stage.hout, *h_fP = h_fm + (out_pinned ? 0 : n_fm);
+    int32_t *h_st = (int32_t *)((double *)g_stage.hout + hout_dbl);
+    // ---- constants and initial moments, then the first block of measurements: one transfer ------------------------------------
+    double *c_gqg = h_c, *c_rr = c_gqg + D * D, *c_ttd = c_rr + Y * Y, *c_tto = c_ttd + T;
+    for (int i = 0; i < D * D; ++i) c_gqg[i] = GQG ? GQG[i] : 0.0;
+    for (int i = 0; i < Y * Y; ++i) c_rr[i] = R ? R[i] : 0.0;
+    const bool has_td = time_table(f_dyn->id, T, c_ttd), has_to = time_table(f_obs->id, T, c_tto);
+    if (per_traj) {
+        for (int d = 0; d < D; ++d)
+            for (int64_t b = 0; b < ld; ++b) h_m0[(size_t)d * ld + b] = b < B ? m0[b * D + d] : 0.0;
+        for (int i = 0; i < D * D; ++i)
+            for (int64_t b = 0; b < ld; ++b) h_P0[(size_t)i * ld + b] = b < B ? P0[b * D * D + i] : ((i / D == i % D) ? 1.0 : 0.0);
+    } else {
+        for (int d = 0; d < D; ++d) std::fill(h_m0 + (size_t)d * ld, h_m0 + (size_t)(d + 1) * ld, m0[d]);
+        for (int i = 0; i < D * D; ++i) std::fill(h_P0 + (size_t)i * ld, h_P0 + (size_t)(i + 1) * ld, P0[i]);
+    }
+    SSMQ_HIP(hipMemcpyAsync(d_m0, h_m0, sizeof(double) * (n_m + n_P + n_c), hipMemcpyHostToDevice, pc.s_in));      // m0 | P0 | consts are adjacent
+    const double *dc_gqg = d_c, *dc_rr = d_c + D * D, *dc_ttd = has_td ? d_c + D * D + Y * Y : nullptr, *dc_tto = has_to ? d_c + D * D + Y * Y + T : nullptr;
+    auto t_of = [&](int k) { return (int)((int64_t)T * k / K); };
+    auto drain = [&](int k) -> int {        // block k's outputs are in host memory: bring them into the caller's arrays if staged
+        SSMQ_HIP(hipEventSynchronize(pc.ev_out[k]));
+        if (!out_pinned) {
+            const int kb = t_of(k), ke = t_of(k + 1);
+            copy_rows_pool(false, fm, h_fm + (size_t)kb * D * ld, kb, ke, T, D, B, ld);
+            copy_rows_pool(false, fP, h_fP + (size_t)kb * D * D * ld, kb, ke, T, D * D, B, ld);
+        }
+        return SSMQ_OK;
+    };
+    for (int k = 0; k < K; ++k) {
+        const int kb = t_of(k), ke = t_of(k + 1);
+        copy_rows_pool(true, const_cast<double *>(y), h_y + (size_t)kb * Y * ld, kb, ke, T, Y, B, ld);
+        SSMQ_HIP(hipMemcpyAsync(d_y + (size_t)kb * Y * ld, h_y + (size_t)kb * Y * ld, sizeof(double) * (size_t)(ke - kb) * Y * ld, hipMemcpyHostToDevice, pc.s_in));
+        SSMQ_HIP(hipEventRecord(pc.ev_in[k], pc.s_in));
+        SSMQ_HIP(hipStreamWaitEvent(s, pc.ev_in[k], 0));
+        rc = try_launch_range(h_dyn, f_dyn, h_obs, f_obs, sel, B, ld, T, kb, ke, d_y, d_m0, d_P0, dc_gqg, dc_rr, d_fm, d_fP, d_st, d_hand, s, nullptr, false,
+                              dc_ttd, dc_tto);
+        if (rc != 1) return rc < 0 ? rc : SSMQ_E_UNSUPPORTED;
+        SSMQ_HIP(hipEventRecord(pc.ev_run[k], s));
+        SSMQ_HIP(hipStreamWaitEvent(pc.s_out, pc.ev_run[k], 0));
+        if (out_pinned) {
+            // the copy engine writes the reference's layout: host row (e, t) <- plane row (t, e), rows of B doubles
+            for (int e = 0; e < D; ++e)
+                SSMQ_HIP(hipMemcpy2DAsync(fm + ((size_t)e * T + kb) * B, sizeof(double) * B, d_fm + ((size_t)kb * D + e) * ld, sizeof(double) * D * ld,
+                                          sizeof(double) * B, ke - kb, hipMemcpyDeviceToHost, pc.s_out));
+            for (int e = 0; e < D * D; ++e)
+                SSMQ_HIP(hipMemcpy2DAsync(fP + ((size_t)e * T + kb) * B, sizeof(double) * B, d_fP + ((size_t)kb * D * D + e) * ld,
+                                          sizeof(double) * D * D * ld, sizeof(double) * B, ke - kb, hipMemcpyDeviceToHost, pc.s_out));
+        } else {
+            SSMQ_HIP(hipMemcpyAsync(h_fm + (size_t)kb * D * ld, d_fm + (size_t)kb * D * ld, sizeof(double) * (size_t)(ke - kb) * D * ld, hipMemcpyDeviceToHost, pc.s_out));
+            SSMQ_HIP(hipMemcpyAsync(h_fP + (size_t)kb * D * D * ld, d_fP + (size_t)kb * D * D * ld, sizeof(double) * (size_t)(ke - kb) * D * D * ld,
+                                    hipMemcpyDeviceToHost, pc.s_out));
+        }
+        if (k == K - 1) SSMQ_HIP(hipMemcpyAsync(h_st, d_st, sizeof(int32_t) * ld, hipMemcpyDeviceToHost, pc.s_out));
+        SSMQ_HIP(hipEventRecord(pc.ev_out[k], pc.s_out));
+        if (k >= 1 && (rc = drain(k - 1))) return rc;
+    }
+    if ((rc = drain(K - 1))) return rc;
+    memcpy(status, h_st, sizeof(int32_t) * B);
+    // the context's stream has nothing pending that uses the staging blocks (the last block's copies waited for its kernel)
+    return SSMQ_OK;
 }
 
 // Filters whose models take the noise as an argument (ssinf.py:271-272, 282-283, 294-295): the moments are augmented with

@@ -61,6 +61,7 @@ struct Ctx {
     size_t strip_bytes = 0;
     void *multi = nullptr;                   // ssmq_api.hip: MultiCache (side streams, events, constants and captured graph of
                                              // ssmq_filter_forward_multi_dev)
+    void *pipe = nullptr;                    // ssmq_api.hip: PipeCache (copy streams and events of ssmq_filter_forward_piped)
     bool no_strips = false;                  // set while a multi-filter launch is being built: the strip schedule owns ONE buffer
                                              // per context and its jobs run concurrently
 };

@@ -162,6 +162,47 @@ class GaussianInference:
         d_P0.free()
         return d_fm, d_fP, d_st
 
+    def _forward_pass_piped(self, lib, data, x0_mean, x0_cov, raise_on_failure):
+        """The forward pass with its transfers overlapped (`ssmq_filter_forward_piped`: time blocks; the measurements of the next
+        block go up and the moments of the previous one come down while a block runs).  None when the filter has no time-block
+        kernel - the caller then takes the upload / pass / download path.  Results: the same bits either way."""
+        if type(self)._launch is not GaussianInference._launch:        # Studentian recursion: not pipelined
+            return None
+        Y, T, B = data.shape
+        D = self.mod_dyn.dim_state
+        f_dyn, e_dyn = resolve_integrand(self.mod_dyn.dyn_eval)
+        f_obs, e_obs = resolve_integrand(self.mod_obs.meas_eval)
+        h_dyn, h_obs = self.tf_dyn._handle_for(e_dyn), self.tf_obs._handle_for(e_obs)
+        flags = 0
+        if x0_mean is None and x0_cov is None:
+            m0, P0 = np.ascontiguousarray(self.x0_mean, dtype=np.float64), np.ascontiguousarray(self._initial_cov(), dtype=np.float64)
+        else:
+            m0 = np.ascontiguousarray(np.broadcast_to(self.x0_mean, (B, D)) if x0_mean is None else x0_mean, dtype=np.float64)
+            P0 = np.ascontiguousarray(np.broadcast_to(self._initial_cov(), (B, D, D)) if x0_cov is None else x0_cov, dtype=np.float64)
+            flags |= 2           # SSMQ_PIPED_X0_PER_TRAJECTORY
+        fm, fP = _lib.pinned_empty((D, T, B)), _lib.pinned_empty((D, D, T, B))
+        if fm is None or fP is None:
+            fm, fP = np.empty((D, T, B)), np.empty((D, D, T, B))
+        else:
+            flags |= 1           # SSMQ_PIPED_OUT_PINNED
+        st = np.empty(B, dtype=np.int32)
+        gqg, pg = _lib.as_c(self.G.dot(self.q_cov).dot(self.G.T))
+        rr, pr = _lib.as_c(self.r_cov)
+        yc = np.ascontiguousarray(data)
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)       # noqa: E731
+        rc = lib.ssmq_filter_forward_piped(ctypes.c_void_p(h_dyn), ctypes.byref(f_dyn), ctypes.c_void_p(h_obs), ctypes.byref(f_obs), B, T,
+                                           dp(yc), dp(m0), dp(P0), pg, pr, ctypes.c_void_p(fm.ctypes.data),
+                                           ctypes.c_void_p(fP.ctypes.data), ctypes.c_void_p(st.ctypes.data), flags, 0)
+        if rc == -3:             # SSMQ_E_UNSUPPORTED
+            return None
+        _lib.check(rc, 'ssmq_filter_forward_piped')
+        self.status = st
+        if raise_on_failure and st.any():
+            b = int(np.flatnonzero(st)[0])
+            raise np.linalg.LinAlgError('Matrix is not positive definite (trajectory {}, step {})'.format(b, int(st[b]) - 1))
+        self.fi_mean, self.fi_cov = fm, fP
+        return fm, fP
+
     def forward_pass_batch(self, data, x0_mean=None, x0_cov=None, raise_on_failure=True, smooth=False):
         """data (dim_y, T, B).  Optional per-trajectory initial moments x0_mean (B, D), x0_cov (B, D, D)."""
         lib = _lib.load()
@@ -170,6 +211,10 @@ class GaussianInference:
         Y, T, B = data.shape
         D = self.mod_dyn.dim_state
         ld = (B + 63) // 64 * 64
+        if not smooth and self._additive and B > 0 and T > 0:
+            done = self._forward_pass_piped(lib, data, x0_mean, x0_cov, raise_on_failure)
+            if done is not None:
+                return done
         # (dim_y, T, B) -> planes [T][Y][ld]: a row permutation, done between the caller's array and the library's pinned
         # staging block (`ssmq_upload_planes`)
         d_y = _lib.scratch(8 * T * Y * ld)

@@ -3553,6 +3553,73 @@ def test_run_filters_is_the_serial_calls_bit_for_bit(amd, monkeypatch):
     assert lib.ssmq_filter_forward_multi_dev(2, jobs) == -1 and lib.ssmq_filter_forward_multi_dev(0, None) == 0
 
 
+def test_piped_forward_pass_is_the_plain_one_bit_for_bit(amd, monkeypatch):
+    """forward_pass_batch with its transfers overlapped (ssmq_filter_forward_piped: K launches of k_filter_range over consecutive
+    time blocks, copies on their own streams) against the upload / whole pass / download path (SSMQ_NO_PIPED=1): same bits - for the
+    headline filter, for a failing trajectory, for per-trajectory initial moments, for every block count, for pageable and for
+    page-locked result arrays, and for a 5-D filter; the returned arrays are ordinary writable ndarrays."""
+    from ssmtoybox_amd import ssinf, ssmod as sm, _lib
+    from bench import simulate_ungm, simulate_reentry
+    lib = _lib.load()
+    B, T = 5000, 37
+    _, y = simulate_ungm(B, T, 3)
+    y = np.ascontiguousarray(y[None])
+    dyn = sm.UNGMTransition(sm.GaussRV(1), sm.GaussRV(1, cov=np.array([[10.0]])))
+    obs = sm.UNGMMeasurement(sm.GaussRV(1), 1)
+    par = np.array([[1.0, 3.0]])
+    rng = np.random.default_rng(0)
+    x0m = rng.standard_normal((B, 1))
+    x0c = 0.5 + rng.random((B, 1, 1))
+    x0c[17, 0, 0] = -1.0                                           # one trajectory that fails at the first factorisation
+    for make in (lambda: ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut'), lambda: ssinf.UnscentedKalman(dyn, obs),
+                 lambda: ssinf.CubatureKalman(dyn, obs)):
+        monkeypatch.setenv('SSMQ_NO_PIPED', '1')
+        a0 = make()
+        ref = a0.forward_pass_batch(y)
+        ref_x = a0.forward_pass_batch(y, x0m, x0c, raise_on_failure=False) + (a0.status.copy(),)
+        monkeypatch.delenv('SSMQ_NO_PIPED')
+        a1 = make()
+        got = a1.forward_pass_batch(y)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and not a1.status.any()
+        assert lib.ssmq_pinned_is_block(ctypes.c_void_p(got[0].ctypes.data)) == 1          # (the pipelined route was taken)
+        got[0][0, 0, 0] += 1.0                                      # writable, the caller's own (ssinf.py:279 mutates its results)
+        got_x = a1.forward_pass_batch(y, x0m, x0c, raise_on_failure=False)
+        assert np.array_equal(got_x[0], ref_x[0], equal_nan=True) and np.array_equal(got_x[1], ref_x[1], equal_nan=True)
+        assert np.array_equal(a1.status, ref_x[2]) and a1.status[17] == 1
+        with pytest.raises(np.linalg.LinAlgError):
+            a1.forward_pass_batch(y, x0m, x0c)
+    # the C entry point: every block count, pageable outputs
+    alg = ssinf.GaussianProcessKalman(dyn, obs, par, par, 'rbf', 'ut')
+    monkeypatch.setenv('SSMQ_NO_PIPED', '1')
+    ref = alg.forward_pass_batch(y)
+    monkeypatch.delenv('SSMQ_NO_PIPED')
+    from ssmtoybox_amd.mtran import resolve_integrand
+    f_dyn, e_dyn = resolve_integrand(dyn.dyn_eval)
+    f_obs, e_obs = resolve_integrand(obs.meas_eval)
+    dp = lambda a: a.ctypes.data_as(_lib.c_double_p)            # noqa: E731
+    for K in (1, 2, 5, 36, 37, 64):
+        fm, fP, st = np.full((1, T, B), np.nan), np.full((1, 1, T, B), np.nan), np.full(B, -7, dtype=np.int32)
+        rc = lib.ssmq_filter_forward_piped(ctypes.c_void_p(alg.tf_dyn._handle_for(e_dyn)), ctypes.byref(f_dyn),
+                                           ctypes.c_void_p(alg.tf_obs._handle_for(e_obs)), ctypes.byref(f_obs), B, T, dp(y), dp(np.zeros(1)),
+                                           dp(np.ones((1, 1))), dp(np.array([[10.0]])), dp(np.ones((1, 1))), ctypes.c_void_p(fm.ctypes.data),
+                                           ctypes.c_void_p(fP.ctypes.data), ctypes.c_void_p(st.ctypes.data), 0, K)
+        assert rc == 0 and np.array_equal(fm, ref[0]) and np.array_equal(fP, ref[1]) and not st.any(), K
+    # a 5-D filter (42 strided copies per block) and a shape without a time-block kernel (falls back, same call)
+    Br, Tr = 3000, 20
+    x5, y5, m5, P5, Q5, G5, R5 = simulate_reentry(Br, Tr, 8, False)
+    dyn5 = sm.ReentryVehicle2DTransition(sm.GaussRV(5, m5, P5), sm.GaussRV(3, cov=Q5))
+    obs5 = sm.Radar2DMeasurement(sm.GaussRV(2, cov=R5), 5)
+    monkeypatch.setenv('SSMQ_NO_PIPED', '1')
+    ref = ssinf.UnscentedKalman(dyn5, obs5).forward_pass_batch(y5)
+    refg = ssinf.GaussHermiteKalman(dyn, obs, deg=7).forward_pass_batch(y)
+    monkeypatch.delenv('SSMQ_NO_PIPED')
+    got = ssinf.UnscentedKalman(dyn5, obs5).forward_pass_batch(y5)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert lib.ssmq_pinned_is_block(ctypes.c_void_p(got[0].ctypes.data)) == 1
+    gotg = ssinf.GaussHermiteKalman(dyn, obs, deg=7).forward_pass_batch(y)
+    assert np.array_equal(gotg[0], refg[0]) and lib.ssmq_pinned_is_block(ctypes.c_void_p(gotg[0].ctypes.data)) == 0
+
+
 def test_chunked_many_small_strips_across_xcds(amd, monkeypatch):
     """Stress of the strip hand-over's ordering (csrc/ssmq_filter_chunked.hip, "Ordering"): strip counts just below the block count
     make nearly every wave both publish a state and consume one, on compute units of different XCDs, hundreds of hand-overs per
