@@ -17,6 +17,7 @@
 #include "ssmq_host.h"
 #include "ssmq_update.h"
 #include "ssmq_apply_small.h"
+#include "ssmq_fused.h"
 
 namespace ssmq {
 
@@ -1836,6 +1837,11 @@ extern "C" int ssmq_filter_forward_dev(ssmq_transform *h_dyn, const ssmq_integra
 // forks into one branch per job inside a captured graph - each branch is the job's own fused time-loop kernel, so the RESULTS ARE
 // THE BITS of ssmq_filter_forward_dev / ssmq_student_filter_forward_dev - and joins again; a repeated call with the same jobs is one
 // hipGraphLaunch.  Jobs without a fused kernel run after the graph, one by one, through the ordinary path.
+namespace ssmq {
+int multi_family_table(int n, const ssmq_transform *const *hd, const ssmq_integrand *const *fd, const ssmq_transform *const *ho,
+                       const ssmq_integrand *const *fo, const FusedArgs *args, std::vector<char> *table, int *blocks);
+int multi_family_launch(const char *d_table, int blocks, hipStream_t s);
+}
 namespace {
 struct MultiCache {
     std::vector<hipStream_t> side;
@@ -1847,12 +1853,15 @@ struct MultiCache {
     hipGraphExec_t exec = nullptr;
     std::vector<uint64_t> key;
     std::vector<char> fused;          // per job of the cached key: 1 = in the graph
+    std::vector<char> htable;         // one-kernel route (every job of one model family): the kernel's argument block
+    int table_blocks = 0;             // > 0: the cached key runs as ONE launch of the family kernel
     void drop_graph() {
         if (exec) hipGraphExecDestroy(exec);
         if (graph) hipGraphDestroy(graph);
         exec = nullptr;
         graph = nullptr;
         key.clear();
+        table_blocks = 0;
     }
     void drop_all() {
         drop_graph();
@@ -1939,6 +1948,7 @@ extern "C" int ssmq_filter_forward_multi_dev(int n_jobs, const ssmq_filter_job *
     }
     key.push_back(ssmq::sw("SSMQ_NO_FUSED") ? 1 : 0);
     key.push_back(ssmq::sw("SSMQ_MULTI_NO_GRAPH") ? 1 : 0);
+    key.push_back(ssmq::sw("SSMQ_MULTI_NO_FAMILY") ? 1 : 0);
     auto run_rest = [&]() -> int {       // the jobs that are not in the graph, through the ordinary path, one by one
         for (int i = 0; i < n_jobs; ++i) {
             if (mc.fused[i]) continue;
@@ -1949,6 +1959,7 @@ extern "C" int ssmq_filter_forward_multi_dev(int n_jobs, const ssmq_filter_job *
         }
         return SSMQ_OK;
     };
+    if (mc.table_blocks > 0 && mc.key == key) return multi_family_launch(mc.htable.data(), mc.table_blocks, s);
     if (mc.exec && mc.key == key) {
         SSMQ_HIP(hipGraphLaunch(mc.exec, s));
         return run_rest();
@@ -2019,6 +2030,36 @@ extern "C" int ssmq_filter_forward_multi_dev(int n_jobs, const ssmq_filter_job *
     }
     int n_fused = 0;
     for (int i = 0; i < n_jobs; ++i) n_fused += mc.fused[i];
+    if (n_fused == n_jobs && !ssmq::sw("SSMQ_MULTI_NO_FAMILY")) {
+        // every job a filter of one model family with a common kernel: ONE launch, the jobs' blocks side by side
+        std::vector<FusedArgs> fa(n_jobs);
+        std::vector<const ssmq_transform *> vhd(n_jobs), vho(n_jobs);
+        std::vector<const ssmq_integrand *> vfd(n_jobs), vfo(n_jobs);
+        for (int i = 0; i < n_jobs; ++i) {
+            const ssmq_filter_job &j = jobs[i];
+            FusedArgs &a = fa[i];
+            memset(&a, 0, sizeof(a));
+            a.y = j.d_y; a.m0 = j.d_m0; a.P0 = j.d_P0; a.fm = j.d_fm; a.fP = j.d_fP; a.status = j.d_status;
+            a.c_dyn = j.h_dyn->d_small; a.c_obs = j.h_obs->d_small; a.gqg = jc[i].gqg; a.rr = jc[i].rr; a.B = j.B; a.ld = j.ld; a.T = j.T;
+            a.emv_dyn = j.h_dyn->emv_mode; a.emv_obs = j.h_obs->emv_mode; a.nu_dyn = j.h_dyn->tp_nu; a.nu_obs = j.h_obs->tp_nu;
+            a.sscale = jc[i].svec; a.student_dof = j.dof; a.lpw = 64;
+            fill_fpar(j.f_dyn, &a.fd);
+            fill_fpar(j.f_obs, &a.fo);
+            a.fd.ttab = jc[i].ttd;
+            a.fo.ttab = jc[i].tto;
+            vhd[i] = j.h_dyn; vho[i] = j.h_obs; vfd[i] = j.f_dyn; vfo[i] = j.f_obs;
+        }
+        std::vector<char> table;
+        int blocks = 0;
+        if (multi_family_table(n_jobs, vhd.data(), vfd.data(), vho.data(), vfo.data(), fa.data(), &table, &blocks) == 1) {
+            mc.htable = table;
+            rc = multi_family_launch(mc.htable.data(), blocks, s);
+            if (rc) return rc;
+            mc.table_blocks = blocks;
+            mc.key = key;
+            return SSMQ_OK;
+        }
+    }
     const bool capture = n_fused > 0 && !ssmq::sw("SSMQ_MULTI_NO_GRAPH");
     Ctx &cx = ctx();
     struct StripsOff {
@@ -2317,9 +2358,9 @@ extern "C" int ssmq_filter_forward_piped(ssmq_transform *h_dyn, const ssmq_integ
     double *d_y = dv; dv += n_y;
     double *d_m0 = dv; dv += n_m;
     double *d_P0 = dv; dv += n_P;
+    double *d_c = dv; dv += n_c;             // (m0 | P0 | constants: ONE transfer, same order as in the pinned block)
     double *d_fm = dv; dv += n_fm;
     double *d_fP = dv; dv += n_fP;
-    double *d_c = dv; dv += n_c;
     double *d_hand = dv; dv += n_hand;
     int32_t *d_st = (int32_t *)dv;
     double *hin = (double *)g_stage.hin;

@@ -23,8 +23,9 @@
 //     0.459 -> 0.432 ms.  The strips: 0.455 -> 0.405 ms (reentry UKF 5-D, B = 1e5), 0.584 -> 0.514 (6-D), 0.448 -> 0.285 at B = 7e4
 //     (1 094 blocks: 1.07 rounds instead of 2) - the balanced figure at the ~2.07 GHz the chip holds with every SIMD busy.
 //     Ordering, stated once: producer = [state: system-scope atomic stores, sc0 sc1 = write-through past the
-//     per-XCD L2] -> release fence, workgroup scope (s_waitcnt vmcnt(0): every one of those stores has been ACKNOWLEDGED by
-//     memory; plus the compiler barrier) -> __syncthreads -> [flag: system-scope atomic store].  Consumer = [spin on a system-scope
+//     per-XCD L2] -> release fence, workgroup scope (the compiler barrier) + an EXPLICIT s_waitcnt vmcnt(0) (every one of those
+//     stores has been ACKNOWLEDGED: the fence alone emits no such wait for a one-CU workgroup, see the kernel) -> __syncthreads ->
+//     [flag: system-scope atomic store].  Consumer = [spin on a system-scope
 //     atomic load of the flag] -> acquire fence, workgroup scope (compiler barrier: the loads below stay below) -> [state:
 //     system-scope atomic loads, sc0 sc1 = served from memory, never from this XCD's L2].  Every access of the shared words is an
 //     atomic of system scope, so there is no data race in the language's sense; what the fences do NOT do is write back / invalidate
@@ -88,7 +89,14 @@ __global__ __launch_bounds__(kSmallBlock, (D >= 6 ? 1 : ((D >= 5 && FORM == SSMQ
         }
         if ((int)threadIdx.x < a.lpw) fused_pass<D, Y, ND, NO, FD, FO, FORM, TP, SELO, OPT, STU, true>(a, (uint32_t)blk, kb, ke, kb == 0, ke == a.T);
         if (is_head) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the state stores have completed (s_waitcnt) ...
+            // RELEASE side: every state store of this wave has been ACKNOWLEDGED before the flag goes out.  The wait is spelled out:
+            // round 5 relied on a workgroup-scope release fence for it, and hipcc lowers that fence to NO vmcnt wait when a
+            // workgroup cannot span compute units (non-tgsplit mode; checked in the disassembly in round 6: the flag store followed
+            // the state stores with only an lgkmcnt wait between them) - the flag, on another memory channel, could then overtake
+            // the state it announces: one bitwise mismatch in ~10 suite runs (test_chunked_time_loop_is_bitwise_the_whole_pass,
+            // ct / tpqkf, round 6).  The fence stays as the compiler-level barrier.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(&flag[blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // ... then the flag
         }

@@ -8,6 +8,7 @@
 // The input-state cross-covariance of the dynamics transform is only consumed by the smoother (ssinf.py:105-107,
 // 325-344) and is not formed in the forward pass.
 #include <cstring>
+#include <vector>
 #include "ssmq_filter_fused_kernel.h"
 
 namespace ssmq {
@@ -79,6 +80,111 @@ static const FusedEntry kFused[] = {
     SSMQ_FUSED(SSMQ_F_CT_DYN, SSMQ_F_BEARING_MEAS, 5, 4, 10, 1),
 #endif
 };
+
+// ---- several filters of ONE model family in one launch (round 6; ssmq_filter_forward_multi_dev) -------------------------------
+// A graph with one branch per filter still reaches the device as one dispatch after the other (measured: six configs[1]-sized UNGM
+// filters 160 us as a forked graph, 187 us as six streams, 31 us each - the launch path serialises them).  The filters of the
+// reference's UNGM studies (research/bsq/bsq_ungm.py:132-137, research/tpq/tpq_base.py:175-192: UKF, CKF, GHKF, GPQKF, TPQKF,
+// BSQKF) differ only in point count and form, so they fit ONE kernel: the grid is the concatenation of the jobs' blocks, a block
+// looks its job up in a table in memory and runs that job's time loop - the same fused_pass<> instantiation k_filter_fused runs,
+// hence the same bits.  942 waves for six filters of 1e4 trajectories: every one has a SIMD to itself.
+// The job table travels in the kernel-argument segment (constant memory: a block reads its job's fields with scalar loads on
+// demand - a table in global memory, copied into a local FusedArgs, cost 495 spilled SGPRs): only what the UNGM time loop reads.
+struct MultiJob {
+    const double *y, *m0, *P0, *c_dyn, *c_obs, *gqg, *rr, *ttd, *tto;
+    double *fm, *fP;
+    int32_t *status;
+    int64_t B, ld;
+    int32_t T, emv_dyn, emv_obs, kind;
+    double nu_dyn, nu_obs;
+    int32_t first, pad;          // first block of the job in the grid
+};
+constexpr int kMultiMaxJobs = 24;
+struct MultiKernArgs {
+    int32_t n, blocks;
+    MultiJob job[kMultiMaxJobs];
+};
+static_assert(sizeof(MultiKernArgs) <= 4096, "kernel-argument segment");
+
+// One NON-INLINED function per kind: nine time loops inlined into one kernel body shared one scalar-register allocation and
+// spilled 500 SGPRs (to vector-register lanes, read back inside the loops); as functions each has the allocation of its own
+// whole-pass kernel.  The job record is read through the constant address space (scalar loads).
+typedef const __attribute__((address_space(4))) MultiJob *multi_job_p;
+template <int N, int FORM, int TP>
+__device__ __attribute__((noinline)) void multi_case(multi_job_p q, uint32_t blk) {
+    FusedArgs a;
+    a.y = q->y; a.m0 = q->m0; a.P0 = q->P0; a.fm = q->fm; a.fP = q->fP; a.status = q->status;
+    a.c_dyn = q->c_dyn; a.c_obs = q->c_obs; a.gqg = q->gqg; a.rr = q->rr; a.B = q->B; a.ld = q->ld; a.T = q->T;
+    a.emv_dyn = q->emv_dyn; a.emv_obs = q->emv_obs; a.lpw = 64; a.nu_dyn = q->nu_dyn; a.nu_obs = q->nu_obs;
+    a.sscale = nullptr; a.student_dof = 0.0;
+    a.fd.n_par = a.fd.n_idx = a.fo.n_par = a.fo.n_idx = 0;
+    a.fd.ttab = q->ttd; a.fd.tval = 0.0; a.fd.use_tval = 0;
+    a.fo.ttab = q->tto; a.fo.tval = 0.0; a.fo.use_tval = 0;
+    a.t_chunk = a.n_blocks = 0; a.queue = nullptr; a.hand = nullptr;
+    fused_pass<1, 1, N, N, SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, FORM, TP, 0, 0, 0, false>(a, blk, 0, a.T, true, true);
+}
+
+__global__ __launch_bounds__(kSmallBlock, 2) void k_filter_multi_ungm(const MultiKernArgs) {
+    const __attribute__((address_space(4))) MultiKernArgs *m =
+        (const __attribute__((address_space(4))) MultiKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    int j = 0;
+    while (j + 1 < m->n && (int)blockIdx.x >= m->job[j + 1].first) ++j;
+    multi_job_p q = &m->job[j];
+    const uint32_t blk = blockIdx.x - (uint32_t)q->first;
+    switch (q->kind) {
+        case 0: multi_case<2, SSMQ_FORM_BQ, 0>(q, blk); break;
+        case 1: multi_case<2, SSMQ_FORM_BQ, 1>(q, blk); break;
+        case 2: multi_case<2, SSMQ_FORM_SIGMA, 0>(q, blk); break;
+        case 3: multi_case<3, SSMQ_FORM_BQ, 0>(q, blk); break;
+        case 4: multi_case<3, SSMQ_FORM_BQ, 1>(q, blk); break;
+        case 5: multi_case<3, SSMQ_FORM_SIGMA, 0>(q, blk); break;
+        case 6: multi_case<5, SSMQ_FORM_BQ, 0>(q, blk); break;
+        case 7: multi_case<5, SSMQ_FORM_BQ, 1>(q, blk); break;
+        case 8: multi_case<5, SSMQ_FORM_SIGMA, 0>(q, blk); break;
+        default: break;
+    }
+}
+
+// Host side: 1 = every job is a Gaussian-recursion UNGM filter with 2 / 3 / 5 points, at most kMultiMaxJobs of them (the kernel
+// arguments are written to `table`, the grid size to *blocks); 0 = not one family (the caller forks a graph instead).
+int multi_family_table(int n, const ssmq_transform *const *hd, const ssmq_integrand *const *fd, const ssmq_transform *const *ho,
+                       const ssmq_integrand *const *fo, const FusedArgs *args, std::vector<char> *table, int *blocks) {
+    if (n < 1 || n > kMultiMaxJobs) return 0;
+    MultiKernArgs m;
+    memset(&m, 0, sizeof(m));
+    m.n = n;
+    int64_t first = 0;
+    for (int i = 0; i < n; ++i) {
+        const FusedArgs &a = args[i];
+        if (fd[i]->id != SSMQ_F_UNGM_DYN || fo[i]->id != SSMQ_F_UNGM_MEAS || hd[i]->D != 1 || ho[i]->E != 1 || hd[i]->N != ho[i]->N ||
+            hd[i]->form != ho[i]->form || (hd[i]->tp_nu > 0.0) != (ho[i]->tp_nu > 0.0) || a.sscale != nullptr || a.student_dof > 0.0 ||
+            fd[i]->n_idx > 0 || fo[i]->n_idx > 0 || !a.fd.ttab || a.lpw != 64)
+            return 0;
+        const int N = hd[i]->N, in = N == 2 ? 0 : (N == 3 ? 1 : (N == 5 ? 2 : -1));
+        if (in < 0) return 0;
+        MultiJob &q = m.job[i];
+        q.y = a.y; q.m0 = a.m0; q.P0 = a.P0; q.c_dyn = a.c_dyn; q.c_obs = a.c_obs; q.gqg = a.gqg; q.rr = a.rr; q.ttd = a.fd.ttab; q.tto = a.fo.ttab;
+        q.fm = a.fm; q.fP = a.fP; q.status = a.status; q.B = a.B; q.ld = a.ld; q.T = a.T; q.emv_dyn = a.emv_dyn; q.emv_obs = a.emv_obs;
+        q.kind = 3 * in + (hd[i]->form == SSMQ_FORM_SIGMA ? 2 : (hd[i]->tp_nu > 0.0 ? 1 : 0));
+        q.nu_dyn = a.nu_dyn; q.nu_obs = a.nu_obs;
+        q.first = (int32_t)first;
+        first += (a.B + 63) / 64;
+        if (first > (1 << 30)) return 0;
+    }
+    m.blocks = (int32_t)first;
+    table->assign(sizeof(m), 0);
+    memcpy(table->data(), &m, sizeof(m));
+    *blocks = m.blocks;
+    return 1;
+}
+// `table`: the HOST copy multi_family_table() produced (kernel arguments are captured at launch)
+int multi_family_launch(const char *table, int blocks, hipStream_t s) {
+    if (blocks <= 0) return SSMQ_OK;
+    MultiKernArgs m;
+    memcpy(&m, table, sizeof(m));
+    hipLaunchKernelGGL(k_filter_multi_ungm, dim3((unsigned)blocks), dim3(kSmallBlock), 0, s, m);
+    return hip_fail(hipGetLastError(), "k_filter_multi_ungm");
+}
 
 // ---- models that take their noise as an argument (ssinf.py:271-272, 282-283, 294-295) -------------------------------------
 // Same time loop with the inputs of either transform augmented in registers: [m; noise_mean], blockdiag(P, noise_cov)

@@ -3507,6 +3507,17 @@ def test_run_filters_is_the_serial_calls_bit_for_bit(amd, monkeypatch):
     _, y = simulate_ungm(B, T, 77)
     y = np.ascontiguousarray(y[None])
     serial = [a.forward_pass_batch(y, raise_on_failure=False) + (a.status.copy(),) for a in _ungm_study_filters(ssinf, sm, True)]
+    # the six filters of one model family: ONE kernel (k_filter_multi_ungm), first call and repeated call; then the same six as
+    # a forked graph (SSMQ_MULTI_NO_FAMILY)
+    for mode in ('family', 'family again', 'graph of six'):
+        if mode == 'graph of six':
+            monkeypatch.setenv('SSMQ_MULTI_NO_FAMILY', '1')
+        algs = _ungm_study_filters(ssinf, sm) if mode != 'family again' else algs
+        got = ssinf.run_filters(algs, y, raise_on_failure=False)
+        for i, (a, g, s) in enumerate(zip(algs, got, serial)):
+            assert np.array_equal(g[0], s[0], equal_nan=True) and np.array_equal(g[1], s[1], equal_nan=True), (mode, i, type(a).__name__)
+            assert np.array_equal(a.status, s[2])
+    monkeypatch.delenv('SSMQ_MULTI_NO_FAMILY')
     for mode in ('graph', 'replay', 'nograph'):
         if mode == 'nograph':
             monkeypatch.setenv('SSMQ_MULTI_NO_GRAPH', '1')

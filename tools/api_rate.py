@@ -53,4 +53,4 @@ for pinned in (1, 0):
             ctypes.c_void_p(alg.tf_dyn._handle_for(e_dyn)), ctypes.byref(f_dyn), ctypes.c_void_p(alg.tf_obs._handle_for(e_obs)), ctypes.byref(f_obs),
             B, T, dp(y), dp(m0), dp(P0), dp(q), dp(r), ctypes.c_void_p(fm.ctypes.data), ctypes.c_void_p(fP.ctypes.data),
             ctypes.c_void_p(st.ctypes.data), pinned, K))
-        print('C entry point, %s results, K = %2d blocks   min %.3f ms  median %.3f ms' % (('pinned  ' if pinned else 'pageable'), K) + best(call))
+        print('C entry point, %s results, K = %2d blocks   min %.3f ms  median %.3f ms' % ((('pinned  ' if pinned else 'pageable'), K) + best(call)))

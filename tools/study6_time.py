@@ -21,12 +21,16 @@ one = st.time_single(0)
 ser = st.time_serial()
 os.environ.pop('SSMQ_MULTI_NO_GRAPH', None)
 mul = st.time_multi()
+os.environ['SSMQ_MULTI_NO_FAMILY'] = '1'
+mul_g = st.time_multi()
 os.environ['SSMQ_MULTI_NO_GRAPH'] = '1'
 mul_ng = st.time_multi()
 os.environ.pop('SSMQ_MULTI_NO_GRAPH', None)
+os.environ.pop('SSMQ_MULTI_NO_FAMILY', None)
 print('one pass (GPQKF)                 %.1f us' % (one * 1e3))
 print('six passes, one after the other  %.1f us  (%.2f x one pass)' % (ser * 1e3, ser / one))
-print('six passes, one launch graph     %.1f us  (%.2f x one pass)  -> %.3e filter steps/s' % (mul * 1e3, mul / one, 6 * B * T / (mul * 1e-3)))
+print('six passes, ONE kernel (family)   %.1f us  (%.2f x one pass)  -> %.3e filter steps/s' % (mul * 1e3, mul / one, 6 * B * T / (mul * 1e-3)))
+print('six passes, one forked graph     %.1f us  (%.2f x one pass)' % (mul_g * 1e3, mul_g / one))
 print('six passes, branches, no graph   %.1f us  (%.2f x one pass)' % (mul_ng * 1e3, mul_ng / one))
 print('results equal to the serial calls:', st.check())
 st.free()
