@@ -2317,7 +2317,9 @@ extern "C" int ssmq_filter_forward_piped(ssmq_transform *h_dyn, const ssmq_integ
     }
     const int sel = sel_pattern(f_obs, fio.din);
     const char *kname = nullptr;
-    if (ssmq::sw("SSMQ_NO_FUSED") || ssmq::sw("SSMQ_NO_PIPED") ||
+    // (a forced route - wave split, quad, strips, lanes per wave - means the caller wants THAT kernel: not pipelined)
+    if (ssmq::sw("SSMQ_NO_FUSED") || ssmq::sw("SSMQ_NO_PIPED") || ssmq::sw("SSMQ_FUSED_WSPLIT") || ssmq::sw("SSMQ_FUSED_QUAD") ||
+        ssmq::sw("SSMQ_FUSED_CHUNKED") || ssmq::sw("SSMQ_FUSED_LPW") ||
         try_launch_range(h_dyn, f_dyn, h_obs, f_obs, sel, B, 0, T, 0, T, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                          nullptr, &kname, true, nullptr, nullptr) != 1) {
         set_error("filter_forward_piped: no time-block kernel for this (models, shapes, form) combination");
@@ -2331,13 +2333,11 @@ extern "C" int ssmq_filter_forward_piped(ssmq_transform *h_dyn, const ssmq_integ
     PipeCache &pc = *(PipeCache *)cx.pipe;
     if (!pc.s_in) SSMQ_HIP(hipStreamCreateWithFlags(&pc.s_in, hipStreamNonBlocking));
     if (!pc.s_out) SSMQ_HIP(hipStreamCreateWithFlags(&pc.s_out, hipStreamNonBlocking));
-    // ---- time blocks: ~2 MB of output per block, at most 16 -------------------------------------------------------------------
+    // ---- time blocks: ~8 MB of output per block, at most 16 (measured at configs[1], 16 MB of output: 0.62 ms with one block,
+    // 0.55 with two or three, 0.59 with five, 0.66 with seven, 0.92 with sixteen - every block costs its launches and events) ----
     const size_t out_step = sizeof(double) * ((size_t)D + (size_t)D * D) * ld;
     int K = n_blocks;
-    if (K == 0) {
-        const int64_t steps = std::max<int64_t>(1, (int64_t)((size_t(2) << 20) / out_step));
-        K = (int)std::max<int64_t>(1, std::min<int64_t>(16, T / steps));
-    }
+    if (K == 0) K = (int)std::max<size_t>(1, std::min<size_t>(16, (out_step * (size_t)T + (size_t(8) << 20) - 1) / (size_t(8) << 20)));
     K = std::max(1, std::min(K, T));
     while ((int)pc.ev_in.size() < K) {
         hipEvent_t a = nullptr, b = nullptr, c = nullptr;

@@ -431,6 +431,11 @@ int try_launch_wsplit(const ssmq_transform *hd, const ssmq_integrand *fd, const 
                       const double *d_gqg, const double *d_rr, double *d_fm, double *d_fP, int32_t *d_status, hipStream_t s,
                       const char **name, bool dry_run, const double *d_sscale, double student_dof, int cus);
 
+int try_launch_quad(const ssmq_transform *hd, const ssmq_integrand *fd, const ssmq_transform *ho, const ssmq_integrand *fo, int sel_obs,
+                    int64_t B, int64_t ld, int T, const double *d_y, const double *d_m0, const double *d_P0, const double *d_gqg,
+                    const double *d_rr, double *d_fm, double *d_fP, int32_t *d_status, hipStream_t s, const char **name, bool dry_run,
+                    const double *d_sscale, double student_dof, int cus);
+
 // ... and for batches of the heavy shapes that do not fill the chip evenly, the time loop in chunks dealt from a queue
 // (ssmq_filter_chunked.hip)
 int try_launch_chunked(const FusedArgs &a0, int fd, int fo, int D, int Y, int ND, int NO, int form, int tp, int selo, int opt, int cus,
@@ -457,7 +462,11 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
                      const double *d_sscale, double student_dof, const double *d_ttab_dyn, const double *d_ttab_obs) {
     if (hd->form != ho->form || (hd->tp_nu > 0.0) != (ho->tp_nu > 0.0) || sel_obs < 0 || fd->n_idx > 0) return 0;
     if (!dry_run || B > 0) {
-        // batches that leave most of the chip idle: sigma points shared out over the waves of a workgroup (ssmq_filter_wsplit.hip)
+        // batches whose waves would each sit alone on a SIMD: one trajectory on four lanes (ssmq_filter_quad.hip) ...
+        const int rq = try_launch_quad(hd, fd, ho, fo, sel_obs, B, ld, T, d_y, d_m0, d_P0, d_gqg, d_rr, d_fm, d_fP, d_status, s, name, dry_run,
+                                       d_sscale, student_dof, device_cus());
+        if (rq != 0) return rq;
+        // ... or the sigma points shared out over the waves of a workgroup (ssmq_filter_wsplit.hip)
         const int rw = try_launch_wsplit(hd, fd, ho, fo, sel_obs, B, ld, T, d_y, d_m0, d_P0, d_gqg, d_rr, d_fm, d_fP, d_status, s, name,
                                          dry_run, d_sscale, student_dof, device_cus());    // (the dry run asks the same device: 256 only without one)
         if (rw != 0) return rw;

@@ -3449,6 +3449,52 @@ def test_wsplit_filters_match_oracle_and_register_kernel(amd, monkeypatch):
         assert np.array_equal(fm2, runs['2'][0], equal_nan=True) and np.array_equal(fP2, runs['2'][1], equal_nan=True)
 
 
+def test_quad_filters_match_oracle_and_register_kernel(amd, monkeypatch):
+    """k_filter_quad (csrc/ssmq_filter_quad.hip: one trajectory on the four lanes of a quad, the sigma points dealt to the lanes,
+    partial sums all-reduced with DPP) against the C oracle on the same trajectories with the bars of the register kernel, against
+    the register kernel itself (summation order differs: rounding, not bits), batch sizes that are not multiples of 16, failing
+    trajectories at the same step, the default choice, and device-resident repeats bitwise equal."""
+    from oracle import c_oracle as co
+    from ssmtoybox_amd import ssinf, ssmod as sm
+    flt = _wsplit_filters(61)
+    cases = [flt[0], flt[2]]                      # UKF on the 5-D reentry model and on the 6-D variant
+    # + the unscented filter on the coordinated-turn model with four bearing sensors (measurements of the t-process case)
+    name, tpq, yc, _, _, m0c, P0c, Qc, Rc, _, _ = flt[3]
+    ukfc = ssinf.UnscentedKalman(tpq.mod_dyn, tpq.mod_obs)
+    spc = lambda tf, E, ci: co.make_transform(1, tf.unit_sp.shape[0], E, tf.unit_sp, tf.wm, np.diag(tf.Wc).copy(), integrand=ci)   # noqa: E731
+    cases.append(('ukf ct + bearings', ukfc, yc, spc(ukfc.tf_dyn, 5, co.Integrand.make(orc.F_CT_DYN, (0.1,))),
+                  spc(ukfc.tf_obs, 4, co.Integrand.make(orc.F_BEARING_MEAS, tuple(SENSORS.reshape(-1)), (0, 2))), m0c, P0c, Qc, Rc, 1e-8, 1e-7))
+    for name, alg, y, (td, k1), (to, k2), m0, P0, GQG, R, tol_m, tol_P in cases:
+        T, B = y.shape[1], y.shape[2]
+        y = y[:, :, :B - 5]                       # 195 trajectories: 12 full quads-of-16 and a wave with 3 trajectories
+        B = y.shape[2]
+        cfm, cfP, cst = co.filter_forward(td, to, np.ascontiguousarray(y.transpose(2, 1, 0)), m0, P0, GQG, R, threads=8)
+        cfm, cfP = cfm.transpose(2, 1, 0), cfP.transpose(2, 3, 1, 0)
+        x0c = np.tile(P0, (B, 1, 1))
+        x0c[7] = -np.eye(P0.shape[0])             # not positive definite from the start
+        runs = {}
+        for mode in ('0', '1'):
+            monkeypatch.setenv('SSMQ_FUSED_QUAD', mode)
+            kn = alg.kernel_name(B)
+            assert ('k_filter_quad<' if mode == '1' else 'k_filter_fused<') in kn, kn
+            fm, fP = alg.forward_pass_batch(y, raise_on_failure=False)
+            runs[mode] = (fm.copy(), fP.copy(), alg.status.copy())
+            _compare_filter_prefix(fm, fP, alg.status, cfm, cfP, cst, T, '%s, quad mode %s vs C oracle' % (name, mode), tol_m, tol_P)
+            fmx, fPx = alg.forward_pass_batch(y, x0_cov=x0c, raise_on_failure=False)
+            runs[mode + 'x'] = (fmx.copy(), fPx.copy(), alg.status.copy())
+        monkeypatch.delenv('SSMQ_FUSED_QUAD')
+        assert np.array_equal(runs['1'][2], runs['0'][2]), name
+        _compare_filter_prefix(runs['1'][0], runs['1'][1], runs['1'][2], runs['0'][0], runs['0'][1], runs['0'][2], T,
+                               '%s, quad vs the register kernel' % name, tol_m, tol_P)
+        assert np.array_equal(runs['1x'][2], runs['0x'][2]) and runs['1x'][2][7] == 1 and np.isnan(runs['1x'][0][:, :, 7]).all()
+        # the default for a batch this small is the quad kernel; a second pass replays nothing stale
+        assert 'k_filter_quad<' in alg.kernel_name(B) and 'k_filter_quad<' in alg.kernel_name(12500) and 'k_filter_quad<' not in alg.kernel_name(20000)
+        monkeypatch.setenv('SSMQ_FUSED_QUAD', '1')
+        fm2, fP2 = alg.forward_pass_batch(y, raise_on_failure=False)
+        monkeypatch.delenv('SSMQ_FUSED_QUAD')
+        assert np.array_equal(fm2, runs['1'][0], equal_nan=True) and np.array_equal(fP2, runs['1'][1], equal_nan=True)
+
+
 def test_chunked_time_loop_is_bitwise_the_whole_pass(amd, monkeypatch):
     """k_filter_chunked (csrc/ssmq_filter_chunked.hip): the block-steps of a batch cut into equal strips, one wave per strip; a block
     that straddles two strips is begun by one wave and finished by another from the state - mean, covariance triangle, status word
@@ -3698,7 +3744,10 @@ def test_wsplit_default_choice_and_failures(amd, monkeypatch):
     ukf, tpq = flt[0][1], flt[3][1]
     # (the wave split is not for the unscented reentry filter; at 1e5 trajectories - 1 563 blocks on 1 024 SIMDs - the five- and
     # six-state time loops run as equal strips of block-steps, csrc/ssmq_filter_chunked.hip, below the SIMD count as whole passes)
-    assert 'k_filter_fused<' in ukf.kernel_name(200) and 'k_filter_fused<' in ukf.kernel_name(60000)
+    # (... and below 16 384 trajectories - every whole-pass wave alone on a SIMD - with a trajectory on four lanes, ssmq_filter_quad.hip)
+    if 'SSMQ_FUSED_QUAD' not in os.environ:
+        assert 'k_filter_quad<' in ukf.kernel_name(200) and 'k_filter_quad<' in ukf.kernel_name(12500) and 'k_filter_fused<' in ukf.kernel_name(20000)
+    assert 'k_filter_fused<' in ukf.kernel_name(60000)
     if 'SSMQ_FUSED_CHUNKED' not in os.environ:           # (tools/alt_paths.sh runs the suite with the choice forced either way)
         assert 'k_filter_chunked<' in ukf.kernel_name(100000)
     assert 'k_filter_wsplit' in tpq.kernel_name(10000) and 'W=2>' in tpq.kernel_name(10000)
