@@ -38,7 +38,7 @@ from benchlib.common import (HBM_PEAK_GBS, CLOCK_HZ, F64_MFMA_PEAK_TF, pmc_traff
                              issue_block, settle, timed_passes, cpu_port_info, host_cores, c_port_transforms,
                              cpu_baseline_filter, cpu_baseline_apply)
 from benchlib.workloads import simulate_ungm, simulate_reentry, synthetic_reentry6, FilterBench                        # noqa: E402,F401
-from benchlib.legs import (Mt6Bench, C5GemmBench, measure_c5_unisolvent, measure_c5_degree7, measure_linearize,        # noqa: E402,F401
+from benchlib.legs import (Mt6Bench, Study6Bench, measure_study6, register_kernel_ms, C5GemmBench, measure_c5_unisolvent, measure_c5_degree7, measure_linearize,        # noqa: E402,F401
                            measure_theta_step, filter_leg, saturated_sweep, measure_api_rate, c5_full_record)
 from benchlib.launch import make_comm, final_aggregation, free_port, child_env, needs_launcher, launch_ranks, rank_devices  # noqa: E402,F401
 from benchlib.record import compact_record, result_line, write_detail                                                  # noqa: E402,F401
@@ -254,6 +254,7 @@ def main():
             'ukf_reentry5_gpu_share': filter_leg(amd, 'reentry5', 'ukf', 12500, 50, 35, 0, 0.0,
                                                  'UKF, reentry 5-D + radar, B=12500 (1e5 over 8 GPUs) x T=50', False),
         }
+        out['roofline_c3']['ukf_reentry5_gpu_share']['register_kernel_ms'] = register_kernel_ms(amd, 'reentry5', 'ukf', 12500, 50, 35)
         # BASELINE configs[3]: t-process quadrature Kalman filter, 5-D coordinated turn + four bearing sensors
         out['roofline_c4'] = filter_leg(amd, 'ct', 'tpqkf', 10000, 20, 34, 2000, 3.0,
                                         'TPQ-Kalman (StudentProcessKalman), coordinated turn 5-D + 4 bearings, B=1e4 x T=20',
@@ -263,6 +264,8 @@ def main():
         out['roofline_c5'] = c5_full_record(c5, with_cpu)
         out['roofline_c5']['unisolvent_n21'] = measure_c5_unisolvent(amd)
         out['roofline_c5']['degree7_as_worded'] = measure_c5_degree7(amd, with_cpu=with_cpu)
+    if rank == 0 and single and headline and not args.no_mt6:
+        out['study6'] = measure_study6(amd, B, T)
     if rank == 0 and single and not args.no_mt6:
         out['theta_step'] = measure_theta_step()
         out['roofline_linear'] = measure_linearize()

@@ -429,6 +429,20 @@ class Study6Bench:
             b.free()
 
 
+def measure_study6(amd, B=10000, T=100):
+    """Six configs[1]-sized filters over the same measurements (the loop of the reference's UNGM studies) as one launch."""
+    st = Study6Bench(amd, B, T, seed=1)
+    one = st.time_single(3)                     # the headline filter (GPQKF) alone
+    ser = st.time_serial()
+    mul = st.time_multi()
+    ok = st.check()
+    st.free()
+    return {'filters': st.names, 'mc': B, 'time_steps': T, 'one_pass_ms': one, 'serial_ms': ser, 'multi_ms': mul, 'x_one_pass': mul / one,
+            'serial_x_one_pass': ser / one, 'steps_per_s': len(st.names) * B * T / (mul * 1e-3), 'equal_to_serial_calls': ok,
+            'note': 'ssmq_filter_forward_multi_dev: the six filters of the UNGM family as ONE kernel (k_filter_multi_ungm), device-resident; '
+                    'x_one_pass = time of the six together / time of the GPQ-Kalman pass alone'}
+
+
 class Mt6Bench:
     """Batched GPQ moment transform, D = E = 6, N = 13, B = 1e5, rotating buffer sets (> 256 MB in total so that the
     Infinity Cache cannot hold the working set between launches)."""
@@ -508,6 +522,26 @@ class Mt6Bench:
                         np.max(np.abs(g_cfx[i] - r[2])) / (s * np.sqrt(np.max(np.abs(covs[i])))))
         return float(worst)
 
+
+
+def register_kernel_ms(amd, workload, filt, B, T, seed):
+    """The same device-resident pass with the one-trajectory-per-lane kernel forced (SSMQ_FUSED_QUAD=0, SSMQ_FUSED_WSPLIT=0): what a
+    leg that now takes k_filter_quad / k_filter_wsplit is compared with."""
+    import os
+    old = {k: os.environ.get(k) for k in ('SSMQ_FUSED_QUAD', 'SSMQ_FUSED_WSPLIT')}
+    os.environ['SSMQ_FUSED_QUAD'], os.environ['SSMQ_FUSED_WSPLIT'] = '0', '0'
+    try:
+        wl = FilterBench(amd, B, T, seed, workload, filt)
+        settle(wl.step, wl._lib.sync)
+        ms = timed_passes(wl, 3, 20)
+        wl.free()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return ms
 
 
 def filter_leg(amd, workload, filt, B, T, seed, cpu_sample, cpu_budget, what, with_cpu=True):

@@ -97,6 +97,10 @@ def compact_record(detail):
     leg('c3_ukf6_ms', 'roofline_c3', 'ukf_reentry6', 'ms_per_launch')
     leg('c3_ukf6_frac', 'roofline_c3', 'ukf_reentry6', 'frac')
     leg('c3_ukf5_share_ms', 'roofline_c3', 'ukf_reentry5_gpu_share', 'ms_per_launch')
+    leg('c3_ukf5_share_register_kernel_ms', 'roofline_c3', 'ukf_reentry5_gpu_share', 'register_kernel_ms')
+    leg('study6_steps_per_s', 'study6', 'steps_per_s')
+    leg('study6_x_one_pass', 'study6', 'x_one_pass')
+    leg('study6_serial_x_one_pass', 'study6', 'serial_x_one_pass')
     leg('c4_tpq_ms', 'roofline_c4', 'ms_per_launch')
     leg('c4_tpq_valu_per_wave_step', 'roofline_c4', 'issue', 'valu_instructions_per_wave_per_step')
     leg('c5_gemm_frac', 'roofline_c5', 'frac')

@@ -118,7 +118,7 @@ struct ChunkedEntry {
     SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 0), SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 1, SELO, 0), \
     SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_SIGMA, 0, SELO, 0)
 #define SSMQ_CH_FAST(FD, FO, D, Y, N, SELO)                             \
-    SSMQ_CH(FD, FO, D, Y, N, SELO), SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 3), SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 1, SELO, 2), \
+    SSMQ_CH(FD, FO, D, Y, N, SELO), SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 7), SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 3), SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 1, SELO, 2), \
     SSMQ_CH_ONE(FD, FO, D, Y, N, SSMQ_FORM_SIGMA, 0, SELO, 2)
 const ChunkedEntry kChunked[] = {
     // (NOT the scalar UNGM filters: a 36-register kernel with a dependent chain of 125 instructions per step lives on many waves per

@@ -54,6 +54,7 @@ struct FusedEntry {
 // larger shapes: also with the LDL' / unscented-point fast paths of ssmq_apply_small.h
 #define SSMQ_FUSED_FAST(FD, FO, D, Y, N, SELO)                                 \
     SSMQ_FUSED(FD, FO, D, Y, N, SELO),                                         \
+    SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 0, SELO, 7),              \
     SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 0, SELO, 3),              \
     SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_BQ, 1, SELO, 2),              \
     SSMQ_FUSED_ONE(FD, FO, D, Y, N, N, SSMQ_FORM_SIGMA, 0, SELO, 2)
@@ -473,9 +474,12 @@ int try_launch_fused(const ssmq_transform *hd, const ssmq_integrand *fd, const s
     }
     const int tp = hd->tp_nu > 0.0 ? 1 : 0;
     const int both = hd->opt_mask & ho->opt_mask;
-    const int want[2] = {both & (tp || hd->form == SSMQ_FORM_SIGMA ? SSMQ_OPT_UT : 3), 0};
-    for (int w = 0; w < 2; ++w)
+    // best fast path BOTH handles qualify for: reflection-symmetric weights (7), LDL' + unscented points (3), the dense kernel
+    const int plain = !(tp || hd->form == SSMQ_FORM_SIGMA);
+    const int want[3] = {(plain && (both & 7) == 7) ? 7 : -1, both & (plain ? 3 : SSMQ_OPT_UT), 0};
+    for (int w = 0; w < 3; ++w)
     for (const FusedEntry &e : kFused) {
+        if (want[w] < 0) break;      // (no such variant for these handles: next w)
         if (e.fd == fd->id && e.fo == fo->id && e.D == hd->D && e.Y == ho->E && e.ND == hd->N && e.NO == ho->N &&
             e.form == hd->form && e.tp == tp && e.selo == sel_obs && e.opt == want[w]) {
             const int stu = (d_sscale != nullptr && student_dof > 0.0) ? 1 : 0;

@@ -34,7 +34,7 @@ struct RangeEntry {
     SSMQ_RG_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 0), SSMQ_RG_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 1, SELO, 0), \
     SSMQ_RG_ONE(FD, FO, D, Y, N, SSMQ_FORM_SIGMA, 0, SELO, 0)
 #define SSMQ_RG_FAST(FD, FO, D, Y, N, SELO)                                                                                    \
-    SSMQ_RG(FD, FO, D, Y, N, SELO), SSMQ_RG_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 3), SSMQ_RG_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 1, SELO, 2), \
+    SSMQ_RG(FD, FO, D, Y, N, SELO), SSMQ_RG_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 7), SSMQ_RG_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 0, SELO, 3), SSMQ_RG_ONE(FD, FO, D, Y, N, SSMQ_FORM_BQ, 1, SELO, 2), \
     SSMQ_RG_ONE(FD, FO, D, Y, N, SSMQ_FORM_SIGMA, 0, SELO, 2)
 const RangeEntry kRange[] = {
     // the scalar UNGM filters (BASELINE configs[1] and the six filters of the reference's UNGM studies) ...
@@ -62,9 +62,11 @@ int try_launch_range(const ssmq_transform *hd, const ssmq_integrand *fd, const s
     if (hd->form != ho->form || (hd->tp_nu > 0.0) != (ho->tp_nu > 0.0) || sel_obs < 0 || fd->n_idx > 0) return 0;
     const int tp = hd->tp_nu > 0.0 ? 1 : 0;
     const int both = hd->opt_mask & ho->opt_mask;
-    const int want[2] = {both & (tp || hd->form == SSMQ_FORM_SIGMA ? SSMQ_OPT_UT : 3), 0};
-    for (int w = 0; w < 2; ++w)
+    const int plain = !(tp || hd->form == SSMQ_FORM_SIGMA);
+    const int want[3] = {(plain && (both & 7) == 7) ? 7 : -1, both & (plain ? 3 : SSMQ_OPT_UT), 0};
+    for (int w = 0; w < 3; ++w)
         for (const RangeEntry &e : kRange) {
+            if (want[w] < 0) break;
             if (!(e.fd == fd->id && e.fo == fo->id && e.D == hd->D && e.Y == ho->E && e.ND == hd->N && e.NO == ho->N && e.form == hd->form &&
                   e.tp == tp && e.selo == sel_obs && e.opt == want[w]))
                 continue;

@@ -42,6 +42,22 @@ __device__ __forceinline__ double quad_sum(double v) {
     return v;
 }
 
+// ... for NV values at once: all exchanges of a level first, then its additions - the DPP moves read registers written several
+// instructions earlier (no hazard wait states) and the additions of a level are independent of each other (a lone wave issues a
+// DEPENDENT fp64 operation every ~7 cycles, an independent one every ~5: profiles/r05_lane_prims.txt)
+template <int NV>
+__device__ __forceinline__ void quad_sum_all(double (&v)[NV]) {
+    double t[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) t[i] = quad_perm<0xB1>(v[i]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] += t[i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) t[i] = quad_perm<0x4E>(v[i]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] += t[i];
+}
+
 constexpr int kQuadTraj = 16;     // trajectories per wave
 
 // One moment transform in the centred form on unscented points, the N = 2 DI + 1 points dealt to the quad's lanes.
@@ -87,8 +103,9 @@ __device__ __forceinline__ void quad_transform(const double (&m)[DI], const doub
         double p = fx[0][e] * wm[0];
 #pragma unroll
         for (int s = 1; s < S; ++s) p = fma(fx[s][e], wm[s], p);
-        mf[e] = quad_sum(p);
+        mf[e] = p;
     }
+    quad_sum_all<E>(mf);
     // centred, weighted
     double fw[S][E];
 #pragma unroll
@@ -98,6 +115,9 @@ __device__ __forceinline__ void quad_transform(const double (&m)[DI], const doub
             fx[s][e] -= mf[e];
             fw[s][e] = fx[s][e] * wc[s];
         }
+    // covariance and cross-covariance: the partial sums of every entry, one all-reduce for all of them
+    constexpr int NC = E * (E + 1) / 2, NX = CROSS ? E * DI : 0;
+    double red[NC + NX];
 #pragma unroll
     for (int e = 0; e < E; ++e)
 #pragma unroll
@@ -105,7 +125,7 @@ __device__ __forceinline__ void quad_transform(const double (&m)[DI], const doub
             double p = fw[0][e] * fx[0][e2];
 #pragma unroll
             for (int s = 1; s < S; ++s) p = fma(fw[s][e], fx[s][e2], p);
-            cv[SSMQ_PK(e, e2)] = quad_sum(p) + cadd[e * E + e2];
+            red[SSMQ_PK(e, e2)] = p;
         }
     if (CROSS) {
 #pragma unroll
@@ -115,8 +135,19 @@ __device__ __forceinline__ void quad_transform(const double (&m)[DI], const doub
                 double p = fw[0][e] * dx[0][d];
 #pragma unroll
                 for (int s = 1; s < S; ++s) p = fma(fw[s][e], dx[s][d], p);
-                cx[e][d] = quad_sum(p);
+                red[NC + e * DI + d] = p;
             }
+    }
+    quad_sum_all<NC + NX>(red);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int e2 = 0; e2 <= e; ++e2) cv[SSMQ_PK(e, e2)] = red[SSMQ_PK(e, e2)] + cadd[e * E + e2];
+    if (CROSS) {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int d = 0; d < DI; ++d) cx[e][d] = red[NC + e * DI + d];
     }
 }
 
@@ -165,11 +196,10 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_filter_quad(const FusedArgs 
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) Pl[SSMQ_PK(i, j)] = a.P0[(i * D + j) * ld + bb];
-    FPar fd = a.fd, fo = a.fo;
-    constexpr bool kTTd = HasTimeTable<FD>::value, kTTo = HasTimeTable<FO>::value;
-    const cdouble_p ttd = (cdouble_p)a.fd.ttab, tto = (cdouble_p)a.fo.ttab;
-    if constexpr (kTTd) fd.use_tval = 1;
-    if constexpr (kTTo) fo.use_tval = 1;
+    // (none of the instantiated models has a per-step time table: their integrand constants are read from the kernel arguments
+    // where they are used - copies held across the loop cost 60 spilled scalar registers)
+    static_assert(!HasTimeTable<FD>::value && !HasTimeTable<FO>::value, "k_filter_quad: time-table integrands are not wired");
+    const FPar &fd = a.fd, &fo = a.fo;
     const cdouble_p gqg = (cdouble_p)a.gqg, rr = (cdouble_p)a.rr;
     const double nan = __builtin_nan("");
     int32_t agg = 0;
@@ -187,8 +217,6 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_filter_quad(const FusedArgs 
 #pragma unroll
             for (int i = 0; i < Y; ++i) ynext[i] = a.y[((int64_t)kn * Y + i) * ld + bb];
         }
-        if constexpr (kTTd) fd.tval = ttd[k];
-        if constexpr (kTTo) fo.tval = tto[k];
         // G Q G' / R are re-read from the scalar cache in the step that adds them: hoisted out of the loop their D^2 + Y^2 values
         // overflow the scalar registers and come back as ~100 v_readlane per step
         const cdouble_p gqg_k = launder(gqg), rr_k = launder(rr);
@@ -310,6 +338,7 @@ int try_launch_quad(const ssmq_transform *hd, const ssmq_integrand *fd, const ss
     const char *ev = ssmq::sw("SSMQ_FUSED_QUAD");
     const int force = ev ? atoi(ev) : -1;
     if (force == 0 || d_sscale || student_dof > 0.0 || B <= 0) return 0;
+    if (!dry_run && ctx().no_strips) return 0;       // a job of a multi-filter launch shares the chip: whole-pass kernels only
     if (force != 1 && ssmq::sw("SSMQ_FUSED_WSPLIT")) return 0;          // a forced wave-split mode (0 = the register kernel) is what runs
     if (hd->form != SSMQ_FORM_SIGMA || ho->form != SSMQ_FORM_SIGMA || hd->tp_nu > 0.0 || ho->tp_nu > 0.0 || sel_obs < 0 || fd->n_idx > 0) return 0;
     if (!(hd->opt_mask & ho->opt_mask & SSMQ_OPT_UT)) return 0;          // unscented-type points [0 | c I | -c I], verified on the host
