@@ -86,17 +86,58 @@ def cpu_port_info():
     return dict(_CPU_PORT)
 
 
+def cgroup_cpu_share():
+    """CPUs this process is ALLOWED to use at once when a cgroup quota is set (cpu.max / cfs_quota_us), else None: a GPU box shows
+    256 hardware threads in its affinity mask and grants a one-GPU job 16 of them."""
+    for path, parse in (('/sys/fs/cgroup/cpu.max', lambda t: (t.split()[0], t.split()[1])),):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != 'max' and float(period) > 0:
+                return max(1, int(round(float(quota) / float(period))))
+        except (OSError, ValueError, IndexError):
+            pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        p = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0 and p > 0:
+            return max(1, int(round(q / p)))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def host_cores(max_threads=None):
-    """Host threads the CPU baseline uses: ALL the cores this process may run on ("all host cores"; rounds 1-5
-    capped this at 16, which understated the baseline on the 64-core boxes).  The record carries the count as `cores`."""
+    """Host threads the CPU baseline may use: ALL the cores this process may run on ("all host cores") - the
+    affinity mask, cut to the cgroup's CPU quota where there is one.  Rounds 1-5 capped this at 16 outright; with no cap at all
+    the port ran its OpenMP loop on 256 threads inside a 16-CPU quota and came out TEN TIMES slower (5.9e6 against 6.0e7 filter
+    steps/s, round 6) - so where no quota can be read, `cpu_threads_for()` times both candidates and keeps the faster."""
     from oracle import c_oracle as co
     cpu_port_info()
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    share = cgroup_cpu_share()
+    if share:
+        cores = min(cores, share)
     cores = min(cores, co.max_threads())
     return min(cores, max_threads) if max_threads else cores
+
+
+def cpu_threads_for(run):
+    """Thread count for a CPU-baseline leg: `run(threads)` executes one pass.  With a readable cgroup quota: host_cores().  Without
+    one, the faster of {16, every core of the affinity mask} on a single probe pass each - the record's `cores` is what was used."""
+    cores = host_cores()
+    if cgroup_cpu_share() or cores <= 16:
+        return cores
+    best, best_t = cores, None
+    for n in (16, cores):
+        t0 = time.perf_counter()
+        run(n)
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best, best_t = n, dt
+    return best
 
 
 def c_port_transforms(wl):
@@ -127,10 +168,10 @@ def cpu_baseline_filter(wl, B_sample, budget_s, what):
     the first B_sample trajectories of the device run, repeated for ~budget_s.  Returns (record, fm (D, T, b), status)."""
     from oracle import c_oracle as co
     (td, k1), (to, k2) = c_port_transforms(wl)
-    cores = host_cores()
     T = wl.T
     yb = np.ascontiguousarray(wl.y_host[:, :, :B_sample].transpose(2, 1, 0))
     GQG = wl.alg.G.dot(wl.alg.q_cov).dot(wl.alg.G.T)
+    cores = cpu_threads_for(lambda n: co.filter_forward(td, to, yb, wl.m0, wl.P0, GQG, wl.alg.r_cov, threads=n))
     t0 = time.perf_counter()
     fm, fP, st = co.filter_forward(td, to, yb, wl.m0, wl.P0, GQG, wl.alg.r_cov, threads=cores)
     dt = time.perf_counter() - t0
@@ -149,11 +190,11 @@ def cpu_baseline_filter(wl, B_sample, budget_s, what):
 def cpu_baseline_apply(tf, integ_id, integ_par, D, E, means, covs, budget_s, what):
     """One batched moment transform in the C oracle (same weights as the device handle), on the host cores."""
     from oracle import c_oracle as co
-    cores = host_cores()
     mv = tf.model.model_var
     emv = (np.asarray(mv, dtype=float) * np.ones((E, E))) if np.ndim(mv) == 0 else np.asarray(mv, dtype=float)
     t, keep = co.make_transform(0, D, E, tf.model.points, tf.wm, tf.Wc, tf.Wcc, emv,
                                 integrand=co.Integrand.make(integ_id, integ_par))
+    cores = cpu_threads_for(lambda n: co.apply_batch(t, means, covs, 0.0, threads=n))
     t0 = time.perf_counter()
     co.apply_batch(t, means, covs, 0.0, threads=cores)
     dt = time.perf_counter() - t0
