@@ -64,9 +64,6 @@ static bool HasTimeTableRT(int fid) { return fid == SSMQ_F_UNGM_DYN || fid == SS
 static const FusedEntry kFused[] = {
     SSMQ_FUSED_S(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 2),
     SSMQ_FUSED_S(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 3),
-    // ... and the headline filter (GPQ / Bayes-Sard weights on the three unscented points of a scalar state) with the
-    // reflection-symmetric weights (SSMQ_OPT_SYM): ~10 of the step's 125 instructions fewer on its dependent chain
-    SSMQ_FUSED_ONE_S(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 3, SSMQ_FORM_BQ, 0, 0, 7),
     SSMQ_FUSED_S(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 5),
 #ifndef SSMQ_FUSED_UNGM_ONLY   // tools/build_variant.sh: quick builds for A/B timing of the UNGM kernels
     SSMQ_FUSED(SSMQ_F_PENDULUM_DYN, SSMQ_F_PENDULUM_MEAS, 2, 1, 5, 0),
@@ -114,7 +111,7 @@ static_assert(sizeof(MultiKernArgs) <= 4096, "kernel-argument segment");
 // spilled 500 SGPRs (to vector-register lanes, read back inside the loops); as functions each has the allocation of its own
 // whole-pass kernel.  The job record is read through the constant address space (scalar loads).
 typedef const __attribute__((address_space(4))) MultiJob *multi_job_p;
-template <int N, int FORM, int TP, int OPT = 0>
+template <int N, int FORM, int TP>
 __device__ __attribute__((noinline)) void multi_case(multi_job_p q, uint32_t blk) {
     FusedArgs a;
     a.y = q->y; a.m0 = q->m0; a.P0 = q->P0; a.fm = q->fm; a.fP = q->fP; a.status = q->status;
@@ -125,7 +122,7 @@ __device__ __attribute__((noinline)) void multi_case(multi_job_p q, uint32_t blk
     a.fd.ttab = q->ttd; a.fd.tval = 0.0; a.fd.use_tval = 0;
     a.fo.ttab = q->tto; a.fo.tval = 0.0; a.fo.use_tval = 0;
     a.t_chunk = a.n_blocks = 0; a.queue = nullptr; a.hand = nullptr;
-    fused_pass<1, 1, N, N, SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, FORM, TP, 0, OPT, 0, false>(a, blk, 0, a.T, true, true);
+    fused_pass<1, 1, N, N, SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, FORM, TP, 0, 0, 0, false>(a, blk, 0, a.T, true, true);
 }
 
 __global__ __launch_bounds__(kSmallBlock, 2) void k_filter_multi_ungm(const MultiKernArgs) {
@@ -145,7 +142,6 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_filter_multi_ungm(const Mult
         case 6: multi_case<5, SSMQ_FORM_BQ, 0>(q, blk); break;
         case 7: multi_case<5, SSMQ_FORM_BQ, 1>(q, blk); break;
         case 8: multi_case<5, SSMQ_FORM_SIGMA, 0>(q, blk); break;
-        case 9: multi_case<3, SSMQ_FORM_BQ, 0, 7>(q, blk); break;
         default: break;
     }
 }
@@ -171,8 +167,6 @@ int multi_family_table(int n, const ssmq_transform *const *hd, const ssmq_integr
         q.y = a.y; q.m0 = a.m0; q.P0 = a.P0; q.c_dyn = a.c_dyn; q.c_obs = a.c_obs; q.gqg = a.gqg; q.rr = a.rr; q.ttd = a.fd.ttab; q.tto = a.fo.ttab;
         q.fm = a.fm; q.fP = a.fP; q.status = a.status; q.B = a.B; q.ld = a.ld; q.T = a.T; q.emv_dyn = a.emv_dyn; q.emv_obs = a.emv_obs;
         q.kind = 3 * in + (hd[i]->form == SSMQ_FORM_SIGMA ? 2 : (hd[i]->tp_nu > 0.0 ? 1 : 0));
-        // (the variant k_filter_fused picks for this pair of handles: the same bits)
-        if (q.kind == 3 && (hd[i]->opt_mask & ho[i]->opt_mask & 7) == 7) q.kind = 9;
         q.nu_dyn = a.nu_dyn; q.nu_obs = a.nu_obs;
         q.first = (int32_t)first;
         first += (a.B + 63) / 64;

@@ -39,7 +39,7 @@ struct RangeEntry {
 const RangeEntry kRange[] = {
     // the scalar UNGM filters (BASELINE configs[1] and the six filters of the reference's UNGM studies) ...
     SSMQ_RG(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 2, 0),
-    SSMQ_RG(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 0), SSMQ_RG_ONE(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, SSMQ_FORM_BQ, 0, 0, 7),
+    SSMQ_RG(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 3, 0),
     SSMQ_RG(SSMQ_F_UNGM_DYN, SSMQ_F_UNGM_MEAS, 1, 1, 5, 0),
     // ... and the reentry / coordinated-turn shapes of configs[2] and configs[3] with unscented points
     SSMQ_RG_FAST(SSMQ_F_REENTRY2D_DYN, SSMQ_F_RADAR2D_MEAS, 5, 2, 11, 0),
