@@ -2350,7 +2350,12 @@ extern "C" int ssmq_filter_forward_piped(ssmq_transform *h_dyn, const ssmq_integ
     const size_t n_y = (size_t)T * Y * ld, n_m = (size_t)D * ld, n_P = (size_t)D * D * ld, n_fm = (size_t)T * D * ld, n_fP = (size_t)T * D * D * ld;
     const size_t n_c = ((size_t)D * D + (size_t)Y * Y + 2 * (size_t)T + 7) / 8 * 8, n_hand = (size_t)nblk * range_hand_doubles(D);
     const size_t d_dbl = n_y + n_m + n_P + n_fm + n_fP + n_c + n_hand;
-    const size_t hin_dbl = n_y + n_m + n_P + n_c, hout_dbl = (out_pinned ? 0 : n_fm + n_fP);
+    // pageable results are staged block by block through TWO slots (block k + 1 lands while block k - 1's slot is free again)
+    auto t_of = [&](int k) { return (int)((int64_t)T * k / K); };
+    size_t blk_steps = 0;
+    for (int k = 0; k < K; ++k) blk_steps = std::max<size_t>(blk_steps, (size_t)(t_of(k + 1) - t_of(k)));
+    const size_t slot_dbl = blk_steps * ((size_t)D + (size_t)D * D) * ld;
+    const size_t hin_dbl = n_y + n_m + n_P + n_c, hout_dbl = (out_pinned ? 0 : 2 * slot_dbl);
     // (the staging arena may be resized: nothing of an earlier call is in flight - every call ends with its last copy complete)
     if ((rc = g_stage.reserve(sizeof(double) * d_dbl + sizeof(int32_t) * ld, sizeof(double) * hin_dbl, sizeof(double) * hout_dbl + sizeof(int32_t) * ld)))
         return rc;
@@ -2365,7 +2370,7 @@ extern "C" int ssmq_filter_forward_piped(ssmq_transform *h_dyn, const ssmq_integ
     int32_t *d_st = (int32_t *)dv;
     double *hin = (double *)g_stage.hin;
     double *h_y = hin, *h_m0 = hin + n_y, *h_P0 = h_m0 + n_m, *h_c = h_P0 + n_P;
-    double *h_fm = (double *)g_stage.hout, *h_fP = h_fm + (out_pinned ? 0 : n_fm);
+    double *h_out = (double *)g_stage.hout;       // [2][slot_dbl]: a block's means, then its covariances
     int32_t *h_st = (int32_t *)((double *)g_stage.hout + hout_dbl);
     // ---- constants and initial moments, then the first block of measurements: one transfer ------------------------------------
     double *c_gqg = h_c, *c_rr = c_gqg + D * D, *c_ttd = c_rr + Y * Y, *c_tto = c_ttd + T;
@@ -2383,13 +2388,13 @@ extern "C" int ssmq_filter_forward_piped(ssmq_transform *h_dyn, const ssmq_integ
     }
     SSMQ_HIP(hipMemcpyAsync(d_m0, h_m0, sizeof(double) * (n_m + n_P + n_c), hipMemcpyHostToDevice, pc.s_in));      // m0 | P0 | consts are adjacent
     const double *dc_gqg = d_c, *dc_rr = d_c + D * D, *dc_ttd = has_td ? d_c + D * D + Y * Y : nullptr, *dc_tto = has_to ? d_c + D * D + Y * Y + T : nullptr;
-    auto t_of = [&](int k) { return (int)((int64_t)T * k / K); };
     auto drain = [&](int k) -> int {        // block k's outputs are in host memory: bring them into the caller's arrays if staged
         SSMQ_HIP(hipEventSynchronize(pc.ev_out[k]));
         if (!out_pinned) {
             const int kb = t_of(k), ke = t_of(k + 1);
-            copy_rows_pool(false, fm, h_fm + (size_t)kb * D * ld, kb, ke, T, D, B, ld);
-            copy_rows_pool(false, fP, h_fP + (size_t)kb * D * D * ld, kb, ke, T, D * D, B, ld);
+            double *slot = h_out + (size_t)(k & 1) * slot_dbl;
+            copy_rows_pool(false, fm, slot, kb, ke, T, D, B, ld);
+            copy_rows_pool(false, fP, slot + (size_t)(ke - kb) * D * ld, kb, ke, T, D * D, B, ld);
         }
         return SSMQ_OK;
     };
@@ -2413,8 +2418,9 @@ extern "C" int ssmq_filter_forward_piped(ssmq_transform *h_dyn, const ssmq_integ
                 SSMQ_HIP(hipMemcpy2DAsync(fP + ((size_t)e * T + kb) * B, sizeof(double) * B, d_fP + ((size_t)kb * D * D + e) * ld,
                                           sizeof(double) * D * D * ld, sizeof(double) * B, ke - kb, hipMemcpyDeviceToHost, pc.s_out));
         } else {
-            SSMQ_HIP(hipMemcpyAsync(h_fm + (size_t)kb * D * ld, d_fm + (size_t)kb * D * ld, sizeof(double) * (size_t)(ke - kb) * D * ld, hipMemcpyDeviceToHost, pc.s_out));
-            SSMQ_HIP(hipMemcpyAsync(h_fP + (size_t)kb * D * D * ld, d_fP + (size_t)kb * D * D * ld, sizeof(double) * (size_t)(ke - kb) * D * D * ld,
+            double *slot = h_out + (size_t)(k & 1) * slot_dbl;
+            SSMQ_HIP(hipMemcpyAsync(slot, d_fm + (size_t)kb * D * ld, sizeof(double) * (size_t)(ke - kb) * D * ld, hipMemcpyDeviceToHost, pc.s_out));
+            SSMQ_HIP(hipMemcpyAsync(slot + (size_t)(ke - kb) * D * ld, d_fP + (size_t)kb * D * D * ld, sizeof(double) * (size_t)(ke - kb) * D * D * ld,
                                     hipMemcpyDeviceToHost, pc.s_out));
         }
         if (k == K - 1) SSMQ_HIP(hipMemcpyAsync(h_st, d_st, sizeof(int32_t) * ld, hipMemcpyDeviceToHost, pc.s_out));

@@ -3461,6 +3461,8 @@ def test_quad_filters_match_oracle_and_register_kernel(amd, monkeypatch):
     trajectories at the same step, the default choice, and device-resident repeats bitwise equal."""
     from oracle import c_oracle as co
     from ssmtoybox_amd import ssinf, ssmod as sm
+    if 'SSMQ_NO_FASTPATH' in os.environ or 'SSMQ_NO_FUSED' in os.environ:
+        pytest.skip('k_filter_quad is offered for point sets the host verified as unscented-type (SSMQ_OPT_UT) only')
     flt = _wsplit_filters(61)
     cases = [flt[0], flt[2]]                      # UKF on the 5-D reentry model and on the 6-D variant
     # + the unscented filter on the coordinated-turn model with four bearing sensors (measurements of the t-process case)
@@ -3752,7 +3754,7 @@ def test_wsplit_default_choice_and_failures(amd, monkeypatch):
     # (the wave split is not for the unscented reentry filter; at 1e5 trajectories - 1 563 blocks on 1 024 SIMDs - the five- and
     # six-state time loops run as equal strips of block-steps, csrc/ssmq_filter_chunked.hip, below the SIMD count as whole passes)
     # (... and below 16 384 trajectories - every whole-pass wave alone on a SIMD - with a trajectory on four lanes, ssmq_filter_quad.hip)
-    if 'SSMQ_FUSED_QUAD' not in os.environ:
+    if 'SSMQ_FUSED_QUAD' not in os.environ and 'SSMQ_NO_FASTPATH' not in os.environ:      # (the quad kernel needs the verified unscented point set)
         assert 'k_filter_quad<' in ukf.kernel_name(200) and 'k_filter_quad<' in ukf.kernel_name(12500) and 'k_filter_fused<' in ukf.kernel_name(20000)
     assert 'k_filter_fused<' in ukf.kernel_name(60000)
     if 'SSMQ_FUSED_CHUNKED' not in os.environ:           # (tools/alt_paths.sh runs the suite with the choice forced either way)

@@ -37,6 +37,24 @@ def test_integrand_struct_layout():
         _lib.Integrand.make(1, range(17))
 
 
+def test_round6_entry_points_without_a_device():
+    """The round-6 entry points (ABI 102) on a host without a GPU: the job struct has the header's layout, argument errors are
+    argument errors, and anything that needs the device fails loudly (SSMQ_E_HIP) - there is no CPU path behind the ABI."""
+    import ssmtoybox_amd as amd
+    from ssmtoybox_amd import _lib
+    lib = _lib.load()
+    # struct ssmq_filter_job: 4 pointers, 2 int64, 2 int32, 3 + 2 + 2 + 1 + 1 pointers, 1 double
+    assert ctypes.sizeof(_lib.FilterJob) == 4 * 8 + 2 * 8 + 2 * 4 + 9 * 8 + 8
+    assert lib.ssmq_filter_forward_multi_dev(0, None) == 0
+    assert lib.ssmq_filter_forward_multi_dev(-1, None) == -1 and lib.ssmq_filter_forward_multi_dev(65, (_lib.FilterJob * 65)()) == -1
+    assert lib.ssmq_filter_forward_multi_dev(1, (_lib.FilterJob * 1)()) == -1            # null handles
+    assert lib.ssmq_filter_forward_piped(None, None, None, None, 1, 1, None, None, None, None, None, None, None, None, 0, 0) == -1
+    assert lib.ssmq_pinned_is_block(ctypes.c_void_p(12345)) == 0 and lib.ssmq_pinned_free(None) == 0
+    if amd.device_count() == 0:
+        p = ctypes.c_void_p()
+        assert lib.ssmq_pinned_alloc(ctypes.c_size_t(64), ctypes.byref(p)) == -2 and not p.value      # SSMQ_E_HIP
+
+
 def test_integrand_ids_match_oracle_numbering():
     from ssmtoybox_amd import _lib
     for name in dir(orc):
