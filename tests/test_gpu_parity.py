@@ -858,7 +858,13 @@ def test_fused_filter_matches_unfused_loop(amd, golden, monkeypatch):
     obs = sm.Radar2DMeasurement(sm.GaussRV(2, cov=g['rer_R']), 5)
     alg = ssinf.UnscentedKalman(dyn, obs)
     assert 'k_filter_fused<D=5,Y=2' in alg.kernel_name()
+    had_quad = os.environ.get('SSMQ_FUSED_QUAD')
+    monkeypatch.setenv('SSMQ_FUSED_QUAD', '0')          # the register kernel (a batch this small would take k_filter_quad: other summation order)
     fm, fP = alg.forward_pass_batch(y)
+    if had_quad is None:
+        monkeypatch.delenv('SSMQ_FUSED_QUAD')
+    else:
+        monkeypatch.setenv('SSMQ_FUSED_QUAD', had_quad)
     monkeypatch.setenv('SSMQ_NO_FUSED', '1')
     fm2, fP2 = alg.forward_pass_batch(y)
     monkeypatch.delenv('SSMQ_NO_FUSED')
@@ -1861,6 +1867,8 @@ def test_fast_paths_match_dense(amd, monkeypatch):
              (lambda: amd.GaussianProcessTransform(5, 2, gp_par(5, 3.0)), h5, 5, 'OPT=7'),
              (lambda: amd.GaussianProcessTransform(5, 5, gp_par(5, 3.0), 'rbf', 'sr'), f5, 5, 'OPT=0')]
     for make, f, d, tag in cases:
+        if tag == 'OPT=7' and 'SSMQ_NO_SYM' in os.environ:         # (tools/alt_paths.sh)
+            tag = 'OPT=3'
         monkeypatch.delenv('SSMQ_NO_FASTPATH', raising=False)
         tf = make()
         assert tag in tf.kernel_name(f), tf.kernel_name(f)
@@ -3495,7 +3503,8 @@ def test_quad_filters_match_oracle_and_register_kernel(amd, monkeypatch):
                                '%s, quad vs the register kernel' % name, tol_m, tol_P)
         assert np.array_equal(runs['1x'][2], runs['0x'][2]) and runs['1x'][2][7] == 1 and np.isnan(runs['1x'][0][:, :, 7]).all()
         # the default for a batch this small is the quad kernel; a second pass replays nothing stale
-        assert 'k_filter_quad<' in alg.kernel_name(B) and 'k_filter_quad<' in alg.kernel_name(12500) and 'k_filter_quad<' not in alg.kernel_name(20000)
+        if 'SSMQ_FUSED_WSPLIT' not in os.environ:       # (a forced wave-split mode keeps its meaning: tools/alt_paths.sh)
+            assert 'k_filter_quad<' in alg.kernel_name(B) and 'k_filter_quad<' in alg.kernel_name(12500) and 'k_filter_quad<' not in alg.kernel_name(20000)
         monkeypatch.setenv('SSMQ_FUSED_QUAD', '1')
         fm2, fP2 = alg.forward_pass_batch(y, raise_on_failure=False)
         monkeypatch.delenv('SSMQ_FUSED_QUAD')
@@ -3595,7 +3604,13 @@ def test_run_filters_is_the_serial_calls_bit_for_bit(amd, monkeypatch):
         b.tf_dyn.model.model_var = 2e-6 * np.eye(5)
         b.tf_obs.model.model_var = 0 * np.eye(2)
         return [ssinf.UnscentedKalman(dyn5, obs5), ssinf.CubatureKalman(dyn5, obs5), b]
+    had_quad = os.environ.get('SSMQ_FUSED_QUAD')
+    monkeypatch.setenv('SSMQ_FUSED_QUAD', '0')          # (the jobs of a multi-launch are whole-pass kernels; so is the serial reference)
     serial = [a.forward_pass_batch(y5, raise_on_failure=False) for a in make5()]
+    if had_quad is None:
+        monkeypatch.delenv('SSMQ_FUSED_QUAD')
+    else:
+        monkeypatch.setenv('SSMQ_FUSED_QUAD', had_quad)
     got = ssinf.run_filters(make5(), y5, raise_on_failure=False)
     for g, s in zip(got, serial):
         assert np.array_equal(g[0], s[0], equal_nan=True) and np.array_equal(g[1], s[1], equal_nan=True)
@@ -3625,6 +3640,8 @@ def test_piped_forward_pass_is_the_plain_one_bit_for_bit(amd, monkeypatch):
     from ssmtoybox_amd import ssinf, ssmod as sm, _lib
     from bench import simulate_ungm, simulate_reentry
     lib = _lib.load()
+    # tools/alt_paths.sh runs the suite with routes forced through the environment: a forced route is not pipelined
+    piped = 0 if any(k in os.environ for k in ('SSMQ_NO_FUSED', 'SSMQ_FUSED_WSPLIT', 'SSMQ_FUSED_QUAD', 'SSMQ_FUSED_CHUNKED', 'SSMQ_FUSED_LPW')) else 1
     B, T = 5000, 37
     _, y = simulate_ungm(B, T, 3)
     y = np.ascontiguousarray(y[None])
@@ -3645,7 +3662,7 @@ def test_piped_forward_pass_is_the_plain_one_bit_for_bit(amd, monkeypatch):
         a1 = make()
         got = a1.forward_pass_batch(y)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and not a1.status.any()
-        assert lib.ssmq_pinned_is_block(ctypes.c_void_p(got[0].ctypes.data)) == 1          # (the pipelined route was taken)
+        assert lib.ssmq_pinned_is_block(ctypes.c_void_p(got[0].ctypes.data)) == piped      # (the pipelined route was taken)
         got[0][0, 0, 0] += 1.0                                      # writable, the caller's own (ssinf.py:279 mutates its results)
         got_x = a1.forward_pass_batch(y, x0m, x0c, raise_on_failure=False)
         assert np.array_equal(got_x[0], ref_x[0], equal_nan=True) and np.array_equal(got_x[1], ref_x[1], equal_nan=True)
@@ -3667,21 +3684,29 @@ def test_piped_forward_pass_is_the_plain_one_bit_for_bit(amd, monkeypatch):
                                            ctypes.c_void_p(alg.tf_obs._handle_for(e_obs)), ctypes.byref(f_obs), B, T, dp(y), dp(np.zeros(1)),
                                            dp(np.ones((1, 1))), dp(np.array([[10.0]])), dp(np.ones((1, 1))), ctypes.c_void_p(fm.ctypes.data),
                                            ctypes.c_void_p(fP.ctypes.data), ctypes.c_void_p(st.ctypes.data), 0, K)
+        if not piped:
+            assert rc == -3
+            continue
         assert rc == 0 and np.array_equal(fm, ref[0]) and np.array_equal(fP, ref[1]) and not st.any(), K
     # a 5-D filter (42 strided copies per block) and a shape without a time-block kernel (falls back, same call)
     Br, Tr = 3000, 20
     x5, y5, m5, P5, Q5, G5, R5 = simulate_reentry(Br, Tr, 8, False)
     dyn5 = sm.ReentryVehicle2DTransition(sm.GaussRV(5, m5, P5), sm.GaussRV(3, cov=Q5))
     obs5 = sm.Radar2DMeasurement(sm.GaussRV(2, cov=R5), 5)
+    had_quad = os.environ.get('SSMQ_FUSED_QUAD')
     monkeypatch.setenv('SSMQ_NO_PIPED', '1')
     monkeypatch.setenv('SSMQ_FUSED_QUAD', '0')          # (device-resident batches this small take k_filter_quad: rounding-level differences)
     ref = ssinf.UnscentedKalman(dyn5, obs5).forward_pass_batch(y5)
     refg = ssinf.GaussHermiteKalman(dyn, obs, deg=7).forward_pass_batch(y)
     monkeypatch.delenv('SSMQ_NO_PIPED')
-    monkeypatch.delenv('SSMQ_FUSED_QUAD')
+    if had_quad is None:
+        monkeypatch.delenv('SSMQ_FUSED_QUAD')
+    else:
+        monkeypatch.setenv('SSMQ_FUSED_QUAD', had_quad)
     got = ssinf.UnscentedKalman(dyn5, obs5).forward_pass_batch(y5)
-    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
-    assert lib.ssmq_pinned_is_block(ctypes.c_void_p(got[0].ctypes.data)) == 1
+    if piped:
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert lib.ssmq_pinned_is_block(ctypes.c_void_p(got[0].ctypes.data)) == piped
     gotg = ssinf.GaussHermiteKalman(dyn, obs, deg=7).forward_pass_batch(y)
     assert np.array_equal(gotg[0], refg[0]) and lib.ssmq_pinned_is_block(ctypes.c_void_p(gotg[0].ctypes.data)) == 0
 
@@ -3755,7 +3780,8 @@ def test_wsplit_default_choice_and_failures(amd, monkeypatch):
     # six-state time loops run as equal strips of block-steps, csrc/ssmq_filter_chunked.hip, below the SIMD count as whole passes)
     # (... and below 16 384 trajectories - every whole-pass wave alone on a SIMD - with a trajectory on four lanes, ssmq_filter_quad.hip)
     if 'SSMQ_FUSED_QUAD' not in os.environ and 'SSMQ_NO_FASTPATH' not in os.environ:      # (the quad kernel needs the verified unscented point set)
-        assert 'k_filter_quad<' in ukf.kernel_name(200) and 'k_filter_quad<' in ukf.kernel_name(12500) and 'k_filter_fused<' in ukf.kernel_name(20000)
+        assert 'k_filter_quad<' in ukf.kernel_name(200) and 'k_filter_quad<' in ukf.kernel_name(12500)
+        assert 'SSMQ_FUSED_CHUNKED' in os.environ or 'k_filter_fused<' in ukf.kernel_name(20000)
     assert 'k_filter_fused<' in ukf.kernel_name(60000)
     if 'SSMQ_FUSED_CHUNKED' not in os.environ:           # (tools/alt_paths.sh runs the suite with the choice forced either way)
         assert 'k_filter_chunked<' in ukf.kernel_name(100000)
@@ -3894,7 +3920,7 @@ def test_marginal_filter_failures_are_the_reference_s_linalg_errors(amd, golden)
     failed, reason = alg.batch_failed, alg.batch_failed_reason
     idx = np.flatnonzero(failed)
     print('failed trajectories', idx.tolist(), 'at steps', failed[idx].tolist(), 'reasons', reason[idx].tolist())
-    assert 1 <= idx.size <= 12                              # a handful of 1 024 (bench.py reports the count)
+    assert 1 <= idx.size <= 8                               # what is measured: 6 of 1 024 on this batch in every run since round 5 (bench.py: legs.marginal_failed)
     for b in idx:
         k = int(failed[b])
         assert np.all(np.isfinite(fm[:, :k - 1, b])) and np.all(np.isnan(fm[:, k - 1:, b]))
