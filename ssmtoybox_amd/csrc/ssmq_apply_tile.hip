@@ -35,6 +35,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #ifndef SSMQ_TILE_LATE_FETCH
 #define SSMQ_TILE_LATE_FETCH 1      // round 5: 0.2507 -> 0.2385 ms (D = E = 10, N = 21, B = 1e5; tools/tile_ab.sh)
 #endif
+#ifndef SSMQ_TILE_PAD_TRAJ
+#define SSMQ_TILE_PAD_TRAJ 0        // A/B builds (tools/tile_variants.sh): extra doubles per trajectory part / per wave slice - moves the
+#endif                              // LDS banks the trajectories of a workgroup start on (step 4 reads 12 of them per instruction)
+#ifndef SSMQ_TILE_PAD_WAVE
+#define SSMQ_TILE_PAD_WAVE 0
+#endif
 constexpr int kTileWaves = 4;
 
 struct TileGeom {
@@ -68,7 +74,8 @@ __host__ __device__ inline TileGeom tile_geom(int D, int E, int N, bool tp, bool
     g.out_off = g.in_doubles;
     g.per_traj = g.in_doubles + E + E * E + E * D;
 #endif
-    g.wave_doubles = g.G * g.per_traj + 2 + 64 + 16;   // per trajectory: factor + mean + FX tile; status words, column slots
+    g.per_traj += SSMQ_TILE_PAD_TRAJ;
+    g.wave_doubles = g.G * g.per_traj + 2 + 64 + 16 + SSMQ_TILE_PAD_WAVE;   // per trajectory: factor + mean + FX tile; status words, column slots
     g.wave_doubles = (g.wave_doubles + 1) & ~1;
     return g;
 }

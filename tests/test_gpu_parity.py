@@ -3782,7 +3782,7 @@ def test_wsplit_default_choice_and_failures(amd, monkeypatch):
     if 'SSMQ_FUSED_QUAD' not in os.environ and 'SSMQ_NO_FASTPATH' not in os.environ:      # (the quad kernel needs the verified unscented point set)
         assert 'k_filter_quad<' in ukf.kernel_name(200) and 'k_filter_quad<' in ukf.kernel_name(12500)
         assert 'SSMQ_FUSED_CHUNKED' in os.environ or 'k_filter_fused<' in ukf.kernel_name(20000)
-    assert 'k_filter_fused<' in ukf.kernel_name(60000)
+    assert 'SSMQ_FUSED_CHUNKED' in os.environ or 'k_filter_fused<' in ukf.kernel_name(60000)
     if 'SSMQ_FUSED_CHUNKED' not in os.environ:           # (tools/alt_paths.sh runs the suite with the choice forced either way)
         assert 'k_filter_chunked<' in ukf.kernel_name(100000)
     assert 'k_filter_wsplit' in tpq.kernel_name(10000) and 'W=2>' in tpq.kernel_name(10000)
