@@ -49,7 +49,7 @@ def main():
     import datetime
     out['_collected'] = datetime.datetime.utcnow().strftime('%Y-%m-%d %H:%M UTC')
     for (name, grid), v in fetch.items():
-        if ('k_apply_small<6' in name.replace(' ', '') or 'k_filter_fused' in name or 'k_filter_chunked' in name or 'k_fxwc' in name or
+        if ('k_apply_small<6' in name.replace(' ', '') or 'k_filter_fused' in name or 'k_filter_chunked' in name or 'k_filter_quad' in name or 'k_filter_multi' in name or 'k_filter_range' in name or 'k_fxwc' in name or
                 'k_eval_wave' in name or 'k_apply_tile' in name or 'k_big_rest' in name or 'k_bq_fused' in name or 'k_bq_stream' in name):
             w = write.get((name, grid), [0.0])
             rd = sum(v) / len(v) * 1024 * (fr or 2.0)
