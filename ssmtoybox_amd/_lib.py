@@ -422,24 +422,32 @@ def scratch(nbytes):
 
 
 class _PinnedOwner:
-    """Owns one block of ssmq_pinned_alloc; the block goes back to the library's pool when the last ndarray that views it is
-    collected."""
+    """Owns one block of ssmq_pinned_alloc and presents it through the array interface; the block goes back to the library's pool
+    when the last ndarray that views it is collected (np.asarray(owner).base is the owner)."""
+    __slots__ = ('ptr', 'nbytes', '__array_interface__')
 
-    def __init__(self, nbytes):
+    def __init__(self, shape):
+        n = 1
+        for v in shape:
+            n *= int(v)
         p = ctypes.c_void_p()
-        check(load().ssmq_pinned_alloc(ctypes.c_size_t(max(int(nbytes), 8)), ctypes.byref(p)), 'ssmq_pinned_alloc')
-        self.ptr, self.nbytes = p.value, int(nbytes)
+        check(load().ssmq_pinned_alloc(ctypes.c_size_t(max(8 * n, 8)), ctypes.byref(p)), 'ssmq_pinned_alloc')
+        self.ptr, self.nbytes = p.value, 8 * n
+        self.__array_interface__ = {'data': (p.value, False), 'shape': tuple(int(v) for v in shape), 'typestr': '<f8', 'version': 3}
+        _pinned_out[0] += self.nbytes
 
     def __del__(self):
         try:
-            if self.ptr and _lib is not None:
-                _lib.ssmq_pinned_free(ctypes.c_void_p(self.ptr))
+            if self.ptr:
+                _pinned_out[0] -= self.nbytes
+                if _lib is not None:
+                    _lib.ssmq_pinned_free(ctypes.c_void_p(self.ptr))
         except Exception:       # noqa: BLE001  (interpreter shutdown)
             pass
         self.ptr = None
 
 
-PINNED_RESULT_LIMIT = 256 << 20      # results larger than this (or once this much is out) are ordinary pageable arrays
+PINNED_RESULT_LIMIT = 256 << 20      # results larger than this (or once four times this much is out) are ordinary pageable arrays
 _pinned_out = [0]
 
 
@@ -447,20 +455,12 @@ def pinned_empty(shape):
     """An ndarray in page-locked memory (what `forward_pass_batch` returns when it pipelines its transfers: the copy engine
     writes the result in place).  An ordinary array to its user - writable, owned by nobody else; the block returns to the
     library's pool when the array is collected.  None when the request is over the limit for pinned results."""
-    import weakref
-    n = int(np.prod(shape))
+    n = 1
+    for v in shape:
+        n *= int(v)
     if 8 * n > PINNED_RESULT_LIMIT or _pinned_out[0] + 8 * n > 4 * PINNED_RESULT_LIMIT:
         return None
-    owner = _PinnedOwner(8 * n)
-    buf = (ctypes.c_double * max(n, 1)).from_address(owner.ptr)
-    buf._owner = owner                                   # the ctypes array (the ndarray's base) keeps the block alive
-    _pinned_out[0] += 8 * n
-    weakref.finalize(buf, _pinned_release, 8 * n)
-    return np.ctypeslib.as_array(buf)[:n].reshape(shape)
-
-
-def _pinned_release(nbytes):
-    _pinned_out[0] -= nbytes
+    return np.asarray(_PinnedOwner(shape))
 
 
 def upload_study(arr, n_elem, ld, dst):

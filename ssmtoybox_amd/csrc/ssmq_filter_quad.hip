@@ -152,7 +152,7 @@ __device__ __forceinline__ void quad_transform(const double (&m)[DI], const doub
 }
 
 template <int D, int Y, int FD, int FO, int SELO>
-__global__ __launch_bounds__(kSmallBlock, 2) void k_filter_quad(const FusedArgs a) {
+__global__ __launch_bounds__(kSmallBlock, 1) void k_filter_quad(const FusedArgs a) {      // (one wave per SIMD is the regime: all 512 registers)
     constexpr int N = 2 * D + 1, S = (N + 3) / 4, NP = D * (D + 1) / 2;
     constexpr int CS = D + (D & 1);                    // column pitch (even: 16-byte aligned columns)
     constexpr int ROW = (D * CS) | 1;                  // doubles per trajectory record: odd, so that the 16 records start on different banks
@@ -201,6 +201,11 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_filter_quad(const FusedArgs 
     static_assert(!HasTimeTable<FD>::value && !HasTimeTable<FO>::value, "k_filter_quad: time-table integrands are not wired");
     const FPar &fd = a.fd, &fo = a.fo;
     const cdouble_p gqg = (cdouble_p)a.gqg, rr = (cdouble_p)a.rr;
+    uint32_t off_m[D], off_P[D * D];              // byte offsets of this lane's entries inside one step's planes (< 4 GB: D^2 ld doubles)
+#pragma unroll
+    for (int d = 0; d < D; ++d) off_m[d] = (uint32_t)(((int64_t)d * ld + bb) * 8);
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) off_P[i] = (uint32_t)(((int64_t)i * ld + bb) * 8);
     const double nan = __builtin_nan("");
     int32_t agg = 0;
     double ynext[Y];
@@ -236,12 +241,21 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_filter_quad(const FusedArgs 
 #pragma unroll
         for (int i = 0; i < Y * (Y + 1) / 2; ++i) Sf[i] = Sy[i];
         double G[D][Y];
+        if (Y == 1) ok = (Sf[0] > 0.0) && ok;
+        else ok = chol_packed<Y>(Sf) && ok;
+        if (agg == 0 && !ok) agg = k + 1;
+        // From the first failing step on every result is NaN (the reference raises there).  ONE poisoned row of the cross-covariance
+        // does it: the gain, and with it the mean and every covariance entry of this and all later steps, inherit the NaN - D
+        // additions instead of two selects on each of the D + D^2 results.
+        {
+            const double pois = agg == 0 ? 0.0 : nan;
+#pragma unroll
+            for (int d = 0; d < D; ++d) cx[0][d] += pois;
+        }
         if (Y == 1) {
-            ok = (Sf[0] > 0.0) && ok;
 #pragma unroll
             for (int d = 0; d < D; ++d) G[d][0] = div_nr(cx[0][d], Sf[0]);
         } else {
-            ok = chol_packed<Y>(Sf) && ok;
             // the two substitutions of cho_solve with the pivots' reciprocals formed once (Y divisions instead of 2 Y per state
             // coordinate; a product with the correctly rounded reciprocal is within an ulp of the quotient k_filter_fused forms)
             double ri[Y];
@@ -268,8 +282,6 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_filter_quad(const FusedArgs 
                 for (int i = 0; i < Y; ++i) G[d][i] = v[i];
             }
         }
-        if (agg == 0 && !ok) agg = k + 1;
-        const bool good = agg == 0;
         const bool st = writer && valid;
         double pout[D][D];
 #pragma unroll
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_filter_quad(const FusedArgs 
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < Y; ++i) s += G[d][i] * (ycur[i] - ym[i]);
-            m[d] = good ? pm[d] + s : nan;
+            m[d] = pm[d] + s;
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -289,24 +301,28 @@ __global__ __launch_bounds__(kSmallBlock, 2) void k_filter_quad(const FusedArgs 
                 for (int i = 0; i < Y; ++i) s += G[d][i] * Sy[i >= j ? SSMQ_PK(i, j) : SSMQ_PK(j, i)];
                 w[j] = s;
             }
+            // the lower triangle, mirrored: K P_y K' is symmetric; the reference's product leaves the two triangles an ulp apart
+            // (ssinf.py:323), which only a bit-for-bit kernel has to reproduce
 #pragma unroll
-            for (int d2 = 0; d2 < D; ++d2) {
+            for (int d2 = 0; d2 <= d; ++d2) {
                 double s = 0.0;
 #pragma unroll
                 for (int j = 0; j < Y; ++j) s += w[j] * G[d2][j];
-                double p = pP[d >= d2 ? SSMQ_PK(d, d2) : SSMQ_PK(d2, d)] - s;
-                p = good ? p : nan;
+                const double p = pP[SSMQ_PK(d, d2)] - s;
                 pout[d][d2] = p;
-                if (d2 <= d) Pl[SSMQ_PK(d, d2)] = p;
+                pout[d2][d] = p;
+                Pl[SSMQ_PK(d, d2)] = p;
             }
         }
-        if (st) {          // the quad's first lane stores the step's results: ONE masked region for the D + D^2 stores
+        if (st) {          // the quad's first lane stores the step's results: ONE masked region for the D + D^2 stores; addresses =
+                           // the step's plane base (scalar) + a per-lane offset formed once before the loop
+            char *bm = (char *)a.fm + (int64_t)k * D * ld * 8, *bP = (char *)a.fP + (int64_t)k * D * D * ld * 8;
 #pragma unroll
-            for (int d = 0; d < D; ++d) SSMQ_STORE(a.fm[((int64_t)k * D + d) * ld + b], m[d]);
+            for (int d = 0; d < D; ++d) SSMQ_STORE(*(double *)(bm + off_m[d]), m[d]);
 #pragma unroll
             for (int d = 0; d < D; ++d)
 #pragma unroll
-                for (int d2 = 0; d2 < D; ++d2) SSMQ_STORE(a.fP[((int64_t)k * D * D + d * D + d2) * ld + b], pout[d][d2]);
+                for (int d2 = 0; d2 < D; ++d2) SSMQ_STORE(*(double *)(bP + off_P[d * D + d2]), pout[d][d2]);
         }
     }
     if (writer && valid) a.status[b] = agg;
