@@ -9,6 +9,7 @@
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -2135,6 +2136,7 @@ PinnedPool &pinned_pool() {
 }
 constexpr size_t kPinnedIdleCap = size_t(1) << 30;
 
+std::atomic<bool> g_forked{false};        // a forked child has the pool object but none of its threads: it copies by itself
 // a few persistent threads for the row copies between caller memory and the pinned blocks (std::thread per call costs 30-50 us)
 struct CopyPool {
     std::mutex mu;
@@ -2172,7 +2174,7 @@ struct CopyPool {
     }
     // fn(lo, hi) over [0, n) in pieces of `chunk`; the caller works too; returns when everything is done
     void run(int64_t n_, int64_t chunk_, std::function<void(int64_t, int64_t)> f) {
-        if (n_ <= chunk_ || th.empty()) {
+        if (n_ <= chunk_ || th.empty() || g_forked.load()) {
             f(0, n_);
             return;
         }
@@ -2192,7 +2194,10 @@ struct CopyPool {
     }
 };
 CopyPool &copy_pool() {
-    static CopyPool *p = new CopyPool((int)std::max(1u, std::min(6u, std::thread::hardware_concurrency() / 2)));
+    static CopyPool *p = [] {
+        pthread_atfork(nullptr, nullptr, [] { g_forked.store(true); });
+        return new CopyPool((int)std::max(1u, std::min(6u, std::thread::hardware_concurrency() / 2)));
+    }();
     return *p;
 }
 std::mutex g_copy_pool_mu;       // one user of the pool at a time (calls from several threads take turns; the copies are short)

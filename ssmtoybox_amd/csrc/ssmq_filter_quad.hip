@@ -359,6 +359,7 @@ int try_launch_quad(const ssmq_transform *hd, const ssmq_integrand *fd, const ss
     if (hd->form != SSMQ_FORM_SIGMA || ho->form != SSMQ_FORM_SIGMA || hd->tp_nu > 0.0 || ho->tp_nu > 0.0 || sel_obs < 0 || fd->n_idx > 0) return 0;
     if (!(hd->opt_mask & ho->opt_mask & SSMQ_OPT_UT)) return 0;          // unscented-type points [0 | c I | -c I], verified on the host
     if (hd->N != 2 * hd->D + 1 || ho->N != hd->N || ho->D != hd->D || hd->E != hd->D) return 0;
+    if ((int64_t)hd->D * hd->D * ld * 8 >= ((int64_t)1 << 32)) return 0;        // (the kernel's 32-bit store offsets inside one step's planes)
     const int64_t waves = (B + kQuadTraj - 1) / kQuadTraj;
     if (force != 1 && waves > 4 * (int64_t)cus) return 0;
     for (const QuadEntry &e : kQuad) {

@@ -3511,6 +3511,45 @@ def test_quad_filters_match_oracle_and_register_kernel(amd, monkeypatch):
         assert np.array_equal(fm2, runs['1'][0], equal_nan=True) and np.array_equal(fP2, runs['1'][1], equal_nan=True)
 
 
+def test_quad_share_of_config3_at_full_size(amd):
+    """One GPU's share of BASELINE configs[2] on an eight-GPU node: 12 500 trajectories x 50 steps of the unscented filter on the
+    reentry model, device-resident - the batch k_filter_quad is the default for.  A 600-trajectory sample against the C oracle with
+    the bars of the 1e5 test, every trajectory against the register kernel (rounding-level: other summation order), the route
+    by name."""
+    from oracle import c_oracle as co
+    from benchlib.workloads import FilterBench
+    if any(k in os.environ for k in ('SSMQ_NO_FASTPATH', 'SSMQ_NO_FUSED', 'SSMQ_FUSED_QUAD', 'SSMQ_FUSED_WSPLIT')):
+        pytest.skip('the default route of this batch is what is tested')
+    B, T = 12500, 50
+    wl = FilterBench(amd, B, T, 35, 'reentry5', 'ukf')
+    assert 'k_filter_quad<D=5,Y=2' in wl.kernel, wl.kernel
+    wl.step()
+    fm, fP, st = wl.results()
+    assert not st.any()
+    idx = np.random.default_rng(1).choice(B, 600, replace=False)
+    pts = orc.points_ut(5)
+    wm, wc = orc.weights_ut(5)
+    td, k1 = co.make_transform(1, 5, 5, pts, wm, wc, integrand=co.Integrand.make(orc.F_REENTRY2D_DYN, (0.1,)))
+    to, k2 = co.make_transform(1, 5, 2, pts, wm, wc, integrand=co.Integrand.make(orc.F_RADAR2D_MEAS, (0.0, 0.0)))
+    GQG = wl.alg.G.dot(wl.alg.q_cov).dot(wl.alg.G.T)
+    cfm, cfP, cst = co.filter_forward(td, to, np.ascontiguousarray(wl.y_host[:, :, idx].transpose(2, 1, 0)), wl.m0, wl.P0, GQG, wl.alg.r_cov, threads=8)
+    assert not cst.any()
+    assert within(mean_err(fm[:, :, idx], cfm.transpose(2, 1, 0)), 1e-8, 'configs[2] share, k_filter_quad fm vs oracle (row-scaled)')
+    assert within(cov_err(fP[:, :, :, idx], cfP.transpose(2, 3, 1, 0)), 2e-8, 'configs[2] share, k_filter_quad fP vs oracle (entry-scaled)')
+    os.environ['SSMQ_FUSED_QUAD'] = '0'
+    try:
+        wl.d_fm.upload(np.zeros((T, wl.D, wl.ld)))
+        assert 'k_filter_fused<D=5,Y=2' in wl.alg.kernel_name(B)
+        wl.step()
+        rm, rP, rst = wl.results()
+    finally:
+        os.environ.pop('SSMQ_FUSED_QUAD')
+    assert not rst.any()
+    assert within(mean_err(fm, rm), 1e-9, 'configs[2] share, k_filter_quad vs k_filter_fused fm (row-scaled)')
+    assert within(cov_err(fP, rP), 2e-9, 'configs[2] share, k_filter_quad vs k_filter_fused fP (entry-scaled)')
+    wl.free()
+
+
 def test_chunked_time_loop_is_bitwise_the_whole_pass(amd, monkeypatch):
     """k_filter_chunked (csrc/ssmq_filter_chunked.hip): the block-steps of a batch cut into equal strips, one wave per strip; a block
     that straddles two strips is begun by one wave and finished by another from the state - mean, covariance triangle, status word
