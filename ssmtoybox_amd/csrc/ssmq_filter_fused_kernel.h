@@ -136,6 +136,21 @@ __device__ __forceinline__ void fused_pass(const FusedArgs &a, uint32_t blk, int
 #pragma unroll
         for (int i = 0; i < Y * (Y + 1) / 2; ++i) S[i] = ob.cv[i];
         double G[D][Y];
+        // (Round 6) From the first failing step on every result of a trajectory is NaN (the reference raises there).  Where the state
+        // is not scalar, ONE poisoned row of the cross-covariance does it - the gain, and through it the mean and every covariance
+        // entry of this and all later steps, inherit the NaN: 2 D selects instead of 2 (D + D^2) on the results.  Bit-neutral for
+        // the trajectories that do not fail (a select, not an addition: not even the sign of a zero changes).
+        constexpr bool kPoisonRow = !kScalar;
+        if (kPoisonRow && Y > 1) {
+            ok = chol_packed<Y>(S) && ok;
+        } else if (kPoisonRow) {
+            ok = (S[0] > 0.0) && ok;
+        }
+        if (kPoisonRow) {
+            if (agg == 0 && !ok) agg = k + 1;
+#pragma unroll
+            for (int d = 0; d < D; ++d) ob.cx[0][d] = (agg == 0) ? ob.cx[0][d] : nan;
+        }
         if (Y == 1) {
             // scalar measurement: P_y^-1 P_yx is one division; the factor-and-two-substitutions route of cho_solve
             // (sqrt + two divisions by it) would only lengthen the serial dependency chain of the time loop
@@ -147,13 +162,10 @@ __device__ __forceinline__ void fused_pass(const FusedArgs &a, uint32_t blk, int
                 int hi = __double2hiint(S[0]);
                 hi = (S[0] > 0.0) ? hi : 0x7ff80000;
                 S[0] = __hiloint2double(hi, __double2loint(S[0]));
-            } else {
-                ok = (S[0] > 0.0) && ok;
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) G[d][0] = div_nr(ob.cx[0][d], S[0]);
         } else {
-            ok = chol_packed<Y>(S) && ok;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 double v[Y];
@@ -175,8 +187,7 @@ __device__ __forceinline__ void fused_pass(const FusedArgs &a, uint32_t blk, int
                 for (int i = 0; i < Y; ++i) G[d][i] = v[i];
             }
         }
-        if (!kScalar && agg == 0 && !ok) agg = k + 1;
-        const bool good = kScalar || (agg == 0);
+        const bool good = true;       // (failures travel as NaN: the scalar kernels through the innovation variance, the others through the poisoned row)
         double sc2 = 1.0;
         if (stu_update) {   // (dof + delta'delta) / (dof + Y), delta = chol(S)^-1 (y - y_mean)  (ssinf.py:729-733)
             double dl[Y], dd = 0.0;
