@@ -55,8 +55,8 @@ struct TileGeom {
 __host__ __device__ constexpr inline int tile_ksm(int N) {
     return N <= 16 ? 4 : N <= 24 ? 6 : N <= 32 ? 8 : N <= 52 ? 13 : 16;
 }
-__host__ __device__ inline TileGeom tile_geom(int D, int E, int N, bool tp, bool mrow = false) {
-    TileGeom g;
+__host__ __device__ constexpr inline TileGeom tile_geom(int D, int E, int N, bool tp, bool mrow = false) {
+    TileGeom g{};
     g.KS = tile_ksm(N);
     g.KSP = g.KS | 1;                       // odd pitch: the 64 lanes of a fragment read fall on distinct banks
     g.NB = (g.KS + 3) / 4;
@@ -91,15 +91,20 @@ __host__ __device__ inline TileGeom tile_geom(int D, int E, int N, bool tp, bool
 #ifndef SSMQ_TILE_WGS_PER_CU
 #define SSMQ_TILE_WGS_PER_CU 2      // the resident number at this register count: every wave walks ~16 groups
 #endif
-template <int DM, int KS, int FC = -1>
+// NX > 0 (round 6): the EXACT shape D = E = DM, N = NX in the BQ form without the t-process variance, mean riding in the Wcc
+// operand - everything the geometry, the index maps and the masks are made of is then a compile-time constant.  With the shape
+// at run time the kernel keeps ~60 wave-uniform quantities in scalar registers, spills 167 of them and reads them back
+// (v_readlane) inside its loops; BASELINE configs[4]'s unisolvent half (D = E = 10, N = 21) gets the exact variant.
+template <int DM, int KS, int FC = -1, int NX = 0>
 __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(const WideArgs a, int64_t B) {
     extern __shared__ __align__(16) double lds[];
     constexpr int KSM = KS, NBM = (KS + 3) / 4, NB = NBM, KSP = KS | 1;
-    const int D = a.D, E = a.E, N = a.N;
-    const bool tp = a.tp_nu > 0.0, sigma = a.form == SSMQ_FORM_SIGMA;
+    constexpr bool kExact = NX > 0;
+    const int D = kExact ? DM : a.D, E = kExact ? DM : a.E, N = kExact ? NX : a.N;
+    const bool tp = kExact ? false : a.tp_nu > 0.0, sigma = kExact ? false : a.form == SSMQ_FORM_SIGMA;
     // BQ form, D <= 15: row 15 of the Wcc operand is free and carries wm, so the transformed mean comes out of the
     // cross-covariance product (accumulator register 3 of the lanes q = 3) instead of a separate sum + cross-lane adds
-    const bool mrow = !sigma && D <= 15 && a.wave_k == 0;     // (wave_k = 1: SSMQ_TILE_NO_MROW, to test the D = 16 path on smaller models)
+    const bool mrow = kExact ? true : (!sigma && D <= 15 && a.wave_k == 0);     // (wave_k = 1: SSMQ_TILE_NO_MROW, to test the D = 16 path on smaller models)
     const TileGeom tg = tile_geom(D, E, N, tp, mrow);
     const int G = tg.G, GL = tg.GL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(64 * kTileWaves, SSMQ_TILE_OCC) void k_apply_tile(c
     }
 }
 
-template <int DM, int KS, int FC>
+template <int DM, int KS, int FC, int NX = 0>
 hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
     WideArgs aw = a;
     aw.wave_k = ssmq::sw("SSMQ_TILE_NO_MROW") ? 1 : 0;
@@ -435,7 +440,7 @@ hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
     const TileGeom tg = tile_geom(a.D, a.E, a.N, a.tp_nu > 0.0, mrow);
     const size_t lds = sizeof(double) * ((size_t)tg.frag_doubles + (size_t)kTileWaves * tg.wave_doubles);
     if (lds > 48 * 1024) {     // per device and instantiation; a cheap call, rare shapes
-        hipError_t e = hipFuncSetAttribute((const void *)k_apply_tile<DM, KS, FC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)k_apply_tile<DM, KS, FC, NX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024 - 64);
         if (e != hipSuccess) return e;
     }
@@ -444,10 +449,10 @@ hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
     const int64_t cap = 256 * SSMQ_TILE_WGS_PER_CU;
     if (ssmq::sw("SSMQ_TILE_DEBUG")) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_apply_tile<DM, KS, FC>, 64 * kTileWaves, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_apply_tile<DM, KS, FC, NX>, 64 * kTileWaves, lds);
         fprintf(stderr, "k_apply_tile: %zu bytes of LDS, %d workgroups per CU\n", lds, nb);
     }
-    hipLaunchKernelGGL((k_apply_tile<DM, KS, FC>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(64 * kTileWaves), lds, s,
+    hipLaunchKernelGGL((k_apply_tile<DM, KS, FC, NX>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(64 * kTileWaves), lds, s,
                        aw, B);
     return hipGetLastError();
 }
@@ -455,8 +460,13 @@ hipError_t launch_tile_one(const WideArgs &a, int64_t B, hipStream_t s) {
 template <int KS>
 hipError_t launch_tile_ks(const WideArgs &a, int64_t B, hipStream_t s) {
     const int dm = a.D > a.E ? a.D : a.E;
-    if constexpr (KS == 6)
+    if constexpr (KS == 6) {
+        // BASELINE configs[4], unisolvent half, as an exact shape (the kernel's comment); SSMQ_TILE_NO_EXACT=1: the run-time-shape body
+        if (a.fid == SSMQ_F_SMOOTH10D_DYN && a.fp.n_idx == 0 && a.D == 10 && a.E == 10 && a.N == 21 && a.form == SSMQ_FORM_BQ && !(a.tp_nu > 0.0) &&
+            !ssmq::sw("SSMQ_TILE_NO_MROW") && !ssmq::sw("SSMQ_TILE_NO_EXACT"))
+            return launch_tile_one<10, KS, SSMQ_F_SMOOTH10D_DYN, 21>(a, B, s);
         if (a.fid == SSMQ_F_SMOOTH10D_DYN && a.fp.n_idx == 0 && dm <= 10) return launch_tile_one<10, KS, SSMQ_F_SMOOTH10D_DYN>(a, B, s);
+    }
     if (dm <= 4) return launch_tile_one<4, KS, -1>(a, B, s);
     if (dm <= 8) return launch_tile_one<8, KS, -1>(a, B, s);
     if (dm <= 12) return launch_tile_one<12, KS, -1>(a, B, s);

@@ -1965,6 +1965,15 @@ def test_bsq_d10_full_batch(amd, golden, tag, pstr, ppar, B):
     perm = np.random.default_rng(79).permutation(B)[:2048]
     mf2, cf2, cfx2 = tf.apply_batch(f, means[perm], covs[perm], 0.0)
     assert np.array_equal(mf2, mf[perm]) and np.array_equal(cf2, cf[perm]) and np.array_equal(cfx2, cfx[perm])
+    if pstr == 'ut' and 'SSMQ_TILE_NO_EXACT' not in os.environ and 'SSMQ_TILE_NO_MROW' not in os.environ:
+        # this shape runs k_apply_tile's EXACT-shape instantiation (D = E = 10, N = 21 at compile time, round 6): the same arithmetic
+        # as the run-time-shape body, so the same bits
+        os.environ['SSMQ_TILE_NO_EXACT'] = '1'
+        try:
+            mf3, cf3, cfx3 = tf.apply_batch(f, means[:20000], covs[:20000], 0.0)
+        finally:
+            os.environ.pop('SSMQ_TILE_NO_EXACT')
+        assert np.array_equal(mf3, mf[:20000]) and np.array_equal(cf3, cf[:20000]) and np.array_equal(cfx3, cfx[:20000])
 
 
 @pytest.mark.parametrize('N,E,B', [(201, 10, 64), (201, 7, 37), (120, 5, 60), (250, 3, 100), (201, 10, 2500)])

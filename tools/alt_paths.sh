@@ -8,11 +8,11 @@
 # of the one-launch kernel, no wave split, the fused time loop never / wherever possible as strips
 # (SSMQ_FUSED_CHUNKED=64: 64 strips for every batch of more than 64 blocks; "=1" only meant "default" and is no longer in the list).
 # Round 6: the LDL' kernels instead of the reflection-symmetric ones, no quad kernel, upload / pass / download instead of the pipelined
-# forward pass, the forked graph instead of the one-kernel multi-filter launch (twenty-six runs).
+# forward pass, the forked graph instead of the one-kernel multi-filter launch (twenty-seven runs; SSMQ_TILE_NO_EXACT: the run-time-shape body of k_apply_tile for the shape that has an exact one).
 # Exit status: non-zero when any run failed.
 # usage: tools/alt_paths.sh [VAR=value ...]   (default: every toggle)
 list="$*"
-[ -z "$list" ] && list="SSMQ_NO_FUSED=1 SSMQ_NO_FASTPATH=1 SSMQ_NO_FUSED_COV=1 SSMQ_NO_MFMA=1 SSMQ_WEIGHTS_NO_LDS=1 SSMQ_WIDE_ONE_WAVE=1 SSMQ_NO_WAVE=1 SSMQ_NO_TILE=1 SSMQ_TILE_NO_MROW=1 SSMQ_NO_BQ_FUSED=1 SSMQ_NO_THETA_FUSED=1 SSMQ_NO_BQ_STREAM=1 SSMQ_WEIGHTS_ONE_WG=1 SSMQ_LINEAR_GENERIC=1 SSMQ_BQ_STREAM_NO_SPLIT=1 SSMQ_NO_THETA_ITEM=1 SSMQ_MARGINAL_ROUNDS=1 SSMQ_MARGINAL_HOST_ROUNDS=1 SSMQ_FUSED_WSPLIT=0 SSMQ_FUSED_CHUNKED=0 SSMQ_FUSED_CHUNKED=64 SSMQ_NO_SYM=1 SSMQ_FUSED_QUAD=0 SSMQ_NO_PIPED=1 SSMQ_MULTI_NO_FAMILY=1"
+[ -z "$list" ] && list="SSMQ_NO_FUSED=1 SSMQ_NO_FASTPATH=1 SSMQ_NO_FUSED_COV=1 SSMQ_NO_MFMA=1 SSMQ_WEIGHTS_NO_LDS=1 SSMQ_WIDE_ONE_WAVE=1 SSMQ_NO_WAVE=1 SSMQ_NO_TILE=1 SSMQ_TILE_NO_MROW=1 SSMQ_NO_BQ_FUSED=1 SSMQ_NO_THETA_FUSED=1 SSMQ_NO_BQ_STREAM=1 SSMQ_WEIGHTS_ONE_WG=1 SSMQ_LINEAR_GENERIC=1 SSMQ_BQ_STREAM_NO_SPLIT=1 SSMQ_NO_THETA_ITEM=1 SSMQ_MARGINAL_ROUNDS=1 SSMQ_MARGINAL_HOST_ROUNDS=1 SSMQ_FUSED_WSPLIT=0 SSMQ_FUSED_CHUNKED=0 SSMQ_FUSED_CHUNKED=64 SSMQ_NO_SYM=1 SSMQ_FUSED_QUAD=0 SSMQ_NO_PIPED=1 SSMQ_MULTI_NO_FAMILY=1 SSMQ_TILE_NO_EXACT=1"
 fail=0
 for kv in $list; do
   v=${kv%%=*}
