@@ -1,4 +1,4 @@
-// The fused filter time loop by TIME BLOCKS, for the host-array entry point (round 6; ssmq_filter_forward_piped in ssmq_api.hip).
+// The fused filter time loop by TIME BLOCKS, for the host-array entry point (round 6; ssmq_filter_forward_piped in ssmq_api_study.hip).
 //
 // forward_pass takes the measurements as a host array and returns host arrays (ssinf.py:66-118).  At BASELINE configs[1] that is
 // 8 MB up and 16 MB down around a 34 us kernel: 1.15 ms per call when upload, pass and downloads run back to back.  Here the pass is

@@ -59,9 +59,9 @@ struct Ctx {
     void *pinned_flags = nullptr;            // 64 bytes of pinned host memory the device rounds report through (ssmq_marginal.hip)
     void *strip_buf = nullptr;               // flags + hand-over buffer of the strip schedule (ssmq_filter_chunked.hip), grow-only
     size_t strip_bytes = 0;
-    void *multi = nullptr;                   // ssmq_api.hip: MultiCache (side streams, events, constants and captured graph of
+    void *multi = nullptr;                   // ssmq_api_study.hip: MultiCache (side streams, events, constants and captured graph of
                                              // ssmq_filter_forward_multi_dev)
-    void *pipe = nullptr;                    // ssmq_api.hip: PipeCache (copy streams and events of ssmq_filter_forward_piped)
+    void *pipe = nullptr;                    // ssmq_api_study.hip: PipeCache (copy streams and events of ssmq_filter_forward_piped)
     bool no_strips = false;                  // set while a multi-filter launch is being built: the strip schedule owns ONE buffer
                                              // per context and its jobs run concurrently
 };
@@ -90,11 +90,50 @@ int ensure_device();
 // (the `static thread_local unsigned attr_epoch` of the launchers).
 unsigned device_epoch();
 
+// Device arena + pinned staging blocks of the host-buffer entry points (ssmq_api.hip, ssmq_api_study.hip): one per context.
+struct StagingArena;
+StagingArena &stage_of_ctx();
+
 #define SSMQ_HIP(call)                                        \
     do {                                                      \
         hipError_t e__ = (call);                              \
         if (e__ != hipSuccess) return ssmq::hip_fail(e__, #call); \
     } while (0)
+
+// Device arena + pinned staging blocks of the host-buffer entry points that are called in tight loops with small batches
+// (ssmq_apply_batch: the drop-in apply(); ssmq_gp_theta_step), grow-only, dropped when the device changes.  The calls are
+// synchronous on the library's one stream, so one arena serves them all.
+struct StagingArena {
+    void *dev = nullptr, *hin = nullptr, *hout = nullptr;
+    size_t dev_bytes = 0, hin_bytes = 0, hout_bytes = 0;
+    static int grow(void **p, size_t *have, size_t need, bool host) {
+        if (*have >= need) return SSMQ_OK;
+        if (*p) {
+            SSMQ_HIP(hipStreamSynchronize(stream()));
+            if (host) hipHostFree(*p); else hipFree(*p);
+        }
+        *p = nullptr;
+        *have = 0;
+        const size_t want = need + need / 4;       // a little head room: consecutive calls differ by a few items
+        if (host) SSMQ_HIP(hipHostMalloc(p, want, hipHostMallocDefault)); else SSMQ_HIP(hipMalloc(p, want));
+        *have = want;
+        return SSMQ_OK;
+    }
+    int reserve(size_t d, size_t hi, size_t ho) {
+        int rc;
+        if ((rc = grow(&dev, &dev_bytes, d, false)) || (rc = grow(&hin, &hin_bytes, hi, true)) ||
+            (rc = grow(&hout, &hout_bytes, ho, true)))
+            return rc;
+        return SSMQ_OK;
+    }
+    void drop() {
+        if (dev) hipFree(dev);
+        if (hin) hipHostFree(hin);
+        if (hout) hipHostFree(hout);
+        dev = hin = hout = nullptr;
+        dev_bytes = hin_bytes = hout_bytes = 0;
+    }
+};
 
 void fill_fpar(const ssmq_integrand *f, FPar *fp);
 
