@@ -61,6 +61,8 @@ def compact_record(detail):
     r = {k: _num(rf.get(k)) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'ms_per_launch', 'bytes_per_launch')
          if k in rf}
     r['kernel'] = short_kernel(rf.get('kernel'))
+    if isinstance(rf.get('traffic_source'), str):        # where `traffic` / `target_traffic` come from (committed PMC passes: file, tree, date)
+        r['traffic_source'] = rf['traffic_source'][:160]
     for k in ('target_kernel', 'target_frac', 'target_achieved_gbs', 'target_ms_per_launch', 'target_bytes_per_launch',
               'target_bytes_moved_per_launch', 'target_traffic', 'target_max_scaled_err_vs_oracle', 'target_ms_min_block',
               'target_ms_max_block', 'target_frac_at_1e6', 'saturated_frac_1e4', 'saturated_frac_1e5', 'saturated_frac_1e6',
